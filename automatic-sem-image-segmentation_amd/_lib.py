@@ -1,0 +1,82 @@
+"""ctypes binding of libsemseg_hip.so (include/semseg_hip.h).  Fails loudly when the library is absent:
+there is no CPU or eager-PyTorch fallback for the hot path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsemseg_hip.so")
+
+c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("n", "ih", "iw", "cin", "in_cstride", "oh", "ow", "cout", "out_cstride",
+                                     "kh", "kw", "stride", "pad_top", "pad_left", "pad_mode", "transposed", "act")] + \
+               [("act_alpha", c_f32), ("algo", c_i32)]
+
+
+class NormDesc(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("n", "h", "w", "c", "x_cstride", "y_cstride", "res_cstride", "groups")] + \
+               [("eps", c_f32), ("act", c_i32), ("act_alpha", c_f32)]
+
+
+PAD_ZERO, PAD_REFLECT = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+PASS_FWD, PASS_BWD_DATA, PASS_BWD_WEIGHT = 0, 1, 2
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+
+# name -> (restype, argtypes); the complete export list of include/semseg_hip.h
+SIGNATURES = {
+    "ss_version": (c_i32, []),
+    "ss_status_string": (ctypes.c_char_p, [c_i32]),
+    "ss_conv2d_workspace_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
+    "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ss_conv2d_bwd_data": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
+    "ss_conv2d_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
+    "ss_norm_workspace_bytes": (c_sz, [ctypes.POINTER(NormDesc)]),
+    "ss_norm_fwd": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_sz, c_vp]),
+    "ss_norm_infer": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ss_norm_bwd": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
+    "ss_act_bwd": (c_i32, [c_i32, c_f32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ss_axpby": (c_i32, [c_f32, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ss_maxpool2x2_fwd": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "ss_maxpool2x2_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "ss_copy": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ss_fill": (c_i32, [c_vp, c_f32, c_i64, c_vp]),
+    "ss_loss_workspace_bytes": (c_sz, [c_i64]),
+    "ss_loss_mse_const": (c_i32, [c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ss_loss_mae": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ss_loss_weighted_bce": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ss_adam_keras": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+}
+
+_lib = None
+
+
+class SemsegHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SemsegHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(make -C automatic-sem-image-segmentation_amd/csrc).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().ss_status_string(status).decode()
+        raise SemsegHipError(f"{what} failed: {msg} ({status})")

@@ -1,0 +1,99 @@
+// Shared helpers for libsemseg_hip.so (gfx950 only; no CUDA/compat paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/semseg_hip.h"
+
+#define SS_LAUNCH_CHECK()                                   \
+    do {                                                    \
+        if (hipGetLastError() != hipSuccess) return SS_ERR_LAUNCH; \
+    } while (0)
+
+static inline size_t ss_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float ss_apply_act(float v, int act, float alpha) {
+    switch (act) {
+        case SS_ACT_RELU: return v > 0.f ? v : 0.f;
+        case SS_ACT_LRELU: return v > 0.f ? v : alpha * v;
+        case SS_ACT_TANH: return tanhf(v);
+        case SS_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+// derivative of the activation expressed through the forward OUTPUT y
+__device__ __forceinline__ float ss_act_grad_from_out(float y, int act, float alpha) {
+    switch (act) {
+        case SS_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case SS_ACT_LRELU: return y > 0.f ? 1.f : alpha;
+        case SS_ACT_TANH: return 1.f - y * y;
+        case SS_ACT_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
+
+// Reflection / zero padding index map. Returns -1 when the tap falls into zero padding.
+__device__ __forceinline__ int ss_map_index(int i, int size, int reflect) {
+    if (reflect) {
+        if (i < 0) i = -i;
+        if (i >= size) i = 2 * (size - 1) - i;
+        return i;
+    }
+    return (i < 0 || i >= size) ? -1 : i;
+}
+
+// ---- internal gather-GEMM problem descriptions (conv_api.hip builds them) -------------------
+#define SS_MAX_TAPS 64
+
+struct GTap {
+    int16_t dy, dx;    // offset added to the (strided) class-grid coordinate
+    int32_t woff;      // element offset of this tap's [Cred x Cout] weight block
+};
+
+// out[n, yc*out_s+out_oy, xc*out_s+out_ox, co] (+)= act(bias[co] +
+//     sum_t sum_ci in[n, map(yc*in_s+in_oy+dy_t), map(xc*in_s+in_ox+dx_t), ci] * w[woff_t + ci*ldb + co])
+struct GConvParams {
+    const float* in;
+    const float* w;
+    const float* bias;
+    float* out;
+    int32_t N, IH, IW, Cin, in_cs;
+    int32_t OHc, OWc;             // class grid
+    int32_t in_s, in_oy, in_ox;
+    int32_t OH, OW, Cout, out_cs;
+    int32_t out_s, out_oy, out_ox;
+    int32_t ldb;
+    int32_t reflect;
+    int32_t act;
+    float alpha;
+    int32_t accumulate;
+    int32_t ntaps;
+    GTap taps[SS_MAX_TAPS];
+};
+
+// part[split][ (t,ca) ][cb] = sum over a pixel range of
+//     a[n, map(yc*a_s+a_oy+dy_t), map(xc*a_s+a_ox+dx_t), ca] * b[n, yc, xc, cb]
+struct WGradParams {
+    const float* a;
+    const float* b;
+    float* part;
+    int32_t N, AH, AW, Ca, a_cs;
+    int32_t GH, GW, Cb, b_cs;     // grid == b's spatial dims
+    int32_t a_s, a_oy, a_ox;
+    int32_t reflect;
+    int32_t splits, pix_per_split;
+    int32_t ntaps;
+    GTap taps[SS_MAX_TAPS];       // woff = destination offset of the tap block inside dw
+};
+
+// kernels / launchers implemented in the .hip files
+int ss_launch_gconv_direct(const GConvParams& p, hipStream_t s);
+int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s);
+bool ss_gconv_mfma_ok(const GConvParams& p);
+int ss_launch_wgrad_direct(const WGradParams& p, float* dw, int ldw, int accumulate, hipStream_t s);
+int ss_launch_wgrad_mfma(const WGradParams& p, float* dw, int ldw, int accumulate, hipStream_t s);
+int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split);

@@ -1,0 +1,485 @@
+// Matrix-core (MFMA) implicit-GEMM kernels for gfx950, fp32 in / fp32 accumulate
+// (v_mfma_f32_32x32x2_f32: exact f32, 64 FLOP/clk/SIMD).
+//
+//  gconv_mfma : C[pixel][cout] = sum_{tap,ci} A_gather[pixel][(tap,ci)] * W[(tap,ci)][cout]
+//               serves conv forward, conv backward-data (transposed weights, parity classes for
+//               stride 2) and through them Conv2DTranspose forward/backward-data.
+//  wgrad_mfma : C[(tap,ca)][cb] = sum_pixel A_gather[pixel][(tap,ca)] * B[pixel][cb]   (split over pixels)
+//
+// Tiling: 256 threads = 4 wave64; block tile BM x BN, K step 32; operands staged global -> VGPR ->
+// LDS (double buffered, one barrier per K step, next tile's global loads issued before the MFMAs).
+// LDS layouts are chosen so that the MFMA operand reads are bank-conflict free:
+//   A (pixel-major, row stride 36 floats): lane (i = l&31, h = l>>5) reads one ds_read_b128 holding
+//     k = 8*kk + 4h .. +3; the four MFMAs of a group consume k = 8kk+jj (h=0) and 8kk+4+jj (h=1),
+//     a permutation of the K order that A and B share (sums are order-independent up to rounding).
+//   B (k-major): lanes 0..31 read consecutive cout -> consecutive banks.
+#include "common.h"
+
+template <int BM_, int BN_>
+struct Cfg {
+    static constexpr int BM = BM_, BN = BN_, BK = 32;
+    static constexpr int WAVES_N = (BN >= 64) ? 2 : 1;
+    static constexpr int WAVES_M = 4 / WAVES_N;
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    static constexpr int TM = WM / 32, TN = WN / 32;
+    static constexpr int LDA = BK + 4;   // gconv A: [BM][LDA]
+    static constexpr int LDB = BN + 4;   // B: [BK][LDB]
+    static constexpr int LDAT = BM + 4;  // wgrad A: [BK][LDAT]
+    static constexpr int A_UNITS = BM * (BK / 4) / 256;
+    static constexpr int B_UNITS = BK * (BN / 4) / 256;
+    static constexpr int AT_UNITS = BK * (BM / 4) / 256;
+    static_assert(TM >= 1 && TN >= 1, "tile too small");
+    static_assert(A_UNITS >= 1 && B_UNITS >= 1, "tile too small");
+    static constexpr size_t smem_gconv = (2 * BM * LDA + 2 * BK * LDB) * sizeof(float) + BM * sizeof(int);
+    static constexpr size_t smem_wgrad = (2 * BK * LDAT + 2 * BK * LDB) * sizeof(float);
+};
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gconv_mfma_kernel(GConvParams p, int vecA, int vecB) {
+    using C = Cfg<BM, BN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * C::LDA;
+    int* pixtab = (int*)(Bs + 2 * C::BK * C::LDB);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+
+    const long M = (long)p.N * p.OHc * p.OWc;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int K = p.ntaps * p.Cin;
+    const int nchunks = (K + C::BK - 1) / C::BK;
+
+    // output pixel table (linear NHW index of the destination pixel, -1 = masked)
+    if (tid < BM) {
+        const long m = m0 + tid;
+        int v = -1;
+        if (m < M) {
+            const int xc = (int)(m % p.OWc);
+            const long r = m / p.OWc;
+            const int yc = (int)(r % p.OHc);
+            const int n = (int)(r / p.OHc);
+            const int oy = yc * p.out_s + p.out_oy, ox = xc * p.out_s + p.out_ox;
+            if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) v = (n * p.OH + oy) * p.OW + ox;
+        }
+        pixtab[tid] = v;
+    }
+
+    // per-thread A rows: row = (tid>>3) + 32*j, float4 column c4a = tid&7
+    const int c4a = tid & 7;
+    int a_nb[C::A_UNITS], a_by[C::A_UNITS], a_bx[C::A_UNITS];
+#pragma unroll
+    for (int j = 0; j < C::A_UNITS; ++j) {
+        const long m = m0 + (tid >> 3) + 32 * j;
+        if (m < M) {
+            const int xc = (int)(m % p.OWc);
+            const long r = m / p.OWc;
+            const int yc = (int)(r % p.OHc);
+            a_nb[j] = (int)(r / p.OHc) * p.IH;
+            a_by[j] = yc * p.in_s + p.in_oy;
+            a_bx[j] = xc * p.in_s + p.in_ox;
+        } else {
+            a_nb[j] = -1; a_by[j] = 0; a_bx[j] = 0;
+        }
+    }
+
+    f32x4 ra[C::A_UNITS], rb[C::B_UNITS];
+
+    auto load_tiles = [&](int k0) {
+        // ---- A: gathered activations ----
+        const int k = k0 + c4a * 4;
+        if (vecA) {
+            const bool kval = k < K;
+            const int t = kval ? k / p.Cin : 0;
+            const int ci = k - t * p.Cin;
+            const int dy = p.taps[t].dy, dx = p.taps[t].dx;
+#pragma unroll
+            for (int j = 0; j < C::A_UNITS; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kval && a_nb[j] >= 0) {
+                    const int iy = ss_map_index(a_by[j] + dy, p.IH, p.reflect);
+                    const int ix = ss_map_index(a_bx[j] + dx, p.IW, p.reflect);
+                    if (iy >= 0 && ix >= 0)
+                        v = *(const f32x4*)(p.in + ((long)(a_nb[j] + iy) * p.IW + ix) * p.in_cs + ci);
+                }
+                ra[j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < C::A_UNITS; ++j) ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ke = k + e;
+                if (ke < K) {
+                    const int t = ke / p.Cin;
+                    const int ci = ke - t * p.Cin;
+                    const int dy = p.taps[t].dy, dx = p.taps[t].dx;
+#pragma unroll
+                    for (int j = 0; j < C::A_UNITS; ++j) {
+                        if (a_nb[j] >= 0) {
+                            const int iy = ss_map_index(a_by[j] + dy, p.IH, p.reflect);
+                            const int ix = ss_map_index(a_bx[j] + dx, p.IW, p.reflect);
+                            if (iy >= 0 && ix >= 0)
+                                ra[j][e] = p.in[((long)(a_nb[j] + iy) * p.IW + ix) * p.in_cs + ci];
+                        }
+                    }
+                }
+            }
+        }
+        // ---- B: weights ----
+#pragma unroll
+        for (int j = 0; j < C::B_UNITS; ++j) {
+            const int u = tid + 256 * j;
+            const int row = u / (BN / 4), c4 = u % (BN / 4);
+            const int kb = k0 + row;
+            const int col = n0 + c4 * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kb < K && col < p.Cout) {
+                const int t = kb / p.Cin;
+                const int ci = kb - t * p.Cin;
+                const float* wp = p.w + p.taps[t].woff + (long)ci * p.ldb + col;
+                if (vecB && col + 3 < p.Cout) {
+                    v = *(const f32x4*)wp;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < p.Cout) v[e] = wp[e];
+                }
+            }
+            rb[j] = v;
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* Ab = As + buf * BM * C::LDA;
+        float* Bb = Bs + buf * C::BK * C::LDB;
+#pragma unroll
+        for (int j = 0; j < C::A_UNITS; ++j)
+            *(f32x4*)(Ab + ((tid >> 3) + 32 * j) * C::LDA + c4a * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < C::B_UNITS; ++j) {
+            const int u = tid + 256 * j;
+            const int row = u / (BN / 4), c4 = u % (BN / 4);
+            *(f32x4*)(Bb + row * C::LDB + c4 * 4) = rb[j];
+        }
+    };
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int mi = 0; mi < C::TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_tiles((c + 1) * C::BK);
+        const float* Ab = As + buf * BM * C::LDA + (wm * C::WM + l31) * C::LDA + 4 * lh;
+        const float* Bb = Bs + buf * C::BK * C::LDB + (4 * lh) * C::LDB + wn * C::WN + l31;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 a[C::TM];
+            float b[C::TN][4];
+#pragma unroll
+            for (int mi = 0; mi < C::TM; ++mi) a[mi] = *(const f32x4*)(Ab + mi * 32 * C::LDA + kk * 8);
+#pragma unroll
+            for (int ni = 0; ni < C::TN; ++ni)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) b[ni][jj] = Bb[(kk * 8 + jj) * C::LDB + ni * 32];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int mi = 0; mi < C::TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < C::TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][jj], b[ni][jj], acc[mi][ni], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int ni = 0; ni < C::TN; ++ni) {
+        const int co = n0 + wn * C::WN + ni * 32 + l31;
+        if (co >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < C::TM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int pix = pixtab[wm * C::WM + mi * 32 + row];
+                if (pix < 0) continue;
+                float* op = p.out + (long)pix * p.out_cs + co;
+                float v = ss_apply_act(acc[mi][ni][r] + bv, p.act, p.alpha);
+                if (p.accumulate) v += *op;
+                *op = v;
+            }
+        }
+    }
+}
+
+bool ss_gconv_mfma_ok(const GConvParams& p) {
+    // Cout == 1 heads and degenerate reductions stay on the direct kernel
+    return p.Cout >= 8 && (long)p.ntaps * p.Cin >= 8;
+}
+
+template <int BM, int BN>
+static int launch_gconv(const GConvParams& p, int vecA, int vecB, hipStream_t s) {
+    using C = Cfg<BM, BN>;
+    const long M = (long)p.N * p.OHc * p.OWc;
+    dim3 grid((unsigned)((M + BM - 1) / BM), (p.Cout + BN - 1) / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gconv_mfma_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem_gconv);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gconv_mfma_kernel<BM, BN>), grid, dim3(256), C::smem_gconv, s, p, vecA, vecB);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
+    const long M = (long)p.N * p.OHc * p.OWc;
+    if (M == 0) return SS_OK;
+    const int vecA = (p.Cin % 4 == 0) && (p.in_cs % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
+    int vecB = (p.ldb % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
+    for (int t = 0; t < p.ntaps && vecB; ++t) vecB = (p.taps[t].woff % 4 == 0);
+    if (p.Cout > 64) return launch_gconv<128, 128>(p, vecA, vecB, s);
+    if (p.Cout > 32) return launch_gconv<128, 64>(p, vecA, vecB, s);
+    return launch_gconv<128, 32>(p, vecA, vecB, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA, int vecB) {
+    using C = Cfg<BM, BN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BK][LDAT]
+    float* Bs = smem + 2 * C::BK * C::LDAT;    // [2][BK][LDB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+
+    const int M = p.ntaps * p.Ca;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const long P = (long)p.N * p.GH * p.GW;
+    const long ps = (long)split * p.pix_per_split;
+    const long pe = (ps + p.pix_per_split < P) ? ps + p.pix_per_split : P;
+    const int nchunks = (int)((pe - ps + C::BK - 1) / C::BK);
+
+    // this thread's A columns m = m0 + c4*4 + e  (fixed over the pixel loop)
+    const int c4a = tid % (BM / 4);
+    int a_dy[4], a_dx[4], a_c[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int m = m0 + c4a * 4 + e;
+        if (m < M) {
+            const int t = m / p.Ca;
+            a_c[e] = m - t * p.Ca;
+            a_dy[e] = p.taps[t].dy;
+            a_dx[e] = p.taps[t].dx;
+        } else {
+            a_c[e] = -1; a_dy[e] = 0; a_dx[e] = 0;
+        }
+    }
+    const int c4b = tid % (BN / 4);
+
+    f32x4 ra[C::AT_UNITS], rb[C::B_UNITS];
+
+    auto load_tiles = [&](long pk0) {
+#pragma unroll
+        for (int j = 0; j < C::AT_UNITS; ++j) {
+            const int row = (tid + 256 * j) / (BM / 4);
+            const long pk = pk0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pk < pe) {
+                const int xc = (int)(pk % p.GW);
+                const long r = pk / p.GW;
+                const int yc = (int)(r % p.GH);
+                const int nb = (int)(r / p.GH) * p.AH;
+                const int by = yc * p.a_s + p.a_oy, bx = xc * p.a_s + p.a_ox;
+                if (vecA) {
+                    if (a_c[0] >= 0) {
+                        const int iy = ss_map_index(by + a_dy[0], p.AH, p.reflect);
+                        const int ix = ss_map_index(bx + a_dx[0], p.AW, p.reflect);
+                        if (iy >= 0 && ix >= 0)
+                            v = *(const f32x4*)(p.a + ((long)(nb + iy) * p.AW + ix) * p.a_cs + a_c[0]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (a_c[e] >= 0) {
+                            const int iy = ss_map_index(by + a_dy[e], p.AH, p.reflect);
+                            const int ix = ss_map_index(bx + a_dx[e], p.AW, p.reflect);
+                            if (iy >= 0 && ix >= 0)
+                                v[e] = p.a[((long)(nb + iy) * p.AW + ix) * p.a_cs + a_c[e]];
+                        }
+                    }
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < C::B_UNITS; ++j) {
+            const int row = (tid + 256 * j) / (BN / 4);
+            const long pk = pk0 + row;
+            const int col = n0 + c4b * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pk < pe && col < p.Cb) {
+                const float* bp = p.b + pk * p.b_cs + col;
+                if (vecB && col + 3 < p.Cb) {
+                    v = *(const f32x4*)bp;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < p.Cb) v[e] = bp[e];
+                }
+            }
+            rb[j] = v;
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* Ab = As + buf * C::BK * C::LDAT;
+        float* Bb = Bs + buf * C::BK * C::LDB;
+#pragma unroll
+        for (int j = 0; j < C::AT_UNITS; ++j) {
+            const int row = (tid + 256 * j) / (BM / 4);
+            *(f32x4*)(Ab + row * C::LDAT + c4a * 4) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < C::B_UNITS; ++j) {
+            const int row = (tid + 256 * j) / (BN / 4);
+            *(f32x4*)(Bb + row * C::LDB + c4b * 4) = rb[j];
+        }
+    };
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int mi = 0; mi < C::TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    if (nchunks > 0) {
+        load_tiles(ps);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_tiles(ps + (long)(c + 1) * C::BK);
+        const float* Ab = As + buf * C::BK * C::LDAT + lh * C::LDAT + wm * C::WM + l31;
+        const float* Bb = Bs + buf * C::BK * C::LDB + lh * C::LDB + wn * C::WN + l31;
+#pragma unroll
+        for (int s2 = 0; s2 < C::BK / 2; ++s2) {
+            float a[C::TM], b[C::TN];
+#pragma unroll
+            for (int mi = 0; mi < C::TM; ++mi) a[mi] = Ab[(2 * s2) * C::LDAT + mi * 32];
+#pragma unroll
+            for (int ni = 0; ni < C::TN; ++ni) b[ni] = Bb[(2 * s2) * C::LDB + ni * 32];
+#pragma unroll
+            for (int mi = 0; mi < C::TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < C::TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* part = p.part + (long)split * M * p.Cb;
+#pragma unroll
+    for (int ni = 0; ni < C::TN; ++ni) {
+        const int n = n0 + wn * C::WN + ni * 32 + l31;
+        if (n >= p.Cb) continue;
+#pragma unroll
+        for (int mi = 0; mi < C::TM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * C::WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M) part[(long)m * p.Cb + n] = acc[mi][ni][r];
+            }
+        }
+    }
+}
+
+// dw[woff_t + ca*ldw + cb] (+)= sum_split part[split][(t,ca)][cb]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WGradParams p, float* dw, int ldw, int accumulate) {
+    const long total = (long)p.ntaps * p.Ca * p.Cb;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int cb = (int)(e % p.Cb);
+    const long m = e / p.Cb;
+    const int t = (int)(m / p.Ca);
+    const int ca = (int)(m - (long)t * p.Ca);
+    float acc = 0.f;
+    for (int s = 0; s < p.splits; ++s) acc += p.part[(long)s * total + e];
+    float* o = dw + p.taps[t].woff + (long)ca * ldw + cb;
+    *o = accumulate ? (*o + acc) : acc;
+}
+
+int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split) {
+    const int bn = Cb > 64 ? 128 : (Cb > 32 ? 64 : 32);
+    const long tiles = (long)((M + 127) / 128) * ((Cb + bn - 1) / bn);
+    long splits = (1024 + tiles - 1) / tiles;
+    const long max_splits = (pixels + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long pps = (pixels + splits - 1) / splits;
+    pps = (pps + 31) / 32 * 32;
+    splits = (pixels + pps - 1) / pps;
+    if (splits < 1) splits = 1;
+    *pix_per_split = (int)pps;
+    return (int)splits;
+}
+
+template <int BM, int BN>
+static int launch_wgrad(const WGradParams& p, int vecA, int vecB, hipStream_t s) {
+    using C = Cfg<BM, BN>;
+    const int M = p.ntaps * p.Ca;
+    dim3 grid((M + BM - 1) / BM, (p.Cb + BN - 1) / BN, p.splits);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem_wgrad);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_mfma_kernel<BM, BN>), grid, dim3(256), C::smem_wgrad, s, p, vecA, vecB);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_launch_wgrad_mfma(const WGradParams& p, float* dw, int ldw, int accumulate, hipStream_t s) {
+    const long P = (long)p.N * p.GH * p.GW;
+    const long total = (long)p.ntaps * p.Ca * p.Cb;
+    if (total == 0) return SS_OK;
+    if (P > 0) {
+        const int vecA = (p.Ca % 4 == 0) && (p.a_cs % 4 == 0) && (((uintptr_t)p.a & 15) == 0);
+        const int vecB = (p.b_cs % 4 == 0) && (((uintptr_t)p.b & 15) == 0);
+        int rc;
+        if (p.Cb > 64) rc = launch_wgrad<128, 128>(p, vecA, vecB, s);
+        else if (p.Cb > 32) rc = launch_wgrad<128, 64>(p, vecA, vecB, s);
+        else rc = launch_wgrad<128, 32>(p, vecA, vecB, s);
+        if (rc != SS_OK) return rc;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, dw, ldw, accumulate);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}

@@ -1,0 +1,331 @@
+// Element-wise, pooling, loss and optimizer kernels (all HBM-bound; NHWC views with pixel strides).
+#include "common.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+inline unsigned ew_grid(long total) {
+    long b = (total + EW_BLOCK - 1) / EW_BLOCK;
+    const long cap = 256L * 16;      // grid-stride beyond ~16 blocks per CU
+    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void act_bwd_kernel(int act, float alpha, const float* __restrict__ dy, int dy_cs,
+                                                           const float* __restrict__ y, int y_cs, float* __restrict__ dx, int dx_cs,
+                                                           long rows, int C) {
+    const long total = rows * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / C;
+        const int c = (int)(e - r * C);
+        dx[r * dx_cs + c] = dy[r * dy_cs + c] * ss_act_grad_from_out(y[r * y_cs + c], act, alpha);
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void axpby_kernel(float alpha, const float* __restrict__ a, int a_cs, float beta,
+                                                         const float* __restrict__ b, int b_cs, float* __restrict__ out, int out_cs,
+                                                         long rows, int C) {
+    const long total = rows * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / C;
+        const int c = (int)(e - r * C);
+        float v = alpha * a[r * a_cs + c];
+        if (b) v = fmaf(beta, b[r * b_cs + c], v);
+        out[r * out_cs + c] = v;
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void fill_kernel(float* __restrict__ dst, float v, long count) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) dst[e] = v;
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void maxpool_fwd_kernel(const float* __restrict__ x, int x_cs, float* __restrict__ y, int y_cs,
+                                                               int N, int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2;
+    const long total = (long)N * OH * OW * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH);
+        const int n = (int)(r / OH);
+        const float* ip = x + ((long)(n * H + 2 * oy) * W + 2 * ox) * x_cs + c;
+        const float v00 = ip[0], v01 = ip[x_cs], v10 = ip[(long)W * x_cs], v11 = ip[(long)(W + 1) * x_cs];
+        y[((long)(n * OH + oy) * OW + ox) * y_cs + c] = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+    }
+}
+
+// one thread per INPUT element: gets dy of its window iff it is the first maximum in row-major order
+__global__ __launch_bounds__(EW_BLOCK) void maxpool_bwd_kernel(const float* __restrict__ dy, int dy_cs, const float* __restrict__ x, int x_cs,
+                                                               float* __restrict__ dx, int dx_cs, int accumulate,
+                                                               int N, int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2;
+    const long total = (long)N * H * W * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int n = (int)(r / H);
+        float g = 0.f;
+        const int oy = iy >> 1, ox = ix >> 1;
+        if (oy < OH && ox < OW) {
+            const float* ip = x + ((long)(n * H + 2 * oy) * W + 2 * ox) * x_cs + c;
+            const float v[4] = {ip[0], ip[x_cs], ip[(long)W * x_cs], ip[(long)(W + 1) * x_cs]};
+            int arg = 0;
+            float m = v[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k] > m) { m = v[k]; arg = k; }
+            if (arg == ((iy & 1) * 2 + (ix & 1))) g = dy[((long)(n * OH + oy) * OW + ox) * dy_cs + c];
+        }
+        float* o = dx + ((long)(n * H + iy) * W + ix) * dx_cs + c;
+        *o = accumulate ? (*o + g) : g;
+    }
+}
+
+// ---- losses: stage 1 per-block partial sums (K values each), stage 2 single block finishes -------
+constexpr int LOSS_MAX_BLOCKS = 1024;
+
+template <int K>
+__device__ __forceinline__ void block_reduce_store(float (&v)[K], float* part) {
+    __shared__ float red[K][EW_BLOCK / 64];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float s = v[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float s = 0.f;
+            for (int w = 0; w < EW_BLOCK / 64; ++w) s += red[k][w];
+            part[(long)blockIdx.x * K + k] = s;
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(EW_BLOCK) void loss_finish_kernel(const float* __restrict__ part, int nblocks, float inv_count, float* __restrict__ out) {
+    __shared__ double red[K][EW_BLOCK];
+    double acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += EW_BLOCK)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += part[(long)b * K + k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int off = EW_BLOCK / 2; off >= 1; off >>= 1) {
+        if (threadIdx.x < off)
+#pragma unroll
+            for (int k = 0; k < K; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = (float)(red[k][0] * (double)inv_count);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void mse_const_kernel(const float* __restrict__ pred, long count, float target, float gscale,
+                                                             float* __restrict__ grad, float* __restrict__ part) {
+    float v[1] = {0.f};
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
+        const float d = pred[e] - target;
+        v[0] = fmaf(d, d, v[0]);
+        if (grad) grad[e] = gscale * 2.f * d;
+    }
+    block_reduce_store<1>(v, part);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void mae_kernel(const float* __restrict__ truth, const float* __restrict__ pred, long count, float gscale,
+                                                       float* __restrict__ grad, float* __restrict__ part) {
+    float v[1] = {0.f};
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
+        const float d = pred[e] - truth[e];
+        v[0] += fabsf(d);
+        if (grad) grad[e] = gscale * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+    }
+    block_reduce_store<1>(v, part);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void wbce_kernel(const float* __restrict__ truth, const float* __restrict__ pred, long count,
+                                                        float weighting, float gscale, float* __restrict__ grad, float* __restrict__ part) {
+    float v[3] = {0.f, 0.f, 0.f};
+    const float eps = 1e-7f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
+        const float t = truth[e], pr = pred[e];
+        const float pc = fminf(fmaxf(pr, eps), 1.f - eps);
+        const float w = t * (weighting - 1.f) + 1.f;
+        v[0] += -w * (t * logf(pc) + (1.f - t) * logf(1.f - pc));
+        v[1] += fabsf(t - pr);
+        v[2] += ((pr > 0.5f ? 1.f : 0.f) == t) ? 1.f : 0.f;
+        if (grad) {
+            // d/dp of -w[t log p + (1-t) log(1-p)], zero where the clip is active (as torch.clip backward)
+            const bool inside = (pr >= eps) && (pr <= 1.f - eps);
+            grad[e] = inside ? gscale * w * (-(t / pc) + (1.f - t) / (1.f - pc)) : 0.f;
+        }
+    }
+    block_reduce_store<3>(v, part);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long count, float alpha, float b1, float b2, float eps,
+                                                        float gscale) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
+        const float gv = g[e] * gscale;
+        const float mv = fmaf(b1, m[e], (1.f - b1) * gv);
+        const float vv = fmaf(b2, v[e], (1.f - b2) * gv * gv);
+        m[e] = mv;
+        v[e] = vv;
+        p[e] -= alpha * mv / (sqrtf(vv) + eps);
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void adam_kernel_v4(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m,
+                                                           f32x4* __restrict__ v, long count4, float alpha, float b1, float b2, float eps,
+                                                           float gscale) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count4; e += (long)gridDim.x * blockDim.x) {
+        const f32x4 gv = g[e] * gscale;
+        f32x4 mv = m[e], vv = v[e], pv = p[e];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mv[k] = fmaf(b1, mv[k], (1.f - b1) * gv[k]);
+            vv[k] = fmaf(b2, vv[k], (1.f - b2) * gv[k] * gv[k]);
+            pv[k] -= alpha * mv[k] / (sqrtf(vv[k]) + eps);
+        }
+        m[e] = mv;
+        v[e] = vv;
+        p[e] = pv;
+    }
+}
+
+inline int loss_blocks(long count) {
+    long b = (count + EW_BLOCK * 4 - 1) / (EW_BLOCK * 4);
+    if (b > LOSS_MAX_BLOCKS) b = LOSS_MAX_BLOCKS;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_act_bwd(int act, float act_alpha, const float* dy, int32_t dy_cstride, const float* y, int32_t y_cstride,
+               float* dx, int32_t dx_cstride, int64_t rows, int32_t c, void* stream) {
+    if (!dy || !y || !dx || rows < 0 || c <= 0) return SS_ERR_INVALID;
+    if (rows == 0) return SS_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(rows * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       act, act_alpha, dy, dy_cstride, y, y_cstride, dx, dx_cstride, (long)rows, c);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_axpby(float alpha, const float* a, int32_t a_cstride, float beta, const float* b, int32_t b_cstride,
+             float* out, int32_t out_cstride, int64_t rows, int32_t c, void* stream) {
+    if (!a || !out || rows < 0 || c <= 0) return SS_ERR_INVALID;
+    if (rows == 0) return SS_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(rows * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       alpha, a, a_cstride, beta, b, b_cstride, out, out_cstride, (long)rows, c);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_copy(const float* src, int32_t src_cstride, float* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream) {
+    return ss_axpby(1.f, src, src_cstride, 0.f, nullptr, 0, dst, dst_cstride, rows, c, stream);
+}
+
+int ss_fill(float* dst, float value, int64_t count, void* stream) {
+    if (!dst || count < 0) return SS_ERR_INVALID;
+    if (count == 0) return SS_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(count)), dim3(EW_BLOCK), 0, (hipStream_t)stream, dst, value, (long)count);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_maxpool2x2_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride,
+                      int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+    if (!x || !y || n <= 0 || h < 2 || w < 2 || c <= 0) return SS_ERR_INVALID;
+    const long total = (long)n * (h / 2) * (w / 2) * c;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, x_cstride, y, y_cstride, n, h, w, c);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_maxpool2x2_bwd(const float* dy, int32_t dy_cstride, const float* x, int32_t x_cstride,
+                      float* dx, int32_t dx_cstride, int accumulate,
+                      int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+    if (!dy || !x || !dx || n <= 0 || h < 2 || w < 2 || c <= 0) return SS_ERR_INVALID;
+    const long total = (long)n * h * w * c;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       dy, dy_cstride, x, x_cstride, dx, dx_cstride, accumulate, n, h, w, c);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+size_t ss_loss_workspace_bytes(int64_t count) { (void)count; return (size_t)LOSS_MAX_BLOCKS * 3 * sizeof(float); }
+
+int ss_loss_mse_const(const float* pred, int64_t count, float target, float grad_scale,
+                      float* loss_out, float* grad, void* ws, size_t ws_bytes, void* stream) {
+    if (!pred || !loss_out || count <= 0) return SS_ERR_INVALID;
+    if (!ws || ws_bytes < ss_loss_workspace_bytes(count)) return SS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = loss_blocks(count);
+    hipLaunchKernelGGL(mse_const_kernel, dim3(nb), dim3(EW_BLOCK), 0, s, pred, (long)count, target, grad_scale / (float)count, grad, (float*)ws);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finish_kernel<1>, dim3(1), dim3(EW_BLOCK), 0, s, (const float*)ws, nb, 1.f / (float)count, loss_out);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_loss_mae(const float* truth, const float* pred, int64_t count, float grad_scale,
+                float* loss_out, float* grad, void* ws, size_t ws_bytes, void* stream) {
+    if (!truth || !pred || !loss_out || count <= 0) return SS_ERR_INVALID;
+    if (!ws || ws_bytes < ss_loss_workspace_bytes(count)) return SS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = loss_blocks(count);
+    hipLaunchKernelGGL(mae_kernel, dim3(nb), dim3(EW_BLOCK), 0, s, truth, pred, (long)count, grad_scale / (float)count, grad, (float*)ws);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finish_kernel<1>, dim3(1), dim3(EW_BLOCK), 0, s, (const float*)ws, nb, 1.f / (float)count, loss_out);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_loss_weighted_bce(const float* truth, const float* pred, int64_t count, float weighting, float grad_scale,
+                         float* out3, float* grad, void* ws, size_t ws_bytes, void* stream) {
+    if (!truth || !pred || !out3 || count <= 0) return SS_ERR_INVALID;
+    if (!ws || ws_bytes < ss_loss_workspace_bytes(count)) return SS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = loss_blocks(count);
+    hipLaunchKernelGGL(wbce_kernel, dim3(nb), dim3(EW_BLOCK), 0, s, truth, pred, (long)count, weighting, grad_scale / (float)count, grad, (float*)ws);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finish_kernel<3>, dim3(1), dim3(EW_BLOCK), 0, s, (const float*)ws, nb, 1.f / (float)count, out3);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_adam_keras(float* p, const float* g, float* m, float* v, int64_t count,
+                  float alpha, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || count < 0) return SS_ERR_INVALID;
+    if (count == 0) return SS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool al = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    const long c4 = al ? count / 4 : 0;
+    if (c4 > 0) {
+        hipLaunchKernelGGL(adam_kernel_v4, dim3(ew_grid(c4)), dim3(EW_BLOCK), 0, s, (f32x4*)p, (const f32x4*)g, (f32x4*)m, (f32x4*)v,
+                           c4, alpha, beta1, beta2, eps, grad_scale);
+        SS_LAUNCH_CHECK();
+    }
+    const long rem = count - c4 * 4;
+    if (rem > 0) {
+        hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(rem)), dim3(EW_BLOCK), 0, s, p + c4 * 4, g + c4 * 4, m + c4 * 4, v + c4 * 4,
+                           rem, alpha, beta1, beta2, eps, grad_scale);
+        SS_LAUNCH_CHECK();
+    }
+    return SS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+"""Host-side execution engine: NHWC activation views, a flat parameter arena per network and a minimal
+reverse-mode tape.  PyTorch is used only for device memory and streams; every arithmetic step is a call
+into libsemseg_hip.so (include/semseg_hip.h).
+
+Layout decisions (MI355X-first):
+* activations: fp32 NHWC, channel-strided views so that Keras ``concatenate`` never copies -- producers write
+  straight into their slice of the concatenated buffer (UNet_Segmentation.py:469,542-551);
+* parameters: ONE flat fp32 arena per network (16-byte aligned variables, Keras layouts) with matching flat
+  gradient / Adam-m / Adam-v arenas -> the optimizer is a single fused launch and the data-parallel gradient
+  exchange is a single bucketed all-reduce over the arena.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+_WS = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer shared by all calls on a device (stream-ordered use)."""
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Act:
+    """An NHWC activation view: channels [c0, c0+c) of a base tensor [n,h,w,cs]."""
+
+    __slots__ = ("t", "c0", "c", "grad", "grad_init", "requires_grad", "parent")
+
+    def __init__(self, t, c0=0, c=None, requires_grad=True, parent=None):
+        assert t.dim() == 4 and t.dtype == torch.float32 and t.is_contiguous()
+        self.t, self.c0 = t, c0
+        self.c = t.shape[3] - c0 if c is None else c
+        self.grad = None
+        self.grad_init = False
+        self.requires_grad = requires_grad
+        self.parent = parent
+
+    # geometry
+    @property
+    def n(self): return self.t.shape[0]
+    @property
+    def h(self): return self.t.shape[1]
+    @property
+    def w(self): return self.t.shape[2]
+    @property
+    def cs(self): return self.t.shape[3]
+    @property
+    def rows(self): return self.t.shape[0] * self.t.shape[1] * self.t.shape[2]
+    @property
+    def device(self): return self.t.device
+    @property
+    def ptr(self): return ctypes.c_void_p(self.t.data_ptr() + 4 * self.c0)
+
+    @staticmethod
+    def empty(n, h, w, c, device, requires_grad=True):
+        return Act(torch.empty((n, h, w, c), dtype=torch.float32, device=device), requires_grad=requires_grad)
+
+    def slice(self, c0, c):
+        """Channel slice sharing storage (and, lazily, gradient storage) with this buffer."""
+        return Act(self.t, self.c0 + c0, c, self.requires_grad, parent=self if self.parent is None else self.parent)
+
+    def dense(self):
+        """Contiguous torch tensor of this view (copy when strided) -- for inspection / tests."""
+        return self.t[..., self.c0:self.c0 + self.c].contiguous()
+
+    def grad_target(self):
+        """(grad view to write, accumulate flag) for a backward op producing d loss / d self."""
+        if self.parent is not None:
+            p = self.parent
+            if p.grad is None:
+                p.grad = Act(torch.zeros_like(p.t), requires_grad=False)
+                p.grad_init = True
+            elif not p.grad_init:
+                p.grad.t.zero_()
+                p.grad_init = True
+            return Act(p.grad.t, self.c0, self.c, False), 1
+        if self.grad is None:
+            self.grad = Act(torch.empty_like(self.t), self.c0, self.c, False)
+            self.grad_init = True
+            return self.grad, 0
+        if not self.grad_init:
+            self.grad_init = True
+            return self.grad, 0
+        return self.grad, 1
+
+    def get_grad(self):
+        """Gradient accumulated so far (None when nothing flowed into this activation)."""
+        if self.parent is not None:
+            p = self.parent
+            if p.grad is None or not p.grad_init:
+                return None
+            return Act(p.grad.t, self.c0, self.c, False)
+        return self.grad if self.grad_init else None
+
+
+class Tape:
+    """Records backward closures in forward order; ``backward()`` replays them in reverse."""
+
+    def __init__(self, enabled=True, param_grads=True):
+        self.ops = []
+        self.enabled = enabled
+        self.param_grads = param_grads   # False: ops recorded now skip weight gradients (input grads only)
+
+    def record(self, fn):
+        if self.enabled:
+            self.ops.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.ops):
+            fn()
+        self.ops = []
+
+
+class ParamArena:
+    """Flat fp32 storage for a network's variables (Keras layouts, creation order)."""
+
+    ALIGN = 4  # floats (16 bytes)
+
+    def __init__(self, device):
+        self.device = device
+        self.specs = []      # (name, shape, trainable, offset)
+        self.n_train = 0
+        self.n_state = 0
+        self.params = None   # trainable arena
+        self.grads = None
+        self.m = None
+        self.v = None
+        self.state = None    # non-trainable arena (BN moving statistics)
+        self.views = {}
+        self.gviews = {}
+
+    def declare(self, name, shape, trainable=True):
+        size = 1
+        for s in shape:
+            size *= s
+        if trainable:
+            off = self.n_train
+            self.n_train = off + (size + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        else:
+            off = self.n_state
+            self.n_state = off + (size + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.specs.append((name, tuple(shape), trainable, off))
+
+    def materialize(self):
+        dev = self.device
+        self.params = torch.zeros(max(self.n_train, 4), dtype=torch.float32, device=dev)
+        self.grads = torch.zeros_like(self.params)
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.state = torch.zeros(max(self.n_state, 4), dtype=torch.float32, device=dev)
+        for name, shape, trainable, off in self.specs:
+            size = 1
+            for s in shape:
+                size *= s
+            if trainable:
+                self.views[name] = self.params[off:off + size].view(shape)
+                self.gviews[name] = self.grads[off:off + size].view(shape)
+            else:
+                self.views[name] = self.state[off:off + size].view(shape)
+
+    def __getitem__(self, name):
+        return self.views[name]
+
+    def grad(self, name):
+        return self.gviews[name]
+
+    def zero_grad(self):
+        lib = L.load()
+        L.check(lib.ss_fill(_p(self.grads), 0.0, self.grads.numel(), _stream()), "ss_fill")

@@ -1,0 +1,215 @@
+"""Layer operations on top of the C ABI: each op runs its forward kernels and records the backward closure
+on the tape.  Mirrors the Keras layers the reference composes (Conv2D / Conv2DTranspose /
+GroupNormalization / BatchNormalization / MaxPooling2D / activations; CycleGAN.py:323-451,
+UNet_Segmentation.py:401-562) with the fusions chosen for MI355X: reflection padding lives in the conv
+gather, activation and residual add live in the norm apply pass, bias+activation in the conv epilogue.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from .engine import Act, _p, _stream, workspace
+
+ACTS = {None: L.ACT_NONE, "relu": L.ACT_RELU, "lrelu": L.ACT_LRELU, "tanh": L.ACT_TANH, "sigmoid": L.ACT_SIGMOID}
+
+
+def same_pad(size, k, s):
+    """Keras/TF 'same' (SURVEY K-list 2): total = k-1-((size-1)%s); before = total//2."""
+    total = max(k - 1 - ((size - 1) % s), 0)
+    return total // 2, (total + 1) // 2
+
+
+class Conv2D:
+    """keras.layers.Conv2D / Conv2DTranspose parameters + geometry.
+
+    padding: 'valid' | 'same' | ('reflect', p)  -- ('reflect', p) = ReflectionPadding2D((2p,2p)) followed by a
+    'valid' conv (CycleGAN.py:326-327,368-372,392-393), fused into the gather.
+    """
+
+    def __init__(self, arena, name, k, cin, cout, stride=1, padding="valid", use_bias=False, act=None,
+                 act_alpha=0.0, transposed=False, algo=L.ALGO_AUTO):
+        self.arena, self.name = arena, name
+        self.k, self.cin, self.cout, self.stride = k, cin, cout, stride
+        self.padding, self.use_bias, self.act, self.act_alpha = padding, use_bias, act, act_alpha
+        self.transposed, self.algo = transposed, algo
+        arena.declare(f"{name}/kernel", (k, k, cout, cin) if transposed else (k, k, cin, cout))
+        if use_bias:
+            arena.declare(f"{name}/bias", (cout,))
+        self._desc_cache = {}
+
+    def out_hw(self, h, w):
+        k, s = self.k, self.stride
+        if self.transposed:
+            return h * s, w * s
+        if self.padding == "valid":
+            return (h - k) // s + 1, (w - k) // s + 1
+        if self.padding == "same":
+            return -(-h // s), -(-w // s)
+        p = self.padding[1]
+        return h + 2 * p - k + 1, w + 2 * p - k + 1
+
+    def desc(self, x, y):
+        key = (x.n, x.h, x.w, x.cs, y.cs)
+        d = self._desc_cache.get(key)
+        if d is None:
+            k, s = self.k, self.stride
+            pt = pl = 0
+            mode = L.PAD_ZERO
+            if self.transposed:
+                # torch-backend alignment of Conv2DTranspose(padding='same') (SURVEY K-list 3)
+                output_padding = s - k % 2
+                pt = pl = max(-((k % 2 - k + output_padding) // 2), 0)
+            elif self.padding == "same":
+                pt, pl = same_pad(x.h, k, s)[0], same_pad(x.w, k, s)[0]
+            elif self.padding != "valid":
+                pt = pl = self.padding[1]
+                mode = L.PAD_REFLECT
+            d = L.ConvDesc(x.n, x.h, x.w, self.cin, x.cs, y.h, y.w, self.cout, y.cs, k, k, s, pt, pl, mode,
+                           1 if self.transposed else 0, ACTS[self.act], float(self.act_alpha), self.algo)
+            self._desc_cache[key] = d
+        return d
+
+    def __call__(self, tape, x, out=None):
+        lib = L.load()
+        assert x.c == self.cin, (self.name, x.c, self.cin)
+        oh, ow = self.out_hw(x.h, x.w)
+        y = out if out is not None else Act.empty(x.n, oh, ow, self.cout, x.device)
+        assert (y.h, y.w, y.c) == (oh, ow, self.cout)
+        d = self.desc(x, y)
+        w = self.arena[f"{self.name}/kernel"]
+        b = self.arena[f"{self.name}/bias"] if self.use_bias else None
+        nb = lib.ss_conv2d_workspace_bytes(ctypes.byref(d), L.PASS_FWD)
+        ws = workspace(nb, x.device)
+        L.check(lib.ss_conv2d_fwd(ctypes.byref(d), x.ptr, _p(w), _p(b), y.ptr, _p(ws), ws.numel(), _stream()),
+                f"conv2d_fwd[{self.name}]")
+        param_grads = tape.param_grads
+
+        def backward():
+            dy = y.get_grad()
+            if dy is None:
+                return
+            if self.act is not None:
+                dz = Act.empty(y.n, y.h, y.w, y.c, y.device, False)
+                L.check(lib.ss_act_bwd(ACTS[self.act], float(self.act_alpha), dy.ptr, dy.cs, y.ptr, y.cs,
+                                       dz.ptr, dz.cs, y.rows, y.c, _stream()), "act_bwd")
+                dy = dz
+            # the descriptor's out_cstride must describe the dy buffer actually passed
+            dd = d if dy.cs == y.cs else self.desc_with_out_cs(d, dy.cs)
+            if param_grads:
+                nbw = lib.ss_conv2d_workspace_bytes(ctypes.byref(dd), L.PASS_BWD_WEIGHT)
+                wsw = workspace(nbw, x.device)
+                gw = self.arena.grad(f"{self.name}/kernel")
+                gb = self.arena.grad(f"{self.name}/bias") if self.use_bias else None
+                L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), x.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wsw), wsw.numel(),
+                                                 _stream()), f"conv2d_bwd_weight[{self.name}]")
+            if x.requires_grad:
+                dx, accum = x.grad_target()
+                ddx = dd if dx.cs == x.cs else self.desc_with_in_cs(dd, dx.cs)
+                nbd = lib.ss_conv2d_workspace_bytes(ctypes.byref(ddx), L.PASS_BWD_DATA)
+                wsd = workspace(nbd, x.device)
+                L.check(lib.ss_conv2d_bwd_data(ctypes.byref(ddx), dy.ptr, _p(w), dx.ptr, accum, _p(wsd), wsd.numel(),
+                                               _stream()), f"conv2d_bwd_data[{self.name}]")
+
+        tape.record(backward)
+        return y
+
+    @staticmethod
+    def desc_with_out_cs(d, cs):
+        d2 = L.ConvDesc.from_buffer_copy(d)
+        d2.out_cstride = cs
+        return d2
+
+    @staticmethod
+    def desc_with_in_cs(d, cs):
+        d2 = L.ConvDesc.from_buffer_copy(d)
+        d2.in_cstride = cs
+        return d2
+
+
+class Norm:
+    """InstanceNorm (groups = n) or BatchNorm (groups = 1) with fused activation / residual add."""
+
+    def __init__(self, arena, name, c, kind, scale=True, eps=None, momentum=0.99):
+        assert kind in ("instance", "batch")
+        self.arena, self.name, self.c, self.kind, self.scale = arena, name, c, kind, scale
+        self.eps = eps if eps is not None else (1e-5 if kind == "instance" else 1e-3)
+        self.momentum = momentum
+        if scale:
+            arena.declare(f"{name}/gamma", (c,))
+        arena.declare(f"{name}/beta", (c,))
+        if kind == "batch":
+            arena.declare(f"{name}/moving_mean", (c,), trainable=False)
+            arena.declare(f"{name}/moving_variance", (c,), trainable=False)
+
+    def __call__(self, tape, x, act=None, act_alpha=0.0, residual=None, out=None, training=True):
+        lib = L.load()
+        assert x.c == self.c
+        y = out if out is not None else Act.empty(x.n, x.h, x.w, x.c, x.device)
+        groups = x.n if self.kind == "instance" else 1
+        d = L.NormDesc(x.n, x.h, x.w, x.c, x.cs, y.cs, residual.cs if residual is not None else 0, groups,
+                       float(self.eps), ACTS[act], float(act_alpha))
+        gamma = self.arena[f"{self.name}/gamma"] if self.scale else None
+        beta = self.arena[f"{self.name}/beta"]
+        rp = residual.ptr if residual is not None else None
+        if self.kind == "batch" and not training:
+            L.check(lib.ss_norm_infer(ctypes.byref(d), x.ptr, _p(gamma), _p(beta),
+                                      _p(self.arena[f"{self.name}/moving_mean"]),
+                                      _p(self.arena[f"{self.name}/moving_variance"]), rp, y.ptr, _stream()), "norm_infer")
+            return y
+        mean = torch.empty(groups * x.c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        mm = mv = None
+        if self.kind == "batch":
+            mm, mv = self.arena[f"{self.name}/moving_mean"], self.arena[f"{self.name}/moving_variance"]
+        nb = lib.ss_norm_workspace_bytes(ctypes.byref(d))
+        ws = workspace(nb, x.device)
+        L.check(lib.ss_norm_fwd(ctypes.byref(d), x.ptr, _p(gamma), _p(beta), rp, y.ptr, _p(mean), _p(rstd),
+                                _p(mm), _p(mv), float(self.momentum), _p(ws), ws.numel(), _stream()),
+                f"norm_fwd[{self.name}]")
+        param_grads = tape.param_grads
+
+        def backward():
+            dy = y.get_grad()
+            if dy is None:
+                return
+            dx, accum = x.grad_target()
+            dres, racc = (None, 0)
+            if residual is not None and residual.requires_grad:
+                dres, racc = residual.grad_target()
+            db = L.NormDesc.from_buffer_copy(d)
+            db.res_cstride = dres.cs if dres is not None else 0
+            ws2 = workspace(lib.ss_norm_workspace_bytes(ctypes.byref(db)), x.device)
+            ggam = self.arena.grad(f"{self.name}/gamma") if (self.scale and param_grads) else None
+            gbet = self.arena.grad(f"{self.name}/beta") if param_grads else None
+            L.check(lib.ss_norm_bwd(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, y.ptr, _p(gamma), _p(mean), _p(rstd),
+                                    dx.ptr, dx.cs, accum, dres.ptr if dres is not None else None, racc,
+                                    _p(ggam), _p(gbet), 1, _p(ws2), ws2.numel(), _stream()), f"norm_bwd[{self.name}]")
+
+        tape.record(backward)
+        return y
+
+
+def maxpool2x2(tape, x):
+    lib = L.load()
+    y = Act.empty(x.n, x.h // 2, x.w // 2, x.c, x.device)
+    L.check(lib.ss_maxpool2x2_fwd(x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, _stream()), "maxpool_fwd")
+
+    def backward():
+        dy = y.get_grad()
+        if dy is None or not x.requires_grad:
+            return
+        dx, accum = x.grad_target()
+        L.check(lib.ss_maxpool2x2_bwd(dy.ptr, dy.cs, x.ptr, x.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, _stream()),
+                "maxpool_bwd")
+
+    tape.record(backward)
+    return y
+
+
+def add_grad(dst_act, src):
+    """Accumulate the dense gradient view ``src`` into dst_act's gradient (fan-out of an activation)."""
+    lib = L.load()
+    dg, accum = dst_act.grad_target()
+    L.check(lib.ss_axpby(1.0, src.ptr, src.cs, 1.0 if accum else 0.0, dg.ptr if accum else None, dg.cs,
+                         dg.ptr, dg.cs, dst_act.rows, dst_act.c, _stream()), "axpby")

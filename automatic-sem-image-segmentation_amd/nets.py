@@ -1,0 +1,268 @@
+"""Network topologies of the hot path, composed from layers.py.
+
+* ``ResnetGenerator``   -- CycleGAN.get_resnet_generator, CycleGAN.py:360-423 (blocks :323-358)
+* ``PatchDiscriminator``-- CycleGAN.get_discriminator,   CycleGAN.py:425-451
+* ``MultiResUNet``      -- UNet.multi_res_unet,          UNet_Segmentation.py:401-562
+
+Variables are declared in Keras creation order with Keras shapes, so ``get_weights()`` /
+``set_weights()`` exchange lists with ``keras.Model.get_weights()`` of the reference networks.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .engine import Act, ParamArena, Tape
+from .layers import Conv2D, Norm, maxpool2x2
+
+
+class Network:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.arena = ParamArena(self.device)
+        self.training_runs = 0
+
+    # ---- Keras-like weight surface -------------------------------------------------------------
+    def _finish(self, seed):
+        self.arena.materialize()
+        self.init_weights(seed)
+
+    def init_weights(self, seed=0):
+        """Glorot-uniform kernels (keras default / GlorotUniform, CycleGAN.py:125), zeros bias/beta/moving_mean,
+        ones gamma/moving_variance.  Keras' stateful SeedGenerator stream is not reproducible (SURVEY K-list 9);
+        parity tests always load explicit weights."""
+        gen = torch.Generator().manual_seed(seed)
+        for name, shape, trainable, _ in self.arena.specs:
+            v = self.arena[name]
+            if name.endswith("/kernel"):
+                rf = int(np.prod(shape[:-2]))
+                limit = math.sqrt(6.0 / (shape[-2] * rf + shape[-1] * rf))
+                u = torch.rand(shape, generator=gen, dtype=torch.float64)
+                v.copy_(((u * 2.0 - 1.0) * limit).to(torch.float32))
+            elif name.endswith("/gamma") or name.endswith("/moving_variance"):
+                v.fill_(1.0)
+            else:
+                v.zero_()
+
+    @property
+    def variable_names(self):
+        return [s[0] for s in self.arena.specs]
+
+    def get_weights(self):
+        return [self.arena[name].detach().cpu().numpy().copy() for name, *_ in self.arena.specs]
+
+    def set_weights(self, arrays):
+        assert len(arrays) == len(self.arena.specs), (len(arrays), len(self.arena.specs))
+        for (name, shape, *_), a in zip(self.arena.specs, arrays):
+            self.arena[name].copy_(torch.as_tensor(np.asarray(a), dtype=torch.float32).reshape(shape))
+
+    def get_gradients(self):
+        return {name: self.arena.grad(name).detach().cpu().numpy().copy()
+                for name, _, trainable, _ in self.arena.specs if trainable}
+
+    def zero_grad(self):
+        self.arena.zero_grad()
+
+    def count_params(self):
+        return sum(int(np.prod(s[1])) for s in self.arena.specs)
+
+    def __call__(self, x, training=True, tape=None):
+        """x: Act or NHWC torch tensor.  Returns the output Act; backward closures go to ``tape``."""
+        if not isinstance(x, Act):
+            x = Act(x.contiguous(), requires_grad=False)
+        return self.forward(tape if tape is not None else Tape(enabled=False), x, training)
+
+
+class ResnetGenerator(Network):
+    """Default StartProcess configuration: no skip connection, transposed-conv upsampling, tanh output."""
+
+    def __init__(self, filters=64, num_downsampling_blocks=3, num_residual_blocks=9, num_upsample_blocks=3,
+                 channels=1, device="cuda", seed=0, algo=L.ALGO_AUTO):
+        super().__init__(device)
+        A = self.arena
+        self.nd, self.nr, self.nu = num_downsampling_blocks, num_residual_blocks, num_upsample_blocks
+        f = filters
+        self.c7_in = Conv2D(A, "c7_in", 7, channels, f, padding=("reflect", 3), algo=algo)
+        self.in_c7 = Norm(A, "c7_in", f, "instance")
+        self.down = []
+        for i in range(self.nd):
+            conv = Conv2D(A, f"down{i}", 3, f, 2 * f, stride=2, padding="same", algo=algo)
+            f *= 2
+            self.down.append((conv, Norm(A, f"down{i}", f, "instance")))
+        self.res = []
+        for i in range(self.nr):
+            c0 = Conv2D(A, f"res{i}.0", 3, f, f, padding=("reflect", 1), algo=algo)
+            n0 = Norm(A, f"res{i}.0", f, "instance")
+            c1 = Conv2D(A, f"res{i}.1", 3, f, f, padding=("reflect", 1), algo=algo)
+            n1 = Norm(A, f"res{i}.1", f, "instance")
+            self.res.append((c0, n0, c1, n1))
+        self.up = []
+        for i in range(self.nu):
+            conv = Conv2D(A, f"up{i}", 3, f, f // 2, stride=2, transposed=True, algo=algo)
+            f //= 2
+            self.up.append((conv, Norm(A, f"up{i}", f, "instance")))
+        self.c7_out = Conv2D(A, "c7_out", 7, f, channels, padding=("reflect", 3), use_bias=True, act="tanh", algo=algo)
+        self._finish(seed)
+
+    def forward(self, tape, x, training=True):
+        m = 2 ** self.nd
+        if x.h % m or x.w % m:
+            # CycleGAN.py:365-367 pre-pads by reflection to a multiple of 2**n_down and never crops back.
+            raise NotImplementedError("tile size must be a multiple of %d (all StartProcess/BASELINE sizes are)" % m)
+        h = self.in_c7(tape, self.c7_in(tape, x), act="relu")
+        for conv, norm in self.down:
+            h = norm(tape, conv(tape, h), act="relu")
+        for c0, n0, c1, n1 in self.res:
+            y = n0(tape, c0(tape, h), act="relu")
+            h = n1(tape, c1(tape, y), residual=h)
+        for conv, norm in self.up:
+            h = norm(tape, conv(tape, h), act="relu")
+        return self.c7_out(tape, h)
+
+
+class PatchDiscriminator(Network):
+    """gaussian_noise_value == 0 (StartProcess.py:96), padding='valid' (CycleGAN.py:148)."""
+
+    def __init__(self, filters=128, num_downsampling_blocks=2, channels=1, padding="valid", device="cuda", seed=0,
+                 algo=L.ALGO_AUTO):
+        super().__init__(device)
+        A = self.arena
+        f = filters
+        self.c4_in = Conv2D(A, "c4_in", 4, channels, f, stride=2, padding=padding, use_bias=True, act="lrelu",
+                            act_alpha=0.2, algo=algo)
+        self.down = []
+        for i in range(num_downsampling_blocks):
+            s = 2 if i < 3 else 1
+            conv = Conv2D(A, f"down{i}", 4, f, 2 * f, stride=s, padding=padding, algo=algo)
+            f *= 2
+            self.down.append((conv, Norm(A, f"down{i}", f, "instance")))
+        self.c4_out = Conv2D(A, "c4_out", 4, f, 1, stride=1, padding=padding, use_bias=True, algo=algo)
+        self._finish(seed)
+
+    def forward(self, tape, x, training=True):
+        h = self.c4_in(tape, x)
+        for conv, norm in self.down:
+            h = norm(tape, conv(tape, h), act="lrelu", act_alpha=0.2)
+        return self.c4_out(tape, h)
+
+
+class _ConvBN:
+    """UNet.conv2d_bn: conv(no bias, 'same') + BatchNormalization(scale=False) [+ activation]."""
+
+    def __init__(self, arena, name, k, cin, cout, algo):
+        self.conv = Conv2D(arena, name, k, cin, cout, padding="same", algo=algo)
+        self.bn = Norm(arena, f"{name}/bn", cout, "batch", scale=False)
+
+    def __call__(self, tape, x, act, training, residual=None, out=None):
+        return self.bn(tape, self.conv(tape, x), act=act, residual=residual, out=out, training=training)
+
+
+class _MultiResBlock:
+    """UNet.multi_res_block (UNet_Segmentation.py:451-474)."""
+
+    def __init__(self, arena, name, u, cin, algo):
+        w = MultiResUNet.ALPHA * u
+        a, b, c = int(w * 0.167), int(w * 0.333), int(w * 0.5)
+        self.widths = (a, b, c)
+        self.cout = a + b + c
+        self.sc = _ConvBN(arena, f"{name}.sc1x1", 1, cin, self.cout, algo)
+        self.c3 = _ConvBN(arena, f"{name}.3", 3, cin, a, algo)
+        self.c5 = _ConvBN(arena, f"{name}.5", 3, a, b, algo)
+        self.c7 = _ConvBN(arena, f"{name}.7", 3, b, c, algo)
+        self.bn_a = Norm(arena, f"{name}.bn_a", self.cout, "batch")
+        self.bn_b = Norm(arena, f"{name}.bn_b", self.cout, "batch")
+
+    def __call__(self, tape, x, training, out=None):
+        a, b, c = self.widths
+        sc = self.sc(tape, x, None, training)
+        cat = Act.empty(x.n, x.h, x.w, self.cout, x.device)     # concat buffer: producers write their slices
+        s3 = self.c3(tape, x, "relu", training, out=cat.slice(0, a))
+        s5 = self.c5(tape, s3, "relu", training, out=cat.slice(a, b))
+        self.c7(tape, s5, "relu", training, out=cat.slice(a + b, c))
+        h = self.bn_a(tape, cat, act="relu", residual=sc, training=training)   # relu(shortcut + BN(cat))
+        return self.bn_b(tape, h, training=training, out=out)
+
+
+class _ResPath:
+    """UNet.res_path (UNet_Segmentation.py:476-503)."""
+
+    def __init__(self, arena, name, filters, length, cin, algo):
+        self.stages = []
+        for i in range(length):
+            sc = _ConvBN(arena, f"{name}.{i}.sc", 1, cin, filters, algo)
+            c3 = _ConvBN(arena, f"{name}.{i}.3", 3, cin, filters, algo)
+            bn = Norm(arena, f"{name}.{i}.bn", filters, "batch")
+            self.stages.append((sc, c3, bn))
+            cin = filters
+
+    def __call__(self, tape, x, training, out=None):
+        for i, (sc, c3, bn) in enumerate(self.stages):
+            o = c3(tape, x, "relu", training)
+            s = sc(tape, x, "relu", training, residual=o)          # relu(BN(conv1x1(x)) + o)
+            x = bn(tape, s, training=training, out=out if i == len(self.stages) - 1 else None)
+        return x
+
+
+class MultiResUNet(Network):
+    """output_channels == 1 head (sigmoid).  Decoder block widths follow the reference's hard-coded
+    32*8 / 32*4 / 32*2 (UNet_Segmentation.py:543,546,549), independent of ``conv_filters``."""
+
+    ALPHA = 1.67
+
+    def __init__(self, conv_filters=16, device="cuda", seed=0, algo=L.ALGO_AUTO):
+        super().__init__(device)
+        A = self.arena
+        f = self.filters = conv_filters
+        self.mrb1 = _MultiResBlock(A, "mrb1", f, 1, algo)
+        self.rp1 = _ResPath(A, "rp1", f, 4, self.mrb1.cout, algo)
+        self.mrb2 = _MultiResBlock(A, "mrb2", f * 2, self.mrb1.cout, algo)
+        self.rp2 = _ResPath(A, "rp2", f * 2, 3, self.mrb2.cout, algo)
+        self.mrb3 = _MultiResBlock(A, "mrb3", f * 4, self.mrb2.cout, algo)
+        self.rp3 = _ResPath(A, "rp3", f * 4, 2, self.mrb3.cout, algo)
+        self.mrb4 = _MultiResBlock(A, "mrb4", f * 8, self.mrb3.cout, algo)
+        self.rp4 = _ResPath(A, "rp4", f * 8, 1, self.mrb4.cout, algo)
+        self.mrb5 = _MultiResBlock(A, "mrb5", f * 16, self.mrb4.cout, algo)
+        self.up6 = Conv2D(A, "up6T", 2, self.mrb5.cout, f * 8, stride=2, use_bias=True, transposed=True, algo=algo)
+        self.mrb6 = _MultiResBlock(A, "mrb6", 32 * 8, f * 16, algo)
+        self.up7 = Conv2D(A, "up7T", 2, self.mrb6.cout, f * 4, stride=2, use_bias=True, transposed=True, algo=algo)
+        self.mrb7 = _MultiResBlock(A, "mrb7", 32 * 4, f * 8, algo)
+        self.up8 = Conv2D(A, "up8T", 2, self.mrb7.cout, f * 2, stride=2, use_bias=True, transposed=True, algo=algo)
+        self.mrb8 = _MultiResBlock(A, "mrb8", 32 * 2, f * 4, algo)
+        self.up9 = Conv2D(A, "up9T", 2, self.mrb8.cout, f, stride=2, use_bias=True, transposed=True, algo=algo)
+        self.mrb9 = _MultiResBlock(A, "mrb9", f, f * 2, algo)
+        self.head = _ConvBN(A, "out1x1", 1, self.mrb9.cout, 1, algo)
+        self._finish(seed)
+
+    def forward(self, tape, x, training=True):
+        if x.h % 16 or x.w % 16:
+            raise NotImplementedError("tile size must be a multiple of 16 (UNet_Segmentation.py:520-522 reflect-pads otherwise)")
+        f, t = self.filters, training
+        dev = x.device
+        m1 = self.mrb1(tape, x, t)
+        p1 = maxpool2x2(tape, m1)
+        m2 = self.mrb2(tape, p1, t)
+        p2 = maxpool2x2(tape, m2)
+        m3 = self.mrb3(tape, p2, t)
+        p3 = maxpool2x2(tape, m3)
+        m4 = self.mrb4(tape, p3, t)
+        p4 = maxpool2x2(tape, m4)
+        m5 = self.mrb5(tape, p4, t)
+        # skip concatenations [upT(deeper), ResPath(encoder)]: both producers write into the concat buffer
+        cat6 = Act.empty(x.n, m4.h, m4.w, f * 16, dev)
+        self.rp4(tape, m4, t, out=cat6.slice(f * 8, f * 8))
+        self.up6(tape, m5, out=cat6.slice(0, f * 8))
+        m6 = self.mrb6(tape, cat6, t)
+        cat7 = Act.empty(x.n, m3.h, m3.w, f * 8, dev)
+        self.rp3(tape, m3, t, out=cat7.slice(f * 4, f * 4))
+        self.up7(tape, m6, out=cat7.slice(0, f * 4))
+        m7 = self.mrb7(tape, cat7, t)
+        cat8 = Act.empty(x.n, m2.h, m2.w, f * 4, dev)
+        self.rp2(tape, m2, t, out=cat8.slice(f * 2, f * 2))
+        self.up8(tape, m7, out=cat8.slice(0, f * 2))
+        m8 = self.mrb8(tape, cat8, t)
+        cat9 = Act.empty(x.n, m1.h, m1.w, f * 2, dev)
+        self.rp1(tape, m1, t, out=cat9.slice(f, f))
+        self.up9(tape, m8, out=cat9.slice(0, f))
+        m9 = self.mrb9(tape, cat9, t)
+        return self.head(tape, m9, "sigmoid", t)

@@ -1,0 +1,178 @@
+/*
+ * semseg_hip.h -- C ABI of libsemseg_hip.so: the MI355X (gfx950) kernels behind the
+ * CycleGAN -> MultiResUNet training hot path of BAMresearch/automatic-sem-image-segmentation.
+ *
+ * The reference has no FFI: its "operator API" for this path is the set of Keras layers /
+ * losses / optimizer calls listed below (Releases/Version 1.2.0/...), executed by the Keras
+ * torch backend.  Each entry point names the reference call sites it replaces.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; all device buffers are CALLER-OWNED fp32, 16-byte aligned.
+ *  - activations are NHWC "views": pointer + (n,h,w,c) + cstride, where cstride >= c is the
+ *    distance in elements between consecutive pixels (lets a layer write straight into a slice
+ *    of a concatenated tensor: keras.layers.concatenate, UNet_Segmentation.py:469,542-551).
+ *  - weights use the Keras variable layouts: Conv2D kernel (kh,kw,cin,cout), bias (cout);
+ *    Conv2DTranspose kernel (kh,kw,cout,cin); norm gamma/beta (c).
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing
+ *    and keeps no global mutable state; scratch comes from the caller (`ws`, size from the
+ *    matching *_workspace_bytes()).
+ *  - return value: SS_OK or a negative ss_status; ss_status_string() names it.
+ */
+#ifndef SEMSEG_HIP_H
+#define SEMSEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ss_status {
+    SS_OK = 0,
+    SS_ERR_INVALID = -1,      /* bad descriptor / null pointer */
+    SS_ERR_WORKSPACE = -2,    /* ws_bytes too small */
+    SS_ERR_LAUNCH = -3,       /* HIP launch error (hipGetLastError) */
+    SS_ERR_UNSUPPORTED = -4   /* combination not implemented */
+} ss_status;
+
+enum { SS_PAD_ZERO = 0, SS_PAD_REFLECT = 1 };
+enum { SS_ACT_NONE = 0, SS_ACT_RELU = 1, SS_ACT_LRELU = 2, SS_ACT_TANH = 3, SS_ACT_SIGMOID = 4 };
+enum { SS_PASS_FWD = 0, SS_PASS_BWD_DATA = 1, SS_PASS_BWD_WEIGHT = 2 };
+enum { SS_ALGO_AUTO = 0, SS_ALGO_DIRECT = 1, SS_ALGO_MFMA = 2 };
+
+int ss_version(void);
+const char* ss_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * 2-D convolution / transposed convolution.
+ * Replaces keras.layers.Conv2D at CycleGAN.py:327,333,340,372,393,429/431,448 and
+ * UNet_Segmentation.py:421; keras.layers.Conv2DTranspose at CycleGAN.py:353 and
+ * UNet_Segmentation.py:542-551; and the ReflectionPadding2D that precedes the 'valid' convs
+ * (CycleGAN.py:326,332,368,392) which is folded into the gather (never materialised in fwd).
+ *
+ * transposed == 0 : y[n,oy,ox,co] = bias[co] + sum x_pad[n, oy*stride+kh, ox*stride+kw, ci] * w[kh,kw,ci,co]
+ *                   x_pad = x padded by pad_top/pad_left (and whatever is needed after) with zeros
+ *                   (Keras 'same'/'valid') or by reflection (pad_mode == SS_PAD_REFLECT, stride 1 only).
+ * transposed == 1 : Keras Conv2DTranspose(padding='same') with the torch-backend alignment:
+ *                   y[n, iy*stride - pad_top + kh, ix*stride - pad_left + kw, co] += x[n,iy,ix,ci] * w[kh,kw,co,ci]
+ *                   (pad_top = pad_left = torch `padding`; k=3,s=2 -> 1, output 2x; k=2,s=2 -> 0).
+ * (ih,iw,cin) always describe x and (oh,ow,cout) always describe y of the FORWARD op.
+ * `act` is applied to y in the forward epilogue (after bias); backward entry points take the
+ * gradient w.r.t. the pre-activation output (use ss_act_bwd first).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ss_conv_desc {
+    int32_t n, ih, iw, cin, in_cstride;
+    int32_t oh, ow, cout, out_cstride;
+    int32_t kh, kw, stride;
+    int32_t pad_top, pad_left;
+    int32_t pad_mode;
+    int32_t transposed;
+    int32_t act;
+    float act_alpha;
+    int32_t algo;
+} ss_conv_desc;
+
+size_t ss_conv2d_workspace_bytes(const ss_conv_desc* d, int pass);
+int ss_conv2d_fwd(const ss_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                  void* ws, size_t ws_bytes, void* stream);
+/* dx (view with in_cstride) = d loss / d x ; overwritten (accumulate == 0) or added to (accumulate != 0) */
+int ss_conv2d_bwd_data(const ss_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
+                       void* ws, size_t ws_bytes, void* stream);
+/* dw (Keras layout, dense) and optional dbias; accumulate != 0 adds to the existing contents
+ * (a net that is run several times per step, CycleGAN.py:621-633). */
+int ss_conv2d_bwd_weight(const ss_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                         int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation.  One descriptor serves
+ *   InstanceNorm = keras.layers.GroupNormalization(groups=-1, axis=3, epsilon=1e-5)
+ *                  (CycleGAN.py:329,335,342,355,374): groups = n, per-sample statistics;
+ *   BatchNorm    = keras.layers.BatchNormalization(axis=3[, scale=False]), momentum 0.99,
+ *                  epsilon 1e-3 (UNet_Segmentation.py:422,448,470,473,494,502): groups = 1.
+ * Forward:  z = (x - mean) * rstd * gamma + beta ;  y = act(z + residual)
+ *           (biased variance, var = E[x^2] - E[x]^2 as keras.ops.moments on torch).
+ * The fused activation / residual replace keras.layers.Activation / add / LeakyReLU that follow
+ * the norm (CycleGAN.py:330,336,344,357,375; UNet_Segmentation.py:425,471-472,492-493).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ss_norm_desc {
+    int32_t n, h, w, c;
+    int32_t x_cstride, y_cstride, res_cstride;
+    int32_t groups;          /* n -> instance norm, 1 -> batch norm */
+    float eps;
+    int32_t act;
+    float act_alpha;
+} ss_norm_desc;
+
+size_t ss_norm_workspace_bytes(const ss_norm_desc* d);
+/* gamma may be NULL (scale=False); residual may be NULL.  mean/rstd: [groups*c] outputs kept for backward.
+ * If moving_mean/moving_var are non-NULL (batch norm training) they are updated in place:
+ * moving = moving*momentum + batch*(1-momentum), with the biased batch variance. */
+int ss_norm_fwd(const ss_norm_desc* d, const float* x, const float* gamma, const float* beta,
+                const float* residual, float* y, float* mean, float* rstd,
+                float* moving_mean, float* moving_var, float momentum,
+                void* ws, size_t ws_bytes, void* stream);
+/* inference-mode batch norm: statistics come from moving_mean / moving_var */
+int ss_norm_infer(const ss_norm_desc* d, const float* x, const float* gamma, const float* beta,
+                  const float* moving_mean, const float* moving_var, const float* residual, float* y,
+                  void* stream);
+/* dy: gradient w.r.t. y.  y: forward output (needed when act != NONE).
+ * dx (view with dx_cstride) receives d loss / d x.  dres (optional, view with d->res_cstride) receives the
+ * gradient w.r.t. the residual input (= dy * act'(.)).  dgamma may be NULL.  Each accumulate_* flag != 0
+ * adds into the destination instead of overwriting it. */
+int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
+                const float* gamma, const float* mean, const float* rstd,
+                float* dx, int32_t dx_cstride, int accumulate_dx, float* dres, int accumulate_dres,
+                float* dgamma, float* dbeta, int accumulate_params,
+                void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise / pooling on NHWC views (rows = n*h*w pixels, c channels, explicit pixel strides).
+ * ---------------------------------------------------------------------------------------- */
+/* dx = dy * act'(.) expressed through the forward OUTPUT y (tanh, sigmoid, relu, lrelu):
+ * keras.layers.Activation("tanh") CycleGAN.py:420, LeakyReLU(0.2) CycleGAN.py:433. */
+int ss_act_bwd(int act, float act_alpha, const float* dy, int32_t dy_cstride, const float* y, int32_t y_cstride,
+               float* dx, int32_t dx_cstride, int64_t rows, int32_t c, void* stream);
+/* out = alpha*a + beta*b  (b may be NULL) -- gradient accumulation where a tensor has two consumers */
+int ss_axpby(float alpha, const float* a, int32_t a_cstride, float beta, const float* b, int32_t b_cstride,
+             float* out, int32_t out_cstride, int64_t rows, int32_t c, void* stream);
+/* keras.layers.MaxPooling2D(pool_size=(2,2)) UNet_Segmentation.py:525,529,533,537 */
+int ss_maxpool2x2_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride,
+                      int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+/* dx (+)= routed dy (first maximum in row-major window order wins, as torch max_pool2d) */
+int ss_maxpool2x2_bwd(const float* dy, int32_t dy_cstride, const float* x, int32_t x_cstride,
+                      float* dx, int32_t dx_cstride, int accumulate,
+                      int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+int ss_copy(const float* src, int32_t src_cstride, float* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream);
+int ss_fill(float* dst, float value, int64_t count, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses (Keras 'sum_over_batch_size' = mean over every element).  Each writes the scalar loss to
+ * *loss_out (device memory) and, if grad != NULL, grad = grad_scale * d loss / d pred.
+ * ws: ss_loss_workspace_bytes(count).
+ * ---------------------------------------------------------------------------------------- */
+size_t ss_loss_workspace_bytes(int64_t count);
+/* mean((target - pred)^2): keras.losses.MeanSquaredError against ones/zeros, CycleGAN.py:301-308 */
+int ss_loss_mse_const(const float* pred, int64_t count, float target, float grad_scale,
+                      float* loss_out, float* grad, void* ws, size_t ws_bytes, void* stream);
+/* mean(|truth - pred|): keras.losses.MeanAbsoluteError, CycleGAN.py:103-106,644-650 */
+int ss_loss_mae(const float* truth, const float* pred, int64_t count, float grad_scale,
+                float* loss_out, float* grad, void* ws, size_t ws_bytes, void* stream);
+/* class-weighted BCE + metrics, UNet_Segmentation.py:379-384,395.  out3 = {loss, mae, binary acc@0.5} */
+int ss_loss_weighted_bce(const float* truth, const float* pred, int64_t count, float weighting, float grad_scale,
+                         float* out3, float* grad, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * keras.optimizers.Adam as applied at CycleGAN.py:668-669,690-692 and by Model.fit for the UNet
+ * (UNet_Segmentation.py:393): fused single pass over a flat parameter arena.
+ *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= alpha * m / (sqrt(v) + eps)
+ *   alpha = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller (t = iterations + 1).
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce).
+ * ---------------------------------------------------------------------------------------- */
+int ss_adam_keras(float* p, const float* g, float* m, float* v, int64_t count,
+                  float alpha, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMSEG_HIP_H */

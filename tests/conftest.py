@@ -17,3 +17,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def load_pkg():
+    """The package directory carries the reference's (hyphenated) name -> import through importlib."""
+    import importlib
+    return importlib.import_module("automatic-sem-image-segmentation_amd")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_pkg()

@@ -1,0 +1,399 @@
+"""CycleGAN workflow, model and image buffer with the reference's class / attribute / metric names
+(Releases/Version 1.2.0/CycleGAN.py), executing on libsemseg_hip.so.
+
+Reference surface mirrored here (file:line in the reference):
+* ``CycleGAN`` ctor + attribute defaults ............ CycleGAN.py:20-114   (StartProcess.py:91-102 overrides)
+* ``create_model`` / ``start_training`` .............. CycleGAN.py:116-222
+* ``generator_loss_fn`` / ``discriminator_loss_fn`` .. CycleGAN.py:301-308  (LSGAN, label smoothing)
+* ``linear_decay`` .................................. CycleGAN.py:310-317
+* ``DataLoader`` .................................... CycleGAN.py:454-479
+* ``CycleGanModel`` (+ ``compile``, ``train_step``) .. CycleGAN.py:512-710  (torch-backend semantics)
+* ``ImagePool`` ..................................... CycleGAN.py:908-964
+
+Behavioural quirks kept on purpose (SURVEY.md "Three facts"):
+* the pools are built in ``__init__`` with the constructor default ``batch_size = 2`` and never see the
+  later ``cycle_gan.batch_size = N`` assignment, so ``query`` only ever uses the first two images of a batch;
+* both generator losses are back-propagated into BOTH generators (``retain_graph`` double backward without
+  zeroing, CycleGAN.py:664-665): implemented as ONE backward of (L_a + L_b) -- same gradient, 6 generator
+  backward traversals instead of 8.
+"""
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import dist as D
+from . import losses
+from .engine import Act, Tape, _stream
+from .nets import PatchDiscriminator, ResnetGenerator
+from .optim import Adam
+
+METRIC_NAMES = ("d_a", "d_b", "d_fake_a", "d_fake_b", "d_real_a", "d_real_b", "g_a", "g_b",
+                "g_adv_a", "g_adv_b", "g_cyc_a", "g_cyc_b", "g_id_a", "g_id_b")
+
+
+class ImagePool:
+    """History buffer of generated images (device resident).  Same control flow and python ``random`` stream
+    consumption as CycleGAN.py:927-964: one ``uniform`` (+ one ``randint`` on a swap) per image once full."""
+
+    def __init__(self, batch_size, pool_size=50, rng=random):
+        self.pool_size = pool_size
+        self.batch_size = batch_size
+        self.rng = rng
+        if self.pool_size > 0:
+            self.num_imgs = 0
+            self.images = []
+
+    def query(self, images):
+        """images: NHWC device tensor.  Returns a new [k,H,W,C] tensor, k = min(self.batch_size, N)."""
+        if self.pool_size == 0:
+            return images
+        lib = L.load()
+        picks = []
+        for index in range(0, self.batch_size):
+            if index >= images.shape[0]:
+                break  # short batch: the reference's documented intent (CycleGAN.py:945-948)
+            image = images[index:index + 1]
+            if self.num_imgs < self.pool_size:
+                self.num_imgs += 1
+                self.images.append(image.clone())
+                picks.append(image)
+            else:
+                p = self.rng.uniform(0, 1)
+                if p > 0.5:
+                    random_id = self.rng.randint(0, self.pool_size - 1)
+                    tmp = self.images[random_id]
+                    self.images[random_id] = image.clone()
+                    picks.append(tmp)
+                else:
+                    picks.append(image)
+        out = torch.empty((len(picks),) + tuple(images.shape[1:]), dtype=images.dtype, device=images.device)
+        per = out[0].numel()
+        for i, src in enumerate(picks):
+            L.check(lib.ss_copy(src.data_ptr(), 1, out[i].data_ptr(), 1, per, 1, _stream()), "ss_copy")
+        return out
+
+
+class CycleGanModel:
+    """Drop-in for the reference's ``CycleGanModel(keras.Model)``: same constructor arguments, ``compile``
+    keywords, ``gen_a/gen_b/disc_a/disc_b`` attributes and ``train_step`` metric keys."""
+
+    def __init__(self, generator_a, generator_b, discriminator_a, discriminator_b, image_pool_a=None,
+                 image_pool_b=None, lambda_cycle_a=10.0, lambda_cycle_b=10.0, lambda_identity_a=0.5,
+                 lambda_identity_b=0.5, **kwargs):
+        self.gen_a, self.gen_b = generator_a, generator_b
+        self.disc_a, self.disc_b = discriminator_a, discriminator_b
+        self.lambda_cycle_a, self.lambda_cycle_b = lambda_cycle_a, lambda_cycle_b
+        self.lambda_identity_a, self.lambda_identity_b = lambda_identity_a, lambda_identity_b
+        self.use_identity_loss = lambda_identity_a > 0 or lambda_identity_b > 0
+        self.gen_a_optimizer = self.gen_b_optimizer = self.disc_a_optimizer = self.disc_b_optimizer = None
+        self.image_pool_a = image_pool_a if image_pool_a is not None else ImagePool(1, 0)
+        self.image_pool_b = image_pool_b if image_pool_b is not None else ImagePool(1, 0)
+        self.label_smoothing_factor = 0.0
+        self.device = generator_a.device
+        # 14 running means (keras.metrics.Mean, CycleGAN.py:547-560): device sums, one host read per query
+        self._scalars = torch.zeros(16, dtype=torch.float32, device=self.device)
+        self._sums = np.zeros(14, dtype=np.float64)
+        self._count = 0
+        self.sync_metrics = True
+        self.built = True
+
+    def compile(self, gen_a_optimizer, gen_b_optimizer, disc_x_optimizer, disc_y_optimizer, disc_loss_fn=None,
+                gen_loss_fn=None, cycle_loss_fn_a=None, cycle_loss_fn_b=None, identity_loss_fn_a=None,
+                identity_loss_fn_b=None, label_smoothing_factor=0.0, **kwargs):
+        """The loss callables of the reference are fixed functions here (LSGAN MSE with label smoothing,
+        MAE cycle / identity); they are accepted for signature compatibility."""
+        self.gen_a_optimizer, self.gen_b_optimizer = gen_a_optimizer, gen_b_optimizer
+        self.disc_a_optimizer, self.disc_b_optimizer = disc_x_optimizer, disc_y_optimizer
+        self.label_smoothing_factor = label_smoothing_factor
+
+    @property
+    def metrics_names(self):
+        return list(METRIC_NAMES)
+
+    def reset_metrics(self):
+        self._sums[:] = 0.0
+        self._count = 0
+
+    def _slot(self, i):
+        return self._scalars[i:i + 1]
+
+    def train_step(self, batch_data):
+        """One optimisation step of G_a, G_b, D_a, D_b (CycleGAN.py:615-710).  batch_data = (real_a, real_b):
+        NHWC float32 arrays / tensors in [-1, 1].  Returns {metric: running mean}."""
+        real_a, real_b = (self._to_act(t) for t in batch_data)
+        ga, gb, da, db = self.gen_a, self.gen_b, self.disc_a, self.disc_b
+        ls = self.label_smoothing_factor
+        one = 1.0 - ls + ls / 2.0
+        zero = ls / 2.0
+        world = D.world_size()
+
+        # ---- generators -------------------------------------------------------------------------------
+        tape = Tape()
+        fake_b = ga(real_a, True, tape)
+        fake_a = gb(real_b, True, tape)
+        cycled_a = gb(fake_b, True, tape)
+        cycled_b = ga(fake_a, True, tape)
+        if self.use_identity_loss:
+            same_a = gb(real_a, True, tape)
+            same_b = ga(real_b, True, tape)
+        tape.param_grads = False            # discriminators only route gradients in this phase
+        disc_fake_a = da(fake_a, True, tape)
+        disc_fake_b = db(fake_b, True, tape)
+        tape.param_grads = True
+        # slots: 0 adv_a 1 adv_b 2 cyc_a 3 cyc_b 4 id_a 5 id_b | 6 d_real_a 7 d_fake_a 8 d_real_b 9 d_fake_b
+        losses.mse_const(disc_fake_b, one, 1.0, self._slot(0))
+        losses.mse_const(disc_fake_a, one, 1.0, self._slot(1))
+        losses.mae(real_b, cycled_b, self.lambda_cycle_a, self._slot(2))
+        losses.mae(real_a, cycled_a, self.lambda_cycle_b, self._slot(3))
+        if self.use_identity_loss:
+            losses.mae(real_b, same_b, self.lambda_cycle_a * self.lambda_identity_a, self._slot(4))
+            losses.mae(real_a, same_a, self.lambda_cycle_b * self.lambda_identity_b, self._slot(5))
+        ga.zero_grad()
+        gb.zero_grad()
+        tape.backward()                      # d(L_a + L_b)/d theta for both generators in one traversal
+        D.all_reduce_grads([ga, gb])
+        self.gen_a_optimizer.apply(ga, 1.0 / world)
+        self.gen_b_optimizer.apply(gb, 1.0 / world)
+
+        # ---- discriminators ---------------------------------------------------------------------------
+        tape = Tape()
+        disc_real_a = da(real_a, True, tape)
+        pooled_a = self.image_pool_a.query(fake_a.t)          # detached copy of the generated batch
+        disc_fake_a2 = da(Act(pooled_a, requires_grad=False), True, tape)
+        disc_real_b = db(real_b, True, tape)
+        pooled_b = self.image_pool_b.query(fake_b.t)
+        disc_fake_b2 = db(Act(pooled_b, requires_grad=False), True, tape)
+        losses.mse_const(disc_real_a, one, 0.5, self._slot(6))
+        losses.mse_const(disc_fake_a2, zero, 0.5, self._slot(7))
+        losses.mse_const(disc_real_b, one, 0.5, self._slot(8))
+        losses.mse_const(disc_fake_b2, zero, 0.5, self._slot(9))
+        da.zero_grad()
+        db.zero_grad()
+        tape.backward()
+        D.all_reduce_grads([da, db])
+        self.disc_a_optimizer.apply(da, 1.0 / world)
+        self.disc_b_optimizer.apply(db, 1.0 / world)
+
+        return self._update_metrics()
+
+    # ---- helpers --------------------------------------------------------------------------------------
+    def _to_act(self, t):
+        if isinstance(t, Act):
+            return t
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+        return Act(t.to(self.device, dtype=torch.float32).contiguous(), requires_grad=False)
+
+    def _update_metrics(self):
+        if not self.sync_metrics:
+            self._count += 1
+            return {}
+        s = self._scalars.cpu().numpy().astype(np.float64)   # one device->host read per step
+        s = D.mean_scalars(s)
+        adv_a, adv_b = s[0], s[1]
+        cyc_a, cyc_b = s[2] * self.lambda_cycle_a, s[3] * self.lambda_cycle_b
+        id_a = s[4] * self.lambda_cycle_a * self.lambda_identity_a if self.use_identity_loss else 0.0
+        id_b = s[5] * self.lambda_cycle_b * self.lambda_identity_b if self.use_identity_loss else 0.0
+        vals = dict(d_a=(s[6] + s[7]) * 0.5, d_b=(s[8] + s[9]) * 0.5, d_fake_a=s[7], d_fake_b=s[9],
+                    d_real_a=s[6], d_real_b=s[8], g_a=adv_a + cyc_a + id_a, g_b=adv_b + cyc_b + id_b,
+                    g_adv_a=adv_a, g_adv_b=adv_b, g_cyc_a=cyc_a, g_cyc_b=cyc_b, g_id_a=id_a, g_id_b=id_b)
+        self._count += 1
+        self._sums += np.array([vals[k] for k in METRIC_NAMES])
+        return {k: float(self._sums[i] / self._count) for i, k in enumerate(METRIC_NAMES)}
+
+    @staticmethod
+    def to_numpy_array(x):
+        if isinstance(x, Act):
+            x = x.dense()
+        return x.detach().cpu().numpy().copy()
+
+    # ---- persistence (Keras variable order; see DESIGN.md for the .keras/HDF5 status) ----------------------
+    def get_weights(self):
+        return {nm: net.get_weights() for nm, net in (("gen_a", self.gen_a), ("gen_b", self.gen_b),
+                                                      ("disc_a", self.disc_a), ("disc_b", self.disc_b))}
+
+    def save(self, path):
+        arrays = {}
+        for nm, ws in self.get_weights().items():
+            net = getattr(self, nm)
+            for name, w in zip(net.variable_names, ws):
+                arrays[f"{nm}/{name}"] = w
+        np.savez(path if path.endswith(".npz") else path + ".npz", **arrays)
+
+
+class DataLoader:
+    """Unpaired A/B batches: floor length, contiguous slices, independent per-epoch shuffles (CycleGAN.py:454-479)."""
+
+    def __init__(self, train_a, train_b, batch_size=1, use_dataloader=False, scale_for_binary_crossentropy=False,
+                 invert_images=False, **kwargs):
+        self.batch_size = batch_size
+        self.train_a, self.train_b = train_a, train_b
+        self.use_dataloader = use_dataloader
+        self.scale_for_binary_crossentropy = scale_for_binary_crossentropy
+        self.invert_images = invert_images
+
+    def __len__(self):
+        return int(min(len(self.train_a), len(self.train_b)) / float(self.batch_size))
+
+    def __getitem__(self, idx):
+        a = self.train_a[idx * self.batch_size:(idx + 1) * self.batch_size]
+        b = self.train_b[idx * self.batch_size:(idx + 1) * self.batch_size]
+        if self.use_dataloader:
+            a = CycleGAN.load_images(a, False, invert=self.invert_images)
+            b = CycleGAN.load_images(b, self.scale_for_binary_crossentropy)
+        return np.asarray(a), np.asarray(b)
+
+    def on_epoch_end(self):
+        np.random.shuffle(self.train_a)
+        np.random.shuffle(self.train_b)
+
+
+class CycleGAN:
+    """Workflow object with the reference's attribute names and defaults (CycleGAN.py:21-114)."""
+
+    def __init__(self, root_dir='./', image_shape=(384, 384, 1), allow_memory_growth=True, use_gpus_no=(0,)):
+        self.batch_size = 2
+        self.epochs = 50
+        self.learning_rate = 2e-4
+        self.use_data_loader = False
+        self.filters = 32
+        self.num_downsampling_blocks_gen = 3
+        self.num_residual_blocks_gen = 9
+        self.num_upsampling_blocks_gen = 3
+        self.num_downsampling_blocks_disc = 2
+        self.allow_memory_growth = allow_memory_growth
+        self.use_gpus_no = use_gpus_no
+        self.lambda_cycle_a = 10
+        self.lambda_cycle_b = 10
+        self.use_binary_crossentropy = False
+        self.use_linear_decay = True
+        self.decay_epoch = int(0.75 * self.epochs)
+        # Keras' LearningRateScheduler acts on model.optimizer, which is none of the four Adams,
+        # so the reference's linear decay never reaches them.  Default reproduces that (constant 2e-4).
+        self.apply_lr_decay_to_adams = False
+        self.lambda_identity_a = 0.5
+        self.lambda_identity_b = 0.5
+        self.use_skip_connection = True
+        self.use_resize_convolution = False
+        self.label_smoothing_factor = 0.0
+        self.gaussian_noise_value = 0.15
+        self.invert_images = False
+        self.image_pool_size = 50
+        self.gen_a = self.gen_b = self.disc_a = self.disc_b = None
+        self.model = None
+        self.data = None
+        self.root_dir = root_dir
+        self.model_dir = os.path.join(self.root_dir, '2_CycleGAN', 'Models')
+        self.image_shape = image_shape
+        self.prefix = time.strftime('%Y-%m-%d_%H-%M-%S', time.localtime())
+        # pools are created HERE, with the constructor default batch_size (= 2) -- reference quirk, see module doc
+        self.image_pool_a = ImagePool(batch_size=self.batch_size, pool_size=self.image_pool_size)
+        self.image_pool_b = ImagePool(batch_size=self.batch_size, pool_size=self.image_pool_size)
+        self.device = D.local_device()
+        self.seed = 0
+        from . import HelperFunctions
+        data = os.path.join(self.root_dir, '2_CycleGAN', 'data')
+        self.train_a = HelperFunctions.get_image_file_paths_from_directory(os.path.join(data, 'trainA'), missing_ok=True)
+        self.test_a = HelperFunctions.get_image_file_paths_from_directory(os.path.join(data, 'testA'), missing_ok=True)
+        self.train_b = HelperFunctions.get_image_file_paths_from_directory(os.path.join(data, 'trainB'), missing_ok=True)
+        self.test_b = HelperFunctions.get_image_file_paths_from_directory(os.path.join(data, 'testB'), missing_ok=True)
+
+    def create_model(self):
+        if self.use_binary_crossentropy:
+            raise NotImplementedError("use_binary_crossentropy=True is off in StartProcess.py:101 and not built yet")
+        if self.use_skip_connection:
+            raise NotImplementedError("use_skip_connection=True (StartProcess default is False, StartProcess.py:36) not built yet")
+        if self.use_resize_convolution:
+            raise NotImplementedError("use_resize_convolution=True is off in StartProcess.py:102 and not built yet")
+        if self.gaussian_noise_value > 0:
+            raise NotImplementedError("gaussian_noise_value > 0 is off in StartProcess.py:96 and not built yet")
+        ch = self.image_shape[-1] if len(self.image_shape) == 3 else 1
+        kw = dict(filters=self.filters, num_downsampling_blocks=self.num_downsampling_blocks_gen,
+                  num_residual_blocks=self.num_residual_blocks_gen, num_upsample_blocks=self.num_upsampling_blocks_gen,
+                  channels=ch, device=self.device)
+        self.gen_a = ResnetGenerator(seed=self.seed + 1, **kw)
+        self.gen_b = ResnetGenerator(seed=self.seed + 2, **kw)
+        self.disc_a = PatchDiscriminator(filters=2 * self.filters, num_downsampling_blocks=self.num_downsampling_blocks_disc,
+                                         channels=ch, padding="valid", device=self.device, seed=self.seed + 3)
+        self.disc_b = PatchDiscriminator(filters=2 * self.filters, num_downsampling_blocks=self.num_downsampling_blocks_disc,
+                                         channels=ch, padding="valid", device=self.device, seed=self.seed + 4)
+        D.broadcast_params([self.gen_a, self.gen_b, self.disc_a, self.disc_b])
+        model = CycleGanModel(generator_a=self.gen_a, generator_b=self.gen_b, discriminator_a=self.disc_a,
+                              discriminator_b=self.disc_b, image_pool_a=self.image_pool_a, image_pool_b=self.image_pool_b,
+                              lambda_cycle_a=self.lambda_cycle_a, lambda_cycle_b=self.lambda_cycle_b,
+                              lambda_identity_a=self.lambda_identity_a, lambda_identity_b=self.lambda_identity_b)
+        model.compile(gen_a_optimizer=Adam(learning_rate=self.learning_rate, beta_1=0.5),
+                      gen_b_optimizer=Adam(learning_rate=self.learning_rate, beta_1=0.5),
+                      disc_x_optimizer=Adam(learning_rate=self.learning_rate, beta_1=0.5),
+                      disc_y_optimizer=Adam(learning_rate=self.learning_rate, beta_1=0.5),
+                      gen_loss_fn=self.generator_loss_fn, disc_loss_fn=self.discriminator_loss_fn,
+                      label_smoothing_factor=self.label_smoothing_factor)
+        return model
+
+    # LSGAN targets, kept for API compatibility / documentation (the kernels implement them)
+    def generator_loss_fn(self, fake):
+        raise NotImplementedError("losses run as HIP kernels inside CycleGanModel.train_step")
+
+    def discriminator_loss_fn(self, real, fake):
+        raise NotImplementedError("losses run as HIP kernels inside CycleGanModel.train_step")
+
+    def linear_decay(self, epoch, current_lr=None):
+        if epoch < self.decay_epoch:
+            return self.learning_rate
+        decay = (1 - ((epoch - self.decay_epoch) / float(self.epochs - self.decay_epoch))) ** 1
+        return self.learning_rate * decay
+
+    @staticmethod
+    def load_images(image_list, scale_for_binary_crossentropy=False, invert=False):
+        from . import HelperFunctions
+        r = (0, 1) if scale_for_binary_crossentropy else (-1, 1)
+        images = HelperFunctions.load_and_preprocess_images(input_dir_or_filelist=image_list, threshold_value=None,
+                                                            normalization_range=r, output_channels=1,
+                                                            contrast_optimization_range=None)
+        if invert:
+            images *= -1.0
+        return images
+
+    def start_training(self):
+        """Epoch loop equivalent to ``model.fit(DataLoader, epochs, callbacks)`` (CycleGAN.py:182-222): per-epoch metric
+        reset, CSV log (';'), per-epoch weight checkpoint, final ``model`` file.  Under torch.distributed each rank
+        takes a contiguous slice of every global batch."""
+        os.makedirs(os.path.join(self.model_dir, self.prefix), exist_ok=True)
+        self.decay_epoch = int(0.75 * self.epochs)
+        if not self.use_data_loader:
+            self.train_a = self.load_images(self.train_a, False, invert=self.invert_images)
+            self.train_b = self.load_images(self.train_b, self.use_binary_crossentropy)
+        self.data = DataLoader(self.train_a, self.train_b, batch_size=self.batch_size, use_dataloader=self.use_data_loader,
+                               scale_for_binary_crossentropy=self.use_binary_crossentropy, invert_images=self.invert_images)
+        self.model = self.create_model()
+        log_path = os.path.join(self.model_dir, self.prefix, 'training_log.csv')
+        rank, world = D.rank(), D.world_size()
+        for epoch in range(self.epochs):
+            if self.use_linear_decay and self.apply_lr_decay_to_adams:
+                lr = self.linear_decay(epoch)
+                for opt in (self.model.gen_a_optimizer, self.model.gen_b_optimizer, self.model.disc_a_optimizer,
+                            self.model.disc_b_optimizer):
+                    opt.learning_rate = lr
+            self.model.reset_metrics()
+            logs = {}
+            order = list(range(len(self.data)))
+            np.random.shuffle(order)     # Keras fit(shuffle=True) shuffles the batch order of a Sequence (K-list 10)
+            for idx in order:
+                a, b = self.data[idx]
+                per = len(a) // world
+                logs = self.model.train_step((a[rank * per:(rank + 1) * per], b[rank * per:(rank + 1) * per]))
+            self.data.on_epoch_end()
+            if rank == 0:
+                new = not os.path.exists(log_path)
+                with open(log_path, 'a') as f:
+                    if new:
+                        f.write(';'.join(['epoch'] + sorted(logs)) + '\n')
+                    f.write(';'.join([str(epoch)] + [repr(logs[k]) for k in sorted(logs)]) + '\n')
+                self.model.save(os.path.join(self.model_dir, self.prefix, 'checkpoints_{:03d}.keras'.format(epoch + 1)))
+        if rank == 0:
+            self.model.save(os.path.join(self.model_dir, self.prefix, 'model.keras'))
+        return self.model

@@ -1,0 +1,289 @@
+"""MultiResUNet workflow with the reference's class / attribute names (Releases/Version 1.2.0/UNet_Segmentation.py),
+executing on libsemseg_hip.so.
+
+Reference surface mirrored here (file:line in the reference):
+* ``ImageDataset`` / ``DataLoader`` / ``DataSet`` ... UNet_Segmentation.py:21-144
+* ``UNet`` ctor + attribute defaults ............... UNet_Segmentation.py:147-205 (StartProcess.py:151-156 overrides)
+* ``run_training`` / ``create_model`` .............. UNet_Segmentation.py:246-288, 363-396
+* ``step_decay`` / ``linear_decay`` ................ UNet_Segmentation.py:233-244
+* the Keras default ``train_step`` + metrics (loss / mae / acc) that ``model.fit`` runs (third party in the reference).
+"""
+import math
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import HelperFunctions
+from . import dist as D
+from . import losses
+from .engine import Act, Tape
+from .nets import MultiResUNet
+from .optim import Adam
+
+
+class ImageDataset:
+    """80/20 split with ``random.Random(1234)``, four flip augmentations per image (UNet_Segmentation.py:21-101)."""
+
+    def __init__(self, image_dir, mask_dir, contrast_optimization_range=(0.5, 99.5), use_brightness_and_contrast_augmentation=False):
+        self.image_ids = []
+        self.image_info = {}
+        self.type = ''
+        self.image_dir, self.mask_dir = image_dir, mask_dir
+        self.contrast_optimization_range = contrast_optimization_range
+        self.use_brightness_and_contrast_augmentation = use_brightness_and_contrast_augmentation
+
+    def add_image(self, image_id, path, mask, augmentation):
+        self.image_info[image_id] = {'id': image_id, 'image_path': path, 'mask_path': mask, 'augmentation': augmentation}
+        self.image_ids.append(image_id)
+
+    def initialize_images(self, subset, train_val_split=0.8, seed=1234):
+        assert subset in ["train", "val"]
+        all_images = HelperFunctions.get_image_file_paths_from_directory(self.image_dir)
+        random.Random(seed).shuffle(all_images)
+        self.type = subset
+        cut = int(train_val_split * len(all_images))
+        images = all_images[:cut] if subset == "train" else all_images[cut:]
+        for i, image_path in enumerate(images):
+            mask_path = image_path.replace(self.image_dir, self.mask_dir)
+            for j in range(4):
+                self.add_image('{:05d}'.format(i) + '_augmentation_' + str(j), image_path, mask_path, j)
+
+    def load_from_file(self, image_ids, is_mask):
+        if isinstance(image_ids, str):
+            image_ids = [image_ids]
+        images = []
+        for image_id in image_ids:
+            info = self.image_info[image_id]
+            if is_mask:
+                image = HelperFunctions.load_and_preprocess_images(info['mask_path'], normalization_range=(0, 1), threshold_value=0.5)[0]
+            elif self.type == 'train' and self.use_brightness_and_contrast_augmentation:
+                c_opt = random.random() * 2
+                image = HelperFunctions.load_and_preprocess_images(
+                    info['image_path'], normalization_range=(0 - random.random(), 1 + random.random()),
+                    contrast_optimization_range=(c_opt, c_opt + 98))[0]
+                image -= np.min(image)
+                image /= np.max(image)
+            else:
+                image = HelperFunctions.load_and_preprocess_images(info['image_path'], normalization_range=(0, 1),
+                                                                   contrast_optimization_range=self.contrast_optimization_range)[0]
+            a = info['augmentation']
+            if a == 1:
+                image = np.fliplr(image)
+            elif a == 2:
+                image = np.flipud(image)
+            elif a == 3:
+                image = np.fliplr(np.flipud(image))
+            images.append(image)
+        return np.asarray(images, dtype='float32')
+
+
+class DataLoader:
+    """Batches loaded from disk on demand; ceil length (partial last batch) -- UNet_Segmentation.py:104-121."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=True, **kwargs):
+        self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
+        self.all_image_ids = self.dataset.image_ids.copy()
+
+    def __len__(self):
+        return math.ceil(len(self.all_image_ids) / self.batch_size)
+
+    def __getitem__(self, idx):
+        ids = self.all_image_ids[idx * self.batch_size:(idx + 1) * self.batch_size]
+        return self.dataset.load_from_file(ids, is_mask=False), self.dataset.load_from_file(ids, is_mask=True)
+
+    def on_epoch_end(self):
+        if self.shuffle:
+            np.random.shuffle(self.all_image_ids)
+
+
+class DataSet:
+    """In-memory arrays; floor length -- UNet_Segmentation.py:124-144."""
+
+    def __init__(self, x, y, batch_size=1, shuffle=True, **kwargs):
+        self.x, self.y, self.batch_size, self.shuffle = x, y, batch_size, shuffle
+
+    def __len__(self):
+        return self.x.shape[0] // self.batch_size
+
+    def __getitem__(self, idx):
+        return self.x[idx * self.batch_size:(idx + 1) * self.batch_size], self.y[idx * self.batch_size:(idx + 1) * self.batch_size]
+
+    def on_epoch_end(self):
+        if self.shuffle:
+            xy = list(zip(self.x, self.y))
+            random.shuffle(xy)
+            self.x, self.y = zip(*xy)
+            self.x = np.asarray(self.x, dtype='float32')
+            self.y = np.asarray(self.y, dtype='float32')
+
+
+class UNetModel:
+    """What ``keras.models.Model(input, multi_res_unet).compile(loss=weighted_bce, optimizer=Adam, metrics=['mae','acc'])``
+    provides to the workflow: ``train_step`` / ``test_step`` / ``predict`` (UNet_Segmentation.py:386-396)."""
+
+    def __init__(self, net, weighting, optimizer):
+        self.net, self.weighting, self.optimizer = net, float(weighting), optimizer
+        self.device = net.device
+        self._out3 = torch.zeros(4, dtype=torch.float32, device=self.device)
+
+    def _to_act(self, t):
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+        return Act(t.to(self.device, dtype=torch.float32).contiguous(), requires_grad=False)
+
+    def train_step(self, batch):
+        """fwd(training=True) -> class-weighted BCE -> backward -> Adam.  Returns {'loss','mae','acc'} of this batch."""
+        x, y = (self._to_act(t) for t in batch)
+        world = D.world_size()
+        tape = Tape()
+        p = self.net(x, True, tape)
+        losses.weighted_bce(y, p, self.weighting, 1.0, self._out3)
+        self.net.zero_grad()
+        tape.backward()
+        D.all_reduce_grads([self.net])
+        self.optimizer.apply(self.net, 1.0 / world)
+        s = D.mean_scalars(self._out3.cpu().numpy().astype(np.float64))
+        return {"loss": float(s[0]), "mae": float(s[1]), "acc": float(s[2])}
+
+    def test_step(self, batch):
+        x, y = (self._to_act(t) for t in batch)
+        p = self.net(x, False)
+        losses.weighted_bce(y, p, self.weighting, 1.0, self._out3, want_grad=False)
+        s = self._out3.cpu().numpy().astype(np.float64)
+        return {"loss": float(s[0]), "mae": float(s[1]), "acc": float(s[2])}
+
+    def predict(self, x, training=False):
+        return self.net(self._to_act(x), training).dense()
+
+    __call__ = predict
+
+    def get_weights(self):
+        return self.net.get_weights()
+
+    def set_weights(self, w):
+        self.net.set_weights(w)
+
+    def save(self, path):
+        np.savez(path if path.endswith(".npz") else path + ".npz",
+                 **{name: w for name, w in zip(self.net.variable_names, self.net.get_weights())})
+
+
+class UNet:
+    def __init__(self, root_dir, image_dir, mask_dir, allow_memory_growth=True, use_gpus_no=(0,)):
+        self.root_dir = os.path.join(root_dir, '3_UNet')
+        self.model_dir = os.path.join(self.root_dir, "Models")
+        self.image_dir, self.mask_dir = image_dir, mask_dir
+        self.use_dataloader = False
+        self.contrast_optimization_range = (1, 99)
+        self.prefix = time.strftime('%Y-%m-%d_%H-%M-%S', time.localtime())
+        self.batch_size = 1
+        self.epochs = 100
+        self.learning_rate = 0.001
+        self.loss_function = 'binary_crossentropy'
+        self.lr_decay = 'STEP_DECAY'
+        self.image_shape = (384, 384, 1)
+        self.filters = 16
+        self.output_channels = 1
+        self.allow_memory_growth = allow_memory_growth
+        self.use_gpus_no = use_gpus_no
+        self.dataset_train = self.dataset_val = None
+        self.training_data = self.validation_data = None
+        self.model = None
+        self.device = D.local_device()
+        self.seed = 0
+
+    def load_images(self, subset):
+        assert subset in ['train', 'val']
+        ds = self.dataset_train if subset == "train" else self.dataset_val
+        if self.use_dataloader:
+            return DataLoader(ds, self.batch_size)
+        x = ds.load_from_file(ds.image_ids, is_mask=False)
+        y = ds.load_from_file(ds.image_ids, is_mask=True)
+        return DataSet(x, y, self.batch_size)
+
+    def step_decay(self, epoch, current_lr, drop=0.5, epochs_drop=10):
+        return current_lr * drop if (epoch + 1) % epochs_drop == 0 else current_lr
+
+    def linear_decay(self, epoch, current_lr):
+        return self.learning_rate * (1 - (epoch / float(self.epochs))) ** 1
+
+    def class_weighting(self):
+        """#zeros / #ones over all training masks (UNet_Segmentation.py:364-376)."""
+        if self.use_dataloader:
+            zeros = ones = 0
+            tmp = None
+            for image_id in self.dataset_train.image_ids:
+                tmp = np.array(self.dataset_train.load_from_file(image_id, is_mask=True))
+                zeros += np.count_nonzero(tmp == 0)
+                ones += np.count_nonzero(tmp)
+            self.image_shape = tmp.shape[1:3]
+            return zeros / ones
+        y = self.training_data.y
+        self.image_shape = y.shape[1:3]
+        return np.count_nonzero(y == 0) / np.count_nonzero(y)
+
+    def create_model(self, weighting=None):
+        if self.output_channels != 1:
+            raise NotImplementedError("multi-class softmax head (UNet_Segmentation.py:558-560) is off by default and not built yet")
+        if weighting is None:
+            weighting = self.class_weighting()
+        net = MultiResUNet(conv_filters=self.filters, device=self.device, seed=self.seed)
+        D.broadcast_params([net])
+        wd = self.lr_decay if isinstance(self.lr_decay, float) else 0.0
+        return UNetModel(net, weighting, Adam(learning_rate=self.learning_rate, weight_decay=wd))
+
+    def run_training(self):
+        """Equivalent of ``model.fit(training_data, epochs, callbacks, validation_data)`` (UNet_Segmentation.py:246-288)."""
+        os.makedirs(os.path.join(self.model_dir, self.prefix), exist_ok=True)
+        self.dataset_train = ImageDataset(self.image_dir, self.mask_dir, self.contrast_optimization_range)
+        self.dataset_val = ImageDataset(self.image_dir, self.mask_dir, self.contrast_optimization_range)
+        self.dataset_train.initialize_images('train')
+        self.dataset_val.initialize_images('val')
+        self.training_data = self.load_images('train')
+        self.validation_data = self.load_images('val')
+        self.model = self.create_model()
+        log_path = os.path.join(self.model_dir, self.prefix, 'training_log.csv')
+        best = float('inf')
+        rank, world = D.rank(), D.world_size()
+        for epoch in range(self.epochs):
+            if self.lr_decay == 'STEP_DECAY':
+                self.model.optimizer.learning_rate = self.step_decay(epoch, self.model.optimizer.learning_rate)
+            elif self.lr_decay == 'LINEAR_DECAY':
+                self.model.optimizer.learning_rate = self.linear_decay(epoch, self.model.optimizer.learning_rate)
+            tot = {"loss": 0.0, "mae": 0.0, "acc": 0.0}
+            seen = 0
+            order = list(range(len(self.training_data)))
+            np.random.shuffle(order)
+            for idx in order:
+                x, y = self.training_data[idx]
+                per = max(len(x) // world, 1)
+                m = self.model.train_step((x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]))
+                for k in tot:
+                    tot[k] += m[k] * len(x)     # Keras weights the running means by batch size
+                seen += len(x)
+            self.training_data.on_epoch_end()
+            logs = {k: v / max(seen, 1) for k, v in tot.items()}
+            vt = {"loss": 0.0, "mae": 0.0, "acc": 0.0}
+            vseen = 0
+            for idx in range(len(self.validation_data)):
+                x, y = self.validation_data[idx]
+                m = self.model.test_step((x, y))
+                for k in vt:
+                    vt[k] += m[k] * len(x)
+                vseen += len(x)
+            logs.update({"val_" + k: v / max(vseen, 1) for k, v in vt.items()})
+            if rank == 0:
+                new = not os.path.exists(log_path)
+                with open(log_path, 'a') as f:
+                    if new:
+                        f.write(';'.join(['epoch'] + sorted(logs)) + '\n')
+                    f.write(';'.join([str(epoch)] + [repr(logs[k]) for k in sorted(logs)]) + '\n')
+                if logs["loss"] < best:
+                    best = logs["loss"]
+                    self.model.save(os.path.join(self.model_dir, self.prefix, "Checkpoint_Lowest_Loss.keras"))
+        if rank == 0:
+            self.model.save(os.path.join(self.model_dir, self.prefix, 'model.keras'))
+        return self.model

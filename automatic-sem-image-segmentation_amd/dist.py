@@ -1,0 +1,84 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl" on ROCm),
+gloo for the CPU tests.  The reference has no working multi-GPU path on the torch backend: the
+design here is new, with single-device semantics as the parity target.
+
+Tiles are independent in every CycleGAN layer (InstanceNorm is per-sample), so the only exchange step is the
+gradient all-reduce: each network keeps ONE flat gradient arena, reduced in a few large buckets (xGMI is
+point-to-point, 7 links x ~153 GB/s per GPU -> few large messages, not many small ones).  Losses are means over
+the GLOBAL batch: gradients are summed over ranks and scaled by 1/world inside the fused Adam kernel.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+BUCKET_ELEMS = 16 * 1024 * 1024     # 64 MiB fp32 buckets
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def rank():
+    return dist.get_rank() if is_dist() else 0
+
+
+def local_device():
+    if torch.cuda.is_available():
+        return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    return torch.device("cpu")
+
+
+def init_from_env(backend=None):
+    """Initialise the process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
+    if is_dist() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_device())
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend=backend)
+
+
+def all_reduce_flat(flat, bucket_elems=BUCKET_ELEMS):
+    """Sum ``flat`` (1-D tensor) over ranks in large buckets, all launched before any is waited for."""
+    if world_size() == 1:
+        return
+    works = []
+    n = flat.numel()
+    for off in range(0, n, bucket_elems):
+        works.append(dist.all_reduce(flat[off:min(off + bucket_elems, n)], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+
+
+def all_reduce_grads(nets):
+    if world_size() == 1:
+        return
+    for net in nets:
+        all_reduce_flat(net.arena.grads)
+
+
+def broadcast_params(nets, src=0):
+    """Replicas start from rank 0's weights (and BN state)."""
+    if world_size() == 1:
+        return
+    for net in nets:
+        dist.broadcast(net.arena.params, src)
+        dist.broadcast(net.arena.state, src)
+
+
+def mean_scalars(values):
+    """Average a small numpy vector of per-rank scalar means over ranks (equal per-rank batch sizes)."""
+    if world_size() == 1:
+        return values
+    dev = local_device() if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.as_tensor(np.asarray(values, dtype=np.float64), device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return (t / world_size()).cpu().numpy()

@@ -1,0 +1,28 @@
+"""keras.optimizers.Adam semantics on a flat parameter arena (CycleGAN.py:168-171,668-669,690-692;
+UNet_Segmentation.py:393): one fused HIP launch per network and step (ss_adam_keras)."""
+import math
+
+from . import _lib as L
+from .engine import _p, _stream
+
+
+class Adam:
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, weight_decay=None):
+        self.learning_rate = learning_rate
+        self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
+        # Keras applies `variable -= variable * weight_decay * lr` when weight_decay is not None; the reference
+        # only ever passes 0.0 (UNet_Segmentation.py:393), which is a no-op.
+        if weight_decay not in (None, 0, 0.0):
+            raise NotImplementedError("weight_decay != 0 is not on the reference path")
+        self.iterations = 0
+
+    def apply(self, net, grad_scale=1.0):
+        """Equivalent of ``optimizer.apply(grads, net.trainable_weights)`` with the grads in ``net.arena.grads``."""
+        lib = L.load()
+        t = self.iterations + 1
+        lr = float(self.learning_rate)
+        alpha = lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        a = net.arena
+        L.check(lib.ss_adam_keras(_p(a.params), _p(a.grads), _p(a.m), _p(a.v), a.n_train, alpha,
+                                  self.beta_1, self.beta_2, self.epsilon, float(grad_scale), _stream()), "ss_adam_keras")
+        self.iterations = t

@@ -47,7 +47,7 @@ def conv2d(x, kernel, bias=None, stride=1, padding="valid"):
         xc = F.pad(xc, (pl, pr, pt, pb))
     elif padding != "valid":
         raise ValueError(padding)
-    w = kernel.permute(3, 2, 0, 1)
+    w = kernel.permute(3, 2, 0, 1).contiguous()
     y = F.conv2d(xc, w, bias, stride=stride)
     return _nhwc(y)
 
@@ -63,7 +63,7 @@ def conv2d_transpose(x, kernel, bias=None, stride=2):
     output_padding = stride - k % 2
     torch_padding = max(-((k % 2 - k + output_padding) // 2), 0)
     torch_output_padding = 2 * torch_padding + k % 2 - k + output_padding
-    w = kernel.permute(3, 2, 0, 1)  # (cin, cout, kh, kw)
+    w = kernel.permute(3, 2, 0, 1).contiguous()  # (cin, cout, kh, kw)
     y = F.conv_transpose2d(_nchw(x), w, bias, stride=stride, padding=torch_padding,
                            output_padding=torch_output_padding)
     return _nhwc(y)

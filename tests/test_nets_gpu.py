@@ -1,0 +1,179 @@
+"""GPU parity of whole networks and train steps against the oracle / the committed golden vectors
+(the goldens come from the reference's own CycleGanModel.train_step_torch, tests/golden/make_goldens.py)."""
+import importlib
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as ON
+from oracle import steps as OS
+
+pytestmark = pytest.mark.gpu
+BASE = "automatic-sem-image-segmentation_amd"
+
+
+def mod(name):
+    return importlib.import_module(f"{BASE}.{name}")
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def check_tensor(got, ref, what, rtol_l2=1e-4, atol=0.0):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    r = rel_l2(got, ref)
+    m = float(np.abs(got - ref).max())
+    assert r <= rtol_l2 or m <= atol, f"{what}: relL2={r:.3e} (tol {rtol_l2:.1e}) max|d|={m:.3e} (atol {atol:.1e})"
+
+
+# Gradient tensors: rel-L2 vs the fp64 oracle.  fp32 accumulation order differs between the HIP kernels
+# (k-sequential MFMA chains, split-K partials) and torch's CPU kernels; the deepest MultiResUNet parameter
+# gradients sit 60 layers behind the loss.
+GRAD_TOL = float(os.environ.get("SS_GRAD_TOL", "1e-4"))
+
+
+def _oracle_run(net, x_cpu, gy):
+    xr = x_cpu.to(net.dtype).clone().requires_grad_(True)
+    yr = net(xr, True)
+    net.zero_grad()
+    yr.backward(gy.to(net.dtype))
+    return yr.detach(), xr.grad, {v.name: v.value.grad for v in net.trainable_weights}
+
+
+def run_net_fwd_bwd(net_hip, make_ref, x_cpu, gen, grad_tol=None):
+    """HIP fp32 vs the oracle.  The fp64 oracle is the truth; the fp32 oracle's own distance to it is the noise
+    model ('fp64 restatement arbitrates'): err_hip <= tol + 3 * err_oracle32."""
+    E = mod("engine")
+    ref32, ref64 = make_ref(torch.float32), make_ref(torch.float64)
+    ref64.set_weights(ref32.get_weights())
+    net_hip.set_weights(ref32.get_weights())
+    with torch.no_grad():
+        shape = ref32(x_cpu, True).shape
+    ref32.set_weights(ref64.get_weights())      # undo BN moving-stat update of the probe forward
+    gy = (torch.rand(shape, generator=gen, dtype=torch.float64) - 0.5)
+    y64, dx64, gw64 = _oracle_run(ref64, x_cpu, gy)
+    y32, dx32, gw32 = _oracle_run(ref32, x_cpu, gy)
+    tape = E.Tape()
+    x = E.Act(x_cpu.cuda(), requires_grad=True)
+    y = net_hip(x, True, tape)
+    got_y = y.dense().cpu().numpy()
+    gt, _ = y.grad_target()
+    gt.t.copy_(gy.float().cuda())
+    net_hip.zero_grad()
+    tape.backward()
+    torch.cuda.synchronize()
+
+    report = []
+
+    def check(got, r64, r32, what, tol):
+        e_hip, e_32 = rel_l2(got, r64), rel_l2(r32, r64)
+        report.append((e_hip, e_32, what))
+        assert e_hip <= tol + 3 * e_32, f"{what}: relL2 hip={e_hip:.3e} oracle32={e_32:.3e} tol={tol:.1e}"
+
+    ref_max = float(y64.abs().max())
+    assert float(np.abs(got_y - y64.numpy()).max()) <= 1e-4 * max(ref_max, 1e-3) + 3 * float((y32.double() - y64).abs().max()), "forward output"
+    check(x.get_grad().dense().cpu(), dx64, dx32, "dx", 1e-4)
+    grads = net_hip.get_gradients()
+    for name in gw64:
+        if float(gw64[name].abs().max()) < 1e-9:
+            assert float(np.abs(grads[name]).max()) < 1e-5, name   # analytically-zero gradients (conv bias-free before a norm etc.)
+            continue
+        check(grads[name], gw64[name], gw32[name], f"grad {name}", grad_tol or GRAD_TOL)
+    if os.environ.get("SS_TEST_REPORT"):
+        for e_hip, e_32, what in sorted(report, reverse=True)[:12]:
+            print(f"  {what:40s} hip={e_hip:.2e} oracle32={e_32:.2e}")
+    return ref32, ref64
+
+
+def test_generator_fwd_bwd():
+    gen = torch.Generator().manual_seed(0)
+    hip = mod("nets").ResnetGenerator(filters=8, num_residual_blocks=3, device="cuda:0")
+    run_net_fwd_bwd(hip, lambda dt: ON.ResnetGenerator(filters=8, num_residual_blocks=3, seed=5, dtype=dt),
+                    torch.rand((2, 64, 64, 1), generator=gen) * 2 - 1, gen)
+
+
+def test_discriminator_fwd_bwd():
+    gen = torch.Generator().manual_seed(1)
+    hip = mod("nets").PatchDiscriminator(filters=16, device="cuda:0")
+    run_net_fwd_bwd(hip, lambda dt: ON.PatchDiscriminator(filters=16, seed=6, dtype=dt),
+                    torch.rand((2, 64, 64, 1), generator=gen) * 2 - 1, gen)
+
+
+def test_multiresunet_fwd_bwd_and_state():
+    gen = torch.Generator().manual_seed(2)
+    hip = mod("nets").MultiResUNet(16, device="cuda:0")
+    assert hip.count_params() == 2429491
+    ref, _ = run_net_fwd_bwd(hip, lambda dt: ON.MultiResUNet(16, seed=7, dtype=dt), torch.rand((2, 64, 64, 1), generator=gen), gen,
+                             grad_tol=1e-3)   # 85 BatchNorms + ReLU masks: the fp32 oracle itself is 1e-3..2e-2 from fp64 here
+    # BatchNorm moving statistics after one training-mode forward
+    for name, got, want in zip(hip.variable_names, hip.get_weights(), ref.get_weights()):
+        if "moving" in name:
+            check_tensor(got, want, name, 1e-4, atol=1e-6)
+    # inference mode uses the moving statistics
+    x = torch.rand((1, 64, 64, 1), generator=gen)
+    yi = hip(x.cuda(), False).dense().cpu().numpy()
+    yr = ref(x, False).detach().numpy()
+    assert float(np.abs(yi - yr).max()) <= 1e-4
+
+
+@pytest.mark.parametrize("fname", ["cyclegan_step_n5_s64_f4.npz", "cyclegan_step_n2_s64_f4.npz"])
+def test_cyclegan_train_step_vs_reference_goldens(golden_dir, fname):
+    """Full CycleGAN steps on the HIP path vs vectors produced by the REFERENCE train_step_torch."""
+    CG, N, OPT = mod("CycleGAN"), mod("nets"), mod("optim")
+    z = np.load(os.path.join(golden_dir, fname))
+    n, size, filters, n_steps, seed = (int(v) for v in z["meta"])
+    nets = dict(gen_a=N.ResnetGenerator(filters=filters, device="cuda:0"), gen_b=N.ResnetGenerator(filters=filters, device="cuda:0"),
+                disc_a=N.PatchDiscriminator(filters=2 * filters, device="cuda:0"),
+                disc_b=N.PatchDiscriminator(filters=2 * filters, device="cuda:0"))
+    for nm, net in nets.items():
+        net.set_weights([z[f"init/{nm}/{i}"] for i in range(len(net.variable_names))])
+    random.seed(seed)
+    model = CG.CycleGanModel(nets["gen_a"], nets["gen_b"], nets["disc_a"], nets["disc_b"],
+                             image_pool_a=CG.ImagePool(2, 3), image_pool_b=CG.ImagePool(2, 3),
+                             lambda_cycle_a=10, lambda_cycle_b=10, lambda_identity_a=0.5, lambda_identity_b=0.5)
+    model.compile(OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5))
+    for s in range(n_steps):
+        m = model.train_step((z[f"step{s}/real_a"], z[f"step{s}/real_b"]))
+        names = [str(x) for x in z[f"step{s}/metric_names"]]
+        assert sorted(m) == names
+        got = np.array([m[k] for k in names])
+        # step 0 depends on forward passes only; later steps also on Adam updates, whose sign-like first steps
+        # amplify rounding-level gradient differences on near-zero gradients
+        np.testing.assert_allclose(got, z[f"step{s}/metrics"], rtol=2e-4 if s == 0 else 2e-3, atol=1e-6, err_msg=f"metrics step {s}")
+    for nm, net in nets.items():
+        for i, (name, w) in enumerate(zip(net.variable_names, net.get_weights())):
+            # after 2-3 Adam steps each element has moved by <= ~3*lr; elements whose gradient is in the rounding
+            # noise may take a different sign step, hence the absolute escape of 2*lr
+            check_tensor(w, z[f"final/{nm}/{i}"], f"{nm}/{name}", 1e-3, atol=4.5e-4)
+    # aggregate: all weights together
+    allg = np.concatenate([w.ravel() for net in nets.values() for w in net.get_weights()])
+    allr = np.concatenate([z[f"final/{nm}/{i}"].ravel() for nm, net in nets.items() for i in range(len(net.variable_names))])
+    assert rel_l2(allg, allr) <= 1e-3
+
+
+def test_unet_train_step_vs_oracle():
+    UN, OPT, N = mod("UNet_Segmentation"), mod("optim"), mod("nets")
+    gen = torch.Generator().manual_seed(3)
+    ref = ON.MultiResUNet(16, seed=9)
+    hip = N.MultiResUNet(16, device="cuda:0")
+    hip.set_weights(ref.get_weights())
+    model = UN.UNetModel(hip, 9.0, OPT.Adam(1e-3))
+    ostep = OS.UNetStep(ref, 9.0)
+    for it in range(2):
+        x = torch.rand((2, 64, 64, 1), generator=gen)
+        y = (torch.rand((2, 64, 64, 1), generator=gen) > 0.9).float()
+        want, _ = ostep.train_step((x, y))
+        got = model.train_step((x.numpy(), y.numpy()))
+        for k in ("loss", "mae", "acc"):
+            assert abs(got[k] - want[k]) <= 2e-4 * max(abs(want[k]), 1.0), (it, k, got[k], want[k])
+    for name, w, r in zip(hip.variable_names, hip.get_weights(), ref.get_weights()):
+        check_tensor(w, r, name, 2e-3, atol=2.5e-3)
+    allg = np.concatenate([w.ravel() for w in hip.get_weights()])
+    allr = np.concatenate([w.ravel() for w in ref.get_weights()])
+    assert rel_l2(allg, allr) <= 2e-3

@@ -96,4 +96,6 @@ int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s);
 bool ss_gconv_mfma_ok(const GConvParams& p);
 int ss_launch_wgrad_direct(const WGradParams& p, float* dw, int ldw, int accumulate, hipStream_t s);
 int ss_launch_wgrad_mfma(const WGradParams& p, float* dw, int ldw, int accumulate, hipStream_t s);
+// same, but only the first `rows` rows of the (ntaps*Ca) x Cb result are written to dw
+int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accumulate, int rows, hipStream_t s);
 int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split);

@@ -98,6 +98,87 @@ int colsum(const float* v, long rows, int C, int cs, float* out, int accumulate,
     return SS_OK;
 }
 
+// ---- single-output-channel restructuring ---------------------------------------------------------
+// A conv with ONE output channel (7x7 64->1 generator head, 4x4 512->1 PatchGAN head and the backward-data of
+// the Cin=1 stems) is a GEMV per pixel: not matrix-core shaped.  It is re-associated into
+//   T[q][t]  = sum_ci in[q][ci] * w[t][ci]            (1x1 conv, N = #taps: an MFMA GEMM, same FLOPs)
+//   out[p]   = act(bias + sum_t T[map(p*s + off + tap_t)][t])      (streaming "tap sum")
+// and its weight gradient into the adjoint
+//   U[q][t]  = sum_{g : map(g*s + off + tap_t) == q} dy[g]          ("tap scatter", one channel)
+//   dw[t][ci] = sum_q U[q][t] * in[q][ci]                           (MFMA GEMM over pixels)
+
+// wt2[ci][t] = w[woff_t + ci*ldb]  (t < ntaps), zero padded to tcs columns
+__global__ __launch_bounds__(256) void gather_w_kernel(GConvParams p, float* __restrict__ wt2, int tcs) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.Cin * tcs) return;
+    const int t = e % tcs, ci = e / tcs;
+    wt2[e] = (t < p.ntaps) ? p.w[p.taps[t].woff + (long)ci * p.ldb] : 0.f;
+}
+
+// p.in = T with channel stride p.in_cs; one thread per output pixel
+__global__ __launch_bounds__(256) void tapsum_kernel(GConvParams p) {
+    const long total = (long)p.N * p.OHc * p.OWc;
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= total) return;
+    const int xc = (int)(pix % p.OWc);
+    const long r = pix / p.OWc;
+    const int yc = (int)(r % p.OHc);
+    const int n = (int)(r / p.OHc);
+    const int oy = yc * p.out_s + p.out_oy, ox = xc * p.out_s + p.out_ox;
+    if (oy < 0 || oy >= p.OH || ox < 0 || ox >= p.OW) return;
+    const int by = yc * p.in_s + p.in_oy, bx = xc * p.in_s + p.in_ox;
+    float acc = 0.f;
+    for (int t = 0; t < p.ntaps; ++t) {
+        const int iy = ss_map_index(by + p.taps[t].dy, p.IH, p.reflect);
+        const int ix = ss_map_index(bx + p.taps[t].dx, p.IW, p.reflect);
+        if (iy >= 0 && ix >= 0) acc += p.in[((long)(n * p.IH + iy) * p.IW + ix) * p.in_cs + t];
+    }
+    float* op = p.out + ((long)(n * p.OH + oy) * p.OW + ox) * p.out_cs;
+    float v = ss_apply_act(acc + (p.bias ? p.bias[0] : 0.f), p.act, p.alpha);
+    if (p.accumulate) v += *op;
+    *op = v;
+}
+
+// U[n,qy,qx,t] = sum over grid positions g whose tap t reads input position q (through the pad map) of b[g]
+__global__ __launch_bounds__(256) void tapscatter_kernel(WGradParams p, float* __restrict__ U, int tcs) {
+    const long total = (long)p.N * p.AH * p.AW * tcs;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int t = (int)(e % tcs);
+    long r = e / tcs;
+    const int qx = (int)(r % p.AW); r /= p.AW;
+    const int qy = (int)(r % p.AH);
+    const int n = (int)(r / p.AH);
+    float acc = 0.f;
+    if (t < p.ntaps) {
+        int cy[3], cx[3], ny = 0, nx = 0;
+        cy[ny++] = qy;
+        cx[nx++] = qx;
+        if (p.reflect) {
+            if (qy >= 1) cy[ny++] = -qy;
+            if (qy <= p.AH - 2) cy[ny++] = 2 * (p.AH - 1) - qy;
+            if (qx >= 1) cx[nx++] = -qx;
+            if (qx <= p.AW - 2) cx[nx++] = 2 * (p.AW - 1) - qx;
+        }
+        for (int a = 0; a < ny; ++a) {
+            const int ty = cy[a] - p.a_oy - p.taps[t].dy;
+            if (ty < 0 || ty % p.a_s) continue;
+            const int gy = ty / p.a_s;
+            if (gy >= p.GH) continue;
+            for (int b = 0; b < nx; ++b) {
+                const int tx = cx[b] - p.a_ox - p.taps[t].dx;
+                if (tx < 0 || tx % p.a_s) continue;
+                const int gx = tx / p.a_s;
+                if (gx >= p.GW) continue;
+                acc += p.b[((long)(n * p.GH + gy) * p.GW + gx) * p.b_cs];
+            }
+        }
+    }
+    U[e] = acc;
+}
+
+inline int round4(int v) { return (v + 3) / 4 * 4; }
+
 // ---- problem builders ---------------------------------------------------------------------------
 bool use_mfma(int algo, const GConvParams& p) {
     if (algo == SS_ALGO_DIRECT) return false;
@@ -105,13 +186,51 @@ bool use_mfma(int algo, const GConvParams& p) {
     return ss_gconv_mfma_ok(p);
 }
 
-int run_gconv(int algo, const GConvParams& p, hipStream_t s) {
+bool gconv_two_stage(int algo, const GConvParams& p) {
+    return algo != SS_ALGO_DIRECT && p.Cout == 1 && p.ntaps >= 4 && p.Cin >= 16;
+}
+
+// upper bound of the two-stage scratch for a gather conv with `cred` reduction channels over an n x ih x iw input
+size_t two_stage_ws(int n, int ih, int iw, int cred, int cout, int ntaps) {
+    if (cout != 1 || ntaps < 4 || cred < 16) return 256;
+    const int tcs = round4(ntaps);
+    return ss_align_up((size_t)cred * tcs * sizeof(float), 256) + ss_align_up((size_t)n * ih * iw * tcs * sizeof(float), 256);
+}
+
+size_t gconv_ws_bytes(int algo, const GConvParams& p) {
+    if (!gconv_two_stage(algo, p)) return 256;
+    return two_stage_ws(p.N, p.IH, p.IW, p.Cin, p.Cout, p.ntaps);
+}
+
+int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (gconv_two_stage(algo, p)) {
+        if (!ws || ws_bytes < gconv_ws_bytes(algo, p)) return SS_ERR_WORKSPACE;
+        const int tcs = round4(p.ntaps);
+        float* wt2 = (float*)ws;
+        float* T = (float*)((char*)ws + ss_align_up((size_t)p.Cin * tcs * sizeof(float), 256));
+        hipLaunchKernelGGL(gather_w_kernel, dim3((p.Cin * tcs + 255) / 256), dim3(256), 0, s, p, wt2, tcs);
+        SS_LAUNCH_CHECK();
+        GConvParams q{};
+        q.in = p.in; q.w = wt2; q.bias = nullptr; q.out = T;
+        q.N = p.N; q.IH = p.IH; q.IW = p.IW; q.Cin = p.Cin; q.in_cs = p.in_cs;
+        q.OHc = p.IH; q.OWc = p.IW; q.in_s = 1; q.in_oy = 0; q.in_ox = 0;
+        q.OH = p.IH; q.OW = p.IW; q.Cout = tcs; q.out_cs = tcs; q.out_s = 1; q.out_oy = 0; q.out_ox = 0;
+        q.ldb = tcs; q.reflect = 0; q.act = SS_ACT_NONE; q.alpha = 0.f; q.accumulate = 0;
+        q.ntaps = 1; q.taps[0].dy = 0; q.taps[0].dx = 0; q.taps[0].woff = 0;
+        int rc = ss_launch_gconv_mfma(q, s);
+        if (rc != SS_OK) return rc;
+        GConvParams r = p;
+        r.in = T; r.in_cs = tcs;
+        const long total = (long)p.N * p.OHc * p.OWc;
+        hipLaunchKernelGGL(tapsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r);
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+    }
     return use_mfma(algo, p) ? ss_launch_gconv_mfma(p, s) : ss_launch_gconv_direct(p, s);
 }
 
-int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
-             int accumulate, int algo, hipStream_t s) {
-    if (c.kh * c.kw > SS_MAX_TAPS) return SS_ERR_UNSUPPORTED;
+GConvParams fwd_params(const ConvProb& c, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
+                       int accumulate) {
     GConvParams p{};
     p.in = x; p.w = w; p.bias = bias; p.out = y;
     p.N = c.n; p.IH = c.ih; p.IW = c.iw; p.Cin = c.cin; p.in_cs = c.in_cs;
@@ -126,16 +245,29 @@ int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bia
             GTap& t = p.taps[p.ntaps++];
             t.dy = (int16_t)a; t.dx = (int16_t)b; t.woff = (a * c.kw + b) * c.cin * c.cout;
         }
-    return run_gconv(algo, p, s);
+    return p;
 }
 
+size_t fwd_ws(const ConvProb& c, int algo) {
+    if (c.kh * c.kw > SS_MAX_TAPS) return 0;
+    return gconv_ws_bytes(algo, fwd_params(c, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0));
+}
+
+int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
+             int accumulate, int algo, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (c.kh * c.kw > SS_MAX_TAPS) return SS_ERR_UNSUPPORTED;
+    return run_gconv(algo, fwd_params(c, x, w, bias, y, act, alpha, accumulate), ws, ws_bytes, s);
+}
+
+size_t bwd_data_wt_bytes(const ConvProb& c) { return ss_align_up((size_t)c.kh * c.kw * c.cin * c.cout * sizeof(float), 256); }
+size_t bwd_data_dpad_bytes(const ConvProb& c) {
+    if (!c.reflect) return 0;
+    const int PH = c.oh + c.kh - 1, PW = c.ow + c.kw - 1;
+    return ss_align_up((size_t)c.n * PH * PW * c.cin * sizeof(float), 256);
+}
 size_t bwd_data_ws(const ConvProb& c) {
-    size_t b = ss_align_up((size_t)c.kh * c.kw * c.cin * c.cout * sizeof(float), 256);
-    if (c.reflect) {
-        const int PH = c.oh + c.kh - 1, PW = c.ow + c.kw - 1;
-        b += ss_align_up((size_t)c.n * PH * PW * c.cin * sizeof(float), 256);
-    }
-    return b;
+    // [transposed weights][padded gradient (reflect)][two-stage scratch of the gather conv (Cin == 1 stems)]
+    return bwd_data_wt_bytes(c) + bwd_data_dpad_bytes(c) + two_stage_ws(c.n, c.oh, c.ow, c.cout, c.cin, c.kh * c.kw);
 }
 
 // dx = dC/dx for the plain conv `c`; bias/act only used when this implements a transposed-conv forward
@@ -146,6 +278,8 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     if (ws_bytes < bwd_data_ws(c) || !ws) return SS_ERR_WORKSPACE;
     float* wt = (float*)ws;
     const int T = c.kh * c.kw;
+    void* gws = (char*)ws + bwd_data_wt_bytes(c) + bwd_data_dpad_bytes(c);
+    const size_t gws_bytes = ws_bytes - bwd_data_wt_bytes(c) - bwd_data_dpad_bytes(c);
     hipLaunchKernelGGL(transpose_last2_kernel, dim3((c.cout + 31) / 32, (c.cin + 31) / 32, T), dim3(256), 0, s, w, wt, c.cin, c.cout);
     SS_LAUNCH_CHECK();
 
@@ -156,7 +290,7 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
 
     if (c.reflect) {
         const int PH = c.oh + c.kh - 1, PW = c.ow + c.kw - 1;
-        float* dpad = (float*)((char*)ws + ss_align_up((size_t)T * c.cin * c.cout * sizeof(float), 256));
+        float* dpad = (float*)((char*)ws + bwd_data_wt_bytes(c));
         p.out = dpad; p.OH = PH; p.OW = PW; p.out_cs = c.cin; p.OHc = PH; p.OWc = PW;
         p.out_s = 1; p.out_oy = 0; p.out_ox = 0; p.in_oy = 0; p.in_ox = 0; p.accumulate = 0;
         p.ntaps = 0;
@@ -165,7 +299,7 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
                 GTap& t = p.taps[p.ntaps++];
                 t.dy = (int16_t)(-a); t.dx = (int16_t)(-b); t.woff = (a * c.kw + b) * c.cin * c.cout;
             }
-        int rc = run_gconv(algo, p, s);
+        int rc = run_gconv(algo, p, gws, gws_bytes, s);
         if (rc != SS_OK) return rc;
         const long total = (long)c.n * c.ih * c.iw * c.cin;
         hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpad, dx,
@@ -193,10 +327,14 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
                     t.woff = (a * c.kw + b) * c.cin * c.cout;
                 }
             }
-            int rc = run_gconv(algo, p, s);
+            int rc = run_gconv(algo, p, gws, gws_bytes, s);
             if (rc != SS_OK) return rc;
         }
     return SS_OK;
+}
+
+bool wgrad_two_stage(const ConvProb& c, int algo) {
+    return algo != SS_ALGO_DIRECT && c.cout == 1 && c.kh * c.kw >= 4 && c.cin >= 16;
 }
 
 size_t bwd_weight_ws(const ConvProb& c) {
@@ -205,6 +343,13 @@ size_t bwd_weight_ws(const ConvProb& c) {
     const int M = c.kh * c.kw * c.cin;
     const int splits = ss_wgrad_mfma_splits(P, M, c.cout, &pps);
     size_t b = ss_align_up((size_t)splits * M * c.cout * sizeof(float), 256);
+    if (wgrad_two_stage(c, SS_ALGO_AUTO)) {
+        const int tcs = round4(c.kh * c.kw);
+        const long Q = (long)c.n * c.ih * c.iw;
+        const int sp2 = ss_wgrad_mfma_splits(Q, tcs, c.cin, &pps);
+        const size_t b2 = ss_align_up((size_t)Q * tcs * sizeof(float), 256) + ss_align_up((size_t)sp2 * tcs * c.cin * sizeof(float), 256);
+        if (b2 > b) b = b2;
+    }
     b += ss_align_up((size_t)COLSUM_CHUNKS * (c.cout > c.cin ? c.cout : c.cin) * sizeof(float), 256);
     return b;
 }
@@ -229,6 +374,24 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
         return ss_launch_wgrad_direct(p, dw, c.cout, accumulate, s);
     }
     int pps;
+    if (wgrad_two_stage(c, algo)) {
+        // U[q][t] (tap scatter of the one-channel dy), then dw[t][ci] = sum_q U[q][t] * x[q][ci]
+        const int tcs = round4(p.ntaps);
+        const long Q = (long)c.n * c.ih * c.iw;
+        float* U = (float*)ws;
+        hipLaunchKernelGGL(tapscatter_kernel, dim3((unsigned)((Q * tcs + 255) / 256)), dim3(256), 0, s, p, U, tcs);
+        SS_LAUNCH_CHECK();
+        WGradParams q{};
+        q.a = U; q.b = x; q.part = (float*)((char*)ws + ss_align_up((size_t)Q * tcs * sizeof(float), 256));
+        q.N = c.n; q.AH = c.ih; q.AW = c.iw; q.Ca = tcs; q.a_cs = tcs;
+        q.GH = c.ih; q.GW = c.iw; q.Cb = c.cin; q.b_cs = c.in_cs;
+        q.a_s = 1; q.a_oy = 0; q.a_ox = 0; q.reflect = 0;
+        q.ntaps = 1; q.taps[0].dy = 0; q.taps[0].dx = 0; q.taps[0].woff = 0;
+        q.splits = ss_wgrad_mfma_splits(Q, tcs, c.cin, &pps);
+        q.pix_per_split = pps;
+        // rows t >= ntaps of U are zero and land beyond the kh*kw*cin weights: mask them by shrinking Ca in the reduce
+        return ss_launch_wgrad_mfma_rows(q, dw, c.cin, accumulate, p.ntaps, s);
+    }
     p.splits = ss_wgrad_mfma_splits((long)c.n * c.oh * c.ow, p.ntaps * p.Ca, p.Cb, &pps);
     p.pix_per_split = pps;
     return ss_launch_wgrad_mfma(p, dw, c.cout, accumulate, s);
@@ -275,12 +438,12 @@ size_t ss_conv2d_workspace_bytes(const ss_conv_desc* d, int pass) {
     if (!valid_desc(d)) return 0;
     const size_t colsum_b = ss_align_up((size_t)COLSUM_CHUNKS * (d->cout > d->cin ? d->cout : d->cin) * sizeof(float), 256);
     if (!d->transposed) {
-        if (pass == SS_PASS_FWD) return 256;
+        if (pass == SS_PASS_FWD) return fwd_ws(plain(d), d->algo);
         if (pass == SS_PASS_BWD_DATA) return bwd_data_ws(plain(d));
         return bwd_weight_ws(plain(d)) + colsum_b;
     }
     if (pass == SS_PASS_FWD) return bwd_data_ws(adjoint(d));
-    if (pass == SS_PASS_BWD_DATA) return 256;
+    if (pass == SS_PASS_BWD_DATA) return fwd_ws(adjoint(d), d->algo);
     return bwd_weight_ws(adjoint(d)) + colsum_b;
 }
 
@@ -288,7 +451,7 @@ int ss_conv2d_fwd(const ss_conv_desc* d, const float* x, const float* w, const f
                   void* ws, size_t ws_bytes, void* stream) {
     if (!valid_desc(d) || !x || !w || !y) return SS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (!d->transposed) return conv_fwd(plain(d), x, w, bias, y, d->act, d->act_alpha, 0, d->algo, s);
+    if (!d->transposed) return conv_fwd(plain(d), x, w, bias, y, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
     return conv_bwd_data(adjoint(d), x, w, y, bias, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
 }
 
@@ -298,7 +461,7 @@ int ss_conv2d_bwd_data(const ss_conv_desc* d, const float* dy, const float* w, f
     hipStream_t s = (hipStream_t)stream;
     if (!d->transposed)
         return conv_bwd_data(plain(d), dy, w, dx, nullptr, SS_ACT_NONE, 0.f, accumulate, d->algo, ws, ws_bytes, s);
-    return conv_fwd(adjoint(d), dy, w, nullptr, dx, SS_ACT_NONE, 0.f, accumulate, d->algo, s);
+    return conv_fwd(adjoint(d), dy, w, nullptr, dx, SS_ACT_NONE, 0.f, accumulate, d->algo, ws, ws_bytes, s);
 }
 
 int ss_conv2d_bwd_weight(const ss_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,

@@ -422,10 +422,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
 }
 
 // dw[woff_t + ca*ldw + cb] (+)= sum_split part[split][(t,ca)][cb]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WGradParams p, float* dw, int ldw, int accumulate) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WGradParams p, float* dw, int ldw, int accumulate, int rows) {
     const long total = (long)p.ntaps * p.Ca * p.Cb;
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
+    if (e >= (long)rows * p.Cb) return;
     const int cb = (int)(e % p.Cb);
     const long m = e / p.Cb;
     const int t = (int)(m / p.Ca);
@@ -467,6 +467,10 @@ static int launch_wgrad(const WGradParams& p, int vecA, int vecB, hipStream_t s)
 }
 
 int ss_launch_wgrad_mfma(const WGradParams& p, float* dw, int ldw, int accumulate, hipStream_t s) {
+    return ss_launch_wgrad_mfma_rows(p, dw, ldw, accumulate, p.ntaps * p.Ca, s);
+}
+
+int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accumulate, int rows, hipStream_t s) {
     const long P = (long)p.N * p.GH * p.GW;
     const long total = (long)p.ntaps * p.Ca * p.Cb;
     if (total == 0) return SS_OK;
@@ -479,7 +483,7 @@ int ss_launch_wgrad_mfma(const WGradParams& p, float* dw, int ldw, int accumulat
         else rc = launch_wgrad<128, 32>(p, vecA, vecB, s);
         if (rc != SS_OK) return rc;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, dw, ldw, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, dw, ldw, accumulate, rows);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -36,6 +36,36 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class KernelTimer:
+    """HIP-event timing of tagged kernel launches on the current stream (bench.py roofline leg)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = []
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, e0, tag):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.events.append((tag, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, e0, e1 in self.events:
+            n, tot = out.get(tag, (0, 0.0))
+            out[tag] = (n + 1, tot + e0.elapsed_time(e1))
+        self.events = []
+        return {k: {"launches": n, "avg_ms": tot / n} for k, (n, tot) in out.items()}
+
+
+TIMER = KernelTimer()
+
+
 class Act:
     """An NHWC activation view: channels [c0, c0+c) of a base tensor [n,h,w,cs]."""
 

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .engine import Act, _p, _stream, workspace
+from .engine import TIMER, Act, _p, _stream, workspace
 
 ACTS = {None: L.ACT_NONE, "relu": L.ACT_RELU, "lrelu": L.ACT_LRELU, "tanh": L.ACT_TANH, "sigmoid": L.ACT_SIGMOID}
 
@@ -37,6 +37,7 @@ class Conv2D:
         if use_bias:
             arena.declare(f"{name}/bias", (cout,))
         self._desc_cache = {}
+        self.profile_tag = None     # set by bench.py to time this layer's forward launch with HIP events
 
     def out_hw(self, h, w):
         k, s = self.k, self.stride
@@ -81,8 +82,11 @@ class Conv2D:
         b = self.arena[f"{self.name}/bias"] if self.use_bias else None
         nb = lib.ss_conv2d_workspace_bytes(ctypes.byref(d), L.PASS_FWD)
         ws = workspace(nb, x.device)
+        e0 = TIMER.start() if (TIMER.enabled and self.profile_tag) else None
         L.check(lib.ss_conv2d_fwd(ctypes.byref(d), x.ptr, _p(w), _p(b), y.ptr, _p(ws), ws.numel(), _stream()),
                 f"conv2d_fwd[{self.name}]")
+        if e0 is not None:
+            TIMER.stop(e0, self.profile_tag)
         param_grads = tape.param_grads
 
         def backward():

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one "step" = one CycleGAN train_step + one MultiResUNet train_step over the same
+global batch of synthetic SEM tiles (BASELINE.json metric: train_step tiles/sec, CycleGAN+UNet, 512x512 bs=8).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     -- dominant kernel (fp32 MFMA implicit-GEMM of the 3x3 512->512 trunk convolution), algorithmic
+                  FLOPs per launch / HIP-event launch duration measured inside the timed region;
+  cpu_baseline -- the oracle (plain-torch CPU restatement of the same two steps) timed on the host cores on a
+                  bounded sample (rank 0, N=1 only).  Reported baseline only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+PKG = "automatic-sem-image-segmentation_amd"
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+G_FWD_GF = {256: 102.29, 384: 230.15, 512: 409.16, 1024: 1636.65}
+D_FWD_GF = {256: 7.88, 384: 18.32, 512: 33.09, 1024: 135.56}
+U_FWD_GF = {256: 10.56, 384: 23.76, 512: 42.24, 1024: 168.94}
+
+
+def synthetic_tiles(n, size, seed):
+    """SEM-like real_a (mean ~0.13, smooth noise) and mask-like real_b (~10 % discs), NHWC in [-1,1]."""
+    g = torch.Generator().manual_seed(seed)
+    noise = torch.randn((n, 1, size + 8, size + 8), generator=g)
+    smooth = torch.nn.functional.avg_pool2d(noise, 9, stride=1) * 3.0      # box blur 9x9, renormalised to ~N(0,1)
+    real_a = (0.13 + 0.18 * smooth).clamp(0, 1) * 2 - 1
+    yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+    real_b = torch.full((n, 1, size, size), -1.0)
+    n_discs = max(int(0.10 * size * size / (3.14159 * 8 * 8)), 1)
+    for i in range(n):
+        cy = torch.randint(0, size, (n_discs,), generator=g)
+        cx = torch.randint(0, size, (n_discs,), generator=g)
+        r = torch.randint(4, 12, (n_discs,), generator=g)
+        for k in range(n_discs):
+            real_b[i, 0][(yy - cy[k]) ** 2 + (xx - cx[k]) ** 2 <= r[k] ** 2] = 1.0
+    return real_a.permute(0, 2, 3, 1).contiguous(), real_b.permute(0, 2, 3, 1).contiguous()
+
+
+def cpu_baseline(size, batch, filters, threads):
+    """Oracle CycleGAN step + UNet step on the host, one step, bounded sample."""
+    from oracle import nets as ON
+    from oracle import steps as OS
+    torch.set_num_threads(threads)
+    a, b = synthetic_tiles(batch, size, 4321)
+    cg = OS.CycleGanStep(ON.ResnetGenerator(filters, seed=1), ON.ResnetGenerator(filters, seed=2),
+                         ON.PatchDiscriminator(2 * filters, seed=3), ON.PatchDiscriminator(2 * filters, seed=4),
+                         OS.ImagePool(2, 50), OS.ImagePool(2, 50))
+    un = OS.UNetStep(ON.MultiResUNet(16, seed=5), 9.0)
+    t0 = time.perf_counter()
+    cg.train_step((a, b))
+    t1 = time.perf_counter()
+    un.train_step(((a + 1) / 2, (b + 1) / 2))
+    t2 = time.perf_counter()
+    return {"value": batch / (t2 - t0), "unit": "tiles/s", "cores": threads, "kind": "port",
+            "sample": f"1 step of the oracle (torch CPU fp32) CycleGAN+UNet train steps on {batch} synthetic {size}x{size} tile(s), "
+                      f"filters={filters}; cyclegan {t1 - t0:.1f}s + unet {t2 - t1:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--global-batch", type=int, default=8)
+    ap.add_argument("--filters", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-size", type=int, default=512)
+    ap.add_argument("--cpu-sample-batch", type=int, default=1)
+    ap.add_argument("--skip-unet", action="store_true", help="diagnostics only: time the CycleGAN step alone")
+    args = ap.parse_args()
+
+    D = importlib.import_module(PKG + ".dist")
+    D.init_from_env()
+    rank, world = D.rank(), D.world_size()
+    assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
+    dev = D.local_device()
+    torch.cuda.set_device(dev)
+    E = importlib.import_module(PKG + ".engine")
+    CG = importlib.import_module(PKG + ".CycleGAN")
+    UN = importlib.import_module(PKG + ".UNet_Segmentation")
+    NETS = importlib.import_module(PKG + ".nets")
+    OPT = importlib.import_module(PKG + ".optim")
+
+    S, GB, F = args.size, args.global_batch, args.filters
+    assert GB % world == 0, "global batch must divide over the ranks"
+    per = GB // world
+
+    # networks exactly as CycleGAN.create_model / UNet.create_model build them for StartProcess.py's options
+    ga = NETS.ResnetGenerator(filters=F, device=dev, seed=1)
+    gb = NETS.ResnetGenerator(filters=F, device=dev, seed=2)
+    da = NETS.PatchDiscriminator(filters=2 * F, device=dev, seed=3)
+    db = NETS.PatchDiscriminator(filters=2 * F, device=dev, seed=4)
+    unet = NETS.MultiResUNet(16, device=dev, seed=5)
+    D.broadcast_params([ga, gb, da, db, unet])
+    model = CG.CycleGanModel(ga, gb, da, db, image_pool_a=CG.ImagePool(2, 50), image_pool_b=CG.ImagePool(2, 50))
+    model.compile(OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5))
+    umodel = UN.UNetModel(unet, 9.0, OPT.Adam(1e-3))
+    for g_ in (ga, gb):
+        for c0, _, c1, _ in g_.res:
+            c0.profile_tag = c1.profile_tag = "trunk_conv_fwd"
+
+    # synthetic tiles, resident in HBM before the timed region
+    a_all, b_all = synthetic_tiles(GB, S, 1234)
+    a = E.Act(a_all[rank * per:(rank + 1) * per].to(dev).contiguous(), requires_grad=False)
+    b = E.Act(b_all[rank * per:(rank + 1) * per].to(dev).contiguous(), requires_grad=False)
+    ux = E.Act(((a.t + 1) / 2).contiguous(), requires_grad=False)
+    uy = E.Act(((b.t + 1) / 2).contiguous(), requires_grad=False)
+
+    def step():
+        model.train_step((a, b))
+        if not args.skip_unet:
+            umodel.train_step((ux.t, uy.t))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    E.TIMER.enabled = True
+    t0 = time.perf_counter()
+    tcg = 0.0
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    E.TIMER.enabled = False
+    ksum = E.TIMER.summary()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = GB * args.steps / elapsed
+        out = {"metric": "train_step tiles/sec (CycleGAN+UNet)", "value": round(value, 4), "unit": "tiles/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"CycleGAN(2xResNet-9 gen F={F} + 2xPatchGAN, image buffer 50) train_step + MultiResUNet(16) "
+                                      f"train_step, {S}x{S} grayscale tiles, global batch {GB}" + (" [CycleGAN only]" if args.skip_unet else ""),
+                          "tile": S, "global_batch": GB, "per_gpu_batch": per, "parallelism": f"dp{world}"}}
+        tk = ksum.get("trunk_conv_fwd")
+        if tk:
+            flops = 2.0 * per * (S // 8) ** 2 * (8 * F) * (9 * 8 * F)      # one 3x3 (8F->8F) conv over per x (S/8)^2 pixels
+            ach = flops / (tk["avg_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "gconv_mfma_kernel<128,128> (fp32 32x32x2 MFMA; 3x3 trunk conv fwd, reflect pad fused)",
+                               "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                               "launches_timed": tk["launches"], "avg_launch_ms": round(tk["avg_ms"], 4),
+                               "flops_per_launch": flops}
+        if S in G_FWD_GF:
+            alg = (18 * G_FWD_GF[S] + 16 * D_FWD_GF[S] + (0 if args.skip_unet else 3 * U_FWD_GF[S])) * 1e9
+            out["step_algorithmic_tflops"] = round(alg * value / 1e12 / world, 2)   # per GPU, whole step incl. HBM-bound parts
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_size, args.cpu_sample_batch, F, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

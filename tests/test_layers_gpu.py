@@ -47,6 +47,12 @@ CONV_CASES = [
     ("unet_1x1", 1, 25, 16, 1, "same", False, None, False, 2, 16, 16),
     ("unet_first", 3, 1, 4, 1, "same", False, None, False, 2, 16, 16),
     ("wide", 3, 40, 200, 1, "same", False, None, False, 1, 12, 12),
+    # single-output-channel convs take the two-stage (1x1 MFMA GEMM + tap sum / tap scatter) path from 16 channels up
+    ("c7_out_16_two_stage", 7, 16, 1, 1, ("reflect", 3), True, "tanh", False, 2, 16, 16),
+    ("c7_in_16_two_stage_dgrad", 7, 1, 16, 1, ("reflect", 3), False, None, False, 2, 16, 16),
+    ("disc_in_16_two_stage_dgrad", 4, 1, 16, 2, "valid", True, "lrelu", False, 2, 32, 32),
+    ("disc_out_32_two_stage", 4, 32, 1, 1, "valid", True, None, False, 2, 7, 9),
+    ("head_same_two_stage", 3, 24, 1, 1, "same", False, None, False, 2, 10, 10),
 ]
 
 

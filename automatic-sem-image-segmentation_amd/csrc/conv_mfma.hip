@@ -14,6 +14,7 @@
 //     a permutation of the K order that A and B share (sums are order-independent up to rounding).
 //   B (k-major): lanes 0..31 read consecutive cout -> consecutive banks.
 #include "common.h"
+#include <stdlib.h>
 
 template <int BM_, int BN_>
 struct Cfg {
@@ -35,13 +36,17 @@ struct Cfg {
 };
 
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+// FAST: Cin % 32 == 0 (every K step lies inside one tap), float4-aligned operands.  The gather offsets of the
+// block's BM pixels for every tap are precomputed once into LDS (offtab), and the per-step global loads are
+// branch-free (clamped address + select) so that the compiler can interleave them with the MFMA stream.
+template <int BM, int BN, bool FAST>
 __global__ __launch_bounds__(256) void gconv_mfma_kernel(GConvParams p, int vecA, int vecB) {
     using C = Cfg<BM, BN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * BM * C::LDA;
     int* pixtab = (int*)(Bs + 2 * C::BK * C::LDB);
+    int* offtab = pixtab + BM;      // [BM][ntaps] element offsets of the gathered pixel, -1 = zero padding (FAST only)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -68,6 +73,24 @@ __global__ __launch_bounds__(256) void gconv_mfma_kernel(GConvParams p, int vecA
         }
         pixtab[tid] = v;
     }
+    if (FAST) {
+        for (int idx = tid; idx < BM * p.ntaps; idx += 256) {
+            const int row = idx / p.ntaps, t = idx - row * p.ntaps;
+            const long m = m0 + row;
+            int off = -1;
+            if (m < M) {
+                const int xc = (int)(m % p.OWc);
+                const long r = m / p.OWc;
+                const int yc = (int)(r % p.OHc);
+                const int n = (int)(r / p.OHc);
+                const int iy = ss_map_index(yc * p.in_s + p.in_oy + p.taps[t].dy, p.IH, p.reflect);
+                const int ix = ss_map_index(xc * p.in_s + p.in_ox + p.taps[t].dx, p.IW, p.reflect);
+                if (iy >= 0 && ix >= 0) off = ((n * p.IH + iy) * p.IW + ix) * p.in_cs;
+            }
+            offtab[idx] = off;
+        }
+        __syncthreads();
+    }
 
     // per-thread A rows: row = (tid>>3) + 32*j, float4 column c4a = tid&7
     const int c4a = tid & 7;
@@ -90,6 +113,28 @@ __global__ __launch_bounds__(256) void gconv_mfma_kernel(GConvParams p, int vecA
     f32x4 ra[C::A_UNITS], rb[C::B_UNITS];
 
     auto load_tiles = [&](int k0) {
+        if (FAST) {
+            const int t = k0 / p.Cin;                 // block-uniform
+            const int ci0 = k0 - t * p.Cin;
+            const float* abase = p.in + ci0 + c4a * 4;
+#pragma unroll
+            for (int j = 0; j < C::A_UNITS; ++j) {
+                const int off = offtab[((tid >> 3) + 32 * j) * p.ntaps + t];
+                const f32x4 v = *(const f32x4*)(abase + (off < 0 ? 0 : off));
+                ra[j] = off < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+            }
+            const float* bbase = p.w + p.taps[t].woff + (long)ci0 * p.ldb;
+#pragma unroll
+            for (int j = 0; j < C::B_UNITS; ++j) {
+                const int u = tid + 256 * j;
+                const int row = u / (BN / 4), c4 = u % (BN / 4);
+                const int col = n0 + c4 * 4;
+                const int colc = col + 4 <= p.Cout ? col : p.Cout - 4;
+                const f32x4 v = *(const f32x4*)(bbase + (long)row * p.ldb + colc);
+                rb[j] = col + 4 <= p.Cout ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            return;
+        }
         // ---- A: gathered activations ----
         const int k = k0 + c4a * 4;
         if (vecA) {
@@ -234,17 +279,18 @@ bool ss_gconv_mfma_ok(const GConvParams& p) {
     return p.Cout >= 8 && (long)p.ntaps * p.Cin >= 8;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool FAST>
 static int launch_gconv(const GConvParams& p, int vecA, int vecB, hipStream_t s) {
     using C = Cfg<BM, BN>;
     const long M = (long)p.N * p.OHc * p.OWc;
     dim3 grid((unsigned)((M + BM - 1) / BM), (p.Cout + BN - 1) / BN);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gconv_mfma_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem_gconv);
+        (void)hipFuncSetAttribute((const void*)gconv_mfma_kernel<BM, BN, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gconv_mfma_kernel<BM, BN>), grid, dim3(256), C::smem_gconv, s, p, vecA, vecB);
+    const size_t smem = C::smem_gconv + (FAST ? (size_t)BM * p.ntaps * sizeof(int) : 0);
+    hipLaunchKernelGGL((gconv_mfma_kernel<BM, BN, FAST>), grid, dim3(256), smem, s, p, vecA, vecB);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -255,13 +301,23 @@ int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
     const int vecA = (p.Cin % 4 == 0) && (p.in_cs % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
     int vecB = (p.ldb % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
     for (int t = 0; t < p.ntaps && vecB; ++t) vecB = (p.taps[t].woff % 4 == 0);
-    if (p.Cout > 64) return launch_gconv<128, 128>(p, vecA, vecB, s);
-    if (p.Cout > 32) return launch_gconv<128, 64>(p, vecA, vecB, s);
-    return launch_gconv<128, 32>(p, vecA, vecB, s);
+    const long in_elems = (long)p.N * p.IH * p.IW * p.in_cs;
+    const bool fast = vecA && vecB && p.ntaps >= 1 && (p.Cin % 32 == 0) && (p.Cout >= 4) && in_elems < (1L << 31) &&
+                      getenv("SS_GCONV_NOFAST") == nullptr;
+    if (fast) {
+        if (p.Cout > 64) return launch_gconv<128, 128, true>(p, vecA, vecB, s);
+        if (p.Cout > 32) return launch_gconv<128, 64, true>(p, vecA, vecB, s);
+        return launch_gconv<128, 32, true>(p, vecA, vecB, s);
+    }
+    if (p.Cout > 64) return launch_gconv<128, 128, false>(p, vecA, vecB, s);
+    if (p.Cout > 32) return launch_gconv<128, 64, false>(p, vecA, vecB, s);
+    return launch_gconv<128, 32, false>(p, vecA, vecB, s);
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+// FAST: float4-aligned operands, grid width >= 32: the pixel coordinates of this thread's rows advance
+// incrementally (no divisions in the loop) and all global loads are branch-free (clamped address + select).
+template <int BM, int BN, bool FAST>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA, int vecB) {
     using C = Cfg<BM, BN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -301,7 +357,49 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
 
     f32x4 ra[C::AT_UNITS], rb[C::B_UNITS];
 
+    // FAST state: decoded coordinates of the pixel each of this thread's A rows will load next
+    int f_n[C::AT_UNITS], f_y[C::AT_UNITS], f_x[C::AT_UNITS];
+    if (FAST) {
+#pragma unroll
+        for (int j = 0; j < C::AT_UNITS; ++j) {
+            const long pk = ps + (tid + 256 * j) / (BM / 4);
+            f_x[j] = (int)(pk % p.GW);
+            const long r = pk / p.GW;
+            f_y[j] = (int)(r % p.GH);
+            f_n[j] = (int)(r / p.GH);
+        }
+    }
+
     auto load_tiles = [&](long pk0) {
+        if (FAST) {
+            const bool mval = a_c[0] >= 0;
+#pragma unroll
+            for (int j = 0; j < C::AT_UNITS; ++j) {
+                const int row = (tid + 256 * j) / (BM / 4);
+                const int iy = ss_map_index(f_y[j] * p.a_s + p.a_oy + a_dy[0], p.AH, p.reflect);
+                const int ix = ss_map_index(f_x[j] * p.a_s + p.a_ox + a_dx[0], p.AW, p.reflect);
+                const bool ok = mval && (pk0 + row < pe) && iy >= 0 && ix >= 0;
+                const long off = ok ? ((long)(f_n[j] * p.AH + iy) * p.AW + ix) * p.a_cs + a_c[0] : 0;
+                const f32x4 v = *(const f32x4*)(p.a + off);
+                ra[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                // advance by one K step (32 pixels); GW >= 32 so at most one row wrap
+                int x = f_x[j] + C::BK, y = f_y[j], n = f_n[j];
+                if (x >= p.GW) { x -= p.GW; ++y; }
+                if (y >= p.GH) { y -= p.GH; ++n; }
+                f_x[j] = x; f_y[j] = y; f_n[j] = n;
+            }
+            const int col = n0 + c4b * 4;
+            const int colc = col + 4 <= p.Cb ? col : p.Cb - 4;
+#pragma unroll
+            for (int j = 0; j < C::B_UNITS; ++j) {
+                const int row = (tid + 256 * j) / (BN / 4);
+                const long pk = pk0 + row;
+                const bool ok = pk < pe && col + 4 <= p.Cb;
+                const f32x4 v = *(const f32x4*)(p.b + (ok ? pk : ps) * p.b_cs + colc);
+                rb[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < C::AT_UNITS; ++j) {
             const int row = (tid + 256 * j) / (BM / 4);
@@ -451,17 +549,17 @@ int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split) {
     return (int)splits;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool FAST>
 static int launch_wgrad(const WGradParams& p, int vecA, int vecB, hipStream_t s) {
     using C = Cfg<BM, BN>;
     const int M = p.ntaps * p.Ca;
     dim3 grid((M + BM - 1) / BM, (p.Cb + BN - 1) / BN, p.splits);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem_wgrad);
+        (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<BM, BN, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem_wgrad);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_mfma_kernel<BM, BN>), grid, dim3(256), C::smem_wgrad, s, p, vecA, vecB);
+    hipLaunchKernelGGL((wgrad_mfma_kernel<BM, BN, FAST>), grid, dim3(256), C::smem_wgrad, s, p, vecA, vecB);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -478,9 +576,14 @@ int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accu
         const int vecA = (p.Ca % 4 == 0) && (p.a_cs % 4 == 0) && (((uintptr_t)p.a & 15) == 0);
         const int vecB = (p.b_cs % 4 == 0) && (((uintptr_t)p.b & 15) == 0);
         int rc;
-        if (p.Cb > 64) rc = launch_wgrad<128, 128>(p, vecA, vecB, s);
-        else if (p.Cb > 32) rc = launch_wgrad<128, 64>(p, vecA, vecB, s);
-        else rc = launch_wgrad<128, 32>(p, vecA, vecB, s);
+        const bool fast = vecA && vecB && p.GW >= 32 && p.Cb >= 4 && p.pix_per_split % 32 == 0 && getenv("SS_GCONV_NOFAST") == nullptr;
+        if (fast) {
+            if (p.Cb > 64) rc = launch_wgrad<128, 128, true>(p, vecA, vecB, s);
+            else if (p.Cb > 32) rc = launch_wgrad<128, 64, true>(p, vecA, vecB, s);
+            else rc = launch_wgrad<128, 32, true>(p, vecA, vecB, s);
+        } else if (p.Cb > 64) rc = launch_wgrad<128, 128, false>(p, vecA, vecB, s);
+        else if (p.Cb > 32) rc = launch_wgrad<128, 64, false>(p, vecA, vecB, s);
+        else rc = launch_wgrad<128, 32, false>(p, vecA, vecB, s);
         if (rc != SS_OK) return rc;
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, dw, ldw, accumulate, rows);

@@ -47,6 +47,9 @@ CONV_CASES = [
     ("unet_1x1", 1, 25, 16, 1, "same", False, None, False, 2, 16, 16),
     ("unet_first", 3, 1, 4, 1, "same", False, None, False, 2, 16, 16),
     ("wide", 3, 40, 200, 1, "same", False, None, False, 1, 12, 12),
+    ("fast_paths_w40", 3, 32, 64, 1, ("reflect", 1), False, None, False, 2, 12, 40),
+    ("fast_paths_s2", 3, 32, 48, 2, "same", False, None, False, 2, 64, 72),
+    ("fast_paths_T", 3, 64, 32, 2, "same", False, None, True, 1, 32, 36),
     # single-output-channel convs take the two-stage (1x1 MFMA GEMM + tap sum / tap scatter) path from 16 channels up
     ("c7_out_16_two_stage", 7, 16, 1, 1, ("reflect", 3), True, "tanh", False, 2, 16, 16),
     ("c7_in_16_two_stage_dgrad", 7, 1, 16, 1, ("reflect", 3), False, None, False, 2, 16, 16),

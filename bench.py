@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-size", type=int, default=512)
     ap.add_argument("--cpu-sample-batch", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--skip-unet", action="store_true", help="diagnostics only: time the CycleGAN step alone")
     args = ap.parse_args()
 
@@ -170,7 +171,8 @@ def main():
             alg = (18 * G_FWD_GF[S] + 16 * D_FWD_GF[S] + (0 if args.skip_unet else 3 * U_FWD_GF[S])) * 1e9
             out["step_algorithmic_tflops"] = round(alg * value / 1e12 / world, 2)   # per GPU, whole step incl. HBM-bound parts
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_size, args.cpu_sample_batch, F, os.cpu_count() or 1)
+            # torch CPU convs on the 256-thread host get SLOWER beyond ~16 threads (measured: 256^2 tile 2.2 s @16, 3.0 s @32, 6.6 s @64)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_size, args.cpu_sample_batch, F, min(os.cpu_count() or 1, args.cpu_threads))
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -16,19 +16,20 @@
 #include "common.h"
 #include <stdlib.h>
 
-template <int BM_, int BN_>
+template <int BM_, int BN_, int NT_ = 256>
 struct Cfg {
-    static constexpr int BM = BM_, BN = BN_, BK = 32;
+    static constexpr int BM = BM_, BN = BN_, BK = 32, NT = NT_;
     static constexpr int WAVES_N = (BN >= 64) ? 2 : 1;
-    static constexpr int WAVES_M = 4 / WAVES_N;
+    static constexpr int WAVES_M = (NT / 64) / WAVES_N;
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     static constexpr int TM = WM / 32, TN = WN / 32;
     static constexpr int LDA = BK + 4;   // gconv A: [BM][LDA]
     static constexpr int LDB = BN + 4;   // B: [BK][LDB]
     static constexpr int LDAT = BM + 4;  // wgrad A: [BK][LDAT]
-    static constexpr int A_UNITS = BM * (BK / 4) / 256;
-    static constexpr int B_UNITS = BK * (BN / 4) / 256;
-    static constexpr int AT_UNITS = BK * (BM / 4) / 256;
+    static constexpr int A_UNITS = BM * (BK / 4) / NT;
+    static constexpr int B_UNITS = BK * (BN / 4) / NT;
+    static constexpr int AT_UNITS = BK * (BM / 4) / NT;
+    static constexpr int A_ROWS = NT / 8;     // pixel rows covered by one pass of the A loader
     static_assert(TM >= 1 && TN >= 1, "tile too small");
     static_assert(A_UNITS >= 1 && B_UNITS >= 1, "tile too small");
     static constexpr size_t smem_gconv = (2 * BM * LDA + 2 * BK * LDB) * sizeof(float) + BM * sizeof(int);
@@ -39,9 +40,9 @@ struct Cfg {
 // FAST: Cin % 32 == 0 (every K step lies inside one tap), float4-aligned operands.  The gather offsets of the
 // block's BM pixels for every tap are precomputed once into LDS (offtab), and the per-step global loads are
 // branch-free (clamped address + select) so that the compiler can interleave them with the MFMA stream.
-template <int BM, int BN, bool FAST>
-__global__ __launch_bounds__(256) void gconv_mfma_kernel(GConvParams p, int vecA, int vecB) {
-    using C = Cfg<BM, BN>;
+template <int BM, int BN, bool FAST, int NT>
+__global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA, int vecB) {
+    using C = Cfg<BM, BN, NT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * BM * C::LDA;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void gconv_mfma_kernel(GConvParams p, int vecA
         pixtab[tid] = v;
     }
     if (FAST) {
-        for (int idx = tid; idx < BM * p.ntaps; idx += 256) {
+        for (int idx = tid; idx < BM * p.ntaps; idx += NT) {
             const int row = idx / p.ntaps, t = idx - row * p.ntaps;
             const long m = m0 + row;
             int off = -1;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void gconv_mfma_kernel(GConvParams p, int vecA
     int a_nb[C::A_UNITS], a_by[C::A_UNITS], a_bx[C::A_UNITS];
 #pragma unroll
     for (int j = 0; j < C::A_UNITS; ++j) {
-        const long m = m0 + (tid >> 3) + 32 * j;
+        const long m = m0 + (tid >> 3) + C::A_ROWS * j;
         if (m < M) {
             const int xc = (int)(m % p.OWc);
             const long r = m / p.OWc;
@@ -119,14 +120,14 @@ __global__ __launch_bounds__(256) void gconv_mfma_kernel(GConvParams p, int vecA
             const float* abase = p.in + ci0 + c4a * 4;
 #pragma unroll
             for (int j = 0; j < C::A_UNITS; ++j) {
-                const int off = offtab[((tid >> 3) + 32 * j) * p.ntaps + t];
+                const int off = offtab[((tid >> 3) + C::A_ROWS * j) * p.ntaps + t];
                 const f32x4 v = *(const f32x4*)(abase + (off < 0 ? 0 : off));
                 ra[j] = off < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
             }
             const float* bbase = p.w + p.taps[t].woff + (long)ci0 * p.ldb;
 #pragma unroll
             for (int j = 0; j < C::B_UNITS; ++j) {
-                const int u = tid + 256 * j;
+                const int u = tid + NT * j;
                 const int row = u / (BN / 4), c4 = u % (BN / 4);
                 const int col = n0 + c4 * 4;
                 const int colc = col + 4 <= p.Cout ? col : p.Cout - 4;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void gconv_mfma_kernel(GConvParams p, int vecA
         // ---- B: weights ----
 #pragma unroll
         for (int j = 0; j < C::B_UNITS; ++j) {
-            const int u = tid + 256 * j;
+            const int u = tid + NT * j;
             const int row = u / (BN / 4), c4 = u % (BN / 4);
             const int kb = k0 + row;
             const int col = n0 + c4 * 4;
@@ -204,10 +205,10 @@ __global__ __launch_bounds__(256) void gconv_mfma_kernel(GConvParams p, int vecA
         float* Bb = Bs + buf * C::BK * C::LDB;
 #pragma unroll
         for (int j = 0; j < C::A_UNITS; ++j)
-            *(f32x4*)(Ab + ((tid >> 3) + 32 * j) * C::LDA + c4a * 4) = ra[j];
+            *(f32x4*)(Ab + ((tid >> 3) + C::A_ROWS * j) * C::LDA + c4a * 4) = ra[j];
 #pragma unroll
         for (int j = 0; j < C::B_UNITS; ++j) {
-            const int u = tid + 256 * j;
+            const int u = tid + NT * j;
             const int row = u / (BN / 4), c4 = u % (BN / 4);
             *(f32x4*)(Bb + row * C::LDB + c4 * 4) = rb[j];
         }
@@ -279,18 +280,18 @@ bool ss_gconv_mfma_ok(const GConvParams& p) {
     return p.Cout >= 8 && (long)p.ntaps * p.Cin >= 8;
 }
 
-template <int BM, int BN, bool FAST>
+template <int BM, int BN, bool FAST, int NT = 256>
 static int launch_gconv(const GConvParams& p, int vecA, int vecB, hipStream_t s) {
-    using C = Cfg<BM, BN>;
+    using C = Cfg<BM, BN, NT>;
     const long M = (long)p.N * p.OHc * p.OWc;
     dim3 grid((unsigned)((M + BM - 1) / BM), (p.Cout + BN - 1) / BN);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gconv_mfma_kernel<BM, BN, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gconv_mfma_kernel<BM, BN, FAST, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const size_t smem = C::smem_gconv + (FAST ? (size_t)BM * p.ntaps * sizeof(int) : 0);
-    hipLaunchKernelGGL((gconv_mfma_kernel<BM, BN, FAST>), grid, dim3(256), smem, s, p, vecA, vecB);
+    hipLaunchKernelGGL((gconv_mfma_kernel<BM, BN, FAST, NT>), grid, dim3(NT), smem, s, p, vecA, vecB);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -305,7 +306,11 @@ int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
     const bool fast = vecA && vecB && p.ntaps >= 1 && (p.Cin % 32 == 0) && (p.Cout >= 4) && in_elems < (1L << 31) &&
                       getenv("SS_GCONV_NOFAST") == nullptr;
     if (fast) {
-        if (p.Cout > 64) return launch_gconv<128, 128, true>(p, vecA, vecB, s);
+        if (p.Cout > 64) {
+            static const bool nt512 = getenv("SS_GCONV_NT512") != nullptr;
+            if (nt512) return launch_gconv<128, 128, true, 512>(p, vecA, vecB, s);
+            return launch_gconv<128, 128, true>(p, vecA, vecB, s);
+        }
         if (p.Cout > 32) return launch_gconv<128, 64, true>(p, vecA, vecB, s);
         return launch_gconv<128, 32, true>(p, vecA, vecB, s);
     }

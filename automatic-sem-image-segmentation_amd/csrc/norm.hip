@@ -5,27 +5,30 @@
 // Statistics: per-thread fp32 partial sums over a pixel chunk, wave/LDS reduction over the pixel lanes,
 // per-chunk partials in the workspace, fp64 combine in the finalize kernel.
 #include "common.h"
+#include <initializer_list>
 
 namespace {
 
 constexpr int NORM_MAX_CHUNKS = 128;
 
 struct NormGeom {
-    int G, C, CT, PT, chunks;   // CT channel lanes (pow2 <= 64), PT = 256/CT pixel lanes
+    int G, C, CT, PT, chunks, cblocks;   // CT channel lanes (pow2 <= 64, each V channels wide), PT = 256/CT pixel lanes
     long P, pix_per_chunk;
 };
 
-NormGeom geom(const ss_norm_desc* d) {
+NormGeom geom(const ss_norm_desc* d, int V = 1) {
     NormGeom g;
     g.G = d->groups;
     g.C = d->c;
     g.P = (long)d->n * d->h * d->w / d->groups;
+    const int cv = (d->c + V - 1) / V;
     int ct = 1;
-    while (ct < d->c && ct < 64) ct <<= 1;
+    while (ct < cv && ct < 64) ct <<= 1;
     g.CT = ct;
     g.PT = 256 / ct;
-    long chunks = (g.P + 1023) / 1024;
-    long want = 2048 / ((long)g.G * ((g.C + ct - 1) / ct));   // aim at >= ~2048 blocks in total
+    g.cblocks = (cv + ct - 1) / ct;
+    long chunks = (g.P + 511) / 512;
+    long want = 4096 / ((long)g.G * g.cblocks);   // aim at >= ~4096 blocks in total
     if (want < 1) want = 1;
     if (chunks > want) chunks = want;
     if (chunks > NORM_MAX_CHUNKS) chunks = NORM_MAX_CHUNKS;
@@ -35,9 +38,20 @@ NormGeom geom(const ss_norm_desc* d) {
     return g;
 }
 
+// V-wide (1 or 4 channels per thread) global access helpers
+template <int V> __device__ __forceinline__ void ldv(const float* p, float (&o)[V]) {
+    if (V == 4) { const f32x4 t = *(const f32x4*)p; o[0] = t[0]; o[1 % V] = t[1]; o[2 % V] = t[2]; o[3 % V] = t[3]; }
+    else o[0] = *p;
+}
+template <int V> __device__ __forceinline__ void stv(float* p, const float (&o)[V]) {
+    if (V == 4) { f32x4 t = {o[0], o[1 % V], o[2 % V], o[3 % V]}; *(f32x4*)p = t; }
+    else *p = o[0];
+}
+
 // partial sums: part[((g*chunks + chunk)*C + c)*2 + {0,1}]
 // MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat) with g = dy * act'(y)
-template <int MODE>
+// Thread = V consecutive channels x a strided set of pixels; CT = channel lanes (in units of V), PT = 256/CT.
+template <int MODE, int V>
 __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, int x_cs,
                                                          const float* __restrict__ dy, int dy_cs,
                                                          const float* __restrict__ y, int y_cs,
@@ -45,44 +59,56 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
                                                          int act, float alpha,
                                                          int C, long P, long pix_per_chunk, int CT, int PT,
                                                          float* __restrict__ part) {
-    __shared__ float red[2][256];
+    __shared__ float red[2 * V][256];
     const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
-    const int c = blockIdx.y * CT + ct;
+    const int c = (blockIdx.y * CT + ct) * V;
     const int g = blockIdx.z;
     const long p0 = (long)blockIdx.x * pix_per_chunk;
     const long p1 = (p0 + pix_per_chunk < P) ? p0 + pix_per_chunk : P;
-    float s1 = 0.f, s2 = 0.f;
+    float s1[V], s2[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { s1[v] = 0.f; s2[v] = 0.f; }
     if (c < C) {
         const long base = (long)g * P;
-        float mu = 0.f, rs = 0.f;
-        if (MODE == 1) { mu = mean[(long)g * C + c]; rs = rstd[(long)g * C + c]; }
+        float mu[V], rs[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) { mu[v] = 0.f; rs[v] = 0.f; }
+        if (MODE == 1) { ldv<V>(mean + (long)g * C + c, mu); ldv<V>(rstd + (long)g * C + c, rs); }
+#pragma unroll 2
         for (long p = p0 + pt; p < p1; p += PT) {
-            const float xv = x[(base + p) * x_cs + c];
+            float xv[V];
+            ldv<V>(x + (base + p) * x_cs + c, xv);
             if (MODE == 0) {
-                s1 += xv;
-                s2 = fmaf(xv, xv, s2);
+#pragma unroll
+                for (int v = 0; v < V; ++v) { s1[v] += xv[v]; s2[v] = fmaf(xv[v], xv[v], s2[v]); }
             } else {
-                float gv = dy[(base + p) * dy_cs + c];
-                if (act != SS_ACT_NONE) gv *= ss_act_grad_from_out(y[(base + p) * y_cs + c], act, alpha);
-                s1 += gv;
-                s2 = fmaf(gv, (xv - mu) * rs, s2);
+                float gv[V];
+                ldv<V>(dy + (base + p) * dy_cs + c, gv);
+                if (act != SS_ACT_NONE) {
+                    float yv[V];
+                    ldv<V>(y + (base + p) * y_cs + c, yv);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out(yv[v], act, alpha);
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v) { s1[v] += gv[v]; s2[v] = fmaf(gv[v], (xv[v] - mu[v]) * rs[v], s2[v]); }
             }
         }
     }
-    red[0][threadIdx.x] = s1;
-    red[1][threadIdx.x] = s2;
+#pragma unroll
+    for (int v = 0; v < V; ++v) { red[2 * v][threadIdx.x] = s1[v]; red[2 * v + 1][threadIdx.x] = s2[v]; }
     __syncthreads();
     for (int off = PT / 2; off >= 1; off >>= 1) {
         if (pt < off) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + off * CT];
-            red[1][threadIdx.x] += red[1][threadIdx.x + off * CT];
+#pragma unroll
+            for (int k = 0; k < 2 * V; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off * CT];
         }
         __syncthreads();
     }
     if (pt == 0 && c < C) {
         float* o = part + (((long)g * gridDim.x + blockIdx.x) * C + c) * 2;
-        o[0] = red[0][threadIdx.x];
-        o[1] = red[1][threadIdx.x];
+#pragma unroll
+        for (int v = 0; v < V; ++v) { o[2 * v] = red[2 * v][threadIdx.x]; o[2 * v + 1] = red[2 * v + 1][threadIdx.x]; }
     }
 }
 
@@ -110,22 +136,35 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd(const float* __restrict
     }
 }
 
-// y = act((x-mean)*rstd*gamma + beta + residual)
+// y = act((x-mean)*rstd*gamma + beta + residual); one thread = V channels of one pixel, grid-stride
+template <int V>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, int x_cs,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ res, int res_cs,
                                                          float* __restrict__ y, int y_cs,
                                                          int act, float alpha, int C, long P, long rows) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= rows * C) return;
-    const int c = (int)(e % C);
-    const long row = e / C;
-    const long gi = (row / P) * C + c;
-    const float sc = rstd[gi] * (gamma ? gamma[c] : 1.f);
-    float v = (x[row * x_cs + c] - mean[gi]) * sc + beta[c];
-    if (res) v += res[row * res_cs + c];
-    y[row * y_cs + c] = ss_apply_act(v, act, alpha);
+    const int CV = C / V;
+    const long total = rows * CV;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % CV) * V;
+        const long row = e / CV;
+        const long gi = (row / P) * C + c;
+        float xv[V], mu[V], rs[V], bt[V], gm[V], rv[V], o[V];
+        ldv<V>(x + row * x_cs + c, xv);
+        ldv<V>(mean + gi, mu);
+        ldv<V>(rstd + gi, rs);
+        ldv<V>(beta + c, bt);
+        if (gamma) ldv<V>(gamma + c, gm);
+        if (res) ldv<V>(res + row * res_cs + c, rv);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float t = (xv[v] - mu[v]) * (rs[v] * (gamma ? gm[v] : 1.f)) + bt[v];
+            if (res) t += rv[v];
+            o[v] = ss_apply_act(t, act, alpha);
+        }
+        stv<V>(y + row * y_cs + c, o);
+    }
 }
 
 // inference: statistics from moving mean / variance
@@ -168,6 +207,7 @@ __global__ __launch_bounds__(256) void norm_finalize_bwd(const float* __restrict
 }
 
 // dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) ; dres = g
+template <int V>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs,
                                                              const float* __restrict__ x, int x_cs,
                                                              const float* __restrict__ y, int y_cs,
@@ -177,23 +217,51 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              float* __restrict__ dx, int dx_cs, int acc_dx,
                                                              float* __restrict__ dres, int dres_cs, int acc_dres,
                                                              int act, float alpha, int C, long P, long rows) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= rows * C) return;
-    const int c = (int)(e % C);
-    const long row = e / C;
-    const long gi = (row / P) * C + c;
-    float gv = dy[row * dy_cs + c];
-    if (act != SS_ACT_NONE) gv *= ss_act_grad_from_out(y[row * y_cs + c], act, alpha);
-    const float rs = rstd[gi];
-    const float xh = (x[row * x_cs + c] - mean[gi]) * rs;
-    const float sc = rs * (gamma ? gamma[c] : 1.f);
-    const float dv = sc * (gv - sums[gi * 2] - xh * sums[gi * 2 + 1]);
-    float* o = dx + row * dx_cs + c;
-    *o = acc_dx ? (*o + dv) : dv;
-    if (dres) {
-        float* r = dres + row * dres_cs + c;
-        *r = acc_dres ? (*r + gv) : gv;
+    const int CV = C / V;
+    const long total = rows * CV;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % CV) * V;
+        const long row = e / CV;
+        const long gi = (row / P) * C + c;
+        float gv[V], xv[V], yv[V], mu[V], rs[V], gm[V], sm[2 * V], o[V], r[V];
+        ldv<V>(dy + row * dy_cs + c, gv);
+        ldv<V>(x + row * x_cs + c, xv);
+        ldv<V>(mean + gi, mu);
+        ldv<V>(rstd + gi, rs);
+        if (gamma) ldv<V>(gamma + c, gm);
+#pragma unroll
+        for (int v = 0; v < V; ++v) { sm[2 * v] = sums[(gi + v) * 2]; sm[2 * v + 1] = sums[(gi + v) * 2 + 1]; }
+        if (act != SS_ACT_NONE) {
+            ldv<V>(y + row * y_cs + c, yv);
+#pragma unroll
+            for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out(yv[v], act, alpha);
+        }
+        if (acc_dx) ldv<V>(dx + row * dx_cs + c, o);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float xh = (xv[v] - mu[v]) * rs[v];
+            const float dv = rs[v] * (gamma ? gm[v] : 1.f) * (gv[v] - sm[2 * v] - xh * sm[2 * v + 1]);
+            o[v] = acc_dx ? o[v] + dv : dv;
+        }
+        stv<V>(dx + row * dx_cs + c, o);
+        if (dres) {
+            if (acc_dres) {
+                ldv<V>(dres + row * dres_cs + c, r);
+#pragma unroll
+                for (int v = 0; v < V; ++v) r[v] += gv[v];
+                stv<V>(dres + row * dres_cs + c, r);
+            } else {
+                stv<V>(dres + row * dres_cs + c, gv);
+            }
+        }
     }
+}
+
+inline bool al16(const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }
+inline unsigned apply_grid(long total) {
+    long b = (total + 255) / 256;
+    const long cap = 256L * 32;
+    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 bool valid(const ss_norm_desc* d) {
@@ -203,14 +271,25 @@ bool valid(const ss_norm_desc* d) {
     return true;
 }
 
+// vector width usable for this call: every view pointer 16-B aligned and every stride a multiple of 4
+int pick_v(int c, std::initializer_list<int> strides, std::initializer_list<const void*> ptrs) {
+    if (c % 4) return 1;
+    for (int st : strides) if (st % 4) return 1;
+    for (const void* q : ptrs) if (!al16(q)) return 1;
+    return 4;
+}
+
+size_t part_bytes(const ss_norm_desc* d) {
+    return ss_align_up((size_t)d->groups * NORM_MAX_CHUNKS * d->c * 2 * sizeof(float), 256);
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t ss_norm_workspace_bytes(const ss_norm_desc* d) {
     if (!valid(d)) return 0;
-    const NormGeom g = geom(d);
-    return ss_align_up((size_t)g.G * g.chunks * g.C * 2 * sizeof(float), 256) + ss_align_up((size_t)g.G * g.C * 2 * sizeof(float), 256);
+    return part_bytes(d) + ss_align_up((size_t)d->groups * d->c * 2 * sizeof(float), 256);
 }
 
 int ss_norm_fwd(const ss_norm_desc* d, const float* x, const float* gamma, const float* beta,
@@ -222,20 +301,29 @@ int ss_norm_fwd(const ss_norm_desc* d, const float* x, const float* gamma, const
     if (moving_mean && d->groups != 1) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_norm_workspace_bytes(d)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    const NormGeom g = geom(d);
+    const int V = pick_v(d->c, {d->x_cstride, d->y_cstride, residual ? d->res_cstride : 0},
+                         {x, y, residual, gamma, beta, mean, rstd});
+    const NormGeom g = geom(d, V);
     float* part = (float*)ws;
-    hipLaunchKernelGGL(norm_stats_kernel<0>, dim3(g.chunks, (g.C + g.CT - 1) / g.CT, g.G), dim3(256), 0, s,
-                       x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, 0.f,
-                       g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
+    const dim3 sgrid(g.chunks, g.cblocks, g.G);
+    if (V == 4)
+        hipLaunchKernelGGL((norm_stats_kernel<0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                           0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
+    else
+        hipLaunchKernelGGL((norm_stats_kernel<0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                           0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     SS_LAUNCH_CHECK();
     const long gc = (long)g.G * g.C;
     hipLaunchKernelGGL(norm_finalize_fwd, dim3((unsigned)((gc + 255) / 256)), dim3(256), 0, s,
                        part, g.chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
-    hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)((rows * g.C + 255) / 256)), dim3(256), 0, s,
-                       x, d->x_cstride, gamma, beta, mean, rstd, residual, d->res_cstride, y, d->y_cstride,
-                       d->act, d->act_alpha, g.C, g.P, rows);
+    if (V == 4)
+        hipLaunchKernelGGL(norm_apply_kernel<4>, dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
+    else
+        hipLaunchKernelGGL(norm_apply_kernel<1>, dim3(apply_grid(rows * g.C)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -260,20 +348,31 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
     if (d->act != SS_ACT_NONE && !y) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_norm_workspace_bytes(d)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    const NormGeom g = geom(d);
+    const int V = pick_v(d->c, {d->x_cstride, dy_cstride, dx_cstride, d->act != SS_ACT_NONE ? d->y_cstride : 0, dres ? d->res_cstride : 0},
+                         {x, dy, dx, d->act != SS_ACT_NONE ? y : nullptr, dres, gamma, mean, rstd});
+    const NormGeom g = geom(d, V);
     float* part = (float*)ws;
-    float* sums = (float*)((char*)ws + ss_align_up((size_t)g.G * g.chunks * g.C * 2 * sizeof(float), 256));
-    hipLaunchKernelGGL(norm_stats_kernel<1>, dim3(g.chunks, (g.C + g.CT - 1) / g.CT, g.G), dim3(256), 0, s,
-                       x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd, d->act, d->act_alpha,
-                       g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
+    float* sums = (float*)((char*)ws + part_bytes(d));
+    const dim3 sgrid(g.chunks, g.cblocks, g.G);
+    if (V == 4)
+        hipLaunchKernelGGL((norm_stats_kernel<1, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+                           d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
+    else
+        hipLaunchKernelGGL((norm_stats_kernel<1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+                           d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + 255) / 256), dim3(256), 0, s,
                        part, g.chunks, g.G, g.C, g.P, sums, dgamma, dbeta, accumulate_params);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3((unsigned)((rows * g.C + 255) / 256)), dim3(256), 0, s,
-                       dy, dy_cstride, x, d->x_cstride, y, d->y_cstride, gamma, mean, rstd, sums,
-                       dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres, d->act, d->act_alpha, g.C, g.P, rows);
+    if (V == 4)
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+                           gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
+                           d->act, d->act_alpha, g.C, g.P, rows);
+    else
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+                           gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
+                           d->act, d->act_alpha, g.C, g.P, rows);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -158,22 +158,35 @@ def test_cyclegan_train_step_vs_reference_goldens(golden_dir, fname):
 
 
 def test_unet_train_step_vs_oracle():
+    """Two UNet train steps.  The fp64 oracle arbitrates: the HIP result must be as close to it as the fp32 oracle is
+    (x3 + 1e-4) -- after Adam's sign-like first steps an absolute tolerance on weights would only measure how many
+    rounding-level gradients flipped sign."""
     UN, OPT, N = mod("UNet_Segmentation"), mod("optim"), mod("nets")
     gen = torch.Generator().manual_seed(3)
     ref = ON.MultiResUNet(16, seed=9)
+    ref64 = ON.MultiResUNet(16, seed=9, dtype=torch.float64)
+    ref64.set_weights(ref.get_weights())
     hip = N.MultiResUNet(16, device="cuda:0")
     hip.set_weights(ref.get_weights())
     model = UN.UNetModel(hip, 9.0, OPT.Adam(1e-3))
-    ostep = OS.UNetStep(ref, 9.0)
+    ostep, ostep64 = OS.UNetStep(ref, 9.0), OS.UNetStep(ref64, 9.0)
     for it in range(2):
         x = torch.rand((2, 64, 64, 1), generator=gen)
         y = (torch.rand((2, 64, 64, 1), generator=gen) > 0.9).float()
-        want, _ = ostep.train_step((x, y))
+        want, p_ref = ostep.train_step((x, y))
+        want64, p_ref64 = ostep64.train_step((x.double(), y.double()))
         got = model.train_step((x.numpy(), y.numpy()))
-        for k in ("loss", "mae", "acc"):
-            assert abs(got[k] - want[k]) <= 2e-4 * max(abs(want[k]), 1.0), (it, k, got[k], want[k])
-    for name, w, r in zip(hip.variable_names, hip.get_weights(), ref.get_weights()):
-        check_tensor(w, r, name, 2e-3, atol=2.5e-3)
+        # label map @0.5 (the 'acc' threshold): identical except on pixels whose oracle probability lies within the
+        # fp tolerance of the threshold (an untrained net sits near 0.5 everywhere); those are counted, not ignored
+        near = float(((p_ref64 - 0.5).abs() < 2e-3).double().mean())
+        for k in ("loss", "mae"):
+            noise = abs(want[k] - want64[k])
+            assert abs(got[k] - want64[k]) <= 2e-4 * max(abs(want64[k]), 1.0) + 3 * noise, (it, k, got[k], want[k], want64[k])
+        assert abs(got["acc"] - want64["acc"]) <= near + 1e-6, (it, got["acc"], want64["acc"], near)
     allg = np.concatenate([w.ravel() for w in hip.get_weights()])
-    allr = np.concatenate([w.ravel() for w in ref.get_weights()])
-    assert rel_l2(allg, allr) <= 2e-3
+    all32 = np.concatenate([w.ravel() for w in ref.get_weights()])
+    all64 = np.concatenate([w.ravel() for w in ref64.get_weights()])
+    e_hip, e_32 = rel_l2(allg, all64), rel_l2(all32, all64)
+    assert e_hip <= 3 * e_32 + 1e-4, (e_hip, e_32)
+    for name, w, r in zip(hip.variable_names, hip.get_weights(), ref64.get_weights()):
+        assert float(np.abs(w - r).max()) <= 2 * 2 * 1e-3 * 1.1 + 1e-6, name    # |step| <= ~lr per Adam step, 2 steps, both signs

@@ -305,18 +305,31 @@ int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
     const long in_elems = (long)p.N * p.IH * p.IW * p.in_cs;
     const bool fast = vecA && vecB && p.ntaps >= 1 && (p.Cin % 32 == 0) && (p.Cout >= 4) && in_elems < (1L << 31) &&
                       getenv("SS_GCONV_NOFAST") == nullptr;
+    // tile choice: the largest tile that still gives every CU ~2 workgroups (256 CUs); small batches need small tiles
+    auto nblocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
+    const long want = 480;
+    int cfg;   // 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32
+    if (p.Cout > 64) cfg = nblocks(128, 128) >= want ? 0 : (nblocks(128, 64) >= want ? 1 : 2);
+    else if (p.Cout > 32) cfg = nblocks(128, 64) >= want ? 1 : 2;
+    else cfg = 3;
     if (fast) {
-        if (p.Cout > 64) {
-            static const bool nt512 = getenv("SS_GCONV_NT512") != nullptr;
-            if (nt512) return launch_gconv<128, 128, true, 512>(p, vecA, vecB, s);
-            return launch_gconv<128, 128, true>(p, vecA, vecB, s);
+        switch (cfg) {
+            case 0: {
+                static const bool nt512 = getenv("SS_GCONV_NT512") != nullptr;
+                if (nt512) return launch_gconv<128, 128, true, 512>(p, vecA, vecB, s);
+                return launch_gconv<128, 128, true>(p, vecA, vecB, s);
+            }
+            case 1: return launch_gconv<128, 64, true>(p, vecA, vecB, s);
+            case 2: return launch_gconv<64, 64, true>(p, vecA, vecB, s);
+            default: return launch_gconv<128, 32, true>(p, vecA, vecB, s);
         }
-        if (p.Cout > 32) return launch_gconv<128, 64, true>(p, vecA, vecB, s);
-        return launch_gconv<128, 32, true>(p, vecA, vecB, s);
     }
-    if (p.Cout > 64) return launch_gconv<128, 128, false>(p, vecA, vecB, s);
-    if (p.Cout > 32) return launch_gconv<128, 64, false>(p, vecA, vecB, s);
-    return launch_gconv<128, 32, false>(p, vecA, vecB, s);
+    switch (cfg) {
+        case 0: return launch_gconv<128, 128, false>(p, vecA, vecB, s);
+        case 1: return launch_gconv<128, 64, false>(p, vecA, vecB, s);
+        case 2: return launch_gconv<64, 64, false>(p, vecA, vecB, s);
+        default: return launch_gconv<128, 32, false>(p, vecA, vecB, s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

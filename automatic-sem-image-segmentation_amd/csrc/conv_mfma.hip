@@ -55,8 +55,19 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
     const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
 
     const long M = (long)p.N * p.OHc * p.OWc;
-    const long m0 = (long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (speed only, never correctness).  Give each
+    // XCD a contiguous chunk of the tile space, N-tile fastest, so that the workgroups resident on one XCD share the
+    // same few activation rows (A) across their N-tiles and neighbouring M-tiles share halo rows in that XCD's L2.
+    const int gridN = (p.Cout + BN - 1) / BN;
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const long m0 = (long)(tile / gridN) * BM;
+    const int n0 = (tile % gridN) * BN;
     const int K = p.ntaps * p.Cin;
     const int nchunks = (K + C::BK - 1) / C::BK;
 
@@ -284,7 +295,7 @@ template <int BM, int BN, bool FAST, int NT = 256>
 static int launch_gconv(const GConvParams& p, int vecA, int vecB, hipStream_t s) {
     using C = Cfg<BM, BN, NT>;
     const long M = (long)p.N * p.OHc * p.OWc;
-    dim3 grid((unsigned)((M + BM - 1) / BM), (p.Cout + BN - 1) / BN);
+    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN)));
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gconv_mfma_kernel<BM, BN, FAST, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -164,7 +164,12 @@ def main():
             ach = flops / (tk["avg_ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "gconv_mfma_kernel<128,128> (fp32 32x32x2 MFMA; 3x3 trunk conv fwd, reflect pad fused)",
                                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                               # PMC cannot be sampled from inside this process: value of the committed rocprofv3 pass on this exact
+                               # kernel/shape at batch 8 (profiles/r01_pmc_trunk_fwd.md): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
+                               "traffic": (2 * 399.2e6 * 1.024 + 65536 * 1024) if (per == 8 and S == 512 and F == 64) else None,
+                               "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_trunk_fwd.md)",
+                               "algorithmic_bytes": 4.0 * (2 * per * (S // 8) ** 2 * 8 * F + 9 * (8 * F) ** 2),
                                "launches_timed": tk["launches"], "avg_launch_ms": round(tk["avg_ms"], 4),
                                "flops_per_launch": flops}
         if S in G_FWD_GF:

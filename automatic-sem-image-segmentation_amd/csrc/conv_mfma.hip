@@ -564,15 +564,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WGradParams p, float*
 }
 
 int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split) {
+    // Split the pixel (K) range so that tiles x splits fills whole "rounds" of the 512 workgroup slots
+    // (256 CUs x 2 resident workgroups): time ~ ceil(tiles*s/512) * K/s.  A partial last round costs a full K/s.
     const int bn = Cb > 64 ? 128 : (Cb > 32 ? 64 : 32);
     const long tiles = (long)((M + 127) / 128) * ((Cb + bn - 1) / bn);
-    long splits = (1024 + tiles - 1) / tiles;
-    const long max_splits = (pixels + 255) / 256;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    long pps = (pixels + splits - 1) / splits;
+    long max_splits = (pixels + 255) / 256;
+    if (max_splits > 64) max_splits = 64;
+    if (max_splits < 1) max_splits = 1;
+    long best = 1;
+    double best_cost = 1e30;
+    for (long sp = 1; sp <= max_splits; ++sp) {
+        const double rounds = (double)((tiles * sp + 511) / 512);
+        const double cost = rounds / (double)sp + 0.002 * sp;      // small penalty per split for the reduce pass
+        if (cost < best_cost - 1e-12) { best_cost = cost; best = sp; }
+    }
+    long pps = (pixels + best - 1) / best;
     pps = (pps + 31) / 32 * 32;
-    splits = (pixels + pps - 1) / pps;
+    long splits = (pixels + pps - 1) / pps;
     if (splits < 1) splits = 1;
     *pix_per_split = (int)pps;
     return (int)splits;

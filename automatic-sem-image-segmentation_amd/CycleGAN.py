@@ -17,6 +17,7 @@ Behavioural quirks kept on purpose (SURVEY.md "Three facts"):
   zeroing, CycleGAN.py:664-665): implemented as ONE backward of (L_a + L_b) -- same gradient, 6 generator
   backward traversals instead of 8.
 """
+import json
 import os
 import random
 import time
@@ -217,12 +218,36 @@ class CycleGanModel:
                                                       ("disc_a", self.disc_a), ("disc_b", self.disc_b))}
 
     def save(self, path):
+        """Weights under their Keras variable names + the constructor configuration (``<path>.npz``; the
+        reference writes a ``.keras`` zip with HDF5 weights)."""
         arrays = {}
         for nm, ws in self.get_weights().items():
             net = getattr(self, nm)
             for name, w in zip(net.variable_names, ws):
                 arrays[f"{nm}/{name}"] = w
+        cfg = dict(filters=self.gen_a.filters, nd=self.gen_a.nd, nr=self.gen_a.nr, nu=self.gen_a.nu,
+                   disc_filters=self.disc_a.filters, disc_nd=self.disc_a.nd,
+                   lambda_cycle_a=self.lambda_cycle_a, lambda_cycle_b=self.lambda_cycle_b,
+                   lambda_identity_a=self.lambda_identity_a, lambda_identity_b=self.lambda_identity_b)
+        arrays["__config__"] = np.array(json.dumps(cfg))
         np.savez(path if path.endswith(".npz") else path + ".npz", **arrays)
+
+    @classmethod
+    def load(cls, path, device=None):
+        """Counterpart of ``keras.models.load_model(.../model.keras)`` (CycleGAN.py:228-231)."""
+        z = np.load(path if path.endswith(".npz") else path + ".npz")
+        cfg = json.loads(str(z["__config__"]))
+        device = device if device is not None else D.local_device()
+        gk = dict(filters=cfg["filters"], num_downsampling_blocks=cfg["nd"], num_residual_blocks=cfg["nr"],
+                  num_upsample_blocks=cfg["nu"], device=device)
+        nets = dict(gen_a=ResnetGenerator(**gk), gen_b=ResnetGenerator(**gk),
+                    disc_a=PatchDiscriminator(filters=cfg["disc_filters"], num_downsampling_blocks=cfg["disc_nd"], device=device),
+                    disc_b=PatchDiscriminator(filters=cfg["disc_filters"], num_downsampling_blocks=cfg["disc_nd"], device=device))
+        for nm, net in nets.items():
+            net.set_weights([z[f"{nm}/{name}"] for name in net.variable_names])
+        return cls(nets["gen_a"], nets["gen_b"], nets["disc_a"], nets["disc_b"], lambda_cycle_a=cfg["lambda_cycle_a"],
+                   lambda_cycle_b=cfg["lambda_cycle_b"], lambda_identity_a=cfg["lambda_identity_a"],
+                   lambda_identity_b=cfg["lambda_identity_b"])
 
 
 class DataLoader:
@@ -357,6 +382,47 @@ class CycleGAN:
         if invert:
             images *= -1.0
         return images
+
+    def run_inference(self, files, output_directory, source_domain, model=None, tile_images=False, min_overlap=2,
+                      manage_overlap_mode=2, use_gpu=False):
+        """CycleGAN.py:224-286: translate every image of ``files`` with generator A (source 'A') or B, whole-image or
+        tiled+stitched, min-max to uint8, save under the input file name.  Always runs on the MI355X (``use_gpu`` is
+        accepted for signature compatibility; there is no CPU path)."""
+        from PIL import Image
+        from . import HelperFunctions
+        if self.model is None:
+            if model is None:
+                latest = sorted(os.listdir(self.model_dir))[-1]     # timestamp-named directories (CycleGAN.py:102,228)
+                self.model = CycleGanModel.load(os.path.join(self.model_dir, latest, 'model.keras'), self.device)
+            elif isinstance(model, str):
+                self.model = CycleGanModel.load(model, self.device)
+            else:
+                self.model = model
+        gen = self.model.gen_a if 'a' in source_domain.lower() else self.model.gen_b
+        input_files = HelperFunctions.load_and_preprocess_images(files, normalization_range=(-1, 1))
+        file_names = HelperFunctions.get_image_file_paths_from_directory(files) if isinstance(files, str) and os.path.isdir(files) \
+            else ([files] if isinstance(files, str) else list(files))
+        os.makedirs(output_directory, exist_ok=True)
+        for i in range(input_files.shape[0]):
+            input_file = input_files[i]
+            if 'a' in source_domain.lower() and self.invert_images:
+                input_file *= -1
+            if tile_images:
+                tiles = np.asarray(HelperFunctions.tile_image(input_file, self.image_shape[0], self.image_shape[1], min_overlap=min_overlap))
+                pred = np.asarray([CycleGanModel.to_numpy_array(gen(torch.from_numpy(t[None]).to(self.device), training=False))[0] for t in tiles])
+                img = HelperFunctions.stitch_image(pred, input_file.shape[1], input_file.shape[0], min_overlap=min_overlap,
+                                                   manage_overlap_mode=manage_overlap_mode)
+            else:
+                # the nets are shape-agnostic: no rebuild + set_weights as in CycleGAN.py:243-251
+                img = CycleGanModel.to_numpy_array(gen(torch.from_numpy(np.ascontiguousarray(input_file[None])).to(self.device), training=False))[0].copy()
+            img = img[:, :, 0]
+            if 'b' in source_domain.lower() and self.invert_images:
+                img *= -1
+            img -= np.min(img)
+            img /= np.max(img)
+            img *= 255
+            img = img.astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(output_directory, os.path.split(file_names[i])[-1]))
 
     def start_training(self):
         """Epoch loop equivalent to ``model.fit(DataLoader, epochs, callbacks)`` (CycleGAN.py:182-222): per-epoch metric

@@ -8,6 +8,7 @@ Reference surface mirrored here (file:line in the reference):
 * ``step_decay`` / ``linear_decay`` ................ UNet_Segmentation.py:233-244
 * the Keras default ``train_step`` + metrics (loss / mae / acc) that ``model.fit`` runs (third party in the reference).
 """
+import json
 import math
 import os
 import random
@@ -167,8 +168,18 @@ class UNetModel:
         self.net.set_weights(w)
 
     def save(self, path):
-        np.savez(path if path.endswith(".npz") else path + ".npz",
-                 **{name: w for name, w in zip(self.net.variable_names, self.net.get_weights())})
+        arrays = {name: w for name, w in zip(self.net.variable_names, self.net.get_weights())}
+        arrays["__config__"] = np.array(json.dumps(dict(filters=self.net.filters, weighting=self.weighting)))
+        np.savez(path if path.endswith(".npz") else path + ".npz", **arrays)
+
+    @classmethod
+    def load(cls, path, device=None):
+        """Counterpart of ``keras.models.load_model(.../model.keras, custom_objects={'weighted_bce': ...})`` (UNet_Segmentation.py:303)."""
+        z = np.load(path if path.endswith(".npz") else path + ".npz")
+        cfg = json.loads(str(z["__config__"]))
+        net = MultiResUNet(conv_filters=cfg["filters"], device=device if device is not None else D.local_device())
+        net.set_weights([z[name] for name in net.variable_names])
+        return cls(net, cfg.get("weighting", 1.0), Adam())
 
 
 class UNet:
@@ -234,6 +245,44 @@ class UNet:
         D.broadcast_params([net])
         wd = self.lr_decay if isinstance(self.lr_decay, float) else 0.0
         return UNetModel(net, weighting, Adam(learning_rate=self.learning_rate, weight_decay=wd))
+
+    def run_inference(self, files, output_directory, model=None, tile_images=False, threshold=-1, watershed_lines=True,
+                      min_distance=9, min_overlap=2, manage_overlap_mode=2, use_gpu=False):
+        """UNet_Segmentation.py:290-351: probabilities (``*_raw.tif``, float32) and the thresholded label map per image.
+        Runs on the MI355X in inference mode (BatchNorm moving statistics).  ``watershed_lines=True`` needs the
+        not-yet-built watershed (HelperFunctions.segment raises); pass False for Otsu/threshold label maps."""
+        from PIL import Image
+        if model is None and self.model is None:
+            latest = sorted(os.listdir(self.model_dir))[-1]
+            self.model = UNetModel.load(os.path.join(self.model_dir, latest, 'model.keras'), self.device)
+        elif isinstance(model, str):
+            self.model = UNetModel.load(model, self.device)
+        elif model is not None:
+            self.model = model
+        input_files = HelperFunctions.load_and_preprocess_images(files, normalization_range=(0, 1),
+                                                                 contrast_optimization_range=self.contrast_optimization_range)
+        file_names = HelperFunctions.get_image_file_paths_from_directory(files) if isinstance(files, str) and os.path.isdir(files) \
+            else ([files] if isinstance(files, str) else list(files))
+        os.makedirs(output_directory, exist_ok=True)
+        for i in range(input_files.shape[0]):
+            input_file = input_files[i]
+            if tile_images:
+                tiles = np.array(HelperFunctions.tile_image(input_file, self.image_shape[0], self.image_shape[1], min_overlap=min_overlap))
+                pred = np.array([self.model.predict(t[None])[0].cpu().numpy() for t in tiles])
+                img = HelperFunctions.stitch_image(pred, input_file.shape[1], input_file.shape[0], min_overlap=min_overlap,
+                                                   manage_overlap_mode=manage_overlap_mode)
+            else:
+                img = self.model.predict(np.ascontiguousarray(input_file[None]))[0].cpu().numpy().copy()
+            img = img[:, :, 0]
+            base = os.path.split(file_names[i])[-1]
+            Image.fromarray(img).save(os.path.join(output_directory, base.replace(os.path.splitext(base)[-1], '_raw.tif')))
+            img -= np.min(img)
+            img /= np.max(img)
+            img *= 255
+            img = img.astype(np.uint8)
+            img = HelperFunctions.segment(image=img, threshold=threshold, watershed_lines=watershed_lines, min_distance=min_distance,
+                                          use_four_connectivity=True)
+            Image.fromarray(img).save(os.path.join(output_directory, base))
 
     def run_training(self):
         """Equivalent of ``model.fit(training_data, epochs, callbacks, validation_data)`` (UNet_Segmentation.py:246-288)."""

@@ -82,6 +82,7 @@ class ResnetGenerator(Network):
         super().__init__(device)
         A = self.arena
         self.nd, self.nr, self.nu = num_downsampling_blocks, num_residual_blocks, num_upsample_blocks
+        self.filters = filters
         f = filters
         self.c7_in = Conv2D(A, "c7_in", 7, channels, f, padding=("reflect", 3), algo=algo)
         self.in_c7 = Norm(A, "c7_in", f, "instance")
@@ -128,6 +129,7 @@ class PatchDiscriminator(Network):
                  algo=L.ALGO_AUTO):
         super().__init__(device)
         A = self.arena
+        self.filters, self.nd = filters, num_downsampling_blocks
         f = filters
         self.c4_in = Conv2D(A, "c4_in", 4, channels, f, stride=2, padding=padding, use_bias=True, act="lrelu",
                             act_alpha=0.2, algo=algo)

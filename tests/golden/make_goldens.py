@@ -164,6 +164,22 @@ def gen_helper_vectors(out_path):
         out[f"tile_{name}/shape"] = np.array([h, w, th, tw])
         for mode in (0, 1, 2):
             out[f"tile_{name}/stitched{mode}"] = HF.stitch_image(tiles, w, h, min_overlap=2, manage_overlap_mode=mode)
+    # 8 -> 4 connectivity (HelperFunctions.py:144-152), pure numpy in the reference
+    for i in range(4):
+        m = (rng.random((24, 31)) > (0.35 + 0.1 * i)).astype("uint8") * 255
+        out[f"conn_{i}/in"] = m.copy()
+        out[f"conn_{i}/out"] = HF.eight_to_four_connected(m.copy())
+    # load_and_preprocess_images (HelperFunctions.py:294-329) on synthetic files written to a temp dir
+    import tempfile
+    from PIL import Image
+    with tempfile.TemporaryDirectory() as td:
+        arr8 = (rng.random((40, 56)) * 255).astype("uint8")
+        arr8[:3, :3] = 255
+        Image.fromarray(arr8).save(os.path.join(td, "a.tif"))
+        out["load/src"] = arr8
+        out["load/m11"] = HF.load_and_preprocess_images(td, normalization_range=(-1, 1))
+        out["load/unet"] = HF.load_and_preprocess_images(td, normalization_range=(0, 1), contrast_optimization_range=(0.5, 99.5))
+        out["load/mask"] = HF.load_and_preprocess_images(td, normalization_range=(0, 1), threshold_value=0.5)
     np.savez_compressed(out_path, **out)
     print("wrote", out_path)
 

@@ -93,3 +93,35 @@ def test_data_parallel_plumbing_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o
+
+
+def test_connectivity_and_loader_match_reference_vectors(golden_dir, tmp_path):
+    from PIL import Image
+    HF = importlib.import_module(BASE + ".HelperFunctions")
+    z = np.load(os.path.join(golden_dir, "helper_tiling.npz"))
+    for i in range(4):
+        np.testing.assert_array_equal(HF.eight_to_four_connected(z[f"conn_{i}/in"].copy()), z[f"conn_{i}/out"])
+    Image.fromarray(z["load/src"]).save(str(tmp_path / "a.tif"))
+    np.testing.assert_array_equal(HF.load_and_preprocess_images(str(tmp_path), normalization_range=(-1, 1)), z["load/m11"])
+    np.testing.assert_array_equal(HF.load_and_preprocess_images(str(tmp_path), normalization_range=(0, 1),
+                                                                contrast_optimization_range=(0.5, 99.5)), z["load/unet"])
+    np.testing.assert_array_equal(HF.load_and_preprocess_images(str(tmp_path), normalization_range=(0, 1), threshold_value=0.5),
+                                  z["load/mask"])
+
+
+def test_otsu_threshold_is_the_variance_maximiser():
+    HF = importlib.import_module(BASE + ".HelperFunctions")
+    rng = np.random.default_rng(0)
+    img = np.concatenate([rng.normal(60, 10, 4000), rng.normal(180, 15, 2000)]).clip(0, 255).astype(np.uint8).reshape(60, 100)
+    t = HF.threshold_otsu(img)
+    best, best_v = None, -1.0
+    for c in range(int(img.min()), int(img.max())):       # brute force over every split value
+        lo, hi = img[img <= c], img[img > c]
+        v = lo.size * hi.size * (lo.mean() - hi.mean()) ** 2
+        if v > best_v:
+            best, best_v = c, v
+    assert t == best and 60 < t < 180
+    lab = HF.segment(img, -1, watershed_lines=False)
+    assert set(np.unique(lab)) <= {0, 255}
+    with pytest.raises(NotImplementedError):
+        HF.segment(img, -1, watershed_lines=True)

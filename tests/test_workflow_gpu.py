@@ -1,0 +1,82 @@
+"""End-to-end drive of the reference's step 3 / 4 / 6a / 6b call sequence (StartProcess.py:89-175) on synthetic data."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+BASE = "automatic-sem-image-segmentation_amd"
+
+
+def _write_tiles(d, n, size, rng, mask):
+    from PIL import Image
+    os.makedirs(d, exist_ok=True)
+    for i in range(n):
+        if mask:
+            a = (rng.random((size, size)) > 0.85).astype(np.uint8) * 255
+        else:
+            a = (rng.random((size, size)) * 255).astype(np.uint8)
+        Image.fromarray(a).save(os.path.join(d, f"{i:03d}.tif"))
+
+
+def test_cyclegan_then_unet_workflow(tmp_path):
+    CG = importlib.import_module(BASE + ".CycleGAN")
+    UN = importlib.import_module(BASE + ".UNet_Segmentation")
+    rng = np.random.default_rng(0)
+    root = str(tmp_path)
+    data = os.path.join(root, "2_CycleGAN", "data")
+    for sub, mask in (("trainA", False), ("trainB", True), ("testA", False), ("testB", True)):
+        _write_tiles(os.path.join(data, sub), 4, 64, rng, mask)
+    os.makedirs(os.path.join(root, "2_CycleGAN", "Models"))
+    os.makedirs(os.path.join(root, "3_UNet", "Models"))
+
+    # step 3 (StartProcess.py:89-104)
+    cg = CG.CycleGAN(root_dir=root, image_shape=(64, 64, 1))
+    cg.batch_size, cg.epochs, cg.use_data_loader = 2, 2, True
+    cg.label_smoothing_factor, cg.gaussian_noise_value, cg.use_skip_connection = 0.0, 0.0, False
+    cg.filters, cg.num_residual_blocks_gen = 4, 2
+    model = cg.start_training()
+    mdir = os.path.join(cg.model_dir, cg.prefix)
+    assert sorted(os.listdir(mdir)) == ["checkpoints_001.keras.npz", "checkpoints_002.keras.npz", "model.keras.npz", "training_log.csv"]
+    log = open(os.path.join(mdir, "training_log.csv")).read().strip().split("\n")
+    assert log[0].split(";")[0] == "epoch" and len(log) == 3 and len(log[0].split(";")) == 15
+    assert cg.image_pool_a.batch_size == 2 and cg.image_pool_a.num_imgs == 4 * 2 // 2 * 1 * 2  # 2 images per step, 2 steps/epoch, 2 epochs
+
+    # step 4 (StartProcess.py:107-130): masks -> fake images, loading the saved model like a fresh process would
+    cg2 = CG.CycleGAN(root_dir=root, image_shape=(64, 64, 1))
+    out_a = os.path.join(root, "2_CycleGAN", "generate_images", "A")
+    cg2.run_inference(files=os.path.join(data, "trainB"), output_directory=out_a, source_domain="B", tile_images=False, use_gpu=True)
+    assert len(os.listdir(out_a)) == 4
+    # tiled inference of a larger image must equal whole-image inference away from tile seams only in shape/type here
+    big = os.path.join(root, "big")
+    _write_tiles(big, 1, 128, rng, False)
+    out_b = os.path.join(root, "out_b")
+    cg2.run_inference(files=big, output_directory=out_b, source_domain="A", tile_images=True, use_gpu=True)
+    from PIL import Image
+    im = np.array(Image.open(os.path.join(out_b, "000.tif")))
+    assert im.shape == (128, 128) and im.dtype == np.uint8 and im.max() == 255 and im.min() == 0
+
+    # step 6a (StartProcess.py:149-157): fake images + masks
+    un = UN.UNet(root_dir=root, image_dir=out_a, mask_dir=os.path.join(data, "trainB"))
+    un.batch_size, un.epochs, un.use_dataloader, un.filters = 2, 2, True, 16
+    un.contrast_optimization_range = (0.5, 99.5)
+    umodel = un.run_training()
+    udir = os.path.join(un.model_dir, un.prefix)
+    assert {"Checkpoint_Lowest_Loss.keras.npz", "model.keras.npz", "training_log.csv"} <= set(os.listdir(udir))
+    hdr = open(os.path.join(udir, "training_log.csv")).read().split("\n")[0].split(";")
+    assert hdr == ["epoch", "acc", "loss", "mae", "val_acc", "val_loss", "val_mae"]
+
+    # step 6b (StartProcess.py:160-175)
+    un2 = UN.UNet(root_dir=root, image_dir=out_a, mask_dir=os.path.join(data, "trainB"))
+    un2.contrast_optimization_range = (0.5, 99.5)
+    out_u = os.path.join(root, "out_unet")
+    un2.run_inference(files=big, output_directory=out_u, tile_images=False, threshold=-1, watershed_lines=False, use_gpu=True)
+    raw = np.array(Image.open(os.path.join(out_u, "000_raw.tif")))
+    lab = np.array(Image.open(os.path.join(out_u, "000.tif")))
+    assert raw.dtype == np.float32 and raw.shape == (128, 128) and 0.0 <= raw.min() and raw.max() <= 1.0
+    assert set(np.unique(lab)) <= {0, 255}
+    # saved-model round trip reproduces the in-memory model bit for bit
+    p1 = umodel.predict(np.ascontiguousarray(np.array(Image.open(os.path.join(big, "000.tif")), dtype=np.float32)[None, :, :, None] / 255.0))
+    p2 = un2.model.predict(np.ascontiguousarray(np.array(Image.open(os.path.join(big, "000.tif")), dtype=np.float32)[None, :, :, None] / 255.0))
+    assert bool((p1 == p2).all())

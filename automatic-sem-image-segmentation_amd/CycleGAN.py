@@ -97,9 +97,11 @@ class CycleGanModel:
         self.device = generator_a.device
         # 14 running means (keras.metrics.Mean, CycleGAN.py:547-560): device sums, one host read per query
         self._scalars = torch.zeros(16, dtype=torch.float32, device=self.device)
+        self._bce3 = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._sums = np.zeros(14, dtype=np.float64)
         self._count = 0
         self.sync_metrics = True
+        self.use_binary_crossentropy_a = False   # cycle/identity loss A = BinaryCrossentropy (generator A ends in a sigmoid)
         self.built = True
 
     def compile(self, gen_a_optimizer, gen_b_optimizer, disc_x_optimizer, disc_y_optimizer, disc_loss_fn=None,
@@ -148,7 +150,11 @@ class CycleGanModel:
         # slots: 0 adv_a 1 adv_b 2 cyc_a 3 cyc_b 4 id_a 5 id_b | 6 d_real_a 7 d_fake_a 8 d_real_b 9 d_fake_b
         losses.mse_const(disc_fake_b, one, 1.0, self._slot(0))
         losses.mse_const(disc_fake_a, one, 1.0, self._slot(1))
-        losses.mae(real_b, cycled_b, self.lambda_cycle_a, self._slot(2))
+        if self.use_binary_crossentropy_a:
+            losses.weighted_bce(real_b, cycled_b, 1.0, self.lambda_cycle_a, self._bce3)
+            L.check(L.load().ss_copy(self._bce3.data_ptr(), 1, self._slot(2).data_ptr(), 1, 1, 1, _stream()), "ss_copy")
+        else:
+            losses.mae(real_b, cycled_b, self.lambda_cycle_a, self._slot(2))
         losses.mae(real_a, cycled_a, self.lambda_cycle_b, self._slot(3))
         if self.use_identity_loss:
             losses.mae(real_b, same_b, self.lambda_cycle_a * self.lambda_identity_a, self._slot(4))
@@ -328,19 +334,16 @@ class CycleGAN:
         self.test_b = HelperFunctions.get_image_file_paths_from_directory(os.path.join(data, 'testB'), missing_ok=True)
 
     def create_model(self):
-        if self.use_binary_crossentropy:
-            raise NotImplementedError("use_binary_crossentropy=True is off in StartProcess.py:101 and not built yet")
-        if self.use_skip_connection:
-            raise NotImplementedError("use_skip_connection=True (StartProcess default is False, StartProcess.py:36) not built yet")
-        if self.use_resize_convolution:
-            raise NotImplementedError("use_resize_convolution=True is off in StartProcess.py:102 and not built yet")
+        assert not (self.use_binary_crossentropy and (self.lambda_identity_a > 0 or self.lambda_identity_b > 0)), \
+            'binary crossentropy cannot be used with identity mapping (CycleGAN.py:71)'
         if self.gaussian_noise_value > 0:
             raise NotImplementedError("gaussian_noise_value > 0 is off in StartProcess.py:96 and not built yet")
         ch = self.image_shape[-1] if len(self.image_shape) == 3 else 1
         kw = dict(filters=self.filters, num_downsampling_blocks=self.num_downsampling_blocks_gen,
                   num_residual_blocks=self.num_residual_blocks_gen, num_upsample_blocks=self.num_upsampling_blocks_gen,
-                  channels=ch, device=self.device)
-        self.gen_a = ResnetGenerator(seed=self.seed + 1, **kw)
+                  channels=ch, device=self.device, use_skip_connection=self.use_skip_connection,
+                  use_resize_convolution=self.use_resize_convolution)
+        self.gen_a = ResnetGenerator(seed=self.seed + 1, sigmoid_output=self.use_binary_crossentropy, **kw)
         self.gen_b = ResnetGenerator(seed=self.seed + 2, **kw)
         self.disc_a = PatchDiscriminator(filters=2 * self.filters, num_downsampling_blocks=self.num_downsampling_blocks_disc,
                                          channels=ch, padding="valid", device=self.device, seed=self.seed + 3)
@@ -357,6 +360,7 @@ class CycleGAN:
                       disc_y_optimizer=Adam(learning_rate=self.learning_rate, beta_1=0.5),
                       gen_loss_fn=self.generator_loss_fn, disc_loss_fn=self.discriminator_loss_fn,
                       label_smoothing_factor=self.label_smoothing_factor)
+        model.use_binary_crossentropy_a = self.use_binary_crossentropy      # CycleGAN.py:117-121
         return model
 
     # LSGAN targets, kept for API compatibility / documentation (the kernels implement them)

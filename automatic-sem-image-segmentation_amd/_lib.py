@@ -42,6 +42,12 @@ SIGNATURES = {
     "ss_axpby": (c_i32, [c_f32, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "ss_maxpool2x2_fwd": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "ss_maxpool2x2_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "ss_reflect_pad2d_fwd": (c_i32, [c_vp, c_i32, c_vp, c_i32] + [c_i32] * 8 + [c_vp]),
+    "ss_reflect_pad2d_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32] + [c_i32] * 8 + [c_vp]),
+    "ss_crop2d_fwd": (c_i32, [c_vp, c_i32, c_vp, c_i32] + [c_i32] * 8 + [c_vp]),
+    "ss_crop2d_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32] + [c_i32] * 8 + [c_vp]),
+    "ss_upsample2x_fwd": (c_i32, [c_vp, c_i32, c_vp, c_i32] + [c_i32] * 4 + [c_vp]),
+    "ss_upsample2x_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32] + [c_i32] * 4 + [c_vp]),
     "ss_copy": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "ss_fill": (c_i32, [c_vp, c_f32, c_i64, c_vp]),
     "ss_loss_workspace_bytes": (c_sz, [c_i64]),

@@ -83,6 +83,97 @@ __global__ __launch_bounds__(EW_BLOCK) void maxpool_bwd_kernel(const float* __re
     }
 }
 
+
+// y[n,py,px,c] = x[n, reflect(py-pt), reflect(px-pl), c]   (keras.ops.pad(mode="reflect"), CycleGAN.py:495-506)
+__global__ __launch_bounds__(EW_BLOCK) void reflect_pad_fwd_kernel(const float* __restrict__ x, int x_cs, float* __restrict__ y, int y_cs,
+                                                                   int N, int H, int W, int C, int pt, int pl, int PH, int PW) {
+    const long total = (long)N * PH * PW * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int px = (int)(r % PW); r /= PW;
+        const int py = (int)(r % PH);
+        const int n = (int)(r / PH);
+        const int iy = ss_map_index(py - pt, H, 1), ix = ss_map_index(px - pl, W, 1);
+        y[((long)(n * PH + py) * PW + px) * y_cs + c] = x[((long)(n * H + iy) * W + ix) * x_cs + c];
+    }
+}
+
+// dx[n,iy,ix,c] (+)= sum of dy over the padded positions that reflect onto (iy,ix)
+__global__ __launch_bounds__(EW_BLOCK) void reflect_pad_bwd_kernel(const float* __restrict__ dy, int dy_cs, float* __restrict__ dx, int dx_cs,
+                                                                   int accumulate, int N, int H, int W, int C, int pt, int pl, int PH, int PW) {
+    const long total = (long)N * H * W * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int n = (int)(r / H);
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = iy + pt;
+        if (iy >= 1 && pt - iy >= 0) ys[ny++] = pt - iy;
+        { const int py = pt + 2 * (H - 1) - iy; if (iy <= H - 2 && py < PH) ys[ny++] = py; }
+        xs[nx++] = ix + pl;
+        if (ix >= 1 && pl - ix >= 0) xs[nx++] = pl - ix;
+        { const int px = pl + 2 * (W - 1) - ix; if (ix <= W - 2 && px < PW) xs[nx++] = px; }
+        float acc = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) acc += dy[((long)(n * PH + ys[a]) * PW + xs[b]) * dy_cs + c];
+        float* o = dx + ((long)(n * H + iy) * W + ix) * dx_cs + c;
+        *o = accumulate ? (*o + acc) : acc;
+    }
+}
+
+// MODE 0: y = x[:, top:top+OH, left:left+OW]   MODE 1 (backward): dx (+)= dy placed at (top,left), zero elsewhere
+template <int MODE>
+__global__ __launch_bounds__(EW_BLOCK) void crop_kernel(const float* __restrict__ src, int src_cs, float* __restrict__ dst, int dst_cs,
+                                                        int accumulate, int N, int H, int W, int C, int top, int left, int OH, int OW) {
+    const long total = MODE == 0 ? (long)N * OH * OW * C : (long)N * H * W * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        if (MODE == 0) {
+            const int ox = (int)(r % OW); r /= OW;
+            const int oy = (int)(r % OH);
+            const int n = (int)(r / OH);
+            dst[((long)(n * OH + oy) * OW + ox) * dst_cs + c] = src[((long)(n * H + oy + top) * W + ox + left) * src_cs + c];
+        } else {
+            const int ix = (int)(r % W); r /= W;
+            const int iy = (int)(r % H);
+            const int n = (int)(r / H);
+            const int oy = iy - top, ox = ix - left;
+            const float g = (oy >= 0 && oy < OH && ox >= 0 && ox < OW) ? src[((long)(n * OH + oy) * OW + ox) * src_cs + c] : 0.f;
+            float* o = dst + ((long)(n * H + iy) * W + ix) * dst_cs + c;
+            *o = accumulate ? (*o + g) : g;
+        }
+    }
+}
+
+// MODE 0: nearest-neighbour 2x upsampling (keras.layers.UpSampling2D, CycleGAN.py:349); MODE 1: its backward (2x2 sums)
+template <int MODE>
+__global__ __launch_bounds__(EW_BLOCK) void upsample2x_kernel(const float* __restrict__ src, int src_cs, float* __restrict__ dst, int dst_cs,
+                                                              int accumulate, int N, int H, int W, int C) {
+    const long total = MODE == 0 ? (long)N * 2 * H * 2 * W * C : (long)N * H * W * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        if (MODE == 0) {
+            const int ox = (int)(r % (2 * W)); r /= 2 * W;
+            const int oy = (int)(r % (2 * H));
+            const int n = (int)(r / (2 * H));
+            dst[((long)(n * 2 * H + oy) * 2 * W + ox) * dst_cs + c] = src[((long)(n * H + oy / 2) * W + ox / 2) * src_cs + c];
+        } else {
+            const int ix = (int)(r % W); r /= W;
+            const int iy = (int)(r % H);
+            const int n = (int)(r / H);
+            const float* q = src + ((long)(n * 2 * H + 2 * iy) * 2 * W + 2 * ix) * src_cs + c;
+            const float g = q[0] + q[src_cs] + q[(long)2 * W * src_cs] + q[(long)(2 * W + 1) * src_cs];
+            float* o = dst + ((long)(n * H + iy) * W + ix) * dst_cs + c;
+            *o = accumulate ? (*o + g) : g;
+        }
+    }
+}
+
 // ---- losses: stage 1 per-block partial sums (K values each), stage 2 single block finishes -------
 constexpr int LOSS_MAX_BLOCKS = 1024;
 
@@ -262,6 +353,62 @@ int ss_maxpool2x2_bwd(const float* dy, int32_t dy_cstride, const float* x, int32
     const long total = (long)n * h * w * c;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
                        dy, dy_cstride, x, x_cstride, dx, dx_cstride, accumulate, n, h, w, c);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_reflect_pad2d_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c,
+                         int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream) {
+    if (!x || !y || n <= 0 || h <= 0 || w <= 0 || c <= 0 || pad_top < 0 || pad_bottom < 0 || pad_left < 0 || pad_right < 0) return SS_ERR_INVALID;
+    if (pad_top >= h || pad_bottom >= h || pad_left >= w || pad_right >= w) return SS_ERR_INVALID;
+    const int PH = h + pad_top + pad_bottom, PW = w + pad_left + pad_right;
+    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(ew_grid((long)n * PH * PW * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       x, x_cstride, y, y_cstride, n, h, w, c, pad_top, pad_left, PH, PW);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_reflect_pad2d_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
+                         int32_t c, int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream) {
+    if (!dy || !dx || n <= 0 || h <= 0 || w <= 0 || c <= 0) return SS_ERR_INVALID;
+    const int PH = h + pad_top + pad_bottom, PW = w + pad_left + pad_right;
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(ew_grid((long)n * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       dy, dy_cstride, dx, dx_cstride, accumulate, n, h, w, c, pad_top, pad_left, PH, PW);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_crop2d_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c,
+                  int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream) {
+    if (!x || !y || n <= 0 || c <= 0 || top < 0 || left < 0 || oh <= 0 || ow <= 0 || top + oh > h || left + ow > w) return SS_ERR_INVALID;
+    hipLaunchKernelGGL(crop_kernel<0>, dim3(ew_grid((long)n * oh * ow * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       x, x_cstride, y, y_cstride, 0, n, h, w, c, top, left, oh, ow);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_crop2d_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
+                  int32_t c, int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream) {
+    if (!dy || !dx || n <= 0 || c <= 0 || top < 0 || left < 0 || oh <= 0 || ow <= 0 || top + oh > h || left + ow > w) return SS_ERR_INVALID;
+    hipLaunchKernelGGL(crop_kernel<1>, dim3(ew_grid((long)n * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       dy, dy_cstride, dx, dx_cstride, accumulate, n, h, w, c, top, left, oh, ow);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_upsample2x_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+    if (!x || !y || n <= 0 || h <= 0 || w <= 0 || c <= 0) return SS_ERR_INVALID;
+    hipLaunchKernelGGL(upsample2x_kernel<0>, dim3(ew_grid((long)n * 4 * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       x, x_cstride, y, y_cstride, 0, n, h, w, c);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_upsample2x_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
+                      int32_t c, void* stream) {
+    if (!dy || !dx || n <= 0 || h <= 0 || w <= 0 || c <= 0) return SS_ERR_INVALID;
+    hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(ew_grid((long)n * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       dy, dy_cstride, dx, dx_cstride, accumulate, n, h, w, c);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

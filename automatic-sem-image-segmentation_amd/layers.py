@@ -217,3 +217,78 @@ def add_grad(dst_act, src):
     dg, accum = dst_act.grad_target()
     L.check(lib.ss_axpby(1.0, src.ptr, src.cs, 1.0 if accum else 0.0, dg.ptr if accum else None, dg.cs,
                          dg.ptr, dg.cs, dst_act.rows, dst_act.c, _stream()), "axpby")
+
+
+def reflect_pad(tape, x, pad_w_total, pad_h_total):
+    """ReflectionPadding2D as a standalone op (CycleGAN.py:482-506): total padding split p//2 before, p//2 + p%2 after."""
+    if pad_w_total == 0 and pad_h_total == 0:
+        return x
+    lib = L.load()
+    pt, pb = pad_h_total // 2, pad_h_total // 2 + pad_h_total % 2
+    pl, pr = pad_w_total // 2, pad_w_total // 2 + pad_w_total % 2
+    y = Act.empty(x.n, x.h + pt + pb, x.w + pl + pr, x.c, x.device, requires_grad=x.requires_grad)
+    L.check(lib.ss_reflect_pad2d_fwd(x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, pt, pb, pl, pr, _stream()), "reflect_pad_fwd")
+
+    def backward():
+        dy = y.get_grad()
+        if dy is None or not x.requires_grad:
+            return
+        dx, accum = x.grad_target()
+        L.check(lib.ss_reflect_pad2d_bwd(dy.ptr, dy.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, pt, pb, pl, pr, _stream()), "reflect_pad_bwd")
+
+    tape.record(backward)
+    return y
+
+
+def crop(tape, x, top, bottom, left, right):
+    """keras.layers.Cropping2D(((top, bottom), (left, right)))."""
+    if top == 0 and bottom == 0 and left == 0 and right == 0:
+        return x
+    lib = L.load()
+    oh, ow = x.h - top - bottom, x.w - left - right
+    y = Act.empty(x.n, oh, ow, x.c, x.device)
+    L.check(lib.ss_crop2d_fwd(x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, top, left, oh, ow, _stream()), "crop_fwd")
+
+    def backward():
+        dy = y.get_grad()
+        if dy is None or not x.requires_grad:
+            return
+        dx, accum = x.grad_target()
+        L.check(lib.ss_crop2d_bwd(dy.ptr, dy.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, top, left, oh, ow, _stream()), "crop_bwd")
+
+    tape.record(backward)
+    return y
+
+
+def upsample2x(tape, x):
+    lib = L.load()
+    y = Act.empty(x.n, 2 * x.h, 2 * x.w, x.c, x.device)
+    L.check(lib.ss_upsample2x_fwd(x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, _stream()), "upsample_fwd")
+
+    def backward():
+        dy = y.get_grad()
+        if dy is None or not x.requires_grad:
+            return
+        dx, accum = x.grad_target()
+        L.check(lib.ss_upsample2x_bwd(dy.ptr, dy.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, _stream()), "upsample_bwd")
+
+    tape.record(backward)
+    return y
+
+
+def add(tape, a, b, out=None):
+    """keras.layers.add([a, b])."""
+    lib = L.load()
+    y = out if out is not None else Act.empty(a.n, a.h, a.w, a.c, a.device)
+    L.check(lib.ss_axpby(1.0, a.ptr, a.cs, 1.0, b.ptr, b.cs, y.ptr, y.cs, a.rows, a.c, _stream()), "axpby")
+
+    def backward():
+        dy = y.get_grad()
+        if dy is None:
+            return
+        for t in (a, b):
+            if t.requires_grad:
+                add_grad(t, dy)
+
+    tape.record(backward)
+    return y

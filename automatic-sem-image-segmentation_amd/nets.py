@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 from .engine import Act, ParamArena, Tape
-from .layers import Conv2D, Norm, maxpool2x2
+from .layers import Conv2D, Norm, add, crop, maxpool2x2, reflect_pad, upsample2x
 
 
 class Network:
@@ -75,14 +75,21 @@ class Network:
 
 
 class ResnetGenerator(Network):
-    """Default StartProcess configuration: no skip connection, transposed-conv upsampling, tanh output."""
+    """CycleGAN.get_resnet_generator (CycleGAN.py:360-423).  Defaults = the StartProcess configuration (no skip
+    connection, transposed-conv upsampling, tanh output); the builder's other branches are options:
+    ``use_skip_connection`` (CycleGAN.py:396-415), ``use_resize_convolution`` (CycleGAN.py:348-351),
+    ``sigmoid_output`` (use_binary_crossentropy generator A, CycleGAN.py:417-418)."""
 
     def __init__(self, filters=64, num_downsampling_blocks=3, num_residual_blocks=9, num_upsample_blocks=3,
-                 channels=1, device="cuda", seed=0, algo=L.ALGO_AUTO):
+                 channels=1, device="cuda", seed=0, algo=L.ALGO_AUTO, use_skip_connection=False,
+                 use_resize_convolution=False, sigmoid_output=False):
         super().__init__(device)
         A = self.arena
         self.nd, self.nr, self.nu = num_downsampling_blocks, num_residual_blocks, num_upsample_blocks
         self.filters = filters
+        self.use_skip_connection, self.use_resize_convolution = use_skip_connection, use_resize_convolution
+        self.sigmoid_output = sigmoid_output
+        final_act = "sigmoid" if sigmoid_output else "tanh"
         f = filters
         self.c7_in = Conv2D(A, "c7_in", 7, channels, f, padding=("reflect", 3), algo=algo)
         self.in_c7 = Norm(A, "c7_in", f, "instance")
@@ -100,17 +107,32 @@ class ResnetGenerator(Network):
             self.res.append((c0, n0, c1, n1))
         self.up = []
         for i in range(self.nu):
-            conv = Conv2D(A, f"up{i}", 3, f, f // 2, stride=2, transposed=True, algo=algo)
+            if use_resize_convolution:   # UpSampling2D -> ReflectionPadding2D -> Conv2D(3x3, valid)
+                conv = Conv2D(A, f"up{i}", 3, f, f // 2, padding=("reflect", 1), algo=algo)
+            else:
+                conv = Conv2D(A, f"up{i}", 3, f, f // 2, stride=2, transposed=True, algo=algo)
             f //= 2
             self.up.append((conv, Norm(A, f"up{i}", f, "instance")))
-        self.c7_out = Conv2D(A, "c7_out", 7, f, channels, padding=("reflect", 3), use_bias=True, act="tanh", algo=algo)
+        self.c7_out = Conv2D(A, "c7_out", 7, f, channels, padding=("reflect", 3), use_bias=True,
+                             act=None if use_skip_connection else final_act, algo=algo)
+        if use_skip_connection:
+            self.sk_sc = Conv2D(A, "skip.sc1x1", 1, channels, f, algo=algo)
+            self.sk_sc_n = Norm(A, "skip.sc1x1", f, "instance")
+            self.sk_c3 = Conv2D(A, "skip.3", 3, channels, f, padding=("reflect", 1), algo=algo)
+            self.sk_c3_n = Norm(A, "skip.3", f, "instance")
+            self.sk_n = Norm(A, "skip.sum", f, "instance")
+            self.sk_out = Conv2D(A, "skip.out1x1", 1, f + channels, channels, act=final_act, algo=algo)
         self._finish(seed)
 
     def forward(self, tape, x, training=True):
         m = 2 ** self.nd
-        if x.h % m or x.w % m:
-            # CycleGAN.py:365-367 pre-pads by reflection to a multiple of 2**n_down and never crops back.
-            raise NotImplementedError("tile size must be a multiple of %d (all StartProcess/BASELINE sizes are)" % m)
+        ph, pw = (m - x.h % m) % m, (m - x.w % m) % m
+        img_input = x
+        if ph or pw:
+            if self.use_skip_connection:
+                raise NotImplementedError("skip connection + pre-padding concatenates mismatching sizes in the reference too")
+            # CycleGAN.py:365-367: reflect pre-pad to a multiple of 2**n_down; the output is NOT cropped back (CycleGAN.py:394)
+            x = reflect_pad(tape, x, pw, ph)
         h = self.in_c7(tape, self.c7_in(tape, x), act="relu")
         for conv, norm in self.down:
             h = norm(tape, conv(tape, h), act="relu")
@@ -118,8 +140,18 @@ class ResnetGenerator(Network):
             y = n0(tape, c0(tape, h), act="relu")
             h = n1(tape, c1(tape, y), residual=h)
         for conv, norm in self.up:
+            if self.use_resize_convolution:
+                h = upsample2x(tape, h)
             h = norm(tape, conv(tape, h), act="relu")
-        return self.c7_out(tape, h)
+        if not self.use_skip_connection:
+            return self.c7_out(tape, h)
+        f = self.sk_sc.cout
+        cat = Act.empty(x.n, x.h, x.w, f + self.c7_out.cout, x.device)       # concatenate([out, x]) without a copy
+        self.c7_out(tape, h, out=cat.slice(f, self.c7_out.cout))
+        sc = self.sk_sc_n(tape, self.sk_sc(tape, img_input), act="relu")
+        o3 = self.sk_c3_n(tape, self.sk_c3(tape, img_input), act="relu")
+        self.sk_n(tape, add(tape, sc, o3), act="relu", out=cat.slice(0, f))
+        return self.sk_out(tape, cat)
 
 
 class PatchDiscriminator(Network):
@@ -237,8 +269,8 @@ class MultiResUNet(Network):
         self._finish(seed)
 
     def forward(self, tape, x, training=True):
-        if x.h % 16 or x.w % 16:
-            raise NotImplementedError("tile size must be a multiple of 16 (UNet_Segmentation.py:520-522 reflect-pads otherwise)")
+        ph, pw = (16 - x.h % 16) % 16, (16 - x.w % 16) % 16
+        x = reflect_pad(tape, x, pw, ph)                      # UNet_Segmentation.py:520-522
         f, t = self.filters, training
         dev = x.device
         m1 = self.mrb1(tape, x, t)
@@ -267,4 +299,5 @@ class MultiResUNet(Network):
         self.rp1(tape, m1, t, out=cat9.slice(f, f))
         self.up9(tape, m8, out=cat9.slice(0, f))
         m9 = self.mrb9(tape, cat9, t)
+        m9 = crop(tape, m9, ph // 2, ph // 2 + ph % 2, pw // 2, pw // 2 + pw % 2)     # Cropping2D, UNet_Segmentation.py:554
         return self.head(tape, m9, "sigmoid", t)

@@ -143,6 +143,21 @@ int ss_maxpool2x2_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cst
 int ss_maxpool2x2_bwd(const float* dy, int32_t dy_cstride, const float* x, int32_t x_cstride,
                       float* dx, int32_t dx_cstride, int accumulate,
                       int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+/* keras.ops.pad(mode="reflect") as a standalone op -- the pre-padding of tiles whose size is not a multiple of
+ * 2^n_down (CycleGAN.py:365-367) or of 16 (UNet_Segmentation.py:520-522); (h,w) describe x.  bwd folds dy back onto x. */
+int ss_reflect_pad2d_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c,
+                         int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream);
+int ss_reflect_pad2d_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
+                         int32_t c, int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream);
+/* keras.layers.Cropping2D (UNet_Segmentation.py:554): y = x[:, top:top+oh, left:left+ow]; (h,w) describe x */
+int ss_crop2d_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c,
+                  int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream);
+int ss_crop2d_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
+                  int32_t c, int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream);
+/* keras.layers.UpSampling2D(size=(2,2)), nearest (CycleGAN.py:349, resize-convolution branch); (h,w) describe x */
+int ss_upsample2x_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+int ss_upsample2x_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
+                      int32_t c, void* stream);
 int ss_copy(const float* src, int32_t src_cstride, float* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream);
 int ss_fill(float* dst, float value, int64_t count, void* stream);
 

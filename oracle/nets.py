@@ -99,9 +99,11 @@ class ResnetGenerator(Net):
     """CycleGAN.get_resnet_generator, default branch (no skip connection, no resize-conv, tanh)."""
 
     def __init__(self, filters=64, num_downsampling_blocks=3, num_residual_blocks=9,
-                 num_upsample_blocks=3, channels=1, dtype=torch.float32, seed=0):
+                 num_upsample_blocks=3, channels=1, dtype=torch.float32, seed=0, use_skip_connection=False,
+                 use_resize_convolution=False, sigmoid_output=False):
         super().__init__(dtype, seed)
         self.nd, self.nr, self.nu = num_downsampling_blocks, num_residual_blocks, num_upsample_blocks
+        self.skip, self.resize, self.sigmoid_output = use_skip_connection, use_resize_convolution, sigmoid_output
         f = filters
         self.add_kernel("c7_in/kernel", (7, 7, channels, f))
         self._gn("c7_in", f)
@@ -114,11 +116,21 @@ class ResnetGenerator(Net):
                 self.add_kernel(f"res{i}.{j}/kernel", (3, 3, f, f))
                 self._gn(f"res{i}.{j}", f)
         for i in range(self.nu):
-            self.add_kernel(f"up{i}/kernel", (3, 3, f // 2, f))  # Conv2DTranspose: (kh,kw,out,in)
+            if use_resize_convolution:
+                self.add_kernel(f"up{i}/kernel", (3, 3, f, f // 2))  # CycleGAN.py:351 plain Conv2D
+            else:
+                self.add_kernel(f"up{i}/kernel", (3, 3, f // 2, f))  # Conv2DTranspose: (kh,kw,out,in)
             f //= 2
             self._gn(f"up{i}", f)
         self.add_kernel("c7_out/kernel", (7, 7, f, channels))
         self.add_zeros("c7_out/bias", (channels,))
+        if use_skip_connection:      # CycleGAN.py:396-415, creation order
+            self.add_kernel("skip.sc1x1/kernel", (1, 1, channels, f))
+            self._gn("skip.sc1x1", f)
+            self.add_kernel("skip.3/kernel", (3, 3, channels, f))
+            self._gn("skip.3", f)
+            self._gn("skip.sum", f)
+            self.add_kernel("skip.out1x1/kernel", (1, 1, f + channels, channels))
 
     def _gn(self, name, c):
         self.add_ones(f"{name}/gamma", (c,))
@@ -131,6 +143,7 @@ class ResnetGenerator(Net):
         m = 2 ** self.nd
         ph = (m - x.shape[1] % m) % m
         pw = (m - x.shape[2] % m) % m
+        img_input = x
         x = ops.reflection_pad(x, (pw, ph))
         x = ops.reflection_pad(x, (6, 6))
         x = torch.relu(self._in("c7_in", ops.conv2d(x, self.p("c7_in/kernel"))))
@@ -144,11 +157,20 @@ class ResnetGenerator(Net):
             y = self._in(f"res{i}.1", ops.conv2d(y, self.p(f"res{i}.1/kernel")))
             x = x + y
         for i in range(self.nu):
-            x = ops.conv2d_transpose(x, self.p(f"up{i}/kernel"), stride=2)
+            if self.resize:
+                x = x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)     # UpSampling2D nearest
+                x = ops.conv2d(ops.reflection_pad(x, (2, 2)), self.p(f"up{i}/kernel"))
+            else:
+                x = ops.conv2d_transpose(x, self.p(f"up{i}/kernel"), stride=2)
             x = torch.relu(self._in(f"up{i}", x))
         x = ops.reflection_pad(x, (6, 6))
         x = ops.conv2d(x, self.p("c7_out/kernel"), self.p("c7_out/bias"))
-        return torch.tanh(x)
+        if self.skip:
+            sc = torch.relu(self._in("skip.sc1x1", ops.conv2d(img_input, self.p("skip.sc1x1/kernel"))))
+            out = torch.relu(self._in("skip.3", ops.conv2d(ops.reflection_pad(img_input, (2, 2)), self.p("skip.3/kernel"))))
+            out = torch.relu(self._in("skip.sum", sc + out))
+            x = ops.conv2d(torch.cat([out, x], dim=3), self.p("skip.out1x1/kernel"))
+        return torch.sigmoid(x) if self.sigmoid_output else torch.tanh(x)
 
 
 class PatchDiscriminator(Net):

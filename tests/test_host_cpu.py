@@ -80,7 +80,9 @@ D.all_reduce_flat(net.arena.grads, bucket_elems=7000)       # several buckets, r
 assert torch.equal(net.arena.grads, torch.arange(40_000, dtype=torch.float32) * 3)
 m = D.mean_scalars(np.array([1.0 + r, 10.0 * r]))
 assert np.allclose(m, [1.5, 5.0])
-print("RANK_OK", r)
+print("RANK_OK", r, flush=True)
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
 '''
 
 

@@ -70,15 +70,18 @@ def run_net_fwd_bwd(net_hip, make_ref, x_cpu, gen, grad_tol=None):
     torch.cuda.synchronize()
 
     report = []
+    # network-wide fp32 noise level: 90th percentile of the fp32 oracle's own per-tensor distance to fp64 (a single
+    # tensor's oracle error can be luckily small -- e.g. BatchNorm beta gradients are heavily cancelling sums)
+    noise = float(np.percentile([rel_l2(gw32[k], gw64[k]) for k in gw64 if float(gw64[k].abs().max()) >= 1e-9], 90))
 
     def check(got, r64, r32, what, tol):
-        e_hip, e_32 = rel_l2(got, r64), rel_l2(r32, r64)
+        e_hip, e_32 = rel_l2(got, r64), max(rel_l2(r32, r64), noise)
         report.append((e_hip, e_32, what))
-        assert e_hip <= tol + 3 * e_32, f"{what}: relL2 hip={e_hip:.3e} oracle32={e_32:.3e} tol={tol:.1e}"
+        assert e_hip <= tol + 3 * e_32, f"{what}: relL2 hip={e_hip:.3e} oracle32/noise={e_32:.3e} tol={tol:.1e}"
 
     ref_max = float(y64.abs().max())
     assert float(np.abs(got_y - y64.numpy()).max()) <= 1e-4 * max(ref_max, 1e-3) + 3 * float((y32.double() - y64).abs().max()), "forward output"
-    check(x.get_grad().dense().cpu(), dx64, dx32, "dx", 1e-4)
+    check(x.get_grad().dense().cpu(), dx64, dx32, "dx", grad_tol or 1e-4)
     grads = net_hip.get_gradients()
     for name in gw64:
         if float(gw64[name].abs().max()) < 1e-9:
@@ -96,6 +99,24 @@ def test_generator_fwd_bwd():
     hip = mod("nets").ResnetGenerator(filters=8, num_residual_blocks=3, device="cuda:0")
     run_net_fwd_bwd(hip, lambda dt: ON.ResnetGenerator(filters=8, num_residual_blocks=3, seed=5, dtype=dt),
                     torch.rand((2, 64, 64, 1), generator=gen) * 2 - 1, gen)
+
+
+@pytest.mark.parametrize("opts,size", [(dict(use_skip_connection=True), (64, 64)), (dict(use_resize_convolution=True), (64, 64)),
+                                       (dict(sigmoid_output=True), (64, 64)), (dict(), (60, 68))],
+                         ids=["skip_connection", "resize_convolution", "sigmoid_output", "prepad_60x68"])
+def test_generator_option_branches(opts, size):
+    """Builder branches that StartProcess.py switches off (CycleGAN.py:348-351,365-367,396-418)."""
+    gen = torch.Generator().manual_seed(4)
+    hip = mod("nets").ResnetGenerator(filters=8, num_residual_blocks=2, device="cuda:0", **opts)
+    run_net_fwd_bwd(hip, lambda dt: ON.ResnetGenerator(filters=8, num_residual_blocks=2, seed=5, dtype=dt, **opts),
+                    torch.rand((2, size[0], size[1], 1), generator=gen) * 2 - 1, gen)
+
+
+def test_multiresunet_prepad_and_crop():
+    """Tile size not a multiple of 16: reflect pre-pad + Cropping2D (UNet_Segmentation.py:520-522,554)."""
+    gen = torch.Generator().manual_seed(8)
+    hip = mod("nets").MultiResUNet(16, device="cuda:0")
+    run_net_fwd_bwd(hip, lambda dt: ON.MultiResUNet(16, seed=7, dtype=dt), torch.rand((2, 72, 88, 1), generator=gen), gen, grad_tol=1e-3)
 
 
 def test_discriminator_fwd_bwd():

@@ -205,6 +205,7 @@ class UNet:
         self.model = None
         self.device = D.local_device()
         self.seed = 0
+        self.sync_batch_norm = True   # data parallel: whole-(global)-batch BatchNorm statistics, as on a single device
 
     def load_images(self, subset):
         assert subset in ['train', 'val']
@@ -243,6 +244,8 @@ class UNet:
             weighting = self.class_weighting()
         net = MultiResUNet(conv_filters=self.filters, device=self.device, seed=self.seed)
         D.broadcast_params([net])
+        if D.world_size() > 1 and self.sync_batch_norm:
+            D.enable_sync_bn(True)
         wd = self.lr_decay if isinstance(self.lr_decay, float) else 0.0
         return UNetModel(net, weighting, Adam(learning_rate=self.learning_rate, weight_decay=wd))
 

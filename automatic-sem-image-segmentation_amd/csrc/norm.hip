@@ -257,6 +257,39 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     }
 }
 
+// sums[(g*C+c)*2+k] = sum over chunks of part (raw sums, fp64 combine)
+__global__ __launch_bounds__(256) void norm_collapse_kernel(const float* __restrict__ part, int chunks, int G, int C, float* __restrict__ sums) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)G * C) return;
+    const int g = (int)(i / C), c = (int)(i % C);
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        const float* o = part + (((long)g * chunks + k) * C + c) * 2;
+        s1 += o[0];
+        s2 += o[1];
+    }
+    sums[i * 2] = (float)s1;
+    sums[i * 2 + 1] = (float)s2;
+}
+
+// cross-rank backward finalize: means from the GLOBAL raw sums / global count, parameter gradients from the LOCAL sums
+__global__ __launch_bounds__(256) void norm_finalize_bwd_sync(const float* __restrict__ gsums, const float* __restrict__ lsums, int G, int C,
+                                                              double count, float* __restrict__ means, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double tg = 0.0, tgx = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const long i = ((long)g * C + c) * 2;
+        means[i] = (float)((double)gsums[i] / count);
+        means[i + 1] = (float)((double)gsums[i + 1] / count);
+        tg += lsums[i];
+        tgx += lsums[i + 1];
+    }
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)tg : (float)tg;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)tgx : (float)tgx;
+}
+
 inline bool al16(const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }
 inline unsigned apply_grid(long total) {
     long b = (total + 255) / 256;
@@ -372,6 +405,105 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
     else
         hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
+                           d->act, d->act_alpha, g.C, g.P, rows);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+/* ---- two-phase forms for data-parallel (cross-rank) batch statistics: stats -> all-reduce(sum) of `sums` by the caller -> finish ---- */
+int ss_norm_fwd_stats(const ss_norm_desc* d, const float* x, float* sums, void* ws, size_t ws_bytes, void* stream) {
+    if (!valid(d) || !x || !sums) return SS_ERR_INVALID;
+    if (!ws || ws_bytes < ss_norm_workspace_bytes(d)) return SS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int V = pick_v(d->c, {d->x_cstride}, {x});
+    const NormGeom g = geom(d, V);
+    float* part = (float*)ws;
+    const dim3 sgrid(g.chunks, g.cblocks, g.G);
+    if (V == 4)
+        hipLaunchKernelGGL((norm_stats_kernel<0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                           0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
+    else
+        hipLaunchKernelGGL((norm_stats_kernel<0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                           0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
+    SS_LAUNCH_CHECK();
+    const long gc = (long)g.G * g.C;
+    hipLaunchKernelGGL(norm_collapse_kernel, dim3((unsigned)((gc + 255) / 256)), dim3(256), 0, s, part, g.chunks, g.G, g.C, sums);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_norm_fwd_finish(const ss_norm_desc* d, const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                       const float* sums, int64_t total_count, float* mean, float* rstd,
+                       float* moving_mean, float* moving_var, float momentum, void* stream) {
+    if (!valid(d) || !x || !beta || !y || !sums || !mean || !rstd || total_count <= 0) return SS_ERR_INVALID;
+    if ((moving_mean != nullptr) != (moving_var != nullptr)) return SS_ERR_INVALID;
+    if (moving_mean && d->groups != 1) return SS_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int V = pick_v(d->c, {d->x_cstride, d->y_cstride, residual ? d->res_cstride : 0}, {x, y, residual, gamma, beta, mean, rstd});
+    const NormGeom g = geom(d, V);
+    const long gc = (long)g.G * g.C;
+    hipLaunchKernelGGL(norm_finalize_fwd, dim3((unsigned)((gc + 255) / 256)), dim3(256), 0, s,
+                       sums, 1, g.G, g.C, (long)total_count, d->eps, mean, rstd, moving_mean, moving_var, momentum);
+    SS_LAUNCH_CHECK();
+    const long rows = (long)g.G * g.P;
+    if (V == 4)
+        hipLaunchKernelGGL(norm_apply_kernel<4>, dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
+    else
+        hipLaunchKernelGGL(norm_apply_kernel<1>, dim3(apply_grid(rows * g.C)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_norm_bwd_stats(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
+                      const float* mean, const float* rstd, float* sums, void* ws, size_t ws_bytes, void* stream) {
+    if (!valid(d) || !dy || !x || !mean || !rstd || !sums) return SS_ERR_INVALID;
+    if (d->act != SS_ACT_NONE && !y) return SS_ERR_INVALID;
+    if (!ws || ws_bytes < ss_norm_workspace_bytes(d)) return SS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int V = pick_v(d->c, {d->x_cstride, dy_cstride, d->act != SS_ACT_NONE ? d->y_cstride : 0},
+                         {x, dy, d->act != SS_ACT_NONE ? y : nullptr, mean, rstd});
+    const NormGeom g = geom(d, V);
+    float* part = (float*)ws;
+    const dim3 sgrid(g.chunks, g.cblocks, g.G);
+    if (V == 4)
+        hipLaunchKernelGGL((norm_stats_kernel<1, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+                           d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
+    else
+        hipLaunchKernelGGL((norm_stats_kernel<1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+                           d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
+    SS_LAUNCH_CHECK();
+    const long gc = (long)g.G * g.C;
+    hipLaunchKernelGGL(norm_collapse_kernel, dim3((unsigned)((gc + 255) / 256)), dim3(256), 0, s, part, g.chunks, g.G, g.C, sums);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_norm_bwd_finish(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
+                       const float* gamma, const float* mean, const float* rstd,
+                       const float* global_sums, const float* local_sums, int64_t total_count,
+                       float* dx, int32_t dx_cstride, int accumulate_dx, float* dres, int accumulate_dres,
+                       float* dgamma, float* dbeta, int accumulate_params, void* ws, size_t ws_bytes, void* stream) {
+    if (!valid(d) || !dy || !x || !mean || !rstd || !dx || !global_sums || !local_sums || total_count <= 0) return SS_ERR_INVALID;
+    if (d->act != SS_ACT_NONE && !y) return SS_ERR_INVALID;
+    if (!ws || ws_bytes < ss_norm_workspace_bytes(d)) return SS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int V = pick_v(d->c, {d->x_cstride, dy_cstride, dx_cstride, d->act != SS_ACT_NONE ? d->y_cstride : 0, dres ? d->res_cstride : 0},
+                         {x, dy, dx, d->act != SS_ACT_NONE ? y : nullptr, dres, gamma, mean, rstd});
+    const NormGeom g = geom(d, V);
+    float* means = (float*)((char*)ws + part_bytes(d));
+    hipLaunchKernelGGL(norm_finalize_bwd_sync, dim3((g.C + 255) / 256), dim3(256), 0, s, global_sums, local_sums, g.G, g.C,
+                       (double)total_count, means, dgamma, dbeta, accumulate_params);
+    SS_LAUNCH_CHECK();
+    const long rows = (long)g.G * g.P;
+    if (V == 4)
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+                           gamma, mean, rstd, means, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
+                           d->act, d->act_alpha, g.C, g.P, rows);
+    else
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+                           gamma, mean, rstd, means, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
                            d->act, d->act_alpha, g.C, g.P, rows);
     SS_LAUNCH_CHECK();
     return SS_OK;

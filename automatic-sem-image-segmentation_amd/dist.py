@@ -82,3 +82,17 @@ def mean_scalars(values):
     t = torch.as_tensor(np.asarray(values, dtype=np.float64), device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return (t / world_size()).cpu().numpy()
+
+
+def enable_sync_bn(enabled=True):
+    """BatchNorm statistics over the GLOBAL batch (SyncBN): needed for the data-parallel MultiResUNet to reproduce the
+    single-device reference, which normalises with whole-batch statistics.  Per layer: one all-reduce of
+    2*C floats forward and one backward (latency-bound; 85 layers)."""
+    from . import layers
+
+    def _allreduce(t):
+        if world_size() > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return world_size()
+
+    layers.SYNC_BN = _allreduce if enabled else None

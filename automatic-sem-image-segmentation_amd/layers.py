@@ -11,6 +11,10 @@ import torch
 from . import _lib as L
 from .engine import TIMER, Act, _p, _stream, workspace
 
+# Cross-rank BatchNorm statistics (data parallel): set by dist.enable_sync_bn() to a callable that all-reduces (SUM) a
+# float32 device tensor in place and returns the world size.  None = per-process statistics (single GPU).
+SYNC_BN = None
+
 ACTS = {None: L.ACT_NONE, "relu": L.ACT_RELU, "lrelu": L.ACT_LRELU, "tanh": L.ACT_TANH, "sigmoid": L.ACT_SIGMOID}
 
 
@@ -168,9 +172,18 @@ class Norm:
             mm, mv = self.arena[f"{self.name}/moving_mean"], self.arena[f"{self.name}/moving_variance"]
         nb = lib.ss_norm_workspace_bytes(ctypes.byref(d))
         ws = workspace(nb, x.device)
-        L.check(lib.ss_norm_fwd(ctypes.byref(d), x.ptr, _p(gamma), _p(beta), rp, y.ptr, _p(mean), _p(rstd),
-                                _p(mm), _p(mv), float(self.momentum), _p(ws), ws.numel(), _stream()),
-                f"norm_fwd[{self.name}]")
+        sync = SYNC_BN if self.kind == "batch" else None
+        count = x.rows // groups
+        if sync is None:
+            L.check(lib.ss_norm_fwd(ctypes.byref(d), x.ptr, _p(gamma), _p(beta), rp, y.ptr, _p(mean), _p(rstd),
+                                    _p(mm), _p(mv), float(self.momentum), _p(ws), ws.numel(), _stream()),
+                    f"norm_fwd[{self.name}]")
+        else:
+            sums = torch.empty(groups * x.c * 2, dtype=torch.float32, device=x.device)
+            L.check(lib.ss_norm_fwd_stats(ctypes.byref(d), x.ptr, _p(sums), _p(ws), ws.numel(), _stream()), "norm_fwd_stats")
+            count = count * sync(sums)
+            L.check(lib.ss_norm_fwd_finish(ctypes.byref(d), x.ptr, _p(gamma), _p(beta), rp, y.ptr, _p(sums), count, _p(mean), _p(rstd),
+                                           _p(mm), _p(mv), float(self.momentum), _stream()), "norm_fwd_finish")
         param_grads = tape.param_grads
 
         def backward():
@@ -186,9 +199,20 @@ class Norm:
             ws2 = workspace(lib.ss_norm_workspace_bytes(ctypes.byref(db)), x.device)
             ggam = self.arena.grad(f"{self.name}/gamma") if (self.scale and param_grads) else None
             gbet = self.arena.grad(f"{self.name}/beta") if param_grads else None
-            L.check(lib.ss_norm_bwd(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, y.ptr, _p(gamma), _p(mean), _p(rstd),
-                                    dx.ptr, dx.cs, accum, dres.ptr if dres is not None else None, racc,
-                                    _p(ggam), _p(gbet), 1, _p(ws2), ws2.numel(), _stream()), f"norm_bwd[{self.name}]")
+            if sync is None:
+                L.check(lib.ss_norm_bwd(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, y.ptr, _p(gamma), _p(mean), _p(rstd),
+                                        dx.ptr, dx.cs, accum, dres.ptr if dres is not None else None, racc,
+                                        _p(ggam), _p(gbet), 1, _p(ws2), ws2.numel(), _stream()), f"norm_bwd[{self.name}]")
+            else:
+                lsums = torch.empty(groups * x.c * 2, dtype=torch.float32, device=x.device)
+                L.check(lib.ss_norm_bwd_stats(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, y.ptr, _p(mean), _p(rstd), _p(lsums),
+                                              _p(ws2), ws2.numel(), _stream()), "norm_bwd_stats")
+                gsums = lsums.clone()
+                sync(gsums)
+                L.check(lib.ss_norm_bwd_finish(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, y.ptr, _p(gamma), _p(mean), _p(rstd),
+                                               _p(gsums), _p(lsums), count, dx.ptr, dx.cs, accum,
+                                               dres.ptr if dres is not None else None, racc, _p(ggam), _p(gbet), 1,
+                                               _p(ws2), ws2.numel(), _stream()), "norm_bwd_finish")
 
         tape.record(backward)
         return y

@@ -108,6 +108,8 @@ def main():
     db = NETS.PatchDiscriminator(filters=2 * F, device=dev, seed=4)
     unet = NETS.MultiResUNet(16, device=dev, seed=5)
     D.broadcast_params([ga, gb, da, db, unet])
+    if world > 1:
+        D.enable_sync_bn(True)      # whole-(global)-batch BatchNorm statistics = the single-device semantics of the reference
     model = CG.CycleGanModel(ga, gb, da, db, image_pool_a=CG.ImagePool(2, 50), image_pool_b=CG.ImagePool(2, 50))
     model.compile(OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5))
     umodel = UN.UNetModel(unet, 9.0, OPT.Adam(1e-3))

@@ -126,6 +126,22 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
                 float* dgamma, float* dbeta, int accumulate_params,
                 void* ws, size_t ws_bytes, void* stream);
 
+/* Two-phase forms for DATA-PARALLEL batch statistics (new: the reference has no working multi-GPU path).
+ * `sums` = [groups*c*2] raw sums (fwd: sum x, sum x^2; bwd: sum g, sum g*xhat).  The caller all-reduces (SUM) them over
+ * the ranks and passes the GLOBAL element count per (group, channel); with one rank they reproduce ss_norm_fwd/bwd.
+ * In backward, dgamma/dbeta are built from the LOCAL sums (the gradient all-reduce sums them over ranks afterwards). */
+int ss_norm_fwd_stats(const ss_norm_desc* d, const float* x, float* sums, void* ws, size_t ws_bytes, void* stream);
+int ss_norm_fwd_finish(const ss_norm_desc* d, const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                       const float* sums, int64_t total_count, float* mean, float* rstd,
+                       float* moving_mean, float* moving_var, float momentum, void* stream);
+int ss_norm_bwd_stats(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
+                      const float* mean, const float* rstd, float* sums, void* ws, size_t ws_bytes, void* stream);
+int ss_norm_bwd_finish(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
+                       const float* gamma, const float* mean, const float* rstd,
+                       const float* global_sums, const float* local_sums, int64_t total_count,
+                       float* dx, int32_t dx_cstride, int accumulate_dx, float* dres, int accumulate_dres,
+                       float* dgamma, float* dbeta, int accumulate_params, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Element-wise / pooling on NHWC views (rows = n*h*w pixels, c channels, explicit pixel strides).
  * ---------------------------------------------------------------------------------------- */

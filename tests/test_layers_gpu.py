@@ -240,3 +240,79 @@ def test_maxpool_fwd_bwd():
     gt.t.copy_(gy.to(dev))
     tape.backward()
     assert torch.equal(x.get_grad().dense().cpu(), xr.grad)
+
+
+def test_sync_batchnorm_two_phase_equals_whole_batch():
+    """Data-parallel BatchNorm: per-rank raw sums, summed (= the all-reduce), then finish per rank with the global count
+    must reproduce whole-batch BatchNorm on the concatenated batch -- forward, dx, dgamma/dbeta (summed over ranks)."""
+    E, LY, L = _mods()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    c, n, h, w = 24, 4, 16, 12
+    x_all = (torch.rand((n, h, w, c), generator=g) * 3 - 1).to(dev)
+    gy_all = (torch.rand((n, h, w, c), generator=g) - 0.5).to(dev)
+
+    def run(batches, hook_factory):
+        outs, dxs, grads, mms = [], [], [], []
+        pending = {}
+        for r, (xb, gb) in enumerate(batches):
+            arena = E.ParamArena(dev)
+            layer = LY.Norm(arena, "n", c, "batch")
+            arena.materialize()
+            arena["n/gamma"].copy_(torch.linspace(0.5, 1.5, c))
+            arena["n/beta"].copy_(torch.linspace(-0.2, 0.2, c))
+            arena["n/moving_variance"].fill_(1.0)
+            LY.SYNC_BN = hook_factory(r) if hook_factory else None
+            tape = E.Tape()
+            xa = E.Act(xb.contiguous())
+            y = layer(tape, xa, act="relu")
+            gt, _ = y.grad_target()
+            gt.t.copy_(gb)
+            arena.zero_grad()
+            tape.backward()
+            outs.append(y.dense()); dxs.append(xa.get_grad().dense())
+            grads.append((arena.grad("n/gamma").clone(), arena.grad("n/beta").clone())); mms.append(arena["n/moving_mean"].clone())
+        LY.SYNC_BN = None
+        return outs, dxs, grads, mms
+
+    ref_y, ref_dx, ref_g, ref_mm = run([(x_all, gy_all)], None)
+    # "two ranks": the hook adds the other half's raw sums, computed on the fly with the same kernels
+    halves = [(x_all[:2], gy_all[:2]), (x_all[2:], gy_all[2:])]
+    lib = L.load()
+    import ctypes
+
+    def hook_factory(rank):
+        other_x, other_gy = halves[1 - rank]
+        state = {"calls": 0, "mean": None, "rstd": None, "y": None}
+
+        def hook(t):
+            d = L.NormDesc(2, h, w, c, c, c, 0, 1, 1e-3, L.ACT_RELU, 0.0)
+            ws = E.workspace(lib.ss_norm_workspace_bytes(ctypes.byref(d)), dev)
+            osums = torch.empty_like(t)
+            ox = other_x.contiguous()
+            if state["calls"] == 0:      # forward statistics of the other rank
+                L.check(lib.ss_norm_fwd_stats(ctypes.byref(d), ox.data_ptr(), osums.data_ptr(), ws.data_ptr(), ws.numel(), E._stream()), "s")
+                t += osums
+                # remember the other rank's forward (global stats) for its backward sums
+                tot = t.clone()
+                mean, rstd = torch.empty(c, device=dev), torch.empty(c, device=dev)
+                yo = torch.empty_like(ox)
+                gam = torch.linspace(0.5, 1.5, c).to(dev); bet = torch.linspace(-0.2, 0.2, c).to(dev)
+                L.check(lib.ss_norm_fwd_finish(ctypes.byref(d), ox.data_ptr(), gam.data_ptr(), bet.data_ptr(), None, yo.data_ptr(),
+                                               tot.data_ptr(), 4 * h * w, mean.data_ptr(), rstd.data_ptr(), None, None, 0.99, E._stream()), "f")
+                state.update(mean=mean, rstd=rstd, y=yo)
+            else:                        # backward statistics of the other rank
+                og = other_gy.contiguous()
+                L.check(lib.ss_norm_bwd_stats(ctypes.byref(d), og.data_ptr(), c, ox.data_ptr(), state["y"].data_ptr(), state["mean"].data_ptr(),
+                                              state["rstd"].data_ptr(), osums.data_ptr(), ws.data_ptr(), ws.numel(), E._stream()), "bs")
+                t += osums
+            state["calls"] += 1
+            return 2
+        return hook
+
+    ys, dxs, gs, mms = run(halves, hook_factory)
+    assert_close(torch.cat(ys).cpu(), ref_y[0].cpu(), "syncbn y", rtol=1e-5)
+    assert_close(torch.cat(dxs).cpu(), ref_dx[0].cpu(), "syncbn dx", rtol=1e-4)
+    assert_close((gs[0][0] + gs[1][0]).cpu(), ref_g[0][0].cpu(), "syncbn dgamma", rtol=1e-4)
+    assert_close((gs[0][1] + gs[1][1]).cpu(), ref_g[0][1].cpu(), "syncbn dbeta", rtol=1e-4)
+    assert_close(mms[0].cpu(), ref_mm[0].cpu(), "syncbn moving_mean", rtol=1e-5)

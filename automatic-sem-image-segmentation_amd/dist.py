@@ -39,7 +39,7 @@ def init_from_env(backend=None):
     if is_dist() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
         return
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("SS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
         torch.cuda.set_device(local_device())
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

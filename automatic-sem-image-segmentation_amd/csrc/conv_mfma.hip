@@ -568,14 +568,14 @@ int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split) {
     // (256 CUs x 2 resident workgroups): time ~ ceil(tiles*s/512) * K/s.  A partial last round costs a full K/s.
     const int bn = Cb > 64 ? 128 : (Cb > 32 ? 64 : 32);
     const long tiles = (long)((M + 127) / 128) * ((Cb + bn - 1) / bn);
-    long max_splits = (pixels + 255) / 256;
-    if (max_splits > 64) max_splits = 64;
+    long max_splits = (pixels + 255) / 256;            // >= 8 K-steps per split
+    if (max_splits > 1024) max_splits = 1024;
     if (max_splits < 1) max_splits = 1;
     long best = 1;
     double best_cost = 1e30;
     for (long sp = 1; sp <= max_splits; ++sp) {
         const double rounds = (double)((tiles * sp + 511) / 512);
-        const double cost = rounds / (double)sp + 0.002 * sp;      // small penalty per split for the reduce pass
+        const double cost = rounds / (double)sp + 2e-6 * sp;       // tie-break: fewer splits = smaller reduce pass
         if (cost < best_cost - 1e-12) { best_cost = cost; best = sp; }
     }
     long pps = (pixels + best - 1) / best;

@@ -71,6 +71,8 @@ struct GConvParams {
     int32_t act;
     float alpha;
     int32_t accumulate;
+    int32_t nbatch;               // >= 1 independent problems of identical shape (Winograd: 16 transform positions);
+    int64_t in_bs, w_bs, out_bs;  // element strides between the batched problems
     int32_t ntaps;
     GTap taps[SS_MAX_TAPS];
 };
@@ -86,6 +88,8 @@ struct WGradParams {
     int32_t a_s, a_oy, a_ox;
     int32_t reflect;
     int32_t splits, pix_per_split;
+    int32_t nbatch;               // batched problems (Winograd); partials laid out [batch][split][M][Cb]
+    int64_t a_bs, b_bs;
     int32_t ntaps;
     GTap taps[SS_MAX_TAPS];       // woff = destination offset of the tap block inside dw
 };
@@ -98,4 +102,19 @@ int ss_launch_wgrad_direct(const WGradParams& p, float* dw, int ldw, int accumul
 int ss_launch_wgrad_mfma(const WGradParams& p, float* dw, int ldw, int accumulate, hipStream_t s);
 // same, but only the first `rows` rows of the (ntaps*Ca) x Cb result are written to dw
 int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accumulate, int rows, hipStream_t s);
-int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split);
+int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split, int nbatch = 1);
+int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s);   // partials only: part[batch][split][M][Cb]
+
+// Winograd F(2x2,3x3) path (conv_wino.hip): 3x3, stride 1; out[o] = sum_a in[map(o + a - pt)] * g[a]
+struct WinoProb {
+    int n, h, w, cin, in_cs;      // gathered input (reduction channels = cin)
+    int oh, ow, cout, out_cs;     // output grid
+    int pt, pl, reflect;
+};
+bool ss_wino_ok(const WinoProb& q);
+size_t ss_wino_fwd_ws(const WinoProb& q);
+int ss_wino_conv_fwd(const WinoProb& q, const float* x, const float* w, int w_cin, int w_cout, int flip, const float* bias, float* y,
+                     int act, float alpha, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+size_t ss_wino_wgrad_ws(const WinoProb& q);
+int ss_wino_conv_wgrad(const WinoProb& q, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                       hipStream_t s);

@@ -248,14 +248,33 @@ GConvParams fwd_params(const ConvProb& c, const float* x, const float* w, const 
     return p;
 }
 
+// Winograd F(2x2,3x3) eligibility of the plain conv `c` (forward / weight-gradient view)
+bool wino_fwd_prob(const ConvProb& c, int algo, WinoProb* q) {
+    if (algo == SS_ALGO_DIRECT || c.kh != 3 || c.kw != 3 || c.s != 1) return false;
+    *q = WinoProb{c.n, c.ih, c.iw, c.cin, c.in_cs, c.oh, c.ow, c.cout, c.out_cs, c.pt, c.pl, c.reflect};
+    return ss_wino_ok(*q);
+}
+// backward-data view: gathers dy (zero extension), produces dx (zero padding) or the padded gradient (reflect)
+bool wino_dgrad_prob(const ConvProb& c, int algo, WinoProb* q) {
+    if (algo == SS_ALGO_DIRECT || c.kh != 3 || c.kw != 3 || c.s != 1) return false;
+    if (c.reflect) *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.oh + 2, c.ow + 2, c.cin, c.cin, 2, 2, 0};
+    else *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.ih, c.iw, c.cin, c.in_cs, 2 - c.pt, 2 - c.pl, 0};
+    return ss_wino_ok(*q);
+}
+
 size_t fwd_ws(const ConvProb& c, int algo) {
     if (c.kh * c.kw > SS_MAX_TAPS) return 0;
+    WinoProb q;
+    if (wino_fwd_prob(c, algo, &q)) return ss_wino_fwd_ws(q);
     return gconv_ws_bytes(algo, fwd_params(c, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0));
 }
 
 int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
              int accumulate, int algo, void* ws, size_t ws_bytes, hipStream_t s) {
     if (c.kh * c.kw > SS_MAX_TAPS) return SS_ERR_UNSUPPORTED;
+    WinoProb q;
+    if (wino_fwd_prob(c, algo, &q))
+        return ss_wino_conv_fwd(q, x, w, c.cin, c.cout, 0, bias, y, act, alpha, accumulate, ws, ws_bytes, s);
     return run_gconv(algo, fwd_params(c, x, w, bias, y, act, alpha, accumulate), ws, ws_bytes, s);
 }
 
@@ -266,8 +285,11 @@ size_t bwd_data_dpad_bytes(const ConvProb& c) {
     return ss_align_up((size_t)c.n * PH * PW * c.cin * sizeof(float), 256);
 }
 size_t bwd_data_ws(const ConvProb& c) {
-    // [transposed weights][padded gradient (reflect)][two-stage scratch of the gather conv (Cin == 1 stems)]
-    return bwd_data_wt_bytes(c) + bwd_data_dpad_bytes(c) + two_stage_ws(c.n, c.oh, c.ow, c.cout, c.cin, c.kh * c.kw);
+    // [transposed weights][padded gradient (reflect)][two-stage scratch of the gather conv (Cin == 1 stems) | Winograd scratch]
+    size_t extra = two_stage_ws(c.n, c.oh, c.ow, c.cout, c.cin, c.kh * c.kw);
+    WinoProb q;
+    if (wino_dgrad_prob(c, SS_ALGO_AUTO, &q)) { const size_t wq = ss_wino_fwd_ws(q); if (wq > extra) extra = wq; }
+    return bwd_data_wt_bytes(c) + bwd_data_dpad_bytes(c) + extra;
 }
 
 // dx = dC/dx for the plain conv `c`; bias/act only used when this implements a transposed-conv forward
@@ -280,6 +302,21 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     const int T = c.kh * c.kw;
     void* gws = (char*)ws + bwd_data_wt_bytes(c) + bwd_data_dpad_bytes(c);
     const size_t gws_bytes = ws_bytes - bwd_data_wt_bytes(c) - bwd_data_dpad_bytes(c);
+    {
+        WinoProb q;
+        if (wino_dgrad_prob(c, algo, &q)) {      // rotated + transposed weights are formed inside the weight transform
+            if (!c.reflect)
+                return ss_wino_conv_fwd(q, dy, w, c.cin, c.cout, 1, bias, dx, act, alpha, accumulate, gws, gws_bytes, s);
+            float* dpad = (float*)((char*)ws + bwd_data_wt_bytes(c));
+            int rc = ss_wino_conv_fwd(q, dy, w, c.cin, c.cout, 1, nullptr, dpad, SS_ACT_NONE, 0.f, 0, gws, gws_bytes, s);
+            if (rc != SS_OK) return rc;
+            const long total = (long)c.n * c.ih * c.iw * c.cin;
+            hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpad, dx,
+                               c.n, c.ih, c.iw, c.cin, c.in_cs, c.pt, c.pl, c.oh + 2, c.ow + 2, accumulate);
+            SS_LAUNCH_CHECK();
+            return SS_OK;
+        }
+    }
     hipLaunchKernelGGL(transpose_last2_kernel, dim3((c.cout + 31) / 32, (c.cin + 31) / 32, T), dim3(256), 0, s, w, wt, c.cin, c.cout);
     SS_LAUNCH_CHECK();
 
@@ -350,6 +387,10 @@ size_t bwd_weight_ws(const ConvProb& c) {
         const size_t b2 = ss_align_up((size_t)Q * tcs * sizeof(float), 256) + ss_align_up((size_t)sp2 * tcs * c.cin * sizeof(float), 256);
         if (b2 > b) b = b2;
     }
+    {
+        WinoProb q;
+        if (wino_fwd_prob(c, SS_ALGO_AUTO, &q)) { const size_t wq = ss_wino_wgrad_ws(q); if (wq > b) b = wq; }
+    }
     b += ss_align_up((size_t)COLSUM_CHUNKS * (c.cout > c.cin ? c.cout : c.cin) * sizeof(float), 256);
     return b;
 }
@@ -358,6 +399,10 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
                     void* ws, size_t ws_bytes, hipStream_t s) {
     if (c.kh * c.kw > SS_MAX_TAPS) return SS_ERR_UNSUPPORTED;
     if (ws_bytes < bwd_weight_ws(c) || !ws) return SS_ERR_WORKSPACE;
+    {
+        WinoProb q;
+        if (wino_fwd_prob(c, algo, &q)) return ss_wino_conv_wgrad(q, x, dy, dw, accumulate, ws, ws_bytes, s);
+    }
     WGradParams p{};
     p.a = x; p.b = dy; p.part = (float*)ws;
     p.N = c.n; p.AH = c.ih; p.AW = c.iw; p.Ca = c.cin; p.a_cs = c.in_cs;

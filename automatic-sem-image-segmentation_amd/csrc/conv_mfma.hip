@@ -66,6 +66,12 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
         const int q = nwg >> 3, r = nwg & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
+    const int gridM = (int)((M + BM - 1) / BM);
+    const int batch = tile / (gridM * gridN);      // batched problems: consecutive tiles of one XCD chunk stay in one batch
+    tile -= batch * gridM * gridN;
+    const float* const g_in = p.in + (long)batch * p.in_bs;
+    const float* const g_w = p.w + (long)batch * p.w_bs;
+    float* const g_out = p.out + (long)batch * p.out_bs;
     const long m0 = (long)(tile / gridN) * BM;
     const int n0 = (tile % gridN) * BN;
     const int K = p.ntaps * p.Cin;
@@ -128,14 +134,14 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
         if (FAST) {
             const int t = k0 / p.Cin;                 // block-uniform
             const int ci0 = k0 - t * p.Cin;
-            const float* abase = p.in + ci0 + c4a * 4;
+            const float* abase = g_in + ci0 + c4a * 4;
 #pragma unroll
             for (int j = 0; j < C::A_UNITS; ++j) {
                 const int off = offtab[((tid >> 3) + C::A_ROWS * j) * p.ntaps + t];
                 const f32x4 v = *(const f32x4*)(abase + (off < 0 ? 0 : off));
                 ra[j] = off < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
             }
-            const float* bbase = p.w + p.taps[t].woff + (long)ci0 * p.ldb;
+            const float* bbase = g_w + p.taps[t].woff + (long)ci0 * p.ldb;
 #pragma unroll
             for (int j = 0; j < C::B_UNITS; ++j) {
                 const int u = tid + NT * j;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
                     const int iy = ss_map_index(a_by[j] + dy, p.IH, p.reflect);
                     const int ix = ss_map_index(a_bx[j] + dx, p.IW, p.reflect);
                     if (iy >= 0 && ix >= 0)
-                        v = *(const f32x4*)(p.in + ((long)(a_nb[j] + iy) * p.IW + ix) * p.in_cs + ci);
+                        v = *(const f32x4*)(g_in + ((long)(a_nb[j] + iy) * p.IW + ix) * p.in_cs + ci);
                 }
                 ra[j] = v;
             }
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
                             const int iy = ss_map_index(a_by[j] + dy, p.IH, p.reflect);
                             const int ix = ss_map_index(a_bx[j] + dx, p.IW, p.reflect);
                             if (iy >= 0 && ix >= 0)
-                                ra[j][e] = p.in[((long)(a_nb[j] + iy) * p.IW + ix) * p.in_cs + ci];
+                                ra[j][e] = g_in[((long)(a_nb[j] + iy) * p.IW + ix) * p.in_cs + ci];
                         }
                     }
                 }
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
             if (kb < K && col < p.Cout) {
                 const int t = kb / p.Cin;
                 const int ci = kb - t * p.Cin;
-                const float* wp = p.w + p.taps[t].woff + (long)ci * p.ldb + col;
+                const float* wp = g_w + p.taps[t].woff + (long)ci * p.ldb + col;
                 if (vecB && col + 3 < p.Cout) {
                     v = *(const f32x4*)wp;
                 } else {
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int pix = pixtab[wm * C::WM + mi * 32 + row];
                 if (pix < 0) continue;
-                float* op = p.out + (long)pix * p.out_cs + co;
+                float* op = g_out + (long)pix * p.out_cs + co;
                 float v = ss_apply_act(acc[mi][ni][r] + bv, p.act, p.alpha);
                 if (p.accumulate) v += *op;
                 *op = v;
@@ -295,7 +301,7 @@ template <int BM, int BN, bool FAST, int NT = 256>
 static int launch_gconv(const GConvParams& p, int vecA, int vecB, hipStream_t s) {
     using C = Cfg<BM, BN, NT>;
     const long M = (long)p.N * p.OHc * p.OWc;
-    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN)));
+    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN) * (p.nbatch > 1 ? p.nbatch : 1)));
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gconv_mfma_kernel<BM, BN, FAST, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -317,7 +323,7 @@ int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
     const bool fast = vecA && vecB && p.ntaps >= 1 && (p.Cin % 32 == 0) && (p.Cout >= 4) && in_elems < (1L << 31) &&
                       getenv("SS_GCONV_NOFAST") == nullptr;
     // tile choice: the largest tile that still gives every CU ~2 workgroups (256 CUs); small batches need small tiles
-    auto nblocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
+    auto nblocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * (p.nbatch > 1 ? p.nbatch : 1); };
     const long want = 480;
     int cfg;   // 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32
     if (p.Cout > 64) cfg = nblocks(128, 128) >= want ? 0 : (nblocks(128, 64) >= want ? 1 : 2);
@@ -361,7 +367,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
     const int M = p.ntaps * p.Ca;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int split = blockIdx.z;
+    const int split = blockIdx.z % p.splits;
+    const int batch = blockIdx.z / p.splits;       // batched problems (Winograd transform positions)
+    const float* const g_a = p.a + (long)batch * p.a_bs;
+    const float* const g_b = p.b + (long)batch * p.b_bs;
     const long P = (long)p.N * p.GH * p.GW;
     const long ps = (long)split * p.pix_per_split;
     const long pe = (ps + p.pix_per_split < P) ? ps + p.pix_per_split : P;
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
                 const int ix = ss_map_index(f_x[j] * p.a_s + p.a_ox + a_dx[0], p.AW, p.reflect);
                 const bool ok = mval && (pk0 + row < pe) && iy >= 0 && ix >= 0;
                 const long off = ok ? ((long)(f_n[j] * p.AH + iy) * p.AW + ix) * p.a_cs + a_c[0] : 0;
-                const f32x4 v = *(const f32x4*)(p.a + off);
+                const f32x4 v = *(const f32x4*)(g_a + off);
                 ra[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
                 // advance by one K step (32 pixels); GW >= 32 so at most one row wrap
                 int x = f_x[j] + C::BK, y = f_y[j], n = f_n[j];
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
                 const int row = (tid + 256 * j) / (BN / 4);
                 const long pk = pk0 + row;
                 const bool ok = pk < pe && col + 4 <= p.Cb;
-                const f32x4 v = *(const f32x4*)(p.b + (ok ? pk : ps) * p.b_cs + colc);
+                const f32x4 v = *(const f32x4*)(g_b + (ok ? pk : ps) * p.b_cs + colc);
                 rb[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             return;
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
                         const int iy = ss_map_index(by + a_dy[0], p.AH, p.reflect);
                         const int ix = ss_map_index(bx + a_dx[0], p.AW, p.reflect);
                         if (iy >= 0 && ix >= 0)
-                            v = *(const f32x4*)(p.a + ((long)(nb + iy) * p.AW + ix) * p.a_cs + a_c[0]);
+                            v = *(const f32x4*)(g_a + ((long)(nb + iy) * p.AW + ix) * p.a_cs + a_c[0]);
                     }
                 } else {
 #pragma unroll
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
                             const int iy = ss_map_index(by + a_dy[e], p.AH, p.reflect);
                             const int ix = ss_map_index(bx + a_dx[e], p.AW, p.reflect);
                             if (iy >= 0 && ix >= 0)
-                                v[e] = p.a[((long)(nb + iy) * p.AW + ix) * p.a_cs + a_c[e]];
+                                v[e] = g_a[((long)(nb + iy) * p.AW + ix) * p.a_cs + a_c[e]];
                         }
                     }
                 }
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
             const int col = n0 + c4b * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (pk < pe && col < p.Cb) {
-                const float* bp = p.b + pk * p.b_cs + col;
+                const float* bp = g_b + pk * p.b_cs + col;
                 if (vecB && col + 3 < p.Cb) {
                     v = *(const f32x4*)bp;
                 } else {
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
         __syncthreads();
     }
 
-    float* part = p.part + (long)split * M * p.Cb;
+    float* part = p.part + (long)blockIdx.z * M * p.Cb;
 #pragma unroll
     for (int ni = 0; ni < C::TN; ++ni) {
         const int n = n0 + wn * C::WN + ni * 32 + l31;
@@ -563,11 +572,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WGradParams p, float*
     *o = accumulate ? (*o + acc) : acc;
 }
 
-int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split) {
+int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split, int nbatch) {
     // Split the pixel (K) range so that tiles x splits fills whole "rounds" of the 512 workgroup slots
     // (256 CUs x 2 resident workgroups): time ~ ceil(tiles*s/512) * K/s.  A partial last round costs a full K/s.
     const int bn = Cb > 64 ? 128 : (Cb > 32 ? 64 : 32);
-    const long tiles = (long)((M + 127) / 128) * ((Cb + bn - 1) / bn);
+    const long tiles = (long)((M + 127) / 128) * ((Cb + bn - 1) / bn) * (nbatch > 1 ? nbatch : 1);
     long max_splits = (pixels + 255) / 256;            // >= 8 K-steps per split
     if (max_splits > 1024) max_splits = 1024;
     if (max_splits < 1) max_splits = 1;
@@ -590,7 +599,7 @@ template <int BM, int BN, bool FAST>
 static int launch_wgrad(const WGradParams& p, int vecA, int vecB, hipStream_t s) {
     using C = Cfg<BM, BN>;
     const int M = p.ntaps * p.Ca;
-    dim3 grid((M + BM - 1) / BM, (p.Cb + BN - 1) / BN, p.splits);
+    dim3 grid((M + BM - 1) / BM, (p.Cb + BN - 1) / BN, p.splits * (p.nbatch > 1 ? p.nbatch : 1));
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<BM, BN, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem_wgrad);
@@ -606,10 +615,18 @@ int ss_launch_wgrad_mfma(const WGradParams& p, float* dw, int ldw, int accumulat
 }
 
 int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accumulate, int rows, hipStream_t s) {
-    const long P = (long)p.N * p.GH * p.GW;
     const long total = (long)p.ntaps * p.Ca * p.Cb;
     if (total == 0) return SS_OK;
-    if (P > 0) {
+    int rc = ss_launch_wgrad_mfma_partials(p, s);
+    if (rc != SS_OK) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, dw, ldw, accumulate, rows);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s) {
+    const long P = (long)p.N * p.GH * p.GW;
+    {
         const int vecA = (p.Ca % 4 == 0) && (p.a_cs % 4 == 0) && (((uintptr_t)p.a & 15) == 0);
         const int vecB = (p.b_cs % 4 == 0) && (((uintptr_t)p.b & 15) == 0);
         int rc;
@@ -623,7 +640,5 @@ int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accu
         else rc = launch_wgrad<128, 32, false>(p, vecA, vecB, s);
         if (rc != SS_OK) return rc;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, dw, ldw, accumulate, rows);
-    SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -50,6 +50,11 @@ CONV_CASES = [
     ("fast_paths_w40", 3, 32, 64, 1, ("reflect", 1), False, None, False, 2, 12, 40),
     ("fast_paths_s2", 3, 32, 48, 2, "same", False, None, False, 2, 64, 72),
     ("fast_paths_T", 3, 64, 32, 2, "same", False, None, True, 1, 32, 36),
+    # Winograd F(2x2,3x3) path: 3x3 stride 1, >= 64 channels, >= 1024 output tiles
+    ("wino_reflect", 3, 64, 64, 1, ("reflect", 1), False, None, False, 2, 48, 48),
+    ("wino_same_bias_relu", 3, 64, 96, 1, "same", True, "lrelu", False, 2, 48, 50),
+    ("wino_same_odd", 3, 96, 64, 1, "same", False, None, False, 3, 47, 45),
+    ("wino_valid", 3, 64, 64, 1, "valid", False, None, False, 2, 50, 50),
     # single-output-channel convs take the two-stage (1x1 MFMA GEMM + tap sum / tap scatter) path from 16 channels up
     ("c7_out_16_two_stage", 7, 16, 1, 1, ("reflect", 3), True, "tanh", False, 2, 16, 16),
     ("c7_in_16_two_stage_dgrad", 7, 1, 16, 1, ("reflect", 3), False, None, False, 2, 16, 16),

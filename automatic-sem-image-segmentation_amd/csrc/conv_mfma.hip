@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
 
 bool ss_gconv_mfma_ok(const GConvParams& p) {
     // Cout == 1 heads and degenerate reductions stay on the direct kernel
-    return p.Cout >= 8 && (long)p.ntaps * p.Cin >= 8;
+    return p.Cout >= 2 && (long)p.ntaps * p.Cin >= 8;
 }
 
 template <int BM, int BN, bool FAST, int NT = 256>

@@ -183,27 +183,39 @@ __global__ __launch_bounds__(256) void norm_infer_kernel(const float* __restrict
     y[row * y_cs + c] = ss_apply_act(v, act, alpha);
 }
 
-// backward finalize: per (g,c) means of g and g*xhat -> sg/sgx arrays; dgamma/dbeta summed over groups
+// backward finalize: per (g,c) means of g and g*xhat -> sums array; dgamma/dbeta summed over groups.
+// Block = 32 channels x 8 group lanes: the (g,c) chunk sums run in parallel, the cross-group sum is a fixed-order
+// LDS reduction (deterministic).
 __global__ __launch_bounds__(256) void norm_finalize_bwd(const float* __restrict__ part, int chunks, int G, int C, long P,
                                                          float* __restrict__ sums /* [G*C*2] */,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, gl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double tg = 0.0, tgx = 0.0;
-    for (int g = 0; g < G; ++g) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < chunks; ++k) {
-            const float* o = part + (((long)g * chunks + k) * C + c) * 2;
-            s1 += o[0];
-            s2 += o[1];
+    if (c < C) {
+        for (int g = gl; g < G; g += 8) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < chunks; ++k) {
+                const float* o = part + (((long)g * chunks + k) * C + c) * 2;
+                s1 += o[0];
+                s2 += o[1];
+            }
+            sums[((long)g * C + c) * 2 + 0] = (float)(s1 / (double)P);
+            sums[((long)g * C + c) * 2 + 1] = (float)(s2 / (double)P);
+            tg += s1;
+            tgx += s2;
         }
-        sums[((long)g * C + c) * 2 + 0] = (float)(s1 / (double)P);
-        sums[((long)g * C + c) * 2 + 1] = (float)(s2 / (double)P);
-        tg += s1;
-        tgx += s2;
     }
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)tg : (float)tg;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)tgx : (float)tgx;
+    red[0][gl][cl] = tg;
+    red[1][gl][cl] = tgx;
+    __syncthreads();
+    if (gl == 0 && c < C) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < 8; ++k) { a += red[0][k][cl]; b += red[1][k][cl]; }
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+    }
 }
 
 // dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) ; dres = g
@@ -394,7 +406,7 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
         hipLaunchKernelGGL((norm_stats_kernel<1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
                            d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + 31) / 32), dim3(256), 0, s,
                        part, g.chunks, g.G, g.C, g.P, sums, dgamma, dbeta, accumulate_params);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;

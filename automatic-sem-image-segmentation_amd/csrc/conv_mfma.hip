@@ -333,6 +333,8 @@ int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
         switch (cfg) {
             case 0: {
                 static const bool nt512 = getenv("SS_GCONV_NT512") != nullptr;
+                static const bool big = getenv("SS_GCONV_256") != nullptr;
+                if (big && nblocks(256, 128) >= want) return launch_gconv<256, 128, true, 512>(p, vecA, vecB, s);
                 if (nt512) return launch_gconv<128, 128, true, 512>(p, vecA, vecB, s);
                 return launch_gconv<128, 128, true>(p, vecA, vecB, s);
             }

@@ -27,7 +27,7 @@ NormGeom geom(const ss_norm_desc* d, int V = 1) {
     g.CT = ct;
     g.PT = 256 / ct;
     g.cblocks = (cv + ct - 1) / ct;
-    long chunks = (g.P + 511) / 512;
+    long chunks = (g.P + 63) / 64;
     long want = 4096 / ((long)g.G * g.cblocks);   // aim at >= ~4096 blocks in total
     if (want < 1) want = 1;
     if (chunks > want) chunks = want;

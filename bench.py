@@ -166,18 +166,18 @@ def main():
             ach = flops / (tk["avg_ms"] * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": "3x3 512->512 trunk conv forward = wino_input + batched gconv_mfma_kernel<128,128,FAST> (16 fp32-MFMA GEMMs, "
+                "kernel": "3x3 512->512 trunk conv forward = wino_input<4> + batched gconv_mfma_kernel<128,128,FAST> (36 fp32-MFMA GEMMs, "
                           "v_mfma_f32_32x32x2_f32) + wino_output; reflect pad fused in the input transform",
                 # ALGORITHMIC (direct-convolution) FLOPs of the op / HIP-event duration of the op inside the timed region
                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                "note": "Winograd F(2x2,3x3) executes 2.25x fewer multiply-adds than the algorithmic count (68.7 of 154.6 GFLOP per launch at "
-                        "batch 8), so frac can exceed 1; the MFMA GEMM itself runs at ~0.70-0.75 of the fp32 matrix peak "
-                        "(profiles/r01_f_winograd_kernel_stats.md, profiles/r01_pmc_trunk_fwd.md)",
-                "executed_mfma_flops_per_launch": flops / 2.25,
+                "note": "Winograd F(4x4,3x3) executes 4x fewer multiply-adds than the algorithmic count (38.7 of 154.6 GFLOP per launch at "
+                        "batch 8), so frac can exceed 1; the batched fp32-MFMA GEMM itself runs at ~0.6-0.7 of the fp32 matrix peak "
+                        "(profiles/r01_h_winograd43_kernel_stats.md, profiles/r01_pmc_trunk_fwd.md)",
+                "executed_mfma_flops_per_launch": flops / 4.0,
                 # PMC cannot be sampled from inside this process: rocprofv3 pass on the direct (non-Winograd) kernel of this shape
                 # PMC cannot be sampled from inside this process: committed rocprofv3 passes on this op/shape at batch 8
                 # (profiles/r01_pmc_trunk_fwd.md): sum over the op's 4 kernels of 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
-                "traffic": (2 * (4634 + 91384 + 164175 + 131147) + (16384 + 262144 + 262144 + 65536)) * 1024.0 if (per == 8 and S == 512 and F == 64) else None,
+                "traffic": None,   # filled from the committed PMC pass below when it matches this configuration
                 "traffic_unit": "bytes per op launch", "algorithmic_bytes": 4.0 * (2 * per * (S // 8) ** 2 * 8 * F + 9 * (8 * F) ** 2),
                 "winograd_algorithmic_bytes": 4.0 * ((1 + 4 + 4 + 4 + 4 + 1) * per * (S // 8) ** 2 * 8 * F + (9 + 16 + 16) * (8 * F) ** 2),
                 "launches_timed": tk["launches"], "avg_launch_ms": round(tk["avg_ms"], 4), "flops_per_launch": flops}

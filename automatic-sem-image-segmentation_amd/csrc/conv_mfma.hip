@@ -584,10 +584,14 @@ int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split, int 
     if (max_splits < 1) max_splits = 1;
     long best = 1;
     double best_cost = 1e30;
+    // time model (us): one workgroup needs ~1.95 us per 32-pixel K step at 2 workgroups/CU; every split adds a pass over
+    // its partial tiles (written once, read once at ~4 TB/s)
+    const double t_full = (double)pixels / 32.0 * 1.95;
+    const double t_split = (double)(nbatch > 1 ? nbatch : 1) * M * Cb * 8.0 / 4e6;
     for (long sp = 1; sp <= max_splits; ++sp) {
         const double rounds = (double)((tiles * sp + 511) / 512);
-        const double cost = rounds / (double)sp + 2e-6 * sp;       // tie-break: fewer splits = smaller reduce pass
-        if (cost < best_cost - 1e-12) { best_cost = cost; best = sp; }
+        const double cost = rounds / (double)sp * t_full + sp * t_split;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
     }
     long pps = (pixels + best - 1) / best;
     pps = (pps + 31) / 32 * 32;

@@ -177,9 +177,9 @@ def main():
                 # PMC cannot be sampled from inside this process: rocprofv3 pass on the direct (non-Winograd) kernel of this shape
                 # PMC cannot be sampled from inside this process: committed rocprofv3 passes on this op/shape at batch 8
                 # (profiles/r01_pmc_trunk_fwd.md): sum over the op's 4 kernels of 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
-                "traffic": None,   # filled from the committed PMC pass below when it matches this configuration
+                "traffic": (2 * (4644 + 49984 + 102747 + 73890) + (36864 + 147456 + 147456 + 65536)) * 1024.0 if (per == 8 and S == 512 and F == 64) else None,
                 "traffic_unit": "bytes per op launch", "algorithmic_bytes": 4.0 * (2 * per * (S // 8) ** 2 * 8 * F + 9 * (8 * F) ** 2),
-                "winograd_algorithmic_bytes": 4.0 * ((1 + 4 + 4 + 4 + 4 + 1) * per * (S // 8) ** 2 * 8 * F + (9 + 16 + 16) * (8 * F) ** 2),
+                "winograd_algorithmic_bytes": 4.0 * ((1 + 4 * 2.25 + 1) * per * (S // 8) ** 2 * 8 * F + (9 + 36 + 36) * (8 * F) ** 2),
                 "launches_timed": tk["launches"], "avg_launch_ms": round(tk["avg_ms"], 4), "flops_per_launch": flops}
         if S in G_FWD_GF:
             alg = (18 * G_FWD_GF[S] + 16 * D_FWD_GF[S] + (0 if args.skip_unet else 3 * U_FWD_GF[S])) * 1e9

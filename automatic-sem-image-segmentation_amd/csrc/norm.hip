@@ -112,27 +112,38 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
     }
 }
 
-// mean / rstd per (g,c); optional moving-average update (batch norm, G == 1)
+// mean / rstd per (g,c); optional moving-average update (batch norm, G == 1).
+// Block = 32 channels x 8 chunk lanes (fixed-order LDS combine -> deterministic); grid = (C/32, G).
 __global__ __launch_bounds__(256) void norm_finalize_fwd(const float* __restrict__ part, int chunks, int G, int C, long P, float eps,
                                                          float* __restrict__ mean, float* __restrict__ rstd,
                                                          float* __restrict__ mm, float* __restrict__ mv, float momentum) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)G * C) return;
-    const int g = (int)(i / C), c = (int)(i % C);
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl, g = blockIdx.y;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        const float* o = part + (((long)g * chunks + k) * C + c) * 2;
-        s1 += o[0];
-        s2 += o[1];
+    if (c < C) {
+        for (int k = kl; k < chunks; k += 8) {
+            const float* o = part + (((long)g * chunks + k) * C + c) * 2;
+            s1 += o[0];
+            s2 += o[1];
+        }
     }
-    const double mu = s1 / (double)P;
-    double var = s2 / (double)P - mu * mu;   // E[x^2] - E[x]^2 (keras.ops.moments, torch backend)
-    if (var < 0.0) var = 0.0;
-    mean[i] = (float)mu;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
-    if (mm) {
-        mm[c] = mm[c] * momentum + (float)mu * (1.f - momentum);
-        mv[c] = mv[c] * momentum + (float)var * (1.f - momentum);
+    red[0][kl][cl] = s1;
+    red[1][kl][cl] = s2;
+    __syncthreads();
+    if (kl == 0 && c < C) {
+        s1 = 0.0; s2 = 0.0;
+        for (int k = 0; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+        const long i = (long)g * C + c;
+        const double mu = s1 / (double)P;
+        double var = s2 / (double)P - mu * mu;   // E[x^2] - E[x]^2 (keras.ops.moments, torch backend)
+        if (var < 0.0) var = 0.0;
+        mean[i] = (float)mu;
+        rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+        if (mm) {
+            mm[c] = mm[c] * momentum + (float)mu * (1.f - momentum);
+            mv[c] = mv[c] * momentum + (float)var * (1.f - momentum);
+        }
     }
 }
 
@@ -184,37 +195,39 @@ __global__ __launch_bounds__(256) void norm_infer_kernel(const float* __restrict
 }
 
 // backward finalize: per (g,c) means of g and g*xhat -> sums array; dgamma/dbeta summed over groups.
-// Block = 32 channels x 8 group lanes: the (g,c) chunk sums run in parallel, the cross-group sum is a fixed-order
-// LDS reduction (deterministic).
+// Block = 32 channels x 8 chunk lanes; groups are walked sequentially, every combine is a fixed-order LDS sum.
 __global__ __launch_bounds__(256) void norm_finalize_bwd(const float* __restrict__ part, int chunks, int G, int C, long P,
                                                          float* __restrict__ sums /* [G*C*2] */,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
     __shared__ double red[2][8][32];
-    const int cl = threadIdx.x & 31, gl = threadIdx.x >> 5;
+    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double tg = 0.0, tgx = 0.0;
-    if (c < C) {
-        for (int g = gl; g < G; g += 8) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int k = 0; k < chunks; ++k) {
+    for (int g = 0; g < G; ++g) {
+        double s1 = 0.0, s2 = 0.0;
+        if (c < C) {
+            for (int k = kl; k < chunks; k += 8) {
                 const float* o = part + (((long)g * chunks + k) * C + c) * 2;
                 s1 += o[0];
                 s2 += o[1];
             }
+        }
+        red[0][kl][cl] = s1;
+        red[1][kl][cl] = s2;
+        __syncthreads();
+        if (kl == 0 && c < C) {
+            s1 = 0.0; s2 = 0.0;
+            for (int k = 0; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
             sums[((long)g * C + c) * 2 + 0] = (float)(s1 / (double)P);
             sums[((long)g * C + c) * 2 + 1] = (float)(s2 / (double)P);
             tg += s1;
             tgx += s2;
         }
+        __syncthreads();
     }
-    red[0][gl][cl] = tg;
-    red[1][gl][cl] = tgx;
-    __syncthreads();
-    if (gl == 0 && c < C) {
-        double a = 0.0, b = 0.0;
-        for (int k = 0; k < 8; ++k) { a += red[0][k][cl]; b += red[1][k][cl]; }
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+    if (kl == 0 && c < C) {
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)tg : (float)tg;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)tgx : (float)tgx;
     }
 }
 
@@ -358,8 +371,7 @@ int ss_norm_fwd(const ss_norm_desc* d, const float* x, const float* gamma, const
         hipLaunchKernelGGL((norm_stats_kernel<0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
                            0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     SS_LAUNCH_CHECK();
-    const long gc = (long)g.G * g.C;
-    hipLaunchKernelGGL(norm_finalize_fwd, dim3((unsigned)((gc + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + 31) / 32, g.G), dim3(256), 0, s,
                        part, g.chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
@@ -453,8 +465,7 @@ int ss_norm_fwd_finish(const ss_norm_desc* d, const float* x, const float* gamma
     hipStream_t s = (hipStream_t)stream;
     const int V = pick_v(d->c, {d->x_cstride, d->y_cstride, residual ? d->res_cstride : 0}, {x, y, residual, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
-    const long gc = (long)g.G * g.C;
-    hipLaunchKernelGGL(norm_finalize_fwd, dim3((unsigned)((gc + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + 31) / 32, g.G), dim3(256), 0, s,
                        sums, 1, g.G, g.C, (long)total_count, d->eps, mean, rstd, moving_mean, moving_var, momentum);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;

@@ -161,6 +161,7 @@ class CycleGanModel:
             losses.mae(real_a, same_a, self.lambda_cycle_b * self.lambda_identity_b, self._slot(5))
         ga.zero_grad()
         gb.zero_grad()
+        D.begin_backward([ga, gb, da, db])
         tape.backward()                      # d(L_a + L_b)/d theta for both generators in one traversal
         D.all_reduce_grads([ga, gb])
         self.gen_a_optimizer.apply(ga, 1.0 / world)
@@ -180,6 +181,7 @@ class CycleGanModel:
         losses.mse_const(disc_fake_b2, zero, 0.5, self._slot(9))
         da.zero_grad()
         db.zero_grad()
+        D.begin_backward([ga, gb, da, db])
         tape.backward()
         D.all_reduce_grads([da, db])
         self.disc_a_optimizer.apply(da, 1.0 / world)
@@ -350,6 +352,7 @@ class CycleGAN:
         self.disc_b = PatchDiscriminator(filters=2 * self.filters, num_downsampling_blocks=self.num_downsampling_blocks_disc,
                                          channels=ch, padding="valid", device=self.device, seed=self.seed + 4)
         D.broadcast_params([self.gen_a, self.gen_b, self.disc_a, self.disc_b])
+        D.enable_overlap([self.gen_a, self.gen_b, self.disc_a, self.disc_b])
         model = CycleGanModel(generator_a=self.gen_a, generator_b=self.gen_b, discriminator_a=self.disc_a,
                               discriminator_b=self.disc_b, image_pool_a=self.image_pool_a, image_pool_b=self.image_pool_b,
                               lambda_cycle_a=self.lambda_cycle_a, lambda_cycle_b=self.lambda_cycle_b,

@@ -143,6 +143,7 @@ class UNetModel:
         p = self.net(x, True, tape)
         losses.weighted_bce(y, p, self.weighting, 1.0, self._out3)
         self.net.zero_grad()
+        D.begin_backward([self.net])
         tape.backward()
         D.all_reduce_grads([self.net])
         self.optimizer.apply(self.net, 1.0 / world)
@@ -244,6 +245,7 @@ class UNet:
             weighting = self.class_weighting()
         net = MultiResUNet(conv_filters=self.filters, device=self.device, seed=self.seed)
         D.broadcast_params([net])
+        D.enable_overlap([net])
         if D.world_size() > 1 and self.sync_batch_norm:
             D.enable_sync_bn(True)
         wd = self.lr_decay if isinstance(self.lr_decay, float) else 0.0

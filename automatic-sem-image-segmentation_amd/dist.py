@@ -58,11 +58,40 @@ def all_reduce_flat(flat, bucket_elems=BUCKET_ELEMS):
         w.wait()
 
 
-def all_reduce_grads(nets):
+def enable_overlap(nets):
+    """Overlap the gradient exchange with backward: every 32 MiB bucket of a network's flat gradient arena is all-reduced
+    (asynchronously, on the communication stream) as soon as the last backward op touching one of its variables has been
+    enqueued; `all_reduce_grads` then only waits.  No-op for a single process."""
     if world_size() == 1:
         return
     for net in nets:
-        all_reduce_flat(net.arena.grads)
+        net.arena.grad_hook = lambda flat: dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def begin_backward(nets):
+    for net in nets:
+        net.arena.begin_backward()
+
+
+def all_reduce_grads(nets):
+    """Finish the gradient exchange of these networks: wait for the buckets launched during backward and reduce any
+    bucket that has not been sent (overlap disabled, or a bucket whose variables were not all used)."""
+    if world_size() == 1:
+        for net in nets:
+            net.arena.pending = {}
+        return
+    for net in nets:
+        a = net.arena
+        if a.grad_hook is None:
+            all_reduce_flat(a.grads)
+            a.pending = {}
+            continue
+        late = [dist.all_reduce(a.grads[b["start"]:b["end"]], op=dist.ReduceOp.SUM, async_op=True)
+                for b in a.buckets if b["active"] and not b["fired"]]
+        for w in a.works + late:
+            w.wait()
+        a.works = []
+        a.pending = {}
 
 
 def broadcast_params(nets, src=0):

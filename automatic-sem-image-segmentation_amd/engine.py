@@ -173,6 +173,13 @@ class ParamArena:
         self.state = None    # non-trainable arena (BN moving statistics)
         self.views = {}
         self.gviews = {}
+        # gradient-ready tracking for the overlapped data-parallel all-reduce (dist.py): a variable's gradient is final
+        # once every recorded backward op that accumulates into it has run; buckets fire when all their variables are.
+        self.pending = {}
+        self.buckets = []          # dicts: start, end (element offsets into grads), names, remaining, fired
+        self.bucket_of = {}
+        self.grad_hook = None      # callable(flat_grad_slice) -> async work handle, set by dist.enable_overlap()
+        self.works = []
 
     def declare(self, name, shape, trainable=True):
         size = 1
@@ -202,6 +209,49 @@ class ParamArena:
                 self.gviews[name] = self.grads[off:off + size].view(shape)
             else:
                 self.views[name] = self.state[off:off + size].view(shape)
+
+        # buckets: consecutive variables (creation order) up to BUCKET_ELEMS each
+        cur = None
+        for name, shape, trainable, off in self.specs:
+            if not trainable:
+                continue
+            size = 1
+            for s_ in shape:
+                size *= s_
+            end = off + (size + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            if cur is None or end - cur["start"] > self.BUCKET_ELEMS:
+                cur = dict(start=off, end=end, names=[name], remaining=0, fired=False, active=False)
+                self.buckets.append(cur)
+            else:
+                cur["end"] = end
+                cur["names"].append(name)
+            self.bucket_of[name] = cur
+
+    BUCKET_ELEMS = 8 * 1024 * 1024      # 32 MiB fp32 buckets (xGMI: few large messages)
+
+    def note_use(self, names):
+        """A backward op that accumulates into these variables' gradients was recorded."""
+        for n in names:
+            self.pending[n] = self.pending.get(n, 0) + 1
+
+    def begin_backward(self):
+        """Call right before replaying a tape: arms the buckets whose variables will receive gradients."""
+        self.works = []
+        for b in self.buckets:
+            b["remaining"] = sum(1 for n in b["names"] if self.pending.get(n, 0) > 0)
+            b["active"] = b["remaining"] > 0
+            b["fired"] = False
+
+    def note_done(self, names):
+        for n in names:
+            c = self.pending.get(n, 0) - 1
+            self.pending[n] = c
+            if c == 0:
+                b = self.bucket_of[n]
+                b["remaining"] -= 1
+                if b["remaining"] == 0 and b["active"] and self.grad_hook is not None:
+                    b["fired"] = True
+                    self.works.append(self.grad_hook(self.grads[b["start"]:b["end"]]))
 
     def __getitem__(self, name):
         return self.views[name]

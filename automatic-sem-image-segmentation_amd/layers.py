@@ -92,6 +92,9 @@ class Conv2D:
         if e0 is not None:
             TIMER.stop(e0, self.profile_tag)
         param_grads = tape.param_grads
+        pnames = [f"{self.name}/kernel"] + ([f"{self.name}/bias"] if self.use_bias else [])
+        if param_grads and tape.enabled:
+            self.arena.note_use(pnames)
 
         def backward():
             dy = y.get_grad()
@@ -111,6 +114,7 @@ class Conv2D:
                 gb = self.arena.grad(f"{self.name}/bias") if self.use_bias else None
                 L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), x.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wsw), wsw.numel(),
                                                  _stream()), f"conv2d_bwd_weight[{self.name}]")
+                self.arena.note_done(pnames)
             if x.requires_grad:
                 dx, accum = x.grad_target()
                 ddx = dd if dx.cs == x.cs else self.desc_with_in_cs(dd, dx.cs)
@@ -185,6 +189,9 @@ class Norm:
             L.check(lib.ss_norm_fwd_finish(ctypes.byref(d), x.ptr, _p(gamma), _p(beta), rp, y.ptr, _p(sums), count, _p(mean), _p(rstd),
                                            _p(mm), _p(mv), float(self.momentum), _stream()), "norm_fwd_finish")
         param_grads = tape.param_grads
+        pnames = ([f"{self.name}/gamma"] if self.scale else []) + [f"{self.name}/beta"]
+        if param_grads and tape.enabled:
+            self.arena.note_use(pnames)
 
         def backward():
             dy = y.get_grad()
@@ -213,6 +220,8 @@ class Norm:
                                                _p(gsums), _p(lsums), count, dx.ptr, dx.cs, accum,
                                                dres.ptr if dres is not None else None, racc, _p(ggam), _p(gbet), 1,
                                                _p(ws2), ws2.numel(), _stream()), "norm_bwd_finish")
+            if param_grads:
+                self.arena.note_done(pnames)
 
         tape.record(backward)
         return y

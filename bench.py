@@ -108,6 +108,7 @@ def main():
     db = NETS.PatchDiscriminator(filters=2 * F, device=dev, seed=4)
     unet = NETS.MultiResUNet(16, device=dev, seed=5)
     D.broadcast_params([ga, gb, da, db, unet])
+    D.enable_overlap([ga, gb, da, db, unet])     # bucketed gradient all-reduce launched during backward
     if world > 1:
         D.enable_sync_bn(True)      # whole-(global)-batch BatchNorm statistics = the single-device semantics of the reference
     model = CG.CycleGanModel(ga, gb, da, db, image_pool_a=CG.ImagePool(2, 50), image_pool_b=CG.ImagePool(2, 50))

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--cpu-sample-batch", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--skip-unet", action="store_true", help="diagnostics only: time the CycleGAN step alone")
+    ap.add_argument("--only-unet", action="store_true", help="diagnostics only: time the UNet step alone")
     args = ap.parse_args()
 
     D = importlib.import_module(PKG + ".dist")
@@ -126,7 +127,8 @@ def main():
     uy = E.Act(((b.t + 1) / 2).contiguous(), requires_grad=False)
 
     def step():
-        model.train_step((a, b))
+        if not args.only_unet:
+            model.train_step((a, b))
         if not args.skip_unet:
             umodel.train_step((ux.t, uy.t))
 

@@ -24,6 +24,7 @@ NormGeom geom(const ss_norm_desc* d, int V = 1) {
     const int cv = (d->c + V - 1) / V;
     int ct = 1;
     while (ct < cv && ct < 64) ct <<= 1;
+    if (cv < 64) ct = cv;          // exact channel lanes (odd MultiResUNet widths): every lane of a pixel row is useful
     g.CT = ct;
     g.PT = 256 / ct;
     g.cblocks = (cv + ct - 1) / ct;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
                                                          int C, long P, long pix_per_chunk, int CT, int PT,
                                                          float* __restrict__ part) {
     __shared__ float red[2 * V][256];
-    const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
+    const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;      // threads with pt >= PT (256 % CT leftovers) idle
     const int c = (blockIdx.y * CT + ct) * V;
     const int g = blockIdx.z;
     const long p0 = (long)blockIdx.x * pix_per_chunk;
@@ -68,13 +69,13 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
     float s1[V], s2[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) { s1[v] = 0.f; s2[v] = 0.f; }
-    if (c < C) {
+    if (c < C && pt < PT) {
         const long base = (long)g * P;
         float mu[V], rs[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) { mu[v] = 0.f; rs[v] = 0.f; }
         if (MODE == 1) { ldv<V>(mean + (long)g * C + c, mu); ldv<V>(rstd + (long)g * C + c, rs); }
-#pragma unroll 2
+#pragma unroll 4
         for (long p = p0 + pt; p < p1; p += PT) {
             float xv[V];
             ldv<V>(x + (base + p) * x_cs + c, xv);
@@ -98,12 +99,18 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
 #pragma unroll
     for (int v = 0; v < V; ++v) { red[2 * v][threadIdx.x] = s1[v]; red[2 * v + 1][threadIdx.x] = s2[v]; }
     __syncthreads();
-    for (int off = PT / 2; off >= 1; off >>= 1) {
-        if (pt < off) {
+    if ((PT & (PT - 1)) == 0) {        // power-of-two pixel lanes: tree
+        for (int off = PT / 2; off >= 1; off >>= 1) {
+            if (pt < off) {
 #pragma unroll
-            for (int k = 0; k < 2 * V; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off * CT];
+                for (int k = 0; k < 2 * V; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off * CT];
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    } else if (pt == 0) {              // odd lane count: fixed-order serial sum (deterministic)
+        for (int q = 1; q < PT; ++q)
+#pragma unroll
+            for (int k = 0; k < 2 * V; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + q * CT];
     }
     if (pt == 0 && c < C) {
         float* o = part + (((long)g * gridDim.x + blockIdx.x) * C + c) * 2;

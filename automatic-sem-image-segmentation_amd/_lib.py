@@ -24,7 +24,12 @@ class NormDesc(ctypes.Structure):
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PASS_FWD, PASS_BWD_DATA, PASS_BWD_WEIGHT = 0, 1, 2
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_BF16X3 = 0, 1, 2, 3
+
+
+def default_algo():
+    """SS_PRECISION=bf16x3 opts in to split-bf16 matrix-core arithmetic for the Winograd GEMMs (default: exact fp32)."""
+    return ALGO_BF16X3 if os.environ.get("SS_PRECISION", "f32").lower() == "bf16x3" else ALGO_AUTO
 
 # name -> (restype, argtypes); the complete export list of include/semseg_hip.h
 SIGNATURES = {

@@ -94,6 +94,9 @@ struct WGradParams {
     GTap taps[SS_MAX_TAPS];       // woff = destination offset of the tap block inside dw
 };
 
+struct SsTuning { bool no_fast, nt512, tile256, no_winograd; int wino_r; };
+const SsTuning& ss_tuning();   // measurement overrides, read once (conv_mfma.hip)
+
 // kernels / launchers implemented in the .hip files
 int ss_launch_gconv_direct(const GConvParams& p, hipStream_t s);
 int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s);
@@ -110,7 +113,18 @@ struct WinoProb {
     int n, h, w, cin, in_cs;      // gathered input (reduction channels = cin)
     int oh, ow, cout, out_cs;     // output grid
     int pt, pl, reflect;
+    int bf16x3;                   // 1: the batched GEMMs run as split-bf16 (3 products) on the bf16 matrix cores (opt-in)
 };
+
+// C[b][m][n] = sum_k (Ah+Al)[b][m][k] * (Bh+Bl)[b][n][k], bf16 planes, fp32 output (gemm_bf16x3.hip)
+struct BGemmParams {
+    const unsigned short *ah, *al, *bh, *bl;
+    float* c;
+    int32_t M, N, K, nbatch;
+    int64_t a_bs, b_bs, c_bs;     // element strides between batches
+    int32_t lda, ldb, ldc;
+};
+int ss_launch_bgemm_bf16x3(const BGemmParams& p, hipStream_t s);
 bool ss_wino_ok(const WinoProb& q);
 size_t ss_wino_fwd_ws(const WinoProb& q);
 int ss_wino_conv_fwd(const WinoProb& q, const float* x, const float* w, int w_cin, int w_cout, int flip, const float* bias, float* y,

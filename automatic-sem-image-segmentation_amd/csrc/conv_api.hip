@@ -251,14 +251,15 @@ GConvParams fwd_params(const ConvProb& c, const float* x, const float* w, const 
 // Winograd F(2x2,3x3) eligibility of the plain conv `c` (forward / weight-gradient view)
 bool wino_fwd_prob(const ConvProb& c, int algo, WinoProb* q) {
     if (algo == SS_ALGO_DIRECT || c.kh != 3 || c.kw != 3 || c.s != 1) return false;
-    *q = WinoProb{c.n, c.ih, c.iw, c.cin, c.in_cs, c.oh, c.ow, c.cout, c.out_cs, c.pt, c.pl, c.reflect};
+    *q = WinoProb{c.n, c.ih, c.iw, c.cin, c.in_cs, c.oh, c.ow, c.cout, c.out_cs, c.pt, c.pl, c.reflect, algo == SS_ALGO_BF16X3};
     return ss_wino_ok(*q);
 }
 // backward-data view: gathers dy (zero extension), produces dx (zero padding) or the padded gradient (reflect)
 bool wino_dgrad_prob(const ConvProb& c, int algo, WinoProb* q) {
     if (algo == SS_ALGO_DIRECT || c.kh != 3 || c.kw != 3 || c.s != 1) return false;
-    if (c.reflect) *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.oh + 2, c.ow + 2, c.cin, c.cin, 2, 2, 0};
-    else *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.ih, c.iw, c.cin, c.in_cs, 2 - c.pt, 2 - c.pl, 0};
+    const int bf = algo == SS_ALGO_BF16X3;
+    if (c.reflect) *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.oh + 2, c.ow + 2, c.cin, c.cin, 2, 2, 0, bf};
+    else *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.ih, c.iw, c.cin, c.in_cs, 2 - c.pt, 2 - c.pl, 0, bf};
     return ss_wino_ok(*q);
 }
 

@@ -292,6 +292,22 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
     }
 }
 
+// Kernel-selection overrides for A/B measurements (tools/bench_kernels.py); read ONCE per process, never needed in
+// production: SS_GCONV_NOFAST (generic loaders), SS_GCONV_NT512 / SS_GCONV_256 (tile variants), SS_NO_WINOGRAD, SS_WINO_R=2.
+const SsTuning& ss_tuning() {
+    static const SsTuning t = [] {
+        SsTuning v;
+        v.no_fast = getenv("SS_GCONV_NOFAST") != nullptr;
+        v.nt512 = getenv("SS_GCONV_NT512") != nullptr;
+        v.tile256 = getenv("SS_GCONV_256") != nullptr;
+        v.no_winograd = getenv("SS_NO_WINOGRAD") != nullptr;
+        const char* r = getenv("SS_WINO_R");
+        v.wino_r = (r && r[0] == '2') ? 2 : 4;
+        return v;
+    }();
+    return t;
+}
+
 bool ss_gconv_mfma_ok(const GConvParams& p) {
     // Cout == 1 heads and degenerate reductions stay on the direct kernel
     return p.Cout >= 2 && (long)p.ntaps * p.Cin >= 8;
@@ -321,7 +337,7 @@ int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
     for (int t = 0; t < p.ntaps && vecB; ++t) vecB = (p.taps[t].woff % 4 == 0);
     const long in_elems = (long)p.N * p.IH * p.IW * p.in_cs;
     const bool fast = vecA && vecB && p.ntaps >= 1 && (p.Cin % 32 == 0) && (p.Cout >= 4) && in_elems < (1L << 31) &&
-                      getenv("SS_GCONV_NOFAST") == nullptr;
+                      !ss_tuning().no_fast;
     // tile choice: the largest tile that still gives every CU ~2 workgroups (256 CUs); small batches need small tiles
     auto nblocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * (p.nbatch > 1 ? p.nbatch : 1); };
     const long want = 480;
@@ -332,10 +348,8 @@ int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
     if (fast) {
         switch (cfg) {
             case 0: {
-                static const bool nt512 = getenv("SS_GCONV_NT512") != nullptr;
-                static const bool big = getenv("SS_GCONV_256") != nullptr;
-                if (big && nblocks(256, 128) >= want) return launch_gconv<256, 128, true, 512>(p, vecA, vecB, s);
-                if (nt512) return launch_gconv<128, 128, true, 512>(p, vecA, vecB, s);
+                if (ss_tuning().tile256 && nblocks(256, 128) >= want) return launch_gconv<256, 128, true, 512>(p, vecA, vecB, s);
+                if (ss_tuning().nt512) return launch_gconv<128, 128, true, 512>(p, vecA, vecB, s);
                 return launch_gconv<128, 128, true>(p, vecA, vecB, s);
             }
             case 1: return launch_gconv<128, 64, true>(p, vecA, vecB, s);
@@ -636,7 +650,7 @@ int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s) {
         const int vecA = (p.Ca % 4 == 0) && (p.a_cs % 4 == 0) && (((uintptr_t)p.a & 15) == 0);
         const int vecB = (p.b_cs % 4 == 0) && (((uintptr_t)p.b & 15) == 0);
         int rc;
-        const bool fast = vecA && vecB && p.GW >= 32 && p.Cb >= 4 && p.pix_per_split % 32 == 0 && getenv("SS_GCONV_NOFAST") == nullptr;
+        const bool fast = vecA && vecB && p.GW >= 32 && p.Cb >= 4 && p.pix_per_split % 32 == 0 && !ss_tuning().no_fast;
         if (fast) {
             if (p.Cb > 64) rc = launch_wgrad<128, 128, true>(p, vecA, vecB, s);
             else if (p.Cb > 32) rc = launch_wgrad<128, 64, true>(p, vecA, vecB, s);

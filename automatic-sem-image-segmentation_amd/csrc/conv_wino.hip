@@ -23,6 +23,33 @@ template <class T> __device__ __forceinline__ T ldz(const float* base, long off,
     return ok ? v : zero_v<T>();
 }
 
+// fp32 -> (hi, lo) bf16 planes, round-to-nearest-even (finite inputs)
+__device__ __forceinline__ unsigned short bf16_rne(float v) {
+    unsigned int u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void split_bf16(float v, unsigned short& hi, unsigned short& lo) {
+    hi = bf16_rne(v);
+    lo = bf16_rne(v - __uint_as_float((unsigned int)hi << 16));
+}
+template <class T> __device__ __forceinline__ void store_split(unsigned short* ph, unsigned short* pl, const T& v) {
+    constexpr int N = (int)(sizeof(T) / 4);
+    unsigned short h[N], l[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) split_bf16(v[k], h[k], l[k]);
+    if (N == 2) {
+        *(unsigned int*)ph = (unsigned int)h[0] | ((unsigned int)h[1] << 16);
+        *(unsigned int*)pl = (unsigned int)l[0] | ((unsigned int)l[1] << 16);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k += 2) {
+            ((unsigned int*)ph)[k / 2] = (unsigned int)h[k] | ((unsigned int)h[k + 1] << 16);
+            ((unsigned int*)pl)[k / 2] = (unsigned int)l[k] | ((unsigned int)l[k + 1] << 16);
+        }
+    }
+}
+
 // 1-D transforms (applied to rows, then columns)
 template <int R, class T> __device__ __forceinline__ void t_in(const T* d, T* v) {      // B^T d
     if (R == 2) {
@@ -81,7 +108,7 @@ template <int R> __device__ __forceinline__ void t_dw(const float* s, float* o) 
 }
 
 // V[xi][tile][c], tile = (n, ty, tx); patch d[i][j] = in[n, map(R*ty + i - pt), map(R*tx + j - pl), c]
-template <int R>
+template <int R, bool BF>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int in_cs, int N, int H, int W, int C,
                                                          int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V) {
     typedef typename WT<R>::T T;
@@ -119,8 +146,15 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     for (int i = 0; i < P; ++i) {
         T v[P];
         t_in<R, T>(t[i], v);
+        if (BF) {       // two bf16 planes [xi][tile][c] (hi plane, then lo plane) in the space of the fp32 V
+            unsigned short* oh = (unsigned short*)V + tile * C + c;
+            unsigned short* ol = oh + (long)P * P * xs;
 #pragma unroll
-        for (int j = 0; j < P; ++j) *(T*)(o + (long)(i * P + j) * xs) = v[j];
+            for (int j = 0; j < P; ++j) store_split<T>(oh + (long)(i * P + j) * xs, ol + (long)(i * P + j) * xs, v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < P; ++j) *(T*)(o + (long)(i * P + j) * xs) = v[j];
+        }
     }
 }
 
@@ -166,7 +200,7 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 
 // U[xi][kr][no] = (G g G^T)_xi with g[kh][kw] = w[kh'][kw'][..]; flip = 0: (kr,no) = (ci,co); flip = 1 (backward-data):
 // (kh',kw') = (2-kh,2-kw), (kr,no) = (co,ci).  w is the Keras (3,3,cin,cout) kernel.
-template <int R>
+template <int R, bool BF>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int Cin, int Cout, int flip, float* __restrict__ U) {
     constexpr int P = R + 2;
     const int KR = flip ? Cout : Cin, NO = flip ? Cin : Cout;
@@ -192,8 +226,15 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     for (int i = 0; i < P; ++i) {
         float u[P];
         t_w<R>(t[i], u);
+        if (BF) {       // transposed planes U^T[xi][no][kr] (K-contiguous rows for the split-bf16 GEMM): hi plane, then lo plane
+            unsigned short* uh = (unsigned short*)U + (long)no * KR + kr;
+            unsigned short* ul = uh + (long)P * P * xs;
 #pragma unroll
-        for (int j = 0; j < P; ++j) U[(long)(i * P + j) * xs + e] = u[j];
+            for (int j = 0; j < P; ++j) split_bf16(u[j], uh[(long)(i * P + j) * xs], ul[(long)(i * P + j) * xs]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < P; ++j) U[(long)(i * P + j) * xs + e] = u[j];
+        }
     }
 }
 
@@ -286,10 +327,7 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 inline unsigned g256(long total) { return (unsigned)((total + 255) / 256); }
 
 // output tile size: F(4x4,3x3) by default (4x fewer multiplies), F(2x2,3x3) with SS_WINO_R=2
-inline int wino_r() {
-    static const int r = [] { const char* e = getenv("SS_WINO_R"); return (e && e[0] == '2') ? 2 : 4; }();
-    return r;
-}
+inline int wino_r() { return ss_tuning().wino_r; }
 inline long n_tiles(const WinoProb& q, int R) { return (long)q.n * ((q.oh + R - 1) / R) * ((q.ow + R - 1) / R); }
 
 template <int R>
@@ -301,9 +339,28 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     float* U = (float*)ws;
     float* V = (float*)((char*)ws + ss_align_up((size_t)XI * q.cin * q.cout * 4, 256));
     float* Mx = (float*)((char*)V + ss_align_up((size_t)XI * tiles * q.cin * 4, 256));
-    hipLaunchKernelGGL(wino_weight_kernel<R>, dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, w, w_cin, w_cout, flip, U);
+    if (q.bf16x3) {
+        hipLaunchKernelGGL((wino_weight_kernel<R, true>), dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, w, w_cin, w_cout, flip, U);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL((wino_input_kernel<R, true>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                           TH, TW, q.pt, q.pl, q.reflect, V);
+        SS_LAUNCH_CHECK();
+        BGemmParams b{};
+        b.ah = (const unsigned short*)V; b.al = b.ah + (long)XI * tiles * q.cin;
+        b.bh = (const unsigned short*)U; b.bl = b.bh + (long)XI * q.cin * q.cout;
+        b.c = Mx; b.M = (int)tiles; b.N = q.cout; b.K = q.cin; b.nbatch = XI;
+        b.a_bs = tiles * q.cin; b.b_bs = (long)q.cin * q.cout; b.c_bs = tiles * q.cout;
+        b.lda = q.cin; b.ldb = q.cin; b.ldc = q.cout;
+        int rcb = ss_launch_bgemm_bf16x3(b, s);
+        if (rcb != SS_OK) return rcb;
+        hipLaunchKernelGGL(wino_output_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
+                           bias, act, alpha, y, q.out_cs, accumulate);
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+    }
+    hipLaunchKernelGGL((wino_weight_kernel<R, false>), dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, w, w_cin, w_cout, flip, U);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wino_input_kernel<R>, dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
+    hipLaunchKernelGGL((wino_input_kernel<R, false>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
                        q.pt, q.pl, q.reflect, V);
     SS_LAUNCH_CHECK();
     GConvParams g{};
@@ -330,7 +387,7 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
     float* V = (float*)ws;
     float* E = (float*)((char*)ws + ss_align_up((size_t)XI * tiles * q.cin * 4, 256));
     float* part = (float*)((char*)E + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
-    hipLaunchKernelGGL(wino_input_kernel<R>, dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
+    hipLaunchKernelGGL((wino_input_kernel<R, false>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
                        q.pt, q.pl, q.reflect, V);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(wino_dy_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, E);
@@ -356,7 +413,7 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
 
 // ---- host side ----------------------------------------------------------------------------------------------------
 bool ss_wino_ok(const WinoProb& q) {
-    if (getenv("SS_NO_WINOGRAD")) return false;
+    if (ss_tuning().no_winograd) return false;
     const int kr = q.cin, no = q.cout;
     return kr % 32 == 0 && no % 4 == 0 && kr >= 64 && no >= 64 && q.in_cs % 4 == 0 && q.out_cs % 4 == 0 &&
            n_tiles(q, 2) >= 1024;

@@ -36,7 +36,7 @@ class Conv2D:
         self.arena, self.name = arena, name
         self.k, self.cin, self.cout, self.stride = k, cin, cout, stride
         self.padding, self.use_bias, self.act, self.act_alpha = padding, use_bias, act, act_alpha
-        self.transposed, self.algo = transposed, algo
+        self.transposed, self.algo = transposed, (L.default_algo() if algo == L.ALGO_AUTO else algo)
         arena.declare(f"{name}/kernel", (k, k, cout, cin) if transposed else (k, k, cin, cout))
         if use_bias:
             arena.declare(f"{name}/bias", (cout,))

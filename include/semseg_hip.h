@@ -39,7 +39,11 @@ typedef enum ss_status {
 enum { SS_PAD_ZERO = 0, SS_PAD_REFLECT = 1 };
 enum { SS_ACT_NONE = 0, SS_ACT_RELU = 1, SS_ACT_LRELU = 2, SS_ACT_TANH = 3, SS_ACT_SIGMOID = 4 };
 enum { SS_PASS_FWD = 0, SS_PASS_BWD_DATA = 1, SS_PASS_BWD_WEIGHT = 2 };
-enum { SS_ALGO_AUTO = 0, SS_ALGO_DIRECT = 1, SS_ALGO_MFMA = 2 };
+enum { SS_ALGO_AUTO = 0, SS_ALGO_DIRECT = 1, SS_ALGO_MFMA = 2,
+       /* AUTO + opt-in "split-bf16" matrix-core arithmetic for the Winograd GEMMs: every fp32 operand is carried as
+        * hi + lo bf16 planes and each product as hi*hi + hi*lo + lo*hi with fp32 accumulation (~2^-16 relative per
+        * product; the default paths are exact fp32) */
+       SS_ALGO_BF16X3 = 3 };
 
 int ss_version(void);
 const char* ss_status_string(int status);

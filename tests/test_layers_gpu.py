@@ -321,3 +321,40 @@ def test_sync_batchnorm_two_phase_equals_whole_batch():
     assert_close((gs[0][0] + gs[1][0]).cpu(), ref_g[0][0].cpu(), "syncbn dgamma", rtol=1e-4)
     assert_close((gs[0][1] + gs[1][1]).cpu(), ref_g[0][1].cpu(), "syncbn dbeta", rtol=1e-4)
     assert_close(mms[0].cpu(), ref_mm[0].cpu(), "syncbn moving_mean", rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0].startswith("wino_")], ids=[c[0] for c in CONV_CASES if c[0].startswith("wino_")])
+def test_conv_split_bf16_opt_in(case):
+    """Opt-in SS_ALGO_BF16X3: Winograd GEMMs as hi*hi + hi*lo + lo*hi on the bf16 matrix cores (16 mantissa bits per operand,
+    amplified by the F(4x4,3x3) output transform): measured rel-L2 ~5e-5, max error ~1e-3 of max|ref| -> tolerance 2e-3.
+    That is 10x looser than the fp32 parity bar, which is why this mode is NOT the default.  The weight gradient stays fp32."""
+    E, LY, L = _mods()
+    name, k, cin, cout, stride, padding, bias, act, transposed, n, h, w = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    arena = E.ParamArena(dev)
+    layer = LY.Conv2D(arena, "c", k, cin, cout, stride=stride, padding=padding, use_bias=bias, act=act, act_alpha=0.2, algo=L.ALGO_BF16X3)
+    arena.materialize()
+    w_cpu = (torch.rand((k, k, cin, cout), generator=g, dtype=torch.float64) - 0.5) * 0.5
+    b_cpu = torch.rand(cout, generator=g, dtype=torch.float64) - 0.5 if bias else None
+    x_cpu = torch.rand((n, h, w, cin), generator=g, dtype=torch.float64) * 2 - 1
+    arena["c/kernel"].copy_(w_cpu.float())
+    if bias:
+        arena["c/bias"].copy_(b_cpu.float())
+    xr = x_cpu.clone().requires_grad_(True)
+    wr = w_cpu.clone().requires_grad_(True)
+    yr = oracle_conv(xr, wr, b_cpu, k, stride, padding, act, transposed)
+    gy = torch.rand(yr.shape, generator=g, dtype=torch.float64) - 0.5
+    yr.backward(gy)
+    tape = E.Tape()
+    x = E.Act(x_cpu.float().to(dev), requires_grad=True)
+    y = layer(tape, x)
+    assert_close(y.dense().cpu(), yr.detach().float(), f"{name} bf16x3 fwd", rtol=2e-3)
+    assert rel_l2(y.dense().cpu().numpy(), yr.detach().numpy()) <= 2e-4
+    gt, _ = y.grad_target()
+    gt.t.copy_(gy.float().to(dev))
+    arena.zero_grad()
+    tape.backward()
+    assert_close(x.get_grad().dense().cpu(), xr.grad.float(), f"{name} bf16x3 dx", rtol=2e-3)
+    assert rel_l2(x.get_grad().dense().cpu().numpy(), xr.grad.numpy()) <= 2e-4
+    assert_close(arena.grad("c/kernel").cpu(), wr.grad.float(), f"{name} bf16x3 dw", rtol=2e-4)

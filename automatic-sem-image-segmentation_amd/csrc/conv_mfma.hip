@@ -16,6 +16,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte global access
+
 template <int BM_, int BN_, int NT_ = 256>
 struct Cfg {
     static constexpr int BM = BM_, BN = BN_, BK = 32, NT = NT_;
@@ -74,7 +76,12 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
     float* const g_out = p.out + (long)batch * p.out_bs;
     const long m0 = (long)(tile / gridN) * BM;
     const int n0 = (tile % gridN) * BN;
-    const int K = p.ntaps * p.Cin;
+    // FAST with vecA == 0 ("padded K"): any channel count.  The reduction index runs over (tap, ci padded to a multiple of 4),
+    // every 4-float unit stays inside one tap and is fetched with ONE dword-aligned global_load_dwordx4 when it lies fully
+    // inside the pixel's channels (scalar masked loads for the ragged last unit) -- the MultiResUNet's odd widths.
+    const int Cq = (p.Cin + 3) & ~3;
+    const bool padk = FAST && !vecA;
+    const int K = padk ? p.ntaps * Cq : p.ntaps * p.Cin;
     const int nchunks = (K + C::BK - 1) / C::BK;
 
     // output pixel table (linear NHW index of the destination pixel, -1 = masked)
@@ -131,6 +138,52 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
     f32x4 ra[C::A_UNITS], rb[C::B_UNITS];
 
     auto load_tiles = [&](int k0) {
+        if (FAST && padk) {
+            const int kq = k0 + c4a * 4;
+            const int tq = kq / Cq;
+            const int ci = kq - tq * Cq;
+            const bool kval = tq < p.ntaps;
+            const int t = kval ? tq : 0;
+            const int nin = p.Cin - ci;               // channels of this unit that exist (>= 4: whole unit)
+#pragma unroll
+            for (int j = 0; j < C::A_UNITS; ++j) {
+                const int off = offtab[((tid >> 3) + C::A_ROWS * j) * p.ntaps + t];
+                const bool ok = kval && off >= 0;
+                const float* ptr = g_in + (ok ? off : 0) + (ok ? ci : 0);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (nin >= 4) {
+                    const f32x4u u = *(const f32x4u*)ptr;
+                    v = f32x4{u[0], u[1], u[2], u[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        if (e < nin) v[e] = ptr[e];
+                }
+                ra[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < C::B_UNITS; ++j) {
+                const int u = tid + NT * j;
+                const int row = u / (BN / 4), c4 = u % (BN / 4);
+                const int kb = k0 + row;
+                const int tb = kb / Cq;
+                const int cb = kb - tb * Cq;
+                const int col = n0 + c4 * 4;
+                const bool okb = tb < p.ntaps && cb < p.Cin && col < p.Cout;
+                const float* wp = g_w + p.taps[okb ? tb : 0].woff + (long)(okb ? cb : 0) * p.ldb + (okb ? col : 0);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (col + 4 <= p.Cout) {
+                    const f32x4u u4 = *(const f32x4u*)wp;
+                    v = f32x4{u4[0], u4[1], u4[2], u4[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        if (col + e < p.Cout) v[e] = wp[e];
+                }
+                rb[j] = okb ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            return;
+        }
         if (FAST) {
             const int t = k0 / p.Cin;                 // block-uniform
             const int ci0 = k0 - t * p.Cin;
@@ -332,12 +385,13 @@ static int launch_gconv(const GConvParams& p, int vecA, int vecB, hipStream_t s)
 int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
     const long M = (long)p.N * p.OHc * p.OWc;
     if (M == 0) return SS_OK;
-    const int vecA = (p.Cin % 4 == 0) && (p.in_cs % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
+    int vecA = (p.Cin % 4 == 0) && (p.in_cs % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
     int vecB = (p.ldb % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
     for (int t = 0; t < p.ntaps && vecB; ++t) vecB = (p.taps[t].woff % 4 == 0);
     const long in_elems = (long)p.N * p.IH * p.IW * p.in_cs;
-    const bool fast = vecA && vecB && p.ntaps >= 1 && (p.Cin % 32 == 0) && (p.Cout >= 4) && in_elems < (1L << 31) &&
-                      !ss_tuning().no_fast;
+    const bool uniform = vecA && vecB && (p.Cin % 32 == 0) && (p.Cout >= 4);      // aligned float4 units, one tap per K step
+    const bool fast = p.ntaps >= 1 && in_elems < (1L << 31) && !ss_tuning().no_fast;
+    if (fast && !uniform) vecA = 0;                                                // -> padded-K loaders
     // tile choice: the largest tile that still gives every CU ~2 workgroups (256 CUs); small batches need small tiles
     auto nblocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * (p.nbatch > 1 ? p.nbatch : 1); };
     const long want = 480;

@@ -9,7 +9,14 @@
 
 namespace {
 
-constexpr int NORM_MAX_CHUNKS = 128;
+// Pixel chunks per group: enough blocks to fill 256 CUs several times over even for batch norm (G = 1) with < 64 channels
+// (one channel block): 128 chunks there meant 128 workgroups on 256 CUs.
+constexpr int NORM_CHUNK_BLOCKS = 4096;
+constexpr int FIN_CL = 8;          // finalize kernels: 8 channels x 32 chunk lanes per block
+inline int norm_max_chunks(int groups) {
+    int m = NORM_CHUNK_BLOCKS / (groups > 0 ? groups : 1);
+    return m < 128 ? 128 : (m > 2048 ? 2048 : m);
+}
 
 struct NormGeom {
     int G, C, CT, PT, chunks, cblocks;   // CT channel lanes (pow2 <= 64, each V channels wide), PT = 256/CT pixel lanes
@@ -29,10 +36,10 @@ NormGeom geom(const ss_norm_desc* d, int V = 1) {
     g.PT = 256 / ct;
     g.cblocks = (cv + ct - 1) / ct;
     long chunks = (g.P + 63) / 64;
-    long want = 4096 / ((long)g.G * g.cblocks);   // aim at >= ~4096 blocks in total
+    long want = NORM_CHUNK_BLOCKS / ((long)g.G * g.cblocks);   // aim at >= ~4096 blocks in total
     if (want < 1) want = 1;
     if (chunks > want) chunks = want;
-    if (chunks > NORM_MAX_CHUNKS) chunks = NORM_MAX_CHUNKS;
+    if (chunks > norm_max_chunks(g.G)) chunks = norm_max_chunks(g.G);
     if (chunks < 1) chunks = 1;
     g.chunks = (int)chunks;
     g.pix_per_chunk = (g.P + chunks - 1) / chunks;
@@ -123,24 +130,25 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
 // Block = 32 channels x 8 chunk lanes (fixed-order LDS combine -> deterministic); grid = (C/32, G).
 __global__ __launch_bounds__(256) void norm_finalize_fwd(const float* __restrict__ part, int chunks, int G, int C, long P, float eps,
                                                          float* __restrict__ mean, float* __restrict__ rstd,
-                                                         float* __restrict__ mm, float* __restrict__ mv, float momentum) {
-    __shared__ double red[2][8][32];
-    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl, g = blockIdx.y;
+                                                         float* __restrict__ mm, float* __restrict__ mv, float momentum, int CL) {
+    __shared__ double red[2][256];
+    const int KL = 256 / CL;                      // CL channels x KL chunk lanes per block (CL = 32, or 8 for narrow tensors)
+    const int cl = threadIdx.x % CL, kl = threadIdx.x / CL;
+    const int c = blockIdx.x * CL + cl, g = blockIdx.y;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int k = kl; k < chunks; k += 8) {
+        for (int k = kl; k < chunks; k += KL) {
             const float* o = part + (((long)g * chunks + k) * C + c) * 2;
             s1 += o[0];
             s2 += o[1];
         }
     }
-    red[0][kl][cl] = s1;
-    red[1][kl][cl] = s2;
+    red[0][kl * CL + cl] = s1;
+    red[1][kl * CL + cl] = s2;
     __syncthreads();
     if (kl == 0 && c < C) {
         s1 = 0.0; s2 = 0.0;
-        for (int k = 0; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+        for (int k = 0; k < KL; ++k) { s1 += red[0][k * CL + cl]; s2 += red[1][k * CL + cl]; }
         const long i = (long)g * C + c;
         const double mu = s1 / (double)P;
         double var = s2 / (double)P - mu * mu;   // E[x^2] - E[x]^2 (keras.ops.moments, torch backend)
@@ -205,26 +213,27 @@ __global__ __launch_bounds__(256) void norm_infer_kernel(const float* __restrict
 // Block = 32 channels x 8 chunk lanes; groups are walked sequentially, every combine is a fixed-order LDS sum.
 __global__ __launch_bounds__(256) void norm_finalize_bwd(const float* __restrict__ part, int chunks, int G, int C, long P,
                                                          float* __restrict__ sums /* [G*C*2] */,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-    __shared__ double red[2][8][32];
-    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int CL) {
+    __shared__ double red[2][256];
+    const int KL = 256 / CL;
+    const int cl = threadIdx.x % CL, kl = threadIdx.x / CL;
+    const int c = blockIdx.x * CL + cl;
     double tg = 0.0, tgx = 0.0;
     for (int g = 0; g < G; ++g) {
         double s1 = 0.0, s2 = 0.0;
         if (c < C) {
-            for (int k = kl; k < chunks; k += 8) {
+            for (int k = kl; k < chunks; k += KL) {
                 const float* o = part + (((long)g * chunks + k) * C + c) * 2;
                 s1 += o[0];
                 s2 += o[1];
             }
         }
-        red[0][kl][cl] = s1;
-        red[1][kl][cl] = s2;
+        red[0][kl * CL + cl] = s1;
+        red[1][kl * CL + cl] = s2;
         __syncthreads();
         if (kl == 0 && c < C) {
             s1 = 0.0; s2 = 0.0;
-            for (int k = 0; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+            for (int k = 0; k < KL; ++k) { s1 += red[0][k * CL + cl]; s2 += red[1][k * CL + cl]; }
             sums[((long)g * C + c) * 2 + 0] = (float)(s1 / (double)P);
             sums[((long)g * C + c) * 2 + 1] = (float)(s2 / (double)P);
             tg += s1;
@@ -345,7 +354,7 @@ int pick_v(int c, std::initializer_list<int> strides, std::initializer_list<cons
 }
 
 size_t part_bytes(const ss_norm_desc* d) {
-    return ss_align_up((size_t)d->groups * NORM_MAX_CHUNKS * d->c * 2 * sizeof(float), 256);
+    return ss_align_up((size_t)d->groups * norm_max_chunks(d->groups) * d->c * 2 * sizeof(float), 256);
 }
 
 }  // namespace
@@ -378,8 +387,8 @@ int ss_norm_fwd(const ss_norm_desc* d, const float* x, const float* gamma, const
         hipLaunchKernelGGL((norm_stats_kernel<0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
                            0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + 31) / 32, g.G), dim3(256), 0, s,
-                       part, g.chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum);
+    hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + FIN_CL - 1) / FIN_CL, g.G), dim3(256), 0, s,
+                       part, g.chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum, FIN_CL);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
     if (V == 4)
@@ -425,8 +434,8 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
         hipLaunchKernelGGL((norm_stats_kernel<1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
                            d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + 31) / 32), dim3(256), 0, s,
-                       part, g.chunks, g.G, g.C, g.P, sums, dgamma, dbeta, accumulate_params);
+    hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + FIN_CL - 1) / FIN_CL), dim3(256), 0, s,
+                       part, g.chunks, g.G, g.C, g.P, sums, dgamma, dbeta, accumulate_params, FIN_CL);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
     if (V == 4)
@@ -472,8 +481,8 @@ int ss_norm_fwd_finish(const ss_norm_desc* d, const float* x, const float* gamma
     hipStream_t s = (hipStream_t)stream;
     const int V = pick_v(d->c, {d->x_cstride, d->y_cstride, residual ? d->res_cstride : 0}, {x, y, residual, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
-    hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + 31) / 32, g.G), dim3(256), 0, s,
-                       sums, 1, g.G, g.C, (long)total_count, d->eps, mean, rstd, moving_mean, moving_var, momentum);
+    hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + FIN_CL - 1) / FIN_CL, g.G), dim3(256), 0, s,
+                       sums, 1, g.G, g.C, (long)total_count, d->eps, mean, rstd, moving_mean, moving_var, momentum, FIN_CL);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
     if (V == 4)

@@ -254,8 +254,8 @@ class UNet:
     def run_inference(self, files, output_directory, model=None, tile_images=False, threshold=-1, watershed_lines=True,
                       min_distance=9, min_overlap=2, manage_overlap_mode=2, use_gpu=False):
         """UNet_Segmentation.py:290-351: probabilities (``*_raw.tif``, float32) and the thresholded label map per image.
-        Runs on the MI355X in inference mode (BatchNorm moving statistics).  ``watershed_lines=True`` needs the
-        not-yet-built watershed (HelperFunctions.segment raises); pass False for Otsu/threshold label maps."""
+        Runs on the MI355X in inference mode (BatchNorm moving statistics).  ``watershed_lines=True`` (the reference default)
+        splits touching particles on the CPU (HelperFunctions.segment -> libsemseg_post.so), as the reference does."""
         from PIL import Image
         if model is None and self.model is None:
             latest = sorted(os.listdir(self.model_dir))[-1]

@@ -125,5 +125,5 @@ def test_otsu_threshold_is_the_variance_maximiser():
     assert t == best and 60 < t < 180
     lab = HF.segment(img, -1, watershed_lines=False)
     assert set(np.unique(lab)) <= {0, 255}
-    with pytest.raises(NotImplementedError):
-        HF.segment(img, -1, watershed_lines=True)
+    lab_ws = HF.segment(img, -1, watershed_lines=True)
+    assert set(np.unique(lab_ws)) <= {0, 255} and np.all(lab_ws <= lab)      # splitting only removes pixels

@@ -24,7 +24,7 @@ class NormDesc(ctypes.Structure):
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PASS_FWD, PASS_BWD_DATA, PASS_BWD_WEIGHT = 0, 1, 2
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_BF16X3 = 0, 1, 2, 3
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_BF16X3, ALGO_X6 = 0, 1, 2, 3, 4
 
 
 def default_algo():

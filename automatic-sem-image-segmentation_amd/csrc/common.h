@@ -94,7 +94,7 @@ struct WGradParams {
     GTap taps[SS_MAX_TAPS];       // woff = destination offset of the tap block inside dw
 };
 
-struct SsTuning { bool no_fast, nt512, tile256, no_winograd; int wino_r; };
+struct SsTuning { bool no_fast, nt512, tile256, no_winograd, x6; int wino_r; };
 const SsTuning& ss_tuning();   // measurement overrides, read once (conv_mfma.hip)
 
 // kernels / launchers implemented in the .hip files
@@ -108,12 +108,20 @@ int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accu
 int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split, int nbatch = 1);
 int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s);   // partials only: part[batch][split][M][Cb]
 
+// fp32-exact contraction on the bf16 matrix cores (conv_mfma_x6.hip): three bf16 pieces per operand, six products
+bool ss_gconv_x6_ok(const GConvParams& p);                  // shape / alignment eligibility
+int ss_x6_npad(int cout);
+size_t ss_gconv_x6_planes_bytes(const GConvParams& p);      // [3][nbatch][npad(Cout)][ntaps*Cin] bf16
+int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s);
+int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipStream_t s);
+
 // Winograd F(2x2,3x3) path (conv_wino.hip): 3x3, stride 1; out[o] = sum_a in[map(o + a - pt)] * g[a]
 struct WinoProb {
     int n, h, w, cin, in_cs;      // gathered input (reduction channels = cin)
     int oh, ow, cout, out_cs;     // output grid
     int pt, pl, reflect;
     int bf16x3;                   // 1: the batched GEMMs run as split-bf16 (3 products) on the bf16 matrix cores (opt-in)
+    int x6;                       // 1: forward / data-gradient GEMMs as fp32-exact 6-product bf16 contraction (conv_mfma_x6.hip)
 };
 
 // C[b][m][n] = sum_k (Ah+Al)[b][m][k] * (Bh+Bl)[b][n][k], bf16 planes, fp32 output (gemm_bf16x3.hip)

@@ -197,8 +197,19 @@ size_t two_stage_ws(int n, int ih, int iw, int cred, int cout, int ntaps) {
     return ss_align_up((size_t)cred * tcs * sizeof(float), 256) + ss_align_up((size_t)n * ih * iw * tcs * sizeof(float), 256);
 }
 
+// x6 (bf16 matrix cores, fp32-exact operands): AUTO (unless SS_X6=0) and SS_ALGO_X6, shapes with Cin % 32 == 0
+bool x6_wanted(int algo) { return algo == SS_ALGO_X6 || (algo == SS_ALGO_AUTO && ss_tuning().x6); }
+bool use_x6(int algo, const GConvParams& p) {
+    return x6_wanted(algo) && ss_gconv_x6_ok(p) && (long)p.N * p.OHc * p.OWc >= 1024;
+}
+// upper bound of the weight-plane scratch of a gather conv with `cred` reduction channels, `cout` outputs, `ntaps` taps
+size_t x6_planes_ub(int cred, int cout, int ntaps) {
+    if (cred % 32 != 0 || cout < 32) return 0;
+    return ss_align_up((size_t)3 * ss_x6_npad(cout) * ntaps * cred * sizeof(unsigned short), 256);
+}
+
 size_t gconv_ws_bytes(int algo, const GConvParams& p) {
-    if (!gconv_two_stage(algo, p)) return 256;
+    if (!gconv_two_stage(algo, p)) return 256 + x6_planes_ub(p.Cin, p.Cout, p.ntaps);
     return two_stage_ws(p.N, p.IH, p.IW, p.Cin, p.Cout, p.ntaps);
 }
 
@@ -226,6 +237,11 @@ int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStre
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
+    if (use_x6(algo, p) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p)) {
+        int rc = ss_launch_wprep_x6(p, (unsigned short*)ws, s);
+        if (rc != SS_OK) return rc;
+        return ss_launch_gconv_x6(p, (const unsigned short*)ws, s);
+    }
     return use_mfma(algo, p) ? ss_launch_gconv_mfma(p, s) : ss_launch_gconv_direct(p, s);
 }
 
@@ -251,15 +267,16 @@ GConvParams fwd_params(const ConvProb& c, const float* x, const float* w, const 
 // Winograd F(2x2,3x3) eligibility of the plain conv `c` (forward / weight-gradient view)
 bool wino_fwd_prob(const ConvProb& c, int algo, WinoProb* q) {
     if (algo == SS_ALGO_DIRECT || c.kh != 3 || c.kw != 3 || c.s != 1) return false;
-    *q = WinoProb{c.n, c.ih, c.iw, c.cin, c.in_cs, c.oh, c.ow, c.cout, c.out_cs, c.pt, c.pl, c.reflect, algo == SS_ALGO_BF16X3};
+    *q = WinoProb{c.n, c.ih, c.iw, c.cin, c.in_cs, c.oh, c.ow, c.cout, c.out_cs, c.pt, c.pl, c.reflect, algo == SS_ALGO_BF16X3, x6_wanted(algo)};
     return ss_wino_ok(*q);
 }
 // backward-data view: gathers dy (zero extension), produces dx (zero padding) or the padded gradient (reflect)
 bool wino_dgrad_prob(const ConvProb& c, int algo, WinoProb* q) {
     if (algo == SS_ALGO_DIRECT || c.kh != 3 || c.kw != 3 || c.s != 1) return false;
     const int bf = algo == SS_ALGO_BF16X3;
-    if (c.reflect) *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.oh + 2, c.ow + 2, c.cin, c.cin, 2, 2, 0, bf};
-    else *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.ih, c.iw, c.cin, c.in_cs, 2 - c.pt, 2 - c.pl, 0, bf};
+    const int x6 = x6_wanted(algo);
+    if (c.reflect) *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.oh + 2, c.ow + 2, c.cin, c.cin, 2, 2, 0, bf, x6};
+    else *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.ih, c.iw, c.cin, c.in_cs, 2 - c.pt, 2 - c.pl, 0, bf, x6};
     return ss_wino_ok(*q);
 }
 
@@ -288,6 +305,7 @@ size_t bwd_data_dpad_bytes(const ConvProb& c) {
 size_t bwd_data_ws(const ConvProb& c) {
     // [transposed weights][padded gradient (reflect)][two-stage scratch of the gather conv (Cin == 1 stems) | Winograd scratch]
     size_t extra = two_stage_ws(c.n, c.oh, c.ow, c.cout, c.cin, c.kh * c.kw);
+    { const size_t xq = x6_planes_ub(c.cout, c.cin, c.kh * c.kw); if (xq > extra) extra = xq; }
     WinoProb q;
     if (wino_dgrad_prob(c, SS_ALGO_AUTO, &q)) { const size_t wq = ss_wino_fwd_ws(q); if (wq > extra) extra = wq; }
     return bwd_data_wt_bytes(c) + bwd_data_dpad_bytes(c) + extra;

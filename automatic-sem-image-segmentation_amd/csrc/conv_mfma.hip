@@ -136,6 +136,10 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
     }
 
     f32x4 ra[C::A_UNITS], rb[C::B_UNITS];
+    // FAST: units that must read as zero (padding taps, columns past Cout).  The select is applied when the registers are
+    // stored to LDS, NOT after the load: a select right behind the load makes the compiler wait for the global loads before
+    // the MFMA phase (s_waitcnt vmcnt(0) ahead of 64 MFMAs), exposing the whole L2 / HBM latency in every K step.
+    bool za[C::A_UNITS], zb[C::B_UNITS];
 
     auto load_tiles = [&](int k0) {
         if (FAST && padk) {
@@ -159,7 +163,8 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
                     for (int e = 0; e < 3; ++e)
                         if (e < nin) v[e] = ptr[e];
                 }
-                ra[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                ra[j] = v;
+                za[j] = !ok;
             }
 #pragma unroll
             for (int j = 0; j < C::B_UNITS; ++j) {
@@ -180,7 +185,8 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
                     for (int e = 0; e < 3; ++e)
                         if (col + e < p.Cout) v[e] = wp[e];
                 }
-                rb[j] = okb ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                rb[j] = v;
+                zb[j] = !okb;
             }
             return;
         }
@@ -191,8 +197,8 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
 #pragma unroll
             for (int j = 0; j < C::A_UNITS; ++j) {
                 const int off = offtab[((tid >> 3) + C::A_ROWS * j) * p.ntaps + t];
-                const f32x4 v = *(const f32x4*)(abase + (off < 0 ? 0 : off));
-                ra[j] = off < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+                ra[j] = *(const f32x4*)(abase + (off < 0 ? 0 : off));
+                za[j] = off < 0;
             }
             const float* bbase = g_w + p.taps[t].woff + (long)ci0 * p.ldb;
 #pragma unroll
@@ -201,8 +207,8 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
                 const int row = u / (BN / 4), c4 = u % (BN / 4);
                 const int col = n0 + c4 * 4;
                 const int colc = col + 4 <= p.Cout ? col : p.Cout - 4;
-                const f32x4 v = *(const f32x4*)(bbase + (long)row * p.ldb + colc);
-                rb[j] = col + 4 <= p.Cout ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                rb[j] = *(const f32x4*)(bbase + (long)row * p.ldb + colc);
+                zb[j] = col + 4 > p.Cout;
             }
             return;
         }
@@ -275,12 +281,12 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
         float* Bb = Bs + buf * C::BK * C::LDB;
 #pragma unroll
         for (int j = 0; j < C::A_UNITS; ++j)
-            *(f32x4*)(Ab + ((tid >> 3) + C::A_ROWS * j) * C::LDA + c4a * 4) = ra[j];
+            *(f32x4*)(Ab + ((tid >> 3) + C::A_ROWS * j) * C::LDA + c4a * 4) = (FAST && za[j]) ? f32x4{0.f, 0.f, 0.f, 0.f} : ra[j];
 #pragma unroll
         for (int j = 0; j < C::B_UNITS; ++j) {
             const int u = tid + NT * j;
             const int row = u / (BN / 4), c4 = u % (BN / 4);
-            *(f32x4*)(Bb + row * C::LDB + c4 * 4) = rb[j];
+            *(f32x4*)(Bb + row * C::LDB + c4 * 4) = (FAST && zb[j]) ? f32x4{0.f, 0.f, 0.f, 0.f} : rb[j];
         }
     };
 
@@ -354,6 +360,8 @@ const SsTuning& ss_tuning() {
         v.nt512 = getenv("SS_GCONV_NT512") != nullptr;
         v.tile256 = getenv("SS_GCONV_256") != nullptr;
         v.no_winograd = getenv("SS_NO_WINOGRAD") != nullptr;
+        const char* x6 = getenv("SS_X6");
+        v.x6 = !(x6 && x6[0] == '0');      // on by default; SS_X6=0 keeps AUTO on the fp32 MFMA instructions
         const char* r = getenv("SS_WINO_R");
         v.wino_r = (r && r[0] == '2') ? 2 : 4;
         return v;
@@ -464,6 +472,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
     const int c4b = tid % (BN / 4);
 
     f32x4 ra[C::AT_UNITS], rb[C::B_UNITS];
+    bool za[C::AT_UNITS], zb[C::B_UNITS];       // FAST: zero-selects deferred to the LDS store (see gconv_mfma_kernel)
 
     // FAST state: decoded coordinates of the pixel each of this thread's A rows will load next
     int f_n[C::AT_UNITS], f_y[C::AT_UNITS], f_x[C::AT_UNITS];
@@ -488,8 +497,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
                 const int ix = ss_map_index(f_x[j] * p.a_s + p.a_ox + a_dx[0], p.AW, p.reflect);
                 const bool ok = mval && (pk0 + row < pe) && iy >= 0 && ix >= 0;
                 const long off = ok ? ((long)(f_n[j] * p.AH + iy) * p.AW + ix) * p.a_cs + a_c[0] : 0;
-                const f32x4 v = *(const f32x4*)(g_a + off);
-                ra[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                ra[j] = *(const f32x4*)(g_a + off);
+                za[j] = !ok;
                 // advance by one K step (32 pixels); GW >= 32 so at most one row wrap
                 int x = f_x[j] + C::BK, y = f_y[j], n = f_n[j];
                 if (x >= p.GW) { x -= p.GW; ++y; }
@@ -503,8 +512,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
                 const int row = (tid + 256 * j) / (BN / 4);
                 const long pk = pk0 + row;
                 const bool ok = pk < pe && col + 4 <= p.Cb;
-                const f32x4 v = *(const f32x4*)(g_b + (ok ? pk : ps) * p.b_cs + colc);
-                rb[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                rb[j] = *(const f32x4*)(g_b + (ok ? pk : ps) * p.b_cs + colc);
+                zb[j] = !ok;
             }
             return;
         }
@@ -566,12 +575,12 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
 #pragma unroll
         for (int j = 0; j < C::AT_UNITS; ++j) {
             const int row = (tid + 256 * j) / (BM / 4);
-            *(f32x4*)(Ab + row * C::LDAT + c4a * 4) = ra[j];
+            *(f32x4*)(Ab + row * C::LDAT + c4a * 4) = (FAST && za[j]) ? f32x4{0.f, 0.f, 0.f, 0.f} : ra[j];
         }
 #pragma unroll
         for (int j = 0; j < C::B_UNITS; ++j) {
             const int row = (tid + 256 * j) / (BN / 4);
-            *(f32x4*)(Bb + row * C::LDB + c4b * 4) = rb[j];
+            *(f32x4*)(Bb + row * C::LDB + c4b * 4) = (FAST && zb[j]) ? f32x4{0.f, 0.f, 0.f, 0.f} : rb[j];
         }
     };
 

@@ -1,0 +1,322 @@
+// Implicit-GEMM convolution on the bf16 matrix cores with fp32-exact operands ("x6"):
+//   every fp32 value is carried as three bf16 pieces  v = h + m + l  (8+8+8 significant bits with signs: the split is
+//   EXACT for finite normal values), and a product a*b is formed as
+//        ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm          (six v_mfma_f32_32x32x16_bf16, fp32 accumulate)
+//   Every bf16 x bf16 product is exact in fp32; the three dropped cross terms are <= 2^-26 |a*b|, below the rounding of a
+//   single fp32 multiply.  The bf16 MFMA runs at 16x the fp32 MFMA rate, so six products still cost 0.375x.
+//
+// Same problem description as gconv_mfma (GConvParams): C[pixel][cout] = sum_{tap,ci} A_gather[pixel][(tap,ci)] * W[(tap,ci)][cout],
+// requires Cin % 32 == 0 (one tap per K step) and float4-aligned activations.
+//   A: fp32 activations gathered through the per-block LDS offset table (as the fp32 FAST path), split into the three
+//      pieces in registers and stored as three bf16 planes in LDS  [plane][128 pixels][32 k (+8 pad)].
+//   B: weights pre-split once per launch into K-contiguous bf16 planes [plane][batch][cout (padded to 128)][ntaps*Cin]
+//      (wprep_x6_kernel below, or directly by the Winograd weight transform), staged global -> VGPR -> LDS as 16-byte rows.
+// LDS rows are 80 bytes apart: the ds_read_b128 MFMA operand fetches (lane = row, 8 consecutive k) are conflict free.
+// One LDS stage (61 KB at 128x128) so that two workgroups share a CU and cover each other's barriers.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int XK = 32;          // K step (elements)
+constexpr int XLD = XK + 8;     // LDS row stride in bf16 elements (80 bytes)
+constexpr int XBM = 128;
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 values -> packed (h, m, l) bf16 pairs, round-to-nearest-even at every step (v_cvt_pk_bf16_f32 + v_pk_add_f32)
+__device__ __forceinline__ void split3x2(f32x2 v, unsigned int& h, unsigned int& m, unsigned int& l) {
+    const bf16x2 hb = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(hb, f32x2);
+    const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(mb, f32x2);
+    const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+    h = __builtin_bit_cast(unsigned int, hb);
+    m = __builtin_bit_cast(unsigned int, mb);
+    l = __builtin_bit_cast(unsigned int, lb);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems,
+                                                          int Npad, int Ktot, int dbg) {
+    constexpr int BM = XBM;
+    constexpr int TN = BN / 64;          // 32-wide MFMA column tiles per wave (2 waves along N)
+    constexpr int BROWS = BN / 64;       // B loader: rows (tid>>2) + 64*j
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    unsigned short* sA = lds;                          // [3][BM][XLD]
+    unsigned short* sB = lds + 3 * BM * XLD;           // [3][BN][XLD]
+    int* pixtab = (int*)(sB + 3 * BN * XLD);
+    int* offtab = pixtab + BM;                         // [BM][ntaps]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const long M = (long)p.N * p.OHc * p.OWc;
+    const int gridN = (p.Cout + BN - 1) / BN;
+    int tile;
+    {   // XCD-aware order (speed only): contiguous chunk of the tile space per XCD, N fastest
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int gridM = (int)((M + BM - 1) / BM);
+    const int batch = tile / (gridM * gridN);
+    tile -= batch * gridM * gridN;
+    const float* const g_in = p.in + (long)batch * p.in_bs;
+    float* const g_out = p.out + (long)batch * p.out_bs;
+    const long m0 = (long)(tile / gridN) * BM;
+    const int n0 = (tile % gridN) * BN;
+    const int nchunks = Ktot / XK;
+
+    if (tid < BM) {
+        const long m = m0 + tid;
+        int v = -1;
+        if (m < M) {
+            const int xc = (int)(m % p.OWc);
+            const long r = m / p.OWc;
+            const int yc = (int)(r % p.OHc);
+            const int n = (int)(r / p.OHc);
+            const int oy = yc * p.out_s + p.out_oy, ox = xc * p.out_s + p.out_ox;
+            if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) v = (n * p.OH + oy) * p.OW + ox;
+        }
+        pixtab[tid] = v;
+    }
+    for (int idx = tid; idx < BM * p.ntaps; idx += 256) {
+        const int row = idx / p.ntaps, t = idx - row * p.ntaps;
+        const long m = m0 + row;
+        int off = -1;
+        if (m < M) {
+            const int xc = (int)(m % p.OWc);
+            const long r = m / p.OWc;
+            const int yc = (int)(r % p.OHc);
+            const int n = (int)(r / p.OHc);
+            const int iy = ss_map_index(yc * p.in_s + p.in_oy + p.taps[t].dy, p.IH, p.reflect);
+            const int ix = ss_map_index(xc * p.in_s + p.in_ox + p.taps[t].dx, p.IW, p.reflect);
+            if (iy >= 0 && ix >= 0) off = ((n * p.IH + iy) * p.IW + ix) * p.in_cs;
+        }
+        offtab[idx] = off;
+    }
+    __syncthreads();
+
+    const int c4a = tid & 7, arow = tid >> 3;          // A loader: rows arow + 32*j, k = 4*c4a .. +3
+    const int brow = tid >> 2, bpc = tid & 3;          // B loader: rows brow + 64*j, k = 8*bpc .. +7
+    const unsigned short* bbase = bpl + ((long)batch * Npad + n0 + brow) * Ktot + bpc * 8;
+
+    // two register sets: the global loads run TWO K steps ahead of the MFMAs (one step of 48 MFMAs per wave is shorter than
+    // the L2 / HBM latency).  Zero-padding taps: the select is applied at LDS-store time, nothing touches a load earlier.
+    f32x4 ra[2][4];
+    bool ra_ok[2][4];
+    u32x4 rb[2][3][BROWS];
+
+    auto load_tiles = [&](auto setc, int k0) {
+        constexpr int S = decltype(setc)::value;
+        const int t = k0 / p.Cin;                      // block-uniform
+        const int ci0 = k0 - t * p.Cin;
+        const float* abase = g_in + ci0 + c4a * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = offtab[(arow + 32 * j) * p.ntaps + t];
+            ra[S][j] = *(const f32x4*)(abase + (off < 0 ? 0 : off));
+            ra_ok[S][j] = off >= 0;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j)
+                rb[S][pl][j] = *(const u32x4*)(bbase + pl * plane_elems + (long)(64 * j) * Ktot + k0);
+    };
+    auto store_tiles = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned int h[2], m[2], l[2];
+            const f32x4 v = ra_ok[S][j] ? ra[S][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (dbg & 4) {
+                h[0] = __float_as_uint(v[0]); m[0] = __float_as_uint(v[1]); l[0] = h[0] ^ m[0];
+                h[1] = __float_as_uint(v[2]); m[1] = __float_as_uint(v[3]); l[1] = h[1] ^ m[1];
+            } else {
+                split3x2(f32x2{v[0], v[1]}, h[0], m[0], l[0]);
+                split3x2(f32x2{v[2], v[3]}, h[1], m[1], l[1]);
+            }
+            unsigned short* dst = sA + (arow + 32 * j) * XLD + c4a * 4;
+            *(u32x2*)(dst) = u32x2{h[0], h[1]};
+            *(u32x2*)(dst + BM * XLD) = u32x2{m[0], m[1]};
+            *(u32x2*)(dst + 2 * BM * XLD) = u32x2{l[0], l[1]};
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j)
+                *(u32x4*)(sB + pl * BN * XLD + (brow + 64 * j) * XLD + bpc * 8) = rb[S][pl][j];
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    load_tiles(S0{}, 0);
+    if (nchunks > 1) load_tiles(S1{}, XK);
+    store_tiles(S0{});
+    __syncthreads();
+
+    const unsigned short* fa = sA + (wm * 64 + l31) * XLD + 8 * lh;
+    const unsigned short* fb = sB + (wn * (BN / 2) + l31) * XLD + 8 * lh;
+
+    bf16x8 a[3][2], b[3][TN];
+    // step c: chunk c is in LDS, chunk c+1 is in (or on its way to) register set (c+1)&1, chunk c+2 is requested into set c&1
+    auto step = [&](int c, auto cur, auto nxt) {
+        if (c + 2 < nchunks && !(dbg & 2)) load_tiles(cur, (c + 2) * XK);
+#pragma unroll
+        for (int ks = 0; ks < XK / 16; ++ks) {
+            if (!(dbg & 8) || c == 0)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const bf16x8*)(fa + pl * BM * XLD + mi * 32 * XLD + ks * 16);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const bf16x8*)(fb + pl * BN * XLD + ni * 32 * XLD + ks * 16);
+            }
+            // six products, smallest terms first; consecutive MFMAs go to different accumulators
+            constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (dbg & 1) return;
+        __syncthreads();
+        if (c + 1 < nchunks) {
+            store_tiles(nxt);
+            __syncthreads();
+        }
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        step(c, S0{}, S1{});
+        if (c + 1 < nchunks) step(c + 1, S1{}, S0{});
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int co = n0 + wn * (BN / 2) + ni * 32 + l31;
+        if (co >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int pix = pixtab[wm * 64 + mi * 32 + row];
+                if (pix < 0) continue;
+                float* op = g_out + (long)pix * p.out_cs + co;
+                float v = ss_apply_act(acc[mi][ni][r] + bv, p.act, p.alpha);
+                if (p.accumulate) v += *op;
+                *op = v;
+            }
+        }
+    }
+}
+
+// planes[pl][batch][n][t*Cin + ci] = piece pl of w[batch*w_bs + taps[t].woff + ci*ldb + n]; rows n in [Cout, Npad) are zero.
+// 32x32 LDS transpose: coalesced reads along n, coalesced writes along k.
+__global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned short* __restrict__ planes, long plane_elems, int Npad, int Ktot) {
+    __shared__ float tl[32][33];
+    const int batch = blockIdx.z;
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const float* w = p.w + (long)batch * p.w_bs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i, n = n0 + tx;
+        float v = 0.f;
+        if (k < Ktot && n < p.Cout) {
+            const int t = k / p.Cin, ci = k - t * p.Cin;
+            v = w[p.taps[t].woff + (long)ci * p.ldb + n];
+        }
+        tl[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, k = k0 + tx;
+        if (n < Npad && k < Ktot) {
+            unsigned int h, m, l;
+            split3x2(f32x2{tl[tx][ty + 8 * i], 0.f}, h, m, l);
+            const long o = ((long)batch * Npad + n) * Ktot + k;
+            planes[o] = (unsigned short)(h & 0xffffu);
+            planes[o + plane_elems] = (unsigned short)(m & 0xffffu);
+            planes[o + 2 * plane_elems] = (unsigned short)(l & 0xffffu);
+        }
+    }
+}
+
+template <int BN>
+int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
+    const long M = (long)p.N * p.OHc * p.OWc;
+    const int nb = p.nbatch > 1 ? p.nbatch : 1;
+    dim3 grid((unsigned)(((M + XBM - 1) / XBM) * ((p.Cout + BN - 1) / BN) * nb));
+    const size_t smem = (size_t)3 * (XBM + BN) * XLD * sizeof(unsigned short) + (size_t)XBM * sizeof(int) * (1 + p.ntaps);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gconv_x6_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    static const int dbg = getenv("SS_X6_DBG") ? atoi(getenv("SS_X6_DBG")) : 0;     // measurement only
+    hipLaunchKernelGGL((gconv_x6_kernel<BN>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot, dbg);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+}  // namespace
+
+int ss_x6_npad(int cout) { return (cout + 127) / 128 * 128; }
+
+bool ss_gconv_x6_ok(const GConvParams& p) {
+    const long in_elems = (long)p.N * p.IH * p.IW * p.in_cs * (p.nbatch > 1 ? 1 : 1);
+    return p.ntaps >= 1 && p.Cin % 32 == 0 && p.in_cs % 4 == 0 && (((uintptr_t)p.in) & 15) == 0 && p.Cout >= 32 &&
+           in_elems < (1L << 31) && (p.nbatch <= 1 || (p.in_bs % 4 == 0));
+}
+
+size_t ss_gconv_x6_planes_bytes(const GConvParams& p) {
+    const int nb = p.nbatch > 1 ? p.nbatch : 1;
+    return ss_align_up((size_t)3 * nb * ss_x6_npad(p.Cout) * p.ntaps * p.Cin * sizeof(unsigned short), 256);
+}
+
+// weights of `p` (fp32, addressed through p.w / taps / ldb / w_bs) -> the three K-contiguous bf16 planes
+int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s) {
+    const int nb = p.nbatch > 1 ? p.nbatch : 1;
+    const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * p.Cin;
+    const long plane_elems = (long)nb * Npad * Ktot;
+    hipLaunchKernelGGL(wprep_x6_kernel, dim3((Ktot + 31) / 32, Npad / 32, nb), dim3(256), 0, s, p, planes, plane_elems, Npad, Ktot);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipStream_t s) {
+    const long M = (long)p.N * p.OHc * p.OWc;
+    if (M == 0) return SS_OK;
+    if (!ss_gconv_x6_ok(p)) return SS_ERR_UNSUPPORTED;
+    const int nb = p.nbatch > 1 ? p.nbatch : 1;
+    const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * p.Cin;
+    const long plane_elems = (long)nb * Npad * Ktot;
+    if (p.Cout > 64) return launch_x6<128>(p, planes, plane_elems, Npad, Ktot, s);
+    return launch_x6<64>(p, planes, plane_elems, Npad, Ktot, s);
+}

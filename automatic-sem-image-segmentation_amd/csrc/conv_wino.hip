@@ -371,7 +371,15 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     g.ldb = q.cout; g.reflect = 0; g.act = SS_ACT_NONE; g.alpha = 0.f; g.accumulate = 0;
     g.nbatch = XI; g.in_bs = tiles * q.cin; g.w_bs = (long)q.cin * q.cout; g.out_bs = tiles * q.cout;
     g.ntaps = 1; g.taps[0].dy = 0; g.taps[0].dx = 0; g.taps[0].woff = 0;
-    int rc = ss_launch_gconv_mfma(g, s);
+    int rc;
+    if (q.x6 && ss_gconv_x6_ok(g)) {     // fp32-exact GEMMs on the bf16 matrix cores: planes of U after the fp32 scratch
+        unsigned short* planes = (unsigned short*)((char*)Mx + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
+        rc = ss_launch_wprep_x6(g, planes, s);
+        if (rc != SS_OK) return rc;
+        rc = ss_launch_gconv_x6(g, planes, s);
+    } else {
+        rc = ss_launch_gconv_mfma(g, s);
+    }
     if (rc != SS_OK) return rc;
     hipLaunchKernelGGL(wino_output_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
                        bias, act, alpha, y, q.out_cs, accumulate);
@@ -422,8 +430,9 @@ bool ss_wino_ok(const WinoProb& q) {
 size_t ss_wino_fwd_ws(const WinoProb& q) {
     const int R = wino_r(), XI = (R + 2) * (R + 2);
     const long tiles = n_tiles(q, R);
+    const size_t planes = ss_align_up((size_t)3 * XI * ss_x6_npad(q.cout) * q.cin * 2, 256);
     return ss_align_up((size_t)XI * q.cin * q.cout * 4, 256) + ss_align_up((size_t)XI * tiles * q.cin * 4, 256) +
-           ss_align_up((size_t)XI * tiles * q.cout * 4, 256);
+           ss_align_up((size_t)XI * tiles * q.cout * 4, 256) + planes;
 }
 
 // y (+)= act(bias + conv3x3_stride1(x)) with out[o] = sum_a in[map(o + a - pt)] * g[a];  flip = 1: g = rotated + transposed w

@@ -43,7 +43,13 @@ enum { SS_ALGO_AUTO = 0, SS_ALGO_DIRECT = 1, SS_ALGO_MFMA = 2,
        /* AUTO + opt-in "split-bf16" matrix-core arithmetic for the Winograd GEMMs: every fp32 operand is carried as
         * hi + lo bf16 planes and each product as hi*hi + hi*lo + lo*hi with fp32 accumulation (~2^-16 relative per
         * product; the default paths are exact fp32) */
-       SS_ALGO_BF16X3 = 3 };
+       SS_ALGO_BF16X3 = 3,
+       /* fp32-exact contraction on the bf16 matrix cores ("x6"): every fp32 operand is split EXACTLY into three bf16
+        * pieces (h + m + l) and each product is formed as the six leading piece products with fp32 accumulation
+        * (dropped terms <= 2^-26 relative, below one fp32 rounding).  AUTO uses it wherever the shape is eligible
+        * (reduction channels % 32 == 0) unless the environment says SS_X6=0; SS_ALGO_MFMA never uses it
+        * (v_mfma_f32_32x32x2_f32 only); SS_ALGO_X6 forces it on eligible shapes. */
+       SS_ALGO_X6 = 4 };
 
 int ss_version(void);
 const char* ss_status_string(int status);

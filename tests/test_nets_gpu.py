@@ -90,7 +90,8 @@ def run_net_fwd_bwd(net_hip, make_ref, x_cpu, gen, grad_tol=None, noise_mult=3, 
         names = [k for k in gw64 if float(gw64[k].abs().max()) >= 1e-9]
         cat = lambda d: np.concatenate([np.asarray(d[k], np.float64).ravel() for k in names])
         e_hip_all, e_32_all = rel_l2(cat(grads), cat(gw64)), rel_l2(cat(gw32), cat(gw64))
-        assert e_hip_all <= 3 * e_32_all + 1e-3, (e_hip_all, e_32_all)
+        print(f'aggregate gradient error: hip={e_hip_all:.3e} oracle32={e_32_all:.3e}')
+        assert e_hip_all <= noise_mult * e_32_all + 1e-3, (e_hip_all, e_32_all)
         for k in names:
             assert rel_l2(grads[k], gw64[k]) <= max(0.05, 30 * noise), k
         return ref32, ref64

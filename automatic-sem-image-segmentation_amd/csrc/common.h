@@ -89,6 +89,7 @@ struct WGradParams {
     int32_t reflect;
     int32_t splits, pix_per_split;
     int32_t nbatch;               // batched problems (Winograd); partials laid out [batch][split][M][Cb]
+    int32_t x6;                   // 1: fp32-exact contraction on the bf16 matrix cores where the shape allows (conv_mfma_x6.hip)
     int64_t a_bs, b_bs;
     int32_t ntaps;
     GTap taps[SS_MAX_TAPS];       // woff = destination offset of the tap block inside dw
@@ -114,6 +115,8 @@ int ss_x6_npad(int cout);
 size_t ss_gconv_x6_planes_bytes(const GConvParams& p);      // [3][nbatch][npad(Cout)][ntaps*Cin] bf16
 int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s);
 int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipStream_t s);
+bool ss_wgrad_x6_ok(const WGradParams& p);
+int ss_launch_wgrad_x6_partials(const WGradParams& p, hipStream_t s);
 
 // Winograd F(2x2,3x3) path (conv_wino.hip): 3x3, stride 1; out[o] = sum_a in[map(o + a - pt)] * g[a]
 struct WinoProb {

@@ -423,6 +423,7 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
         if (wino_fwd_prob(c, algo, &q)) return ss_wino_conv_wgrad(q, x, dy, dw, accumulate, ws, ws_bytes, s);
     }
     WGradParams p{};
+    p.x6 = x6_wanted(algo);
     p.a = x; p.b = dy; p.part = (float*)ws;
     p.N = c.n; p.AH = c.ih; p.AW = c.iw; p.Ca = c.cin; p.a_cs = c.in_cs;
     p.GH = c.oh; p.GW = c.ow; p.Cb = c.cout; p.b_cs = c.out_cs;

@@ -708,7 +708,7 @@ int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accu
 }
 
 int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s) {
-    const long P = (long)p.N * p.GH * p.GW;
+    if (p.x6 && ss_wgrad_x6_ok(p)) return ss_launch_wgrad_x6_partials(p, s);
     {
         const int vecA = (p.Ca % 4 == 0) && (p.a_cs % 4 == 0) && (((uintptr_t)p.a & 15) == 0);
         const int vecB = (p.b_cs % 4 == 0) && (((uintptr_t)p.b & 15) == 0);

@@ -268,6 +268,183 @@ __global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned s
     }
 }
 
+// Weight gradient with the same arithmetic:  part[split][(t,ca)][cb] = sum_pixels A_gather[pixel][(t,ca)] * B[pixel][cb].
+// The reduction index is the PIXEL, which is the slow index of both NHWC operands, so the tiles are transposed on their way
+// into LDS: a thread owns 4 consecutive pixels x 4 consecutive channels (four 16-byte global loads), splits them, and
+// writes, per channel and piece, the 4 pixels as one 8-byte LDS store into the k-contiguous row of that channel.
+// Lane -> (pixel group = tid & 7, channel quad = tid >> 3): a 16-lane store group covers two rows x 16 dwords = 32 banks.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
+    constexpr int BM = XBM;
+    constexpr int TN = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    unsigned short* sA = lds;                          // [3][BM][XLD]
+    unsigned short* sB = lds + 3 * BM * XLD;           // [3][BN][XLD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int M = p.ntaps * p.Ca;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z % p.splits;
+    const int batch = blockIdx.z / p.splits;
+    const float* const g_a = p.a + (long)batch * p.a_bs;
+    const float* const g_b = p.b + (long)batch * p.b_bs;
+    const long P = (long)p.N * p.GH * p.GW;
+    const long ps = (long)split * p.pix_per_split;
+    const long pe = (ps + p.pix_per_split < P) ? ps + p.pix_per_split : P;
+    const int nchunks = (int)((pe - ps + XK - 1) / XK);
+
+    const int kq = tid & 7, cq = tid >> 3;
+    // A: this thread's channel quad (fixed over the pixel loop)
+    const int am = m0 + 4 * cq;
+    const bool a_val = am < M;
+    const int a_t = a_val ? am / p.Ca : 0;
+    const int a_c = a_val ? am - a_t * p.Ca : 0;
+    const int a_dy = p.taps[a_t].dy, a_dx = p.taps[a_t].dx;
+    // B: channel quad n0 + 4*cq (BN = 64: only quads 0..15 exist)
+    const int bn = n0 + 4 * cq;
+    const bool b_val = (4 * cq < BN) && (bn + 4 <= p.Cb);
+
+    // decoded coordinates of this thread's first pixel of the current K step
+    int f_x, f_y, f_n;
+    {
+        const long pk = ps + 4 * kq;
+        f_x = (int)(pk % p.GW);
+        const long r = pk / p.GW;
+        f_y = (int)(r % p.GH);
+        f_n = (int)(r / p.GH);
+    }
+
+    f32x4 ra[4], rb[4];
+    bool za[4], zb[4];
+    auto load_tiles = [&](long pk0) {
+        int x = f_x, y = f_y, n = f_n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long pk = pk0 + 4 * kq + i;
+            const int iy = ss_map_index(y * p.a_s + p.a_oy + a_dy, p.AH, p.reflect);
+            const int ix = ss_map_index(x * p.a_s + p.a_ox + a_dx, p.AW, p.reflect);
+            const bool oka = a_val && pk < pe && iy >= 0 && ix >= 0;
+            const long off = oka ? ((long)(n * p.AH + iy) * p.AW + ix) * p.a_cs + a_c : 0;
+            ra[i] = *(const f32x4*)(g_a + off);
+            za[i] = !oka;
+            const bool okb = b_val && pk < pe;
+            rb[i] = *(const f32x4*)(g_b + (okb ? pk * p.b_cs + bn : 0));
+            zb[i] = !okb;
+            if (++x >= p.GW) { x = 0; if (++y >= p.GH) { y = 0; ++n; } }
+        }
+        // advance the base pixel by one K step
+        f_x += XK;
+        while (f_x >= p.GW) { f_x -= p.GW; if (++f_y >= p.GH) { f_y = 0; ++f_n; } }
+    };
+    auto store_tiles = [&]() {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 va[4], vb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { va[i] = za[i] ? z : ra[i]; vb[i] = zb[i] ? z : rb[i]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned int h0, m0_, l0, h1, m1, l1;
+            split3x2(f32x2{va[0][e], va[1][e]}, h0, m0_, l0);
+            split3x2(f32x2{va[2][e], va[3][e]}, h1, m1, l1);
+            unsigned short* dst = sA + (4 * cq + e) * XLD + 4 * kq;
+            *(u32x2*)(dst) = u32x2{h0, h1};
+            *(u32x2*)(dst + BM * XLD) = u32x2{m0_, m1};
+            *(u32x2*)(dst + 2 * BM * XLD) = u32x2{l0, l1};
+        }
+        if (4 * cq < BN) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned int h0, m0_, l0, h1, m1, l1;
+                split3x2(f32x2{vb[0][e], vb[1][e]}, h0, m0_, l0);
+                split3x2(f32x2{vb[2][e], vb[3][e]}, h1, m1, l1);
+                unsigned short* dst = sB + (4 * cq + e) * XLD + 4 * kq;
+                *(u32x2*)(dst) = u32x2{h0, h1};
+                *(u32x2*)(dst + BN * XLD) = u32x2{m0_, m1};
+                *(u32x2*)(dst + 2 * BN * XLD) = u32x2{l0, l1};
+            }
+        }
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    if (nchunks > 0) {
+        load_tiles(ps);
+        store_tiles();
+    }
+    __syncthreads();
+
+    const unsigned short* fa = sA + (wm * 64 + l31) * XLD + 8 * lh;
+    const unsigned short* fb = sB + (wn * (BN / 2) + l31) * XLD + 8 * lh;
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) load_tiles(ps + (long)(c + 1) * XK);
+#pragma unroll
+        for (int ks = 0; ks < XK / 16; ++ks) {
+            bf16x8 a[3][2], b[3][TN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const bf16x8*)(fa + pl * BM * XLD + mi * 32 * XLD + ks * 16);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const bf16x8*)(fb + pl * BN * XLD + ni * 32 * XLD + ks * 16);
+            }
+            constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+        if (c + 1 < nchunks) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    float* part = p.part + (long)blockIdx.z * M * p.Cb;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int n = n0 + wn * (BN / 2) + ni * 32 + l31;
+        if (n >= p.Cb) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M) part[(long)m * p.Cb + n] = acc[mi][ni][r];
+            }
+        }
+    }
+}
+
+template <int BN>
+int launch_wgrad_x6(const WGradParams& p, hipStream_t s) {
+    const int M = p.ntaps * p.Ca;
+    dim3 grid((M + XBM - 1) / XBM, (p.Cb + BN - 1) / BN, p.splits * (p.nbatch > 1 ? p.nbatch : 1));
+    const size_t smem = (size_t)3 * (XBM + BN) * XLD * sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_x6_kernel<BN>), grid, dim3(256), smem, s, p);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
 template <int BN>
 int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
     const long M = (long)p.N * p.OHc * p.OWc;
@@ -319,4 +496,17 @@ int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipSt
     const long plane_elems = (long)nb * Npad * Ktot;
     if (p.Cout > 64) return launch_x6<128>(p, planes, plane_elems, Npad, Ktot, s);
     return launch_x6<64>(p, planes, plane_elems, Npad, Ktot, s);
+}
+
+bool ss_wgrad_x6_ok(const WGradParams& p) {
+    return p.ntaps >= 1 && p.Ca % 32 == 0 && p.a_cs % 4 == 0 && (((uintptr_t)p.a) & 15) == 0 && p.Cb >= 32 && p.Cb % 4 == 0 &&
+           p.b_cs % 4 == 0 && (((uintptr_t)p.b) & 15) == 0 && p.GW >= 4 && p.pix_per_split % 32 == 0 &&
+           (p.nbatch <= 1 || (p.a_bs % 4 == 0 && p.b_bs % 4 == 0));
+}
+
+// partials only: part[batch][split][(t,ca)][cb]
+int ss_launch_wgrad_x6_partials(const WGradParams& p, hipStream_t s) {
+    if (!ss_wgrad_x6_ok(p)) return SS_ERR_UNSUPPORTED;
+    if (p.Cb > 64) return launch_wgrad_x6<128>(p, s);
+    return launch_wgrad_x6<64>(p, s);
 }

@@ -401,6 +401,7 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
     hipLaunchKernelGGL(wino_dy_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, E);
     SS_LAUNCH_CHECK();
     WGradParams p{};
+    p.x6 = q.x6;
     p.a = V; p.b = E; p.part = part;
     p.N = 1; p.AH = 1; p.AW = (int)tiles; p.Ca = q.cin; p.a_cs = q.cin;
     p.GH = 1; p.GW = (int)tiles; p.Cb = q.cout; p.b_cs = q.cout;

@@ -358,3 +358,58 @@ def test_conv_split_bf16_opt_in(case):
     assert_close(x.get_grad().dense().cpu(), xr.grad.float(), f"{name} bf16x3 dx", rtol=2e-3)
     assert rel_l2(x.get_grad().dense().cpu().numpy(), xr.grad.numpy()) <= 2e-4
     assert_close(arena.grad("c/kernel").cpu(), wr.grad.float(), f"{name} bf16x3 dw", rtol=2e-4)
+
+
+X6_CASES = [
+    # name, k, cin, cout, stride, padding, bias, act, transposed, n, h, w     (reduction channels % 32 == 0, >= 1024 output pixels)
+    ("x6_disc_4x4_s2", 4, 128, 256, 2, "valid", False, None, False, 2, 66, 66),
+    ("x6_down_3x3_s2", 3, 64, 128, 2, "same", False, None, False, 2, 64, 64),
+    ("x6_up_T3", 3, 128, 64, 2, "same", False, None, True, 2, 32, 32),
+    ("x6_trunk_wino", 3, 256, 256, 1, ("reflect", 1), False, None, False, 2, 48, 48),
+    ("x6_3x3_same_bias_tanh", 3, 96, 40, 1, "same", True, "tanh", False, 1, 40, 36),
+]
+
+
+@pytest.mark.parametrize("case", X6_CASES, ids=[c[0] for c in X6_CASES])
+def test_conv_x6_is_fp32_grade(case):
+    """SS_ALGO_X6 (what AUTO picks for these shapes): fp32 operands split EXACTLY into three bf16 pieces, six piece products on
+    the bf16 matrix cores, fp32 accumulation.  Claim under test: the result is as close to the fp64 oracle as the
+    v_mfma_f32_32x32x2_f32 path (SS_ALGO_MFMA) -- same 1e-4 parity bar, and rel-L2 error within 1.5x of the fp32-MFMA
+    path's own rounding error (both are ~1e-7 .. 1e-6; the weight gradient runs on the fp32 MFMA path in both)."""
+    E, LY, L = _mods()
+    name, k, cin, cout, stride, padding, bias, act, transposed, n, h, w = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    w_cpu = (torch.rand((k, k, cout, cin) if transposed else (k, k, cin, cout), generator=g, dtype=torch.float64) - 0.5) * 0.2
+    b_cpu = torch.rand(cout, generator=g, dtype=torch.float64) - 0.5 if bias else None
+    x_cpu = torch.rand((n, h, w, cin), generator=g, dtype=torch.float64) * 2 - 1
+    xr = x_cpu.clone().requires_grad_(True)
+    wr = w_cpu.clone().requires_grad_(True)
+    yr = oracle_conv(xr, wr, b_cpu, k, stride, padding, act, transposed)
+    gy = torch.rand(yr.shape, generator=g, dtype=torch.float64) - 0.5
+    yr.backward(gy)
+    errs = {}
+    for algo in (L.ALGO_MFMA, L.ALGO_X6):
+        arena = E.ParamArena(dev)
+        layer = LY.Conv2D(arena, "c", k, cin, cout, stride=stride, padding=padding, use_bias=bias, act=act, act_alpha=0.2,
+                          transposed=transposed, algo=algo)
+        arena.materialize()
+        arena["c/kernel"].copy_(w_cpu.float())
+        if bias:
+            arena["c/bias"].copy_(b_cpu.float())
+        tape = E.Tape()
+        x = E.Act(x_cpu.float().to(dev), requires_grad=True)
+        y = layer(tape, x)
+        gt, _ = y.grad_target()
+        gt.t.copy_(gy.float().to(dev))
+        arena.zero_grad()
+        tape.backward()
+        got_y, got_dx, got_dw = y.dense().cpu(), x.get_grad().dense().cpu(), arena.grad("c/kernel").cpu()
+        assert_close(got_y, yr.detach(), f"{name}/{algo} fwd", rtol=1e-4)
+        assert_close(got_dx, xr.grad, f"{name}/{algo} dx", rtol=2e-4)
+        assert_close(got_dw, wr.grad, f"{name}/{algo} dw", rtol=2e-4)
+        errs[algo] = (rel_l2(got_y.numpy(), yr.detach().numpy()), rel_l2(got_dx.numpy(), xr.grad.numpy()))
+    print(f"{name}: rel-L2 vs fp64  fp32-MFMA y={errs[L.ALGO_MFMA][0]:.2e} dx={errs[L.ALGO_MFMA][1]:.2e}   "
+          f"x6 y={errs[L.ALGO_X6][0]:.2e} dx={errs[L.ALGO_X6][1]:.2e}")
+    for i in (0, 1):
+        assert errs[L.ALGO_X6][i] <= 1.5 * errs[L.ALGO_MFMA][i] + 2e-7, errs

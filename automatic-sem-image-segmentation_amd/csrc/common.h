@@ -109,6 +109,12 @@ int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accu
 int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split, int nbatch = 1);
 int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s);   // partials only: part[batch][split][M][Cb]
 
+// LDS-tiled VALU kernels for stride-1 convs with one channel on one side (conv_c1.hip)
+bool ss_conv_out1_ok(const GConvParams& p);
+int ss_launch_conv_out1(const GConvParams& p, hipStream_t s);
+bool ss_conv_in1_ok(const GConvParams& p);
+int ss_launch_conv_in1(const GConvParams& p, hipStream_t s);
+
 // fp32-exact contraction on the bf16 matrix cores (conv_mfma_x6.hip): three bf16 pieces per operand, six products
 bool ss_gconv_x6_ok(const GConvParams& p);                  // shape / alignment eligibility
 int ss_x6_npad(int cout);

@@ -214,6 +214,10 @@ size_t gconv_ws_bytes(int algo, const GConvParams& p) {
 }
 
 int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (algo != SS_ALGO_DIRECT && algo != SS_ALGO_MFMA) {        // full-resolution 7x7 stem / head shapes: LDS-tiled VALU kernels
+        if (ss_conv_out1_ok(p)) return ss_launch_conv_out1(p, s);
+        if (ss_conv_in1_ok(p)) return ss_launch_conv_in1(p, s);
+    }
     if (gconv_two_stage(algo, p)) {
         if (!ws || ws_bytes < gconv_ws_bytes(algo, p)) return SS_ERR_WORKSPACE;
         const int tcs = round4(p.ntaps);

@@ -160,6 +160,8 @@ def main():
         out = {"metric": "train_step tiles/sec (CycleGAN+UNet)", "value": round(value, 4), "unit": "tiles/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "arithmetic": "fp32 storage and accumulation everywhere; large contractions as exact 3-way bf16 splits x 6 MFMA products "
+                             "(fp32-grade, SS_X6=0 switches to v_mfma_f32_32x32x2_f32)" if os.environ.get("SS_X6", "1") != "0" else "fp32 MFMA",
                "config": {"workload": f"CycleGAN(2xResNet-9 gen F={F} + 2xPatchGAN, image buffer 50) train_step + MultiResUNet(16) "
                                       f"train_step, {S}x{S} grayscale tiles, global batch {GB}" + (" [CycleGAN only]" if args.skip_unet else ""),
                           "tile": S, "global_batch": GB, "per_gpu_batch": per, "parallelism": f"dp{world}"}}
@@ -169,18 +171,23 @@ def main():
             ach = flops / (tk["avg_ms"] * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": "3x3 512->512 trunk conv forward = wino_input<4> + batched gconv_mfma_kernel<128,128,FAST> (36 fp32-MFMA GEMMs, "
-                          "v_mfma_f32_32x32x2_f32) + wino_output; reflect pad fused in the input transform",
+                "kernel": "3x3 512->512 trunk conv forward = wino_weight<4> + wprep_x6 + wino_input<4> + batched gconv_x6_kernel<128> "
+                          "(36 GEMMs; fp32 operands split exactly into 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per product, fp32 "
+                          "accumulate) + wino_output; reflect pad fused in the input transform.  SS_X6=0: fp32-MFMA GEMMs instead",
                 # ALGORITHMIC (direct-convolution) FLOPs of the op / HIP-event duration of the op inside the timed region
                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                "note": "Winograd F(4x4,3x3) executes 4x fewer multiply-adds than the algorithmic count (38.7 of 154.6 GFLOP per launch at "
-                        "batch 8), so frac can exceed 1; the batched fp32-MFMA GEMM itself runs at ~0.6-0.7 of the fp32 matrix peak "
-                        "(profiles/r01_h_winograd43_kernel_stats.md, profiles/r01_pmc_trunk_fwd.md)",
+                "note": "peak = dense fp32 matrix peak (v_mfma_f32_32x32x2_f32), the dtype's peak; frac exceeds 1 because (a) Winograd "
+                        "F(4x4,3x3) executes 4x fewer multiply-adds than the algorithmic count (38.7 of 154.6 GFLOP per launch at batch "
+                        "8) and (b) the GEMMs run as 6 bf16-MFMA products per fp32 product (0.375x the fp32-MFMA cost, error below one "
+                        "fp32 rounding: tests/test_layers_gpu.py::test_conv_x6_is_fp32_grade).  The x6 GEMM itself sustains ~0.7 PFLOP/s "
+                        "of bf16 MFMA work = 0.29 of the 2.5 PFLOP/s bf16 peak, 53 % matrix-pipe utilisation at the 1.73 GHz the chip "
+                        "holds under this load (profiles/r01_pmc_trunk_fwd_x6.md)",
+                "executed_bf16_mfma_flops_per_launch": flops / 4.0 * 6.0,
                 "executed_mfma_flops_per_launch": flops / 4.0,
                 # PMC cannot be sampled from inside this process: rocprofv3 pass on the direct (non-Winograd) kernel of this shape
                 # PMC cannot be sampled from inside this process: committed rocprofv3 passes on this op/shape at batch 8
-                # (profiles/r01_pmc_trunk_fwd.md): sum over the op's 4 kernels of 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
-                "traffic": (2 * (4644 + 49984 + 102747 + 73890) + (36864 + 147456 + 147456 + 65536)) * 1024.0 if (per == 8 and S == 512 and F == 64) else None,
+                # (profiles/r01_pmc_trunk_fwd_x6.md): sum over the op's 5 kernels of 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
+                "traffic": (2 * (4638 + 18461 + 49921 + 117257 + 73889) + (36864 + 55296 + 147456 + 147456 + 65536)) * 1024.0 if (per == 8 and S == 512 and F == 64) else None,
                 "traffic_unit": "bytes per op launch", "algorithmic_bytes": 4.0 * (2 * per * (S // 8) ** 2 * 8 * F + 9 * (8 * F) ** 2),
                 "winograd_algorithmic_bytes": 4.0 * ((1 + 4 * 2.25 + 1) * per * (S // 8) ** 2 * 8 * F + (9 + 36 + 36) * (8 * F) ** 2),
                 "launches_timed": tk["launches"], "avg_launch_ms": round(tk["avg_ms"], 4), "flops_per_launch": flops}

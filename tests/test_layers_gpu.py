@@ -61,6 +61,11 @@ CONV_CASES = [
     ("disc_in_16_two_stage_dgrad", 4, 1, 16, 2, "valid", True, "lrelu", False, 2, 32, 32),
     ("disc_out_32_two_stage", 4, 32, 1, 1, "valid", True, None, False, 2, 7, 9),
     ("head_same_two_stage", 3, 24, 1, 1, "same", False, None, False, 2, 10, 10),
+    # >= 16384 output pixels, stride 1, one channel on one side: LDS-tiled VALU kernels (conv_c1.hip), forward and data gradient
+    ("c7_out_tiled", 7, 16, 1, 1, ("reflect", 3), True, "tanh", False, 1, 128, 130),
+    ("c7_in_tiled", 7, 1, 32, 1, ("reflect", 3), False, None, False, 1, 130, 128),
+    ("c4_out_tiled_valid", 4, 12, 1, 1, "valid", True, None, False, 2, 100, 96),
+    ("c3_in_tiled_same_bias", 3, 1, 16, 1, "same", True, "lrelu", False, 2, 96, 100),
 ]
 
 

@@ -31,11 +31,18 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // two fp32 values -> packed (h, m, l) bf16 pairs, round-to-nearest-even at every step (v_cvt_pk_bf16_f32 + v_pk_add_f32)
+__device__ __forceinline__ float sub1(float a, float b) {      // plain v_sub_f32: keeps the SLP vectoriser from forming v_pk_add_f32,
+    float r;                                                     // which is slow next to an MFMA stream (MI355X_MICROARCH.md)
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void split3x2(f32x2 v, unsigned int& h, unsigned int& m, unsigned int& l) {
     const bf16x2 hb = __builtin_convertvector(v, bf16x2);
-    const f32x2 r1 = v - __builtin_convertvector(hb, f32x2);
+    const f32x2 hf = __builtin_convertvector(hb, f32x2);
+    const f32x2 r1 = {sub1(v[0], hf[0]), sub1(v[1], hf[1])};
     const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
-    const f32x2 r2 = r1 - __builtin_convertvector(mb, f32x2);
+    const f32x2 mf = __builtin_convertvector(mb, f32x2);
+    const f32x2 r2 = {sub1(r1[0], mf[0]), sub1(r1[1], mf[1])};
     const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
     h = __builtin_bit_cast(unsigned int, hb);
     m = __builtin_bit_cast(unsigned int, mb);
@@ -44,7 +51,7 @@ __device__ __forceinline__ void split3x2(f32x2 v, unsigned int& h, unsigned int&
 
 template <int BN>
 __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems,
-                                                          int Npad, int Ktot, int dbg) {
+                                                          int Npad, int Ktot) {
     constexpr int BM = XBM;
     constexpr int TN = BN / 64;          // 32-wide MFMA column tiles per wave (2 waves along N)
     constexpr int BROWS = BN / 64;       // B loader: rows (tid>>2) + 64*j
@@ -140,13 +147,8 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         for (int j = 0; j < 4; ++j) {
             unsigned int h[2], m[2], l[2];
             const f32x4 v = ra_ok[S][j] ? ra[S][j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (dbg & 4) {
-                h[0] = __float_as_uint(v[0]); m[0] = __float_as_uint(v[1]); l[0] = h[0] ^ m[0];
-                h[1] = __float_as_uint(v[2]); m[1] = __float_as_uint(v[3]); l[1] = h[1] ^ m[1];
-            } else {
-                split3x2(f32x2{v[0], v[1]}, h[0], m[0], l[0]);
-                split3x2(f32x2{v[2], v[3]}, h[1], m[1], l[1]);
-            }
+            split3x2(f32x2{v[0], v[1]}, h[0], m[0], l[0]);
+            split3x2(f32x2{v[2], v[3]}, h[1], m[1], l[1]);
             unsigned short* dst = sA + (arow + 32 * j) * XLD + c4a * 4;
             *(u32x2*)(dst) = u32x2{h[0], h[1]};
             *(u32x2*)(dst + BM * XLD) = u32x2{m[0], m[1]};
@@ -177,13 +179,12 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const unsigned short* fa = sA + (wm * 64 + l31) * XLD + 8 * lh;
     const unsigned short* fb = sB + (wn * (BN / 2) + l31) * XLD + 8 * lh;
 
-    bf16x8 a[3][2], b[3][TN];
     // step c: chunk c is in LDS, chunk c+1 is in (or on its way to) register set (c+1)&1, chunk c+2 is requested into set c&1
     auto step = [&](int c, auto cur, auto nxt) {
-        if (c + 2 < nchunks && !(dbg & 2)) load_tiles(cur, (c + 2) * XK);
+        if (c + 2 < nchunks) load_tiles(cur, (c + 2) * XK);
 #pragma unroll
         for (int ks = 0; ks < XK / 16; ++ks) {
-            if (!(dbg & 8) || c == 0)
+            bf16x8 a[3][2], b[3][TN];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
@@ -201,7 +202,6 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
                     for (int ni = 0; ni < TN; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
         }
-        if (dbg & 1) return;
         __syncthreads();
         if (c + 1 < nchunks) {
             store_tiles(nxt);
@@ -456,8 +456,7 @@ int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_ele
         (void)hipFuncSetAttribute((const void*)gconv_x6_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    static const int dbg = getenv("SS_X6_DBG") ? atoi(getenv("SS_X6_DBG")) : 0;     // measurement only
-    hipLaunchKernelGGL((gconv_x6_kernel<BN>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot, dbg);
+    hipLaunchKernelGGL((gconv_x6_kernel<BN>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

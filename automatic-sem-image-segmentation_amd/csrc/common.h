@@ -131,6 +131,8 @@ struct WinoProb {
     int pt, pl, reflect;
     int bf16x3;                   // 1: the batched GEMMs run as split-bf16 (3 products) on the bf16 matrix cores (opt-in)
     int x6;                       // 1: forward / data-gradient GEMMs as fp32-exact 6-product bf16 contraction (conv_mfma_x6.hip)
+    int fold_h, fold_w;           // > 0: the (oh, ow) grid is a shifted padded gradient that the output transform folds onto an
+                                  // (fold_h x fold_w) tensor (reflect-pad data gradient, conv_wino.hip wino_output_kernel)
 };
 
 // C[b][m][n] = sum_k (Ah+Al)[b][m][k] * (Bh+Bl)[b][n][k], bf16 planes, fp32 output (gemm_bf16x3.hip)

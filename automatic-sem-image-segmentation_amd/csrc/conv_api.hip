@@ -271,16 +271,23 @@ GConvParams fwd_params(const ConvProb& c, const float* x, const float* w, const 
 // Winograd F(2x2,3x3) eligibility of the plain conv `c` (forward / weight-gradient view)
 bool wino_fwd_prob(const ConvProb& c, int algo, WinoProb* q) {
     if (algo == SS_ALGO_DIRECT || c.kh != 3 || c.kw != 3 || c.s != 1) return false;
-    *q = WinoProb{c.n, c.ih, c.iw, c.cin, c.in_cs, c.oh, c.ow, c.cout, c.out_cs, c.pt, c.pl, c.reflect, algo == SS_ALGO_BF16X3, x6_wanted(algo)};
+    *q = WinoProb{c.n, c.ih, c.iw, c.cin, c.in_cs, c.oh, c.ow, c.cout, c.out_cs, c.pt, c.pl, c.reflect, algo == SS_ALGO_BF16X3, x6_wanted(algo), 0, 0};
     return ss_wino_ok(*q);
+}
+// reflect-pad(1) + 3x3 valid conv whose input dims are multiples of the F(4x4,3x3) tile: fold inside the output transform
+bool wino_fold_ok(const ConvProb& c) {
+    return c.reflect && c.pt == 1 && c.pl == 1 && c.oh == c.ih && c.ow == c.iw && c.ih % 4 == 0 && c.iw % 4 == 0 && c.ih >= 4 &&
+           c.iw >= 4 && ss_tuning().wino_r == 4;
 }
 // backward-data view: gathers dy (zero extension), produces dx (zero padding) or the padded gradient (reflect)
 bool wino_dgrad_prob(const ConvProb& c, int algo, WinoProb* q) {
     if (algo == SS_ALGO_DIRECT || c.kh != 3 || c.kw != 3 || c.s != 1) return false;
     const int bf = algo == SS_ALGO_BF16X3;
     const int x6 = x6_wanted(algo);
-    if (c.reflect) *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.oh + 2, c.ow + 2, c.cin, c.cin, 2, 2, 0, bf, x6};
-    else *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.ih, c.iw, c.cin, c.in_cs, 2 - c.pt, 2 - c.pl, 0, bf, x6};
+    if (c.reflect && wino_fold_ok(c))       // padded gradient shifted by one, folded by the output transform straight into dx
+        *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.oh + 4, c.ow + 4, c.cin, c.in_cs, 3, 3, 0, bf, x6, c.ih, c.iw};
+    else if (c.reflect) *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.oh + 2, c.ow + 2, c.cin, c.cin, 2, 2, 0, bf, x6, 0, 0};
+    else *q = WinoProb{c.n, c.oh, c.ow, c.cout, c.out_cs, c.ih, c.iw, c.cin, c.in_cs, 2 - c.pt, 2 - c.pl, 0, bf, x6, 0, 0};
     return ss_wino_ok(*q);
 }
 
@@ -328,7 +335,7 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     {
         WinoProb q;
         if (wino_dgrad_prob(c, algo, &q)) {      // rotated + transposed weights are formed inside the weight transform
-            if (!c.reflect)
+            if (!c.reflect || q.fold_h > 0)
                 return ss_wino_conv_fwd(q, dy, w, c.cin, c.cout, 1, bias, dx, act, alpha, accumulate, gws, gws_bytes, s);
             float* dpad = (float*)((char*)ws + bwd_data_wt_bytes(c));
             int rc = ss_wino_conv_fwd(q, dy, w, c.cin, c.cout, 1, nullptr, dpad, SS_ACT_NONE, 0.f, 0, gws, gws_bytes, s);

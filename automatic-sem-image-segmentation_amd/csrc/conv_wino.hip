@@ -242,7 +242,11 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 template <int R>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, int N, int OH, int OW, int C, int TH, int TW,
                                                           const float* __restrict__ bias, int act, float alpha,
-                                                          float* __restrict__ y, int y_cs, int accumulate) {
+                                                          float* __restrict__ y, int y_cs, int accumulate, int FH, int FW) {
+    // FH > 0 ("reflect fold", data gradient of reflect-pad(1) + 3x3 valid conv): the OH x OW grid is the PADDED gradient shifted by
+    // one (virtual o' = P + 1, P in [0, FH+1]); padded pixel P lands on dx[reflect(P - 1)].  With FH % R == 0 the two padded
+    // rows that fold onto the same dx row (P = 0,2 and P = FH-1,FH+1) sit in ONE tile, i.e. one thread: they are summed in
+    // registers and every dx pixel is written exactly once -- no padded scratch tensor, no separate fold pass.
     typedef typename WT<R>::T T;
     constexpr int VW = WT<R>::VW, P = R + 2;
     const int CV = C / VW;
@@ -269,6 +273,43 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
     T bv = zero_v<T>();
     if (bias) bv = *(const T*)(bias + c);
+    if (FH > 0) {
+        T o[R][R];
+        int dy_[R], dx_[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            t_out<R, T>(s[i], o[i]);
+            const int py = R * ty + i - 1, px = R * tx + i - 1;          // padded coordinates of row i / column i
+            dy_[i] = (py < 0 || py > FH + 1) ? -1 : (py == 0 ? 1 : (py == FH + 1 ? FH - 2 : py - 1));
+            dx_[i] = (px < 0 || px > FW + 1) ? -1 : (px == 0 ? 1 : (px == FW + 1 ? FW - 2 : px - 1));
+        }
+#pragma unroll
+        for (int i = 1; i < R; ++i)
+#pragma unroll
+            for (int i2 = 0; i2 < i; ++i2) {
+                if (dy_[i] >= 0 && dy_[i2] == dy_[i]) {                 // rows folding onto the same dx row
+#pragma unroll
+                    for (int j = 0; j < R; ++j) o[i2][j] += o[i][j];
+                    dy_[i] = -1;
+                }
+                if (dx_[i] >= 0 && dx_[i2] == dx_[i]) {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) o[k][i2] += o[k][i];
+                    dx_[i] = -1;
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (dy_[i] < 0 || dx_[j] < 0) continue;
+                T v = o[i][j];
+                T* dst = (T*)(y + ((long)(n * FH + dy_[i]) * FW + dx_[j]) * y_cs + c);
+                if (accumulate) v += *dst;
+                *dst = v;
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         T o[R];
@@ -354,7 +395,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         int rcb = ss_launch_bgemm_bf16x3(b, s);
         if (rcb != SS_OK) return rcb;
         hipLaunchKernelGGL(wino_output_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
-                           bias, act, alpha, y, q.out_cs, accumulate);
+                           bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w);
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
@@ -382,7 +423,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     }
     if (rc != SS_OK) return rc;
     hipLaunchKernelGGL(wino_output_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
-                       bias, act, alpha, y, q.out_cs, accumulate);
+                       bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

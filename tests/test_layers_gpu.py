@@ -52,6 +52,7 @@ CONV_CASES = [
     ("fast_paths_T", 3, 64, 32, 2, "same", False, None, True, 1, 32, 36),
     # Winograd F(2x2,3x3) path: 3x3 stride 1, >= 64 channels, >= 1024 output tiles
     ("wino_reflect", 3, 64, 64, 1, ("reflect", 1), False, None, False, 2, 48, 48),
+    ("wino_reflect_unaligned", 3, 64, 64, 1, ("reflect", 1), False, None, False, 2, 46, 50),   # not a multiple of 4: padded gradient + fold pass
     ("wino_same_bias_tanh", 3, 64, 96, 1, "same", True, "tanh", False, 2, 48, 50),   # smooth act: a kinked one flips masks at |y|~1e-6
     ("wino_same_odd", 3, 96, 64, 1, "same", False, None, False, 3, 47, 45),
     ("wino_valid", 3, 64, 64, 1, "valid", False, None, False, 2, 50, 50),

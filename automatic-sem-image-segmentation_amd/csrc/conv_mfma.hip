@@ -645,8 +645,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WGradParams p, float*
     const long m = e / p.Cb;
     const int t = (int)(m / p.Ca);
     const int ca = (int)(m - (long)t * p.Ca);
-    float acc = 0.f;
-    for (int s = 0; s < p.splits; ++s) acc += p.part[(long)s * total + e];
+    // 8 independent chains (8 loads in flight per thread: the 512-split reductions of the small UNet layers were latency
+    // bound), combined in a fixed order -> deterministic
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= p.splits; s += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a8[k] += p.part[(long)(s + k) * total + e];
+    }
+    for (; s < p.splits; ++s) a8[0] += p.part[(long)s * total + e];
+    const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     float* o = dw + p.taps[t].woff + (long)ca * ldw + cb;
     *o = accumulate ? (*o + acc) : acc;
 }

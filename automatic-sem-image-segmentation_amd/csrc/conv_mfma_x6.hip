@@ -27,28 +27,6 @@ constexpr int XK = 32;          // K step (elements)
 constexpr int XLD = XK + 8;     // LDS row stride in bf16 elements (80 bytes)
 constexpr int XBM = 128;
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// two fp32 values -> packed (h, m, l) bf16 pairs, round-to-nearest-even at every step (v_cvt_pk_bf16_f32 + v_pk_add_f32)
-__device__ __forceinline__ float sub1(float a, float b) {      // plain v_sub_f32: keeps the SLP vectoriser from forming v_pk_add_f32,
-    float r;                                                     // which is slow next to an MFMA stream (MI355X_MICROARCH.md)
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ void split3x2(f32x2 v, unsigned int& h, unsigned int& m, unsigned int& l) {
-    const bf16x2 hb = __builtin_convertvector(v, bf16x2);
-    const f32x2 hf = __builtin_convertvector(hb, f32x2);
-    const f32x2 r1 = {sub1(v[0], hf[0]), sub1(v[1], hf[1])};
-    const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
-    const f32x2 mf = __builtin_convertvector(mb, f32x2);
-    const f32x2 r2 = {sub1(r1[0], mf[0]), sub1(r1[1], mf[1])};
-    const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
-    h = __builtin_bit_cast(unsigned int, hb);
-    m = __builtin_bit_cast(unsigned int, mb);
-    l = __builtin_bit_cast(unsigned int, lb);
-}
-
 template <int BN>
 __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems,
                                                           int Npad, int Ktot) {
@@ -147,8 +125,8 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         for (int j = 0; j < 4; ++j) {
             unsigned int h[2], m[2], l[2];
             const f32x4 v = ra_ok[S][j] ? ra[S][j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            split3x2(f32x2{v[0], v[1]}, h[0], m[0], l[0]);
-            split3x2(f32x2{v[2], v[3]}, h[1], m[1], l[1]);
+            ss_split3x2(f32x2{v[0], v[1]}, h[0], m[0], l[0]);
+            ss_split3x2(f32x2{v[2], v[3]}, h[1], m[1], l[1]);
             unsigned short* dst = sA + (arow + 32 * j) * XLD + c4a * 4;
             *(u32x2*)(dst) = u32x2{h[0], h[1]};
             *(u32x2*)(dst + BM * XLD) = u32x2{m[0], m[1]};
@@ -259,7 +237,7 @@ __global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned s
         const int n = n0 + ty + 8 * i, k = k0 + tx;
         if (n < Npad && k < Ktot) {
             unsigned int h, m, l;
-            split3x2(f32x2{tl[tx][ty + 8 * i], 0.f}, h, m, l);
+            ss_split3x2(f32x2{tl[tx][ty + 8 * i], 0.f}, h, m, l);
             const long o = ((long)batch * Npad + n) * Ktot + k;
             planes[o] = (unsigned short)(h & 0xffffu);
             planes[o + plane_elems] = (unsigned short)(m & 0xffffu);
@@ -349,8 +327,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             unsigned int h0, m0_, l0, h1, m1, l1;
-            split3x2(f32x2{va[0][e], va[1][e]}, h0, m0_, l0);
-            split3x2(f32x2{va[2][e], va[3][e]}, h1, m1, l1);
+            ss_split3x2(f32x2{va[0][e], va[1][e]}, h0, m0_, l0);
+            ss_split3x2(f32x2{va[2][e], va[3][e]}, h1, m1, l1);
             unsigned short* dst = sA + (4 * cq + e) * XLD + 4 * kq;
             *(u32x2*)(dst) = u32x2{h0, h1};
             *(u32x2*)(dst + BM * XLD) = u32x2{m0_, m1};
@@ -360,8 +338,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 unsigned int h0, m0_, l0, h1, m1, l1;
-                split3x2(f32x2{vb[0][e], vb[1][e]}, h0, m0_, l0);
-                split3x2(f32x2{vb[2][e], vb[3][e]}, h1, m1, l1);
+                ss_split3x2(f32x2{vb[0][e], vb[1][e]}, h0, m0_, l0);
+                ss_split3x2(f32x2{vb[2][e], vb[3][e]}, h1, m1, l1);
                 unsigned short* dst = sB + (4 * cq + e) * XLD + 4 * kq;
                 *(u32x2*)(dst) = u32x2{h0, h1};
                 *(u32x2*)(dst + BN * XLD) = u32x2{m0_, m1};

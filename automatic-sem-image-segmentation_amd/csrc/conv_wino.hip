@@ -238,6 +238,65 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     }
 }
 
+// Same transform, emitted directly as the x6 GEMM's B operand: three K-contiguous bf16 planes
+// planes[pl][xi][no (padded to Npad, zero rows)][kr].  One thread = two consecutive kr of one no (a packed bf16 pair per store,
+// consecutive threads -> consecutive kr: coalesced plane writes; the 9 x 2 weight reads are strided for flip = 0, the whole
+// kernel tensor is 9 MB and stays in L2).
+template <int R>
+__global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __restrict__ w, int Cin, int Cout, int flip, int Npad,
+                                                             unsigned short* __restrict__ planes) {
+    constexpr int P = R + 2;
+    const int KR = flip ? Cout : Cin, NO = flip ? Cin : Cout;
+    const int K2 = KR / 2;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)K2 * Npad) return;
+    const int k2 = (int)(e % K2), no = (int)(e / K2);
+    const long plane_u32 = (long)P * P * Npad * KR / 2;     // u32 (bf16 pair) stride between the three planes
+    const long xs2 = (long)Npad * KR / 2;                   // ... between transform positions
+    unsigned int* dst = (unsigned int*)planes + (long)no * K2 + k2;
+    if (no >= NO) {
+#pragma unroll
+        for (int xi = 0; xi < P * P; ++xi) {
+            dst[xi * xs2] = 0u;
+            dst[xi * xs2 + plane_u32] = 0u;
+            dst[xi * xs2 + 2 * plane_u32] = 0u;
+        }
+        return;
+    }
+    float u2[2][P][P];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int kr = 2 * k2 + half;
+        float t[P][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float g[3], u[P];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int kh = flip ? 2 - a : a, kw = flip ? 2 - b : b;
+                const int ci = flip ? no : kr, co = flip ? kr : no;
+                g[a] = w[((long)(kh * 3 + kw) * Cin + ci) * Cout + co];
+            }
+            t_w<R>(g, u);
+#pragma unroll
+            for (int i = 0; i < P; ++i) t[i][b] = u[i];
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) t_w<R>(t[i], u2[half][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            unsigned int h, m, l;
+            ss_split3x2(f32x2{u2[0][i][j], u2[1][i][j]}, h, m, l);
+            const long o = (long)(i * P + j) * xs2;
+            dst[o] = h;
+            dst[o + plane_u32] = m;
+            dst[o + 2 * plane_u32] = l;
+        }
+}
+
 // y[n, R*ty+i, R*tx+j, c] (+)= act(bias + (A^T M A)_ij)
 template <int R>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, int N, int OH, int OW, int C, int TH, int TW,
@@ -399,8 +458,6 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
-    hipLaunchKernelGGL((wino_weight_kernel<R, false>), dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, w, w_cin, w_cout, flip, U);
-    SS_LAUNCH_CHECK();
     hipLaunchKernelGGL((wino_input_kernel<R, false>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
                        q.pt, q.pl, q.reflect, V);
     SS_LAUNCH_CHECK();
@@ -413,12 +470,15 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     g.nbatch = XI; g.in_bs = tiles * q.cin; g.w_bs = (long)q.cin * q.cout; g.out_bs = tiles * q.cout;
     g.ntaps = 1; g.taps[0].dy = 0; g.taps[0].dx = 0; g.taps[0].woff = 0;
     int rc;
-    if (q.x6 && ss_gconv_x6_ok(g)) {     // fp32-exact GEMMs on the bf16 matrix cores: planes of U after the fp32 scratch
+    if (q.x6 && ss_gconv_x6_ok(g)) {     // fp32-exact GEMMs on the bf16 matrix cores: the weight transform emits the B planes
         unsigned short* planes = (unsigned short*)((char*)Mx + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
-        rc = ss_launch_wprep_x6(g, planes, s);
-        if (rc != SS_OK) return rc;
+        const int Npad = ss_x6_npad(q.cout);
+        hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(g256((long)(q.cin / 2) * Npad)), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
+        SS_LAUNCH_CHECK();
         rc = ss_launch_gconv_x6(g, planes, s);
     } else {
+        hipLaunchKernelGGL((wino_weight_kernel<R, false>), dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, w, w_cin, w_cout, flip, U);
+        SS_LAUNCH_CHECK();
         rc = ss_launch_gconv_mfma(g, s);
     }
     if (rc != SS_OK) return rc;

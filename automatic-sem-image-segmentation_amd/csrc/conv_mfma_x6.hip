@@ -27,10 +27,10 @@ constexpr int XK = 32;          // K step (elements)
 constexpr int XLD = XK + 8;     // LDS row stride in bf16 elements (80 bytes)
 constexpr int XBM = 128;
 
-template <int BN>
+template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems,
                                                           int Npad, int Ktot) {
-    constexpr int BM = XBM;
+    constexpr int TM = BM / 64;          // 32-row MFMA tiles per wave (2 waves along M)
     constexpr int TN = BN / 64;          // 32-wide MFMA column tiles per wave (2 waves along N)
     constexpr int BROWS = BN / 64;       // B loader: rows (tid>>2) + 64*j
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
@@ -98,8 +98,9 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
 
     // two register sets: the global loads run TWO K steps ahead of the MFMAs (one step of 48 MFMAs per wave is shorter than
     // the L2 / HBM latency).  Zero-padding taps: the select is applied at LDS-store time, nothing touches a load earlier.
-    f32x4 ra[2][4];
-    bool ra_ok[2][4];
+    constexpr int AU = BM / 32;          // A loader: rows arow + 32*j
+    f32x4 ra[2][AU];
+    bool ra_ok[2][AU];
     u32x4 rb[2][3][BROWS];
 
     auto load_tiles = [&](auto setc, int k0) {
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         const int ci0 = k0 - t * p.Cin;
         const float* abase = g_in + ci0 + c4a * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < AU; ++j) {
             const int off = offtab[(arow + 32 * j) * p.ntaps + t];
             ra[S][j] = *(const f32x4*)(abase + (off < 0 ? 0 : off));
             ra_ok[S][j] = off >= 0;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     auto store_tiles = [&](auto setc) {
         constexpr int S = decltype(setc)::value;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < AU; ++j) {
             unsigned int h[2], m[2], l[2];
             const f32x4 v = ra_ok[S][j] ? ra[S][j] : f32x4{0.f, 0.f, 0.f, 0.f};
             ss_split3x2(f32x2{v[0], v[1]}, h[0], m[0], l[0]);
@@ -139,9 +140,9 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
                 *(u32x4*)(sB + pl * BN * XLD + (brow + 64 * j) * XLD + bpc * 8) = rb[S][pl][j];
     };
 
-    f32x16 acc[2][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     store_tiles(S0{});
     __syncthreads();
 
-    const unsigned short* fa = sA + (wm * 64 + l31) * XLD + 8 * lh;
+    const unsigned short* fa = sA + (wm * (BM / 2) + l31) * XLD + 8 * lh;
     const unsigned short* fb = sB + (wn * (BN / 2) + l31) * XLD + 8 * lh;
 
     // step c: chunk c is in LDS, chunk c+1 is in (or on its way to) register set (c+1)&1, chunk c+2 is requested into set c&1
@@ -162,11 +163,11 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         if (c + 2 < nchunks) load_tiles(cur, (c + 2) * XK);
 #pragma unroll
         for (int ks = 0; ks < XK / 16; ++ks) {
-            bf16x8 a[3][2], b[3][TN];
+            bf16x8 a[3][TM], b[3][TN];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const bf16x8*)(fa + pl * BM * XLD + mi * 32 * XLD + ks * 16);
+                for (int mi = 0; mi < TM; ++mi) a[pl][mi] = *(const bf16x8*)(fa + pl * BM * XLD + mi * 32 * XLD + ks * 16);
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const bf16x8*)(fb + pl * BN * XLD + ni * 32 * XLD + ks * 16);
             }
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
@@ -198,11 +199,11 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         if (co >= p.Cout) continue;
         const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int pix = pixtab[wm * 64 + mi * 32 + row];
+                const int pix = pixtab[wm * (BM / 2) + mi * 32 + row];
                 if (pix < 0) continue;
                 float* op = g_out + (long)pix * p.out_cs + co;
                 float v = ss_apply_act(acc[mi][ni][r] + bv, p.act, p.alpha);
@@ -423,18 +424,18 @@ int launch_wgrad_x6(const WGradParams& p, hipStream_t s) {
     return SS_OK;
 }
 
-template <int BN>
+template <int BM, int BN>
 int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
     const long M = (long)p.N * p.OHc * p.OWc;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
-    dim3 grid((unsigned)(((M + XBM - 1) / XBM) * ((p.Cout + BN - 1) / BN) * nb));
-    const size_t smem = (size_t)3 * (XBM + BN) * XLD * sizeof(unsigned short) + (size_t)XBM * sizeof(int) * (1 + p.ntaps);
+    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN) * nb));
+    const size_t smem = (size_t)3 * (BM + BN) * XLD * sizeof(unsigned short) + (size_t)BM * sizeof(int) * (1 + p.ntaps);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gconv_x6_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gconv_x6_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gconv_x6_kernel<BN>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot);
+    hipLaunchKernelGGL((gconv_x6_kernel<BM, BN>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -471,8 +472,12 @@ int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipSt
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * p.Cin;
     const long plane_elems = (long)nb * Npad * Ktot;
-    if (p.Cout > 64) return launch_x6<128>(p, planes, plane_elems, Npad, Ktot, s);
-    return launch_x6<64>(p, planes, plane_elems, Npad, Ktot, s);
+    // tile choice: the largest tile that still yields >= ~200 workgroups (small grids at per-GPU batch 1 want more, smaller ones)
+    const long want = 200;
+    auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * nb; };
+    if (p.Cout > 64 && nblk(128, 128) >= want) return launch_x6<128, 128>(p, planes, plane_elems, Npad, Ktot, s);
+    if (nblk(128, 64) >= want) return launch_x6<128, 64>(p, planes, plane_elems, Npad, Ktot, s);
+    return launch_x6<64, 64>(p, planes, plane_elems, Npad, Ktot, s);
 }
 
 bool ss_wgrad_x6_ok(const WGradParams& p) {

@@ -27,6 +27,7 @@ import torch
 
 from . import _lib as L
 from . import dist as D
+from . import layers as LY
 from . import losses
 from .engine import Act, Tape, _stream
 from .nets import PatchDiscriminator, ResnetGenerator
@@ -90,6 +91,8 @@ class CycleGanModel:
         self.lambda_cycle_a, self.lambda_cycle_b = lambda_cycle_a, lambda_cycle_b
         self.lambda_identity_a, self.lambda_identity_b = lambda_identity_a, lambda_identity_b
         self.use_identity_loss = lambda_identity_a > 0 or lambda_identity_b > 0
+        # translation + identity pass of each generator as ONE pass over the concatenated batch (same maths per sample)
+        self.batch_generator_passes = os.environ.get("SS_BATCH_G_PASSES", "1") != "0"
         self.gen_a_optimizer = self.gen_b_optimizer = self.disc_a_optimizer = self.disc_b_optimizer = None
         self.image_pool_a = image_pool_a if image_pool_a is not None else ImagePool(1, 0)
         self.image_pool_b = image_pool_b if image_pool_b is not None else ImagePool(1, 0)
@@ -136,13 +139,22 @@ class CycleGanModel:
 
         # ---- generators -------------------------------------------------------------------------------
         tape = Tape()
-        fake_b = ga(real_a, True, tape)
-        fake_a = gb(real_b, True, tape)
-        cycled_a = gb(fake_b, True, tape)
-        cycled_b = ga(fake_a, True, tape)
-        if self.use_identity_loss:
-            same_a = gb(real_a, True, tape)
-            same_b = ga(real_b, True, tape)
+        if self.use_identity_loss and self.batch_generator_passes:
+            # the translation and the identity pass of a generator use the same weights on independent samples (InstanceNorm
+            # is per sample): one pass over the concatenated batch -- larger GEMMs, one weight transform instead of two
+            n = real_a.n
+            fake_b, same_b = LY.batch_split(tape, ga(Act(torch.cat([real_a.t, real_b.t], 0), requires_grad=False), True, tape), [n, real_b.n])
+            fake_a, same_a = LY.batch_split(tape, gb(Act(torch.cat([real_b.t, real_a.t], 0), requires_grad=False), True, tape), [real_b.n, n])
+            cycled_a = gb(fake_b, True, tape)
+            cycled_b = ga(fake_a, True, tape)
+        else:
+            fake_b = ga(real_a, True, tape)
+            fake_a = gb(real_b, True, tape)
+            cycled_a = gb(fake_b, True, tape)
+            cycled_b = ga(fake_a, True, tape)
+            if self.use_identity_loss:
+                same_a = gb(real_a, True, tape)
+                same_b = ga(real_b, True, tape)
         tape.param_grads = False            # discriminators only route gradients in this phase
         disc_fake_a = da(fake_a, True, tape)
         disc_fake_b = db(fake_b, True, tape)
@@ -169,12 +181,18 @@ class CycleGanModel:
 
         # ---- discriminators ---------------------------------------------------------------------------
         tape = Tape()
-        disc_real_a = da(real_a, True, tape)
         pooled_a = self.image_pool_a.query(fake_a.t)          # detached copy of the generated batch
-        disc_fake_a2 = da(Act(pooled_a, requires_grad=False), True, tape)
-        disc_real_b = db(real_b, True, tape)
         pooled_b = self.image_pool_b.query(fake_b.t)
-        disc_fake_b2 = db(Act(pooled_b, requires_grad=False), True, tape)
+        if self.batch_generator_passes:                       # real + pooled-fake batch of a discriminator in one pass
+            disc_real_a, disc_fake_a2 = LY.batch_split(
+                tape, da(Act(torch.cat([real_a.t, pooled_a], 0), requires_grad=False), True, tape), [real_a.n, pooled_a.shape[0]])
+            disc_real_b, disc_fake_b2 = LY.batch_split(
+                tape, db(Act(torch.cat([real_b.t, pooled_b], 0), requires_grad=False), True, tape), [real_b.n, pooled_b.shape[0]])
+        else:
+            disc_real_a = da(real_a, True, tape)
+            disc_fake_a2 = da(Act(pooled_a, requires_grad=False), True, tape)
+            disc_real_b = db(real_b, True, tape)
+            disc_fake_b2 = db(Act(pooled_b, requires_grad=False), True, tape)
         losses.mse_const(disc_real_a, one, 0.5, self._slot(6))
         losses.mse_const(disc_fake_a2, zero, 0.5, self._slot(7))
         losses.mse_const(disc_real_b, one, 0.5, self._slot(8))

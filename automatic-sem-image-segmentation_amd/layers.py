@@ -252,6 +252,35 @@ def add_grad(dst_act, src):
                          dg.ptr, dg.cs, dst_act.rows, dst_act.c, _stream()), "axpby")
 
 
+def batch_split(tape, x, sizes):
+    """Views of consecutive sample ranges of ``x`` (no copy).  Used to run one network pass over several input batches at once
+    (CycleGAN: the "fake" and "identity" passes of a generator share weights and are per-sample independent); backward gathers
+    the parts' gradients into x's gradient."""
+    assert x.parent is None and x.c0 == 0 and x.c == x.cs and sum(sizes) == x.n
+    parts, n0 = [], 0
+    for n in sizes:
+        parts.append(Act(x.t[n0:n0 + n], requires_grad=x.requires_grad))
+        n0 += n
+
+    def backward():
+        grads = [q.get_grad() for q in parts]
+        if not x.requires_grad or all(g is None for g in grads):
+            return
+        lib = L.load()
+        dx, accum = x.grad_target()
+        if not accum:
+            dx.t.zero_()
+        n0 = 0
+        for q, g in zip(parts, grads):
+            if g is not None:
+                dst = Act(dx.t[n0:n0 + q.n], dx.c0, dx.c, False)
+                L.check(lib.ss_axpby(1.0, g.ptr, g.cs, 1.0, dst.ptr, dst.cs, dst.ptr, dst.cs, q.rows, q.c, _stream()), "axpby")
+            n0 += q.n
+
+    tape.record(backward)
+    return parts
+
+
 def reflect_pad(tape, x, pad_w_total, pad_h_total):
     """ReflectionPadding2D as a standalone op (CycleGAN.py:482-506): total padding split p//2 before, p//2 + p%2 after."""
     if pad_w_total == 0 and pad_h_total == 0:

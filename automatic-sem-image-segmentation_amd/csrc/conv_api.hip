@@ -62,22 +62,27 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
 }
 
 // column sums of a [rows][C] view: stage 1 partials[chunk][c], stage 2 final
-#define COLSUM_CHUNKS 240
-__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ v, long rows, int C, int cs, float* __restrict__ part) {
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-    const int pl = threadIdx.x >> 6;  // 4 row lanes
-    __shared__ float red[4][64];
+#define COLSUM_CHUNKS 1024
+// CT channel lanes (power of two <= 64) x 256/CT row lanes per block: narrow tensors (the 1-channel head bias) still use all threads
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ v, long rows, int C, int cs, float* __restrict__ part, int CT) {
+    const int PT = 256 / CT;
+    const int cl = threadIdx.x % CT, pl = threadIdx.x / CT;
+    const int c = blockIdx.y * CT + cl;
+    __shared__ float red[256];
     float acc = 0.f;
     if (c < C) {
         const long per = (rows + gridDim.x - 1) / gridDim.x;
         const long r0 = (long)blockIdx.x * per;
         const long r1 = (r0 + per < rows) ? r0 + per : rows;
-        for (long r = r0 + pl; r < r1; r += 4) acc += v[r * cs + c];
+        for (long r = r0 + pl; r < r1; r += PT) acc += v[r * cs + c];
     }
-    red[pl][threadIdx.x & 63] = acc;
+    red[threadIdx.x] = acc;
     __syncthreads();
-    if (pl == 0 && c < C)
-        part[(long)blockIdx.x * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    for (int off = PT / 2; off >= 1; off >>= 1) {          // PT is a power of two: fixed-order tree
+        if (pl < off) red[threadIdx.x] += red[threadIdx.x + off * CT];
+        __syncthreads();
+    }
+    if (pl == 0 && c < C) part[(long)blockIdx.x * C + c] = red[threadIdx.x];
 }
 __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int chunks, int C, float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,10 +93,12 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
 }
 
 int colsum(const float* v, long rows, int C, int cs, float* out, int accumulate, float* part, hipStream_t s) {
-    int chunks = (int)((rows + 255) / 256);
+    int CT = 1;
+    while (CT < C && CT < 64) CT <<= 1;
+    int chunks = (int)((rows + 1023) / 1024);
     if (chunks > COLSUM_CHUNKS) chunks = COLSUM_CHUNKS;
     if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(colsum_stage1, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, v, rows, C, cs, part);
+    hipLaunchKernelGGL(colsum_stage1, dim3(chunks, (C + CT - 1) / CT), dim3(256), 0, s, v, rows, C, cs, part, CT);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, s, part, chunks, C, out, accumulate);
     SS_LAUNCH_CHECK();

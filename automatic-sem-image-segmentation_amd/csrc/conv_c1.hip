@@ -227,7 +227,8 @@ int launch_in1(const GConvParams& p, const C1Box& box, hipStream_t s) {
 // Cout == 1, stride 1, full 7x7 / 4x4 / 3x3 tap box, Cin % 4 == 0 and 16-byte aligned pixels
 bool ss_conv_out1_ok(const GConvParams& p) {
     C1Box box;
-    if (p.Cout != 1 || !plain_grid(p) || p.Cin % 4 != 0 || p.in_cs % 4 != 0 || (((uintptr_t)p.in) & 15) != 0) return false;
+    if (p.Cout != 1 || !plain_grid(p) || p.Cin % 4 != 0 || p.Cin > 128 ||     // wide inputs: the 1x1 GEMM + tap sum path is better
+        p.in_cs % 4 != 0 || (((uintptr_t)p.in) & 15) != 0) return false;
     if ((long)p.N * p.OH * p.OW < 16384 || !tap_box(p, &box)) return false;
     return (box.kh == 7 && box.kw == 7) || (box.kh == 4 && box.kw == 4) || (box.kh == 3 && box.kw == 3);
 }

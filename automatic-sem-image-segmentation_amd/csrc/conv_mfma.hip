@@ -472,7 +472,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
     const int c4b = tid % (BN / 4);
 
     f32x4 ra[C::AT_UNITS], rb[C::B_UNITS];
-    bool za[C::AT_UNITS], zb[C::B_UNITS];       // FAST: zero-selects deferred to the LDS store (see gconv_mfma_kernel)
+    // FAST: per-element validity masks; the zero-selects are deferred to the LDS store (see gconv_mfma_kernel)
+    unsigned char za[C::AT_UNITS], zb[C::B_UNITS];
 
     // FAST state: decoded coordinates of the pixel each of this thread's A rows will load next
     int f_n[C::AT_UNITS], f_y[C::AT_UNITS], f_x[C::AT_UNITS];
@@ -493,12 +494,28 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
 #pragma unroll
             for (int j = 0; j < C::AT_UNITS; ++j) {
                 const int row = (tid + 256 * j) / (BM / 4);
-                const int iy = ss_map_index(f_y[j] * p.a_s + p.a_oy + a_dy[0], p.AH, p.reflect);
-                const int ix = ss_map_index(f_x[j] * p.a_s + p.a_ox + a_dx[0], p.AW, p.reflect);
-                const bool ok = mval && (pk0 + row < pe) && iy >= 0 && ix >= 0;
-                const long off = ok ? ((long)(f_n[j] * p.AH + iy) * p.AW + ix) * p.a_cs + a_c[0] : 0;
-                ra[j] = *(const f32x4*)(g_a + off);
-                za[j] = !ok;
+                const bool pval = pk0 + row < pe;
+                const int by = f_y[j] * p.a_s + p.a_oy, bx = f_x[j] * p.a_s + p.a_ox;
+                if (vecA) {
+                    const int iy = ss_map_index(by + a_dy[0], p.AH, p.reflect);
+                    const int ix = ss_map_index(bx + a_dx[0], p.AW, p.reflect);
+                    const bool ok = mval && pval && iy >= 0 && ix >= 0;
+                    const long off = ok ? ((long)(f_n[j] * p.AH + iy) * p.AW + ix) * p.a_cs + a_c[0] : 0;
+                    ra[j] = *(const f32x4*)(g_a + off);
+                    za[j] = ok ? 0xF : 0;
+                } else {        // odd channel counts: the 4 columns of a unit may belong to different taps -> 4 scalar gathers
+                    unsigned char mk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int iy = ss_map_index(by + a_dy[e], p.AH, p.reflect);
+                        const int ix = ss_map_index(bx + a_dx[e], p.AW, p.reflect);
+                        const bool ok = a_c[e] >= 0 && pval && iy >= 0 && ix >= 0;
+                        const long off = ok ? ((long)(f_n[j] * p.AH + iy) * p.AW + ix) * p.a_cs + a_c[e] : 0;
+                        ra[j][e] = g_a[off];
+                        mk |= (unsigned char)(ok ? (1 << e) : 0);
+                    }
+                    za[j] = mk;
+                }
                 // advance by one K step (32 pixels); GW >= 32 so at most one row wrap
                 int x = f_x[j] + C::BK, y = f_y[j], n = f_n[j];
                 if (x >= p.GW) { x -= p.GW; ++y; }
@@ -506,14 +523,26 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
                 f_x[j] = x; f_y[j] = y; f_n[j] = n;
             }
             const int col = n0 + c4b * 4;
-            const int colc = col + 4 <= p.Cb ? col : p.Cb - 4;
 #pragma unroll
             for (int j = 0; j < C::B_UNITS; ++j) {
                 const int row = (tid + 256 * j) / (BN / 4);
                 const long pk = pk0 + row;
-                const bool ok = pk < pe && col + 4 <= p.Cb;
-                rb[j] = *(const f32x4*)(g_b + (ok ? pk : ps) * p.b_cs + colc);
-                zb[j] = !ok;
+                if (vecB) {
+                    const int colc = col + 4 <= p.Cb ? col : (p.Cb >= 4 ? p.Cb - 4 : 0);
+                    const bool ok = pk < pe && col + 4 <= p.Cb;
+                    rb[j] = *(const f32x4*)(g_b + (ok ? pk : ps) * p.b_cs + colc);
+                    zb[j] = ok ? 0xF : 0;
+                } else {
+                    unsigned char mk = 0;
+                    const float* bp = g_b + (pk < pe ? pk : ps) * p.b_cs;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = pk < pe && col + e < p.Cb;
+                        rb[j][e] = bp[ok ? col + e : 0];
+                        mk |= (unsigned char)(ok ? (1 << e) : 0);
+                    }
+                    zb[j] = mk;
+                }
             }
             return;
         }
@@ -575,12 +604,22 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
 #pragma unroll
         for (int j = 0; j < C::AT_UNITS; ++j) {
             const int row = (tid + 256 * j) / (BM / 4);
-            *(f32x4*)(Ab + row * C::LDAT + c4a * 4) = (FAST && za[j]) ? f32x4{0.f, 0.f, 0.f, 0.f} : ra[j];
+            f32x4 va = ra[j];
+            if (FAST) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) va[e] = (za[j] >> e & 1) ? va[e] : 0.f;
+            }
+            *(f32x4*)(Ab + row * C::LDAT + c4a * 4) = va;
         }
 #pragma unroll
         for (int j = 0; j < C::B_UNITS; ++j) {
             const int row = (tid + 256 * j) / (BN / 4);
-            *(f32x4*)(Bb + row * C::LDB + c4b * 4) = (FAST && zb[j]) ? f32x4{0.f, 0.f, 0.f, 0.f} : rb[j];
+            f32x4 vb = rb[j];
+            if (FAST) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vb[e] = (zb[j] >> e & 1) ? vb[e] : 0.f;
+            }
+            *(f32x4*)(Bb + row * C::LDB + c4b * 4) = vb;
         }
     };
 
@@ -721,7 +760,9 @@ int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s) {
         const int vecA = (p.Ca % 4 == 0) && (p.a_cs % 4 == 0) && (((uintptr_t)p.a & 15) == 0);
         const int vecB = (p.b_cs % 4 == 0) && (((uintptr_t)p.b & 15) == 0);
         int rc;
-        const bool fast = vecA && vecB && p.GW >= 32 && p.Cb >= 4 && p.pix_per_split % 32 == 0 && !ss_tuning().no_fast;
+        // FAST = incremental pixel coordinates + deferred zero-selects; vector or (odd channel counts) scalar element loads
+        const bool fast = p.GW >= 32 && p.pix_per_split % 32 == 0 && !ss_tuning().no_fast &&
+                          (long)p.N * p.AH * p.AW * p.a_cs < (1L << 31) && (long)p.N * p.GH * p.GW * p.b_cs < (1L << 31);
         if (fast) {
             if (p.Cb > 64) rc = launch_wgrad<128, 128, true>(p, vecA, vecB, s);
             else if (p.Cb > 32) rc = launch_wgrad<128, 64, true>(p, vecA, vecB, s);

@@ -48,19 +48,20 @@ class KernelTimer:
         e.record()
         return e
 
-    def stop(self, e0, tag):
+    def stop(self, e0, tag, units=1):
+        """``units`` = work units of this launch (samples in the batch): launches of one tag may differ in size."""
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.events.append((tag, e0, e1))
+        self.events.append((tag, e0, e1, units))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for tag, e0, e1 in self.events:
-            n, tot = out.get(tag, (0, 0.0))
-            out[tag] = (n + 1, tot + e0.elapsed_time(e1))
+        for tag, e0, e1, units in self.events:
+            n, tot, u = out.get(tag, (0, 0.0, 0))
+            out[tag] = (n + 1, tot + e0.elapsed_time(e1), u + units)
         self.events = []
-        return {k: {"launches": n, "avg_ms": tot / n} for k, (n, tot) in out.items()}
+        return {k: {"launches": n, "avg_ms": tot / n, "total_ms": tot, "units": u} for k, (n, tot, u) in out.items()}
 
 
 TIMER = KernelTimer()

@@ -90,7 +90,7 @@ class Conv2D:
         L.check(lib.ss_conv2d_fwd(ctypes.byref(d), x.ptr, _p(w), _p(b), y.ptr, _p(ws), ws.numel(), _stream()),
                 f"conv2d_fwd[{self.name}]")
         if e0 is not None:
-            TIMER.stop(e0, self.profile_tag)
+            TIMER.stop(e0, self.profile_tag, x.n)
         param_grads = tape.param_grads
         pnames = [f"{self.name}/kernel"] + ([f"{self.name}/bias"] if self.use_bias else [])
         if param_grads and tape.enabled:

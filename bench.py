@@ -167,8 +167,11 @@ def main():
                           "tile": S, "global_batch": GB, "per_gpu_batch": per, "parallelism": f"dp{world}"}}
         tk = ksum.get("trunk_conv_fwd")
         if tk:
-            flops = 2.0 * per * (S // 8) ** 2 * (8 * F) * (9 * 8 * F)      # one 3x3 (8F->8F) conv over per x (S/8)^2 pixels
-            ach = flops / (tk["avg_ms"] * 1e-3) / 1e12
+            # one 3x3 (8F->8F) conv over n x (S/8)^2 pixels; launches carry per or 2*per samples (the translation and identity
+            # passes of a generator run as one batch): achieved = ALL algorithmic FLOPs of the timed launches / their total time
+            flops_sample = 2.0 * (S // 8) ** 2 * (8 * F) * (9 * 8 * F)
+            flops = flops_sample * tk["units"] / tk["launches"]             # average per launch
+            ach = flops_sample * tk["units"] / (tk["total_ms"] * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": "3x3 512->512 trunk conv forward = wino_weight<4> + wprep_x6 + wino_input<4> + batched gconv_x6_kernel<128> "
@@ -184,16 +187,17 @@ def main():
                         "holds under this load (profiles/r01_pmc_trunk_fwd_x6.md)",
                 "executed_bf16_mfma_flops_per_launch": flops / 4.0 * 6.0,
                 # the GEMM kernel alone, from the committed rocprofv3 summary of this command (profiles/r01_o_kernel_stats.md)
-                "executed": ({"kernel": "gconv_x6_kernel<128> (36 batched GEMMs of the op)", "bf16_mfma_flops": flops / 4.0 * 6.0,
-                              "kernel_avg_ms_rocprof": 0.282, "achieved": round(flops / 4.0 * 6.0 / 0.282e-3 / 1e15, 3), "peak": 2.5,
-                              "unit": "PFLOP/s", "frac": round(flops / 4.0 * 6.0 / 0.282e-3 / 2.5e15, 3)}
+                "executed": ({"kernel": "gconv_x6_kernel<128,128>, the 36 batched GEMMs of a batch-8 op (2304 workgroups)",
+                              "bf16_mfma_flops": flops_sample * 8 / 4.0 * 6.0, "kernel_avg_ms_rocprof": 0.282,
+                              "achieved": round(flops_sample * 8 / 4.0 * 6.0 / 0.282e-3 / 1e15, 3), "peak": 2.5, "unit": "PFLOP/s",
+                              "frac": round(flops_sample * 8 / 4.0 * 6.0 / 0.282e-3 / 2.5e15, 3)}
                              if (per == 8 and S == 512 and F == 64 and os.environ.get("SS_X6", "1") != "0") else None),
                 "executed_mfma_flops_per_launch": flops / 4.0,
                 # PMC cannot be sampled from inside this process: rocprofv3 pass on the direct (non-Winograd) kernel of this shape
                 # PMC cannot be sampled from inside this process: committed rocprofv3 passes on this op/shape at batch 8
                 # (profiles/r01_pmc_trunk_fwd_x6.md): sum over the op's 5 kernels of 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
                 "traffic": (2 * (4638 + 18461 + 49921 + 117257 + 73889) + (36864 + 55296 + 147456 + 147456 + 65536)) * 1024.0 if (per == 8 and S == 512 and F == 64) else None,
-                "traffic_unit": "bytes per op launch", "algorithmic_bytes": 4.0 * (2 * per * (S // 8) ** 2 * 8 * F + 9 * (8 * F) ** 2),
+                "traffic_unit": "bytes per batch-8 op launch (PMC passes on tools/bench_kernels.py trunk_fwd)", "algorithmic_bytes": 4.0 * (2 * per * (S // 8) ** 2 * 8 * F + 9 * (8 * F) ** 2),          # of a batch-`per` launch
                 "winograd_algorithmic_bytes": 4.0 * ((1 + 4 * 2.25 + 1) * per * (S // 8) ** 2 * 8 * F + (9 + 36 + 36) * (8 * F) ** 2),
                 "launches_timed": tk["launches"], "avg_launch_ms": round(tk["avg_ms"], 4), "flops_per_launch": flops}
         if S in G_FWD_GF:

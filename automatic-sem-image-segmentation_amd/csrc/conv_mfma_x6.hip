@@ -445,7 +445,7 @@ int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_ele
 int ss_x6_npad(int cout) { return (cout + 127) / 128 * 128; }
 
 bool ss_gconv_x6_ok(const GConvParams& p) {
-    const long in_elems = (long)p.N * p.IH * p.IW * p.in_cs * (p.nbatch > 1 ? 1 : 1);
+    const long in_elems = (long)p.N * p.IH * p.IW * p.in_cs;       // per batched problem: the LDS offset table holds 32-bit element offsets
     return p.ntaps >= 1 && p.Cin % 32 == 0 && p.in_cs % 4 == 0 && (((uintptr_t)p.in) & 15) == 0 && p.Cout >= 32 &&
            in_elems < (1L << 31) && (p.nbatch <= 1 || (p.in_bs % 4 == 0));
 }

@@ -50,6 +50,15 @@ LAYERS = [
     ("d_c2", 4, 128, 256, 2, "valid", False, 255),
     ("d_c3", 4, 256, 512, 2, "valid", False, 126),
     ("d_out", 4, 512, 1, 1, "valid", False, 62),
+    # MultiResUNet(16) layer shapes at 512x512 (UNet_Segmentation.py:451-562): odd widths, 1-channel shortcut, 2x2 transposed conv
+    ("u_sc1x1", 1, 1, 25, 1, "same", False, 512),
+    ("u_c3", 3, 1, 4, 1, "same", False, 512),
+    ("u_c7", 3, 8, 13, 1, "same", False, 512),
+    ("u_b2_c5", 3, 8, 17, 1, "same", False, 256),
+    ("u_b2_c7", 3, 17, 26, 1, "same", False, 256),
+    ("u_b5_c7", 3, 142, 213, 1, "same", False, 32),
+    ("u_up_T2", 2, 426, 128, 2, "same", True, 32),
+    ("u_head", 1, 25, 1, 1, "same", False, 512),
 ]
 
 

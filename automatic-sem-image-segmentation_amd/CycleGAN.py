@@ -303,6 +303,58 @@ class DataLoader:
         np.random.shuffle(self.train_b)
 
 
+class GANMonitor:
+    """Per-epoch preview sheets, the role of the reference's ``GANMonitor`` callback (CycleGAN.py:810-905): for the first
+    ``num_img`` test images of each domain one row  [input | translated | cycled back | input dimmed + outline of the thresholded
+    translation (A-B-A) or of the input mask (B-A-B)]  written as ``A-B-A_Epoch_#####.tif`` / ``B-A-B_Epoch_#####.tif``.
+    Every panel is min-max scaled to uint8, the outline is mask XOR its 2x eroded self, overlay brightness 0.7.
+    Deviation: the reference normalises its test arrays IN PLACE while drawing, so from the first sheet on it feeds [0, 255]
+    images to the generators; here the test images are left untouched."""
+
+    def __init__(self, test_a, test_b, output_dir, num_img=2):
+        self.test_a, self.test_b, self.output_dir, self.num_img = test_a, test_b, output_dir, num_img
+
+    @staticmethod
+    def _u8(img):
+        img = np.asarray(img, np.float32)
+        lo, hi = float(img.min()), float(img.max())
+        return np.zeros(img.shape, np.uint8) if hi <= lo else ((img - lo) / (hi - lo) * 255.0).astype(np.uint8)
+
+    def _sheet(self, first, gen_1, gen_2, outline_from_input):
+        from scipy import ndimage
+        n = min(self.num_img, len(first))
+        if n == 0:
+            return None
+        h, w = first.shape[1], first.shape[2]
+        sheet = np.zeros((n * h, 4 * w, 3), np.uint8)
+        for i in range(n):
+            x = np.ascontiguousarray(first[i:i + 1], dtype=np.float32)
+            y_act = gen_1(torch.from_numpy(x).to(gen_1.arena.device), False)
+            y = CycleGanModel.to_numpy_array(y_act)
+            z = CycleGanModel.to_numpy_array(gen_2(y_act.dense(), False))
+            panels = [self._u8(x[0, :, :, 0]), self._u8(y[0, :, :, 0]), self._u8(z[0, :, :, 0])]
+            mask = (panels[0] if outline_from_input else panels[1]) > 127
+            mask ^= ndimage.binary_erosion(mask, iterations=2)
+            grey = panels[1] if outline_from_input else panels[0]
+            for k, pnl in enumerate(panels):
+                sheet[i * h:(i + 1) * h, k * w:(k + 1) * w, :] = pnl[:, :, None]
+            dim = (grey * 0.7).astype(np.uint8)
+            sheet[i * h:(i + 1) * h, 3 * w:, :] = dim[:, :, None]
+            sheet[i * h:(i + 1) * h, 3 * w:, 0] = np.maximum(dim, mask.astype(np.uint8) * 255)
+        return sheet
+
+    def on_epoch_end(self, model, epoch):
+        from PIL import Image
+        os.makedirs(self.output_dir, exist_ok=True)
+        for tag, first, g1, g2, from_input in (("A-B-A", self.test_a, model.gen_a, model.gen_b, False),
+                                               ("B-A-B", self.test_b, model.gen_b, model.gen_a, True)):
+            if first is None or len(first) == 0:
+                continue
+            sheet = self._sheet(first, g1, g2, from_input)
+            if sheet is not None:
+                Image.fromarray(sheet).save(os.path.join(self.output_dir, '{}_Epoch_{:05d}.tif'.format(tag, epoch + 1)))
+
+
 class CycleGAN:
     """Workflow object with the reference's attribute names and defaults (CycleGAN.py:21-114)."""
 
@@ -461,6 +513,11 @@ class CycleGAN:
         self.data = DataLoader(self.train_a, self.train_b, batch_size=self.batch_size, use_dataloader=self.use_data_loader,
                                scale_for_binary_crossentropy=self.use_binary_crossentropy, invert_images=self.invert_images)
         self.model = self.create_model()
+        plotter = None
+        if D.rank() == 0 and len(self.test_a) and len(self.test_b):
+            test_a = self.load_images(self.test_a[:2], False, invert=self.invert_images)
+            test_b = self.load_images(self.test_b[:2], self.use_binary_crossentropy)
+            plotter = GANMonitor(test_a, test_b, os.path.join(self.root_dir, '2_CycleGAN', 'images', self.prefix), num_img=2)
         log_path = os.path.join(self.model_dir, self.prefix, 'training_log.csv')
         rank, world = D.rank(), D.world_size()
         for epoch in range(self.epochs):
@@ -485,6 +542,8 @@ class CycleGAN:
                         f.write(';'.join(['epoch'] + sorted(logs)) + '\n')
                     f.write(';'.join([str(epoch)] + [repr(logs[k]) for k in sorted(logs)]) + '\n')
                 self.model.save(os.path.join(self.model_dir, self.prefix, 'checkpoints_{:03d}.keras'.format(epoch + 1)))
+                if plotter is not None:
+                    plotter.on_epoch_end(self.model, epoch)
         if rank == 0:
             self.model.save(os.path.join(self.model_dir, self.prefix, 'model.keras'))
         return self.model

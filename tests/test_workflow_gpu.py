@@ -41,6 +41,12 @@ def test_cyclegan_then_unet_workflow(tmp_path):
     assert sorted(os.listdir(mdir)) == ["checkpoints_001.keras.npz", "checkpoints_002.keras.npz", "model.keras.npz", "training_log.csv"]
     log = open(os.path.join(mdir, "training_log.csv")).read().strip().split("\n")
     assert log[0].split(";")[0] == "epoch" and len(log) == 3 and len(log[0].split(";")) == 15
+    # per-epoch preview sheets (the reference's GANMonitor callback, CycleGAN.py:202,810-905): 2 rows x 4 panels, RGB uint8
+    from PIL import Image as _I
+    idir = os.path.join(root, "2_CycleGAN", "images", cg.prefix)
+    assert sorted(os.listdir(idir)) == ["A-B-A_Epoch_00001.tif", "A-B-A_Epoch_00002.tif", "B-A-B_Epoch_00001.tif", "B-A-B_Epoch_00002.tif"]
+    sheet = np.array(_I.open(os.path.join(idir, "A-B-A_Epoch_00002.tif")))
+    assert sheet.shape == (2 * 64, 4 * 64, 3) and sheet.dtype == np.uint8 and sheet[:, :64].max() == 255
     assert cg.image_pool_a.batch_size == 2 and cg.image_pool_a.num_imgs == 4 * 2 // 2 * 1 * 2  # 2 images per step, 2 steps/epoch, 2 epochs
 
     # step 4 (StartProcess.py:107-130): masks -> fake images, loading the saved model like a fresh process would

@@ -408,8 +408,6 @@ class CycleGAN:
     def create_model(self):
         assert not (self.use_binary_crossentropy and (self.lambda_identity_a > 0 or self.lambda_identity_b > 0)), \
             'binary crossentropy cannot be used with identity mapping (CycleGAN.py:71)'
-        if self.gaussian_noise_value > 0:
-            raise NotImplementedError("gaussian_noise_value > 0 is off in StartProcess.py:96 and not built yet")
         ch = self.image_shape[-1] if len(self.image_shape) == 3 else 1
         kw = dict(filters=self.filters, num_downsampling_blocks=self.num_downsampling_blocks_gen,
                   num_residual_blocks=self.num_residual_blocks_gen, num_upsample_blocks=self.num_upsampling_blocks_gen,
@@ -418,9 +416,11 @@ class CycleGAN:
         self.gen_a = ResnetGenerator(seed=self.seed + 1, sigmoid_output=self.use_binary_crossentropy, **kw)
         self.gen_b = ResnetGenerator(seed=self.seed + 2, **kw)
         self.disc_a = PatchDiscriminator(filters=2 * self.filters, num_downsampling_blocks=self.num_downsampling_blocks_disc,
-                                         channels=ch, padding="valid", device=self.device, seed=self.seed + 3)
+                                         channels=ch, padding="valid", device=self.device, seed=self.seed + 3,
+                                         gaussian_noise_value=self.gaussian_noise_value)
         self.disc_b = PatchDiscriminator(filters=2 * self.filters, num_downsampling_blocks=self.num_downsampling_blocks_disc,
-                                         channels=ch, padding="valid", device=self.device, seed=self.seed + 4)
+                                         channels=ch, padding="valid", device=self.device, seed=self.seed + 4,
+                                         gaussian_noise_value=self.gaussian_noise_value)
         D.broadcast_params([self.gen_a, self.gen_b, self.disc_a, self.disc_b])
         D.enable_overlap([self.gen_a, self.gen_b, self.disc_a, self.disc_b])
         model = CycleGanModel(generator_a=self.gen_a, generator_b=self.gen_b, discriminator_a=self.disc_a,

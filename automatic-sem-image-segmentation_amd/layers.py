@@ -252,6 +252,26 @@ def add_grad(dst_act, src):
                          dg.ptr, dg.cs, dst_act.rows, dst_act.c, _stream()), "axpby")
 
 
+def gaussian_noise(tape, x, stddev, training=True):
+    """keras.layers.GaussianNoise(stddev): additive zero-mean noise in training mode only (CycleGAN.py:427,438,446); identity
+    otherwise.  The samples come from torch's device generator (the reference's come from Keras' seed generator: the streams
+    cannot match, only the distribution); the gradient passes through unchanged."""
+    if not training or stddev <= 0:
+        return x
+    lib = L.load()
+    noise = Act(torch.randn((x.n, x.h, x.w, x.c), dtype=torch.float32, device=x.device), requires_grad=False)
+    y = Act.empty(x.n, x.h, x.w, x.c, x.device, requires_grad=x.requires_grad)
+    L.check(lib.ss_axpby(1.0, x.ptr, x.cs, float(stddev), noise.ptr, noise.cs, y.ptr, y.cs, x.rows, x.c, _stream()), "axpby")
+
+    def backward():
+        dy = y.get_grad()
+        if dy is not None and x.requires_grad:
+            add_grad(x, dy)
+
+    tape.record(backward)
+    return y
+
+
 def batch_split(tape, x, sizes):
     """Views of consecutive sample ranges of ``x`` (no copy).  Used to run one network pass over several input batches at once
     (CycleGAN: the "fake" and "identity" passes of a generator share weights and are per-sample independent); backward gathers

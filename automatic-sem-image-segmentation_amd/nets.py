@@ -155,13 +155,15 @@ class ResnetGenerator(Network):
 
 
 class PatchDiscriminator(Network):
-    """gaussian_noise_value == 0 (StartProcess.py:96), padding='valid' (CycleGAN.py:148)."""
+    """CycleGAN.get_discriminator (CycleGAN.py:425-451), padding='valid' (CycleGAN.py:148).  ``gaussian_noise_value`` > 0 puts a
+    GaussianNoise layer in front of every convolution (training mode only); StartProcess.py:96 leaves it at 0."""
 
     def __init__(self, filters=128, num_downsampling_blocks=2, channels=1, padding="valid", device="cuda", seed=0,
-                 algo=L.ALGO_AUTO):
+                 algo=L.ALGO_AUTO, gaussian_noise_value=0.0):
         super().__init__(device)
         A = self.arena
         self.filters, self.nd = filters, num_downsampling_blocks
+        self.gaussian_noise_value = float(gaussian_noise_value)
         f = filters
         self.c4_in = Conv2D(A, "c4_in", 4, channels, f, stride=2, padding=padding, use_bias=True, act="lrelu",
                             act_alpha=0.2, algo=algo)
@@ -175,10 +177,12 @@ class PatchDiscriminator(Network):
         self._finish(seed)
 
     def forward(self, tape, x, training=True):
-        h = self.c4_in(tape, x)
+        from .layers import gaussian_noise
+        sd = self.gaussian_noise_value
+        h = self.c4_in(tape, gaussian_noise(tape, x, sd, training))
         for conv, norm in self.down:
-            h = norm(tape, conv(tape, h), act="lrelu", act_alpha=0.2)
-        return self.c4_out(tape, h)
+            h = norm(tape, conv(tape, gaussian_noise(tape, h, sd, training)), act="lrelu", act_alpha=0.2)
+        return self.c4_out(tape, gaussian_noise(tape, h, sd, training))
 
 
 class _ConvBN:

@@ -224,3 +224,32 @@ def test_unet_train_step_vs_oracle():
     assert e_hip <= 3 * e_32 + 1e-4, (e_hip, e_32)
     for name, w, r in zip(hip.variable_names, hip.get_weights(), ref64.get_weights()):
         assert float(np.abs(w - r).max()) <= 2 * 2 * 1e-3 * 1.1 + 1e-6, name    # |step| <= ~lr per Adam step, 2 steps, both signs
+
+
+def test_discriminator_gaussian_noise_option():
+    """CycleGAN.py:427-446: GaussianNoise(sigma) in front of every discriminator conv, active in training mode only.  The noise
+    stream cannot match Keras'; checked: inference mode is the noise-free network, training mode differs, the perturbation of
+    the first (linear) layer has the right scale, gradients still reach the input."""
+    E, LY, N = mod("engine"), mod("layers"), mod("nets")
+    gen = torch.Generator().manual_seed(1)
+    x_cpu = torch.rand((2, 64, 64, 1), generator=gen) * 2 - 1
+    ref = N.PatchDiscriminator(filters=16, device="cuda:0", seed=3)
+    noisy = N.PatchDiscriminator(filters=16, device="cuda:0", seed=3, gaussian_noise_value=0.15)
+    noisy.set_weights(ref.get_weights())
+    y0 = ref(x_cpu.cuda(), True).dense()
+    assert torch.equal(noisy(x_cpu.cuda(), False).dense(), ref(x_cpu.cuda(), False).dense())
+    torch.manual_seed(0)
+    x = E.Act(x_cpu.cuda(), requires_grad=True)
+    tape = E.Tape()
+    y1 = noisy(x, True, tape)
+    assert float((y1.dense() - y0).abs().max()) > 1e-3
+    gt, _ = y1.grad_target()
+    gt.t.fill_(1.0)
+    noisy.zero_grad()
+    tape.backward()
+    assert x.get_grad() is not None and float(x.get_grad().dense().abs().max()) > 0
+    # the layer itself: y - x ~ N(0, sigma^2)
+    a = E.Act(torch.zeros((4, 64, 64, 8), device="cuda:0"), requires_grad=False)
+    d = LY.gaussian_noise(E.Tape(enabled=False), a, 0.15, True).dense()
+    assert abs(float(d.mean())) < 5e-3 and abs(float(d.std()) - 0.15) < 5e-3
+    assert LY.gaussian_noise(E.Tape(enabled=False), a, 0.15, False) is a

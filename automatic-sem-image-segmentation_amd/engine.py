@@ -18,8 +18,20 @@ from . import _lib as L
 _WS = {}
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_DEV_INDEX = None
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's CURRENT stream on this process's device (every launch goes there).  Asked thousands of times per
+    step: ``torch.cuda.current_stream()`` builds a Stream object (~8 us, it was a quarter of the host time of a batch-1 step);
+    the raw query is ~0.2 us.  The device index is the process's device (one process per GPU) and is looked up once."""
+    global _DEV_INDEX
+    if _RAW_STREAM is None:
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()
+    return ctypes.c_void_p(_RAW_STREAM(_DEV_INDEX))
 
 
 def workspace(nbytes, device):

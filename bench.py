@@ -73,8 +73,8 @@ def cpu_baseline(size, batch, filters, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--global-batch", type=int, default=8)
     ap.add_argument("--filters", type=int, default=64)

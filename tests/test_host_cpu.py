@@ -127,3 +127,33 @@ def test_otsu_threshold_is_the_variance_maximiser():
     assert set(np.unique(lab)) <= {0, 255}
     lab_ws = HF.segment(img, -1, watershed_lines=True)
     assert set(np.unique(lab_ws)) <= {0, 255} and np.all(lab_ws <= lab)      # splitting only removes pixels
+
+
+def test_three_way_bf16_split_is_exact():
+    """The arithmetic claim behind the x6 contraction (csrc/conv_mfma_x6.hip, common.h ss_split3x2), restated in numpy:
+    h = bf16(v), m = bf16(v - h), l = bf16(v - h - m) with round-to-nearest-even reproduces every finite fp32 v EXACTLY as
+    h + m + l, and the three cross terms the kernel drops (m*l, l*m, l*l) are below 2^-24 of |a*b|."""
+    rng = np.random.default_rng(0)
+
+    def bf16(x):
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+        return (u.astype(np.uint32) << 16).view(np.float32)
+
+    def split(v):
+        h = bf16(v)
+        r1 = (v - h).astype(np.float32)
+        m = bf16(r1)
+        r2 = (r1 - m).astype(np.float32)
+        return h, m, bf16(r2)
+
+    v = np.concatenate([rng.standard_normal(400000), rng.standard_normal(200000) * 1e-20, rng.random(200000) * 1e20,
+                        np.array([1.0, -1.0, 3.0, 1.0 + 2.0 ** -23, 65504.0, 2.0 ** -100])]).astype(np.float32)
+    h, m, l = split(v)
+    assert np.array_equal(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64), v.astype(np.float64))
+    a, b = v[:300000], v[300000:600000]
+    (ah, am, al), (bh, bm, bl) = split(a), split(b)
+    f = lambda x: x.astype(np.float64)
+    six = f(ah) * f(bh) + f(ah) * f(bm) + f(am) * f(bh) + f(ah) * f(bl) + f(al) * f(bh) + f(am) * f(bm)
+    exact = f(a) * f(b)
+    assert float(np.max(np.abs(six - exact) / np.abs(exact))) <= 2.0 ** -24

@@ -93,6 +93,8 @@ class CycleGanModel:
         self.use_identity_loss = lambda_identity_a > 0 or lambda_identity_b > 0
         # translation + identity pass of each generator as ONE pass over the concatenated batch (same maths per sample)
         self.batch_generator_passes = os.environ.get("SS_BATCH_G_PASSES", "1") != "0"
+        # run the two independent chains of each phase on two HIP streams (see _train_step_dual); SS_DUAL_STREAM=0 disables
+        self.dual_stream = os.environ.get("SS_DUAL_STREAM", "1") != "0"
         self.gen_a_optimizer = self.gen_b_optimizer = self.disc_a_optimizer = self.disc_b_optimizer = None
         self.image_pool_a = image_pool_a if image_pool_a is not None else ImagePool(1, 0)
         self.image_pool_b = image_pool_b if image_pool_b is not None else ImagePool(1, 0)
@@ -136,6 +138,9 @@ class CycleGanModel:
         one = 1.0 - ls + ls / 2.0
         zero = ls / 2.0
         world = D.world_size()
+
+        if self.dual_stream and self.use_identity_loss and self.batch_generator_passes and not self.use_binary_crossentropy_a:
+            return self._train_step_dual(real_a, real_b, one, zero, world)
 
         # ---- generators -------------------------------------------------------------------------------
         tape = Tape()
@@ -205,6 +210,99 @@ class CycleGanModel:
         self.disc_a_optimizer.apply(da, 1.0 / world)
         self.disc_b_optimizer.apply(db, 1.0 / world)
 
+        return self._update_metrics()
+
+    def _train_step_dual(self, real_a, real_b, one, zero, world):
+        """The same step as two CONCURRENT kernel chains on two HIP streams.  In the generator phase the A->B->A chain
+        (G_a on [real_a; real_b], G_b on fake_b, D_b on fake_b and their losses) and the B->A->B chain share nothing but
+        read-only weights and inputs; each has its own tape, scratch buffer and gradient buffer (both chains produce gradients
+        of BOTH generators, so chain B accumulates into the alternate buffer and the two are added after the join).  The
+        discriminator phase splits into the D_a and the D_b chain.  Same arithmetic per chain as the single-stream step; the
+        only difference is one extra fp32 addition per generator gradient element (g_A + g_B instead of accumulating in place)."""
+        from .engine import side_streams
+        ga, gb, da, db = self.gen_a, self.gen_b, self.disc_a, self.disc_b
+        cur = torch.cuda.current_stream()
+        s1, s2 = side_streams(real_a.device)
+        n_a, n_b = real_a.n, real_b.n
+
+        # ---- generators -------------------------------------------------------------------------------
+        ga.zero_grad()
+        gb.zero_grad()
+        ga.arena.zero_grad_alt()
+        gb.arena.zero_grad_alt()
+        for net in (ga, gb):
+            net.arena.defer_hooks = True          # a bucket is final only after the two buffers are added: exchange after the join
+        s1.wait_stream(cur)
+        s2.wait_stream(cur)
+        tape_a, tape_b = Tape(), Tape()
+        with torch.cuda.stream(s1):
+            fake_b, same_b = LY.batch_split(tape_a, ga(Act(torch.cat([real_a.t, real_b.t], 0), requires_grad=False), True, tape_a), [n_a, n_b])
+            cycled_a = gb(fake_b, True, tape_a)
+            tape_a.param_grads = False
+            disc_fake_b = db(fake_b, True, tape_a)
+            tape_a.param_grads = True
+            losses.mse_const(disc_fake_b, one, 1.0, self._slot(0))
+            losses.mae(real_a, cycled_a, self.lambda_cycle_b, self._slot(3))
+            losses.mae(real_b, same_b, self.lambda_cycle_a * self.lambda_identity_a, self._slot(4))
+        with torch.cuda.stream(s2):
+            fake_a, same_a = LY.batch_split(tape_b, gb(Act(torch.cat([real_b.t, real_a.t], 0), requires_grad=False), True, tape_b), [n_b, n_a])
+            cycled_b = ga(fake_a, True, tape_b)
+            tape_b.param_grads = False
+            disc_fake_a = da(fake_a, True, tape_b)
+            tape_b.param_grads = True
+            losses.mse_const(disc_fake_a, one, 1.0, self._slot(1))
+            losses.mae(real_b, cycled_b, self.lambda_cycle_a, self._slot(2))
+            losses.mae(real_a, same_a, self.lambda_cycle_b * self.lambda_identity_b, self._slot(5))
+        D.begin_backward([ga, gb, da, db])
+        with torch.cuda.stream(s1):
+            tape_a.backward()
+        ga.arena.swap_grads()
+        gb.arena.swap_grads()
+        try:
+            with torch.cuda.stream(s2):
+                tape_b.backward()
+        finally:
+            ga.arena.swap_grads()
+            gb.arena.swap_grads()
+        cur.wait_stream(s1)
+        cur.wait_stream(s2)
+        ga.arena.merge_alt_grads()
+        gb.arena.merge_alt_grads()
+        D.all_reduce_grads([ga, gb])
+        for net in (ga, gb):
+            net.arena.defer_hooks = False
+        self.gen_a_optimizer.apply(ga, 1.0 / world)
+        self.gen_b_optimizer.apply(gb, 1.0 / world)
+
+        # ---- discriminators ---------------------------------------------------------------------------
+        pooled_a = self.image_pool_a.query(fake_a.t)
+        pooled_b = self.image_pool_b.query(fake_b.t)
+        da.zero_grad()
+        db.zero_grad()
+        s1.wait_stream(cur)
+        s2.wait_stream(cur)
+        tape_a, tape_b = Tape(), Tape()
+        with torch.cuda.stream(s1):
+            disc_real_a, disc_fake_a2 = LY.batch_split(
+                tape_a, da(Act(torch.cat([real_a.t, pooled_a], 0), requires_grad=False), True, tape_a), [n_a, pooled_a.shape[0]])
+            losses.mse_const(disc_real_a, one, 0.5, self._slot(6))
+            losses.mse_const(disc_fake_a2, zero, 0.5, self._slot(7))
+        with torch.cuda.stream(s2):
+            disc_real_b, disc_fake_b2 = LY.batch_split(
+                tape_b, db(Act(torch.cat([real_b.t, pooled_b], 0), requires_grad=False), True, tape_b), [n_b, pooled_b.shape[0]])
+            losses.mse_const(disc_real_b, one, 0.5, self._slot(8))
+            losses.mse_const(disc_fake_b2, zero, 0.5, self._slot(9))
+        D.begin_backward([ga, gb, da, db])
+        with torch.cuda.stream(s1):
+            tape_a.backward()
+        with torch.cuda.stream(s2):
+            tape_b.backward()
+        cur.wait_stream(s1)
+        cur.wait_stream(s2)
+        D.all_reduce_grads([da, db])
+        self.disc_a_optimizer.apply(da, 1.0 / world)
+        self.disc_b_optimizer.apply(db, 1.0 / world)
+        del tape_a, tape_b
         return self._update_metrics()
 
     # ---- helpers --------------------------------------------------------------------------------------

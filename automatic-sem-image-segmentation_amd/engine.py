@@ -34,9 +34,22 @@ def _stream():
     return ctypes.c_void_p(_RAW_STREAM(_DEV_INDEX))
 
 
-def workspace(nbytes, device):
-    """Grow-only scratch buffer shared by all calls on a device (stream-ordered use)."""
+_SIDE = {}
+
+
+def side_streams(device):
+    """Two side streams per device for independent kernel chains (CycleGanModel.train_step runs the A->B->A and B->A->B chains
+    concurrently: at small per-GPU batches a single chain cannot fill 256 CUs)."""
     key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _SIDE[key]
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer shared by all calls on a (device, stream): use is stream-ordered, so concurrent chains on
+    different streams get different buffers."""
+    key = (device.type, device.index, (_stream().value or 0) if device.type == "cuda" else 0)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -262,7 +275,7 @@ class ParamArena:
             if c == 0:
                 b = self.bucket_of[n]
                 b["remaining"] -= 1
-                if b["remaining"] == 0 and b["active"] and self.grad_hook is not None:
+                if b["remaining"] == 0 and b["active"] and self.grad_hook is not None and not getattr(self, "defer_hooks", False):
                     b["fired"] = True
                     self.works.append(self.grad_hook(self.grads[b["start"]:b["end"]]))
 
@@ -271,6 +284,35 @@ class ParamArena:
 
     def grad(self, name):
         return self.gviews[name]
+
+    # ---- second gradient buffer: two backward chains running on different streams must not accumulate into the same memory ----
+    def _alt(self):
+        if getattr(self, "grads_alt", None) is None:
+            self.grads_alt = torch.zeros_like(self.grads)
+            self.gviews_alt = {}
+            for name, shape, trainable, off in self.specs:
+                if trainable:
+                    size = 1
+                    for s_ in shape:
+                        size *= s_
+                    self.gviews_alt[name] = self.grads_alt[off:off + size].view(shape)
+        return self.grads_alt
+
+    def swap_grads(self):
+        """Exchange the roles of the main and the alternate gradient buffer (host-side pointer swap)."""
+        self._alt()
+        self.grads, self.grads_alt = self.grads_alt, self.grads
+        self.gviews, self.gviews_alt = self.gviews_alt, self.gviews
+
+    def zero_grad_alt(self):
+        lib = L.load()
+        L.check(lib.ss_fill(_p(self._alt()), 0.0, self.grads_alt.numel(), _stream()), "ss_fill")
+
+    def merge_alt_grads(self):
+        """grads += grads_alt (on the current stream)."""
+        lib = L.load()
+        n = self.grads.numel()
+        L.check(lib.ss_axpby(1.0, _p(self.grads), 1, 1.0, _p(self.grads_alt), 1, _p(self.grads), 1, n, 1, _stream()), "axpby")
 
     def zero_grad(self):
         lib = L.load()

@@ -140,15 +140,27 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    E.TIMER.enabled = True
     t0 = time.perf_counter()
-    tcg = 0.0
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    E.TIMER.enabled = False
-    ksum = E.TIMER.summary()
+    # roofline leg: the timed steps run the two generator chains CONCURRENTLY on two HIP streams, where the HIP-event duration
+    # of one op includes its neighbour's kernels; so the dominant op is timed live in two further steps of the same workload run
+    # on ONE stream (same process, shapes, buffers; not part of `value`)
+    ksum = {}
+    if not args.only_unet:
+        dual = model.dual_stream
+        model.dual_stream = False
+        step()
+        torch.cuda.synchronize()
+        E.TIMER.enabled = True
+        for _ in range(2):
+            step()
+        E.TIMER.enabled = False
+        ksum = E.TIMER.summary()
+        model.dual_stream = dual
+    barrier()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -177,7 +189,7 @@ def main():
                 "kernel": "3x3 512->512 trunk conv forward = wino_weight<4> + wprep_x6 + wino_input<4> + batched gconv_x6_kernel<128> "
                           "(36 GEMMs; fp32 operands split exactly into 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per product, fp32 "
                           "accumulate) + wino_output; reflect pad fused in the input transform.  SS_X6=0: fp32-MFMA GEMMs instead",
-                # ALGORITHMIC (direct-convolution) FLOPs of the op / HIP-event duration of the op inside the timed region
+                # ALGORITHMIC (direct-convolution) FLOPs of the op / HIP-event duration of the op (single-stream steps, see above)
                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                 "note": "peak = dense fp32 matrix peak (v_mfma_f32_32x32x2_f32), the dtype's peak; frac exceeds 1 because (a) Winograd "
                         "F(4x4,3x3) executes 4x fewer multiply-adds than the algorithmic count (38.7 of 154.6 GFLOP per launch at batch "

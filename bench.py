@@ -198,11 +198,11 @@ def main():
                         "of bf16 MFMA work = 0.29 of the 2.5 PFLOP/s bf16 peak, 53 % matrix-pipe utilisation at the 1.73 GHz the chip "
                         "holds under this load (profiles/r01_pmc_trunk_fwd_x6.md)",
                 "executed_bf16_mfma_flops_per_launch": flops / 4.0 * 6.0,
-                # the GEMM kernel alone, from the committed rocprofv3 summary of this command (profiles/r01_o_kernel_stats.md)
+                # the GEMM kernel alone, from the committed rocprofv3 summary of this command (profiles/r01_r_single_stream_kernel_stats.md)
                 "executed": ({"kernel": "gconv_x6_kernel<128,128>, the 36 batched GEMMs of a batch-8 op (2304 workgroups)",
-                              "bf16_mfma_flops": flops_sample * 8 / 4.0 * 6.0, "kernel_avg_ms_rocprof": 0.282,
-                              "achieved": round(flops_sample * 8 / 4.0 * 6.0 / 0.282e-3 / 1e15, 3), "peak": 2.5, "unit": "PFLOP/s",
-                              "frac": round(flops_sample * 8 / 4.0 * 6.0 / 0.282e-3 / 2.5e15, 3)}
+                              "bf16_mfma_flops": flops_sample * 8 / 4.0 * 6.0, "kernel_avg_ms_rocprof": 0.2795,
+                              "achieved": round(flops_sample * 8 / 4.0 * 6.0 / 0.2795e-3 / 1e15, 3), "peak": 2.5, "unit": "PFLOP/s",
+                              "frac": round(flops_sample * 8 / 4.0 * 6.0 / 0.2795e-3 / 2.5e15, 3)}
                              if (per == 8 and S == 512 and F == 64 and os.environ.get("SS_X6", "1") != "0") else None),
                 "executed_mfma_flops_per_launch": flops / 4.0,
                 # PMC cannot be sampled from inside this process: rocprofv3 pass on the direct (non-Winograd) kernel of this shape

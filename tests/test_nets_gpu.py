@@ -253,3 +253,28 @@ def test_discriminator_gaussian_noise_option():
     d = LY.gaussian_noise(E.Tape(enabled=False), a, 0.15, True).dense()
     assert abs(float(d.mean())) < 5e-3 and abs(float(d.std()) - 0.15) < 5e-3
     assert LY.gaussian_noise(E.Tape(enabled=False), a, 0.15, False) is a
+
+
+def test_dual_stream_step_equals_single_stream_step():
+    """CycleGanModel._train_step_dual (two concurrent kernel chains on two HIP streams, second gradient buffer) against the
+    one-stream step from the same state: forward quantities (the 14 metrics) are bit-identical -- same kernels, same order per
+    chain --, generator gradients differ only by the association of the final add (g_A + g_B): rel-L2 <= 1e-6."""
+    CG, N, OPT = mod("CycleGAN"), mod("nets"), mod("optim")
+    gen = torch.Generator().manual_seed(21)
+    a = (torch.rand((2, 128, 128, 1), generator=gen) * 2 - 1).numpy()
+    b = ((torch.rand((2, 128, 128, 1), generator=gen) > 0.9).float() * 2 - 1).numpy()
+    out = {}
+    for dual in (False, True):
+        random.seed(3)
+        nets = [N.ResnetGenerator(filters=32, num_residual_blocks=3, device="cuda:0", seed=1),
+                N.ResnetGenerator(filters=32, num_residual_blocks=3, device="cuda:0", seed=2),
+                N.PatchDiscriminator(filters=64, device="cuda:0", seed=3), N.PatchDiscriminator(filters=64, device="cuda:0", seed=4)]
+        model = CG.CycleGanModel(*nets, image_pool_a=CG.ImagePool(2, 50), image_pool_b=CG.ImagePool(2, 50))
+        model.compile(OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5))
+        model.dual_stream = dual
+        m = model.train_step((a, b))
+        out[dual] = (m, [n.get_gradients() for n in nets])
+    assert out[False][0] == out[True][0]
+    for g1, g2 in zip(out[False][1], out[True][1]):
+        for k in g1:
+            assert rel_l2(g2[k], g1[k]) <= 1e-6, k

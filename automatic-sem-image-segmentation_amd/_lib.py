@@ -42,7 +42,7 @@ SIGNATURES = {
     "ss_norm_workspace_bytes": (c_sz, [ctypes.POINTER(NormDesc)]),
     "ss_norm_fwd": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_sz, c_vp]),
     "ss_norm_infer": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "ss_norm_bwd": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
+    "ss_norm_bwd": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "ss_norm_fwd_stats": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_norm_fwd_finish": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     "ss_norm_bwd_stats": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

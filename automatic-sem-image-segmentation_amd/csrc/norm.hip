@@ -66,7 +66,10 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          int act, float alpha,
                                                          int C, long P, long pix_per_chunk, int CT, int PT,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part,
+                                                         const float* __restrict__ rgamma = nullptr, const float* __restrict__ rbeta = nullptr) {
+    // MODE 1 with y == nullptr (relu / leaky relu without residual): the activation mask is recomputed from x with the forward's
+    // expression (y > 0 <=> t > 0) -- one tensor read less in each of the two backward passes
     __shared__ float red[2 * V][256];
     const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;      // threads with pt >= PT (256 % CT leftovers) idle
     const int c = (blockIdx.y * CT + ct) * V;
@@ -81,7 +84,12 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
         float mu[V], rs[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) { mu[v] = 0.f; rs[v] = 0.f; }
+        float gm[V], bt[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) { gm[v] = 1.f; bt[v] = 0.f; }
         if (MODE == 1) { ldv<V>(mean + (long)g * C + c, mu); ldv<V>(rstd + (long)g * C + c, rs); }
+        const bool recompute = MODE == 1 && act != SS_ACT_NONE && y == nullptr;
+        if (recompute) { if (rgamma) ldv<V>(rgamma + c, gm); ldv<V>(rbeta + c, bt); }
 #pragma unroll 4
         for (long p = p0 + pt; p < p1; p += PT) {
             float xv[V];
@@ -92,7 +100,13 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
             } else {
                 float gv[V];
                 ldv<V>(dy + (base + p) * dy_cs + c, gv);
-                if (act != SS_ACT_NONE) {
+                if (recompute) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const float t = (xv[v] - mu[v]) * (rs[v] * gm[v]) + bt[v];
+                        gv[v] *= ss_act_grad_from_out(t, act, alpha);          // relu / lrelu: depends on the sign only
+                    }
+                } else if (act != SS_ACT_NONE) {
                     float yv[V];
                     ldv<V>(y + (base + p) * y_cs + c, yv);
 #pragma unroll
@@ -257,7 +271,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ sums,
                                                              float* __restrict__ dx, int dx_cs, int acc_dx,
                                                              float* __restrict__ dres, int dres_cs, int acc_dres,
-                                                             int act, float alpha, int C, long P, long rows) {
+                                                             int act, float alpha, int C, long P, long rows,
+                                                             const float* __restrict__ rbeta = nullptr) {
     const int CV = C / V;
     const long total = rows * CV;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -272,7 +287,15 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
         if (gamma) ldv<V>(gamma + c, gm);
 #pragma unroll
         for (int v = 0; v < V; ++v) { sm[2 * v] = sums[(gi + v) * 2]; sm[2 * v + 1] = sums[(gi + v) * 2 + 1]; }
-        if (act != SS_ACT_NONE) {
+        if (act != SS_ACT_NONE && y == nullptr) {          // mask recomputed from x (see norm_stats_kernel)
+            float bt[V];
+            ldv<V>(rbeta + c, bt);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float t = (xv[v] - mu[v]) * (rs[v] * (gamma ? gm[v] : 1.f)) + bt[v];
+                gv[v] *= ss_act_grad_from_out(t, act, alpha);
+            }
+        } else if (act != SS_ACT_NONE) {
             ldv<V>(y + row * y_cs + c, yv);
 #pragma unroll
             for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out(yv[v], act, alpha);
@@ -413,26 +436,29 @@ int ss_norm_infer(const ss_norm_desc* d, const float* x, const float* gamma, con
 }
 
 int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
-                const float* gamma, const float* mean, const float* rstd,
+                const float* gamma, const float* beta, const float* mean, const float* rstd,
                 float* dx, int32_t dx_cstride, int accumulate_dx, float* dres, int accumulate_dres,
                 float* dgamma, float* dbeta, int accumulate_params,
                 void* ws, size_t ws_bytes, void* stream) {
     if (!valid(d) || !dy || !x || !mean || !rstd || !dx) return SS_ERR_INVALID;
-    if (d->act != SS_ACT_NONE && !y) return SS_ERR_INVALID;
+    if (d->act != SS_ACT_NONE && !y) {      // y may be omitted only where its sign can be recomputed from x: relu / lrelu, no residual
+        if ((d->act != SS_ACT_RELU && d->act != SS_ACT_LRELU) || !beta || dres) return SS_ERR_INVALID;
+    }
     if (!ws || ws_bytes < ss_norm_workspace_bytes(d)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    const int V = pick_v(d->c, {d->x_cstride, dy_cstride, dx_cstride, d->act != SS_ACT_NONE ? d->y_cstride : 0, dres ? d->res_cstride : 0},
-                         {x, dy, dx, d->act != SS_ACT_NONE ? y : nullptr, dres, gamma, mean, rstd});
+    const bool use_y = d->act != SS_ACT_NONE && y != nullptr;
+    const int V = pick_v(d->c, {d->x_cstride, dy_cstride, dx_cstride, use_y ? d->y_cstride : 0, dres ? d->res_cstride : 0},
+                         {x, dy, dx, use_y ? y : nullptr, dres, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
     float* part = (float*)ws;
     float* sums = (float*)((char*)ws + part_bytes(d));
     const dim3 sgrid(g.chunks, g.cblocks, g.G);
     if (V == 4)
         hipLaunchKernelGGL((norm_stats_kernel<1, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
-                           d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
+                           d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
     else
         hipLaunchKernelGGL((norm_stats_kernel<1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
-                           d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
+                           d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + FIN_CL - 1) / FIN_CL), dim3(256), 0, s,
                        part, g.chunks, g.G, g.C, g.P, sums, dgamma, dbeta, accumulate_params, FIN_CL);
@@ -441,11 +467,11 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
     if (V == 4)
         hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, rows);
+                           d->act, d->act_alpha, g.C, g.P, rows, beta);
     else
         hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, rows);
+                           d->act, d->act_alpha, g.C, g.P, rows, beta);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

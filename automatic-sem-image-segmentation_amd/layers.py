@@ -207,7 +207,9 @@ class Norm:
             ggam = self.arena.grad(f"{self.name}/gamma") if (self.scale and param_grads) else None
             gbet = self.arena.grad(f"{self.name}/beta") if param_grads else None
             if sync is None:
-                L.check(lib.ss_norm_bwd(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, y.ptr, _p(gamma), _p(mean), _p(rstd),
+                # relu / leaky-relu without a residual: the kernels recompute the mask from x instead of reading y
+                yp = None if (act in ("relu", "lrelu") and residual is None) else y.ptr
+                L.check(lib.ss_norm_bwd(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, yp, _p(gamma), _p(beta), _p(mean), _p(rstd),
                                         dx.ptr, dx.cs, accum, dres.ptr if dres is not None else None, racc,
                                         _p(ggam), _p(gbet), 1, _p(ws2), ws2.numel(), _stream()), f"norm_bwd[{self.name}]")
             else:

@@ -129,9 +129,11 @@ int ss_norm_infer(const ss_norm_desc* d, const float* x, const float* gamma, con
 /* dy: gradient w.r.t. y.  y: forward output (needed when act != NONE).
  * dx (view with dx_cstride) receives d loss / d x.  dres (optional, view with d->res_cstride) receives the
  * gradient w.r.t. the residual input (= dy * act'(.)).  dgamma may be NULL.  Each accumulate_* flag != 0
- * adds into the destination instead of overwriting it. */
+ * adds into the destination instead of overwriting it.  `y` (the forward output, needed for the activation derivative) may be
+ * NULL for relu / leaky-relu layers WITHOUT a residual input: the sign of the pre-activation is then recomputed from x, mean,
+ * rstd, gamma and `beta` (one tensor read less in both backward passes); `beta` is only read in that case. */
 int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
-                const float* gamma, const float* mean, const float* rstd,
+                const float* gamma, const float* beta, const float* mean, const float* rstd,
                 float* dx, int32_t dx_cstride, int accumulate_dx, float* dres, int accumulate_dres,
                 float* dgamma, float* dbeta, int accumulate_params,
                 void* ws, size_t ws_bytes, void* stream);

@@ -94,7 +94,8 @@ class CycleGanModel:
         # translation + identity pass of each generator as ONE pass over the concatenated batch (same maths per sample)
         self.batch_generator_passes = os.environ.get("SS_BATCH_G_PASSES", "1") != "0"
         # run the two independent chains of each phase on two HIP streams (see _train_step_dual); SS_DUAL_STREAM=0 disables
-        self.dual_stream = os.environ.get("SS_DUAL_STREAM", "1") != "0"
+        self.dual_stream = {"0": False, "force": "force"}.get(os.environ.get("SS_DUAL_STREAM", "1"), True)
+        # (switched off automatically when several ranks share one GPU -- dist.ranks_share_device(); "force" overrides, for tests)
         self.gen_a_optimizer = self.gen_b_optimizer = self.disc_a_optimizer = self.disc_b_optimizer = None
         self.image_pool_a = image_pool_a if image_pool_a is not None else ImagePool(1, 0)
         self.image_pool_b = image_pool_b if image_pool_b is not None else ImagePool(1, 0)
@@ -139,7 +140,8 @@ class CycleGanModel:
         zero = ls / 2.0
         world = D.world_size()
 
-        if self.dual_stream and self.use_identity_loss and self.batch_generator_passes and not self.use_binary_crossentropy_a:
+        if (self.dual_stream and self.use_identity_loss and self.batch_generator_passes and not self.use_binary_crossentropy_a
+                and (self.dual_stream == "force" or not D.ranks_share_device())):
             return self._train_step_dual(real_a, real_b, one, zero, world)
 
         # ---- generators -------------------------------------------------------------------------------
@@ -268,11 +270,14 @@ class CycleGanModel:
         cur.wait_stream(s2)
         ga.arena.merge_alt_grads()
         gb.arena.merge_alt_grads()
-        D.all_reduce_grads([ga, gb])
+        # the generator gradient exchange (the bulk of the step's bytes) runs behind the discriminator phase, which touches neither
+        # the generators' weights nor their gradients; the generator optimizer steps are applied after it
+        gen_works = D.begin_all_reduce_grads([ga, gb])
+        if os.environ.get("SS_DEFER_G_ALLREDUCE", "1") == "0":
+            D.finish_all_reduce_grads(gen_works)
+            gen_works = []
         for net in (ga, gb):
             net.arena.defer_hooks = False
-        self.gen_a_optimizer.apply(ga, 1.0 / world)
-        self.gen_b_optimizer.apply(gb, 1.0 / world)
 
         # ---- discriminators ---------------------------------------------------------------------------
         pooled_a = self.image_pool_a.query(fake_a.t)
@@ -302,6 +307,9 @@ class CycleGanModel:
         D.all_reduce_grads([da, db])
         self.disc_a_optimizer.apply(da, 1.0 / world)
         self.disc_b_optimizer.apply(db, 1.0 / world)
+        D.finish_all_reduce_grads(gen_works)
+        self.gen_a_optimizer.apply(ga, 1.0 / world)
+        self.gen_b_optimizer.apply(gb, 1.0 / world)
         del tape_a, tape_b
         return self._update_metrics()
 

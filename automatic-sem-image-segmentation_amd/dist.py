@@ -73,25 +73,47 @@ def begin_backward(nets):
         net.arena.begin_backward()
 
 
-def all_reduce_grads(nets):
-    """Finish the gradient exchange of these networks: wait for the buckets launched during backward and reduce any
-    bucket that has not been sent (overlap disabled, or a bucket whose variables were not all used)."""
+def ranks_share_device():
+    """True when several ranks of this node run on one GPU (CPU-less test rigs: 2 ranks on 1 device).  Multi-stream execution
+    is switched off there: two processes x three streams oversubscribe the hardware queues and the GPU falls into wave
+    context-switch thrashing (measured: 16-24 s per step instead of 0.56 s)."""
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", world_size()))
+    return torch.cuda.is_available() and local > torch.cuda.device_count()
+
+
+def begin_all_reduce_grads(nets):
+    """Launch (asynchronously) whatever part of these networks' gradient exchange has not been launched during backward and
+    return the outstanding work handles; `finish_all_reduce_grads` waits.  Lets the caller put independent work (the CycleGAN
+    discriminator phase) between the two."""
+    works = []
     if world_size() == 1:
         for net in nets:
             net.arena.pending = {}
-        return
+        return works
     for net in nets:
         a = net.arena
         if a.grad_hook is None:
-            all_reduce_flat(a.grads)
-            a.pending = {}
-            continue
-        late = [dist.all_reduce(a.grads[b["start"]:b["end"]], op=dist.ReduceOp.SUM, async_op=True)
-                for b in a.buckets if b["active"] and not b["fired"]]
-        for w in a.works + late:
-            w.wait()
+            n = a.grads.numel()
+            step = 64 * 1024 * 1024 // 4
+            works += [dist.all_reduce(a.grads[off:min(off + step, n)], op=dist.ReduceOp.SUM, async_op=True) for off in range(0, n, step)]
+        else:
+            works += a.works
+            works += [dist.all_reduce(a.grads[b["start"]:b["end"]], op=dist.ReduceOp.SUM, async_op=True)
+                      for b in a.buckets if b["active"] and not b["fired"]]
         a.works = []
         a.pending = {}
+    return works
+
+
+def finish_all_reduce_grads(works):
+    for w in works:
+        w.wait()
+
+
+def all_reduce_grads(nets):
+    """Finish the gradient exchange of these networks: wait for the buckets launched during backward and reduce any
+    bucket that has not been sent (overlap disabled, or a bucket whose variables were not all used)."""
+    finish_all_reduce_grads(begin_all_reduce_grads(nets))
 
 
 def broadcast_params(nets, src=0):

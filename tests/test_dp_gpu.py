@@ -59,7 +59,8 @@ def _run(tmp_path, world):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
     out = str(tmp_path / f"out{world}.npz")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29740 + world), WORLD_SIZE=str(world))
+    # SS_DUAL_STREAM=force: keep the two-stream execution (and its deferred gradient exchange) although both ranks share cuda:0
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29740 + world), WORLD_SIZE=str(world), SS_DUAL_STREAM="force")
     procs = [subprocess.Popen([sys.executable, str(script), REPO, out], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     for r, p in enumerate(procs):

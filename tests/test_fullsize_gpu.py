@@ -263,3 +263,36 @@ def test_cyclegan_step_one_full_resolution_tile_vs_oracle():
         e_32 = float(np.linalg.norm(cat(g32[k]) - r64) / np.linalg.norm(r64))
         print(f"{k}: gradient rel-L2 vs fp64  hip={e_hip:.2e}  oracle32={e_32:.2e}")
         assert e_hip <= 3 * e_32 + 1e-4, (k, e_hip, e_32)
+
+
+def test_unet_step_baseline_tiles_vs_oracle():
+    """One MultiResUNet(16) train step on 256x256 tiles (the tile size of BASELINE config 2), batch 4, against the oracle; the
+    fp64 oracle arbitrates as in tests/test_nets_gpu.py::test_unet_train_step_vs_oracle (which runs 64x64 tiles)."""
+    UN, OPT, N = mod("UNet_Segmentation"), mod("optim"), mod("nets")
+    gen = torch.Generator().manual_seed(13)
+    ref = ON.MultiResUNet(16, seed=9)
+    ref64 = ON.MultiResUNet(16, seed=9, dtype=torch.float64)
+    ref64.set_weights(ref.get_weights())
+    hip = N.MultiResUNet(16, device="cuda:0")
+    hip.set_weights(ref.get_weights())
+    model = UN.UNetModel(hip, 9.0, OPT.Adam(1e-3))
+    x = torch.rand((4, 256, 256, 1), generator=gen)
+    y = (torch.rand((4, 256, 256, 1), generator=gen) > 0.9).float()
+    want, _ = OS.UNetStep(ref, 9.0).train_step((x, y))
+    want64, p64 = OS.UNetStep(ref64, 9.0).train_step((x.double(), y.double()))
+    got = model.train_step((x.numpy(), y.numpy()))
+    near = float(((p64 - 0.5).abs() < 2e-3).double().mean())
+    for k in ("loss", "mae"):
+        noise = abs(want[k] - want64[k])
+        assert abs(got[k] - want64[k]) <= 2e-4 * max(abs(want64[k]), 1.0) + 3 * noise, (k, got[k], want[k], want64[k])
+    assert abs(got["acc"] - want64["acc"]) <= near + 1e-6
+    gh = hip.get_gradients()
+    g32 = {v.name: v.value.grad.detach().double().numpy() for v in ref.trainable_weights}
+    g64 = {v.name: v.value.grad.detach().numpy() for v in ref64.trainable_weights}
+    names = [n for n in g64 if float(np.abs(g64[n]).max()) > 1e-12]
+    cat = lambda d: np.concatenate([np.asarray(d[n], np.float64).ravel() for n in names])
+    r64 = cat(g64)
+    e_hip = float(np.linalg.norm(cat(gh) - r64) / np.linalg.norm(r64))
+    e_32 = float(np.linalg.norm(cat(g32) - r64) / np.linalg.norm(r64))
+    print(f"UNet gradient rel-L2 vs fp64: hip={e_hip:.2e} oracle32={e_32:.2e}")
+    assert e_hip <= 5 * e_32 + 1e-3, (e_hip, e_32)

@@ -1,5 +1,7 @@
+"""Build the four CycleGAN networks three times from the same seeds, run one train step each on the same tiles and compare
+metrics and every parameter gradient bit for bit.  Usage: python tools/check_determinism.py S N F  (tile, batch, filters)"""
 import importlib, random, sys, os, numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG="automatic-sem-image-segmentation_amd"
 CG=importlib.import_module(PKG+".CycleGAN"); NETS=importlib.import_module(PKG+".nets"); OPT=importlib.import_module(PKG+".optim")
 def build(F):

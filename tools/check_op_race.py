@@ -1,5 +1,8 @@
+"""One conv layer (7x7 stem 1->F, or head F->1 with OPHEAD=1) forward + backward in a loop on one HIP stream while a generator
+forward + backward runs on another: every result must equal the one obtained alone (this is the test that exposed the packed-fp32
+hazard described in csrc/Makefile).  OPALGO=auto|mfma|direct selects the kernel family of the layer under test."""
 import importlib, sys, os, torch, ctypes
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG="automatic-sem-image-segmentation_amd"
 E=importlib.import_module(PKG+".engine"); NETS=importlib.import_module(PKG+".nets"); LY=importlib.import_module(PKG+".layers"); L=importlib.import_module(PKG+"._lib")
 dev=torch.device("cuda:0")

@@ -118,6 +118,21 @@ struct WGradParams {
     GTap taps[SS_MAX_TAPS];       // woff = destination offset of the tap block inside dw
 };
 
+// batched NT GEMM on pre-split bf16 planes (gemm_x6p.hip): C[batch][split][m][n] = sum_k A[batch][m][k] * B[batch][n][k]
+#define SS_X6P_BM 256
+#define SS_X6P_BN 128
+struct X6PParams {
+    const unsigned short* a;      // [3 planes][batch][rows padded to SS_X6P_BM][lda]
+    const unsigned short* b;      // [3 planes][batch][rows padded to SS_X6P_BN][ldb]
+    float* c;                     // [batch][split][M][ldc]
+    int32_t M, N, K, nbatch, splits, k_per_split;
+    int32_t lda, ldb, ldc;
+    int64_t a_plane, b_plane, a_bs, b_bs, c_bs, c_ss;
+};
+bool ss_x6p_enabled();
+bool ss_x6p_wanted(long M, int N, int nbatch);
+int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
+
 struct SsTuning { bool no_fast, nt512, tile256, no_winograd, x6; int wino_r; };
 const SsTuning& ss_tuning();   // measurement overrides, read once (conv_mfma.hip)
 

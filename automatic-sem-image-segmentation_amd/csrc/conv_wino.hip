@@ -108,9 +108,11 @@ template <int R> __device__ __forceinline__ void t_dw(const float* s, float* o) 
 }
 
 // V[xi][tile][c], tile = (n, ty, tx); patch d[i][j] = in[n, map(R*ty + i - pt), map(R*tx + j - pl), c]
-template <int R, bool BF>
+// BF = 0: fp32 V;  1: two bf16 planes (SS_PRECISION=bf16x3);  2: the three bf16 planes of the x6 arithmetic,
+// [plane][xi][tile rows padded to Mpad][c] -- the A operand of gemm_x6p.hip, no conversion left for the GEMM
+template <int R, int BF>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int in_cs, int N, int H, int W, int C,
-                                                         int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V) {
+                                                         int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V, long Mpad = 0) {
     typedef typename WT<R>::T T;
     constexpr int VW = WT<R>::VW, P = R + 2;
     const int CV = C / VW;
@@ -146,7 +148,23 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     for (int i = 0; i < P; ++i) {
         T v[P];
         t_in<R, T>(t[i], v);
-        if (BF) {       // two bf16 planes [xi][tile][c] (hi plane, then lo plane) in the space of the fp32 V
+        if (BF == 2) {
+            const long xs3 = Mpad * C;                       // elements between transform positions
+            unsigned int* o3 = (unsigned int*)((unsigned short*)V + tile * C + c);
+            const long pl32 = (long)P * P * xs3 / 2;         // u32 between planes
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+#pragma unroll
+                for (int k = 0; k < VW; k += 2) {
+                    unsigned int h, m, l;
+                    ss_split3x2(f32x2{v[j][k], v[j][k + 1]}, h, m, l);
+                    unsigned int* d = o3 + (long)(i * P + j) * xs3 / 2 + k / 2;
+                    d[0] = h;
+                    d[pl32] = m;
+                    d[2 * pl32] = l;
+                }
+            }
+        } else if (BF == 1) {       // two bf16 planes [xi][tile][c] (hi plane, then lo plane) in the space of the fp32 V
             unsigned short* oh = (unsigned short*)V + tile * C + c;
             unsigned short* ol = oh + (long)P * P * xs;
 #pragma unroll
@@ -458,6 +476,31 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
+    if (q.x6 && q.cin % 32 == 0 && ss_x6p_wanted(tiles, q.cout, XI)) {
+        // both GEMM operands as pre-split bf16 planes: V planes in the V region (1.5x the fp32 size, see ss_wino_fwd_ws)
+        const long Mpad = (tiles + SS_X6P_BM - 1) / SS_X6P_BM * SS_X6P_BM;
+        const int Npad = ss_x6_npad(q.cout);
+        Mx = (float*)((char*)V + ss_align_up((size_t)3 * XI * Mpad * q.cin * 2, 256));
+        unsigned short* planes = (unsigned short*)((char*)Mx + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
+        hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(g256((long)(q.cin / 2) * Npad)), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL((wino_input_kernel<R, 2>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                           TH, TW, q.pt, q.pl, q.reflect, V, Mpad);
+        SS_LAUNCH_CHECK();
+        X6PParams g{};
+        g.a = (const unsigned short*)V; g.b = planes; g.c = Mx;
+        g.M = (int)tiles; g.N = q.cout; g.K = q.cin; g.nbatch = XI; g.splits = 1; g.k_per_split = q.cin;
+        g.lda = q.cin; g.ldb = q.cin; g.ldc = q.cout;
+        g.a_plane = (long)XI * Mpad * q.cin; g.a_bs = Mpad * q.cin;
+        g.b_plane = (long)XI * Npad * q.cin; g.b_bs = (long)Npad * q.cin;
+        g.c_bs = tiles * q.cout; g.c_ss = 0;
+        const int rcx = ss_launch_gemm_x6p(g, s);
+        if (rcx != SS_OK) return rcx;
+        hipLaunchKernelGGL(wino_output_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
+                           bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w);
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+    }
     hipLaunchKernelGGL((wino_input_kernel<R, false>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
                        q.pt, q.pl, q.reflect, V);
     SS_LAUNCH_CHECK();
@@ -533,8 +576,9 @@ size_t ss_wino_fwd_ws(const WinoProb& q) {
     const int R = wino_r(), XI = (R + 2) * (R + 2);
     const long tiles = n_tiles(q, R);
     const size_t planes = ss_align_up((size_t)3 * XI * ss_x6_npad(q.cout) * q.cin * 2, 256);
-    return ss_align_up((size_t)XI * q.cin * q.cout * 4, 256) + ss_align_up((size_t)XI * tiles * q.cin * 4, 256) +
-           ss_align_up((size_t)XI * tiles * q.cout * 4, 256) + planes;
+    const long Mpad = (tiles + SS_X6P_BM - 1) / SS_X6P_BM * SS_X6P_BM;
+    const size_t vbytes = ss_align_up((size_t)XI * Mpad * q.cin * 6, 256);      // fp32 V or three bf16 planes with padded rows
+    return ss_align_up((size_t)XI * q.cin * q.cout * 4, 256) + vbytes + ss_align_up((size_t)XI * tiles * q.cout * 4, 256) + planes;
 }
 
 // y (+)= act(bias + conv3x3_stride1(x)) with out[o] = sum_a in[map(o + a - pt)] * g[a];  flip = 1: g = rotated + transposed w

@@ -1,0 +1,215 @@
+// Batched "NT" GEMM with the x6 arithmetic (conv_mfma_x6.hip) on operands that are ALREADY split into three bf16 planes:
+//     C[batch][split][m][n] = sum_{k in split} A[batch][m][k] * B[batch][n][k],      a*b = ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm
+// Both operands are K-contiguous rows of bf16 (three planes each), produced once by the kernel that writes the operand (the
+// Winograd input / weight / dy transforms), so the K loop carries no conversion work: every tile goes global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4, no staging registers, no ds_write pass) into a double-buffered stage while the matrix cores
+// work on the other stage; ONE barrier per K step.
+//
+// Tile 256 (M) x 128 (N) x 32 (K), 512 threads = 8 waves as 4 (M) x 2 (N), 64x64 per wave = 2x2 MFMA tiles of 32x32.
+// LDS stage: 3 planes x (256 + 128) rows x 64 B = 72 KiB, two stages = 144 KiB (one workgroup per CU, two waves per SIMD).
+// An LDS-DMA instruction writes lane-linear (wave base + 16 B x lane) = 16 rows x 4 slots of 16 B.  Rows are 64 B with no padding;
+// bank conflicts of the ds_read_b128 operand fetch (lane = row) are avoided by an XOR swizzle of the 16-B slot with bits 2..3 of
+// the row, applied on the SOURCE address of the DMA (which k-octet a lane fetches) and on the read address alike.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PBM = SS_X6P_BM, PBN = SS_X6P_BN, PBK = 32;
+constexpr int ROWB = PBK * 2;                  // bytes per LDS row
+constexpr int A_PLANE_B = PBM * ROWB;          // 16 KiB
+constexpr int B_PLANE_B = PBN * ROWB;          //  8 KiB
+constexpr int STAGE_B = 3 * (A_PLANE_B + B_PLANE_B);
+constexpr int NDMA = STAGE_B / 1024 / 8;       // LDS-DMA instructions per wave and K step (9)
+
+__device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + PBN - 1) / PBN;
+    int tile;
+    {   // XCD-aware order (speed only): a contiguous chunk of the tile space per XCD, N fastest
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int per = gridM * gridN;
+    const int bs = tile / per;
+    tile -= bs * per;
+    const int batch = bs / p.splits, split = bs - batch * p.splits;
+    const int m0 = (tile / gridN) * PBM, n0 = (tile % gridN) * PBN;
+    const int k_begin = split * p.k_per_split;
+    const int k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
+    const int nchunks = (k_end - k_begin) / PBK;
+
+    // this wave's share of a stage: NDMA pieces of 16 rows (A planes: 48 pieces, B planes: 24)
+    const unsigned short* gp[NDMA];
+    int loff[NDMA];
+    {
+        const int rl = lane >> 2, sl = lane & 3;
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) {
+            const int q = wave * NDMA + j;
+            if (q < 3 * (PBM / 16)) {
+                const int pl = q / (PBM / 16), rb = q % (PBM / 16);
+                const int row = rb * 16 + rl;
+                const int ko = sl ^ ((row >> 2) & 3);
+                gp[j] = p.a + pl * p.a_plane + batch * p.a_bs + (long)(m0 + row) * p.lda + k_begin + 8 * ko;
+                loff[j] = pl * A_PLANE_B + rb * 1024;
+            } else {
+                const int q2 = q - 3 * (PBM / 16);
+                const int pl = q2 / (PBN / 16), rb = q2 % (PBN / 16);
+                const int row = rb * 16 + rl;
+                const int ko = sl ^ ((row >> 2) & 3);
+                gp[j] = p.b + pl * p.b_plane + batch * p.b_bs + (long)(n0 + row) * p.ldb + k_begin + 8 * ko;
+                loff[j] = 3 * A_PLANE_B + pl * B_PLANE_B + rb * 1024;
+            }
+        }
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // operand fetch addresses (stage 0): row = (wave tile base) + l31, slot = (lh + 2*ks) ^ ((row >> 2) & 3)
+    const int sw = (l31 >> 2) & 3;
+    const int so0 = ((lh ^ sw) << 4), so1 = so0 ^ 32;
+    const unsigned char* fa = lds + (wm * 64 + l31) * ROWB;
+    const unsigned char* fb = lds + 3 * A_PLANE_B + (wn * 64 + l31) * ROWB;
+
+    // Software pipeline, ONE barrier per K step.  Two fragment register sets: F0 = (tile c, k 0..15), F1 = (tile c, k 16..31).
+    //   top of step c:  F0 holds tile c / half 0 (read after the previous barrier);  stage (c+1)&1 is being filled by DMA
+    //     read F1 <- tile c half 1          (in flight under the next MFMAs)
+    //     24 MFMAs on F0
+    //     vmcnt(0) + barrier                -> tile c+1 visible to everyone, nobody reads tile c's stage any more
+    //     read F0 <- tile c+1 half 0        (in flight under the next MFMAs)
+    //     24 MFMAs on F1, the 9 DMAs of tile c+2 (into tile c's stage) issued between them
+    bf16x8 a0[3][2], b0[3][2], a1[3][2], b1[3][2];
+    auto frag = [&](bf16x8 (&a)[3][2], bf16x8 (&b)[3][2], int stage, int so) {
+        const int sb = stage * STAGE_B;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const bf16x8*)(fa + sb + pl * A_PLANE_B + mi * 32 * ROWB + so);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[pl][ni] = *(const bf16x8*)(fb + sb + pl * B_PLANE_B + ni * 32 * ROWB + so);
+        }
+    };
+    // six products, smallest terms first; consecutive MFMAs go to different accumulators
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+    auto mma4 = [&](bf16x8 (&a)[3][2], bf16x8 (&b)[3][2], int q) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
+    };
+
+    if (nchunks > 0) {
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) dma16(gp[j], lds + loff[j]);
+    }
+    if (nchunks > 1) {
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) dma16(gp[j] + PBK, lds + STAGE_B + loff[j]);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");      // tile 0 landed, tile 1 may be in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (nchunks > 0) frag(a0, b0, 0, so0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int st = c & 1;
+        frag(a1, b1, st, so1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) mma4(a0, b0, q);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): a real s_waitcnt, so that the compiler's own counting sees it
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // branch-free from here to the loop end (one basic block keeps the compiler's lgkmcnt counting exact): past the last
+        // tile the fragment read fetches stale LDS and the DMA re-fetches the last tile into the stage nobody reads any more
+        frag(a0, b0, st ^ 1, so0);
+        const int cn = c + 2 < nchunks ? c + 2 : nchunks - 1;
+        const long goff = (long)cn * PBK;
+        unsigned char* dst = lds + st * STAGE_B;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            mma4(a1, b1, q);
+#pragma unroll
+            for (int j = 0; j < NDMA; ++j)
+                if (j * 6 / NDMA == q) dma16(gp[j] + goff, dst + loff[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // F0's reads finished long ago (24 MFMAs back): a free wait that lets the compiler start the next step without one
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may still be landing when the LDS is handed to the next workgroup
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* cb = p.c + (long)batch * p.c_bs + (long)split * p.c_ss;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + wn * 64 + ni * 32 + l31;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M) cb[(long)m * p.ldc + n] = acc[mi][ni][r];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Operand rows must be allocated up to the tile edge: A rows padded to SS_X6P_BM, B rows to SS_X6P_BN per batch (pad rows of
+// A may hold anything finite or not: they only reach C rows >= M, which are not stored; pad rows of B likewise columns >= N).
+// K (and k_per_split) must be multiples of 32; pad COLUMNS of a split-K operand must be zero.
+bool ss_x6p_enabled() {
+    static const bool on = !(getenv("SS_X6P") && getenv("SS_X6P")[0] == '0');
+    return on && ss_tuning().x6;
+}
+
+// One 512-thread workgroup per CU and 256x128 tiles: worth it from about four rounds of workgroups over the 256 CUs (batch >= 8 at
+// 512x512 tiles); smaller problems keep the 128x128 / 128x64 / 64x64 register-staged kernels (conv_mfma_x6.hip), which fill the
+// chip with more, smaller workgroups.  SS_X6P=force: always.
+bool ss_x6p_wanted(long M, int N, int nbatch) {
+    static const bool force = getenv("SS_X6P") && getenv("SS_X6P")[0] == 'f';
+    if (!ss_x6p_enabled()) return false;
+    const long nwg = ((M + PBM - 1) / PBM) * ((N + PBN - 1) / PBN) * nbatch;
+    return force || nwg >= 1024;
+}
+
+int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
+    if (p.K % PBK || p.k_per_split % PBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
+    const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + PBN - 1) / PBN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const long nwg = (long)gridM * gridN * p.nbatch * p.splits;
+    hipLaunchKernelGGL(gemm_x6p_kernel, dim3((unsigned)nwg), dim3(512), 2 * STAGE_B, s, p);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}

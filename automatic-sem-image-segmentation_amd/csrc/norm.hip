@@ -5,6 +5,7 @@
 // Statistics: per-thread fp32 partial sums over a pixel chunk, wave/LDS reduction over the pixel lanes,
 // per-chunk partials in the workspace, fp64 combine in the finalize kernel.
 #include "common.h"
+#include <stdlib.h>
 #include <initializer_list>
 
 namespace {
@@ -354,6 +355,227 @@ __global__ __launch_bounds__(256) void norm_finalize_bwd_sync(const float* __res
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)tgx : (float)tgx;
 }
 
+// ---- small tensors: statistics + finalize + apply in ONE launch --------------------------------------------------------------
+// At per-GPU batch 1-2 a norm layer is three ~10 us launches whose cost is launch latency, not bandwidth.  Here a block owns
+// CL*V channels of ONE group and walks that group's pixels twice (statistics, then apply: the second walk hits L2); groups are
+// independent blocks in forward, sequential inside the block in backward (dgamma / dbeta are sums over the groups).
+// Block = CL channel lanes x 256/CL pixel lanes; fp32 lane partials, fixed-order tree over the pixel lanes, fp64 finalize.
+constexpr long NORM_SMALL_ELEMS = 4L << 20;
+
+template <int V>
+__global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __restrict__ x, int x_cs,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ res, int res_cs,
+                                                             float* __restrict__ y, int y_cs,
+                                                             float* __restrict__ mean, float* __restrict__ rstd,
+                                                             float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
+                                                             int act, float alpha, int C, long P, int CL) {
+    __shared__ float red[2 * V][256];
+    __shared__ float stat[2 * V][64];
+    const int PT = 256 / CL;
+    const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
+    const int c = (blockIdx.x * CL + cl) * V;
+    const int g = blockIdx.y;
+    const bool cval = c < C;
+    const long base = (long)g * P;
+    float s1[V], s2[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { s1[v] = 0.f; s2[v] = 0.f; }
+    if (cval) {
+#pragma unroll 4
+        for (long p = pl; p < P; p += PT) {
+            float xv[V];
+            ldv<V>(x + (base + p) * x_cs + c, xv);
+#pragma unroll
+            for (int v = 0; v < V; ++v) { s1[v] += xv[v]; s2[v] = fmaf(xv[v], xv[v], s2[v]); }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) { red[2 * v][threadIdx.x] = s1[v]; red[2 * v + 1][threadIdx.x] = s2[v]; }
+    __syncthreads();
+    for (int off = PT / 2; off >= 1; off >>= 1) {        // PT is a power of two
+        if (pl < off) {
+#pragma unroll
+            for (int k = 0; k < 2 * V; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off * CL];
+        }
+        __syncthreads();
+    }
+    if (pl == 0 && cval) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const double mu = (double)red[2 * v][threadIdx.x] / (double)P;
+            double var = (double)red[2 * v + 1][threadIdx.x] / (double)P - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float muf = (float)mu, rsf = (float)(1.0 / sqrt(var + (double)eps));
+            const long i = (long)g * C + c + v;
+            mean[i] = muf;
+            rstd[i] = rsf;
+            if (mm) {
+                mm[c + v] = mm[c + v] * momentum + muf * (1.f - momentum);
+                mv[c + v] = mv[c + v] * momentum + (float)var * (1.f - momentum);
+            }
+            stat[2 * v][cl] = muf;
+            stat[2 * v + 1][cl] = rsf;
+        }
+    }
+    __syncthreads();
+    if (!cval) return;
+    float mu[V], sc[V], bt[V];
+    {
+        float gm[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) gm[v] = 1.f;
+        if (gamma) ldv<V>(gamma + c, gm);
+        ldv<V>(beta + c, bt);
+#pragma unroll
+        for (int v = 0; v < V; ++v) { mu[v] = stat[2 * v][cl]; sc[v] = stat[2 * v + 1][cl] * gm[v]; }
+    }
+#pragma unroll 4
+    for (long p = pl; p < P; p += PT) {
+        float xv[V], rv[V], o[V];
+        ldv<V>(x + (base + p) * x_cs + c, xv);
+        if (res) ldv<V>(res + (base + p) * res_cs + c, rv);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float t = (xv[v] - mu[v]) * sc[v] + bt[v];
+            if (res) t += rv[v];
+            o[v] = ss_apply_act(t, act, alpha);
+        }
+        stv<V>(y + (base + p) * y_cs + c, o);
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __restrict__ dy, int dy_cs, const float* __restrict__ x, int x_cs,
+                                                             const float* __restrict__ y, int y_cs,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float* __restrict__ dx, int dx_cs, int acc_dx,
+                                                             float* __restrict__ dres, int dres_cs, int acc_dres,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_params,
+                                                             int act, float alpha, int G, int C, long P, int CL) {
+    __shared__ float red[2 * V][256];
+    __shared__ float stat[2 * V][64];
+    const int PT = 256 / CL;
+    const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
+    const int c = (blockIdx.x * CL + cl) * V;
+    const bool cval = c < C;
+    const bool recompute = act != SS_ACT_NONE && y == nullptr;
+    float gm[V], bt[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { gm[v] = 1.f; bt[v] = 0.f; }
+    if (cval) {
+        if (gamma) ldv<V>(gamma + c, gm);
+        if (recompute) ldv<V>(beta + c, bt);
+    }
+    double tg[V], tgx[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { tg[v] = 0.0; tgx[v] = 0.0; }
+    for (int g = 0; g < G; ++g) {
+        const long base = (long)g * P;
+        float mu[V], rs[V], s1[V], s2[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) { mu[v] = 0.f; rs[v] = 0.f; s1[v] = 0.f; s2[v] = 0.f; }
+        if (cval) {
+            ldv<V>(mean + (long)g * C + c, mu);
+            ldv<V>(rstd + (long)g * C + c, rs);
+#pragma unroll 2
+            for (long p = pl; p < P; p += PT) {
+                float xv[V], gv[V];
+                ldv<V>(x + (base + p) * x_cs + c, xv);
+                ldv<V>(dy + (base + p) * dy_cs + c, gv);
+                if (recompute) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out((xv[v] - mu[v]) * (rs[v] * gm[v]) + bt[v], act, alpha);
+                } else if (act != SS_ACT_NONE) {
+                    float yv[V];
+                    ldv<V>(y + (base + p) * y_cs + c, yv);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out(yv[v], act, alpha);
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v) { s1[v] += gv[v]; s2[v] = fmaf(gv[v], (xv[v] - mu[v]) * rs[v], s2[v]); }
+            }
+        }
+        __syncthreads();                 // previous group's stat[] reads are done
+#pragma unroll
+        for (int v = 0; v < V; ++v) { red[2 * v][threadIdx.x] = s1[v]; red[2 * v + 1][threadIdx.x] = s2[v]; }
+        __syncthreads();
+        for (int off = PT / 2; off >= 1; off >>= 1) {
+            if (pl < off) {
+#pragma unroll
+                for (int k = 0; k < 2 * V; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off * CL];
+            }
+            __syncthreads();
+        }
+        if (pl == 0) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const double a = (double)red[2 * v][threadIdx.x], b = (double)red[2 * v + 1][threadIdx.x];
+                stat[2 * v][cl] = (float)(a / (double)P);
+                stat[2 * v + 1][cl] = (float)(b / (double)P);
+                tg[v] += a;
+                tgx[v] += b;
+            }
+        }
+        __syncthreads();
+        if (cval) {
+            float m1[V], m2[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) { m1[v] = stat[2 * v][cl]; m2[v] = stat[2 * v + 1][cl]; }
+#pragma unroll 2
+            for (long p = pl; p < P; p += PT) {
+                float xv[V], gv[V], o[V], r[V];
+                ldv<V>(x + (base + p) * x_cs + c, xv);
+                ldv<V>(dy + (base + p) * dy_cs + c, gv);
+                if (recompute) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out((xv[v] - mu[v]) * (rs[v] * gm[v]) + bt[v], act, alpha);
+                } else if (act != SS_ACT_NONE) {
+                    float yv[V];
+                    ldv<V>(y + (base + p) * y_cs + c, yv);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out(yv[v], act, alpha);
+                }
+                if (acc_dx) ldv<V>(dx + (base + p) * dx_cs + c, o);
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float xh = (xv[v] - mu[v]) * rs[v];
+                    const float dv = rs[v] * gm[v] * (gv[v] - m1[v] - xh * m2[v]);
+                    o[v] = acc_dx ? o[v] + dv : dv;
+                }
+                stv<V>(dx + (base + p) * dx_cs + c, o);
+                if (dres) {
+                    if (acc_dres) {
+                        ldv<V>(dres + (base + p) * dres_cs + c, r);
+#pragma unroll
+                        for (int v = 0; v < V; ++v) r[v] += gv[v];
+                        stv<V>(dres + (base + p) * dres_cs + c, r);
+                    } else {
+                        stv<V>(dres + (base + p) * dres_cs + c, gv);
+                    }
+                }
+            }
+        }
+    }
+    if (pl == 0 && cval) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if (dbeta) dbeta[c + v] = acc_params ? dbeta[c + v] + (float)tg[v] : (float)tg[v];
+            if (dgamma) dgamma[c + v] = acc_params ? dgamma[c + v] + (float)tgx[v] : (float)tgx[v];
+        }
+    }
+}
+
+// channel lanes of the small-tensor kernels: 8 channels per block (V = 4: 2 lanes, V = 1: 8 lanes)
+inline int small_cl(int V) { return V == 4 ? 2 : 8; }
+// One block walks a whole group's pixels for its 8 channels: worth it while that walk is short (launch latency dominates).
+inline bool norm_small(const ss_norm_desc* d) {
+    static const long max_pix = getenv("SS_NORM_FUSED_PIX") ? atol(getenv("SS_NORM_FUSED_PIX")) : 1024;   // 0 disables
+    const long P = (long)d->n * d->h * d->w / (d->groups > 0 ? d->groups : 1);
+    return P <= max_pix && P * d->groups * d->c <= NORM_SMALL_ELEMS;
+}
+
 inline bool al16(const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }
 inline unsigned apply_grid(long total) {
     long b = (total + 255) / 256;
@@ -401,6 +623,18 @@ int ss_norm_fwd(const ss_norm_desc* d, const float* x, const float* gamma, const
     const int V = pick_v(d->c, {d->x_cstride, d->y_cstride, residual ? d->res_cstride : 0},
                          {x, y, residual, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
+    if (norm_small(d)) {
+        const int CL = small_cl(V);
+        const dim3 grid((g.C + CL * V - 1) / (CL * V), g.G);
+        if (V == 4)
+            hipLaunchKernelGGL(norm_small_fwd_kernel<4>, grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, residual, d->res_cstride, y,
+                               d->y_cstride, mean, rstd, moving_mean, moving_var, momentum, d->eps, d->act, d->act_alpha, g.C, g.P, CL);
+        else
+            hipLaunchKernelGGL(norm_small_fwd_kernel<1>, grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, residual, d->res_cstride, y,
+                               d->y_cstride, mean, rstd, moving_mean, moving_var, momentum, d->eps, d->act, d->act_alpha, g.C, g.P, CL);
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+    }
     float* part = (float*)ws;
     const dim3 sgrid(g.chunks, g.cblocks, g.G);
     if (V == 4)
@@ -450,6 +684,20 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
     const int V = pick_v(d->c, {d->x_cstride, dy_cstride, dx_cstride, use_y ? d->y_cstride : 0, dres ? d->res_cstride : 0},
                          {x, dy, dx, use_y ? y : nullptr, dres, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
+    if (norm_small(d)) {
+        const int CL = small_cl(V);
+        const dim3 grid((g.C + CL * V - 1) / (CL * V));
+        if (V == 4)
+            hipLaunchKernelGGL(norm_small_bwd_kernel<4>, grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride, gamma, beta,
+                               mean, rstd, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres, dgamma, dbeta,
+                               accumulate_params, d->act, d->act_alpha, g.G, g.C, g.P, CL);
+        else
+            hipLaunchKernelGGL(norm_small_bwd_kernel<1>, grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride, gamma, beta,
+                               mean, rstd, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres, dgamma, dbeta,
+                               accumulate_params, d->act, d->act_alpha, g.G, g.C, g.P, CL);
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+    }
     float* part = (float*)ws;
     float* sums = (float*)((char*)ws + part_bytes(d));
     const dim3 sgrid(g.chunks, g.cblocks, g.G);

@@ -1,5 +1,6 @@
 """GPU parity of every C-ABI op (through the layer/tape engine) against the oracle ops on the same seeded
 inputs.  fp32 tolerances: forward |d| <= 1e-4*max|ref| (+1e-5 abs), gradients rel-L2 <= 1e-4."""
+import os
 import importlib
 
 import numpy as np
@@ -419,3 +420,17 @@ def test_conv_x6_is_fp32_grade(case):
           f"x6 y={errs[L.ALGO_X6][0]:.2e} dx={errs[L.ALGO_X6][1]:.2e}")
     for i in (0, 1):
         assert errs[L.ALGO_X6][i] <= 1.5 * errs[L.ALGO_MFMA][i] + 2e-7, errs
+
+
+def test_x6p_forced_on_small_shapes():
+    """The pre-split-plane GEMM (csrc/gemm_x6p.hip) is only chosen for launches of >= 1024 workgroups (tests/test_fullsize_gpu.py
+    runs it at the real trunk shape); SS_X6P=force sends the small Winograd cases of this file through it too: ragged M (tiles not
+    a multiple of 256) and N (channels not a multiple of 128) tile edges."""
+    import subprocess
+    import sys
+    if os.environ.get("SS_X6P") == "force":
+        pytest.skip("already the forced child run")
+    env = dict(os.environ, SS_X6P="force")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "wino or x6_trunk", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

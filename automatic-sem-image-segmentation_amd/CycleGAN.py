@@ -224,12 +224,19 @@ class CycleGanModel:
         from .engine import side_streams
         ga, gb, da, db = self.gen_a, self.gen_b, self.disc_a, self.disc_b
         cur = torch.cuda.current_stream()
-        s1, s2 = side_streams(real_a.device)
+        s1, s2, s3, s4 = side_streams(real_a.device, 4)
         n_a, n_b = real_a.n, real_b.n
+        # SS_OVERLAP_D=0: discriminator chains only after the generator backward passes (two phases); default: they start as soon
+        # as the generator FORWARD passes have produced the fakes and run beside the generator backward passes.  Nothing they
+        # write is read there: the generator backward goes through the discriminators with weight gradients switched off, all
+        # four optimizer steps are applied at the end of the step (every gradient is taken at the pre-update weights, as in the
+        # reference's single GradientTape, CycleGAN.py:500-560).
+        overlap_d = os.environ.get("SS_OVERLAP_D", "1") != "0"
 
-        # ---- generators -------------------------------------------------------------------------------
         ga.zero_grad()
         gb.zero_grad()
+        da.zero_grad()
+        db.zero_grad()
         ga.arena.zero_grad_alt()
         gb.arena.zero_grad_alt()
         for net in (ga, gb):
@@ -246,6 +253,7 @@ class CycleGanModel:
             losses.mse_const(disc_fake_b, one, 1.0, self._slot(0))
             losses.mae(real_a, cycled_a, self.lambda_cycle_b, self._slot(3))
             losses.mae(real_b, same_b, self.lambda_cycle_a * self.lambda_identity_a, self._slot(4))
+            fwd_a_done = s1.record_event()
         with torch.cuda.stream(s2):
             fake_a, same_a = LY.batch_split(tape_b, gb(Act(torch.cat([real_b.t, real_a.t], 0), requires_grad=False), True, tape_b), [n_b, n_a])
             cycled_b = ga(fake_a, True, tape_b)
@@ -255,17 +263,51 @@ class CycleGanModel:
             losses.mse_const(disc_fake_a, one, 1.0, self._slot(1))
             losses.mae(real_b, cycled_b, self.lambda_cycle_a, self._slot(2))
             losses.mae(real_a, same_a, self.lambda_cycle_b * self.lambda_identity_b, self._slot(5))
-        D.begin_backward([ga, gb, da, db])
-        with torch.cuda.stream(s1):
-            tape_a.backward()
-        ga.arena.swap_grads()
-        gb.arena.swap_grads()
-        try:
-            with torch.cuda.stream(s2):
-                tape_b.backward()
-        finally:
+            fwd_b_done = s2.record_event()
+
+        def generator_backward():
+            with torch.cuda.stream(s1):
+                tape_a.backward()
             ga.arena.swap_grads()
             gb.arena.swap_grads()
+            try:
+                with torch.cuda.stream(s2):
+                    tape_b.backward()
+            finally:
+                ga.arena.swap_grads()
+                gb.arena.swap_grads()
+
+        def discriminator_chains():
+            """Forward + backward of the two discriminator losses on s3 / s4 (entered with the fakes visible on ``cur``)."""
+            pooled_a = self.image_pool_a.query(fake_a.t)
+            pooled_b = self.image_pool_b.query(fake_b.t)
+            s3.wait_stream(cur)
+            s4.wait_stream(cur)
+            tape_da, tape_db = Tape(), Tape()
+            with torch.cuda.stream(s3):
+                disc_real_a, disc_fake_a2 = LY.batch_split(
+                    tape_da, da(Act(torch.cat([real_a.t, pooled_a], 0), requires_grad=False), True, tape_da), [n_a, pooled_a.shape[0]])
+                losses.mse_const(disc_real_a, one, 0.5, self._slot(6))
+                losses.mse_const(disc_fake_a2, zero, 0.5, self._slot(7))
+            with torch.cuda.stream(s4):
+                disc_real_b, disc_fake_b2 = LY.batch_split(
+                    tape_db, db(Act(torch.cat([real_b.t, pooled_b], 0), requires_grad=False), True, tape_db), [n_b, pooled_b.shape[0]])
+                losses.mse_const(disc_real_b, one, 0.5, self._slot(8))
+                losses.mse_const(disc_fake_b2, zero, 0.5, self._slot(9))
+            D.begin_backward([da, db])
+            with torch.cuda.stream(s3):
+                tape_da.backward()
+            with torch.cuda.stream(s4):
+                tape_db.backward()
+            return pooled_a, pooled_b      # alive until the caller has joined s3 / s4
+
+        keep = None
+        D.begin_backward([ga, gb])
+        if overlap_d:
+            cur.wait_event(fwd_a_done)
+            cur.wait_event(fwd_b_done)
+            keep = discriminator_chains()         # issued first: they are short and start while the host still issues what follows
+        generator_backward()
         cur.wait_stream(s1)
         cur.wait_stream(s2)
         ga.arena.merge_alt_grads()
@@ -278,38 +320,17 @@ class CycleGanModel:
             gen_works = []
         for net in (ga, gb):
             net.arena.defer_hooks = False
-
-        # ---- discriminators ---------------------------------------------------------------------------
-        pooled_a = self.image_pool_a.query(fake_a.t)
-        pooled_b = self.image_pool_b.query(fake_b.t)
-        da.zero_grad()
-        db.zero_grad()
-        s1.wait_stream(cur)
-        s2.wait_stream(cur)
-        tape_a, tape_b = Tape(), Tape()
-        with torch.cuda.stream(s1):
-            disc_real_a, disc_fake_a2 = LY.batch_split(
-                tape_a, da(Act(torch.cat([real_a.t, pooled_a], 0), requires_grad=False), True, tape_a), [n_a, pooled_a.shape[0]])
-            losses.mse_const(disc_real_a, one, 0.5, self._slot(6))
-            losses.mse_const(disc_fake_a2, zero, 0.5, self._slot(7))
-        with torch.cuda.stream(s2):
-            disc_real_b, disc_fake_b2 = LY.batch_split(
-                tape_b, db(Act(torch.cat([real_b.t, pooled_b], 0), requires_grad=False), True, tape_b), [n_b, pooled_b.shape[0]])
-            losses.mse_const(disc_real_b, one, 0.5, self._slot(8))
-            losses.mse_const(disc_fake_b2, zero, 0.5, self._slot(9))
-        D.begin_backward([ga, gb, da, db])
-        with torch.cuda.stream(s1):
-            tape_a.backward()
-        with torch.cuda.stream(s2):
-            tape_b.backward()
-        cur.wait_stream(s1)
-        cur.wait_stream(s2)
+        if not overlap_d:
+            keep = discriminator_chains()
+        cur.wait_stream(s3)
+        cur.wait_stream(s4)
         D.all_reduce_grads([da, db])
         self.disc_a_optimizer.apply(da, 1.0 / world)
         self.disc_b_optimizer.apply(db, 1.0 / world)
         D.finish_all_reduce_grads(gen_works)
         self.gen_a_optimizer.apply(ga, 1.0 / world)
         self.gen_b_optimizer.apply(gb, 1.0 / world)
+        del keep
         del tape_a, tape_b
         return self._update_metrics()
 

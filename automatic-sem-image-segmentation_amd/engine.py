@@ -37,13 +37,15 @@ def _stream():
 _SIDE = {}
 
 
-def side_streams(device):
-    """Two side streams per device for independent kernel chains (CycleGanModel.train_step runs the A->B->A and B->A->B chains
-    concurrently: at small per-GPU batches a single chain cannot fill 256 CUs)."""
+def side_streams(device, n=2):
+    """``n`` side streams per device for independent kernel chains (CycleGanModel.train_step runs the A->B->A and B->A->B
+    generator chains and the two discriminator chains concurrently: at small per-GPU batches a single chain cannot fill 256 CUs)."""
     key = (device.type, device.index)
-    if key not in _SIDE:
-        _SIDE[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
-    return _SIDE[key]
+    have = _SIDE.get(key, ())
+    if len(have) < n:
+        have = have + tuple(torch.cuda.Stream(device=device) for _ in range(n - len(have)))
+        _SIDE[key] = have
+    return have[:n]
 
 
 def workspace(nbytes, device):

@@ -186,29 +186,30 @@ def main():
             ach = flops_sample * tk["units"] / (tk["total_ms"] * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": "3x3 512->512 trunk conv forward = wino_weight<4> + wprep_x6 + wino_input<4> + batched gconv_x6_kernel<128> "
-                          "(36 GEMMs; fp32 operands split exactly into 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per product, fp32 "
-                          "accumulate) + wino_output; reflect pad fused in the input transform.  SS_X6=0: fp32-MFMA GEMMs instead",
+                "kernel": "3x3 512->512 trunk conv forward = wino_weight_x6<4> + wino_input<4,2> (V as 3 bf16 planes) + batched "
+                          "gemm_x6p_kernel (36 GEMMs; fp32 operands split exactly into 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per "
+                          "product, fp32 accumulate; both operands by LDS-DMA) + wino_output; reflect pad fused in the input transform.  "
+                          "SS_X6=0: fp32-MFMA GEMMs instead",
                 # ALGORITHMIC (direct-convolution) FLOPs of the op / HIP-event duration of the op (single-stream steps, see above)
                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                 "note": "peak = dense fp32 matrix peak (v_mfma_f32_32x32x2_f32), the dtype's peak; frac exceeds 1 because (a) Winograd "
                         "F(4x4,3x3) executes 4x fewer multiply-adds than the algorithmic count (38.7 of 154.6 GFLOP per launch at batch "
                         "8) and (b) the GEMMs run as 6 bf16-MFMA products per fp32 product (0.375x the fp32-MFMA cost, error below one "
-                        "fp32 rounding: tests/test_layers_gpu.py::test_conv_x6_is_fp32_grade).  The x6 GEMM itself sustains ~0.7 PFLOP/s "
-                        "of bf16 MFMA work = 0.29 of the 2.5 PFLOP/s bf16 peak, 53 % matrix-pipe utilisation at the 1.73 GHz the chip "
-                        "holds under this load (profiles/r01_pmc_trunk_fwd_x6.md)",
+                        "fp32 rounding: tests/test_layers_gpu.py::test_conv_x6_is_fp32_grade).  The x6 GEMM itself sustains 1.0 PFLOP/s "
+                        "of bf16 MFMA work = 0.40 of the 2.5 PFLOP/s bf16 peak (`executed`), at the ~1.7 GHz the chip holds under this "
+                        "load (profiles/r01_t_single_stream_kernel_stats.md, profiles/r01_pmc_trunk_fwd_x6p.md)",
                 "executed_bf16_mfma_flops_per_launch": flops / 4.0 * 6.0,
-                # the GEMM kernel alone, from the committed rocprofv3 summary of this command (profiles/r01_r_single_stream_kernel_stats.md)
-                "executed": ({"kernel": "gconv_x6_kernel<128,128>, the 36 batched GEMMs of a batch-8 op (2304 workgroups)",
-                              "bf16_mfma_flops": flops_sample * 8 / 4.0 * 6.0, "kernel_avg_ms_rocprof": 0.2795,
-                              "achieved": round(flops_sample * 8 / 4.0 * 6.0 / 0.2795e-3 / 1e15, 3), "peak": 2.5, "unit": "PFLOP/s",
-                              "frac": round(flops_sample * 8 / 4.0 * 6.0 / 0.2795e-3 / 2.5e15, 3)}
+                # the GEMM kernel alone, from the committed rocprofv3 summary of this command (profiles/r01_t_single_stream_kernel_stats.md)
+                "executed": ({"kernel": "gemm_x6p_kernel, the 36 batched GEMMs of a batch-8 op (1152 workgroups of 256x128)",
+                              "bf16_mfma_flops": flops_sample * 8 / 4.0 * 6.0, "kernel_avg_ms_rocprof": 0.2321,
+                              "achieved": round(flops_sample * 8 / 4.0 * 6.0 / 0.2321e-3 / 1e15, 3), "peak": 2.5, "unit": "PFLOP/s",
+                              "frac": round(flops_sample * 8 / 4.0 * 6.0 / 0.2321e-3 / 2.5e15, 3)}
                              if (per == 8 and S == 512 and F == 64 and os.environ.get("SS_X6", "1") != "0") else None),
                 "executed_mfma_flops_per_launch": flops / 4.0,
                 # PMC cannot be sampled from inside this process: rocprofv3 pass on the direct (non-Winograd) kernel of this shape
                 # PMC cannot be sampled from inside this process: committed rocprofv3 passes on this op/shape at batch 8
-                # (profiles/r01_pmc_trunk_fwd_x6.md): sum over the op's 5 kernels of 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
-                "traffic": (2 * (4638 + 18461 + 49921 + 117257 + 73889) + (36864 + 55296 + 147456 + 147456 + 65536)) * 1024.0 if (per == 8 and S == 512 and F == 64) else None,
+                # (profiles/r01_pmc_trunk_fwd_x6p.md): sum over the op's 4 kernels of 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
+                "traffic": (2 * (39819 + 50114 + 153735 + 73891) + (55296 + 221184 + 147456 + 65536)) * 1024.0 if (per == 8 and S == 512 and F == 64) else None,
                 "traffic_unit": "bytes per batch-8 op launch (PMC passes on tools/bench_kernels.py trunk_fwd)", "algorithmic_bytes": 4.0 * (2 * per * (S // 8) ** 2 * 8 * F + 9 * (8 * F) ** 2),          # of a batch-`per` launch
                 "winograd_algorithmic_bytes": 4.0 * ((1 + 4 * 2.25 + 1) * per * (S // 8) ** 2 * 8 * F + (9 + 36 + 36) * (8 * F) ** 2),
                 "launches_timed": tk["launches"], "avg_launch_ms": round(tk["avg_ms"], 4), "flops_per_launch": flops}

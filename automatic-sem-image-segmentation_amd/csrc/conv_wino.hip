@@ -257,57 +257,72 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 }
 
 // Same transform, emitted directly as the x6 GEMM's B operand: three K-contiguous bf16 planes
-// planes[pl][xi][no (padded to Npad, zero rows)][kr].  One thread = two consecutive kr of one no (a packed bf16 pair per store,
-// consecutive threads -> consecutive kr: coalesced plane writes; the 9 x 2 weight reads are strided for flip = 0, the whole
-// kernel tensor is 9 MB and stays in L2).
+// planes[pl][xi][no (padded to Npad, zero rows)][kr].  A block owns a 32 (kr) x 32 (no) tile of the 3x3 kernel: the 9 taps are
+// staged in LDS with loads that are contiguous in memory whichever index that is (co: `no` for flip = 0, `kr` for flip = 1 --
+// a thread-per-output version read the 9 MiB kernel tensor at 2 KB strides: 8x over-fetch, 20 us), then one thread = two
+// consecutive kr of one no: a packed bf16 pair per store, consecutive threads -> consecutive kr.
 template <int R>
 __global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __restrict__ w, int Cin, int Cout, int flip, int Npad,
                                                              unsigned short* __restrict__ planes) {
-    constexpr int P = R + 2;
+    constexpr int P = R + 2, HP = P / 2;
+    __shared__ float tl[9][32][17];        // [logical tap a*3+b][kr][no]
     const int KR = flip ? Cout : Cin, NO = flip ? Cin : Cout;
     const int K2 = KR / 2;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long)K2 * Npad) return;
-    const int k2 = (int)(e % K2), no = (int)(e / K2);
+    const int kr0 = blockIdx.x * 32, no0 = blockIdx.y * 16;
+    const int i0 = blockIdx.z * HP;        // this block's rows of the (R+2) x (R+2) transform
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int a = t / 3, b2 = t % 3;
+        const int kh = flip ? 2 - a : a, kw = flip ? 2 - b2 : b2;
+        const float* wt = w + (long)(kh * 3 + kw) * Cin * Cout;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // the memory-contiguous index (co) goes to the fast lanes: flip = 0: (kr, no) = (ci, co);  flip = 1: (kr, no) = (co, ci)
+            const int e = tid + 256 * i;
+            const int krl = flip ? (e & 31) : (e >> 4), nol = flip ? (e >> 5) : (e & 15);
+            const int kr = kr0 + krl, no = no0 + nol;
+            float v = 0.f;
+            if (no < NO) {
+                const int ci = flip ? no : kr, co = flip ? kr : no;
+                v = wt[(long)ci * Cout + co];
+            }
+            tl[t][krl][nol] = v;
+        }
+    }
+    __syncthreads();
+    const int k2l = tid & 15, nol = tid >> 4;
+    const int no = no0 + nol;
     const long plane_u32 = (long)P * P * Npad * KR / 2;     // u32 (bf16 pair) stride between the three planes
     const long xs2 = (long)Npad * KR / 2;                   // ... between transform positions
-    unsigned int* dst = (unsigned int*)planes + (long)no * K2 + k2;
-    if (no >= NO) {
-#pragma unroll
-        for (int xi = 0; xi < P * P; ++xi) {
-            dst[xi * xs2] = 0u;
-            dst[xi * xs2 + plane_u32] = 0u;
-            dst[xi * xs2 + 2 * plane_u32] = 0u;
-        }
-        return;
-    }
-    float u2[2][P][P];
+    float u2[2][HP][P];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        const int kr = 2 * k2 + half;
         float t[P][3];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
+        for (int b2 = 0; b2 < 3; ++b2) {
             float g[3], u[P];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const int kh = flip ? 2 - a : a, kw = flip ? 2 - b : b;
-                const int ci = flip ? no : kr, co = flip ? kr : no;
-                g[a] = w[((long)(kh * 3 + kw) * Cin + ci) * Cout + co];
-            }
+            for (int a = 0; a < 3; ++a) g[a] = tl[a * 3 + b2][2 * k2l + half][nol];
             t_w<R>(g, u);
 #pragma unroll
-            for (int i = 0; i < P; ++i) t[i][b] = u[i];
+            for (int i = 0; i < P; ++i) t[i][b2] = u[i];
         }
 #pragma unroll
-        for (int i = 0; i < P; ++i) t_w<R>(t[i], u2[half][i]);
-    }
+        for (int i = 0; i < HP; ++i) {
+            float row[3];
 #pragma unroll
-    for (int i = 0; i < P; ++i)
+            for (int b2 = 0; b2 < 3; ++b2) row[b2] = i0 ? t[HP + i][b2] : t[i][b2];
+            t_w<R>(row, u2[half][i]);
+        }
+    }
+    unsigned int* dst = (unsigned int*)planes + (long)no * K2 + kr0 / 2 + k2l + (long)(i0 * P) * xs2;
+#pragma unroll
+    for (int i = 0; i < HP; ++i)
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             unsigned int h, m, l;
-            ss_split3x2(f32x2{u2[0][i][j], u2[1][i][j]}, h, m, l);
+            ss_split3x2(f32x2{u2[0][i][j], u2[1][i][j]}, h, m, l);      // rows no >= NO were staged as zeros
             const long o = (long)(i * P + j) * xs2;
             dst[o] = h;
             dst[o + plane_u32] = m;
@@ -482,7 +497,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         const int Npad = ss_x6_npad(q.cout);
         Mx = (float*)((char*)V + ss_align_up((size_t)3 * XI * Mpad * q.cin * 2, 256));
         unsigned short* planes = (unsigned short*)((char*)Mx + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
-        hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(g256((long)(q.cin / 2) * Npad)), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
+        hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL((wino_input_kernel<R, 2>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
                            TH, TW, q.pt, q.pl, q.reflect, V, Mpad);
@@ -516,7 +531,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     if (q.x6 && ss_gconv_x6_ok(g)) {     // fp32-exact GEMMs on the bf16 matrix cores: the weight transform emits the B planes
         unsigned short* planes = (unsigned short*)((char*)Mx + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
         const int Npad = ss_x6_npad(q.cout);
-        hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(g256((long)(q.cin / 2) * Npad)), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
+        hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
         SS_LAUNCH_CHECK();
         rc = ss_launch_gconv_x6(g, planes, s);
     } else {

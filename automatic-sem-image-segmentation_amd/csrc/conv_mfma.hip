@@ -85,7 +85,47 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
     const int nchunks = (K + C::BK - 1) / C::BK;
 
     // output pixel table (linear NHW index of the destination pixel, -1 = masked)
-    if (tid < BM) {
+    if (FAST) {
+        // 32-bit pixel decode (the launcher guarantees M < 2^31), ONE division pair per tile row, kept in LDS; the gather-offset
+        // table below divides nothing.  (The 64-bit `m % OWc`, `r / OHc` per table entry -- emulated, ~150 instructions each --
+        // were most of a workgroup's life for the MultiResUNet's full-resolution layers, whose K loop is 1-8 steps.)
+        int* rowc = offtab + BM * p.ntaps;      // [3][BM]: image index, base input y, base input x of the row's pixel
+        if (tid < BM) {
+            const unsigned m = (unsigned)m0 + (unsigned)tid;
+            int v = -1, rn = -1, ry = 0, rx = 0;
+            if (m < (unsigned)M) {
+                const unsigned r = m / (unsigned)p.OWc;
+                const int xc = (int)(m - r * (unsigned)p.OWc);
+                const unsigned n = r / (unsigned)p.OHc;
+                const int yc = (int)(r - n * (unsigned)p.OHc);
+                const int oy = yc * p.out_s + p.out_oy, ox = xc * p.out_s + p.out_ox;
+                if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) v = ((int)n * p.OH + oy) * p.OW + ox;
+                rn = (int)n;
+                ry = yc * p.in_s + p.in_oy;
+                rx = xc * p.in_s + p.in_ox;
+            }
+            pixtab[tid] = v;
+            rowc[tid] = rn;
+            rowc[BM + tid] = ry;
+            rowc[2 * BM + tid] = rx;
+        }
+        __syncthreads();
+        {
+            constexpr int TSTEP = NT / BM;
+            const int row = tid % BM;
+            const int rn = rowc[row], ry = rowc[BM + row], rx = rowc[2 * BM + row];
+            for (int t = tid / BM; t < p.ntaps; t += TSTEP) {
+                int off = -1;
+                if (rn >= 0) {
+                    const int iy = ss_map_index(ry + p.taps[t].dy, p.IH, p.reflect);
+                    const int ix = ss_map_index(rx + p.taps[t].dx, p.IW, p.reflect);
+                    if (iy >= 0 && ix >= 0) off = ((rn * p.IH + iy) * p.IW + ix) * p.in_cs;
+                }
+                offtab[row * p.ntaps + t] = off;
+            }
+        }
+        __syncthreads();
+    } else if (tid < BM) {
         const long m = m0 + tid;
         int v = -1;
         if (m < M) {
@@ -98,24 +138,6 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
         }
         pixtab[tid] = v;
     }
-    if (FAST) {
-        for (int idx = tid; idx < BM * p.ntaps; idx += NT) {
-            const int row = idx / p.ntaps, t = idx - row * p.ntaps;
-            const long m = m0 + row;
-            int off = -1;
-            if (m < M) {
-                const int xc = (int)(m % p.OWc);
-                const long r = m / p.OWc;
-                const int yc = (int)(r % p.OHc);
-                const int n = (int)(r / p.OHc);
-                const int iy = ss_map_index(yc * p.in_s + p.in_oy + p.taps[t].dy, p.IH, p.reflect);
-                const int ix = ss_map_index(xc * p.in_s + p.in_ox + p.taps[t].dx, p.IW, p.reflect);
-                if (iy >= 0 && ix >= 0) off = ((n * p.IH + iy) * p.IW + ix) * p.in_cs;
-            }
-            offtab[idx] = off;
-        }
-        __syncthreads();
-    }
 
     // per-thread A rows: row = (tid>>3) + 32*j, float4 column c4a = tid&7
     const int c4a = tid & 7;
@@ -123,7 +145,7 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
 #pragma unroll
     for (int j = 0; j < C::A_UNITS; ++j) {
         const long m = m0 + (tid >> 3) + C::A_ROWS * j;
-        if (m < M) {
+        if (!FAST && m < M) {
             const int xc = (int)(m % p.OWc);
             const long r = m / p.OWc;
             const int yc = (int)(r % p.OHc);
@@ -384,7 +406,7 @@ static int launch_gconv(const GConvParams& p, int vecA, int vecB, hipStream_t s)
         (void)hipFuncSetAttribute((const void*)gconv_mfma_kernel<BM, BN, FAST, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const size_t smem = C::smem_gconv + (FAST ? (size_t)BM * p.ntaps * sizeof(int) : 0);
+    const size_t smem = C::smem_gconv + (FAST ? (size_t)BM * (p.ntaps + 3) * sizeof(int) : 0);
     hipLaunchKernelGGL((gconv_mfma_kernel<BM, BN, FAST, NT>), grid, dim3(NT), smem, s, p, vecA, vecB);
     SS_LAUNCH_CHECK();
     return SS_OK;
@@ -398,7 +420,7 @@ int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
     for (int t = 0; t < p.ntaps && vecB; ++t) vecB = (p.taps[t].woff % 4 == 0);
     const long in_elems = (long)p.N * p.IH * p.IW * p.in_cs;
     const bool uniform = vecA && vecB && (p.Cin % 32 == 0) && (p.Cout >= 4);      // aligned float4 units, one tap per K step
-    const bool fast = p.ntaps >= 1 && in_elems < (1L << 31) && !ss_tuning().no_fast;
+    const bool fast = p.ntaps >= 1 && in_elems < (1L << 31) && M < (1L << 31) && !ss_tuning().no_fast;
     if (fast && !uniform) vecA = 0;                                                // -> padded-K loaders
     // tile choice: the largest tile that still gives every CU ~2 workgroups (256 CUs); small batches need small tiles
     auto nblocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * (p.nbatch > 1 ? p.nbatch : 1); };

@@ -62,33 +62,40 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const int n0 = (tile % gridN) * BN;
     const int nchunks = Ktot / XK;
 
-    if (tid < BM) {
-        const long m = m0 + tid;
-        int v = -1;
-        if (m < M) {
-            const int xc = (int)(m % p.OWc);
-            const long r = m / p.OWc;
-            const int yc = (int)(r % p.OHc);
-            const int n = (int)(r / p.OHc);
-            const int oy = yc * p.out_s + p.out_oy, ox = xc * p.out_s + p.out_ox;
-            if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) v = (n * p.OH + oy) * p.OW + ox;
+    {   // 32-bit pixel decode (ss_gconv_x6_ok: M < 2^31), one division pair per tile row; the offset table divides nothing
+        int* rowc = offtab + BM * p.ntaps;      // [3][BM]
+        if (tid < BM) {
+            const unsigned m = (unsigned)m0 + (unsigned)tid;
+            int v = -1, rn = -1, ry = 0, rx = 0;
+            if (m < (unsigned)M) {
+                const unsigned r = m / (unsigned)p.OWc;
+                const int xc = (int)(m - r * (unsigned)p.OWc);
+                const unsigned n = r / (unsigned)p.OHc;
+                const int yc = (int)(r - n * (unsigned)p.OHc);
+                const int oy = yc * p.out_s + p.out_oy, ox = xc * p.out_s + p.out_ox;
+                if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) v = ((int)n * p.OH + oy) * p.OW + ox;
+                rn = (int)n;
+                ry = yc * p.in_s + p.in_oy;
+                rx = xc * p.in_s + p.in_ox;
+            }
+            pixtab[tid] = v;
+            rowc[tid] = rn;
+            rowc[BM + tid] = ry;
+            rowc[2 * BM + tid] = rx;
         }
-        pixtab[tid] = v;
-    }
-    for (int idx = tid; idx < BM * p.ntaps; idx += 256) {
-        const int row = idx / p.ntaps, t = idx - row * p.ntaps;
-        const long m = m0 + row;
-        int off = -1;
-        if (m < M) {
-            const int xc = (int)(m % p.OWc);
-            const long r = m / p.OWc;
-            const int yc = (int)(r % p.OHc);
-            const int n = (int)(r / p.OHc);
-            const int iy = ss_map_index(yc * p.in_s + p.in_oy + p.taps[t].dy, p.IH, p.reflect);
-            const int ix = ss_map_index(xc * p.in_s + p.in_ox + p.taps[t].dx, p.IW, p.reflect);
-            if (iy >= 0 && ix >= 0) off = ((n * p.IH + iy) * p.IW + ix) * p.in_cs;
+        __syncthreads();
+        constexpr int TSTEP = 256 / BM;
+        const int row = tid % BM;
+        const int rn = rowc[row], ry = rowc[BM + row], rx = rowc[2 * BM + row];
+        for (int t = tid / BM; t < p.ntaps; t += TSTEP) {
+            int off = -1;
+            if (rn >= 0) {
+                const int iy = ss_map_index(ry + p.taps[t].dy, p.IH, p.reflect);
+                const int ix = ss_map_index(rx + p.taps[t].dx, p.IW, p.reflect);
+                if (iy >= 0 && ix >= 0) off = ((rn * p.IH + iy) * p.IW + ix) * p.in_cs;
+            }
+            offtab[row * p.ntaps + t] = off;
         }
-        offtab[idx] = off;
     }
     __syncthreads();
 
@@ -429,7 +436,7 @@ int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_ele
     const long M = (long)p.N * p.OHc * p.OWc;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     dim3 grid((unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN) * nb));
-    const size_t smem = (size_t)3 * (BM + BN) * XLD * sizeof(unsigned short) + (size_t)BM * sizeof(int) * (1 + p.ntaps);
+    const size_t smem = (size_t)3 * (BM + BN) * XLD * sizeof(unsigned short) + (size_t)BM * sizeof(int) * (4 + p.ntaps);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gconv_x6_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -447,7 +454,7 @@ int ss_x6_npad(int cout) { return (cout + 127) / 128 * 128; }
 bool ss_gconv_x6_ok(const GConvParams& p) {
     const long in_elems = (long)p.N * p.IH * p.IW * p.in_cs;       // per batched problem: the LDS offset table holds 32-bit element offsets
     return p.ntaps >= 1 && p.Cin % 32 == 0 && p.in_cs % 4 == 0 && (((uintptr_t)p.in) & 15) == 0 && p.Cout >= 32 &&
-           in_elems < (1L << 31) && (p.nbatch <= 1 || (p.in_bs % 4 == 0));
+           in_elems < (1L << 31) && (long)p.N * p.OHc * p.OWc < (1L << 31) && (p.nbatch <= 1 || (p.in_bs % 4 == 0));
 }
 
 size_t ss_gconv_x6_planes_bytes(const GConvParams& p) {

@@ -480,7 +480,7 @@ int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipSt
     const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * p.Cin;
     const long plane_elems = (long)nb * Npad * Ktot;
     // tile choice: the largest tile that still yields >= ~200 workgroups (small grids at per-GPU batch 1 want more, smaller ones)
-    static const long want = getenv("SS_X6_WANT") ? atol(getenv("SS_X6_WANT")) : 200;
+    const long want = 200;      // swept at per-GPU batch 1 / 2 (200 / 600 / 1200): 200 is the fastest
     auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * nb; };
     if (p.Cout > 64 && nblk(128, 128) >= want) return launch_x6<128, 128>(p, planes, plane_elems, Npad, Ktot, s);
     if (nblk(128, 64) >= want) return launch_x6<128, 64>(p, planes, plane_elems, Npad, Ktot, s);

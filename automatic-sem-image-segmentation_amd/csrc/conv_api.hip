@@ -36,17 +36,21 @@ __global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __res
 }
 
 // dx[n,iy,ix,c] (+)= sum over the padded positions that reflect onto (iy,ix) of dpad[n,py,px,c]
+// One thread = V (4 or 1) consecutive channels of one dx pixel; 32-bit index arithmetic (the launcher checks the element count).
+template <int V>
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ dpad, float* __restrict__ dx,
                                                            int N, int IH, int IW, int C, int dx_cs,
                                                            int pt, int pl, int PH, int PW, int accumulate) {
-    const long total = (long)N * IH * IW * C;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned CV = (unsigned)C / V;
+    const unsigned total = (unsigned)N * IH * IW * CV;
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    const int c = (int)(e % C);
-    long r = e / C;
-    const int ix = (int)(r % IW); r /= IW;
-    const int iy = (int)(r % IH);
-    const int n = (int)(r / IH);
+    unsigned r = e / CV;
+    const int c = (int)(e - r * CV) * V;
+    const unsigned r2 = r / (unsigned)IW;
+    const int ix = (int)(r - r2 * IW);
+    const int n = (int)(r2 / (unsigned)IH);
+    const int iy = (int)(r2 - (unsigned)n * IH);
     int ys[3], xs[3], ny = 0, nx = 0;
     ys[ny++] = iy + pt;
     if (iy >= 1 && pt - iy >= 0) ys[ny++] = pt - iy;
@@ -54,11 +58,38 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
     xs[nx++] = ix + pl;
     if (ix >= 1 && pl - ix >= 0) xs[nx++] = pl - ix;
     { const int px = pl + 2 * (IW - 1) - ix; if (ix <= IW - 2 && px < PW) xs[nx++] = px; }
-    float acc = 0.f;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
     for (int a = 0; a < ny; ++a)
-        for (int b = 0; b < nx; ++b) acc += dpad[((long)(n * PH + ys[a]) * PW + xs[b]) * C + c];
+        for (int b = 0; b < nx; ++b) {
+            const float* q = dpad + ((long)(n * PH + ys[a]) * PW + xs[b]) * C + c;
+            if (V == 4) {
+                const f32x4 t = *(const f32x4*)q;
+                acc[0] += t[0]; acc[1 % V] += t[1]; acc[2 % V] += t[2]; acc[3 % V] += t[3];
+            } else {
+                acc[0] += *q;
+            }
+        }
     float* o = dx + ((long)(n * IH + iy) * IW + ix) * dx_cs + c;
-    *o = accumulate ? (*o + acc) : acc;
+    if (V == 4) {
+        f32x4 t = {acc[0], acc[1 % V], acc[2 % V], acc[3 % V]};
+        if (accumulate) t += *(const f32x4*)o;
+        *(f32x4*)o = t;
+    } else {
+        *o = accumulate ? (*o + acc[0]) : acc[0];
+    }
+}
+
+inline int launch_reflect_fold(const float* dpad, float* dx, int N, int IH, int IW, int C, int dx_cs, int pt, int pl, int PH, int PW,
+                               int accumulate, hipStream_t s) {
+    const bool v4 = C % 4 == 0 && dx_cs % 4 == 0 && (((uintptr_t)dpad | (uintptr_t)dx) & 15) == 0;
+    const long total = (long)N * IH * IW * (C / (v4 ? 4 : 1));
+    if (total >= (1L << 32)) return SS_ERR_UNSUPPORTED;      // 32-bit thread index
+    if (v4) hipLaunchKernelGGL(reflect_fold_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpad, dx, N, IH, IW, C, dx_cs, pt, pl, PH, PW, accumulate);
+    else hipLaunchKernelGGL(reflect_fold_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpad, dx, N, IH, IW, C, dx_cs, pt, pl, PH, PW, accumulate);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
 }
 
 // column sums of a [rows][C] view: stage 1 partials[chunk][c], stage 2 final
@@ -347,11 +378,7 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
             float* dpad = (float*)((char*)ws + bwd_data_wt_bytes(c));
             int rc = ss_wino_conv_fwd(q, dy, w, c.cin, c.cout, 1, nullptr, dpad, SS_ACT_NONE, 0.f, 0, gws, gws_bytes, s);
             if (rc != SS_OK) return rc;
-            const long total = (long)c.n * c.ih * c.iw * c.cin;
-            hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpad, dx,
-                               c.n, c.ih, c.iw, c.cin, c.in_cs, c.pt, c.pl, c.oh + 2, c.ow + 2, accumulate);
-            SS_LAUNCH_CHECK();
-            return SS_OK;
+            return launch_reflect_fold(dpad, dx, c.n, c.ih, c.iw, c.cin, c.in_cs, c.pt, c.pl, c.oh + 2, c.ow + 2, accumulate, s);
         }
     }
     hipLaunchKernelGGL(transpose_last2_kernel, dim3((c.cout + 31) / 32, (c.cin + 31) / 32, T), dim3(256), 0, s, w, wt, c.cin, c.cout);
@@ -375,11 +402,7 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
             }
         int rc = run_gconv(algo, p, gws, gws_bytes, s);
         if (rc != SS_OK) return rc;
-        const long total = (long)c.n * c.ih * c.iw * c.cin;
-        hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpad, dx,
-                           c.n, c.ih, c.iw, c.cin, c.in_cs, c.pt, c.pl, PH, PW, accumulate);
-        SS_LAUNCH_CHECK();
-        return SS_OK;
+        return launch_reflect_fold(dpad, dx, c.n, c.ih, c.iw, c.cin, c.in_cs, c.pt, c.pl, PH, PW, accumulate, s);
     }
 
     p.out = dx; p.OH = c.ih; p.OW = c.iw; p.out_cs = c.in_cs; p.accumulate = accumulate;

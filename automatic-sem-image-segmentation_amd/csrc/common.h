@@ -152,6 +152,11 @@ bool ss_conv_out1_ok(const GConvParams& p);
 int ss_launch_conv_out1(const GConvParams& p, hipStream_t s);
 bool ss_conv_in1_ok(const GConvParams& p);
 int ss_launch_conv_in1(const GConvParams& p, hipStream_t s);
+// weight gradients of the same layers: mode 0: Cout == 1 (X = x, S = dy), mode 1: Cin == 1 (X = dy, S = x)
+bool ss_wgrad_c1_ok(int n, int xh, int xw, int C, int kh, int kw);
+size_t ss_wgrad_c1_ws(int n, int xh, int xw, int C, int kh, int kw);
+int ss_launch_wgrad_c1(int mode, const float* X, int X_cs, int C, int n, int xh, int xw, const float* S, int S_cs, int sh, int sw,
+                       int kh, int kw, int pt, int pl, int reflect, float* dw, int accumulate, void* ws, hipStream_t s);
 
 // fp32-exact contraction on the bf16 matrix cores (conv_mfma_x6.hip): three bf16 pieces per operand, six products
 bool ss_gconv_x6_ok(const GConvParams& p);                  // shape / alignment eligibility

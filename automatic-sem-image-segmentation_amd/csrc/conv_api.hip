@@ -178,41 +178,52 @@ __global__ __launch_bounds__(256) void tapsum_kernel(GConvParams p) {
 }
 
 // U[n,qy,qx,t] = sum over grid positions g whose tap t reads input position q (through the pad map) of b[g]
+// One thread = 4 consecutive taps of one pixel (one 16-byte store); 32-bit index arithmetic (the launcher checks the range):
+// the per-element 64-bit div/mod chain of the first version made this streaming kernel VALU-bound (667 us for 436 MB).
 __global__ __launch_bounds__(256) void tapscatter_kernel(WGradParams p, float* __restrict__ U, int tcs) {
-    const long total = (long)p.N * p.AH * p.AW * tcs;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned T4 = (unsigned)tcs / 4;
+    const unsigned total = (unsigned)p.N * p.AH * p.AW * T4;
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    const int t = (int)(e % tcs);
-    long r = e / tcs;
-    const int qx = (int)(r % p.AW); r /= p.AW;
-    const int qy = (int)(r % p.AH);
-    const int n = (int)(r / p.AH);
-    float acc = 0.f;
-    if (t < p.ntaps) {
-        int cy[3], cx[3], ny = 0, nx = 0;
-        cy[ny++] = qy;
-        cx[nx++] = qx;
-        if (p.reflect) {
-            if (qy >= 1) cy[ny++] = -qy;
-            if (qy <= p.AH - 2) cy[ny++] = 2 * (p.AH - 1) - qy;
-            if (qx >= 1) cx[nx++] = -qx;
-            if (qx <= p.AW - 2) cx[nx++] = 2 * (p.AW - 1) - qx;
-        }
+    unsigned r = e / T4;
+    const int t0 = (int)(e - r * T4) * 4;
+    const unsigned r2 = r / (unsigned)p.AW;
+    const int qx = (int)(r - r2 * p.AW);
+    const int n = (int)(r2 / (unsigned)p.AH);
+    const int qy = (int)(r2 - (unsigned)n * p.AH);
+    int cy[3], cx[3], ny = 0, nx = 0;
+    cy[ny++] = qy;
+    cx[nx++] = qx;
+    if (p.reflect) {
+        if (qy >= 1) cy[ny++] = -qy;
+        if (qy <= p.AH - 2) cy[ny++] = 2 * (p.AH - 1) - qy;
+        if (qx >= 1) cx[nx++] = -qx;
+        if (qx <= p.AW - 2) cx[nx++] = 2 * (p.AW - 1) - qx;
+    }
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = t0 + k;
+        if (t >= p.ntaps) continue;
+        float acc = 0.f;
         for (int a = 0; a < ny; ++a) {
             const int ty = cy[a] - p.a_oy - p.taps[t].dy;
-            if (ty < 0 || ty % p.a_s) continue;
-            const int gy = ty / p.a_s;
+            if (ty < 0) continue;
+            int gy = ty;
+            if (p.a_s != 1) { if (ty % p.a_s) continue; gy = ty / p.a_s; }
             if (gy >= p.GH) continue;
             for (int b = 0; b < nx; ++b) {
                 const int tx = cx[b] - p.a_ox - p.taps[t].dx;
-                if (tx < 0 || tx % p.a_s) continue;
-                const int gx = tx / p.a_s;
+                if (tx < 0) continue;
+                int gx = tx;
+                if (p.a_s != 1) { if (tx % p.a_s) continue; gx = tx / p.a_s; }
                 if (gx >= p.GW) continue;
                 acc += p.b[((long)(n * p.GH + gy) * p.GW + gx) * p.b_cs];
             }
         }
+        out[k] = acc;
     }
-    U[e] = acc;
+    *(f32x4*)(U + (long)e * 4) = out;
 }
 
 inline int round4(int v) { return (v + 3) / 4 * 4; }
@@ -434,6 +445,14 @@ bool wgrad_two_stage(const ConvProb& c, int algo) {
     return algo != SS_ALGO_DIRECT && c.cout == 1 && c.kh * c.kw >= 4 && c.cin >= 16;
 }
 
+// LDS-tiled weight-gradient kernel for stride-1 convs with one channel on one side (conv_c1.hip): 0: Cout == 1, 1: Cin == 1, -1: no
+int wgrad_c1_mode(const ConvProb& c, int algo) {
+    if (algo == SS_ALGO_DIRECT || c.s != 1 || c.ih < 2 * c.pt + 4 || c.iw < 2 * c.pl + 4) return -1;
+    if (c.cout == 1 && c.cin > 1 && ss_wgrad_c1_ok(c.n, c.ih, c.iw, c.cin, c.kh, c.kw)) return 0;
+    if (c.cin == 1 && c.cout > 1 && ss_wgrad_c1_ok(c.n, c.oh, c.ow, c.cout, c.kh, c.kw)) return 1;
+    return -1;
+}
+
 size_t bwd_weight_ws(const ConvProb& c) {
     int pps;
     const long P = (long)c.n * c.oh * c.ow;
@@ -451,6 +470,11 @@ size_t bwd_weight_ws(const ConvProb& c) {
         WinoProb q;
         if (wino_fwd_prob(c, SS_ALGO_AUTO, &q)) { const size_t wq = ss_wino_wgrad_ws(q); if (wq > b) b = wq; }
     }
+    if (wgrad_c1_mode(c, SS_ALGO_AUTO) >= 0) {
+        const bool m0 = wgrad_c1_mode(c, SS_ALGO_AUTO) == 0;
+        const size_t wq = m0 ? ss_wgrad_c1_ws(c.n, c.ih, c.iw, c.cin, c.kh, c.kw) : ss_wgrad_c1_ws(c.n, c.oh, c.ow, c.cout, c.kh, c.kw);
+        if (wq > b) b = wq;
+    }
     b += ss_align_up((size_t)COLSUM_CHUNKS * (c.cout > c.cin ? c.cout : c.cin) * sizeof(float), 256);
     return b;
 }
@@ -462,6 +486,15 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
     {
         WinoProb q;
         if (wino_fwd_prob(c, algo, &q)) return ss_wino_conv_wgrad(q, x, dy, dw, accumulate, ws, ws_bytes, s);
+    }
+    {
+        const int m = wgrad_c1_mode(c, algo);
+        if (m == 0)
+            return ss_launch_wgrad_c1(0, x, c.in_cs, c.cin, c.n, c.ih, c.iw, dy, c.out_cs, c.oh, c.ow, c.kh, c.kw, c.pt, c.pl, c.reflect,
+                                      dw, accumulate, ws, s);
+        if (m == 1)
+            return ss_launch_wgrad_c1(1, dy, c.out_cs, c.cout, c.n, c.oh, c.ow, x, c.in_cs, c.ih, c.iw, c.kh, c.kw, c.pt, c.pl, c.reflect,
+                                      dw, accumulate, ws, s);
     }
     WGradParams p{};
     p.x6 = x6_wanted(algo);
@@ -485,7 +518,8 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
         const int tcs = round4(p.ntaps);
         const long Q = (long)c.n * c.ih * c.iw;
         float* U = (float*)ws;
-        hipLaunchKernelGGL(tapscatter_kernel, dim3((unsigned)((Q * tcs + 255) / 256)), dim3(256), 0, s, p, U, tcs);
+        if (Q * (tcs / 4) >= (1L << 32)) return SS_ERR_UNSUPPORTED;      // 32-bit thread index
+        hipLaunchKernelGGL(tapscatter_kernel, dim3((unsigned)((Q * (tcs / 4) + 255) / 256)), dim3(256), 0, s, p, U, tcs);
         SS_LAUNCH_CHECK();
         WGradParams q{};
         q.a = U; q.b = x; q.part = (float*)((char*)ws + ss_align_up((size_t)Q * tcs * sizeof(float), 256));

@@ -222,6 +222,200 @@ int launch_in1(const GConvParams& p, const C1Box& box, hipStream_t s) {
     return SS_OK;
 }
 
+// ---- weight gradient of the same layers -------------------------------------------------------------------------------------------
+//   dw[(a,b)][c] = sum over the pixels of the C-channel tensor X of  X[n,y,x,c] * U[(n,y,x)][(a,b)]
+//   MODE 0 (Cout == 1, the 7x7 head):  X = x (C = Cin), U[q][(a,b)] = sum over the padded positions that reflect onto q of
+//           dy[pos - tap]  (the tap scatter of the one-channel gradient: the reflection is folded onto the one-channel side);
+//   MODE 1 (Cin == 1, the 7x7 stem):   X = dy (C = Cout), U[p][(a,b)] = x[map(py + a - pt), map(px + b - pl)].
+// The generic path wrote U for all pixels to HBM (436 MB, 0.4-0.7 ms) and ran a tall-skinny split-K GEMM over U and X (0.8 ms).
+// Here U never leaves the CU: a persistent block walks 4 x 64 pixel tiles, stages the one-channel halo in LDS, builds the
+// tile's U[256 pixels][64 taps (zero padded)] in LDS from it and contracts it with X on the fp32 matrix cores,
+//        D[c][t] += sum_k X[k][c] * U[k][t]        (v_mfma_f32_32x32x2_f32, exact fp32: one 32 x 32 tile of D per wave)
+// Both operands are read in their NATURAL layouts with 4-byte accesses (lane = channel for X straight from global memory, 16
+// loads in flight per lane; lane = tap for U from LDS): at 64 cycles per MFMA there is nothing to gain from wider fragments.
+// Deterministic: one partial per block, summed in block order by the reduce kernel.
+struct C1WParams {
+    const float* X; const float* S; float* part;
+    int N, XH, XW, C, X_cs;        // the C-channel tensor and its pixel grid
+    int SH, SW, S_cs;              // the one-channel tensor
+    int kh, kw, pt, pl, reflect;
+    int tiles_y, tiles_x, ntiles;
+};
+constexpr int C1W_TH = 4, C1W_TW = 64, C1W_PIX = C1W_TH * C1W_TW, C1W_T = 64;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(C1WParams p) {
+    extern __shared__ __attribute__((aligned(16))) float c1w_lds[];
+    float* const us = c1w_lds;                       // U tile [C1W_PIX][C1W_T]
+    float* const hs = c1w_lds + C1W_PIX * C1W_T;     // one-channel halo [TH + kh - 1][TW + kw - 1]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int c0 = blockIdx.y * 64 + (wave & 1) * 32;        // this wave's 32 channels
+    const int t0 = (wave >> 1) * 32;                         // ... and 32 taps
+    const int HR = C1W_TH + p.kh - 1, HW = C1W_TW + p.kw - 1;
+    // the U entries this thread builds: tap tid & 63 of pixels (tid >> 6) + 4j
+    const int ut = tid & 63;
+    const int ua = ut / p.kw, ub = ut - ua * p.kw;
+    const bool utap = ut < p.kh * p.kw;
+    const int cc = c0 + l31 < p.C ? c0 + l31 : p.C - 1;      // clamped channel (rows >= C are not written)
+    // B operand straight from the halo (tiles that need no folded / masked U): U[pixel][t] = halo[tapoff(t) + ry * HW + rx]
+    int tapoff = 0;
+    {
+        const int bt = t0 + l31;
+        if (bt < p.kh * p.kw) {
+            const int ba = bt / p.kw, bb = bt - ba * p.kw;
+            tapoff = MODE == 0 ? (p.kh - 1 - ba) * HW + (p.kw - 1 - bb) : ba * HW + bb;
+        }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int n = tile / (p.tiles_y * p.tiles_x);
+        const int tr = tile - n * p.tiles_y * p.tiles_x;
+        const int y0 = (tr / p.tiles_x) * C1W_TH, x0 = (tr % p.tiles_x) * C1W_TW;
+        // halo of the one-channel tensor.  MODE 0: rows gy = hy0 + r of dy, zero outside;  MODE 1: rows map(hy0 + r) of x
+        const int hy0 = MODE == 0 ? y0 + p.pt - (p.kh - 1) : y0 - p.pt;
+        const int hx0 = MODE == 0 ? x0 + p.pl - (p.kw - 1) : x0 - p.pl;
+        __syncthreads();                             // the previous tile's U / halo are no longer read
+        for (int idx = tid; idx < HR * HW; idx += 256) {
+            const int r = idx / HW, col = idx - r * HW;
+            int sy = hy0 + r, sx = hx0 + col;
+            if (MODE == 1) { sy = ss_map_index(sy, p.SH, p.reflect); sx = ss_map_index(sx, p.SW, p.reflect); }
+            float v = 0.f;
+            if (sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW) v = p.S[((long)(n * p.SH + sy) * p.SW + sx) * p.S_cs];
+            hs[idx] = v;
+        }
+        __syncthreads();
+        // whole tiles whose pixels receive nothing through the reflection (MODE 1: the halo is already the padded image) read
+        // the halo directly; the others (26 % at 512x512) build the folded / masked U tile first
+        const bool direct = y0 + C1W_TH <= p.XH && x0 + C1W_TW <= p.XW &&
+                            (MODE == 1 || !p.reflect ||
+                             (y0 > p.pt && y0 + C1W_TH - 1 < p.XH - 1 - p.pt && x0 > p.pl && x0 + C1W_TW - 1 < p.XW - 1 - p.pl));
+        if (!direct) {
+#pragma unroll 4
+        for (int j = 0; j < C1W_PIX / 4; ++j) {
+            const int px = (tid >> 6) + 4 * j;
+            const int ry = px / C1W_TW, rx = px % C1W_TW;
+            const int qy = y0 + ry, qx = x0 + rx;
+            float u = 0.f;
+            if (utap && qy < p.XH && qx < p.XW) {
+                if (MODE == 1) {
+                    u = hs[(ry + ua) * HW + (rx + ub)];
+                } else if (!p.reflect || (qy > p.pt && qy < p.XH - 1 - p.pt && qx > p.pl && qx < p.XW - 1 - p.pl)) {
+                    // pixels away from the border (no second padded position reflects onto them; wave-uniform: a wave's lanes are
+                    // the taps of ONE pixel): one read, gy = qy + pt - a is always inside the halo
+                    u = hs[(ry + p.kh - 1 - ua) * HW + (rx + p.kw - 1 - ub)];
+                } else {
+                    // border pixel: besides q itself at most ONE more padded row and ONE more padded column reflect onto q (the
+                    // tile is shorter / narrower than half the image: launcher), i.e. up to four lookups of the plain formula
+                    auto h = [&](int y, int x) -> float {
+                        const int hr = y + p.pt - ua - hy0, hc = x + p.pl - ub - hx0;      // outside the halo = outside dy
+                        return (hr >= 0 && hr < HR && hc >= 0 && hc < HW) ? hs[hr * HW + hc] : 0.f;
+                    };
+                    // (a pixel of the upper half cannot receive from the bottom padding and vice versa: image >= 2*pad + 4, launcher)
+                    const bool top = 2 * qy < p.XH, left = 2 * qx < p.XW;
+                    const bool ay = p.reflect && (top ? qy >= 1 : qy <= p.XH - 2);
+                    const bool ax = p.reflect && (left ? qx >= 1 : qx <= p.XW - 2);
+                    const int y2 = top ? -qy : 2 * (p.XH - 1) - qy;
+                    const int x2 = left ? -qx : 2 * (p.XW - 1) - qx;
+                    u = h(qy, qx);
+                    if (ay) u += h(y2, qx);
+                    if (ax) u += h(qy, x2);
+                    if (ay && ax) u += h(y2, x2);
+                }
+            }
+            us[px * C1W_T + ut] = u;
+        }
+        __syncthreads();
+        }
+        // contraction over the tile's 256 pixels, 32 per batch (16 MFMAs of K = 2): A = X[pixel][c] from global, B = U[pixel][t] from LDS
+        // (the loads of batch k+1 are issued before the MFMAs of batch k: two register sets, fully unrolled)
+        const float* ub_ = us + t0 + l31;
+        const float* xb_ = p.X + (long)n * p.XH * p.XW * p.X_cs;      // wave-uniform base, 32-bit per-lane offsets (launcher: < 2^31 elements)
+        float av0[16], bv0[16], av1[16], bv1[16], av2[16], bv2[16];
+        auto fetch = [&](float (&a_)[16], float (&b_)[16], int k0) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int px = k0 + 2 * m + lh;
+                int qy = y0 + px / C1W_TW, qx = x0 + px % C1W_TW;
+                qy = qy < p.XH ? qy : p.XH - 1;              // pad pixels: U is zero there, any finite X will do
+                qx = qx < p.XW ? qx : p.XW - 1;
+                a_[m] = xb_[(unsigned)((qy * p.XW + qx) * p.X_cs + cc)];
+                b_[m] = direct ? hs[tapoff + (px / C1W_TW) * HW + (px % C1W_TW)] : ub_[px * C1W_T];
+            }
+        };
+        auto mma = [&](const float (&a_)[16], const float (&b_)[16]) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[m], b_[m], acc, 0, 0, 0);
+        };
+        // three register sets: the loads run TWO batches (32 MFMAs = 2048 cycles) ahead of their use
+        constexpr int NB = C1W_PIX / 32;
+        fetch(av0, bv0, 0);
+        fetch(av1, bv1, 32);
+#pragma unroll 1
+        for (int kb = 0; kb < NB; kb += 3) {
+            if (kb + 2 < NB) fetch(av2, bv2, (kb + 2) * 32);
+            mma(av0, bv0);
+            if (kb + 1 < NB) {
+                if (kb + 3 < NB) fetch(av0, bv0, (kb + 3) * 32);
+                mma(av1, bv1);
+            }
+            if (kb + 2 < NB) {
+                if (kb + 4 < NB) fetch(av1, bv1, (kb + 4) * 32);
+                mma(av2, bv2);
+            }
+        }
+    }
+    // D[row = channel][col = tap]: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int t = t0 + l31;
+    if (t < p.kh * p.kw) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (c < p.C) p.part[((long)blockIdx.x * p.kh * p.kw + t) * p.C + c] = acc[r];
+        }
+    }
+}
+
+// dw[t][c] (+)= sum over blocks (in block order) of part[blk][t][c]
+__global__ __launch_bounds__(256) void wgrad_c1_reduce_kernel(const float* __restrict__ part, int nblk, int total, float* __restrict__ dw,
+                                                              int accumulate) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    float s0 = 0.f;
+    for (int k = 0; k < nblk; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = k + u < nblk ? part[(long)(k + u) * total + e] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s0 += v[u];
+    }
+    dw[e] = accumulate ? dw[e] + s0 : s0;
+}
+
+// 2 blocks per CU; an ODD block count, so that the tiles of one image column (the border columns are slower) spread over all blocks
+inline int c1w_blocks(long ntiles) { return (int)(ntiles < 511 ? ntiles : 511); }
+
+template <int MODE>
+int launch_wgrad_c1(const C1WParams& p, float* dw, int accumulate, hipStream_t s) {
+    const size_t smem = ((size_t)C1W_PIX * C1W_T + (size_t)(C1W_TH + p.kh - 1) * (C1W_TW + p.kw - 1)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_c1_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int nblk = c1w_blocks(p.ntiles);
+    hipLaunchKernelGGL((wgrad_c1_kernel<MODE>), dim3(nblk, (p.C + 63) / 64), dim3(256), smem, s, p);
+    SS_LAUNCH_CHECK();
+    const int total = p.kh * p.kw * p.C;
+    hipLaunchKernelGGL(wgrad_c1_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p.part, nblk, total, dw, accumulate);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
 }  // namespace
 
 // Cout == 1, stride 1, full 7x7 / 4x4 / 3x3 tap box, Cin % 4 == 0 and 16-byte aligned pixels
@@ -256,4 +450,30 @@ int ss_launch_conv_in1(const GConvParams& p, hipStream_t s) {
     if (box.kh == 7) return launch_in1<7, 7>(p, box, s);
     if (box.kh == 4) return launch_in1<4, 4>(p, box, s);
     return launch_in1<3, 3>(p, box, s);
+}
+
+// ---- weight gradient, one channel on one side (stride 1, kh * kw <= 64 taps) ----------------------------------------------------
+// mode 0: Cout == 1 (X = conv input x with C = Cin channels, S = dy);  mode 1: Cin == 1 (X = dy with C = Cout channels, S = x)
+bool ss_wgrad_c1_ok(int n, int xh, int xw, int C, int kh, int kw) {
+    static const bool off = getenv("SS_WGRAD_C1") && getenv("SS_WGRAD_C1")[0] == '0';
+    return !off && C >= 32 && C <= 128 && kh >= 1 && kw >= 1 && kh * kw <= C1W_T && kh <= 8 && kw <= 8 && (long)n * xh * xw >= 65536 &&
+           (long)n * xh * xw * C < (1L << 31);
+}
+
+size_t ss_wgrad_c1_ws(int n, int xh, int xw, int C, int kh, int kw) {
+    const long ntiles = (long)n * ((xh + C1W_TH - 1) / C1W_TH) * ((xw + C1W_TW - 1) / C1W_TW);
+    return ss_align_up((size_t)c1w_blocks(ntiles) * kh * kw * C * sizeof(float), 256);
+}
+
+int ss_launch_wgrad_c1(int mode, const float* X, int X_cs, int C, int n, int xh, int xw, const float* S, int S_cs, int sh, int sw,
+                       int kh, int kw, int pt, int pl, int reflect, float* dw, int accumulate, void* ws, hipStream_t s) {
+    C1WParams p{};
+    p.X = X; p.S = S; p.part = (float*)ws;
+    p.N = n; p.XH = xh; p.XW = xw; p.C = C; p.X_cs = X_cs;
+    p.SH = sh; p.SW = sw; p.S_cs = S_cs;
+    p.kh = kh; p.kw = kw; p.pt = pt; p.pl = pl; p.reflect = reflect;
+    p.tiles_y = (xh + C1W_TH - 1) / C1W_TH;
+    p.tiles_x = (xw + C1W_TW - 1) / C1W_TW;
+    p.ntiles = n * p.tiles_y * p.tiles_x;
+    return mode == 0 ? launch_wgrad_c1<0>(p, dw, accumulate, s) : launch_wgrad_c1<1>(p, dw, accumulate, s);
 }

@@ -127,9 +127,11 @@ struct X6PParams {
     float* c;                     // [batch][split][M][ldc]
     int32_t M, N, K, nbatch, splits, k_per_split;
     int32_t lda, ldb, ldc;
+    int32_t fp16x2;               // 0: three bf16 planes, six products (x6);  1: two fp16 planes h + 2^-11 l, three products (x3h)
     int64_t a_plane, b_plane, a_bs, b_bs, c_bs, c_ss;
 };
 bool ss_x6p_enabled();
+bool ss_x3h_enabled();
 bool ss_x6p_wanted(long M, int N, int nbatch);
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
 

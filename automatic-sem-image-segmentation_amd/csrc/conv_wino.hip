@@ -112,7 +112,8 @@ template <int R> __device__ __forceinline__ void t_dw(const float* s, float* o) 
 // [plane][xi][tile rows padded to Mpad][c] -- the A operand of gemm_x6p.hip, no conversion left for the GEMM
 template <int R, int BF>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int in_cs, int N, int H, int W, int C,
-                                                         int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V, long Mpad = 0) {
+                                                         int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V, long Mpad = 0,
+                                                         float* __restrict__ tile_inv = nullptr) {
     typedef typename WT<R>::T T;
     constexpr int VW = WT<R>::VW, P = R + 2;
     const int CV = C / VW;
@@ -144,11 +145,59 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     }
     const long xs = tiles * C;     // stride between transform positions
     float* o = V + tile * C + c;
+    float x3h_scale = 1.f;
+    if (BF == 3) {
+        // largest |V| of this tile: thread maximum over its 36 x VW values, then over the C/VW threads of the tile
+        // (C/VW in {64, 128, 256}: whole waves; 256-thread blocks hold whole tiles)
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            T v[P];
+            t_in<R, T>(t[i], v);
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+#pragma unroll
+                for (int k = 0; k < VW; ++k) mx = fmaxf(mx, fabsf(v[j][k]));
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        __shared__ float wmax[4];
+        const int wave = threadIdx.x >> 6, wpg = CV >> 6;          // waves per tile
+        if ((threadIdx.x & 63) == 0) wmax[wave] = mx;
+        __syncthreads();
+        const int w0 = wave / wpg * wpg;
+        mx = wmax[w0];
+        for (int k = 1; k < wpg; ++k) mx = fmaxf(mx, wmax[w0 + k]);
+        int ex = 0;
+        if (mx > 0.f) (void)frexpf(mx, &ex);                       // mx = f * 2^ex, f in [0.5, 1)
+        else ex = 14;
+        x3h_scale = ldexpf(1.f, 14 - ex);
+        if (c == 0) tile_inv[tile] = ldexpf(1.f, ex - 14);
+    }
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         T v[P];
         t_in<R, T>(t[i], v);
-        if (BF == 2) {
+        if (BF == 3) {
+            // x3h: v*s = h + 2^-11 l with h, l fp16 and s = 2^e per TILE (all 36 positions, all channels) such that the largest
+            // |v*s| of the tile lies in [2^13, 2^14): fp16 keeps 11 bits for everything within 2^-28 of the tile's maximum.
+            // 1/s goes to tile_inv[tile]; the output transform multiplies it back (the GEMM is linear in each A row).
+            const long xs3 = Mpad * C;
+            unsigned int* o3 = (unsigned int*)((unsigned short*)V + tile * C + c);
+            const long pl32 = (long)P * P * xs3 / 2;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+#pragma unroll
+                for (int k = 0; k < VW; k += 2) {
+                    const float v0 = v[j][k] * x3h_scale, v1 = v[j][k + 1] * x3h_scale;
+                    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+                    const _Float16 l0 = (_Float16)((v0 - (float)h0) * 2048.f), l1 = (_Float16)((v1 - (float)h1) * 2048.f);
+                    unsigned int* d = o3 + (long)(i * P + j) * xs3 / 2 + k / 2;
+                    d[0] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+                    d[pl32] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+            }
+        } else if (BF == 2) {
             const long xs3 = Mpad * C;                       // elements between transform positions
             unsigned int* o3 = (unsigned int*)((unsigned short*)V + tile * C + c);
             const long pl32 = (long)P * P * xs3 / 2;         // u32 between planes
@@ -261,9 +310,21 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 // staged in LDS with loads that are contiguous in memory whichever index that is (co: `no` for flip = 0, `kr` for flip = 1 --
 // a thread-per-output version read the 9 MiB kernel tensor at 2 KB strides: 8x over-fetch, 20 us), then one thread = two
 // consecutive kr of one no: a packed bf16 pair per store, consecutive threads -> consecutive kr.
-template <int R>
+// F16 (x3h): two fp16 planes U*s = h + 2^-11 l with ONE power-of-two scale s per launch, from the largest |w| of the kernel tensor
+// (|U| <= max|w|: every row of G has absolute sum <= 1); 1/s goes to *w_inv for the output transform.
+__global__ __launch_bounds__(256) void amax_bits_kernel(const float* __restrict__ v, long n, unsigned int* __restrict__ out) {
+    unsigned int m = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(fabsf(v[i])));          // non-negative floats order like their bit patterns
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);        // a maximum does not depend on the order: deterministic
+}
+
+template <int R, bool F16 = false>
 __global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __restrict__ w, int Cin, int Cout, int flip, int Npad,
-                                                             unsigned short* __restrict__ planes) {
+                                                             unsigned short* __restrict__ planes,
+                                                             const unsigned int* __restrict__ amax_bits = nullptr, float* __restrict__ w_inv = nullptr) {
     constexpr int P = R + 2, HP = P / 2;
     __shared__ float tl[9][32][17];        // [logical tap a*3+b][kr][no]
     const int KR = flip ? Cout : Cin, NO = flip ? Cin : Cout;
@@ -317,16 +378,32 @@ __global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __rest
         }
     }
     unsigned int* dst = (unsigned int*)planes + (long)no * K2 + kr0 / 2 + k2l + (long)(i0 * P) * xs2;
+    float sc = 1.f;
+    if (F16) {
+        const float am = __uint_as_float(*amax_bits);
+        int ex = 14;
+        if (am > 0.f) (void)frexpf(am, &ex);
+        sc = ldexpf(1.f, 14 - ex);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) *w_inv = ldexpf(1.f, ex - 14);
+    }
 #pragma unroll
     for (int i = 0; i < HP; ++i)
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            unsigned int h, m, l;
-            ss_split3x2(f32x2{u2[0][i][j], u2[1][i][j]}, h, m, l);      // rows no >= NO were staged as zeros
             const long o = (long)(i * P + j) * xs2;
-            dst[o] = h;
-            dst[o + plane_u32] = m;
-            dst[o + 2 * plane_u32] = l;
+            if (F16) {
+                const float v0 = u2[0][i][j] * sc, v1 = u2[1][i][j] * sc;
+                const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+                const _Float16 l0 = (_Float16)((v0 - (float)h0) * 2048.f), l1 = (_Float16)((v1 - (float)h1) * 2048.f);
+                dst[o] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+                dst[o + plane_u32] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+            } else {
+                unsigned int h, m, l;
+                ss_split3x2(f32x2{u2[0][i][j], u2[1][i][j]}, h, m, l);      // rows no >= NO were staged as zeros
+                dst[o] = h;
+                dst[o + plane_u32] = m;
+                dst[o + 2 * plane_u32] = l;
+            }
         }
 }
 
@@ -334,7 +411,8 @@ __global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __rest
 template <int R>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, int N, int OH, int OW, int C, int TH, int TW,
                                                           const float* __restrict__ bias, int act, float alpha,
-                                                          float* __restrict__ y, int y_cs, int accumulate, int FH, int FW) {
+                                                          float* __restrict__ y, int y_cs, int accumulate, int FH, int FW,
+                                                          const float* __restrict__ tile_inv = nullptr, const float* __restrict__ w_inv = nullptr) {
     // FH > 0 ("reflect fold", data gradient of reflect-pad(1) + 3x3 valid conv): the OH x OW grid is the PADDED gradient shifted by
     // one (virtual o' = P + 1, P in [0, FH+1]); padded pixel P lands on dx[reflect(P - 1)].  With FH % R == 0 the two padded
     // rows that fold onto the same dx row (P = 0,2 and P = FH-1,FH+1) sit in ONE tile, i.e. one thread: they are summed in
@@ -353,12 +431,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     const int n = (int)(r / TH);
     const long xs = tiles * C;
     const float* m = Mx + tile * C + c;
+    const float unscale = tile_inv ? tile_inv[tile] * w_inv[0] : 1.f;      // x3h operands carry power-of-two scales (exact to undo)
     T s[R][P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         T col[P], o[R];
 #pragma unroll
-        for (int i = 0; i < P; ++i) col[i] = *(const T*)(m + (long)(i * P + j) * xs);
+        for (int i = 0; i < P; ++i) col[i] = *(const T*)(m + (long)(i * P + j) * xs) * unscale;
         t_out<R, T>(col, o);
 #pragma unroll
         for (int i = 0; i < R; ++i) s[i][j] = o[i];
@@ -491,18 +570,39 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
-    if (q.x6 && q.cin % 32 == 0 && ss_x6p_wanted(tiles, q.cout, XI)) {
+    // x3h: fp16 two-piece operands (three products instead of six) where a tile's channels are whole waves of the input transform
+    const int cvi = q.cin / VW;
+    const bool x3h = R == 4 && q.x6 && ss_x3h_enabled() && (cvi == 64 || cvi == 128 || cvi == 256) && (tiles * cvi) % 256 == 0;
+    if (q.x6 && q.cin % 32 == 0 && (x3h || ss_x6p_wanted(tiles, q.cout, XI))) {
         // both GEMM operands as pre-split bf16 planes: V planes in the V region (1.5x the fp32 size, see ss_wino_fwd_ws)
         const long Mpad = (tiles + SS_X6P_BM - 1) / SS_X6P_BM * SS_X6P_BM;
         const int Npad = ss_x6_npad(q.cout);
         Mx = (float*)((char*)V + ss_align_up((size_t)3 * XI * Mpad * q.cin * 2, 256));
         unsigned short* planes = (unsigned short*)((char*)Mx + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
+        float* tile_inv = nullptr;
+        float* w_inv = nullptr;
+        if (x3h) {
+            char* extra = (char*)planes + ss_align_up((size_t)3 * XI * Npad * q.cin * 2, 256);
+            w_inv = (float*)extra;                               // [0]: 1/s_w, [1]: max|w| bits
+            tile_inv = (float*)(extra + 256);
+            (void)hipMemsetAsync(w_inv + 1, 0, 4, s);
+            hipLaunchKernelGGL(amax_bits_kernel, dim3(256), dim3(256), 0, s, w, (long)9 * w_cin * w_cout, (unsigned int*)(w_inv + 1));
+            SS_LAUNCH_CHECK();
+            hipLaunchKernelGGL((wino_weight_x6_kernel<R, true>), dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes,
+                               (const unsigned int*)(w_inv + 1), w_inv);
+            SS_LAUNCH_CHECK();
+            hipLaunchKernelGGL((wino_input_kernel<R, 3>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                               TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
+            SS_LAUNCH_CHECK();
+        } else {
         hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL((wino_input_kernel<R, 2>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
                            TH, TW, q.pt, q.pl, q.reflect, V, Mpad);
         SS_LAUNCH_CHECK();
+        }
         X6PParams g{};
+        g.fp16x2 = x3h ? 1 : 0;
         g.a = (const unsigned short*)V; g.b = planes; g.c = Mx;
         g.M = (int)tiles; g.N = q.cout; g.K = q.cin; g.nbatch = XI; g.splits = 1; g.k_per_split = q.cin;
         g.lda = q.cin; g.ldb = q.cin; g.ldc = q.cout;
@@ -512,7 +612,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         const int rcx = ss_launch_gemm_x6p(g, s);
         if (rcx != SS_OK) return rcx;
         hipLaunchKernelGGL(wino_output_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
-                           bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w);
+                           bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w, tile_inv, w_inv);
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
@@ -593,7 +693,8 @@ size_t ss_wino_fwd_ws(const WinoProb& q) {
     const size_t planes = ss_align_up((size_t)3 * XI * ss_x6_npad(q.cout) * q.cin * 2, 256);
     const long Mpad = (tiles + SS_X6P_BM - 1) / SS_X6P_BM * SS_X6P_BM;
     const size_t vbytes = ss_align_up((size_t)XI * Mpad * q.cin * 6, 256);      // fp32 V or three bf16 planes with padded rows
-    return ss_align_up((size_t)XI * q.cin * q.cout * 4, 256) + vbytes + ss_align_up((size_t)XI * tiles * q.cout * 4, 256) + planes;
+    return ss_align_up((size_t)XI * q.cin * q.cout * 4, 256) + vbytes + ss_align_up((size_t)XI * tiles * q.cout * 4, 256) + planes +
+           256 + ss_align_up((size_t)tiles * 4, 256);          // x3h: weight scale + per-tile scales
 }
 
 // y (+)= act(bias + conv3x3_stride1(x)) with out[o] = sum_a in[map(o + a - pt)] * g[a];  flip = 1: g = rotated + transposed w

@@ -21,14 +21,20 @@ constexpr int PBM = SS_X6P_BM, PBN = SS_X6P_BN, PBK = 32;
 constexpr int ROWB = PBK * 2;                  // bytes per LDS row
 constexpr int A_PLANE_B = PBM * ROWB;          // 16 KiB
 constexpr int B_PLANE_B = PBN * ROWB;          //  8 KiB
-constexpr int STAGE_B = 3 * (A_PLANE_B + B_PLANE_B);
-constexpr int NDMA = STAGE_B / 1024 / 8;       // LDS-DMA instructions per wave and K step (9)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NPL> struct Frag;
+template <> struct Frag<3> { typedef bf16x8 T; };      // x6:  three bf16 planes, six products
+template <> struct Frag<2> { typedef f16x8 T; };       // x3h: two fp16 planes (x = h + 2^-11 l), three products
 
 __device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+template <int NPL>
 __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
+    constexpr int STAGE_B = NPL * (A_PLANE_B + B_PLANE_B);
+    constexpr int NDMA = STAGE_B / 1024 / 8;       // LDS-DMA instructions per wave and K step (9 / 6)
+    typedef typename Frag<NPL>::T FT;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
     const int k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
     const int nchunks = (k_end - k_begin) / PBK;
 
-    // this wave's share of a stage: NDMA pieces of 16 rows (A planes: 48 pieces, B planes: 24)
+    // this wave's share of a stage: NDMA pieces of 16 rows (per plane: A 16 pieces, B 8)
     const unsigned short* gp[NDMA];
     int loff[NDMA];
     {
@@ -61,35 +67,38 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) {
             const int q = wave * NDMA + j;
-            if (q < 3 * (PBM / 16)) {
+            if (q < NPL * (PBM / 16)) {
                 const int pl = q / (PBM / 16), rb = q % (PBM / 16);
                 const int row = rb * 16 + rl;
                 const int ko = sl ^ ((row >> 2) & 3);
                 gp[j] = p.a + pl * p.a_plane + batch * p.a_bs + (long)(m0 + row) * p.lda + k_begin + 8 * ko;
                 loff[j] = pl * A_PLANE_B + rb * 1024;
             } else {
-                const int q2 = q - 3 * (PBM / 16);
+                const int q2 = q - NPL * (PBM / 16);
                 const int pl = q2 / (PBN / 16), rb = q2 % (PBN / 16);
                 const int row = rb * 16 + rl;
                 const int ko = sl ^ ((row >> 2) & 3);
                 gp[j] = p.b + pl * p.b_plane + batch * p.b_bs + (long)(n0 + row) * p.ldb + k_begin + 8 * ko;
-                loff[j] = 3 * A_PLANE_B + pl * B_PLANE_B + rb * 1024;
+                loff[j] = NPL * A_PLANE_B + pl * B_PLANE_B + rb * 1024;
             }
         }
     }
-    f32x16 acc[2][2];
+    constexpr int NACC = NPL == 2 ? 2 : 1;          // x3h: the cross terms h*l + l*h accumulate apart (they carry the factor 2^-11)
+    f32x16 acc[NACC][2][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int s = 0; s < NACC; ++s)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][mi][ni][r] = 0.f;
 
     // operand fetch addresses (stage 0): row = (wave tile base) + l31, slot = (lh + 2*ks) ^ ((row >> 2) & 3)
     const int sw = (l31 >> 2) & 3;
     const int so0 = ((lh ^ sw) << 4), so1 = so0 ^ 32;
     const unsigned char* fa = lds + (wm * 64 + l31) * ROWB;
-    const unsigned char* fb = lds + 3 * A_PLANE_B + (wn * 64 + l31) * ROWB;
+    const unsigned char* fb = lds + NPL * A_PLANE_B + (wn * 64 + l31) * ROWB;
 
     // Software pipeline, ONE barrier per K step.  Two fragment register sets: F0 = (tile c, k 0..15), F1 = (tile c, k 16..31).
     //   top of step c:  F0 holds tile c / half 0 (read after the previous barrier);  stage (c+1)&1 is being filled by DMA
@@ -98,25 +107,31 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
     //     vmcnt(0) + barrier                -> tile c+1 visible to everyone, nobody reads tile c's stage any more
     //     read F0 <- tile c+1 half 0        (in flight under the next MFMAs)
     //     24 MFMAs on F1, the 9 DMAs of tile c+2 (into tile c's stage) issued between them
-    bf16x8 a0[3][2], b0[3][2], a1[3][2], b1[3][2];
-    auto frag = [&](bf16x8 (&a)[3][2], bf16x8 (&b)[3][2], int stage, int so) {
+    FT a0[NPL][2], b0[NPL][2], a1[NPL][2], b1[NPL][2];
+    auto frag = [&](FT (&a)[NPL][2], FT (&b)[NPL][2], int stage, int so) {
         const int sb = stage * STAGE_B;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const bf16x8*)(fa + sb + pl * A_PLANE_B + mi * 32 * ROWB + so);
+            for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const FT*)(fa + sb + pl * A_PLANE_B + mi * 32 * ROWB + so);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[pl][ni] = *(const bf16x8*)(fb + sb + pl * B_PLANE_B + ni * 32 * ROWB + so);
+            for (int ni = 0; ni < 2; ++ni) b[pl][ni] = *(const FT*)(fb + sb + pl * B_PLANE_B + ni * 32 * ROWB + so);
         }
     };
-    // six products, smallest terms first; consecutive MFMAs go to different accumulators
+    // x6: six products, smallest terms first;  x3h: l*h, h*l (cross accumulators), h*h.  Consecutive MFMAs go to different accumulators
+    constexpr int NQ = NPL == 3 ? 6 : 3;
     constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-    auto mma4 = [&](bf16x8 (&a)[3][2], bf16x8 (&b)[3][2], int q) {
+    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0}, HS[3] = {1, 1, 0};
+    auto mma4 = [&](FT (&a)[NPL][2], FT (&b)[NPL][2], int q) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < 2; ++ni) {
+                if constexpr (NPL == 3)
+                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[0][mi][ni], 0, 0, 0);
+                else
+                    acc[HS[q]][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], acc[HS[q]][mi][ni], 0, 0, 0);
+            }
     };
 
     if (nchunks > 0) {
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
         frag(a1, b1, st, so1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) mma4(a0, b0, q);
+        for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): a real s_waitcnt, so that the compiler's own counting sees it
         __builtin_amdgcn_s_barrier();
@@ -151,11 +166,11 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
         const long goff = (long)cn * PBK;
         unsigned char* dst = lds + st * STAGE_B;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             mma4(a1, b1, q);
 #pragma unroll
             for (int j = 0; j < NDMA; ++j)
-                if (j * 6 / NDMA == q) dma16(gp[j] + goff, dst + loff[j]);
+                if (j * NQ / NDMA == q) dma16(gp[j] + goff, dst + loff[j]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // F0's reads finished long ago (24 MFMAs back): a free wait that lets the compiler start the next step without one
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M) cb[(long)m * p.ldc + n] = acc[mi][ni][r];
+                if (m < p.M) cb[(long)m * p.ldc + n] = NPL == 3 ? acc[0][mi][ni][r] : fmaf(acc[NACC - 1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
             }
         }
     }
@@ -188,6 +203,12 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
 bool ss_x6p_enabled() {
     static const bool on = !(getenv("SS_X6P") && getenv("SS_X6P")[0] == '0');
     return on && ss_tuning().x6;
+}
+
+// x3h (fp16 two-piece operands, three products): SS_X3H=0 keeps the exact three-piece bf16 arithmetic everywhere
+bool ss_x3h_enabled() {
+    static const bool on = !(getenv("SS_X3H") && getenv("SS_X3H")[0] == '0');
+    return on && ss_x6p_enabled();
 }
 
 // One 512-thread workgroup per CU and 256x128 tiles: worth it from about four rounds of workgroups over the 256 CUs (batch >= 8 at
@@ -205,11 +226,13 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + PBN - 1) / PBN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const long nwg = (long)gridM * gridN * p.nbatch * p.splits;
-    hipLaunchKernelGGL(gemm_x6p_kernel, dim3((unsigned)nwg), dim3(512), 2 * STAGE_B, s, p);
+    if (p.fp16x2) hipLaunchKernelGGL(gemm_x6p_kernel<2>, dim3((unsigned)nwg), dim3(512), 2 * 2 * (A_PLANE_B + B_PLANE_B), s, p);
+    else hipLaunchKernelGGL(gemm_x6p_kernel<3>, dim3((unsigned)nwg), dim3(512), 2 * 3 * (A_PLANE_B + B_PLANE_B), s, p);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

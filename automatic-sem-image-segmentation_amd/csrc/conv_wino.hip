@@ -314,10 +314,14 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 // (|U| <= max|w|: every row of G has absolute sum <= 1); 1/s goes to *w_inv for the output transform.
 __global__ __launch_bounds__(256) void amax_bits_kernel(const float* __restrict__ v, long n, unsigned int* __restrict__ out) {
     unsigned int m = 0;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        m = max(m, __float_as_uint(fabsf(v[i])));          // non-negative floats order like their bit patterns
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 t = ((const f32x4*)v)[i];               // kernel tensors are 16-byte aligned (parameter arena)
+        m = max(max(m, __float_as_uint(fabsf(t[0]))), max(__float_as_uint(fabsf(t[1])), max(__float_as_uint(fabsf(t[2])), __float_as_uint(fabsf(t[3])))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(fabsf(v[(n4 << 2) + threadIdx.x])));
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, off, 64));
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, off, 64));   // non-negative floats order like their bits
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);        // a maximum does not depend on the order: deterministic
 }
 
@@ -572,7 +576,8 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     }
     // x3h: fp16 two-piece operands (three products instead of six) where a tile's channels are whole waves of the input transform
     const int cvi = q.cin / VW;
-    const bool x3h = R == 4 && q.x6 && ss_x3h_enabled() && (cvi == 64 || cvi == 128 || cvi == 256) && (tiles * cvi) % 256 == 0;
+    const bool x3h = R == 4 && q.x6 && ss_x3h_enabled() && (cvi == 64 || cvi == 128 || cvi == 256) && (tiles * cvi) % 256 == 0 &&
+                     (((uintptr_t)w) & 15) == 0;
     if (q.x6 && q.cin % 32 == 0 && (x3h || ss_x6p_wanted(tiles, q.cout, XI))) {
         // both GEMM operands as pre-split bf16 planes: V planes in the V region (1.5x the fp32 size, see ss_wino_fwd_ws)
         const long Mpad = (tiles + SS_X6P_BM - 1) / SS_X6P_BM * SS_X6P_BM;
@@ -586,7 +591,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
             w_inv = (float*)extra;                               // [0]: 1/s_w, [1]: max|w| bits
             tile_inv = (float*)(extra + 256);
             (void)hipMemsetAsync(w_inv + 1, 0, 4, s);
-            hipLaunchKernelGGL(amax_bits_kernel, dim3(256), dim3(256), 0, s, w, (long)9 * w_cin * w_cout, (unsigned int*)(w_inv + 1));
+            hipLaunchKernelGGL(amax_bits_kernel, dim3(1024), dim3(256), 0, s, w, (long)9 * w_cin * w_cout, (unsigned int*)(w_inv + 1));
             SS_LAUNCH_CHECK();
             hipLaunchKernelGGL((wino_weight_x6_kernel<R, true>), dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes,
                                (const unsigned int*)(w_inv + 1), w_inv);

@@ -172,8 +172,10 @@ def main():
         out = {"metric": "train_step tiles/sec (CycleGAN+UNet)", "value": round(value, 4), "unit": "tiles/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "arithmetic": "fp32 storage and accumulation everywhere; large contractions as exact 3-way bf16 splits x 6 MFMA products "
-                             "(fp32-grade, SS_X6=0 switches to v_mfma_f32_32x32x2_f32)" if os.environ.get("SS_X6", "1") != "0" else "fp32 MFMA",
+               "arithmetic": "fp32 storage and accumulation everywhere; large contractions on the bf16/fp16 matrix cores with fp32-grade "
+                             "operand splits: exact 3-way bf16 split x 6 products (x6), or, for the Winograd GEMMs, 2-way fp16 split with "
+                             "per-tile power-of-two scales x 3 products (x3h, SS_X3H=0 switches it off); measured error vs fp64 below the "
+                             "v_mfma_f32_32x32x2_f32 path's (SS_X6=0)" if os.environ.get("SS_X6", "1") != "0" else "fp32 MFMA",
                "config": {"workload": f"CycleGAN(2xResNet-9 gen F={F} + 2xPatchGAN, image buffer 50) train_step + MultiResUNet(16) "
                                       f"train_step, {S}x{S} grayscale tiles, global batch {GB}" + (" [CycleGAN only]" if args.skip_unet else ""),
                           "tile": S, "global_batch": GB, "per_gpu_batch": per, "parallelism": f"dp{world}"}}
@@ -186,25 +188,26 @@ def main():
             ach = flops_sample * tk["units"] / (tk["total_ms"] * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": "3x3 512->512 trunk conv forward = wino_weight_x6<4> + wino_input<4,2> (V as 3 bf16 planes) + batched "
-                          "gemm_x6p_kernel (36 GEMMs; fp32 operands split exactly into 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per "
-                          "product, fp32 accumulate; both operands by LDS-DMA) + wino_output; reflect pad fused in the input transform.  "
-                          "SS_X6=0: fp32-MFMA GEMMs instead",
+                "kernel": "3x3 512->512 trunk conv forward = amax(w) + wino_weight_x6<4,fp16> + wino_input<4,3> (V as 2 fp16 planes, one "
+                          "power-of-two scale per tile) + batched gemm_x6p_kernel<2> (36 GEMMs; x = h + 2^-11 l, 3 x v_mfma_f32_32x32x16_f16 "
+                          "per product, fp32 accumulate; both operands by LDS-DMA) + wino_output (undoes the scales); reflect pad fused in "
+                          "the input transform.  SS_X3H=0: three bf16 planes, six products; SS_X6=0: fp32-MFMA GEMMs",
                 # ALGORITHMIC (direct-convolution) FLOPs of the op / HIP-event duration of the op (single-stream steps, see above)
                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                 "note": "peak = dense fp32 matrix peak (v_mfma_f32_32x32x2_f32), the dtype's peak; frac exceeds 1 because (a) Winograd "
                         "F(4x4,3x3) executes 4x fewer multiply-adds than the algorithmic count (38.7 of 154.6 GFLOP per launch at batch "
-                        "8) and (b) the GEMMs run as 6 bf16-MFMA products per fp32 product (0.375x the fp32-MFMA cost, error below one "
-                        "fp32 rounding: tests/test_layers_gpu.py::test_conv_x6_is_fp32_grade).  The x6 GEMM itself sustains 1.0 PFLOP/s "
-                        "of bf16 MFMA work = 0.40 of the 2.5 PFLOP/s bf16 peak (`executed`), at the ~1.7 GHz the chip holds under this "
-                        "load (profiles/r01_t_single_stream_kernel_stats.md, profiles/r01_pmc_trunk_fwd_x6p.md)",
-                "executed_bf16_mfma_flops_per_launch": flops / 4.0 * 6.0,
-                # the GEMM kernel alone, from the committed rocprofv3 summary of this command (profiles/r01_t_single_stream_kernel_stats.md)
-                "executed": ({"kernel": "gemm_x6p_kernel, the 36 batched GEMMs of a batch-8 op (1152 workgroups of 256x128)",
-                              "bf16_mfma_flops": flops_sample * 8 / 4.0 * 6.0, "kernel_avg_ms_rocprof": 0.2321,
-                              "achieved": round(flops_sample * 8 / 4.0 * 6.0 / 0.2321e-3 / 1e15, 3), "peak": 2.5, "unit": "PFLOP/s",
-                              "frac": round(flops_sample * 8 / 4.0 * 6.0 / 0.2321e-3 / 2.5e15, 3)}
-                             if (per == 8 and S == 512 and F == 64 and os.environ.get("SS_X6", "1") != "0") else None),
+                        "8) and (b) the GEMMs run as 3 fp16-MFMA products per fp32 product (0.19x the fp32-MFMA cost; rel-L2 error vs fp64 "
+                        "1.5e-6 against 3.1e-6 for the fp32-MFMA path: tests/test_layers_gpu.py::test_conv_x6_is_fp32_grade under "
+                        "SS_X6P=force).  The GEMM itself sustains 0.71 PFLOP/s of fp16 MFMA work = 0.28 of the 2.5 PFLOP/s peak "
+                        "(`executed`; 0.40 with the six-product bf16 kernel, which does twice the matrix work in 1.41x the time) "
+                        "(profiles/r01_w_x3h_single_stream_kernel_stats.md, profiles/r01_pmc_trunk_fwd_x6p.md)",
+                "executed_16bit_mfma_flops_per_launch": flops / 4.0 * (3.0 if os.environ.get("SS_X3H", "1") != "0" else 6.0),
+                # the GEMM kernel alone, from the committed rocprofv3 summary of this command (profiles/r01_w_x3h_single_stream_kernel_stats.md)
+                "executed": ({"kernel": "gemm_x6p_kernel<2>, the 36 batched GEMMs of a batch-8 op (1152 workgroups of 256x128)",
+                              "fp16_mfma_flops": flops_sample * 8 / 4.0 * 3.0, "kernel_avg_ms_rocprof": 0.1641,
+                              "achieved": round(flops_sample * 8 / 4.0 * 3.0 / 0.1641e-3 / 1e15, 3), "peak": 2.5, "unit": "PFLOP/s",
+                              "frac": round(flops_sample * 8 / 4.0 * 3.0 / 0.1641e-3 / 2.5e15, 3)}
+                             if (per == 8 and S == 512 and F == 64 and os.environ.get("SS_X6", "1") != "0" and os.environ.get("SS_X3H", "1") != "0") else None),
                 "executed_mfma_flops_per_launch": flops / 4.0,
                 # PMC cannot be sampled from inside this process: rocprofv3 pass on the direct (non-Winograd) kernel of this shape
                 # PMC cannot be sampled from inside this process: committed rocprofv3 passes on this op/shape at batch 8

@@ -380,7 +380,8 @@ X6_CASES = [
 @pytest.mark.parametrize("case", X6_CASES, ids=[c[0] for c in X6_CASES])
 def test_conv_x6_is_fp32_grade(case):
     """SS_ALGO_X6 (what AUTO picks for these shapes): fp32 operands split EXACTLY into three bf16 pieces, six piece products on
-    the bf16 matrix cores, fp32 accumulation.  Claim under test: the result is as close to the fp64 oracle as the
+    the bf16 matrix cores, fp32 accumulation -- or, for the Winograd case with 128 / 256 / 512 channels (x6_trunk_wino), "x3h": two
+    fp16 pieces with per-tile power-of-two scales, three products (csrc/gemm_x6p.hip).  Claim under test: the result is as close to the fp64 oracle as the
     v_mfma_f32_32x32x2_f32 path (SS_ALGO_MFMA) -- same 1e-4 parity bar, and rel-L2 error within 1.5x of the fp32-MFMA
     path's own rounding error (both are ~1e-7 .. 1e-6; the weight gradient runs on the fp32 MFMA path in both)."""
     E, LY, L = _mods()
@@ -434,3 +435,35 @@ def test_x6p_forced_on_small_shapes():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "wino or x6_trunk", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("k2", [-24, -9, 13])
+def test_x3h_power_of_two_invariance(k2):
+    """x3h (fp16 two-piece operands of the Winograd GEMMs) picks one power-of-two scale per tile from the data, so scaling the
+    input -- or the weights -- by 2^k must scale the result by exactly 2^k, bit for bit: gradients of any magnitude (1e-7 ... 1e4)
+    get the same relative accuracy as O(1) activations.  (An fp16 path WITHOUT the dynamic scales fails this at 2^-24.)"""
+    E, LY, L = _mods()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    cin = cout = 256
+    w_cpu = (torch.rand((3, 3, cin, cout), generator=g) - 0.5) * 0.2
+    x_cpu = torch.rand((2, 48, 48, cin), generator=g) * 2 - 1
+    outs = []
+    for sx, sw in ((0, 0), (k2, 0), (0, k2)):
+        arena = E.ParamArena(dev)
+        layer = LY.Conv2D(arena, "c", 3, cin, cout, stride=1, padding=("reflect", 1), use_bias=False)
+        arena.materialize()
+        arena["c/kernel"].copy_(w_cpu * (2.0 ** sw))
+        x = E.Act((x_cpu * (2.0 ** sx)).to(dev), requires_grad=True)
+        tape = E.Tape()
+        y = layer(tape, x)
+        gt, _ = y.grad_target()
+        gt.t.copy_(torch.ones_like(gt.t) * 0.25)
+        arena.zero_grad()
+        tape.backward()
+        outs.append((y.dense().cpu(), x.get_grad().dense().cpu()))
+    y0, dx0 = outs[0]
+    assert torch.isfinite(y0).all() and float(y0.abs().max()) > 0
+    assert torch.equal(outs[1][0], y0 * (2.0 ** k2)), "forward is not exactly homogeneous in the input"
+    assert torch.equal(outs[2][0], y0 * (2.0 ** k2)), "forward is not exactly homogeneous in the weights"
+    assert torch.equal(outs[2][1], dx0 * (2.0 ** k2)), "data gradient is not exactly homogeneous in the weights"

@@ -211,8 +211,8 @@ def main():
                 "executed_mfma_flops_per_launch": flops / 4.0,
                 # PMC cannot be sampled from inside this process: rocprofv3 pass on the direct (non-Winograd) kernel of this shape
                 # PMC cannot be sampled from inside this process: committed rocprofv3 passes on this op/shape at batch 8
-                # (profiles/r01_pmc_trunk_fwd_x6p.md): sum over the op's 4 kernels of 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
-                "traffic": (2 * (39819 + 50114 + 153735 + 73891) + (55296 + 221184 + 147456 + 65536)) * 1024.0 if (per == 8 and S == 512 and F == 64) else None,
+                # (profiles/r01_pmc_trunk_fwd_x3h.md): sum over the op's 5 kernels of 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
+                "traffic": (2 * (4622 + 4658 + 48737 + 100230 + 73922) + (128 + 36864 + 147526 + 147456 + 65536)) * 1024.0 if (per == 8 and S == 512 and F == 64) else None,
                 "traffic_unit": "bytes per batch-8 op launch (PMC passes on tools/bench_kernels.py trunk_fwd)", "algorithmic_bytes": 4.0 * (2 * per * (S // 8) ** 2 * 8 * F + 9 * (8 * F) ** 2),          # of a batch-`per` launch
                 "winograd_algorithmic_bytes": 4.0 * ((1 + 4 * 2.25 + 1) * per * (S // 8) ** 2 * 8 * F + (9 + 36 + 36) * (8 * F) ** 2),
                 "launches_timed": tk["launches"], "avg_launch_ms": round(tk["avg_ms"], 4), "flops_per_launch": flops}

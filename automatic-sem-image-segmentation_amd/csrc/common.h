@@ -97,6 +97,7 @@ struct GConvParams {
     int32_t nbatch;               // >= 1 independent problems of identical shape (Winograd: 16 transform positions);
     int64_t in_bs, w_bs, out_bs;  // element strides between the batched problems
     int32_t ntaps;
+    const unsigned int* h_amax;   // x3h (conv_mfma_x6.hip): bit patterns of max|input|, max|weights| -- nullptr: three-piece bf16 arithmetic
     GTap taps[SS_MAX_TAPS];
 };
 

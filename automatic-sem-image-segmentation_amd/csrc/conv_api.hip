@@ -254,7 +254,59 @@ bool use_x6(int algo, const GConvParams& p) {
 // upper bound of the weight-plane scratch of a gather conv with `cred` reduction channels, `cout` outputs, `ntaps` taps
 size_t x6_planes_ub(int cred, int cout, int ntaps) {
     if (cred % 32 != 0 || cout < 32) return 0;
-    return ss_align_up((size_t)3 * ss_x6_npad(cout) * ntaps * cred * sizeof(unsigned short), 256);
+    return ss_align_up((size_t)3 * ss_x6_npad(cout) * ntaps * cred * sizeof(unsigned short), 256) + 256;   // + the x3h amax slot
+}
+
+// ---- x3h for the direct (non-Winograd) x6 convolutions: one power-of-two scale per operand TENSOR, from max|.| ----------------------
+// out[0] = max over the [rows][C] view (row stride cs) of |v|, as a bit pattern (non-negative floats order like unsigned ints; an
+// atomic max does not depend on the order: deterministic).  out must be zero on entry.
+__global__ __launch_bounds__(256) void amax_view_kernel(const float* __restrict__ v, long rows, int C, int cs, unsigned int* __restrict__ out) {
+    unsigned int m = 0;
+    const bool al = (((uintptr_t)v) & 15) == 0;
+    if (cs == C && al) {                     // dense: one flat array, no index arithmetic
+        const long n = rows * C, n4 = n >> 2;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+            const f32x4 t = ((const f32x4*)v)[i];
+            m = max(max(m, __float_as_uint(fabsf(t[0]))), max(__float_as_uint(fabsf(t[1])), max(__float_as_uint(fabsf(t[2])), __float_as_uint(fabsf(t[3])))));
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(fabsf(v[(n4 << 2) + threadIdx.x])));
+    } else if (C % 4 == 0 && cs % 4 == 0 && al) {
+        const int C4 = C / 4;
+        const long total = rows * C4;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const long r = i / C4;
+            const int c = (int)(i - r * C4) * 4;
+            const f32x4 t = *(const f32x4*)(v + r * cs + c);
+            m = max(max(m, __float_as_uint(fabsf(t[0]))), max(__float_as_uint(fabsf(t[1])), max(__float_as_uint(fabsf(t[2])), __float_as_uint(fabsf(t[3])))));
+        }
+    } else {
+        const long total = rows * C;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const long r = i / C;
+            m = max(m, __float_as_uint(fabsf(v[r * cs + (i - r * C)])));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, off, 64));
+    __shared__ unsigned int wm[4];           // ONE atomic per block: thousands of atomics on one address serialise in L2 (10 ns each)
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(wm[0], wm[1]), max(wm[2], wm[3])));
+}
+
+// slot[0] = max|activation view|, slot[1] = max|kernel tensor|; returns slot (device pointer), nullptr when x3h is off
+const unsigned int* x3h_amax(const float* act, long rows, int C, int cs, const float* w, long wn, void* slot, hipStream_t s) {
+    unsigned int* am = (unsigned int*)slot;
+    (void)hipMemsetAsync(am, 0, 8, s);
+    const long work = rows * C / 4;
+    const unsigned nb = (unsigned)(work / 4096 < 32 ? 32 : (work / 4096 > 1024 ? 1024 : work / 4096));
+    hipLaunchKernelGGL(amax_view_kernel, dim3(nb), dim3(256), 0, s, act, rows, C, cs, am);
+    hipLaunchKernelGGL(amax_view_kernel, dim3(wn / 8192 < 16 ? 16 : (wn / 8192 > 256 ? 256 : (unsigned)(wn / 8192))), dim3(256), 0, s, w, 1L, (int)wn, (int)wn, am + 1);
+    return am;
+}
+bool x3h_direct_wanted(int algo, int cred, int cout) {
+    static const bool off = getenv("SS_X3H_DIRECT") && getenv("SS_X3H_DIRECT")[0] == '0';
+    return !off && ss_x3h_enabled() && x6_wanted(algo) && cred % 32 == 0 && cout >= 32;
 }
 
 size_t gconv_ws_bytes(int algo, const GConvParams& p) {
@@ -353,7 +405,11 @@ int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bia
     WinoProb q;
     if (wino_fwd_prob(c, algo, &q))
         return ss_wino_conv_fwd(q, x, w, c.cin, c.cout, 0, bias, y, act, alpha, accumulate, ws, ws_bytes, s);
-    return run_gconv(algo, fwd_params(c, x, w, bias, y, act, alpha, accumulate), ws, ws_bytes, s);
+    GConvParams p = fwd_params(c, x, w, bias, y, act, alpha, accumulate);
+    if (x3h_direct_wanted(algo, c.cin, c.cout) && use_x6(algo, p) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p) + 256)
+        p.h_amax = x3h_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, w, (long)c.kh * c.kw * c.cin * c.cout,
+                            (char*)ws + ss_gconv_x6_planes_bytes(p), s);
+    return run_gconv(algo, p, ws, ws_bytes, s);
 }
 
 size_t bwd_data_wt_bytes(const ConvProb& c) { return ss_align_up((size_t)c.kh * c.kw * c.cin * c.cout * sizeof(float), 256); }
@@ -399,6 +455,9 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     p.in = dy; p.w = wt; p.bias = bias;
     p.N = c.n; p.IH = c.oh; p.IW = c.ow; p.Cin = c.cout; p.in_cs = c.out_cs;
     p.in_s = 1; p.Cout = c.cin; p.ldb = c.cin; p.reflect = 0; p.act = act; p.alpha = alpha;
+    if (x3h_direct_wanted(algo, c.cout, c.cin) && gws_bytes >= x6_planes_ub(c.cout, c.cin, T) && (long)c.n * c.oh * c.ow >= 1024)
+        p.h_amax = x3h_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, w, (long)T * c.cin * c.cout,
+                            (char*)gws + x6_planes_ub(c.cout, c.cin, T) - 256, s);
 
     if (c.reflect) {
         const int PH = c.oh + c.kh - 1, PW = c.ow + c.kw - 1;

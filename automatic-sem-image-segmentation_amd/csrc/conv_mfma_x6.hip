@@ -20,6 +20,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -27,16 +28,22 @@ constexpr int XK = 32;          // K step (elements)
 constexpr int XLD = XK + 8;     // LDS row stride in bf16 elements (80 bytes)
 constexpr int XBM = 128;
 
-template <int BM, int BN>
+// H = true ("x3h"): two fp16 pieces per operand instead of three bf16 ones,  x*s = h + l  with h = fp16(x*s), l = fp16(x*s - h) and
+// ONE power-of-two scale s per operand TENSOR (p.h_amax: bit patterns of max|activation|, max|weight|, set by conv_api.hip), three
+// products h*h + h*l + l*h in the same accumulator (the cross terms are 2^-11 smaller by themselves); values within 2^-17 of
+// the tensor maximum keep 22 bits, smaller ones keep an absolute 2^-38 of the maximum.  The scales are undone in the epilogue.
+template <int BM, int BN, bool H>
 __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems,
                                                           int Npad, int Ktot) {
+    constexpr int NP = H ? 2 : 3;        // operand planes
+    typedef typename std::conditional<H, f16x8, bf16x8>::type FT;
     constexpr int TM = BM / 64;          // 32-row MFMA tiles per wave (2 waves along M)
     constexpr int TN = BN / 64;          // 32-wide MFMA column tiles per wave (2 waves along N)
     constexpr int BROWS = BN / 64;       // B loader: rows (tid>>2) + 64*j
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-    unsigned short* sA = lds;                          // [3][BM][XLD]
-    unsigned short* sB = lds + 3 * BM * XLD;           // [3][BN][XLD]
-    int* pixtab = (int*)(sB + 3 * BN * XLD);
+    unsigned short* sA = lds;                          // [NP][BM][XLD]
+    unsigned short* sB = lds + NP * BM * XLD;          // [NP][BN][XLD]
+    int* pixtab = (int*)(sB + NP * BN * XLD);
     int* offtab = pixtab + BM;                         // [BM][ntaps]
 
     const int tid = threadIdx.x;
@@ -61,6 +68,15 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const long m0 = (long)(tile / gridN) * BM;
     const int n0 = (tile % gridN) * BN;
     const int nchunks = Ktot / XK;
+    float a_scale = 1.f, out_scale = 1.f;
+    if constexpr (H) {
+        int ea = 14, ew = 14;
+        const float aa = __uint_as_float(p.h_amax[0]), aw = __uint_as_float(p.h_amax[1]);
+        if (aa > 0.f) (void)frexpf(aa, &ea);
+        if (aw > 0.f) (void)frexpf(aw, &ew);
+        a_scale = ldexpf(1.f, 14 - ea);
+        out_scale = ldexpf(1.f, ea - 14 + ew - 14);
+    }
 
     {   // 32-bit pixel decode (ss_gconv_x6_ok: M < 2^31), one division pair per tile row; the offset table divides nothing
         int* rowc = offtab + BM * p.ntaps;      // [3][BM]
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     constexpr int AU = BM / 32;          // A loader: rows arow + 32*j
     f32x4 ra[2][AU];
     bool ra_ok[2][AU];
-    u32x4 rb[2][3][BROWS];
+    u32x4 rb[2][NP][BROWS];
 
     auto load_tiles = [&](auto setc, int k0) {
         constexpr int S = decltype(setc)::value;
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
             ra_ok[S][j] = off >= 0;
         }
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int j = 0; j < BROWS; ++j)
                 rb[S][pl][j] = *(const u32x4*)(bbase + pl * plane_elems + (long)(64 * j) * Ktot + k0);
@@ -131,17 +147,31 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int j = 0; j < AU; ++j) {
-            unsigned int h[2], m[2], l[2];
             const f32x4 v = ra_ok[S][j] ? ra[S][j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            ss_split3x2(f32x2{v[0], v[1]}, h[0], m[0], l[0]);
-            ss_split3x2(f32x2{v[2], v[3]}, h[1], m[1], l[1]);
             unsigned short* dst = sA + (arow + 32 * j) * XLD + c4a * 4;
-            *(u32x2*)(dst) = u32x2{h[0], h[1]};
-            *(u32x2*)(dst + BM * XLD) = u32x2{m[0], m[1]};
-            *(u32x2*)(dst + 2 * BM * XLD) = u32x2{l[0], l[1]};
+            if constexpr (H) {
+                unsigned int hh[2], ll[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float x0 = v[2 * e] * a_scale, x1 = v[2 * e + 1] * a_scale;
+                    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+                    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+                    hh[e] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+                    ll[e] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+                *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
+                *(u32x2*)(dst + BM * XLD) = u32x2{ll[0], ll[1]};
+            } else {
+                unsigned int h[2], m[2], l[2];
+                ss_split3x2(f32x2{v[0], v[1]}, h[0], m[0], l[0]);
+                ss_split3x2(f32x2{v[2], v[3]}, h[1], m[1], l[1]);
+                *(u32x2*)(dst) = u32x2{h[0], h[1]};
+                *(u32x2*)(dst + BM * XLD) = u32x2{m[0], m[1]};
+                *(u32x2*)(dst + 2 * BM * XLD) = u32x2{l[0], l[1]};
+            }
         }
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int j = 0; j < BROWS; ++j)
                 *(u32x4*)(sB + pl * BN * XLD + (brow + 64 * j) * XLD + bpc * 8) = rb[S][pl][j];
@@ -170,23 +200,29 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         if (c + 2 < nchunks) load_tiles(cur, (c + 2) * XK);
 #pragma unroll
         for (int ks = 0; ks < XK / 16; ++ks) {
-            bf16x8 a[3][TM], b[3][TN];
+            FT a[NP][TM], b[NP][TN];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) a[pl][mi] = *(const bf16x8*)(fa + pl * BM * XLD + mi * 32 * XLD + ks * 16);
+                for (int mi = 0; mi < TM; ++mi) a[pl][mi] = *(const FT*)(fa + pl * BM * XLD + mi * 32 * XLD + ks * 16);
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const bf16x8*)(fb + pl * BN * XLD + ni * 32 * XLD + ks * 16);
+                for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const FT*)(fb + pl * BN * XLD + ni * 32 * XLD + ks * 16);
             }
-            // six products, smallest terms first; consecutive MFMAs go to different accumulators
+            // x6: six products, smallest terms first;  x3h: l*h, h*l, h*h.  Consecutive MFMAs go to different accumulators
+            constexpr int NQ = H ? 3 : 6;
             constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+            constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < TN; ++ni) {
+                        if constexpr (H)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], acc[mi][ni], 0, 0, 0);
+                        else
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
+                    }
         }
         __syncthreads();
         if (c + 1 < nchunks) {
@@ -213,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
                 const int pix = pixtab[wm * (BM / 2) + mi * 32 + row];
                 if (pix < 0) continue;
                 float* op = g_out + (long)pix * p.out_cs + co;
-                float v = ss_apply_act(acc[mi][ni][r] + bv, p.act, p.alpha);
+                float v = ss_apply_act((H ? acc[mi][ni][r] * out_scale : acc[mi][ni][r]) + bv, p.act, p.alpha);
                 if (p.accumulate) v += *op;
                 *op = v;
             }
@@ -223,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
 
 // planes[pl][batch][n][t*Cin + ci] = piece pl of w[batch*w_bs + taps[t].woff + ci*ldb + n]; rows n in [Cout, Npad) are zero.
 // 32x32 LDS transpose: coalesced reads along n, coalesced writes along k.
+template <bool H>
 __global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned short* __restrict__ planes, long plane_elems, int Npad, int Ktot) {
     __shared__ float tl[32][33];
     const int batch = blockIdx.z;
@@ -244,12 +281,23 @@ __global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned s
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + ty + 8 * i, k = k0 + tx;
         if (n < Npad && k < Ktot) {
-            unsigned int h, m, l;
-            ss_split3x2(f32x2{tl[tx][ty + 8 * i], 0.f}, h, m, l);
             const long o = ((long)batch * Npad + n) * Ktot + k;
-            planes[o] = (unsigned short)(h & 0xffffu);
-            planes[o + plane_elems] = (unsigned short)(m & 0xffffu);
-            planes[o + 2 * plane_elems] = (unsigned short)(l & 0xffffu);
+            if constexpr (H) {
+                int ew = 14;
+                const float aw = __uint_as_float(p.h_amax[1]);
+                if (aw > 0.f) (void)frexpf(aw, &ew);
+                const float x0 = tl[tx][ty + 8 * i] * ldexpf(1.f, 14 - ew);
+                const _Float16 h0 = (_Float16)x0;
+                const _Float16 l0 = (_Float16)(x0 - (float)h0);
+                planes[o] = __builtin_bit_cast(unsigned short, h0);
+                planes[o + plane_elems] = __builtin_bit_cast(unsigned short, l0);
+            } else {
+                unsigned int h, m, l;
+                ss_split3x2(f32x2{tl[tx][ty + 8 * i], 0.f}, h, m, l);
+                planes[o] = (unsigned short)(h & 0xffffu);
+                planes[o + plane_elems] = (unsigned short)(m & 0xffffu);
+                planes[o + 2 * plane_elems] = (unsigned short)(l & 0xffffu);
+            }
         }
     }
 }
@@ -431,20 +479,24 @@ int launch_wgrad_x6(const WGradParams& p, hipStream_t s) {
     return SS_OK;
 }
 
-template <int BM, int BN>
-int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
+template <int BM, int BN, bool H>
+int launch_x6h(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
     const long M = (long)p.N * p.OHc * p.OWc;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     dim3 grid((unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN) * nb));
-    const size_t smem = (size_t)3 * (BM + BN) * XLD * sizeof(unsigned short) + (size_t)BM * sizeof(int) * (4 + p.ntaps);
+    const size_t smem = (size_t)(H ? 2 : 3) * (BM + BN) * XLD * sizeof(unsigned short) + (size_t)BM * sizeof(int) * (4 + p.ntaps);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gconv_x6_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gconv_x6_kernel<BM, BN, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gconv_x6_kernel<BM, BN>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot);
+    hipLaunchKernelGGL((gconv_x6_kernel<BM, BN, H>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot);
     SS_LAUNCH_CHECK();
     return SS_OK;
+}
+template <int BM, int BN>
+int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
+    return p.h_amax ? launch_x6h<BM, BN, true>(p, planes, plane_elems, Npad, Ktot, s) : launch_x6h<BM, BN, false>(p, planes, plane_elems, Npad, Ktot, s);
 }
 
 }  // namespace
@@ -467,7 +519,8 @@ int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * p.Cin;
     const long plane_elems = (long)nb * Npad * Ktot;
-    hipLaunchKernelGGL(wprep_x6_kernel, dim3((Ktot + 31) / 32, Npad / 32, nb), dim3(256), 0, s, p, planes, plane_elems, Npad, Ktot);
+    if (p.h_amax) hipLaunchKernelGGL(wprep_x6_kernel<true>, dim3((Ktot + 31) / 32, Npad / 32, nb), dim3(256), 0, s, p, planes, plane_elems, Npad, Ktot);
+    else hipLaunchKernelGGL(wprep_x6_kernel<false>, dim3((Ktot + 31) / 32, Npad / 32, nb), dim3(256), 0, s, p, planes, plane_elems, Npad, Ktot);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

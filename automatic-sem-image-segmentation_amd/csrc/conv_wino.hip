@@ -322,7 +322,10 @@ __global__ __launch_bounds__(256) void amax_bits_kernel(const float* __restrict_
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(fabsf(v[(n4 << 2) + threadIdx.x])));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, off, 64));   // non-negative floats order like their bits
-    if ((threadIdx.x & 63) == 0) atomicMax(out, m);        // a maximum does not depend on the order: deterministic
+    __shared__ unsigned int wm[4];          // ONE atomic per block (thousands of atomics on one address serialise in L2)
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(wm[0], wm[1]), max(wm[2], wm[3])));      // order-independent: deterministic
 }
 
 template <int R, bool F16 = false>
@@ -591,7 +594,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
             w_inv = (float*)extra;                               // [0]: 1/s_w, [1]: max|w| bits
             tile_inv = (float*)(extra + 256);
             (void)hipMemsetAsync(w_inv + 1, 0, 4, s);
-            hipLaunchKernelGGL(amax_bits_kernel, dim3(1024), dim3(256), 0, s, w, (long)9 * w_cin * w_cout, (unsigned int*)(w_inv + 1));
+            hipLaunchKernelGGL(amax_bits_kernel, dim3(256), dim3(256), 0, s, w, (long)9 * w_cin * w_cout, (unsigned int*)(w_inv + 1));
             SS_LAUNCH_CHECK();
             hipLaunchKernelGGL((wino_weight_x6_kernel<R, true>), dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes,
                                (const unsigned int*)(w_inv + 1), w_inv);

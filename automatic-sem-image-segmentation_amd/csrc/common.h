@@ -114,6 +114,7 @@ struct WGradParams {
     int32_t splits, pix_per_split;
     int32_t nbatch;               // batched problems (Winograd); partials laid out [batch][split][M][Cb]
     int32_t x6;                   // 1: fp32-exact contraction on the bf16 matrix cores where the shape allows (conv_mfma_x6.hip)
+    const unsigned int* h_amax;   // x3h: bit patterns of max|a|, max|b| (one scale per operand tensor); nullptr: three-piece bf16 arithmetic
     int64_t a_bs, b_bs;
     int32_t ntaps;
     GTap taps[SS_MAX_TAPS];       // woff = destination offset of the tap block inside dw

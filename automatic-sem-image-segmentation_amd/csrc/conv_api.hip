@@ -294,13 +294,25 @@ __global__ __launch_bounds__(256) void amax_view_kernel(const float* __restrict_
     if (threadIdx.x == 0) atomicMax(out, max(max(wm[0], wm[1]), max(wm[2], wm[3])));
 }
 
+inline void launch_amax_view(const float* v, long rows, int C, int cs, unsigned int* out, hipStream_t s) {
+    const long work = rows * C / 4;
+    const unsigned nb = (unsigned)(work / 4096 < 32 ? 32 : (work / 4096 > 1024 ? 1024 : work / 4096));
+    hipLaunchKernelGGL(amax_view_kernel, dim3(nb), dim3(256), 0, s, v, rows, C, cs, out);
+}
+// slot[0] = max|view a|, slot[1] = max|view b| (weight gradients: both operands are activations)
+const unsigned int* x3h_amax2(const float* a, long arows, int aC, int acs, const float* b, long brows, int bC, int bcs, void* slot,
+                              hipStream_t s) {
+    unsigned int* am = (unsigned int*)slot;
+    (void)hipMemsetAsync(am, 0, 8, s);
+    launch_amax_view(a, arows, aC, acs, am, s);
+    launch_amax_view(b, brows, bC, bcs, am + 1, s);
+    return am;
+}
 // slot[0] = max|activation view|, slot[1] = max|kernel tensor|; returns slot (device pointer), nullptr when x3h is off
 const unsigned int* x3h_amax(const float* act, long rows, int C, int cs, const float* w, long wn, void* slot, hipStream_t s) {
     unsigned int* am = (unsigned int*)slot;
     (void)hipMemsetAsync(am, 0, 8, s);
-    const long work = rows * C / 4;
-    const unsigned nb = (unsigned)(work / 4096 < 32 ? 32 : (work / 4096 > 1024 ? 1024 : work / 4096));
-    hipLaunchKernelGGL(amax_view_kernel, dim3(nb), dim3(256), 0, s, act, rows, C, cs, am);
+    launch_amax_view(act, rows, C, cs, am, s);
     hipLaunchKernelGGL(amax_view_kernel, dim3(wn / 8192 < 16 ? 16 : (wn / 8192 > 256 ? 256 : (unsigned)(wn / 8192))), dim3(256), 0, s, w, 1L, (int)wn, (int)wn, am + 1);
     return am;
 }
@@ -517,7 +529,7 @@ size_t bwd_weight_ws(const ConvProb& c) {
     const long P = (long)c.n * c.oh * c.ow;
     const int M = c.kh * c.kw * c.cin;
     const int splits = ss_wgrad_mfma_splits(P, M, c.cout, &pps);
-    size_t b = ss_align_up((size_t)splits * M * c.cout * sizeof(float), 256);
+    size_t b = ss_align_up((size_t)splits * M * c.cout * sizeof(float), 256) + 256;      // + the x3h amax slot
     if (wgrad_two_stage(c, SS_ALGO_AUTO)) {
         const int tcs = round4(c.kh * c.kw);
         const long Q = (long)c.n * c.ih * c.iw;
@@ -593,6 +605,9 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
     }
     p.splits = ss_wgrad_mfma_splits((long)c.n * c.oh * c.ow, p.ntaps * p.Ca, p.Cb, &pps);
     p.pix_per_split = pps;
+    if (p.x6 && ss_x3h_enabled() && x3h_direct_wanted(algo, 32, 32) && ss_wgrad_x6_ok(p))
+        p.h_amax = x3h_amax2(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs,
+                             (char*)ws + ss_align_up((size_t)p.splits * p.ntaps * p.Ca * p.Cb * sizeof(float), 256), s);
     return ss_launch_wgrad_mfma(p, dw, c.cout, accumulate, s);
 }
 

@@ -24,6 +24,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// two fp32 values (already scaled) -> packed fp16 pairs (h, l) with x = h + l
+__device__ __forceinline__ void split_h2(float x0, float x1, unsigned int& hh, unsigned int& ll) {
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    hh = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+    ll = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+}
+
 constexpr int XK = 32;          // K step (elements)
 constexpr int XLD = XK + 8;     // LDS row stride in bf16 elements (80 bytes)
 constexpr int XBM = 128;
@@ -307,13 +315,15 @@ __global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned s
 // into LDS: a thread owns 4 consecutive pixels x 4 consecutive channels (four 16-byte global loads), splits them, and
 // writes, per channel and piece, the 4 pixels as one 8-byte LDS store into the k-contiguous row of that channel.
 // Lane -> (pixel group = tid & 7, channel quad = tid >> 3): a 16-lane store group covers two rows x 16 dwords = 32 banks.
-template <int BN>
+template <int BN, bool H>
 __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
     constexpr int BM = XBM;
+    constexpr int NP = H ? 2 : 3;        // operand planes (H: fp16 two-piece split with one scale per operand tensor, see gconv_x6_kernel)
+    typedef typename std::conditional<H, f16x8, bf16x8>::type FT;
     constexpr int TN = BN / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-    unsigned short* sA = lds;                          // [3][BM][XLD]
-    unsigned short* sB = lds + 3 * BM * XLD;           // [3][BN][XLD]
+    unsigned short* sA = lds;                          // [NP][BM][XLD]
+    unsigned short* sB = lds + NP * BM * XLD;          // [NP][BN][XLD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -331,6 +341,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
     const long ps = (long)split * p.pix_per_split;
     const long pe = (ps + p.pix_per_split < P) ? ps + p.pix_per_split : P;
     const int nchunks = (int)((pe - ps + XK - 1) / XK);
+    float a_scale = 1.f, b_scale = 1.f, out_scale = 1.f;
+    if constexpr (H) {
+        int ea = 14, eb = 14;
+        const float aa = __uint_as_float(p.h_amax[0]), ab = __uint_as_float(p.h_amax[1]);
+        if (aa > 0.f) (void)frexpf(aa, &ea);
+        if (ab > 0.f) (void)frexpf(ab, &eb);
+        a_scale = ldexpf(1.f, 14 - ea);
+        b_scale = ldexpf(1.f, 14 - eb);
+        out_scale = ldexpf(1.f, ea - 14 + eb - 14);
+    }
 
     const int kq = tid & 7, cq = tid >> 3;
     // A: this thread's channel quad (fixed over the pixel loop)
@@ -382,24 +402,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
         for (int i = 0; i < 4; ++i) { va[i] = za[i] ? z : ra[i]; vb[i] = zb[i] ? z : rb[i]; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            unsigned int h0, m0_, l0, h1, m1, l1;
-            ss_split3x2(f32x2{va[0][e], va[1][e]}, h0, m0_, l0);
-            ss_split3x2(f32x2{va[2][e], va[3][e]}, h1, m1, l1);
             unsigned short* dst = sA + (4 * cq + e) * XLD + 4 * kq;
-            *(u32x2*)(dst) = u32x2{h0, h1};
-            *(u32x2*)(dst + BM * XLD) = u32x2{m0_, m1};
-            *(u32x2*)(dst + 2 * BM * XLD) = u32x2{l0, l1};
+            if constexpr (H) {
+                unsigned int hh[2], ll[2];
+                split_h2(va[0][e] * a_scale, va[1][e] * a_scale, hh[0], ll[0]);
+                split_h2(va[2][e] * a_scale, va[3][e] * a_scale, hh[1], ll[1]);
+                *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
+                *(u32x2*)(dst + BM * XLD) = u32x2{ll[0], ll[1]};
+            } else {
+                unsigned int h0, m0_, l0, h1, m1, l1;
+                ss_split3x2(f32x2{va[0][e], va[1][e]}, h0, m0_, l0);
+                ss_split3x2(f32x2{va[2][e], va[3][e]}, h1, m1, l1);
+                *(u32x2*)(dst) = u32x2{h0, h1};
+                *(u32x2*)(dst + BM * XLD) = u32x2{m0_, m1};
+                *(u32x2*)(dst + 2 * BM * XLD) = u32x2{l0, l1};
+            }
         }
         if (4 * cq < BN) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                unsigned int h0, m0_, l0, h1, m1, l1;
-                ss_split3x2(f32x2{vb[0][e], vb[1][e]}, h0, m0_, l0);
-                ss_split3x2(f32x2{vb[2][e], vb[3][e]}, h1, m1, l1);
                 unsigned short* dst = sB + (4 * cq + e) * XLD + 4 * kq;
-                *(u32x2*)(dst) = u32x2{h0, h1};
-                *(u32x2*)(dst + BN * XLD) = u32x2{m0_, m1};
-                *(u32x2*)(dst + 2 * BN * XLD) = u32x2{l0, l1};
+                if constexpr (H) {
+                    unsigned int hh[2], ll[2];
+                    split_h2(vb[0][e] * b_scale, vb[1][e] * b_scale, hh[0], ll[0]);
+                    split_h2(vb[2][e] * b_scale, vb[3][e] * b_scale, hh[1], ll[1]);
+                    *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
+                    *(u32x2*)(dst + BN * XLD) = u32x2{ll[0], ll[1]};
+                } else {
+                    unsigned int h0, m0_, l0, h1, m1, l1;
+                    ss_split3x2(f32x2{vb[0][e], vb[1][e]}, h0, m0_, l0);
+                    ss_split3x2(f32x2{vb[2][e], vb[3][e]}, h1, m1, l1);
+                    *(u32x2*)(dst) = u32x2{h0, h1};
+                    *(u32x2*)(dst + BN * XLD) = u32x2{m0_, m1};
+                    *(u32x2*)(dst + 2 * BN * XLD) = u32x2{l0, l1};
+                }
             }
         }
     };
@@ -424,22 +460,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
         if (c + 1 < nchunks) load_tiles(ps + (long)(c + 1) * XK);
 #pragma unroll
         for (int ks = 0; ks < XK / 16; ++ks) {
-            bf16x8 a[3][2], b[3][TN];
+            FT a[NP][2], b[NP][TN];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const bf16x8*)(fa + pl * BM * XLD + mi * 32 * XLD + ks * 16);
+                for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const FT*)(fa + pl * BM * XLD + mi * 32 * XLD + ks * 16);
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const bf16x8*)(fb + pl * BN * XLD + ni * 32 * XLD + ks * 16);
+                for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const FT*)(fb + pl * BN * XLD + ni * 32 * XLD + ks * 16);
             }
+            constexpr int NQ = H ? 3 : 6;
             constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+            constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < TN; ++ni) {
+                        if constexpr (H)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], acc[mi][ni], 0, 0, 0);
+                        else
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
+                    }
         }
         __syncthreads();
         if (c + 1 < nchunks) {
@@ -458,25 +500,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < M) part[(long)m * p.Cb + n] = acc[mi][ni][r];
+                if (m < M) part[(long)m * p.Cb + n] = H ? acc[mi][ni][r] * out_scale : acc[mi][ni][r];
             }
         }
     }
 }
 
-template <int BN>
-int launch_wgrad_x6(const WGradParams& p, hipStream_t s) {
+template <int BN, bool H>
+int launch_wgrad_x6h(const WGradParams& p, hipStream_t s) {
     const int M = p.ntaps * p.Ca;
     dim3 grid((M + XBM - 1) / XBM, (p.Cb + BN - 1) / BN, p.splits * (p.nbatch > 1 ? p.nbatch : 1));
-    const size_t smem = (size_t)3 * (XBM + BN) * XLD * sizeof(unsigned short);
+    const size_t smem = (size_t)(H ? 2 : 3) * (XBM + BN) * XLD * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel<BN, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_x6_kernel<BN>), grid, dim3(256), smem, s, p);
+    hipLaunchKernelGGL((wgrad_x6_kernel<BN, H>), grid, dim3(256), smem, s, p);
     SS_LAUNCH_CHECK();
     return SS_OK;
+}
+template <int BN>
+int launch_wgrad_x6(const WGradParams& p, hipStream_t s) {
+    return p.h_amax ? launch_wgrad_x6h<BN, true>(p, s) : launch_wgrad_x6h<BN, false>(p, s);
 }
 
 template <int BM, int BN, bool H>

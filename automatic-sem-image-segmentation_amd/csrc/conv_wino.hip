@@ -107,13 +107,23 @@ template <int R> __device__ __forceinline__ void t_dw(const float* s, float* o) 
     }
 }
 
+// max of a non-negative value over the block -> atomic max of its bit pattern (order-independent: deterministic); all 256 threads
+__device__ __forceinline__ void block_amax(float v, unsigned int* out) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    __shared__ float bm[4];
+    if ((threadIdx.x & 63) == 0) bm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(bm[0], bm[1]), fmaxf(bm[2], bm[3]))));
+}
+
 // V[xi][tile][c], tile = (n, ty, tx); patch d[i][j] = in[n, map(R*ty + i - pt), map(R*tx + j - pl), c]
 // BF = 0: fp32 V;  1: two bf16 planes (SS_PRECISION=bf16x3);  2: the three bf16 planes of the x6 arithmetic,
 // [plane][xi][tile rows padded to Mpad][c] -- the A operand of gemm_x6p.hip, no conversion left for the GEMM
 template <int R, int BF>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int in_cs, int N, int H, int W, int C,
                                                          int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V, long Mpad = 0,
-                                                         float* __restrict__ tile_inv = nullptr) {
+                                                         float* __restrict__ tile_inv = nullptr, unsigned int* __restrict__ amax_out = nullptr) {
     typedef typename WT<R>::T T;
     constexpr int VW = WT<R>::VW, P = R + 2;
     const int CV = C / VW;
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         x3h_scale = ldexpf(1.f, 14 - ex);
         if (c == 0) tile_inv[tile] = ldexpf(1.f, ex - 14);
     }
+    float vmax = 0.f;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         T v[P];
@@ -220,15 +231,22 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
             for (int j = 0; j < P; ++j) store_split<T>(oh + (long)(i * P + j) * xs, ol + (long)(i * P + j) * xs, v[j]);
         } else {
 #pragma unroll
-            for (int j = 0; j < P; ++j) *(T*)(o + (long)(i * P + j) * xs) = v[j];
+            for (int j = 0; j < P; ++j) {
+                *(T*)(o + (long)(i * P + j) * xs) = v[j];
+                if (BF == 0) {
+#pragma unroll
+                    for (int k = 0; k < VW; ++k) vmax = fmaxf(vmax, fabsf(v[j][k]));
+                }
+            }
         }
     }
+    if (BF == 0 && amax_out) block_amax(vmax, amax_out);      // launcher: whole blocks only
 }
 
 // E[xi][tile][c] = (A e A^T)_xi for the RxR tile e of dy (zero outside the dy extent)
 template <int R>
 __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, int dy_cs, int N, int OH, int OW, int C,
-                                                      int TH, int TW, float* __restrict__ E) {
+                                                      int TH, int TW, float* __restrict__ E, unsigned int* __restrict__ amax_out = nullptr) {
     typedef typename WT<R>::T T;
     constexpr int VW = WT<R>::VW, P = R + 2;
     const int CV = C / VW;
@@ -256,13 +274,19 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
     }
     const long xs = tiles * C;
     float* o = E + tile * C + c;
+    float emax = 0.f;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         T w[P];
         t_dy<R, T>(a[i], w);
 #pragma unroll
-        for (int j = 0; j < P; ++j) *(T*)(o + (long)(i * P + j) * xs) = w[j];
+        for (int j = 0; j < P; ++j) {
+            *(T*)(o + (long)(i * P + j) * xs) = w[j];
+#pragma unroll
+            for (int k = 0; k < VW; ++k) emax = fmaxf(emax, fabsf(w[j][k]));
+        }
     }
+    if (amax_out) block_amax(emax, amax_out);      // launcher: whole blocks only
 }
 
 // U[xi][kr][no] = (G g G^T)_xi with g[kh][kw] = w[kh'][kw'][..]; flip = 0: (kr,no) = (ci,co); flip = 1 (backward-data):
@@ -662,13 +686,21 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
     float* V = (float*)ws;
     float* E = (float*)((char*)ws + ss_align_up((size_t)XI * tiles * q.cin * 4, 256));
     float* part = (float*)((char*)E + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
+    // x3h weight gradient: the GEMM splits both operands in-kernel with one scale per operand, from the maxima the transforms report
+    unsigned int* am = nullptr;
+    if (q.x6 && ss_x3h_enabled() && (tiles * (q.cin / VW)) % 256 == 0 && (tiles * (q.cout / VW)) % 256 == 0) {
+        am = (unsigned int*)((char*)ws + ss_wino_wgrad_ws(q) - 256);
+        (void)hipMemsetAsync(am, 0, 8, s);
+    }
     hipLaunchKernelGGL((wino_input_kernel<R, false>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
-                       q.pt, q.pl, q.reflect, V);
+                       q.pt, q.pl, q.reflect, V, 0L, nullptr, am);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wino_dy_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, E);
+    hipLaunchKernelGGL(wino_dy_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, E,
+                       am ? am + 1 : nullptr);
     SS_LAUNCH_CHECK();
     WGradParams p{};
     p.x6 = q.x6;
+    p.h_amax = am;
     p.a = V; p.b = E; p.part = part;
     p.N = 1; p.AH = 1; p.AW = (int)tiles; p.Ca = q.cin; p.a_cs = q.cin;
     p.GH = 1; p.GW = (int)tiles; p.Cb = q.cout; p.b_cs = q.cout;
@@ -719,7 +751,7 @@ size_t ss_wino_wgrad_ws(const WinoProb& q) {
     int pps;
     const int splits = ss_wgrad_mfma_splits(tiles, q.cin, q.cout, &pps, XI);
     return ss_align_up((size_t)XI * tiles * q.cin * 4, 256) + ss_align_up((size_t)XI * tiles * q.cout * 4, 256) +
-           ss_align_up((size_t)XI * (splits + 1) * q.cin * q.cout * 4, 256);
+           ss_align_up((size_t)XI * (splits + 1) * q.cin * q.cout * 4, 256) + 256;      // + the x3h amax slot (last 256 bytes)
 }
 
 // dw (3,3,cin,cout) (+)= sum_pixels xpad[o + a] * dy[o]

@@ -383,7 +383,9 @@ def test_conv_x6_is_fp32_grade(case):
     the bf16 matrix cores, fp32 accumulation -- or, for the Winograd case with 128 / 256 / 512 channels (x6_trunk_wino), "x3h": two
     fp16 pieces with per-tile power-of-two scales, three products (csrc/gemm_x6p.hip).  Claim under test: the result is as close to the fp64 oracle as the
     v_mfma_f32_32x32x2_f32 path (SS_ALGO_MFMA) -- same 1e-4 parity bar, and rel-L2 error within 1.5x of the fp32-MFMA
-    path's own rounding error (both are ~1e-7 .. 1e-6; the weight gradient runs on the fp32 MFMA path in both)."""
+    path's own rounding error (both are ~1e-7 .. 1e-6), for the output, the data gradient and the weight gradient.  With SS_X3H
+    (default) the same kernels carry two fp16 pieces with one power-of-two scale per operand tensor (per tile for the Winograd
+    forward / data-gradient GEMMs) and three products."""
     E, LY, L = _mods()
     name, k, cin, cout, stride, padding, bias, act, transposed, n, h, w = case
     dev = torch.device("cuda:0")
@@ -416,10 +418,11 @@ def test_conv_x6_is_fp32_grade(case):
         assert_close(got_y, yr.detach(), f"{name}/{algo} fwd", rtol=1e-4)
         assert_close(got_dx, xr.grad, f"{name}/{algo} dx", rtol=2e-4)
         assert_close(got_dw, wr.grad, f"{name}/{algo} dw", rtol=2e-4)
-        errs[algo] = (rel_l2(got_y.numpy(), yr.detach().numpy()), rel_l2(got_dx.numpy(), xr.grad.numpy()))
-    print(f"{name}: rel-L2 vs fp64  fp32-MFMA y={errs[L.ALGO_MFMA][0]:.2e} dx={errs[L.ALGO_MFMA][1]:.2e}   "
-          f"x6 y={errs[L.ALGO_X6][0]:.2e} dx={errs[L.ALGO_X6][1]:.2e}")
-    for i in (0, 1):
+        errs[algo] = (rel_l2(got_y.numpy(), yr.detach().numpy()), rel_l2(got_dx.numpy(), xr.grad.numpy()),
+                      rel_l2(got_dw.numpy(), wr.grad.numpy()))
+    print(f"{name}: rel-L2 vs fp64  fp32-MFMA y={errs[L.ALGO_MFMA][0]:.2e} dx={errs[L.ALGO_MFMA][1]:.2e} dw={errs[L.ALGO_MFMA][2]:.2e}   "
+          f"x6/x3h y={errs[L.ALGO_X6][0]:.2e} dx={errs[L.ALGO_X6][1]:.2e} dw={errs[L.ALGO_X6][2]:.2e}")
+    for i in (0, 1, 2):
         assert errs[L.ALGO_X6][i] <= 1.5 * errs[L.ALGO_MFMA][i] + 2e-7, errs
 
 
@@ -461,9 +464,10 @@ def test_x3h_power_of_two_invariance(k2):
         gt.t.copy_(torch.ones_like(gt.t) * 0.25)
         arena.zero_grad()
         tape.backward()
-        outs.append((y.dense().cpu(), x.get_grad().dense().cpu()))
-    y0, dx0 = outs[0]
+        outs.append((y.dense().cpu(), x.get_grad().dense().cpu(), arena.grad("c/kernel").cpu().clone()))
+    y0, dx0, dw0 = outs[0]
     assert torch.isfinite(y0).all() and float(y0.abs().max()) > 0
     assert torch.equal(outs[1][0], y0 * (2.0 ** k2)), "forward is not exactly homogeneous in the input"
     assert torch.equal(outs[2][0], y0 * (2.0 ** k2)), "forward is not exactly homogeneous in the weights"
     assert torch.equal(outs[2][1], dx0 * (2.0 ** k2)), "data gradient is not exactly homogeneous in the weights"
+    assert torch.equal(outs[1][2], dw0 * (2.0 ** k2)), "weight gradient is not exactly homogeneous in the input"

@@ -173,8 +173,8 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "arithmetic": "fp32 storage and accumulation everywhere; large contractions on the bf16/fp16 matrix cores with fp32-grade "
-                             "operand splits: exact 3-way bf16 split x 6 products (x6), or, for the Winograd GEMMs, 2-way fp16 split with "
-                             "per-tile power-of-two scales x 3 products (x3h, SS_X3H=0 switches it off); measured error vs fp64 below the "
+                             "operand splits: 2-way fp16 split with power-of-two scales (per operand tensor; per tile in the Winograd GEMMs) "
+                             "x 3 products (x3h; SS_X3H=0: exact 3-way bf16 split x 6 products); measured error vs fp64 below the "
                              "v_mfma_f32_32x32x2_f32 path's (SS_X6=0)" if os.environ.get("SS_X6", "1") != "0" else "fp32 MFMA",
                "config": {"workload": f"CycleGAN(2xResNet-9 gen F={F} + 2xPatchGAN, image buffer 50) train_step + MultiResUNet(16) "
                                       f"train_step, {S}x{S} grayscale tiles, global batch {GB}" + (" [CycleGAN only]" if args.skip_unet else ""),

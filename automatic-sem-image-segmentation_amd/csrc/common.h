@@ -59,6 +59,14 @@ __device__ __forceinline__ void ss_split3x2(f32x2 v, unsigned int& h, unsigned i
     l = __builtin_bit_cast(unsigned int, lb);
 }
 
+// x3h scales: exponent e of a tensor maximum (max = f * 2^e, f in [0.5, 1)); 14 for an all-zero tensor; clamped from below so
+// that the scale 2^(14-e) stays finite for subnormal maxima (the results of such tensors underflow in fp32 as well)
+__device__ __forceinline__ int ss_amax_exp(float amax) {
+    int e = 14;
+    if (amax > 0.f) (void)frexpf(amax, &e);
+    return e < -100 ? -100 : e;
+}
+
 // Reflection / zero padding index map. Returns -1 when the tap falls into zero padding.
 __device__ __forceinline__ int ss_map_index(int i, int size, int reflect) {
     if (reflect) {

@@ -78,10 +78,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const int nchunks = Ktot / XK;
     float a_scale = 1.f, out_scale = 1.f;
     if constexpr (H) {
-        int ea = 14, ew = 14;
-        const float aa = __uint_as_float(p.h_amax[0]), aw = __uint_as_float(p.h_amax[1]);
-        if (aa > 0.f) (void)frexpf(aa, &ea);
-        if (aw > 0.f) (void)frexpf(aw, &ew);
+        const int ea = ss_amax_exp(__uint_as_float(p.h_amax[0])), ew = ss_amax_exp(__uint_as_float(p.h_amax[1]));
         a_scale = ldexpf(1.f, 14 - ea);
         out_scale = ldexpf(1.f, ea - 14 + ew - 14);
     }
@@ -291,9 +288,7 @@ __global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned s
         if (n < Npad && k < Ktot) {
             const long o = ((long)batch * Npad + n) * Ktot + k;
             if constexpr (H) {
-                int ew = 14;
-                const float aw = __uint_as_float(p.h_amax[1]);
-                if (aw > 0.f) (void)frexpf(aw, &ew);
+                const int ew = ss_amax_exp(__uint_as_float(p.h_amax[1]));
                 const float x0 = tl[tx][ty + 8 * i] * ldexpf(1.f, 14 - ew);
                 const _Float16 h0 = (_Float16)x0;
                 const _Float16 l0 = (_Float16)(x0 - (float)h0);
@@ -343,10 +338,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
     const int nchunks = (int)((pe - ps + XK - 1) / XK);
     float a_scale = 1.f, b_scale = 1.f, out_scale = 1.f;
     if constexpr (H) {
-        int ea = 14, eb = 14;
-        const float aa = __uint_as_float(p.h_amax[0]), ab = __uint_as_float(p.h_amax[1]);
-        if (aa > 0.f) (void)frexpf(aa, &ea);
-        if (ab > 0.f) (void)frexpf(ab, &eb);
+        const int ea = ss_amax_exp(__uint_as_float(p.h_amax[0])), eb = ss_amax_exp(__uint_as_float(p.h_amax[1]));
         a_scale = ldexpf(1.f, 14 - ea);
         b_scale = ldexpf(1.f, 14 - eb);
         out_scale = ldexpf(1.f, ea - 14 + eb - 14);

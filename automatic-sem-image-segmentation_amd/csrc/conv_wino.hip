@@ -178,9 +178,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         const int w0 = wave / wpg * wpg;
         mx = wmax[w0];
         for (int k = 1; k < wpg; ++k) mx = fmaxf(mx, wmax[w0 + k]);
-        int ex = 0;
-        if (mx > 0.f) (void)frexpf(mx, &ex);                       // mx = f * 2^ex, f in [0.5, 1)
-        else ex = 14;
+        const int ex = ss_amax_exp(mx);                            // mx = f * 2^ex, f in [0.5, 1)
         x3h_scale = ldexpf(1.f, 14 - ex);
         if (c == 0) tile_inv[tile] = ldexpf(1.f, ex - 14);
     }
@@ -412,8 +410,7 @@ __global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __rest
     float sc = 1.f;
     if (F16) {
         const float am = __uint_as_float(*amax_bits);
-        int ex = 14;
-        if (am > 0.f) (void)frexpf(am, &ex);
+        const int ex = ss_amax_exp(am);
         sc = ldexpf(1.f, 14 - ex);
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) *w_inv = ldexpf(1.f, ex - 14);
     }

@@ -13,7 +13,9 @@ c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("n", "ih", "iw", "cin", "in_cstride", "oh", "ow", "cout", "out_cstride",
                                      "kh", "kw", "stride", "pad_top", "pad_left", "pad_mode", "transposed", "act")] + \
-               [("act_alpha", c_f32), ("algo", c_i32)]
+               [("act_alpha", c_f32), ("algo", c_i32),
+                # optional x3h slots (include/semseg_hip.h): device uint32 with the bit pattern of max|x| / max|dy| + "already computed" flags
+                ("x_amax", c_vp), ("dy_amax", c_vp), ("x_amax_valid", c_i32), ("dy_amax_valid", c_i32)]
 
 
 class NormDesc(ctypes.Structure):
@@ -36,6 +38,7 @@ SIGNATURES = {
     "ss_version": (c_i32, []),
     "ss_status_string": (ctypes.c_char_p, [c_i32]),
     "ss_conv2d_workspace_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
+    "ss_conv2d_uses_amax": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_conv2d_bwd_data": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "ss_conv2d_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),

@@ -105,7 +105,8 @@ struct GConvParams {
     int32_t nbatch;               // >= 1 independent problems of identical shape (Winograd: 16 transform positions);
     int64_t in_bs, w_bs, out_bs;  // element strides between the batched problems
     int32_t ntaps;
-    const unsigned int* h_amax;   // x3h (conv_mfma_x6.hip): bit patterns of max|input|, max|weights| -- nullptr: three-piece bf16 arithmetic
+    const unsigned int* h_amax;   // x3h (conv_mfma_x6.hip): bit pattern of max|input| -- nullptr: three-piece bf16 arithmetic
+    const unsigned int* h_amax2;  //      ... of max|weights|
     GTap taps[SS_MAX_TAPS];
 };
 
@@ -122,7 +123,8 @@ struct WGradParams {
     int32_t splits, pix_per_split;
     int32_t nbatch;               // batched problems (Winograd); partials laid out [batch][split][M][Cb]
     int32_t x6;                   // 1: fp32-exact contraction on the bf16 matrix cores where the shape allows (conv_mfma_x6.hip)
-    const unsigned int* h_amax;   // x3h: bit patterns of max|a|, max|b| (one scale per operand tensor); nullptr: three-piece bf16 arithmetic
+    const unsigned int* h_amax;   // x3h: bit pattern of max|a| (one scale per operand tensor); nullptr: three-piece bf16 arithmetic
+    const unsigned int* h_amax2;  //      ... of max|b|
     int64_t a_bs, b_bs;
     int32_t ntaps;
     GTap taps[SS_MAX_TAPS];       // woff = destination offset of the tap block inside dw

@@ -13,6 +13,10 @@ struct ConvProb {
     int n, ih, iw, cin, in_cs;
     int oh, ow, cout, out_cs;
     int kh, kw, s, pt, pl, reflect;
+    // caller-owned x3h slots (ss_conv_desc::x_amax / dy_amax): bit pattern of max|x| / max|dy|; valid = already computed
+    unsigned int* x_amax = nullptr;
+    unsigned int* dy_amax = nullptr;
+    int x_valid = 0, dy_valid = 0;
 };
 
 // ---- small helper kernels -----------------------------------------------------------------------
@@ -299,27 +303,32 @@ inline void launch_amax_view(const float* v, long rows, int C, int cs, unsigned 
     const unsigned nb = (unsigned)(work / 4096 < 32 ? 32 : (work / 4096 > 1024 ? 1024 : work / 4096));
     hipLaunchKernelGGL(amax_view_kernel, dim3(nb), dim3(256), 0, s, v, rows, C, cs, out);
 }
-// slot[0] = max|view a|, slot[1] = max|view b| (weight gradients: both operands are activations)
-const unsigned int* x3h_amax2(const float* a, long arows, int aC, int acs, const float* b, long brows, int bC, int bcs, void* slot,
-                              hipStream_t s) {
-    unsigned int* am = (unsigned int*)slot;
-    (void)hipMemsetAsync(am, 0, 8, s);
-    launch_amax_view(a, arows, aC, acs, am, s);
-    launch_amax_view(b, brows, bC, bcs, am + 1, s);
-    return am;
+// maximum of an activation / gradient view for its x3h scale: into the caller's slot when there is one (computed only if the
+// caller does not vouch for its contents), else into `scratch`; returns the slot the kernels read
+const unsigned int* act_amax(const float* v, long rows, int C, int cs, unsigned int* ext, int ext_valid, unsigned int* scratch, hipStream_t s) {
+    unsigned int* slot = ext ? ext : scratch;
+    if (!(ext && ext_valid)) {
+        (void)hipMemsetAsync(slot, 0, 4, s);
+        launch_amax_view(v, rows, C, cs, slot, s);
+    }
+    return slot;
 }
-// slot[0] = max|activation view|, slot[1] = max|kernel tensor|; returns slot (device pointer), nullptr when x3h is off
-const unsigned int* x3h_amax(const float* act, long rows, int C, int cs, const float* w, long wn, void* slot, hipStream_t s) {
-    unsigned int* am = (unsigned int*)slot;
-    (void)hipMemsetAsync(am, 0, 8, s);
-    launch_amax_view(act, rows, C, cs, am, s);
-    hipLaunchKernelGGL(amax_view_kernel, dim3(wn / 8192 < 16 ? 16 : (wn / 8192 > 256 ? 256 : (unsigned)(wn / 8192))), dim3(256), 0, s, w, 1L, (int)wn, (int)wn, am + 1);
-    return am;
+const unsigned int* weight_amax(const float* w, long wn, unsigned int* scratch, hipStream_t s) {
+    (void)hipMemsetAsync(scratch, 0, 4, s);
+    hipLaunchKernelGGL(amax_view_kernel, dim3(wn / 8192 < 16 ? 16 : (wn / 8192 > 256 ? 256 : (unsigned)(wn / 8192))), dim3(256), 0, s, w, 1L, (int)wn, (int)wn, scratch);
+    return scratch;
 }
 bool x3h_direct_wanted(int algo, int cred, int cout) {
     static const bool off = getenv("SS_X3H_DIRECT") && getenv("SS_X3H_DIRECT")[0] == '0';
     return !off && ss_x3h_enabled() && x6_wanted(algo) && cred % 32 == 0 && cout >= 32;
 }
+// Which tensor maxima a pass computes / reads.  The passes FILL the slots exactly when these say so (whatever kernel ends up
+// running), so ss_conv2d_uses_amax can promise the caller that a slot is valid afterwards.
+bool wino_fwd_prob(const ConvProb& c, int algo, WinoProb* q);
+bool wino_dgrad_prob(const ConvProb& c, int algo, WinoProb* q);
+bool need_x_amax_fwd(const ConvProb& c, int algo);
+bool need_dy_amax_dgrad(const ConvProb& c, int algo);
+bool need_amax_wgrad(const ConvProb& c, int algo);
 
 size_t gconv_ws_bytes(int algo, const GConvParams& p) {
     if (!gconv_two_stage(algo, p)) return 256 + x6_planes_ub(p.Cin, p.Cout, p.ntaps);
@@ -418,9 +427,14 @@ int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bia
     if (wino_fwd_prob(c, algo, &q))
         return ss_wino_conv_fwd(q, x, w, c.cin, c.cout, 0, bias, y, act, alpha, accumulate, ws, ws_bytes, s);
     GConvParams p = fwd_params(c, x, w, bias, y, act, alpha, accumulate);
-    if (x3h_direct_wanted(algo, c.cin, c.cout) && use_x6(algo, p) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p) + 256)
-        p.h_amax = x3h_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, w, (long)c.kh * c.kw * c.cin * c.cout,
-                            (char*)ws + ss_gconv_x6_planes_bytes(p), s);
+    if (need_x_amax_fwd(c, algo) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p) + 256) {
+        unsigned int* sl = (unsigned int*)((char*)ws + ss_gconv_x6_planes_bytes(p));
+        const unsigned int* ax = act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
+        if (use_x6(algo, p)) {
+            p.h_amax = ax;
+            p.h_amax2 = weight_amax(w, (long)c.kh * c.kw * c.cin * c.cout, sl + 1, s);
+        }
+    }
     return run_gconv(algo, p, ws, ws_bytes, s);
 }
 
@@ -467,9 +481,11 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     p.in = dy; p.w = wt; p.bias = bias;
     p.N = c.n; p.IH = c.oh; p.IW = c.ow; p.Cin = c.cout; p.in_cs = c.out_cs;
     p.in_s = 1; p.Cout = c.cin; p.ldb = c.cin; p.reflect = 0; p.act = act; p.alpha = alpha;
-    if (x3h_direct_wanted(algo, c.cout, c.cin) && gws_bytes >= x6_planes_ub(c.cout, c.cin, T) && (long)c.n * c.oh * c.ow >= 1024)
-        p.h_amax = x3h_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, w, (long)T * c.cin * c.cout,
-                            (char*)gws + x6_planes_ub(c.cout, c.cin, T) - 256, s);
+    if (need_dy_amax_dgrad(c, algo) && gws_bytes >= x6_planes_ub(c.cout, c.cin, T)) {
+        unsigned int* sl = (unsigned int*)((char*)gws + x6_planes_ub(c.cout, c.cin, T) - 256);
+        p.h_amax = act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl, s);
+        p.h_amax2 = weight_amax(w, (long)T * c.cin * c.cout, sl + 1, s);
+    }
 
     if (c.reflect) {
         const int PH = c.oh + c.kh - 1, PW = c.ow + c.kw - 1;
@@ -522,6 +538,25 @@ int wgrad_c1_mode(const ConvProb& c, int algo) {
     if (c.cout == 1 && c.cin > 1 && ss_wgrad_c1_ok(c.n, c.ih, c.iw, c.cin, c.kh, c.kw)) return 0;
     if (c.cin == 1 && c.cout > 1 && ss_wgrad_c1_ok(c.n, c.oh, c.ow, c.cout, c.kh, c.kw)) return 1;
     return -1;
+}
+
+bool need_x_amax_fwd(const ConvProb& c, int algo) {
+    WinoProb q;
+    return x3h_direct_wanted(algo, c.cin, c.cout) && (long)c.n * c.oh * c.ow >= 1024 && c.in_cs % 4 == 0 &&
+           c.kh * c.kw <= SS_MAX_TAPS && !wino_fwd_prob(c, algo, &q);
+}
+bool need_dy_amax_dgrad(const ConvProb& c, int algo) {
+    WinoProb q;
+    return x3h_direct_wanted(algo, c.cout, c.cin) && (long)c.n * c.oh * c.ow >= 1024 && c.out_cs % 4 == 0 &&
+           c.kh * c.kw <= SS_MAX_TAPS && !(c.reflect && c.s != 1) && !wino_dgrad_prob(c, algo, &q);
+}
+bool need_amax_wgrad(const ConvProb& c, int algo) {
+    WinoProb q;
+    if (c.kh * c.kw > SS_MAX_TAPS || algo == SS_ALGO_DIRECT || wino_fwd_prob(c, algo, &q) || wgrad_c1_mode(c, algo) >= 0 ||
+        wgrad_two_stage(c, algo))
+        return false;
+    return x6_wanted(algo) && ss_x3h_enabled() && x3h_direct_wanted(algo, 32, 32) && c.cin % 32 == 0 && c.in_cs % 4 == 0 &&
+           c.cout >= 32 && c.cout % 4 == 0 && c.out_cs % 4 == 0 && c.ow >= 4;
 }
 
 size_t bwd_weight_ws(const ConvProb& c) {
@@ -605,9 +640,12 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
     }
     p.splits = ss_wgrad_mfma_splits((long)c.n * c.oh * c.ow, p.ntaps * p.Ca, p.Cb, &pps);
     p.pix_per_split = pps;
-    if (p.x6 && ss_x3h_enabled() && x3h_direct_wanted(algo, 32, 32) && ss_wgrad_x6_ok(p))
-        p.h_amax = x3h_amax2(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs,
-                             (char*)ws + ss_align_up((size_t)p.splits * p.ntaps * p.Ca * p.Cb * sizeof(float), 256), s);
+    if (need_amax_wgrad(c, algo)) {
+        unsigned int* sl = (unsigned int*)((char*)ws + ss_align_up((size_t)p.splits * p.ntaps * p.Ca * p.Cb * sizeof(float), 256));
+        const unsigned int* ax = act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
+        const unsigned int* ay = act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl + 1, s);
+        if (p.x6 && ss_wgrad_x6_ok(p)) { p.h_amax = ax; p.h_amax2 = ay; }
+    }
     return ss_launch_wgrad_mfma(p, dw, c.cout, accumulate, s);
 }
 
@@ -622,13 +660,19 @@ bool valid_desc(const ss_conv_desc* d) {
 }
 
 ConvProb plain(const ss_conv_desc* d) {
-    return ConvProb{d->n, d->ih, d->iw, d->cin, d->in_cstride, d->oh, d->ow, d->cout, d->out_cstride,
-                    d->kh, d->kw, d->stride, d->pad_top, d->pad_left, d->pad_mode == SS_PAD_REFLECT};
+    ConvProb c{d->n, d->ih, d->iw, d->cin, d->in_cstride, d->oh, d->ow, d->cout, d->out_cstride,
+               d->kh, d->kw, d->stride, d->pad_top, d->pad_left, d->pad_mode == SS_PAD_REFLECT};
+    c.x_amax = (unsigned int*)d->x_amax; c.x_valid = d->x_amax_valid;
+    c.dy_amax = (unsigned int*)d->dy_amax; c.dy_valid = d->dy_amax_valid;
+    return c;
 }
-// adjoint conv of a transposed conv: output space -> input space
+// adjoint conv of a transposed conv: output space -> input space (its "x" is the transposed conv's dy and vice versa)
 ConvProb adjoint(const ss_conv_desc* d) {
-    return ConvProb{d->n, d->oh, d->ow, d->cout, d->out_cstride, d->ih, d->iw, d->cin, d->in_cstride,
-                    d->kh, d->kw, d->stride, d->pad_top, d->pad_left, 0};
+    ConvProb c{d->n, d->oh, d->ow, d->cout, d->out_cstride, d->ih, d->iw, d->cin, d->in_cstride,
+               d->kh, d->kw, d->stride, d->pad_top, d->pad_left, 0};
+    c.x_amax = (unsigned int*)d->dy_amax; c.x_valid = d->dy_amax_valid;
+    c.dy_amax = (unsigned int*)d->x_amax; c.dy_valid = d->x_amax_valid;
+    return c;
 }
 
 }  // namespace
@@ -659,6 +703,21 @@ size_t ss_conv2d_workspace_bytes(const ss_conv_desc* d, int pass) {
     if (pass == SS_PASS_FWD) return bwd_data_ws(adjoint(d));
     if (pass == SS_PASS_BWD_DATA) return fwd_ws(adjoint(d), d->algo);
     return bwd_weight_ws(adjoint(d)) + colsum_b;
+}
+
+// which tensor maxima a pass reads (bit 0: of x, bit 1: of dy, in the caller's naming) -- mirrors the dispatch of conv_fwd /
+// conv_bwd_data / conv_bwd_weight: only the direct x3h kernels use per-tensor scales (the Winograd passes scale per tile)
+int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass) {
+    if (!valid_desc(d)) return 0;
+    const ConvProb c = d->transposed ? adjoint(d) : plain(d);
+    // pass and roles inside the (adjoint) problem: bit 0 = its x, bit 1 = its dy
+    const int p2 = !d->transposed ? pass : (pass == SS_PASS_FWD ? SS_PASS_BWD_DATA : (pass == SS_PASS_BWD_DATA ? SS_PASS_FWD : pass));
+    int roles;
+    if (p2 == SS_PASS_FWD) roles = need_x_amax_fwd(c, d->algo) ? 1 : 0;
+    else if (p2 == SS_PASS_BWD_DATA) roles = need_dy_amax_dgrad(c, d->algo) ? 2 : 0;
+    else roles = need_amax_wgrad(c, d->algo) ? 3 : 0;
+    if (!d->transposed) return roles;
+    return ((roles & 1) ? 2 : 0) | ((roles & 2) ? 1 : 0);
 }
 
 int ss_conv2d_fwd(const ss_conv_desc* d, const float* x, const float* w, const float* bias, float* y,

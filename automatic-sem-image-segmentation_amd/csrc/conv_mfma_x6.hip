@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const int nchunks = Ktot / XK;
     float a_scale = 1.f, out_scale = 1.f;
     if constexpr (H) {
-        const int ea = ss_amax_exp(__uint_as_float(p.h_amax[0])), ew = ss_amax_exp(__uint_as_float(p.h_amax[1]));
+        const int ea = ss_amax_exp(__uint_as_float(p.h_amax[0])), ew = ss_amax_exp(__uint_as_float(p.h_amax2[0]));
         a_scale = ldexpf(1.f, 14 - ea);
         out_scale = ldexpf(1.f, ea - 14 + ew - 14);
     }
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned s
         if (n < Npad && k < Ktot) {
             const long o = ((long)batch * Npad + n) * Ktot + k;
             if constexpr (H) {
-                const int ew = ss_amax_exp(__uint_as_float(p.h_amax[1]));
+                const int ew = ss_amax_exp(__uint_as_float(p.h_amax2[0]));
                 const float x0 = tl[tx][ty + 8 * i] * ldexpf(1.f, 14 - ew);
                 const _Float16 h0 = (_Float16)x0;
                 const _Float16 l0 = (_Float16)(x0 - (float)h0);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
     const int nchunks = (int)((pe - ps + XK - 1) / XK);
     float a_scale = 1.f, b_scale = 1.f, out_scale = 1.f;
     if constexpr (H) {
-        const int ea = ss_amax_exp(__uint_as_float(p.h_amax[0])), eb = ss_amax_exp(__uint_as_float(p.h_amax[1]));
+        const int ea = ss_amax_exp(__uint_as_float(p.h_amax[0])), eb = ss_amax_exp(__uint_as_float(p.h_amax2[0]));
         a_scale = ldexpf(1.f, 14 - ea);
         b_scale = ldexpf(1.f, 14 - eb);
         out_scale = ldexpf(1.f, ea - 14 + eb - 14);

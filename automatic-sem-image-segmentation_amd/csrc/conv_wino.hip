@@ -698,6 +698,7 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
     WGradParams p{};
     p.x6 = q.x6;
     p.h_amax = am;
+    p.h_amax2 = am ? am + 1 : nullptr;
     p.a = V; p.b = E; p.part = part;
     p.N = 1; p.AH = 1; p.AW = (int)tiles; p.Ca = q.cin; p.a_cs = q.cin;
     p.GH = 1; p.GW = (int)tiles; p.Cb = q.cout; p.b_cs = q.cout;

@@ -97,7 +97,7 @@ TIMER = KernelTimer()
 class Act:
     """An NHWC activation view: channels [c0, c0+c) of a base tensor [n,h,w,cs]."""
 
-    __slots__ = ("t", "c0", "c", "grad", "grad_init", "requires_grad", "parent")
+    __slots__ = ("t", "c0", "c", "grad", "grad_init", "requires_grad", "parent", "amax", "amax_valid")
 
     def __init__(self, t, c0=0, c=None, requires_grad=True, parent=None):
         assert t.dim() == 4 and t.dtype == torch.float32 and t.is_contiguous()
@@ -107,6 +107,8 @@ class Act:
         self.grad_init = False
         self.requires_grad = requires_grad
         self.parent = parent
+        self.amax = None          # device uint32[1]: bit pattern of max|view| once a conv pass has computed it (x3h scale)
+        self.amax_valid = False
 
     # geometry
     @property
@@ -123,6 +125,13 @@ class Act:
     def device(self): return self.t.device
     @property
     def ptr(self): return ctypes.c_void_p(self.t.data_ptr() + 4 * self.c0)
+
+    def amax_slot(self):
+        """Caller-owned slot for ss_conv_desc.x_amax / dy_amax: the first conv pass that needs this tensor's maximum leaves it
+        here, later passes over the same (unchanged) tensor reuse it instead of scanning the tensor again."""
+        if self.amax is None:
+            self.amax = torch.zeros(1, dtype=torch.int32, device=self.t.device)
+        return ctypes.c_void_p(self.amax.data_ptr())
 
     @staticmethod
     def empty(n, h, w, c, device, requires_grad=True):

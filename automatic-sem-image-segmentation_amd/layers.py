@@ -41,6 +41,7 @@ class Conv2D:
         if use_bias:
             arena.declare(f"{name}/bias", (cout,))
         self._desc_cache = {}
+        self._amax_cache = {}
         self.profile_tag = None     # set by bench.py to time this layer's forward launch with HIP events
 
     def out_hw(self, h, w):
@@ -87,8 +88,16 @@ class Conv2D:
         nb = lib.ss_conv2d_workspace_bytes(ctypes.byref(d), L.PASS_FWD)
         ws = workspace(nb, x.device)
         e0 = TIMER.start() if (TIMER.enabled and self.profile_tag) else None
+        uses = self._uses_amax(d, L.PASS_FWD)
+        if uses & 1:        # this pass needs max|x|: it computes it into x's slot unless an earlier pass already has
+            d.x_amax, d.x_amax_valid = x.amax_slot(), 1 if x.amax_valid else 0
+        else:
+            d.x_amax, d.x_amax_valid = None, 0
+        d.dy_amax, d.dy_amax_valid = None, 0
         L.check(lib.ss_conv2d_fwd(ctypes.byref(d), x.ptr, _p(w), _p(b), y.ptr, _p(ws), ws.numel(), _stream()),
                 f"conv2d_fwd[{self.name}]")
+        if uses & 1:
+            x.amax_valid = True
         if e0 is not None:
             TIMER.stop(e0, self.profile_tag, x.n)
         param_grads = tape.param_grads
@@ -112,19 +121,40 @@ class Conv2D:
                 wsw = workspace(nbw, x.device)
                 gw = self.arena.grad(f"{self.name}/kernel")
                 gb = self.arena.grad(f"{self.name}/bias") if self.use_bias else None
+                uses = self._uses_amax(dd, L.PASS_BWD_WEIGHT)
+                dd.x_amax, dd.x_amax_valid = (x.amax_slot(), 1 if x.amax_valid else 0) if uses & 1 else (None, 0)
+                dd.dy_amax, dd.dy_amax_valid = (dy.amax_slot(), 1 if dy.amax_valid else 0) if uses & 2 else (None, 0)
                 L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), x.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wsw), wsw.numel(),
                                                  _stream()), f"conv2d_bwd_weight[{self.name}]")
+                if uses & 1:
+                    x.amax_valid = True
+                if uses & 2:
+                    dy.amax_valid = True
                 self.arena.note_done(pnames)
             if x.requires_grad:
                 dx, accum = x.grad_target()
                 ddx = dd if dx.cs == x.cs else self.desc_with_in_cs(dd, dx.cs)
                 nbd = lib.ss_conv2d_workspace_bytes(ctypes.byref(ddx), L.PASS_BWD_DATA)
                 wsd = workspace(nbd, x.device)
+                uses = self._uses_amax(ddx, L.PASS_BWD_DATA)
+                ddx.x_amax, ddx.x_amax_valid = None, 0
+                ddx.dy_amax, ddx.dy_amax_valid = (dy.amax_slot(), 1 if dy.amax_valid else 0) if uses & 2 else (None, 0)
                 L.check(lib.ss_conv2d_bwd_data(ctypes.byref(ddx), dy.ptr, _p(w), dx.ptr, accum, _p(wsd), wsd.numel(),
                                                _stream()), f"conv2d_bwd_data[{self.name}]")
+                if uses & 2:
+                    dy.amax_valid = True
 
         tape.record(backward)
         return y
+
+    def _uses_amax(self, d, pass_):
+        """ss_conv2d_uses_amax(d, pass), cached per geometry: bit 0 = the pass reads (and leaves in the slot) max|x|, bit 1 = max|dy|."""
+        key = (d.n, d.ih, d.iw, d.in_cstride, d.out_cstride, d.oh, d.ow, pass_)
+        u = self._amax_cache.get(key)
+        if u is None:
+            u = L.load().ss_conv2d_uses_amax(ctypes.byref(d), pass_)
+            self._amax_cache[key] = u
+        return u
 
     @staticmethod
     def desc_with_out_cs(d, cs):

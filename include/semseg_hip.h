@@ -81,7 +81,18 @@ typedef struct ss_conv_desc {
     int32_t act;
     float act_alpha;
     int32_t algo;
+    /* Optional (may be NULL / 0): caller-owned device uint32 slots for the bit pattern of max|x| and max|dy| -- the power-of-two
+     * scales of the fp16 two-piece ("x3h") contraction.  A pass that needs a maximum (ss_conv2d_uses_amax) computes it INTO the
+     * slot unless the matching *_valid flag says the slot already holds it, so that a tensor consumed by several passes (x:
+     * forward + weight gradient, dy: data + weight gradient) is scanned once.  Without slots every pass scans for itself. */
+    void* x_amax;
+    void* dy_amax;
+    int32_t x_amax_valid;
+    int32_t dy_amax_valid;
 } ss_conv_desc;
+
+/* bit 0: this pass reads max|x| (and leaves it in d->x_amax when that is set), bit 1: likewise max|dy|.  Pure function of d. */
+int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass);
 
 size_t ss_conv2d_workspace_bytes(const ss_conv_desc* d, int pass);
 int ss_conv2d_fwd(const ss_conv_desc* d, const float* x, const float* w, const float* bias, float* y,

@@ -257,8 +257,8 @@ bool use_x6(int algo, const GConvParams& p) {
 }
 // upper bound of the weight-plane scratch of a gather conv with `cred` reduction channels, `cout` outputs, `ntaps` taps
 size_t x6_planes_ub(int cred, int cout, int ntaps) {
-    if (cred % 32 != 0 || cout < 32) return 0;
-    return ss_align_up((size_t)3 * ss_x6_npad(cout) * ntaps * cred * sizeof(unsigned short), 256) + 256;   // + the x3h amax slot
+    if (cred < 16 || cout < 32) return 0;
+    return ss_align_up((size_t)3 * ss_x6_npad(cout) * ntaps * ((cred + 31) / 32 * 32) * sizeof(unsigned short), 256) + 256;   // + the x3h amax slot
 }
 
 // ---- x3h for the direct (non-Winograd) x6 convolutions: one power-of-two scale per operand TENSOR, from max|.| ----------------------
@@ -320,7 +320,7 @@ const unsigned int* weight_amax(const float* w, long wn, unsigned int* scratch, 
 }
 bool x3h_direct_wanted(int algo, int cred, int cout) {
     static const bool off = getenv("SS_X3H_DIRECT") && getenv("SS_X3H_DIRECT")[0] == '0';
-    return !off && ss_x3h_enabled() && x6_wanted(algo) && cred % 32 == 0 && cout >= 32;
+    return !off && ss_x3h_enabled() && x6_wanted(algo) && cred >= 16 && cout >= 32;
 }
 // Which tensor maxima a pass computes / reads.  The passes FILL the slots exactly when these say so (whatever kernel ends up
 // running), so ss_conv2d_uses_amax can promise the caller that a slot is valid afterwards.
@@ -542,12 +542,12 @@ int wgrad_c1_mode(const ConvProb& c, int algo) {
 
 bool need_x_amax_fwd(const ConvProb& c, int algo) {
     WinoProb q;
-    return x3h_direct_wanted(algo, c.cin, c.cout) && (long)c.n * c.oh * c.ow >= 1024 && c.in_cs % 4 == 0 &&
+    return x3h_direct_wanted(algo, c.cin, c.cout) && (long)c.n * c.oh * c.ow >= 1024 &&
            c.kh * c.kw <= SS_MAX_TAPS && !wino_fwd_prob(c, algo, &q);
 }
 bool need_dy_amax_dgrad(const ConvProb& c, int algo) {
     WinoProb q;
-    return x3h_direct_wanted(algo, c.cout, c.cin) && (long)c.n * c.oh * c.ow >= 1024 && c.out_cs % 4 == 0 &&
+    return x3h_direct_wanted(algo, c.cout, c.cin) && (long)c.n * c.oh * c.ow >= 1024 &&
            c.kh * c.kw <= SS_MAX_TAPS && !(c.reflect && c.s != 1) && !wino_dgrad_prob(c, algo, &q);
 }
 bool need_amax_wgrad(const ConvProb& c, int algo) {

@@ -21,6 +21,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // dword-aligned 16-byte load
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -76,6 +77,8 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const long m0 = (long)(tile / gridN) * BM;
     const int n0 = (tile % gridN) * BN;
     const int nchunks = Ktot / XK;
+    const int Cq = Ktot / p.ntaps;       // reduction channels per tap, padded to a multiple of 32
+    const bool ragged = Cq != p.Cin || (p.in_cs & 3) != 0 || (((uintptr_t)p.in) & 15) != 0;
     float a_scale = 1.f, out_scale = 1.f;
     if constexpr (H) {
         const int ea = ss_amax_exp(__uint_as_float(p.h_amax[0])), ew = ss_amax_exp(__uint_as_float(p.h_amax2[0]));
@@ -133,14 +136,39 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
 
     auto load_tiles = [&](auto setc, int k0) {
         constexpr int S = decltype(setc)::value;
-        const int t = k0 / p.Cin;                      // block-uniform
-        const int ci0 = k0 - t * p.Cin;
-        const float* abase = g_in + ci0 + c4a * 4;
+        const int t = k0 / Cq;                         // block-uniform
+        const int ci0 = k0 - t * Cq;
+        if (!ragged) {
+            const float* abase = g_in + ci0 + c4a * 4;
 #pragma unroll
-        for (int j = 0; j < AU; ++j) {
-            const int off = offtab[(arow + 32 * j) * p.ntaps + t];
-            ra[S][j] = *(const f32x4*)(abase + (off < 0 ? 0 : off));
-            ra_ok[S][j] = off >= 0;
+            for (int j = 0; j < AU; ++j) {
+                const int off = offtab[(arow + 32 * j) * p.ntaps + t];
+                ra[S][j] = *(const f32x4*)(abase + (off < 0 ? 0 : off));
+                ra_ok[S][j] = off >= 0;
+            }
+        } else {
+            // any channel count / pixel stride (the MultiResUNet's odd widths): the reduction index runs over (tap, ci padded to a
+            // multiple of 32 -- the weight planes hold zeros there); a 4-channel unit is fetched with ONE dword-aligned
+            // global_load_dwordx4 when it lies fully inside the pixel's channels, element-wise when it straddles the end
+            const int ci = ci0 + c4a * 4;
+            const int nin = p.Cin - ci;                // channels of this unit that exist
+#pragma unroll
+            for (int j = 0; j < AU; ++j) {
+                const int off = offtab[(arow + 32 * j) * p.ntaps + t];
+                const bool ok = off >= 0 && nin > 0;
+                const float* ptr = g_in + (ok ? off + ci : 0);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (nin >= 4) {
+                    const f32x4u u = *(const f32x4u*)ptr;
+                    v = f32x4{u[0], u[1], u[2], u[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        if (e < nin) v[e] = ptr[e];
+                }
+                ra[S][j] = v;
+                ra_ok[S][j] = ok;
+            }
         }
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
@@ -276,8 +304,9 @@ __global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned s
         const int k = k0 + ty + 8 * i, n = n0 + tx;
         float v = 0.f;
         if (k < Ktot && n < p.Cout) {
-            const int t = k / p.Cin, ci = k - t * p.Cin;
-            v = w[p.taps[t].woff + (long)ci * p.ldb + n];
+            const int Cq = Ktot / p.ntaps;
+            const int t = k / Cq, ci = k - t * Cq;
+            if (ci < p.Cin) v = w[p.taps[t].woff + (long)ci * p.ldb + n];
         }
         tl[ty + 8 * i][tx] = v;
     }
@@ -543,19 +572,19 @@ int ss_x6_npad(int cout) { return (cout + 127) / 128 * 128; }
 
 bool ss_gconv_x6_ok(const GConvParams& p) {
     const long in_elems = (long)p.N * p.IH * p.IW * p.in_cs;       // per batched problem: the LDS offset table holds 32-bit element offsets
-    return p.ntaps >= 1 && p.Cin % 32 == 0 && p.in_cs % 4 == 0 && (((uintptr_t)p.in) & 15) == 0 && p.Cout >= 32 &&
+    return p.ntaps >= 1 && p.Cin >= 16 && p.Cout >= 32 &&
            in_elems < (1L << 31) && (long)p.N * p.OHc * p.OWc < (1L << 31) && (p.nbatch <= 1 || (p.in_bs % 4 == 0));
 }
 
 size_t ss_gconv_x6_planes_bytes(const GConvParams& p) {
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
-    return ss_align_up((size_t)3 * nb * ss_x6_npad(p.Cout) * p.ntaps * p.Cin * sizeof(unsigned short), 256);
+    return ss_align_up((size_t)3 * nb * ss_x6_npad(p.Cout) * p.ntaps * ((p.Cin + 31) / 32 * 32) * sizeof(unsigned short), 256);
 }
 
 // weights of `p` (fp32, addressed through p.w / taps / ldb / w_bs) -> the three K-contiguous bf16 planes
 int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s) {
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
-    const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * p.Cin;
+    const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * ((p.Cin + 31) / 32 * 32);
     const long plane_elems = (long)nb * Npad * Ktot;
     if (p.h_amax) hipLaunchKernelGGL(wprep_x6_kernel<true>, dim3((Ktot + 31) / 32, Npad / 32, nb), dim3(256), 0, s, p, planes, plane_elems, Npad, Ktot);
     else hipLaunchKernelGGL(wprep_x6_kernel<false>, dim3((Ktot + 31) / 32, Npad / 32, nb), dim3(256), 0, s, p, planes, plane_elems, Npad, Ktot);
@@ -568,7 +597,7 @@ int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipSt
     if (M == 0) return SS_OK;
     if (!ss_gconv_x6_ok(p)) return SS_ERR_UNSUPPORTED;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
-    const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * p.Cin;
+    const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * ((p.Cin + 31) / 32 * 32);
     const long plane_elems = (long)nb * Npad * Ktot;
     // tile choice: the largest tile that still yields >= ~200 workgroups (small grids at per-GPU batch 1 want more, smaller ones)
     const long want = 200;      // swept at per-GPU batch 1 / 2 (200 / 600 / 1200): 200 is the fastest

@@ -215,6 +215,14 @@ class CycleGanModel:
         return self._update_metrics()
 
     def _train_step_dual(self, real_a, real_b, one, zero, world):
+        try:
+            return self._train_step_dual_body(real_a, real_b, one, zero, world)
+        finally:
+            # whatever happened (a kernel error in one of the chains), leave the arenas in their single-chain state
+            for net in (self.gen_a, self.gen_b):
+                net.arena.defer_hooks = False
+
+    def _train_step_dual_body(self, real_a, real_b, one, zero, world):
         """The same step as two CONCURRENT kernel chains on two HIP streams.  In the generator phase the A->B->A chain
         (G_a on [real_a; real_b], G_b on fake_b, D_b on fake_b and their losses) and the B->A->B chain share nothing but
         read-only weights and inputs; each has its own tape, scratch buffer and gradient buffer (both chains produce gradients
@@ -550,6 +558,10 @@ class CycleGAN:
                                          gaussian_noise_value=self.gaussian_noise_value)
         D.broadcast_params([self.gen_a, self.gen_b, self.disc_a, self.disc_b])
         D.enable_overlap([self.gen_a, self.gen_b, self.disc_a, self.disc_b])
+        if D.world_size() > 1:
+            # per-rank image buffers draw from per-rank streams (the reference's single process has one module-level stream)
+            self.image_pool_a.rng = random.Random(1000003 * (self.seed + 1) + 2 * D.rank())
+            self.image_pool_b.rng = random.Random(1000003 * (self.seed + 1) + 2 * D.rank() + 1)
         model = CycleGanModel(generator_a=self.gen_a, generator_b=self.gen_b, discriminator_a=self.disc_a,
                               discriminator_b=self.disc_b, image_pool_a=self.image_pool_a, image_pool_b=self.image_pool_b,
                               lambda_cycle_a=self.lambda_cycle_a, lambda_cycle_b=self.lambda_cycle_b,
@@ -563,12 +575,24 @@ class CycleGAN:
         model.use_binary_crossentropy_a = self.use_binary_crossentropy      # CycleGAN.py:117-121
         return model
 
-    # LSGAN targets, kept for API compatibility / documentation (the kernels implement them)
+    # LSGAN losses with label smoothing (CycleGAN.py:301-308).  train_step calls the same kernel with the same targets; these
+    # methods give the reference's callable surface: NHWC device tensors (or Acts) in, python floats out.
+    @staticmethod
+    def _mse_to(t, target):
+        a = t if isinstance(t, Act) else Act(t.to(dtype=torch.float32).contiguous(), requires_grad=False)
+        slot = torch.zeros(1, dtype=torch.float32, device=a.device)
+        losses.mse_const(a, target, 1.0, slot, want_grad=False)
+        return float(slot.item())
+
     def generator_loss_fn(self, fake):
-        raise NotImplementedError("losses run as HIP kernels inside CycleGanModel.train_step")
+        ls = self.label_smoothing_factor
+        return self._mse_to(fake, 1.0 - ls + ls / 2)
 
     def discriminator_loss_fn(self, real, fake):
-        raise NotImplementedError("losses run as HIP kernels inside CycleGanModel.train_step")
+        ls = self.label_smoothing_factor
+        real_loss = self._mse_to(real, 1.0 - ls + ls / 2)
+        fake_loss = self._mse_to(fake, ls / 2)
+        return (real_loss + fake_loss) * 0.5, real_loss, fake_loss
 
     def linear_decay(self, epoch, current_lr=None):
         if epoch < self.decay_epoch:
@@ -647,6 +671,7 @@ class CycleGAN:
             plotter = GANMonitor(test_a, test_b, os.path.join(self.root_dir, '2_CycleGAN', 'images', self.prefix), num_img=2)
         log_path = os.path.join(self.model_dir, self.prefix, 'training_log.csv')
         rank, world = D.rank(), D.world_size()
+        D.check_batch_divisible(self.batch_size, world, 'CycleGAN.batch_size')
         for epoch in range(self.epochs):
             if self.use_linear_decay and self.apply_lr_decay_to_adams:
                 lr = self.linear_decay(epoch)

@@ -302,6 +302,7 @@ class UNet:
         log_path = os.path.join(self.model_dir, self.prefix, 'training_log.csv')
         best = float('inf')
         rank, world = D.rank(), D.world_size()
+        D.check_batch_divisible(self.batch_size, world, 'UNet.batch_size')
         for epoch in range(self.epochs):
             if self.lr_decay == 'STEP_DECAY':
                 self.model.optimizer.learning_rate = self.step_decay(epoch, self.model.optimizer.learning_rate)
@@ -313,7 +314,15 @@ class UNet:
             np.random.shuffle(order)
             for idx in order:
                 x, y = self.training_data[idx]
-                per = max(len(x) // world, 1)
+                # ragged last batch of the on-demand loader (ceil length, UNet_Segmentation.py:111-112): every rank trims it to the
+                # same multiple of the world size, so the collectives stay matched; a batch smaller than the world is skipped
+                per = len(x) // world
+                if per == 0:
+                    D.warn_once('a partial batch smaller than the number of ranks was skipped (data parallel)')
+                    continue
+                if per * world != len(x):
+                    D.warn_once('partial last batch trimmed to a multiple of the number of ranks (data parallel)')
+                    x, y = x[:per * world], y[:per * world]
                 m = self.model.train_step((x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]))
                 for k in tot:
                     tot[k] += m[k] * len(x)     # Keras weights the running means by batch size

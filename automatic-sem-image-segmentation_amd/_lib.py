@@ -10,16 +10,24 @@ c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
 
-class ConvDesc(ctypes.Structure):
-    _fields_ = [(n, c_i32) for n in ("n", "ih", "iw", "cin", "in_cstride", "oh", "ow", "cout", "out_cstride",
+class _SizedDesc(ctypes.Structure):
+    """First field = sizeof(struct) (checked by the library), second = ss_dtype of the activations; positional constructor
+    arguments start at the third field."""
+
+    def __init__(self, *args, dtype=0, **kw):
+        super().__init__(ctypes.sizeof(type(self)), dtype, *args, **kw)
+
+
+class ConvDesc(_SizedDesc):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("dtype", c_i32)] + [(n, c_i32) for n in ("n", "ih", "iw", "cin", "in_cstride", "oh", "ow", "cout", "out_cstride",
                                      "kh", "kw", "stride", "pad_top", "pad_left", "pad_mode", "transposed", "act")] + \
                [("act_alpha", c_f32), ("algo", c_i32),
                 # optional x3h slots (include/semseg_hip.h): device uint32 with the bit pattern of max|x| / max|dy| + "already computed" flags
                 ("x_amax", c_vp), ("dy_amax", c_vp), ("x_amax_valid", c_i32), ("dy_amax_valid", c_i32)]
 
 
-class NormDesc(ctypes.Structure):
-    _fields_ = [(n, c_i32) for n in ("n", "h", "w", "c", "x_cstride", "y_cstride", "res_cstride", "groups")] + \
+class NormDesc(_SizedDesc):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("dtype", c_i32)] + [(n, c_i32) for n in ("n", "h", "w", "c", "x_cstride", "y_cstride", "res_cstride", "groups")] + \
                [("eps", c_f32), ("act", c_i32), ("act_alpha", c_f32)]
 
 
@@ -37,6 +45,10 @@ def default_algo():
 SIGNATURES = {
     "ss_version": (c_i32, []),
     "ss_status_string": (ctypes.c_char_p, [c_i32]),
+    "ss_last_error": (ctypes.c_char_p, []),
+    "ss_config_set": (c_i32, [ctypes.c_char_p, c_i64]),
+    "ss_config_get": (c_i64, [ctypes.c_char_p]),
+    "ss_config_key": (ctypes.c_char_p, [c_i32]),
     "ss_conv2d_workspace_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_uses_amax": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -97,5 +109,34 @@ def load():
 
 def check(status, what):
     if status != 0:
-        msg = load().ss_status_string(status).decode()
-        raise SemsegHipError(f"{what} failed: {msg} ({status})")
+        lib = load()
+        msg = lib.ss_status_string(status).decode()
+        detail = lib.ss_last_error().decode()
+        raise SemsegHipError(f"{what} failed: {msg} ({status})" + (f": {detail}" if detail else ""))
+
+
+def config_set(key, value):
+    """ss_config_set: explicit kernel-selection switches (include/semseg_hip.h)."""
+    check(load().ss_config_set(key.encode(), int(value)), f"ss_config_set[{key}]")
+
+
+def config_get(key):
+    return int(load().ss_config_get(key.encode()))
+
+
+class config:
+    """``with config(x3h=0): ...`` -- temporarily override switches (tests / bench arithmetic modes)."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = config_get(k)
+            config_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            config_set(k, v)
+        return False

@@ -4,10 +4,16 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/semseg_hip.h"
+struct SsTuning;
+void ss_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
-#define SS_LAUNCH_CHECK()                                   \
-    do {                                                    \
-        if (hipGetLastError() != hipSuccess) return SS_ERR_LAUNCH; \
+#define SS_LAUNCH_CHECK()                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) {                                                             \
+            ss_set_error("%s:%d: HIP launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return SS_ERR_LAUNCH;                                                           \
+        }                                                                                   \
     } while (0)
 
 static inline size_t ss_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -147,8 +153,10 @@ bool ss_x3h_enabled();
 bool ss_x6p_wanted(long M, int N, int nbatch);
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
 
-struct SsTuning { bool no_fast, nt512, tile256, no_winograd, x6; int wino_r; };
-const SsTuning& ss_tuning();   // measurement overrides, read once (conv_mfma.hip)
+// kernel-selection switches: ONE explicit table, set through ss_config_set (config.hip); SS_* environment variables give the initial values
+struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, weight_cache; };
+const SsTuning& ss_tuning();
+
 
 // kernels / launchers implemented in the .hip files
 int ss_launch_gconv_direct(const GConvParams& p, hipStream_t s);

@@ -319,8 +319,7 @@ const unsigned int* weight_amax(const float* w, long wn, unsigned int* scratch, 
     return scratch;
 }
 bool x3h_direct_wanted(int algo, int cred, int cout) {
-    static const bool off = getenv("SS_X3H_DIRECT") && getenv("SS_X3H_DIRECT")[0] == '0';
-    return !off && ss_x3h_enabled() && x6_wanted(algo) && cred >= 16 && cout >= 32;
+    return ss_tuning().x3h_direct && ss_x3h_enabled() && x6_wanted(algo) && cred >= 16 && cout >= 32;
 }
 // Which tensor maxima a pass computes / reads.  The passes FILL the slots exactly when these say so (whatever kernel ends up
 // running), so ss_conv2d_uses_amax can promise the caller that a slot is valid afterwards.
@@ -650,7 +649,12 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
 }
 
 bool valid_desc(const ss_conv_desc* d) {
-    if (!d) return false;
+    if (!d) { ss_set_error("ss_conv_desc is NULL"); return false; }
+    if (d->struct_size != sizeof(ss_conv_desc)) {
+        ss_set_error("ss_conv_desc.struct_size = %u, this library expects %zu (caller built against another header?)", d->struct_size, sizeof(ss_conv_desc));
+        return false;
+    }
+    if (d->dtype != SS_DTYPE_F32) { ss_set_error("ss_conv_desc.dtype = %d: this entry point takes SS_DTYPE_F32 activations", d->dtype); return false; }
     if (d->n <= 0 || d->ih <= 0 || d->iw <= 0 || d->cin <= 0 || d->oh <= 0 || d->ow <= 0 || d->cout <= 0) return false;
     if (d->kh <= 0 || d->kw <= 0 || d->stride <= 0) return false;
     if (d->in_cstride < d->cin || d->out_cstride < d->cout) return false;

@@ -203,11 +203,12 @@ template <int KH, int KW>
 int launch_out1(const GConvParams& p, const C1Box& box, hipStream_t s) {
     constexpr int CC = 8, HR = C1_TH + KH - 1, HW = C1_TW + KW - 1, HS = (HW + 3 + 3) / 4 * 4;
     const size_t smem = (size_t)(CC * HR * HS + CC * KH * 8) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
+    static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)conv_out1_kernel<KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     const unsigned blocks = (unsigned)(p.N * ((p.OH + C1_TH - 1) / C1_TH) * ((p.OW + C1_TW - 1) / C1_TW));
     hipLaunchKernelGGL((conv_out1_kernel<KH, KW>), dim3(blocks), dim3(256), smem, s, p, box);
     SS_LAUNCH_CHECK();
@@ -402,11 +403,12 @@ inline int c1w_blocks(long ntiles) { return (int)(ntiles < 511 ? ntiles : 511); 
 template <int MODE>
 int launch_wgrad_c1(const C1WParams& p, float* dw, int accumulate, hipStream_t s) {
     const size_t smem = ((size_t)C1W_PIX * C1W_T + (size_t)(C1W_TH + p.kh - 1) * (C1W_TW + p.kw - 1)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
+    static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)wgrad_c1_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     const int nblk = c1w_blocks(p.ntiles);
     hipLaunchKernelGGL((wgrad_c1_kernel<MODE>), dim3(nblk, (p.C + 63) / 64), dim3(256), smem, s, p);
     SS_LAUNCH_CHECK();
@@ -455,8 +457,7 @@ int ss_launch_conv_in1(const GConvParams& p, hipStream_t s) {
 // ---- weight gradient, one channel on one side (stride 1, kh * kw <= 64 taps) ----------------------------------------------------
 // mode 0: Cout == 1 (X = conv input x with C = Cin channels, S = dy);  mode 1: Cin == 1 (X = dy with C = Cout channels, S = x)
 bool ss_wgrad_c1_ok(int n, int xh, int xw, int C, int kh, int kw) {
-    static const bool off = getenv("SS_WGRAD_C1") && getenv("SS_WGRAD_C1")[0] == '0';
-    return !off && C >= 32 && C <= 128 && kh >= 1 && kw >= 1 && kh * kw <= C1W_T && kh <= 8 && kw <= 8 && (long)n * xh * xw >= 65536 &&
+    return ss_tuning().wgrad_c1 && C >= 32 && C <= 128 && kh >= 1 && kw >= 1 && kh * kw <= C1W_T && kh <= 8 && kw <= 8 && (long)n * xh * xw >= 65536 &&
            (long)n * xh * xw * C < (1L << 31);
 }
 

@@ -373,24 +373,6 @@ __global__ __launch_bounds__(NT) void gconv_mfma_kernel(GConvParams p, int vecA,
     }
 }
 
-// Kernel-selection overrides for A/B measurements (tools/bench_kernels.py); read ONCE per process, never needed in
-// production: SS_GCONV_NOFAST (generic loaders), SS_GCONV_NT512 / SS_GCONV_256 (tile variants), SS_NO_WINOGRAD, SS_WINO_R=2.
-const SsTuning& ss_tuning() {
-    static const SsTuning t = [] {
-        SsTuning v;
-        v.no_fast = getenv("SS_GCONV_NOFAST") != nullptr;
-        v.nt512 = getenv("SS_GCONV_NT512") != nullptr;
-        v.tile256 = getenv("SS_GCONV_256") != nullptr;
-        v.no_winograd = getenv("SS_NO_WINOGRAD") != nullptr;
-        const char* x6 = getenv("SS_X6");
-        v.x6 = !(x6 && x6[0] == '0');      // on by default; SS_X6=0 keeps AUTO on the fp32 MFMA instructions
-        const char* r = getenv("SS_WINO_R");
-        v.wino_r = (r && r[0] == '2') ? 2 : 4;
-        return v;
-    }();
-    return t;
-}
-
 bool ss_gconv_mfma_ok(const GConvParams& p) {
     // Cout == 1 heads and degenerate reductions stay on the direct kernel
     return p.Cout >= 2 && (long)p.ntaps * p.Cin >= 1;      // K is zero-padded to the 32-wide step by the loaders
@@ -401,11 +383,12 @@ static int launch_gconv(const GConvParams& p, int vecA, int vecB, hipStream_t s)
     using C = Cfg<BM, BN, NT>;
     const long M = (long)p.N * p.OHc * p.OWc;
     dim3 grid((unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN) * (p.nbatch > 1 ? p.nbatch : 1)));
-    static bool attr_set = false;
-    if (!attr_set) {
+    // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
+    static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)gconv_mfma_kernel<BM, BN, FAST, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     const size_t smem = C::smem_gconv + (FAST ? (size_t)BM * (p.ntaps + 3) * sizeof(int) : 0);
     hipLaunchKernelGGL((gconv_mfma_kernel<BM, BN, FAST, NT>), grid, dim3(NT), smem, s, p, vecA, vecB);
     SS_LAUNCH_CHECK();
@@ -420,7 +403,7 @@ int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
     for (int t = 0; t < p.ntaps && vecB; ++t) vecB = (p.taps[t].woff % 4 == 0);
     const long in_elems = (long)p.N * p.IH * p.IW * p.in_cs;
     const bool uniform = vecA && vecB && (p.Cin % 32 == 0) && (p.Cout >= 4);      // aligned float4 units, one tap per K step
-    const bool fast = p.ntaps >= 1 && in_elems < (1L << 31) && M < (1L << 31) && !ss_tuning().no_fast;
+    const bool fast = p.ntaps >= 1 && in_elems < (1L << 31) && M < (1L << 31) && ss_tuning().gconv_fast;
     if (fast && !uniform) vecA = 0;                                                // -> padded-K loaders
     // tile choice: the largest tile that still gives every CU ~2 workgroups (256 CUs); small batches need small tiles
     auto nblocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * (p.nbatch > 1 ? p.nbatch : 1); };
@@ -752,11 +735,12 @@ static int launch_wgrad(const WGradParams& p, int vecA, int vecB, hipStream_t s)
     using C = Cfg<BM, BN>;
     const int M = p.ntaps * p.Ca;
     dim3 grid((M + BM - 1) / BM, (p.Cb + BN - 1) / BN, p.splits * (p.nbatch > 1 ? p.nbatch : 1));
-    static bool attr_set = false;
-    if (!attr_set) {
+    // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
+    static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<BM, BN, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem_wgrad);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     hipLaunchKernelGGL((wgrad_mfma_kernel<BM, BN, FAST>), grid, dim3(256), C::smem_wgrad, s, p, vecA, vecB);
     SS_LAUNCH_CHECK();
     return SS_OK;
@@ -783,7 +767,7 @@ int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s) {
         const int vecB = (p.b_cs % 4 == 0) && (((uintptr_t)p.b & 15) == 0);
         int rc;
         // FAST = incremental pixel coordinates + deferred zero-selects; vector or (odd channel counts) scalar element loads
-        const bool fast = p.GW >= 32 && p.pix_per_split % 32 == 0 && !ss_tuning().no_fast &&
+        const bool fast = p.GW >= 32 && p.pix_per_split % 32 == 0 && ss_tuning().gconv_fast &&
                           (long)p.N * p.AH * p.AW * p.a_cs < (1L << 31) && (long)p.N * p.GH * p.GW * p.b_cs < (1L << 31);
         if (fast) {
             if (p.Cb > 64) rc = launch_wgrad<128, 128, true>(p, vecA, vecB, s);

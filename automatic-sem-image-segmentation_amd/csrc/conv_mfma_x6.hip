@@ -532,11 +532,12 @@ int launch_wgrad_x6h(const WGradParams& p, hipStream_t s) {
     const int M = p.ntaps * p.Ca;
     dim3 grid((M + XBM - 1) / XBM, (p.Cb + BN - 1) / BN, p.splits * (p.nbatch > 1 ? p.nbatch : 1));
     const size_t smem = (size_t)(H ? 2 : 3) * (XBM + BN) * XLD * sizeof(unsigned short);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
+    static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel<BN, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     hipLaunchKernelGGL((wgrad_x6_kernel<BN, H>), grid, dim3(256), smem, s, p);
     SS_LAUNCH_CHECK();
     return SS_OK;
@@ -552,11 +553,12 @@ int launch_x6h(const GConvParams& p, const unsigned short* planes, long plane_el
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     dim3 grid((unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN) * nb));
     const size_t smem = (size_t)(H ? 2 : 3) * (BM + BN) * XLD * sizeof(unsigned short) + (size_t)BM * sizeof(int) * (4 + p.ntaps);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
+    static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)gconv_x6_kernel<BM, BN, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     hipLaunchKernelGGL((gconv_x6_kernel<BM, BN, H>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot);
     SS_LAUNCH_CHECK();
     return SS_OK;

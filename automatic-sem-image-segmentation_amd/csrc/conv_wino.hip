@@ -719,7 +719,7 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
 
 // ---- host side ----------------------------------------------------------------------------------------------------
 bool ss_wino_ok(const WinoProb& q) {
-    if (ss_tuning().no_winograd) return false;
+    if (!ss_tuning().winograd) return false;
     const int kr = q.cin, no = q.cout;
     return kr % 32 == 0 && no % 4 == 0 && kr >= 64 && no >= 64 && q.in_cs % 4 == 0 && q.out_cs % 4 == 0 &&
            n_tiles(q, 2) >= 1024;

@@ -139,11 +139,12 @@ int ss_launch_bgemm_bf16x3(const BGemmParams& p, hipStream_t s) {
     if (p.K % GB_BK != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0) return SS_ERR_UNSUPPORTED;
     const int gridM = (p.M + GB_BM - 1) / GB_BM, gridN = (p.N + GB_BN - 1) / GB_BN;
     const size_t smem = (size_t)2 * 4 * GB_TILE * sizeof(unsigned short);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
+    static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)bgemm_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     hipLaunchKernelGGL(bgemm_bf16x3_kernel, dim3((unsigned)(gridM * gridN * (p.nbatch > 1 ? p.nbatch : 1))), dim3(256), smem, s, p);
     SS_LAUNCH_CHECK();
     return SS_OK;

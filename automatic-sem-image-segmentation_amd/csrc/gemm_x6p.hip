@@ -201,21 +201,19 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
 // A may hold anything finite or not: they only reach C rows >= M, which are not stored; pad rows of B likewise columns >= N).
 // K (and k_per_split) must be multiples of 32; pad COLUMNS of a split-K operand must be zero.
 bool ss_x6p_enabled() {
-    static const bool on = !(getenv("SS_X6P") && getenv("SS_X6P")[0] == '0');
-    return on && ss_tuning().x6;
+    return ss_tuning().x6p && ss_tuning().x6;
 }
 
 // x3h (fp16 two-piece operands, three products): SS_X3H=0 keeps the exact three-piece bf16 arithmetic everywhere
 bool ss_x3h_enabled() {
-    static const bool on = !(getenv("SS_X3H") && getenv("SS_X3H")[0] == '0');
-    return on && ss_x6p_enabled();
+    return ss_tuning().x3h && ss_x6p_enabled();
 }
 
 // One 512-thread workgroup per CU and 256x128 tiles: worth it from about four rounds of workgroups over the 256 CUs (batch >= 8 at
 // 512x512 tiles); smaller problems keep the 128x128 / 128x64 / 64x64 register-staged kernels (conv_mfma_x6.hip), which fill the
 // chip with more, smaller workgroups.  SS_X6P=force: always.
 bool ss_x6p_wanted(long M, int N, int nbatch) {
-    static const bool force = getenv("SS_X6P") && getenv("SS_X6P")[0] == 'f';
+    const bool force = ss_tuning().x6p == 2;
     if (!ss_x6p_enabled()) return false;
     const long nwg = ((M + PBM - 1) / PBM) * ((N + PBN - 1) / PBN) * nbatch;
     return force || nwg >= 1024;
@@ -224,12 +222,13 @@ bool ss_x6p_wanted(long M, int N, int nbatch) {
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     if (p.K % PBK || p.k_per_split % PBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
     const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + PBN - 1) / PBN;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
+    static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     const long nwg = (long)gridM * gridN * p.nbatch * p.splits;
     if (p.fp16x2) hipLaunchKernelGGL(gemm_x6p_kernel<2>, dim3((unsigned)nwg), dim3(512), 2 * 2 * (A_PLANE_B + B_PLANE_B), s, p);
     else hipLaunchKernelGGL(gemm_x6p_kernel<3>, dim3((unsigned)nwg), dim3(512), 2 * 3 * (A_PLANE_B + B_PLANE_B), s, p);

@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __rest
 inline int small_cl(int V) { return V == 4 ? 2 : 8; }
 // One block walks a whole group's pixels for its 8 channels: worth it while that walk is short (launch latency dominates).
 inline bool norm_small(const ss_norm_desc* d) {
-    static const long max_pix = getenv("SS_NORM_FUSED_PIX") ? atol(getenv("SS_NORM_FUSED_PIX")) : 1024;   // 0 disables
+    const long max_pix = ss_tuning().norm_fused_pix;   // 0 disables
     const long P = (long)d->n * d->h * d->w / (d->groups > 0 ? d->groups : 1);
     return P <= max_pix && P * d->groups * d->c <= NORM_SMALL_ELEMS;
 }
@@ -599,6 +599,11 @@ inline unsigned apply_grid(long total) {
 }
 
 bool valid(const ss_norm_desc* d) {
+    if (d && d->struct_size != sizeof(ss_norm_desc)) {
+        ss_set_error("ss_norm_desc.struct_size = %u, this library expects %zu", d->struct_size, sizeof(ss_norm_desc));
+        return false;
+    }
+    if (d && d->dtype != SS_DTYPE_F32) { ss_set_error("ss_norm_desc.dtype = %d unsupported", d->dtype); return false; }
     if (!d || d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0) return false;
     if (d->groups != 1 && d->groups != d->n) return false;
     if (d->x_cstride < d->c || d->y_cstride < d->c) return false;

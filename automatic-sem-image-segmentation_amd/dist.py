@@ -147,3 +147,22 @@ def enable_sync_bn(enabled=True):
         return world_size()
 
     layers.SYNC_BN = _allreduce if enabled else None
+
+
+def check_batch_divisible(batch_size, world, what="batch_size"):
+    """Data parallel splits every global batch into ``world`` equal contiguous shards (losses are means over the global batch,
+    gradients are summed and scaled by 1/world): a batch that does not divide would silently drop tiles or hand some ranks an
+    empty shard while the others block in a collective.  Raise up front instead."""
+    if world > 1 and (batch_size < world or batch_size % world != 0):
+        raise ValueError(f"{what} = {batch_size} cannot be split evenly over {world} ranks: choose a multiple of {world} "
+                         f"(the reference defaults 2 / 5 are single-device values)")
+
+
+_WARNED = set()
+
+
+def warn_once(msg):
+    if msg not in _WARNED and rank() == 0:
+        _WARNED.add(msg)
+        import warnings
+        warnings.warn(msg, stacklevel=2)

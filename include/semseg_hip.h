@@ -36,6 +36,10 @@ typedef enum ss_status {
     SS_ERR_UNSUPPORTED = -4   /* combination not implemented */
 } ss_status;
 
+/* storage type of ACTIVATION tensors (x, y, dy, dx, residual): weights, their gradients, optimizer state, normalisation
+ * statistics and every accumulation stay fp32 ("master" precision).  SURVEY 8(b) B2 dtype enum. */
+typedef enum ss_dtype { SS_DTYPE_F32 = 0, SS_DTYPE_BF16 = 1, SS_DTYPE_F16 = 2 } ss_dtype;
+
 enum { SS_PAD_ZERO = 0, SS_PAD_REFLECT = 1 };
 enum { SS_ACT_NONE = 0, SS_ACT_RELU = 1, SS_ACT_LRELU = 2, SS_ACT_TANH = 3, SS_ACT_SIGMOID = 4 };
 enum { SS_PASS_FWD = 0, SS_PASS_BWD_DATA = 1, SS_PASS_BWD_WEIGHT = 2 };
@@ -53,6 +57,20 @@ enum { SS_ALGO_AUTO = 0, SS_ALGO_DIRECT = 1, SS_ALGO_MFMA = 2,
 
 int ss_version(void);
 const char* ss_status_string(int status);
+/* Human-readable detail behind the last non-OK status returned on the calling thread ("" if none): which check failed, the HIP
+ * error string of a failed launch.  Thread-local; valid until the thread's next failing call. */
+const char* ss_last_error(void);
+
+/* Kernel-selection configuration: ONE explicit process-wide table instead of environment variables latched inside the library.
+ * Keys (ss_config_key(i) enumerates them, NULL past the end): "x6" (16-bit matrix-core contraction with fp32-grade operand
+ * splits; 0 = v_mfma_f32_32x32x2_f32 only), "x3h" (1 = two fp16 pieces / three products, 0 = exact three bf16 pieces / six
+ * products), "x3h_direct", "x6p" (0 / 1 / 2 = off / auto / always), "winograd", "wino_r" (4 | 2), "wgrad_c1", "norm_fused_pix",
+ * "tile_conv", measurement keys "gconv_fast", "gconv_nt512", "gconv_tile256".  Initial values: the matching SS_* environment
+ * variables at load time, else the defaults.  Not synchronised: call while no other call is in flight.
+ * ss_config_get returns INT64_MIN for an unknown key. */
+int ss_config_set(const char* key, int64_t value);
+int64_t ss_config_get(const char* key);
+const char* ss_config_key(int index);
 
 /* ------------------------------------------------------------------------------------------
  * 2-D convolution / transposed convolution.
@@ -72,6 +90,8 @@ const char* ss_status_string(int status);
  * gradient w.r.t. the pre-activation output (use ss_act_bwd first).
  * ---------------------------------------------------------------------------------------- */
 typedef struct ss_conv_desc {
+    uint32_t struct_size;            /* = sizeof(ss_conv_desc): a caller built against another layout gets SS_ERR_INVALID, not a wild read */
+    int32_t dtype;                   /* ss_dtype of x / y / dy / dx */
     int32_t n, ih, iw, cin, in_cstride;
     int32_t oh, ow, cout, out_cstride;
     int32_t kh, kw, stride;
@@ -117,6 +137,8 @@ int ss_conv2d_bwd_weight(const ss_conv_desc* d, const float* x, const float* dy,
  * the norm (CycleGAN.py:330,336,344,357,375; UNet_Segmentation.py:425,471-472,492-493).
  * ---------------------------------------------------------------------------------------- */
 typedef struct ss_norm_desc {
+    uint32_t struct_size;    /* = sizeof(ss_norm_desc) */
+    int32_t dtype;           /* ss_dtype of x / y / residual / dy / dx / dres */
     int32_t n, h, w, c;
     int32_t x_cstride, y_cstride, res_cstride;
     int32_t groups;          /* n -> instance norm, 1 -> batch norm */

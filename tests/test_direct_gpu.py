@@ -1,0 +1,372 @@
+"""Direct known-answer tests of the entry points that round 1 only reached through whole train steps:
+``ss_adam_keras`` against the oracle's KerasAdam for 10 iterations, every loss kernel's value AND gradient (incl. label smoothing),
+the x3h (two fp16 pieces) contraction on heavy-tailed / outlier tensors, the label map of ``UNet.run_inference``, and the explicit
+configuration / error boundary (ss_config_set, ss_last_error, struct_size)."""
+import ctypes
+import importlib
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as ON
+from oracle import ops as O
+from oracle import steps as OS
+
+pytestmark = pytest.mark.gpu
+BASE = "automatic-sem-image-segmentation_amd"
+
+
+def mod(name):
+    return importlib.import_module(f"{BASE}.{name}")
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+# ---- Keras Adam (T8) ---------------------------------------------------------------------------------------------------------------
+
+class _OneVarNet:
+    def __init__(self, n, dev):
+        E = mod("engine")
+        self.arena = E.ParamArena(dev)
+        self.arena.declare("w", (n,))
+        self.arena.materialize()
+
+
+@pytest.mark.parametrize("lr,beta_1,grad_scale", [(2e-4, 0.5, 1.0), (1e-3, 0.9, 1.0), (2e-4, 0.5, 0.125)])
+def test_adam_keras_ten_iterations_vs_oracle(lr, beta_1, grad_scale):
+    """p, m, v after each of 10 ss_adam_keras launches vs oracle.ops.KerasAdam in float64 (T8; CycleGAN.py:168-171,668-669;
+    UNet_Segmentation.py:393): rel-L2 <= 1e-6 for all three.  Gradients span 1e-9 .. 1e+1 so that the position of epsilon (Keras:
+    OUTSIDE the bias correction, lr folded: alpha*m/(sqrt(v)+eps)) matters: the torch form  lr*mhat/(sqrt(vhat)+eps)  moves the
+    small-gradient parameters by a different amount -- asserted below, i.e. this test resolves that bug."""
+    OPT = mod("optim")
+    dev = torch.device("cuda:0")
+    n = 100_003                       # not a multiple of 4: tail path of the float4 kernel
+    g = torch.Generator().manual_seed(3)
+    p0 = (torch.rand(n, generator=g, dtype=torch.float64) - 0.5)
+    mags = 10.0 ** (torch.rand(n, generator=g, dtype=torch.float64) * 10 - 9)
+    net = _OneVarNet(n, dev)
+    net.arena.params[:n].copy_(p0.float())
+    opt = OPT.Adam(lr, beta_1=beta_1)
+    ref_p = p0.float().double().clone()
+    ref = O.KerasAdam(lr, beta_1)
+    alt_p = ref_p.clone()             # torch.optim.Adam semantics, to show the test can tell the two apart
+    alt_m, alt_v = torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    for it in range(10):
+        grad = ((torch.rand(n, generator=g, dtype=torch.float64) - 0.5) * mags).float()
+        net.arena.grads[:n].copy_(grad)
+        opt.apply(net, grad_scale)
+        gs = grad.double() * grad_scale
+        ref.apply([gs], [ref_p])
+        t = it + 1
+        alt_m = beta_1 * alt_m + (1 - beta_1) * gs
+        alt_v = 0.999 * alt_v + 0.001 * gs * gs
+        alt_p = alt_p - lr * (alt_m / (1 - beta_1 ** t)) / ((alt_v / (1 - 0.999 ** t)).sqrt() + 1e-7)
+        got_p = net.arena.params[:n].double().cpu()
+        got_m, got_v = net.arena.m[:n].double().cpu(), net.arena.v[:n].double().cpu()
+        assert rel_l2(got_m, ref.m[0]) <= 1e-6, (it, "m")
+        assert rel_l2(got_v, ref.v[0]) <= 1e-6, (it, "v")
+        # the UPDATE (p - p0), not p itself: |p| ~ 0.3 would hide a wrong step of size lr
+        assert rel_l2(got_p - p0.float().double(), ref_p - p0.float().double()) <= 2e-5, (it, "step")
+        assert float((got_p - ref_p).abs().max()) <= 1e-7 + 1e-6 * lr * t
+    step_ref, step_alt = ref_p - p0.float().double(), alt_p - p0.float().double()
+    assert rel_l2(step_alt, step_ref) > 1e-3, "the torch-Adam form is indistinguishable here: the test has no resolving power"
+    assert opt.iterations == 10
+
+
+# ---- loss kernels (T6, T11) --------------------------------------------------------------------------------------------------------
+
+def _act(t, requires_grad=True):
+    return mod("engine").Act(t.cuda().contiguous(), requires_grad=requires_grad)
+
+
+@pytest.mark.parametrize("target,scale", [(1.0, 1.0), (0.0, 0.5), (0.95, 1.0), (0.05, 0.5)])
+def test_loss_mse_const_value_and_gradient(target, scale):
+    """mean((target - pred)^2) and grad_scale * d/dpred (CycleGAN.py:301-308; targets 0.95 / 0.05 = label smoothing 0.1)."""
+    LS = mod("losses")
+    g = torch.Generator().manual_seed(1)
+    pred = torch.randn((3, 59, 61, 1), generator=g)
+    pr = pred.double().requires_grad_(True)
+    want = O.mse(torch.full_like(pr, target), pr)
+    (want * scale).backward()
+    a = _act(pred)
+    slot = torch.zeros(1, device="cuda")
+    LS.mse_const(a, target, scale, slot)
+    assert abs(float(slot.item()) - float(want)) <= 2e-6 * max(abs(float(want)), 1.0)
+    assert rel_l2(a.get_grad().dense().cpu(), pr.grad) <= 1e-6
+
+
+@pytest.mark.parametrize("scale", [10.0, 5.0])
+def test_loss_mae_value_and_gradient(scale):
+    """mean(|truth - pred|) (CycleGAN.py:103-106,644-650); gradient = -sign(truth - pred) * scale / count."""
+    LS = mod("losses")
+    g = torch.Generator().manual_seed(2)
+    truth = torch.rand((2, 64, 48, 1), generator=g) * 2 - 1
+    pred = torch.rand((2, 64, 48, 1), generator=g) * 2 - 1
+    pr = pred.double().requires_grad_(True)
+    want = O.mae(truth.double(), pr)
+    (want * scale).backward()
+    a = _act(pred)
+    slot = torch.zeros(1, device="cuda")
+    LS.mae(_act(truth, False), a, scale, slot)
+    assert abs(float(slot.item()) - float(want)) <= 2e-6
+    assert rel_l2(a.get_grad().dense().cpu(), pr.grad) <= 1e-6
+
+
+@pytest.mark.parametrize("weighting", [9.0, 1.0, 0.25])
+def test_loss_weighted_bce_value_gradient_and_metrics(weighting):
+    """UNet_Segmentation.py:379-384 + the compile(metrics=['mae','acc']) pair (:395): loss, mae, binary accuracy @0.5 and
+    d loss / d pred, with predictions INSIDE the clip band [1e-7, 1 - 1e-7] and outside it (zero gradient there, as torch's
+    clamp backward gives the oracle)."""
+    LS = mod("losses")
+    g = torch.Generator().manual_seed(4)
+    truth = (torch.rand((2, 40, 56, 1), generator=g) > 0.8).float()
+    pred = torch.rand((2, 40, 56, 1), generator=g)
+    pred.view(-1)[:64] = torch.tensor([0.0, 1.0, 1e-9, 1.0 - 1e-9, 5e-8, 0.5, 0.5 + 1e-6, 0.5 - 1e-6] * 8)
+    pr = pred.double().requires_grad_(True)
+    want = O.weighted_bce(truth.double(), pr, weighting)
+    want.backward()
+    a = _act(pred)
+    out3 = torch.zeros(4, device="cuda")
+    LS.weighted_bce(_act(truth, False), a, weighting, 1.0, out3)
+    got = out3.cpu().double().numpy()
+    assert abs(got[0] - float(want)) <= 2e-6 * max(abs(float(want)), 1.0), (got[0], float(want))
+    assert abs(got[1] - float((truth - pred).abs().double().mean())) <= 1e-6
+    assert abs(got[2] - float(((pred > 0.5).float() == truth).double().mean())) <= 1e-7
+    gg, gr = a.get_grad().dense().cpu().double(), pr.grad
+    # float32 clip boundaries: 1 - 1e-7 rounds to 1 - 1.19e-7 in fp32; compare where the oracle is not within one ulp of the band edge
+    band = ((pred.double() - 1e-7).abs() > 2e-8) & ((pred.double() - (1 - 1e-7)).abs() > 1.3e-7)
+    assert rel_l2(gg[band], gr[band]) <= 2e-6
+
+
+def test_cyclegan_step_with_label_smoothing_vs_oracle():
+    """label_smoothing_factor = 0.1 through the whole step (CycleGAN.py:301-308: targets 0.95 / 0.05): 14 metrics of two steps."""
+    CG, N, OPT = mod("CycleGAN"), mod("nets"), mod("optim")
+    g = torch.Generator().manual_seed(8)
+    refs = dict(gen_a=ON.ResnetGenerator(filters=4, seed=1), gen_b=ON.ResnetGenerator(filters=4, seed=2),
+                disc_a=ON.PatchDiscriminator(filters=8, seed=3), disc_b=ON.PatchDiscriminator(filters=8, seed=4))
+    hips = dict(gen_a=N.ResnetGenerator(filters=4, device="cuda"), gen_b=N.ResnetGenerator(filters=4, device="cuda"),
+                disc_a=N.PatchDiscriminator(filters=8, device="cuda"), disc_b=N.PatchDiscriminator(filters=8, device="cuda"))
+    for k in refs:
+        hips[k].set_weights(refs[k].get_weights())
+    model = CG.CycleGanModel(hips["gen_a"], hips["gen_b"], hips["disc_a"], hips["disc_b"],
+                             image_pool_a=CG.ImagePool(2, 50), image_pool_b=CG.ImagePool(2, 50))
+    model.compile(OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5),
+                  label_smoothing_factor=0.1)
+    ostep = OS.CycleGanStep(refs["gen_a"], refs["gen_b"], refs["disc_a"], refs["disc_b"], OS.ImagePool(2, 50), OS.ImagePool(2, 50),
+                            label_smoothing_factor=0.1)
+    for _ in range(2):
+        a = torch.rand((2, 64, 64, 1), generator=g) * 2 - 1
+        b = (torch.rand((2, 64, 64, 1), generator=g) > 0.8).float() * 2 - 1
+        random.seed(5)
+        got = model.train_step((a.numpy(), b.numpy()))
+        random.seed(5)
+        want = ostep.train_step((a, b))
+        for k in want:
+            assert abs(got[k] - want[k]) <= 2e-4 * max(abs(want[k]), 1.0), (k, got[k], want[k])
+    # and the smoothing is really in effect: an un-smoothed oracle disagrees
+    assert abs(want["d_real_a"] - OS.CycleGanStep(refs["gen_a"], refs["gen_b"], refs["disc_a"], refs["disc_b"]).train_step((a, b))["d_real_a"]) > 1e-3
+
+
+def test_workflow_loss_functions_compute():
+    """CycleGAN.generator_loss_fn / discriminator_loss_fn (CycleGAN.py:301-308) return values like the reference's methods."""
+    CG = mod("CycleGAN")
+    wf = CG.CycleGAN.__new__(CG.CycleGAN)
+    wf.label_smoothing_factor = 0.1
+    g = torch.Generator().manual_seed(6)
+    real, fake = torch.randn((2, 27, 27, 1), generator=g), torch.randn((2, 27, 27, 1), generator=g)
+    got_g = wf.generator_loss_fn(fake.cuda())
+    total, rl, fl = wf.discriminator_loss_fn(real.cuda(), fake.cuda())
+    assert abs(float(got_g) - float(((0.95 - fake.double()) ** 2).mean())) <= 1e-6
+    assert abs(float(rl) - float(((0.95 - real.double()) ** 2).mean())) <= 1e-6
+    assert abs(float(fl) - float(((0.05 - fake.double()) ** 2).mean())) <= 1e-6
+    assert abs(float(total) - 0.5 * (float(rl) + float(fl))) <= 1e-7
+
+
+# ---- x3h on adversarial tensors ------------------------------------------------------------------------------
+
+def _heavy(shape, kind, g):
+    u = torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1
+    if kind == "loguniform":          # magnitudes log-uniform over six decades
+        return u.sign() * 10.0 ** (torch.rand(shape, generator=g, dtype=torch.float64) * 6 - 6)
+    if kind == "outlier":             # one element 1e5 x the rest
+        u = u * 1e-5
+        u.view(-1)[int(torch.randint(0, u.numel(), (1,), generator=g))] = 1.0
+        return u
+    if kind == "tiny_tiles":          # whole spatial tiles ~1e-6 of the rest (per-tile scales must pick them up)
+        n, h, w, c = shape
+        mask = (torch.rand((n, (h + 7) // 8, (w + 7) // 8, 1), generator=g) > 0.5).double()
+        mask = mask.repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :h, :w]
+        return u * (mask + (1 - mask) * 1e-6)
+    if kind == "lognormal":           # sigma 2.5: what a real dy tensor looks like
+        return u.sign() * torch.exp(torch.randn(shape, generator=g, dtype=torch.float64) * 2.5)
+    raise ValueError(kind)
+
+
+def oracle_conv(x, w, k, stride, padding, transposed):
+    if transposed:
+        return O.conv2d_transpose(x, w, None, stride)
+    if isinstance(padding, tuple):
+        return O.conv2d(O.reflection_pad(x, (2 * padding[1], 2 * padding[1])), w, None, stride, "valid")
+    return O.conv2d(x, w, None, stride, padding)
+
+
+ADV_CASES = [
+    # name, k, cin, cout, stride, padding, transposed, n, h, w
+    ("trunk_wino_per_tile", 3, 128, 128, 1, ("reflect", 1), False, 2, 48, 48),
+    ("disc_4x4_s2_per_tensor", 4, 64, 128, 2, "valid", False, 2, 66, 66),
+    ("up_T3_per_tensor", 3, 64, 32, 2, "same", True, 2, 32, 32),
+]
+
+
+@pytest.mark.parametrize("kind", ["loguniform", "outlier", "tiny_tiles", "lognormal"])
+@pytest.mark.parametrize("case", ADV_CASES, ids=[c[0] for c in ADV_CASES])
+def test_x3h_heavy_tailed_tensors_vs_fp64(case, kind):
+    """The default contraction carries operands as two fp16 pieces under ONE power-of-two scale per tile (Winograd) or per tensor
+    (direct convs, all weight gradients).  On tensors whose elements span many decades the per-tensor variant keeps only
+    absolute precision 2^-38 * max for elements below 2^-17 * max.  Criterion: for y, dx and dw the error against the float64
+    definition, measured in the norm that matters for a sum of products (max |d| relative to the float64 value of
+    sum |a||b|, i.e. the conditioning of each output element), must be within 4x of what the exact-fp32-operand path
+    (SS_ALGO_MFMA, v_mfma_f32_32x32x2_f32) achieves on the same data, plus 1e-7."""
+    E, LY, L = mod("engine"), mod("layers"), mod("_lib")
+    name, k, cin, cout, stride, padding, transposed, n, h, w = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(abs(hash((name, kind))) % 10007)
+    wshape = (k, k, cout, cin) if transposed else (k, k, cin, cout)
+    w_cpu = (torch.rand(wshape, generator=g, dtype=torch.float64) - 0.5) * 0.2
+    x_cpu = _heavy((n, h, w, cin), kind, g).float().double()
+    xr, wr = x_cpu.clone().requires_grad_(True), w_cpu.float().double().clone().requires_grad_(True)
+    yr = oracle_conv(xr, wr, k, stride, padding, transposed)
+    gy = _heavy(tuple(yr.shape), kind, g).float().double()
+    yr.backward(gy)
+    # conditioning: sum of |products| per output element
+    xa, wa = x_cpu.abs().requires_grad_(True), wr.detach().abs().requires_grad_(True)
+    ya = oracle_conv(xa, wa, k, stride, padding, transposed)
+    ya.backward(gy.abs())
+    cond = dict(y=ya.detach(), dx=xa.grad, dw=wa.grad)
+    errs = {}
+    for algo in (L.ALGO_MFMA, L.ALGO_AUTO):
+        arena = E.ParamArena(dev)
+        layer = LY.Conv2D(arena, "c", k, cin, cout, stride=stride, padding=padding, transposed=transposed, algo=algo)
+        arena.materialize()
+        arena["c/kernel"].copy_(wr.detach().float())
+        tape = E.Tape()
+        x = E.Act(x_cpu.float().to(dev), requires_grad=True)
+        y = layer(tape, x)
+        gt, _ = y.grad_target()
+        gt.t.copy_(gy.float().to(dev))
+        arena.zero_grad()
+        tape.backward()
+        got = dict(y=y.dense().cpu().double(), dx=x.get_grad().dense().cpu().double(), dw=arena.grad("c/kernel").cpu().double())
+        want = dict(y=yr.detach(), dx=xr.grad, dw=wr.grad)
+        for q in got:
+            assert torch.isfinite(got[q]).all(), (q, algo)
+        errs[algo] = {q: float(((got[q] - want[q]).abs() / cond[q].clamp_min(1e-300)).max()) for q in got}
+    print(f"{name}/{kind}: max |d| / sum|a||b|   fp32-MFMA {errs[L.ALGO_MFMA]}   default {errs[L.ALGO_AUTO]}")
+    for q in ("y", "dx", "dw"):
+        assert errs[L.ALGO_AUTO][q] <= 4 * errs[L.ALGO_MFMA][q] + 1e-7, (q, errs)
+
+
+# ---- label maps of run_inference (north_star: "bit-exact label maps after threshold") ------------------------------------
+
+def _sem_like(h, w, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 40 + 10 * rng.standard_normal((h, w))
+    for _ in range(25):
+        cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(6, 18)
+        img[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] += 120
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_unet_run_inference_label_maps_match_oracle(tmp_path):
+    """``UNet.run_inference`` at 256x256 (BASELINE config 1: one tile, whole-image inference) against the oracle network with the
+    same weights (random BatchNorm moving statistics, inference mode): (i) ``p > 0.5`` and (ii) the reference rule min-max -> uint8
+    -> Otsu (UNet_Segmentation.py:346-350, Measurements.py:276-279) must give BIT-IDENTICAL label maps except on pixels whose oracle
+    value lies within the fp32 tolerance of the threshold (|p - 0.5| <= 2e-4; uint8 image value within 0.06 grey levels of a bucket
+    edge at the Otsu threshold); those pixels are counted and must be < 0.1 %."""
+    from PIL import Image
+    UN, N, OPT, HF = mod("UNet_Segmentation"), mod("nets"), mod("optim"), mod("HelperFunctions")
+    ref = ON.MultiResUNet(16, seed=21)
+    rng = np.random.default_rng(2)
+    ws = ref.get_weights()
+    for i, v in enumerate(ref.variables):
+        kind = v.name.rsplit("/", 1)[-1]
+        if kind == "moving_mean":
+            ws[i] = rng.uniform(-0.2, 0.2, ws[i].shape).astype(np.float32)
+        elif kind in ("moving_variance", "gamma"):
+            ws[i] = rng.uniform(0.6, 1.4, ws[i].shape).astype(np.float32)
+        elif kind == "beta":
+            ws[i] = rng.uniform(-0.2, 0.2, ws[i].shape).astype(np.float32)
+    ref.set_weights(ws)
+    hip = N.MultiResUNet(16, device="cuda:0")
+    hip.set_weights(ws)
+    src = tmp_path / "in"
+    os.makedirs(src)
+    for i in range(2):
+        Image.fromarray(_sem_like(256, 256, i)).save(str(src / f"img{i}.tif"))
+    wf = UN.UNet(str(tmp_path), str(src), str(src))
+    out = tmp_path / "out"
+    wf.run_inference(str(src), str(out), model=UN.UNetModel(hip, 9.0, OPT.Adam()), watershed_lines=False, threshold=-1)
+    x = HF.load_and_preprocess_images(str(src), normalization_range=(0, 1), contrast_optimization_range=wf.contrast_optimization_range)
+    ref64 = ON.MultiResUNet(16, seed=21, dtype=torch.float64)
+    ref64.set_weights(ws)
+    with torch.no_grad():
+        p_or = ref64(torch.from_numpy(x).double(), False).numpy()[..., 0]
+    total = near = 0
+    for i in range(2):
+        raw = np.array(Image.open(str(out / f"img{i}_raw.tif")))
+        lab = np.array(Image.open(str(out / f"img{i}.tif")))
+        p = p_or[i]
+        assert raw.dtype == np.float32 and float(np.abs(raw - p).max()) <= 2e-4, float(np.abs(raw - p).max())
+        # (i) p > 0.5
+        m_hip, m_or = raw > 0.5, p > 0.5
+        diff = m_hip != m_or
+        assert np.all(np.abs(p[diff] - 0.5) <= 2e-4)
+        # (ii) min-max -> uint8 -> Otsu -> 4-connected map, exactly as run_inference post-processes it
+        v = (p - p.min()) / (p.max() - p.min()) * 255.0
+        img8 = v.astype(np.float32).astype(np.uint8)
+        want = HF.segment(image=img8, threshold=-1, watershed_lines=False, min_distance=9, use_four_connectivity=True)
+        assert lab.shape == want.shape and lab.dtype == want.dtype
+        d2 = lab != want
+        t = HF.threshold_otsu(img8)
+        total += d2.size
+        near += int(d2.sum())
+        if d2.any():
+            # a differing pixel must sit on the bucket edge at the threshold (or be an 8->4 connectivity consequence next to one)
+            edge = np.abs(v - (t + 1)) <= 0.06
+            from scipy import ndimage
+            assert np.all(ndimage.binary_dilation(edge, iterations=2)[d2]), "label maps differ away from the threshold"
+    print(f"label-map pixels differing from the oracle (all within tolerance of the threshold): {near} of {total}")
+    assert near <= 1e-3 * total
+
+
+# ---- boundary: explicit config, last error, struct_size ---------------------------------------------------------------------------
+
+def test_boundary_config_last_error_and_struct_size():
+    L = mod("_lib")
+    lib = L.load()
+    keys = []
+    i = 0
+    while lib.ss_config_key(i):
+        keys.append(lib.ss_config_key(i).decode())
+        i += 1
+    assert {"x6", "x3h", "x6p", "winograd", "wino_r", "tile_conv"} <= set(keys)
+    old = L.config_get("x3h")
+    with L.config(x3h=0):
+        assert L.config_get("x3h") == 0
+    assert L.config_get("x3h") == old
+    assert lib.ss_config_set(b"no_such_key", 1) == -1 and b"no_such_key" in lib.ss_last_error()
+    d = L.ConvDesc(1, 8, 8, 4, 4, 8, 8, 4, 4, 3, 3, 1, 1, 1, L.PAD_ZERO, 0, L.ACT_NONE, 0.0, L.ALGO_AUTO)
+    assert d.struct_size == ctypes.sizeof(L.ConvDesc) and lib.ss_conv2d_workspace_bytes(ctypes.byref(d), 0) >= 0
+    d.struct_size -= 16                # a caller built against the round-1 header (19 fields instead of 23 + 2)
+    x = torch.zeros(1, 8, 8, 4, device="cuda")
+    rc = lib.ss_conv2d_fwd(ctypes.byref(d), x.data_ptr(), x.data_ptr(), None, x.data_ptr(), None, 0, None)
+    assert rc == -1 and b"struct_size" in lib.ss_last_error()
+    with pytest.raises(L.SemsegHipError, match="struct_size"):
+        L.check(rc, "ss_conv2d_fwd")

@@ -198,11 +198,13 @@ def _build_models(filters=64, seed=0):
     return model, umodel, (ga, gb, da, db, un)
 
 
-def test_full_size_step_is_deterministic():
-    """CycleGAN + UNet train step at 512x512, batch 8, F = 64, twice from identical state: bit-identical metrics and weights."""
+@pytest.mark.parametrize("batch,size", [(N_FULL, 512), (1, 512), (4, 256)], ids=["b8_512", "b1_512_per_gpu_share_of_8", "b4_256_config3"])
+def test_full_size_step_is_deterministic(batch, size):
+    """CycleGAN + UNet train step (two concurrent kernel chains per phase) with F = 64, twice from identical state: bit-identical
+    metrics and weights -- at the headline shape, at the per-GPU share of an 8-GPU run (batch 1) and at BASELINE config 3's shape."""
     g = torch.Generator().manual_seed(1234)
-    a = torch.rand((N_FULL, 512, 512, 1), generator=g) * 2 - 1
-    b = (torch.rand((N_FULL, 512, 512, 1), generator=g) > 0.9).float() * 2 - 1
+    a = torch.rand((batch, size, size, 1), generator=g) * 2 - 1
+    b = (torch.rand((batch, size, size, 1), generator=g) > 0.9).float() * 2 - 1
     results = []
     for _ in range(2):
         random.seed(7)
@@ -220,13 +222,13 @@ def test_full_size_step_is_deterministic():
         assert np.array_equal(w0, w1)
 
 
-def test_cyclegan_step_one_full_resolution_tile_vs_oracle():
-    """A complete CycleGAN step with the full-size networks (F = 64, 9 residual blocks) on ONE 256x256 tile (the tile size of
-    BASELINE config 3; at 512x512 the fp64 oracle alone needs ~3.5 min of CPU, measured rel-L2 there: generators 3.4e-3 / 8.2e-3
-    vs 1.8e-3 / 4.8e-3 for the fp32 oracle, discriminators 3.2e-4 / 1.1e-4 vs 1.6e-4 / 4.9e-5) against the oracle: the 14
-    metrics and every parameter gradient.  The fp64 oracle arbitrates (SURVEY 8c): gradients pass through up to 2 x 27
-    conv + InstanceNorm + ReLU layers and the PatchGAN, so the fp32 oracle's own distance to fp64 is the noise model --
-    the HIP result must be as close to fp64 as 3 x that distance (+1e-4)."""
+_TILE_ORACLE = {}
+
+
+def _tile_oracle():
+    """fp32 and fp64 oracle CycleGAN steps on one 256x256 tile with the full-size networks (computed once per session: ~1.5 min of CPU)."""
+    if _TILE_ORACLE:
+        return _TILE_ORACLE
     g = torch.Generator().manual_seed(5)
     S = int(__import__("os").environ.get("SS_TEST_FULL_TILE", "256"))
     real_a = torch.rand((1, S, S, 1), generator=g) * 2 - 1
@@ -237,32 +239,54 @@ def test_cyclegan_step_one_full_resolution_tile_vs_oracle():
                     disc_a=ON.PatchDiscriminator(filters=128, seed=3, dtype=dtype), disc_b=ON.PatchDiscriminator(filters=128, seed=4, dtype=dtype))
 
     refs, refs64 = make(torch.float32), make(torch.float64)
-    model, _, nets = _build_models()
-    hips = dict(gen_a=nets[0], gen_b=nets[1], disc_a=nets[2], disc_b=nets[3])
+    init = {k: refs[k].get_weights() for k in refs}
     for k in refs:
-        hips[k].set_weights(refs[k].get_weights())
-        refs64[k].set_weights(refs[k].get_weights())
+        refs64[k].set_weights(init[k])
     out = {}
     for tag, r, dt in (("32", refs, torch.float32), ("64", refs64, torch.float64)):
         ostep = OS.CycleGanStep(r["gen_a"], r["gen_b"], r["disc_a"], r["disc_b"], OS.ImagePool(2, 50), OS.ImagePool(2, 50))
         random.seed(11)
         m = ostep.train_step((real_a.to(dt), real_b.to(dt)))
         out[tag] = (m, {k: {v.name: v.value.grad.detach().double().numpy() for v in r[k].trainable_weights} for k in r})
-    random.seed(11)
-    got = model.train_step((real_a.numpy(), real_b.numpy()))
+    _TILE_ORACLE.update(real_a=real_a, real_b=real_b, init=init, out=out)
+    return _TILE_ORACLE
+
+
+@pytest.mark.parametrize("mode", ["x3h", "x6_bf16_six_products", "fp32_mfma_instructions"])
+def test_cyclegan_step_one_full_resolution_tile_vs_oracle(mode):
+    """A complete CycleGAN step with the full-size networks (F = 64, 9 residual blocks) on ONE 256x256 tile (the tile size of
+    BASELINE config 3; at 512x512 the fp64 oracle alone needs ~3.5 min of CPU, measured rel-L2 there: generators 3.4e-3 / 8.2e-3
+    vs 1.8e-3 / 4.8e-3 for the fp32 oracle, discriminators 3.2e-4 / 1.1e-4 vs 1.6e-4 / 4.9e-5) against the oracle: the 14
+    metrics and every parameter gradient.  The fp64 oracle arbitrates (SURVEY 8c): gradients pass through up to 2 x 27
+    conv + InstanceNorm + ReLU layers and the PatchGAN, so the fp32 oracle's own distance to fp64 is the noise model --
+    the HIP result must be as close to fp64 as 3 x that distance (+1e-4).
+    All THREE arithmetic modes of the contraction engine run here (ss_config_set): the default two-piece fp16 split with three
+    products (x3h), the exact three-piece bf16 split with six products (x3h = 0), and fp32 MFMA instructions only (x6 = 0)."""
+    L = mod("_lib")
+    cfg = {"x3h": dict(), "x6_bf16_six_products": dict(x3h=0), "fp32_mfma_instructions": dict(x6=0)}[mode]
+    o = _tile_oracle()
+    real_a, real_b, out = o["real_a"], o["real_b"], o["out"]
+    with L.config(**cfg):
+        model, _, nets = _build_models()
+        hips = dict(gen_a=nets[0], gen_b=nets[1], disc_a=nets[2], disc_b=nets[3])
+        for k in hips:
+            hips[k].set_weights(o["init"][k])
+        random.seed(11)
+        got = model.train_step((real_a.numpy(), real_b.numpy()))
+        torch.cuda.synchronize()
     (m32, g32), (m64, g64) = out["32"], out["64"]
     for k in m64:
         noise = abs(float(m32[k]) - float(m64[k]))
         assert abs(got[k] - float(m64[k])) <= 2e-4 * max(abs(float(m64[k])), 1.0) + 3 * noise, (k, got[k], m32[k], m64[k])
-    for k in refs:
+    for k in hips:
         gh = hips[k].get_gradients()
         names = [n for n in g64[k] if float(np.abs(g64[k][n]).max()) > 0]
         cat = lambda d: np.concatenate([np.asarray(d[n], np.float64).ravel() for n in names])
         r64 = cat(g64[k])
         e_hip = float(np.linalg.norm(cat(gh) - r64) / np.linalg.norm(r64))
         e_32 = float(np.linalg.norm(cat(g32[k]) - r64) / np.linalg.norm(r64))
-        print(f"{k}: gradient rel-L2 vs fp64  hip={e_hip:.2e}  oracle32={e_32:.2e}")
-        assert e_hip <= 3 * e_32 + 1e-4, (k, e_hip, e_32)
+        print(f"[{mode}] {k}: gradient rel-L2 vs fp64  hip={e_hip:.2e}  oracle32={e_32:.2e}")
+        assert e_hip <= 3 * e_32 + 1e-4, (mode, k, e_hip, e_32)
 
 
 def test_unet_step_baseline_tiles_vs_oracle():

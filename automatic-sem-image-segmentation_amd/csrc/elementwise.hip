@@ -268,8 +268,8 @@ __global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, c
                                                         float gscale) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
         const float gv = g[e] * gscale;
-        const float mv = fmaf(b1, m[e], (1.f - b1) * gv);
-        const float vv = fmaf(b2, v[e], (1.f - b2) * gv * gv);
+        const float mv = m[e] + (gv - m[e]) * b1;       // b1, b2 hold (1 - beta), see adam_kernel_v4
+        const float vv = v[e] + (gv * gv - v[e]) * b2;
         m[e] = mv;
         v[e] = vv;
         p[e] -= alpha * mv / (sqrtf(vv) + eps);
@@ -284,8 +284,8 @@ __global__ __launch_bounds__(EW_BLOCK) void adam_kernel_v4(f32x4* __restrict__ p
         f32x4 mv = m[e], vv = v[e], pv = p[e];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            mv[k] = fmaf(b1, mv[k], (1.f - b1) * gv[k]);
-            vv[k] = fmaf(b2, vv[k], (1.f - b2) * gv[k] * gv[k]);
+            mv[k] += (gv[k] - mv[k]) * b1;                  // b1, b2 hold (1 - beta): keras  m.assign_add((g - m) * (1 - beta_1))
+            vv[k] += (gv[k] * gv[k] - vv[k]) * b2;
             pv[k] -= alpha * mv[k] / (sqrtf(vv[k]) + eps);
         }
         m[e] = mv;
@@ -455,9 +455,13 @@ int ss_loss_weighted_bce(const float* truth, const float* pred, int64_t count, f
 }
 
 int ss_adam_keras(float* p, const float* g, float* m, float* v, int64_t count,
-                  float alpha, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+                  double alpha_d, double beta1_d, double beta2_d, double eps_d, float grad_scale, void* stream) {
     if (!p || !g || !m || !v || count < 0) return SS_ERR_INVALID;
     if (count == 0) return SS_OK;
+    // Keras forms (1 - beta) in python double precision and casts the RESULT to the variable dtype: 1 - 0.999 -> fp32(0.001), whereas
+    // 1.f - fp32(0.999) = 0.00099998713 (1.3e-5 off; found by tests/test_direct_gpu.py::test_adam_keras_ten_iterations_vs_oracle)
+    const float alpha = (float)alpha_d, eps = (float)eps_d;
+    const float beta1 = (float)(1.0 - beta1_d), beta2 = (float)(1.0 - beta2_d);
     hipStream_t s = (hipStream_t)stream;
     const bool al = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
     const long c4 = al ? count / 4 : 0;

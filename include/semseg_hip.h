@@ -240,13 +240,14 @@ int ss_loss_weighted_bce(const float* truth, const float* pred, int64_t count, f
 
 /* ------------------------------------------------------------------------------------------
  * keras.optimizers.Adam as applied at CycleGAN.py:668-669,690-692 and by Model.fit for the UNet
- * (UNet_Segmentation.py:393): fused single pass over a flat parameter arena.
- *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= alpha * m / (sqrt(v) + eps)
- *   alpha = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller (t = iterations + 1).
- * grad_scale multiplies g first (1/world_size after a sum all-reduce).
+ * (UNet_Segmentation.py:393): fused single pass over a flat parameter arena, the Keras update forms
+ *   m += (g - m) * (1 - beta_1) ;  v += (g*g - v) * (1 - beta_2) ;  p -= alpha * m / (sqrt(v) + epsilon)
+ *   alpha = lr*sqrt(1-beta_2^t)/(1-beta_1^t) is computed by the caller (t = iterations + 1).
+ * The hyper-parameters are DOUBLES: Keras forms (1 - beta) in double precision and casts the result to fp32 (1 - 0.999 ->
+ * fp32(0.001); 1.f - fp32(0.999) would be 1.3e-5 off).  grad_scale multiplies g first (1/world_size after a sum all-reduce).
  * ---------------------------------------------------------------------------------------- */
 int ss_adam_keras(float* p, const float* g, float* m, float* v, int64_t count,
-                  float alpha, float beta1, float beta2, float eps, float grad_scale, void* stream);
+                  double alpha, double beta_1, double beta_2, double epsilon, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -147,7 +147,8 @@ class KerasAdam:
         alpha = lr * (1.0 - self.beta_2 ** t) ** 0.5 / (1.0 - self.beta_1 ** t)
         with torch.no_grad():
             for p, g, m, v in zip(params, grads, self.m, self.v):
-                m.mul_(self.beta_1).add_(g, alpha=1.0 - self.beta_1)
-                v.mul_(self.beta_2).add_(g * g, alpha=1.0 - self.beta_2)
+                # keras/src/optimizers/adam.py update_step: assign_add forms, (1 - beta) formed in python double precision
+                m.add_((g - m) * (1.0 - self.beta_1))
+                v.add_((g * g - v) * (1.0 - self.beta_2))
                 p.sub_(m * alpha / (v.sqrt() + self.epsilon))
         self.iterations = t

@@ -31,6 +31,11 @@ class NormDesc(_SizedDesc):
                [("eps", c_f32), ("act", c_i32), ("act_alpha", c_f32)]
 
 
+class ProfEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 64), ("launches", c_i64), ("total_ms", ctypes.c_double), ("flops", ctypes.c_double),
+                ("bytes", ctypes.c_double)]
+
+
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PASS_FWD, PASS_BWD_DATA, PASS_BWD_WEIGHT = 0, 1, 2
@@ -49,6 +54,10 @@ SIGNATURES = {
     "ss_config_set": (c_i32, [ctypes.c_char_p, c_i64]),
     "ss_config_get": (c_i64, [ctypes.c_char_p]),
     "ss_config_key": (ctypes.c_char_p, [c_i32]),
+    "ss_prof_enable": (c_i32, [c_i32]),
+    "ss_prof_reset": (c_i32, []),
+    "ss_prof_count": (c_i32, []),
+    "ss_prof_get": (c_i32, [c_i32, ctypes.POINTER(ProfEntry)]),
     "ss_conv2d_workspace_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_uses_amax": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -115,9 +124,14 @@ def check(status, what):
         raise SemsegHipError(f"{what} failed: {msg} ({status})" + (f": {detail}" if detail else ""))
 
 
+CONFIG_EPOCH = 0      # bumped by config_set: host-side caches of pure functions of (descriptor, configuration) key on it
+
+
 def config_set(key, value):
     """ss_config_set: explicit kernel-selection switches (include/semseg_hip.h)."""
+    global CONFIG_EPOCH
     check(load().ss_config_set(key.encode(), int(value)), f"ss_config_set[{key}]")
+    CONFIG_EPOCH += 1
 
 
 def config_get(key):
@@ -140,3 +154,15 @@ class config:
         for k, v in self.old.items():
             config_set(k, v)
         return False
+
+
+def prof_summary():
+    """{kernel class: {launches, total_ms, avg_ms, flops, bytes}} of the instrumented launches since the last ss_prof_reset."""
+    lib = load()
+    out = {}
+    for i in range(lib.ss_prof_count()):
+        e = ProfEntry()
+        check(lib.ss_prof_get(i, ctypes.byref(e)), "ss_prof_get")
+        out[e.name.decode()] = dict(launches=int(e.launches), total_ms=float(e.total_ms), avg_ms=float(e.total_ms) / max(int(e.launches), 1),
+                                    flops=float(e.flops), bytes=float(e.bytes))
+    return out

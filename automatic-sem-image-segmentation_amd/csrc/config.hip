@@ -7,6 +7,10 @@
 // not synchronised: set it from one thread while no call is in flight.
 #include "common.h"
 
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -59,6 +63,54 @@ thread_local char g_err[512] = "";
 
 const SsTuning& ss_tuning() { return g_tuning; }
 
+// ---- in-process kernel timing (bench.py roofline leg): HIP events recorded on the LAUNCH stream around instrumented kernels ----
+namespace {
+struct ProfSlot { std::string name; long launches = 0; double flops = 0, bytes = 0, ms = 0; };
+struct ProfRec { int slot; hipEvent_t e0, e1; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfSlot> g_prof_slots;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_drain() {       // fold finished records into the slots (synchronises on each end event)
+    for (ProfRec& r : g_prof_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) g_prof_slots[r.slot].ms += ms;
+        g_prof_pool.push_back(r.e0);
+        g_prof_pool.push_back(r.e1);
+    }
+    g_prof_recs.clear();
+}
+}  // namespace
+
+SsProfScope::SsProfScope(const char* name, double flops, double bytes, hipStream_t s) : rec(-1), stream(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int slot = -1;
+    for (size_t i = 0; i < g_prof_slots.size(); ++i)
+        if (g_prof_slots[i].name == name) { slot = (int)i; break; }
+    if (slot < 0) { g_prof_slots.push_back(ProfSlot()); slot = (int)g_prof_slots.size() - 1; g_prof_slots[slot].name = name; }
+    g_prof_slots[slot].launches += 1;
+    g_prof_slots[slot].flops += flops;
+    g_prof_slots[slot].bytes += bytes;
+    ProfRec r{slot, prof_event(), prof_event()};
+    (void)hipEventRecord(r.e0, s);
+    g_prof_recs.push_back(r);
+    rec = (int)g_prof_recs.size() - 1;
+}
+SsProfScope::~SsProfScope() {
+    if (rec < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (rec < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[rec].e1, stream);
+}
+
 void ss_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -92,5 +144,33 @@ const char* ss_config_key(int index) {
 }
 
 const char* ss_last_error(void) { return g_err; }
+
+int ss_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return SS_OK;
+}
+int ss_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_drain();
+    g_prof_slots.clear();
+    return SS_OK;
+}
+int ss_prof_count(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    return (int)g_prof_slots.size();
+}
+int ss_prof_get(int index, ss_prof_entry* out) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!out || index < 0 || index >= (int)g_prof_slots.size()) return SS_ERR_INVALID;
+    prof_drain();
+    const ProfSlot& p = g_prof_slots[index];
+    snprintf(out->name, sizeof(out->name), "%s", p.name.c_str());
+    out->launches = p.launches;
+    out->total_ms = p.ms;
+    out->flops = p.flops;
+    out->bytes = p.bytes;
+    return SS_OK;
+}
 
 }  // extern "C"

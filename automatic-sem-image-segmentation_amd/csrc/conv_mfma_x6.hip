@@ -14,6 +14,7 @@
 // LDS rows are 80 bytes apart: the ds_read_b128 MFMA operand fetches (lane = row, 8 consecutive k) are conflict free.
 // One LDS stage (61 KB at 128x128) so that two workgroups share a CU and cover each other's barriers.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -29,6 +30,15 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_h2(float x0, float x1, unsigned int& hh, unsigned int& ll) {
     const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
     const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    hh = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+    ll = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+}
+
+// same with the low piece carried at 2^11 times its value (normal fp16 range for every element down to 2^-28 of the scaled maximum):
+// the cross products then go to their OWN accumulator, folded in as 2^-11 * (h*l' + l'*h) at the end (wgrad_x6_kernel)
+__device__ __forceinline__ void split_h2s(float x0, float x1, unsigned int& hh, unsigned int& ll) {
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 l0 = (_Float16)((x0 - (float)h0) * 2048.f), l1 = (_Float16)((x1 - (float)h1) * 2048.f);
     hh = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
     ll = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
 }
@@ -426,8 +436,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
             unsigned short* dst = sA + (4 * cq + e) * XLD + 4 * kq;
             if constexpr (H) {
                 unsigned int hh[2], ll[2];
-                split_h2(va[0][e] * a_scale, va[1][e] * a_scale, hh[0], ll[0]);
-                split_h2(va[2][e] * a_scale, va[3][e] * a_scale, hh[1], ll[1]);
+                split_h2s(va[0][e] * a_scale, va[1][e] * a_scale, hh[0], ll[0]);
+                split_h2s(va[2][e] * a_scale, va[3][e] * a_scale, hh[1], ll[1]);
                 *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
                 *(u32x2*)(dst + BM * XLD) = u32x2{ll[0], ll[1]};
             } else {
@@ -445,8 +455,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
                 unsigned short* dst = sB + (4 * cq + e) * XLD + 4 * kq;
                 if constexpr (H) {
                     unsigned int hh[2], ll[2];
-                    split_h2(vb[0][e] * b_scale, vb[1][e] * b_scale, hh[0], ll[0]);
-                    split_h2(vb[2][e] * b_scale, vb[3][e] * b_scale, hh[1], ll[1]);
+                    split_h2s(vb[0][e] * b_scale, vb[1][e] * b_scale, hh[0], ll[0]);
+                    split_h2s(vb[2][e] * b_scale, vb[3][e] * b_scale, hh[1], ll[1]);
                     *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
                     *(u32x2*)(dst + BN * XLD) = u32x2{ll[0], ll[1]};
                 } else {
@@ -461,13 +471,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
         }
     };
 
-    f32x16 acc[2][TN];
+    // H: acc = sum h*h, accx = sum (h*l' + l'*h) with l' = 2^11 * l: the cross terms keep full relative precision for operands of
+    // any magnitude (an output dominated by outlier x tiny needs the tiny element's low bits; tests/test_direct_gpu.py "outlier")
+    f32x16 acc[2][TN], accx[H ? 2 : 1][H ? TN : 1];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[mi][ni][r] = 0.f;
+                if constexpr (H) accx[mi][ni][r] = 0.f;
+            }
 
     if (nchunks > 0) {
         load_tiles(ps);
@@ -498,9 +513,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni) {
-                        if constexpr (H)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], acc[mi][ni], 0, 0, 0);
-                        else
+                        if constexpr (H) {
+                            if (q == 2) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
+                            else accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], accx[mi][ni], 0, 0, 0);
+                        } else
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
                     }
         }
@@ -521,7 +537,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < M) part[(long)m * p.Cb + n] = H ? acc[mi][ni][r] * out_scale : acc[mi][ni][r];
+                if (m < M) {
+                    if constexpr (H) part[(long)m * p.Cb + n] = (acc[mi][ni][r] + accx[mi][ni][r] * (1.f / 2048.f)) * out_scale;
+                    else part[(long)m * p.Cb + n] = acc[mi][ni][r];
+                }
             }
         }
     }
@@ -538,6 +557,10 @@ int launch_wgrad_x6h(const WGradParams& p, hipStream_t s) {
         return true;
     }();
     (void)attr_set;
+    char pname[64];
+    snprintf(pname, sizeof(pname), "wgrad_x6_kernel<%d,%s>", BN, H ? "true" : "false");
+    const double pix = (double)p.N * p.GH * p.GW * (p.nbatch > 1 ? p.nbatch : 1);
+    SsProfScope prof(pname, 2.0 * M * p.Cb * pix * (H ? 3 : 6), 4.0 * pix * (p.Ca + p.Cb) + 4.0 * M * p.Cb * p.splits, s);
     hipLaunchKernelGGL((wgrad_x6_kernel<BN, H>), grid, dim3(256), smem, s, p);
     SS_LAUNCH_CHECK();
     return SS_OK;
@@ -559,6 +582,10 @@ int launch_x6h(const GConvParams& p, const unsigned short* planes, long plane_el
         return true;
     }();
     (void)attr_set;
+    char pname[64];
+    snprintf(pname, sizeof(pname), "gconv_x6_kernel<%d,%d,%s>", BM, BN, H ? "true" : "false");
+    SsProfScope prof(pname, 2.0 * M * p.Cout * p.ntaps * p.Cin * nb * (H ? 3 : 6),
+                     4.0 * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout + (double)p.ntaps * p.Cin * p.Cout), s);
     hipLaunchKernelGGL((gconv_x6_kernel<BM, BN, H>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot);
     SS_LAUNCH_CHECK();
     return SS_OK;

@@ -230,6 +230,8 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     }();
     (void)attr_set;
     const long nwg = (long)gridM * gridN * p.nbatch * p.splits;
+    SsProfScope prof(p.fp16x2 ? "gemm_x6p_kernel<2>" : "gemm_x6p_kernel<3>", 2.0 * p.M * p.N * p.K * p.nbatch * (p.fp16x2 ? 3 : 6),
+                     2.0 * (p.fp16x2 ? 2 : 3) * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
     if (p.fp16x2) hipLaunchKernelGGL(gemm_x6p_kernel<2>, dim3((unsigned)nwg), dim3(512), 2 * 2 * (A_PLANE_B + B_PLANE_B), s, p);
     else hipLaunchKernelGGL(gemm_x6p_kernel<3>, dim3((unsigned)nwg), dim3(512), 2 * 3 * (A_PLANE_B + B_PLANE_B), s, p);
     SS_LAUNCH_CHECK();

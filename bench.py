@@ -6,30 +6,40 @@ global batch of synthetic SEM tiles (BASELINE.json metric: train_step tiles/sec,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     -- dominant kernel (fp32 MFMA implicit-GEMM of the 3x3 512->512 trunk convolution), algorithmic
-                  FLOPs per launch / HIP-event launch duration measured inside the timed region;
-  cpu_baseline -- the oracle (plain-torch CPU restatement of the same two steps) timed on the host cores on a
-                  bounded sample (rank 0, N=1 only).  Reported baseline only.
+Prints ONE JSON line on rank 0.  Every number in it is measured by THIS run (or, for `roofline.traffic`, read from the committed
+rocprofv3 PMC summary `profiles/pmc_traffic.json` that `tools/pmc_traffic.py` produces from this same command, and labelled so):
+
+  value / ms_per_step  -- the K timed steps (barrier + synchronize on both sides, max over ranks); `median_ms_per_step` beside it
+  cyclegan / unet      -- each trainer timed alone in further steps of the same process; `combined` = 1/(1/a + 1/b)
+  roofline             -- dominant CONTRACTION kernel class of the step: EXECUTED matrix-instruction FLOPs (every piece product of
+                          the operand splits) / HIP-event time of those launches (ss_prof_*: events on the launch stream, steps run
+                          on one stream) / dense peak of the instruction the kernel issues; `kernels` lists every instrumented class
+  arithmetic_modes     -- the same step under the two stricter arithmetic modes (x3h = 0: exact 3-piece bf16 split, 6 products;
+                          x6 = 0: fp32 MFMA instructions only)
+  cpu_baseline         -- the oracle (plain-torch CPU restatement of the same two steps) on the host cores, warm, median of the
+                          timed steps, on a bounded sample (rank 0, N=1 only).  Reported baseline only.
 """
 import argparse
 import importlib
 import json
 import os
+import statistics
 import sys
 import time
 
-import numpy as np
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 PKG = "automatic-sem-image-segmentation_amd"
 
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+# MI355X_MICROARCH.md: dense peaks at 256 CUs x 2.4 GHz
+PEAK_TFLOPS = {"f32_mfma": 157.3, "f16_mfma": 2516.6, "bf16_mfma": 2516.6}
+PEAK_HBM_TBPS = 8.0
 G_FWD_GF = {256: 102.29, 384: 230.15, 512: 409.16, 1024: 1636.65}   # SURVEY.md section 8 table
 D_FWD_GF = {256: 7.88, 384: 18.32, 512: 33.09, 1024: 135.56}
 U_FWD_GF = {256: 10.56, 384: 23.76, 512: 42.24, 1024: 168.94}
+UNET_BYTES_PER_TILE_512 = 6.5e9                                      # SURVEY 8(d): fp32 activations, 512x512
 
 
 def synthetic_tiles(n, size, seed):
@@ -50,24 +60,45 @@ def synthetic_tiles(n, size, seed):
     return real_a.permute(0, 2, 3, 1).contiguous(), real_b.permute(0, 2, 3, 1).contiguous()
 
 
-def cpu_baseline(size, batch, filters, threads):
-    """Oracle CycleGAN step + UNet step on the host, one step, bounded sample."""
+def cpu_baseline(size, batch, filters, threads, timed):
+    """Oracle CycleGAN step + UNet step on the host: one warm-up step on a quarter-size tile (thread pools, allocator, oneDNN
+    primitive caches), then `timed` steps at the sample size; the median is reported."""
     from oracle import nets as ON
     from oracle import steps as OS
     torch.set_num_threads(threads)
-    a, b = synthetic_tiles(batch, size, 4321)
     cg = OS.CycleGanStep(ON.ResnetGenerator(filters, seed=1), ON.ResnetGenerator(filters, seed=2),
                          ON.PatchDiscriminator(2 * filters, seed=3), ON.PatchDiscriminator(2 * filters, seed=4),
                          OS.ImagePool(2, 50), OS.ImagePool(2, 50))
     un = OS.UNetStep(ON.MultiResUNet(16, seed=5), 9.0)
-    t0 = time.perf_counter()
-    cg.train_step((a, b))
-    t1 = time.perf_counter()
-    un.train_step(((a + 1) / 2, (b + 1) / 2))
-    t2 = time.perf_counter()
-    return {"value": batch / (t2 - t0), "unit": "tiles/s", "cores": threads, "kind": "port",
-            "sample": f"1 step of the oracle (torch CPU fp32) CycleGAN+UNet train steps on {batch} synthetic {size}x{size} tile(s), "
-                      f"filters={filters}; cyclegan {t1 - t0:.1f}s + unet {t2 - t1:.1f}s"}
+    wa, wb = synthetic_tiles(batch, max(size // 2, 64), 99)
+    cg.train_step((wa, wb))
+    un.train_step(((wa + 1) / 2, (wb + 1) / 2))
+    a, b = synthetic_tiles(batch, size, 4321)
+    t_cg, t_un = [], []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        cg.train_step((a, b))
+        t1 = time.perf_counter()
+        un.train_step(((a + 1) / 2, (b + 1) / 2))
+        t2 = time.perf_counter()
+        t_cg.append(t1 - t0)
+        t_un.append(t2 - t1)
+    m_cg, m_un = statistics.median(t_cg), statistics.median(t_un)
+    return {"value": round(batch / (m_cg + m_un), 5), "unit": "tiles/s", "cores": threads, "kind": "port",
+            "role": "reported baseline only (not a target): plain-torch CPU fp32 restatement of the same two train steps",
+            "sample": f"oracle CycleGAN+UNet train steps on {batch} synthetic {size}x{size} tile(s), filters={filters}: 1 warm-up step on "
+                      f"{max(size // 2, 64)}x{max(size // 2, 64)} + {timed} timed steps, median; cyclegan {m_cg:.2f}s + unet {m_un:.2f}s"}
+
+
+def kernel_peak(name):
+    """Dense peak of the matrix instruction a contraction kernel class issues."""
+    if name.startswith("gemm_x6p_kernel<2>") or name.endswith(",true>"):
+        return "f16_mfma"        # x3h: v_mfma_f32_32x32x16_f16
+    if name.startswith(("gemm_x6p", "gconv_x6", "wgrad_x6")):
+        return "bf16_mfma"       # x6: v_mfma_f32_32x32x16_bf16
+    if name.startswith("tile_conv"):
+        return "f16_mfma" if "f16" in name or "x3h" in name else "bf16_mfma"
+    return "f32_mfma"
 
 
 def main():
@@ -79,8 +110,10 @@ def main():
     ap.add_argument("--global-batch", type=int, default=8)
     ap.add_argument("--filters", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cyclegan/unet split, the arithmetic-mode runs and the profile leg")
     ap.add_argument("--cpu-sample-size", type=int, default=512)
     ap.add_argument("--cpu-sample-batch", type=int, default=1)
+    ap.add_argument("--cpu-timed-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--skip-unet", action="store_true", help="diagnostics only: time the CycleGAN step alone")
     ap.add_argument("--only-unet", action="store_true", help="diagnostics only: time the UNet step alone")
@@ -93,13 +126,18 @@ def main():
     dev = D.local_device()
     torch.cuda.set_device(dev)
     E = importlib.import_module(PKG + ".engine")
+    L = importlib.import_module(PKG + "._lib")
     CG = importlib.import_module(PKG + ".CycleGAN")
     UN = importlib.import_module(PKG + ".UNet_Segmentation")
     NETS = importlib.import_module(PKG + ".nets")
     OPT = importlib.import_module(PKG + ".optim")
+    if world > 1:
+        # the exchange really runs over RCCL with one rank per GPU
+        assert torch.distributed.get_backend() == "nccl" and torch.distributed.get_world_size() == args.gpus
+        assert torch.cuda.device_count() >= args.gpus, "one GPU per rank"
 
     S, GB, F = args.size, args.global_batch, args.filters
-    assert GB % world == 0, "global batch must divide over the ranks"
+    D.check_batch_divisible(GB, world, "--global-batch")
     per = GB // world
 
     # networks exactly as CycleGAN.create_model / UNet.create_model build them for StartProcess.py's options
@@ -115,9 +153,6 @@ def main():
     model = CG.CycleGanModel(ga, gb, da, db, image_pool_a=CG.ImagePool(2, 50), image_pool_b=CG.ImagePool(2, 50))
     model.compile(OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5))
     umodel = UN.UNetModel(unet, 9.0, OPT.Adam(1e-3))
-    for g_ in (ga, gb):
-        for c0, _, c1, _ in g_.res:
-            c0.profile_tag = c1.profile_tag = "trunk_conv_fwd"
 
     # synthetic tiles, resident in HBM before the timed region
     a_all, b_all = synthetic_tiles(GB, S, 1234)
@@ -126,10 +161,10 @@ def main():
     ux = E.Act(((a.t + 1) / 2).contiguous(), requires_grad=False)
     uy = E.Act(((b.t + 1) / 2).contiguous(), requires_grad=False)
 
-    def step():
-        if not args.only_unet:
+    def step(cyclegan=not args.only_unet, unet_=not args.skip_unet):
+        if cyclegan:
             model.train_step((a, b))
-        if not args.skip_unet:
+        if unet_:
             umodel.train_step((ux.t, uy.t))
 
     def barrier():
@@ -137,91 +172,129 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, **kw):
+        """n steps between barriers: (total seconds, per-step seconds).  Every train step ends with a device->host read of its
+        metrics, so the per-step host timestamps are device-synchronous."""
+        barrier()
+        t0 = time.perf_counter()
+        marks = [t0]
+        for _ in range(n):
+            step(**kw)
+            marks.append(time.perf_counter())
+        barrier()
+        total = time.perf_counter() - t0
+        return total, [y - x for x, y in zip(marks[:-1], marks[1:])]
+
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # roofline leg: the timed steps run the two generator chains CONCURRENTLY on two HIP streams, where the HIP-event duration
-    # of one op includes its neighbour's kernels; so the dominant op is timed live in two further steps of the same workload run
-    # on ONE stream (same process, shapes, buffers; not part of `value`)
-    ksum = {}
-    if not args.only_unet:
+    elapsed, per_step = timed(args.steps)
+    elapsed = max_over_ranks(elapsed)
+    median_ms = max_over_ranks(statistics.median(per_step)) * 1e3
+
+    extras = {}
+    if not args.no_extras and not args.only_unet and not args.skip_unet:
+        k = max(3, min(args.steps, 5))
+        _, cg_t = timed(k, cyclegan=True, unet_=False)
+        _, un_t = timed(k, cyclegan=False, unet_=True)
+        cg_ms, un_ms = max_over_ranks(statistics.median(cg_t)) * 1e3, max_over_ranks(statistics.median(un_t)) * 1e3
+        cg_tps, un_tps = GB / cg_ms * 1e3, GB / un_ms * 1e3
+        ub = UNET_BYTES_PER_TILE_512 * (S / 512.0) ** 2
+        extras["cyclegan"] = {"tiles_per_s": round(cg_tps, 3), "median_ms_per_step": round(cg_ms, 3), "steps": k}
+        extras["unet"] = {"tiles_per_s": round(un_tps, 3), "median_ms_per_step": round(un_ms, 3), "steps": k, "bound": "hbm",
+                          "algorithmic_bytes_per_tile": ub, "achieved_TBps_per_gpu": round(un_tps * ub / 1e12 / world, 4),
+                          "hbm_frac": round(un_tps * ub / 1e12 / world / PEAK_HBM_TBPS, 4)}
+        extras["combined"] = {"tiles_per_s": round(1.0 / (1.0 / cg_tps + 1.0 / un_tps), 3), "formula": "1/(1/cyclegan + 1/unet)"}
+        # the same step under the stricter arithmetic modes (explicit ss_config_set switches, same process, same buffers)
+        modes = {}
+        for name, cfg in (("x6_exact_bf16_split_6_products", dict(x3h=0)), ("fp32_mfma_instructions_only", dict(x6=0))):
+            with L.config(**cfg):
+                step()
+                tot, _ = timed(3)
+            modes[name] = {"config": cfg, "tiles_per_s": round(GB * 3 / max_over_ranks(tot), 3)}
+        step()      # back on the default mode (re-warm caches keyed on the configuration)
+        extras["arithmetic_modes"] = modes
+
+    # roofline leg: the timed steps run two kernel chains CONCURRENTLY on two HIP streams, where an event interval also contains
+    # the neighbour's kernels; the contraction kernels are therefore timed (HIP events on the launch stream, inside the library:
+    # ss_prof_*) in two further steps of the same workload run on ONE stream (same process, shapes, buffers; not part of `value`)
+    prof = {}
+    if not args.no_extras:
         dual = model.dual_stream
         model.dual_stream = False
         step()
         torch.cuda.synchronize()
-        E.TIMER.enabled = True
+        lib = L.load()
+        lib.ss_prof_reset()
+        lib.ss_prof_enable(1)
         for _ in range(2):
             step()
-        E.TIMER.enabled = False
-        ksum = E.TIMER.summary()
+        torch.cuda.synchronize()
+        lib.ss_prof_enable(0)
+        prof = L.prof_summary()
         model.dual_stream = dual
     barrier()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = GB * args.steps / elapsed
+        x6, x3h = L.config_get("x6"), L.config_get("x3h")
+        arith = ("f32 storage + f32 accumulate; contractions on the 16-bit matrix cores with fp32-grade operand splits: "
+                 + ("x3h = 2 fp16 pieces under power-of-two scales (per tile in the Winograd GEMMs, per tensor elsewhere), 3 products"
+                    if x3h else "x6 = exact 3-piece bf16 split, 6 products")) if x6 else "f32 everywhere (v_mfma_f32_32x32x2_f32)"
         out = {"metric": "train_step tiles/sec (CycleGAN+UNet)", "value": round(value, 4), "unit": "tiles/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "arithmetic": "fp32 storage and accumulation everywhere; large contractions on the bf16/fp16 matrix cores with fp32-grade "
-                             "operand splits: 2-way fp16 split with power-of-two scales (per operand tensor; per tile in the Winograd GEMMs) "
-                             "x 3 products (x3h; SS_X3H=0: exact 3-way bf16 split x 6 products); measured error vs fp64 below the "
-                             "v_mfma_f32_32x32x2_f32 path's (SS_X6=0)" if os.environ.get("SS_X6", "1") != "0" else "fp32 MFMA",
+               "median_ms_per_step": round(median_ms, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32" if not x6 else ("f32 via 2xf16 split (x3h)" if x3h else "f32 via 3xbf16 split (x6)"),
+               "arithmetic": arith, "data": "synthetic",
                "config": {"workload": f"CycleGAN(2xResNet-9 gen F={F} + 2xPatchGAN, image buffer 50) train_step + MultiResUNet(16) "
-                                      f"train_step, {S}x{S} grayscale tiles, global batch {GB}" + (" [CycleGAN only]" if args.skip_unet else ""),
+                                      f"train_step, {S}x{S} grayscale tiles, global batch {GB}" + (" [CycleGAN only]" if args.skip_unet else "")
+                                      + (" [UNet only]" if args.only_unet else ""),
                           "tile": S, "global_batch": GB, "per_gpu_batch": per, "parallelism": f"dp{world}"}}
-        tk = ksum.get("trunk_conv_fwd")
-        if tk:
-            # one 3x3 (8F->8F) conv over n x (S/8)^2 pixels; launches carry per or 2*per samples (the translation and identity
-            # passes of a generator run as one batch): achieved = ALL algorithmic FLOPs of the timed launches / their total time
-            flops_sample = 2.0 * (S // 8) ** 2 * (8 * F) * (9 * 8 * F)
-            flops = flops_sample * tk["units"] / tk["launches"]             # average per launch
-            ach = flops_sample * tk["units"] / (tk["total_ms"] * 1e-3) / 1e12
-            out["roofline"] = {
-                "bound": "mfma",
-                "kernel": "3x3 512->512 trunk conv forward = amax(w) + wino_weight_x6<4,fp16> + wino_input<4,3> (V as 2 fp16 planes, one "
-                          "power-of-two scale per tile) + batched gemm_x6p_kernel<2> (36 GEMMs; x = h + 2^-11 l, 3 x v_mfma_f32_32x32x16_f16 "
-                          "per product, fp32 accumulate; both operands by LDS-DMA) + wino_output (undoes the scales); reflect pad fused in "
-                          "the input transform.  SS_X3H=0: three bf16 planes, six products; SS_X6=0: fp32-MFMA GEMMs",
-                # ALGORITHMIC (direct-convolution) FLOPs of the op / HIP-event duration of the op (single-stream steps, see above)
-                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                "note": "peak = dense fp32 matrix peak (v_mfma_f32_32x32x2_f32), the dtype's peak; frac exceeds 1 because (a) Winograd "
-                        "F(4x4,3x3) executes 4x fewer multiply-adds than the algorithmic count (38.7 of 154.6 GFLOP per launch at batch "
-                        "8) and (b) the GEMMs run as 3 fp16-MFMA products per fp32 product (0.19x the fp32-MFMA cost; rel-L2 error vs fp64 "
-                        "1.5e-6 against 3.1e-6 for the fp32-MFMA path: tests/test_layers_gpu.py::test_conv_x6_is_fp32_grade under "
-                        "SS_X6P=force).  The GEMM itself sustains 0.71 PFLOP/s of fp16 MFMA work = 0.28 of the 2.5 PFLOP/s peak "
-                        "(`executed`; 0.40 with the six-product bf16 kernel, which does twice the matrix work in 1.41x the time) "
-                        "(profiles/r01_w_x3h_single_stream_kernel_stats.md, profiles/r01_pmc_trunk_fwd_x6p.md)",
-                "executed_16bit_mfma_flops_per_launch": flops / 4.0 * (3.0 if os.environ.get("SS_X3H", "1") != "0" else 6.0),
-                # the GEMM kernel alone, from the committed rocprofv3 summary of this command (profiles/r01_w_x3h_single_stream_kernel_stats.md)
-                "executed": ({"kernel": "gemm_x6p_kernel<2>, the 36 batched GEMMs of a batch-8 op (1152 workgroups of 256x128)",
-                              "fp16_mfma_flops": flops_sample * 8 / 4.0 * 3.0, "kernel_avg_ms_rocprof": 0.1641,
-                              "achieved": round(flops_sample * 8 / 4.0 * 3.0 / 0.1641e-3 / 1e15, 3), "peak": 2.5, "unit": "PFLOP/s",
-                              "frac": round(flops_sample * 8 / 4.0 * 3.0 / 0.1641e-3 / 2.5e15, 3)}
-                             if (per == 8 and S == 512 and F == 64 and os.environ.get("SS_X6", "1") != "0" and os.environ.get("SS_X3H", "1") != "0") else None),
-                "executed_mfma_flops_per_launch": flops / 4.0,
-                # PMC cannot be sampled from inside this process: rocprofv3 pass on the direct (non-Winograd) kernel of this shape
-                # PMC cannot be sampled from inside this process: committed rocprofv3 passes on this op/shape at batch 8
-                # (profiles/r01_pmc_trunk_fwd_x3h.md): sum over the op's 5 kernels of 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
-                "traffic": (2 * (4622 + 4658 + 48737 + 100230 + 73922) + (128 + 36864 + 147526 + 147456 + 65536)) * 1024.0 if (per == 8 and S == 512 and F == 64) else None,
-                "traffic_unit": "bytes per batch-8 op launch (PMC passes on tools/bench_kernels.py trunk_fwd)", "algorithmic_bytes": 4.0 * (2 * per * (S // 8) ** 2 * 8 * F + 9 * (8 * F) ** 2),          # of a batch-`per` launch
-                "winograd_algorithmic_bytes": 4.0 * ((1 + 4 * 2.25 + 1) * per * (S // 8) ** 2 * 8 * F + (9 + 36 + 36) * (8 * F) ** 2),
-                "launches_timed": tk["launches"], "avg_launch_ms": round(tk["avg_ms"], 4), "flops_per_launch": flops}
+        out.update(extras)
+        if prof:
+            table = {}
+            for name, e in prof.items():
+                pk = kernel_peak(name)
+                ach = e["flops"] / (e["total_ms"] * 1e-3) / 1e12 if e["total_ms"] > 0 else 0.0
+                table[name] = {"launches": e["launches"], "avg_ms": round(e["avg_ms"], 4), "total_ms_per_step": round(e["total_ms"] / 2, 3),
+                               "executed_tflop_per_launch": round(e["flops"] / e["launches"] / 1e12, 5), "achieved": round(ach, 1),
+                               "peak": PEAK_TFLOPS[pk], "instruction": pk, "frac": round(ach / PEAK_TFLOPS[pk], 4)}
+            dom = max(table, key=lambda n_: table[n_]["total_ms_per_step"])
+            d = table[dom]
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("workload") == [S, GB, F, world]:
+                        traffic = tj.get("kernels", {}).get(dom)
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s",
+                               "frac": d["frac"], "avg_launch_ms": d["avg_ms"], "launches_timed": d["launches"],
+                               "definition": "EXECUTED matrix-instruction FLOPs of the timed launches (all piece products of the operand "
+                                             "split, useful rows/columns only) / their HIP-event time (ss_prof_*, launch stream, "
+                                             "single-stream steps) / dense peak of the instruction the kernel issues",
+                               "traffic": traffic,
+                               "traffic_source": "profiles/pmc_traffic.json (tools/pmc_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / "
+                                                 "WRITE_SIZE passes of this command, gfx950 corrections of MI355X_MICROARCH.md), bytes per "
+                                                 "launch" if traffic is not None else None,
+                               "kernels": table}
         if S in G_FWD_GF:
-            alg = (18 * G_FWD_GF[S] + 16 * D_FWD_GF[S] + (0 if args.skip_unet else 3 * U_FWD_GF[S])) * 1e9
-            out["step_algorithmic_tflops"] = round(alg * value / 1e12 / world, 2)   # per GPU, whole step incl. HBM-bound parts
+            alg = (0 if args.only_unet else 18 * G_FWD_GF[S] + 16 * D_FWD_GF[S]) + (0 if args.skip_unet else 3 * U_FWD_GF[S])
+            out["algorithmic_tflops_per_gpu"] = round(alg * 1e9 * value / 1e12 / world, 2)   # SURVEY 8d direct-conv FLOPs, whole step
         if world == 1 and not args.no_cpu_baseline:
             # torch CPU convs on the 256-thread host get SLOWER beyond ~16 threads (measured: 256^2 tile 2.2 s @16, 3.0 s @32, 6.6 s @64)
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_size, args.cpu_sample_batch, F, min(os.cpu_count() or 1, args.cpu_threads))
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_size, args.cpu_sample_batch, F, min(os.cpu_count() or 1, args.cpu_threads),
+                                               args.cpu_timed_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -72,6 +72,16 @@ int ss_config_set(const char* key, int64_t value);
 int64_t ss_config_get(const char* key);
 const char* ss_config_key(int index);
 
+/* In-process kernel timing for bench.py's roofline leg: while enabled, the instrumented launchers (the contraction kernels:
+ * gemm_x6p, gconv_x6, wgrad_x6, tile_conv, ...) bracket each kernel with HIP events recorded on the launch stream and count its
+ * EXECUTED matrix-instruction FLOPs (every piece product of the x3h / x6 splits) and algorithmic bytes.  ss_prof_get synchronises
+ * on the recorded events.  Profile on ONE stream: with two concurrent chains an interval also contains the neighbour's kernels. */
+typedef struct ss_prof_entry { char name[64]; int64_t launches; double total_ms; double flops; double bytes; } ss_prof_entry;
+int ss_prof_enable(int on);
+int ss_prof_reset(void);
+int ss_prof_count(void);
+int ss_prof_get(int index, ss_prof_entry* out);
+
 /* ------------------------------------------------------------------------------------------
  * 2-D convolution / transposed convolution.
  * Replaces keras.layers.Conv2D at CycleGAN.py:327,333,340,372,393,429/431,448 and

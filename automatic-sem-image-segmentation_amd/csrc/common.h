@@ -177,6 +177,17 @@ int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accu
 int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split, int nbatch = 1);
 int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s);   // partials only: part[batch][split][M][Cb]
 
+int ss_launch_wgrad_reduce(const WGradParams& p, float* dw, int ldw, int accumulate, int rows, hipStream_t s);
+
+// LDS-staged tile kernels for small-channel stride-1 convs on large maps (conv_tile.hip): forward / data gradient (x3h arithmetic
+// with per-tile scales) and weight gradient (fp32 MFMA, one partial per persistent workgroup)
+bool ss_tconv_ok(const GConvParams& p);
+size_t ss_tconv_ws(const GConvParams& p);
+int ss_launch_tconv(const GConvParams& p, void* ws, size_t ws_bytes, hipStream_t s);
+bool ss_twgrad_ok(const WGradParams& p);
+int ss_twgrad_splits(const WGradParams& p);
+int ss_launch_twgrad_partials(const WGradParams& p, hipStream_t s);
+
 // LDS-tiled VALU kernels for stride-1 convs with one channel on one side (conv_c1.hip)
 bool ss_conv_out1_ok(const GConvParams& p);
 int ss_launch_conv_out1(const GConvParams& p, hipStream_t s);

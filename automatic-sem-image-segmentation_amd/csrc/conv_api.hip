@@ -329,8 +329,21 @@ bool need_x_amax_fwd(const ConvProb& c, int algo);
 bool need_dy_amax_dgrad(const ConvProb& c, int algo);
 bool need_amax_wgrad(const ConvProb& c, int algo);
 
+// LDS-staged tile kernel (conv_tile.hip): small-channel stride-1 problems on large maps, after the one-channel kernels
+bool tconv_takes(int algo, const GConvParams& p) {
+    return (algo == SS_ALGO_AUTO || algo == SS_ALGO_X6) && !ss_conv_out1_ok(p) && !ss_conv_in1_ok(p) && ss_tconv_ok(p);
+}
+// upper bound of its weight-plane scratch for `cred` reduction channels, `cout` outputs, `ntaps` taps
+size_t tconv_ws_ub(int cred, int cout, int ntaps) {
+    const int nq = (ntaps * ((cred + 7) / 8) + 1) / 2 * 2, nb = (cout + 31) / 32;
+    return 256 + (size_t)2 * nb * 32 * nq * 16;
+}
+
 size_t gconv_ws_bytes(int algo, const GConvParams& p) {
-    if (!gconv_two_stage(algo, p)) return 256 + x6_planes_ub(p.Cin, p.Cout, p.ntaps);
+    if (!gconv_two_stage(algo, p)) {
+        const size_t a = 256 + x6_planes_ub(p.Cin, p.Cout, p.ntaps), b = tconv_ws_ub(p.Cin, p.Cout, p.ntaps);
+        return a > b ? a : b;
+    }
     return two_stage_ws(p.N, p.IH, p.IW, p.Cin, p.Cout, p.ntaps);
 }
 
@@ -339,6 +352,7 @@ int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStre
         if (ss_conv_out1_ok(p)) return ss_launch_conv_out1(p, s);
         if (ss_conv_in1_ok(p)) return ss_launch_conv_in1(p, s);
     }
+    if (tconv_takes(algo, p) && ws && ws_bytes >= ss_tconv_ws(p)) return ss_launch_tconv(p, ws, ws_bytes, s);
     if (gconv_two_stage(algo, p)) {
         if (!ws || ws_bytes < gconv_ws_bytes(algo, p)) return SS_ERR_WORKSPACE;
         const int tcs = round4(p.ntaps);
@@ -447,6 +461,7 @@ size_t bwd_data_ws(const ConvProb& c) {
     // [transposed weights][padded gradient (reflect)][two-stage scratch of the gather conv (Cin == 1 stems) | Winograd scratch]
     size_t extra = two_stage_ws(c.n, c.oh, c.ow, c.cout, c.cin, c.kh * c.kw);
     { const size_t xq = x6_planes_ub(c.cout, c.cin, c.kh * c.kw); if (xq > extra) extra = xq; }
+    { const size_t tq = tconv_ws_ub(c.cout, c.cin, c.kh * c.kw); if (tq > extra) extra = tq; }
     WinoProb q;
     if (wino_dgrad_prob(c, SS_ALGO_AUTO, &q)) { const size_t wq = ss_wino_fwd_ws(q); if (wq > extra) extra = wq; }
     return bwd_data_wt_bytes(c) + bwd_data_dpad_bytes(c) + extra;
@@ -539,20 +554,62 @@ int wgrad_c1_mode(const ConvProb& c, int algo) {
     return -1;
 }
 
+// the stride-1, zero-padded data-gradient problem of `c` as conv_bwd_data builds it (pointers left null): eligibility checks only
+GConvParams dgrad_params_s1(const ConvProb& c) {
+    GConvParams p{};
+    p.N = c.n; p.IH = c.oh; p.IW = c.ow; p.Cin = c.cout; p.in_cs = c.out_cs;
+    p.in_s = 1; p.Cout = c.cin; p.ldb = c.cin; p.reflect = 0;
+    p.OH = c.ih; p.OW = c.iw; p.out_cs = c.in_cs; p.out_s = 1; p.OHc = c.ih; p.OWc = c.iw;
+    for (int a = 0; a < c.kh; ++a)
+        for (int b = 0; b < c.kw; ++b) {
+            GTap& t = p.taps[p.ntaps++];
+            t.dy = (int16_t)(c.pt - a); t.dx = (int16_t)(c.pl - b); t.woff = (a * c.kw + b) * c.cin * c.cout;
+        }
+    return p;
+}
+bool tconv_takes_fwd(const ConvProb& c, int algo) {
+    return c.kh * c.kw <= SS_MAX_TAPS && tconv_takes(algo, fwd_params(c, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0));
+}
+bool tconv_takes_dgrad(const ConvProb& c, int algo) {
+    return c.kh * c.kw <= SS_MAX_TAPS && c.s == 1 && !c.reflect && tconv_takes(algo, dgrad_params_s1(c));
+}
+WGradParams wgrad_params(const ConvProb& c, const float* x, const float* dy, float* part) {
+    WGradParams p{};
+    p.a = x; p.b = dy; p.part = part;
+    p.N = c.n; p.AH = c.ih; p.AW = c.iw; p.Ca = c.cin; p.a_cs = c.in_cs;
+    p.GH = c.oh; p.GW = c.ow; p.Cb = c.cout; p.b_cs = c.out_cs;
+    p.a_s = c.s; p.a_oy = -c.pt; p.a_ox = -c.pl; p.reflect = c.reflect;
+    p.ntaps = 0;
+    for (int a = 0; a < c.kh; ++a)
+        for (int b = 0; b < c.kw; ++b) {
+            GTap& t = p.taps[p.ntaps++];
+            t.dy = (int16_t)a; t.dx = (int16_t)b; t.woff = (a * c.kw + b) * c.cin * c.cout;
+        }
+    return p;
+}
+// LDS-staged tile weight gradient (conv_tile.hip, fp32 MFMA): the shapes the 16-bit split kernel (wgrad_x6) does not take
+bool twgrad_takes(const ConvProb& c, int algo) {
+    if (!(algo == SS_ALGO_AUTO || algo == SS_ALGO_X6) || c.kh * c.kw > SS_MAX_TAPS) return false;
+    const bool x6_shape = c.cin % 32 == 0 && c.cout >= 32 && c.cout % 4 == 0;
+    return !x6_shape && ss_twgrad_ok(wgrad_params(c, nullptr, nullptr, nullptr));
+}
+
 bool need_x_amax_fwd(const ConvProb& c, int algo) {
     WinoProb q;
+    if (tconv_takes_fwd(c, algo)) return false;           // per-tile scales, taken while the tile is staged
     return x3h_direct_wanted(algo, c.cin, c.cout) && (long)c.n * c.oh * c.ow >= 1024 &&
            c.kh * c.kw <= SS_MAX_TAPS && !wino_fwd_prob(c, algo, &q);
 }
 bool need_dy_amax_dgrad(const ConvProb& c, int algo) {
     WinoProb q;
+    if (tconv_takes_dgrad(c, algo) && !wino_dgrad_prob(c, algo, &q)) return false;
     return x3h_direct_wanted(algo, c.cout, c.cin) && (long)c.n * c.oh * c.ow >= 1024 &&
            c.kh * c.kw <= SS_MAX_TAPS && !(c.reflect && c.s != 1) && !wino_dgrad_prob(c, algo, &q);
 }
 bool need_amax_wgrad(const ConvProb& c, int algo) {
     WinoProb q;
     if (c.kh * c.kw > SS_MAX_TAPS || algo == SS_ALGO_DIRECT || wino_fwd_prob(c, algo, &q) || wgrad_c1_mode(c, algo) >= 0 ||
-        wgrad_two_stage(c, algo))
+        wgrad_two_stage(c, algo) || twgrad_takes(c, algo))
         return false;
     return x6_wanted(algo) && ss_x3h_enabled() && x3h_direct_wanted(algo, 32, 32) && c.cin % 32 == 0 && c.in_cs % 4 == 0 &&
            c.cout >= 32 && c.cout % 4 == 0 && c.out_cs % 4 == 0 && c.ow >= 4;
@@ -574,6 +631,10 @@ size_t bwd_weight_ws(const ConvProb& c) {
     {
         WinoProb q;
         if (wino_fwd_prob(c, SS_ALGO_AUTO, &q)) { const size_t wq = ss_wino_wgrad_ws(q); if (wq > b) b = wq; }
+    }
+    if (twgrad_takes(c, SS_ALGO_AUTO)) {
+        const size_t tq = ss_align_up((size_t)ss_twgrad_splits(wgrad_params(c, nullptr, nullptr, nullptr)) * M * c.cout * sizeof(float), 256);
+        if (tq > b) b = tq;
     }
     if (wgrad_c1_mode(c, SS_ALGO_AUTO) >= 0) {
         const bool m0 = wgrad_c1_mode(c, SS_ALGO_AUTO) == 0;
@@ -601,18 +662,15 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
             return ss_launch_wgrad_c1(1, dy, c.out_cs, c.cout, c.n, c.oh, c.ow, x, c.in_cs, c.ih, c.iw, c.kh, c.kw, c.pt, c.pl, c.reflect,
                                       dw, accumulate, ws, s);
     }
-    WGradParams p{};
+    WGradParams p = wgrad_params(c, x, dy, (float*)ws);
     p.x6 = x6_wanted(algo);
-    p.a = x; p.b = dy; p.part = (float*)ws;
-    p.N = c.n; p.AH = c.ih; p.AW = c.iw; p.Ca = c.cin; p.a_cs = c.in_cs;
-    p.GH = c.oh; p.GW = c.ow; p.Cb = c.cout; p.b_cs = c.out_cs;
-    p.a_s = c.s; p.a_oy = -c.pt; p.a_ox = -c.pl; p.reflect = c.reflect;
-    p.ntaps = 0;
-    for (int a = 0; a < c.kh; ++a)
-        for (int b = 0; b < c.kw; ++b) {
-            GTap& t = p.taps[p.ntaps++];
-            t.dy = (int16_t)a; t.dx = (int16_t)b; t.woff = (a * c.kw + b) * c.cin * c.cout;
-        }
+    if (twgrad_takes(c, algo)) {
+        p.splits = ss_twgrad_splits(p);
+        p.pix_per_split = 0;
+        int rc = ss_launch_twgrad_partials(p, s);
+        if (rc != SS_OK) return rc;
+        return ss_launch_wgrad_reduce(p, dw, c.cout, accumulate, p.ntaps * p.Ca, s);
+    }
     if (algo == SS_ALGO_DIRECT) {
         p.splits = 1; p.pix_per_split = 0;
         return ss_launch_wgrad_direct(p, dw, c.cout, accumulate, s);

@@ -760,6 +760,14 @@ int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accu
     return SS_OK;
 }
 
+// dw[woff_t + ca*ldw + cb] (+)= sum over p.splits partials part[split][(t,ca)][cb] (fixed order)
+int ss_launch_wgrad_reduce(const WGradParams& p, float* dw, int ldw, int accumulate, int rows, hipStream_t s) {
+    const long total = (long)rows * p.Cb;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, dw, ldw, accumulate, rows);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
 int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s) {
     if (p.x6 && ss_wgrad_x6_ok(p)) return ss_launch_wgrad_x6_partials(p, s);
     {

@@ -226,6 +226,7 @@ ADV_CASES = [
     ("trunk_wino_per_tile", 3, 128, 128, 1, ("reflect", 1), False, 2, 48, 48),
     ("disc_4x4_s2_per_tensor", 4, 64, 128, 2, "valid", False, 2, 66, 66),
     ("up_T3_per_tensor", 3, 64, 32, 2, "same", True, 2, 32, 32),
+    ("tile_3x3_16_16_per_tile", 3, 16, 16, 1, "same", False, 1, 256, 256),      # conv_tile.hip: one scale per 8x32 pixel tile
 ]
 
 

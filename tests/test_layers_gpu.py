@@ -68,6 +68,18 @@ CONV_CASES = [
     ("c7_in_tiled", 7, 1, 32, 1, ("reflect", 3), False, None, False, 1, 130, 128),
     ("c4_out_tiled_valid", 4, 12, 1, 1, "valid", True, None, False, 2, 100, 96),
     ("c3_in_tiled_same_bias", 3, 1, 16, 1, "same", True, "lrelu", False, 2, 96, 100),
+    # >= 65536 output pixels, stride 1, <= 64 channels: LDS-staged tile kernels (conv_tile.hip): forward / data gradient on the fp16
+    # matrix cores with per-tile scales, weight gradient with fp32 MFMA (the MultiResUNet's 512x512 / 256x256 layers)
+    ("tile_3x3_16_16", 3, 16, 16, 1, "same", False, None, False, 1, 256, 256),
+    ("tile_3x3_odd_25_13_ragged", 3, 25, 13, 1, "same", False, None, False, 2, 200, 180),
+    ("tile_1x1_25_51_bias_tanh", 1, 25, 51, 1, "same", True, "tanh", False, 1, 256, 272),
+    ("tile_3x3_1_4", 3, 1, 4, 1, "same", False, None, False, 1, 256, 256),
+    ("tile_3x3_64_17", 3, 64, 17, 1, "same", False, None, False, 1, 264, 256),
+    ("tile_3x3_35_53", 3, 35, 53, 1, "same", False, None, False, 1, 256, 256),
+    ("tile_3x3_reflect_8_8", 3, 8, 8, 1, ("reflect", 1), False, None, False, 1, 258, 254),
+    ("tile_1x1_32_1_head", 1, 32, 1, 1, "same", False, None, False, 1, 256, 256),
+    ("tile_1x1_64_105", 1, 64, 105, 1, "same", False, None, False, 1, 256, 256),
+    ("tile_3x3_valid_8_32", 3, 8, 32, 1, "valid", False, None, False, 1, 300, 260),
 ]
 
 
@@ -130,9 +142,12 @@ def test_conv_fwd_bwd(case, algo):
         assert_close(arena.grad("c/bias").cpu(), br.grad, f"{name}/{algo} db", rtol=2e-4)
 
 
-def test_conv_into_and_from_channel_slices():
-    """Keras concatenate without copies: conv reads a slice and writes a slice of wider buffers."""
+@pytest.mark.parametrize("hw", [(12, 12), (192, 200)], ids=["small", "tile_kernels"])
+def test_conv_into_and_from_channel_slices(hw):
+    """Keras concatenate without copies: conv reads a slice and writes a slice of wider buffers (small maps: implicit-GEMM kernels;
+    >= 65536 pixels: the LDS-staged tile kernels with strided, 16-byte-unaligned channel views)."""
     E, LY, L = _mods()
+    H, W = hw
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(5)
     arena = E.ParamArena(dev)
@@ -140,9 +155,9 @@ def test_conv_into_and_from_channel_slices():
     arena.materialize()
     w_cpu = torch.rand((3, 3, 8, 13), generator=g) - 0.5
     arena["c/kernel"].copy_(w_cpu)
-    xin = torch.rand((2, 12, 12, 20), generator=g)
+    xin = torch.rand((2, H, W, 20), generator=g)
     xbuf = E.Act(xin.to(dev))
-    ybuf = E.Act(torch.zeros((2, 12, 12, 30), device=dev))
+    ybuf = E.Act(torch.zeros((2, H, W, 30), device=dev))
     tape = E.Tape()
     y = layer(tape, xbuf.slice(4, 8), out=ybuf.slice(10, 13))
     xr = xin[..., 4:12].clone().requires_grad_(True)

@@ -33,6 +33,7 @@ const Key KEYS[] = {
     {"gconv_nt512", &SsTuning::nt512, "measurement: 512-thread 128x128 tile variant"},
     {"gconv_tile256", &SsTuning::tile256, "measurement: 256x128 tile variant"},
     {"tile_conv", &SsTuning::tile_conv, "LDS-staged tile kernel for small-channel stride-1 convolutions (MultiResUNet full-resolution layers)"},
+    {"tile_th", &SsTuning::tile_th, "tile kernel rows per tile: 0 auto, 4 or 8 (measurement)"},
     {"weight_cache", &SsTuning::weight_cache, "reserved"},
 };
 
@@ -52,6 +53,7 @@ SsTuning from_env() {
     v.nt512 = getenv("SS_GCONV_NT512") ? 1 : 0;
     v.tile256 = getenv("SS_GCONV_256") ? 1 : 0;
     v.tile_conv = env_is("SS_TILE_CONV", '0') ? 0 : 1;
+    v.tile_th = getenv("SS_TILE_TH") ? atoi(getenv("SS_TILE_TH")) : 0;
     v.weight_cache = 1;
     return v;
 }

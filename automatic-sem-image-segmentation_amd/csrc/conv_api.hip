@@ -335,7 +335,7 @@ bool tconv_takes(int algo, const GConvParams& p) {
 }
 // upper bound of its weight-plane scratch for `cred` reduction channels, `cout` outputs, `ntaps` taps
 size_t tconv_ws_ub(int cred, int cout, int ntaps) {
-    const int nq = (ntaps * ((cred + 7) / 8) + 1) / 2 * 2, nb = (cout + 31) / 32;
+    const int nq = ntaps * (((cred + 7) / 8 + 1) / 2) * 2, nb = (cout + 31) / 32;
     return 256 + (size_t)2 * nb * 32 * nq * 16;
 }
 

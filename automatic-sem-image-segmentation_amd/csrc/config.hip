@@ -34,6 +34,8 @@ const Key KEYS[] = {
     {"gconv_tile256", &SsTuning::tile256, "measurement: 256x128 tile variant"},
     {"tile_conv", &SsTuning::tile_conv, "LDS-staged tile kernel for small-channel stride-1 convolutions (MultiResUNet full-resolution layers)"},
     {"tile_th", &SsTuning::tile_th, "tile kernel rows per tile: 0 auto, 4 or 8 (measurement)"},
+    {"tile_dbg", &SsTuning::tile_dbg, "measurement: phase-skipping bit mask of the tile kernel"},
+    {"tile_stagger", &SsTuning::tile_stagger, "tile kernel: start delay between co-resident workgroups (units of 2048 cycles)"},
     {"weight_cache", &SsTuning::weight_cache, "reserved"},
 };
 
@@ -54,6 +56,8 @@ SsTuning from_env() {
     v.tile256 = getenv("SS_GCONV_256") ? 1 : 0;
     v.tile_conv = env_is("SS_TILE_CONV", '0') ? 0 : 1;
     v.tile_th = getenv("SS_TILE_TH") ? atoi(getenv("SS_TILE_TH")) : 0;
+    v.tile_dbg = getenv("SS_TILE_DBG") ? atoi(getenv("SS_TILE_DBG")) : 0;
+    v.tile_stagger = getenv("SS_TILE_STAGGER") ? atoi(getenv("SS_TILE_STAGGER")) : 2;
     v.weight_cache = 1;
     return v;
 }

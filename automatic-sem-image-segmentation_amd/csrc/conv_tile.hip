@@ -30,13 +30,15 @@ constexpr int T_THREADS = 256;         // 4 waves
 constexpr int MAXQ = 96;               // k-groups (8 channels of one tap) per problem: 9 taps x 64 channels = 72 (+ padding)
 
 struct TileGeom {
-    int th;                 // tile rows (4 or 8)
     int cg;                 // channel groups of 8 per tap (CinPad / 8)
     int cgp;                // K steps (16 channels = two groups) per tap: (cg + 1) / 2; the odd group of the last step has zero weights
     int nq;                 // k-groups in the weight planes: ntaps * cgp * 2
-    int nb;                 // 32-wide output-channel blocks
-    unsigned m_c4n, m_cg;   // ceil(2^32 / d) for d = 2*cg (float4 slots per staged pixel) and d = cg: x / d == umulhi(x, m) for x*d < 2^32
+    int nb;                 // 32-row output-channel blocks
+    int pf;                 // float4 staging slots per thread: ceil(hh * hw * 2 * cg / 256)
+    unsigned m_c4n, m_cg, m_hw, m_cout, m_pertap;   // ceil(2^32 / d): x / d == umulhi(x, m) for x * d < 2^32 (d = 2*cg, cg, hw, Cout; d == 1 handled apart)
     int wgs_per_cu;
+    int stagger;            // start delay between co-resident workgroups, in units of 2048 cycles
+    int dbg;                // measurement only ("tile_dbg"): 1 skip global loads, 2 skip the conversion, 4 skip the MFMAs, 8 skip the stores
     int hy0, hx0;           // smallest tap offset (in_oy + dy, in_ox + dx)
     int hh, hw;             // halo tile extents (pixels)
     int psb;                // bytes per staged pixel: cg * 32 (+16 so that it is an odd multiple of 16 -> conflict-free b128 reads)
@@ -44,7 +46,11 @@ struct TileGeom {
     size_t in_bytes, w_bytes, smem;
 };
 
+constexpr int TH = 4;                  // tile rows: one per wave
+
 inline int odd16(int bytes) { return ((bytes / 16) % 2 == 0) ? bytes + 16 : bytes; }
+inline unsigned magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + d - 1) / d); }
+__device__ __forceinline__ int fdiv(int x, int d, unsigned m) { return d == 1 ? x : (int)__umulhi((unsigned)x, m); }
 
 bool tile_geom(const GConvParams& p, TileGeom* g) {
     if (p.ntaps < 1 || p.nbatch > 1 || p.in_s != 1 || p.out_s != 1 || p.out_oy || p.out_ox || p.OHc != p.OH || p.OWc != p.OW) return false;
@@ -54,76 +60,29 @@ bool tile_geom(const GConvParams& p, TileGeom* g) {
         y0 = oy < y0 ? oy : y0; y1 = oy > y1 ? oy : y1; x0 = ox < x0 ? ox : x0; x1 = ox > x1 ? ox : x1;
     }
     if (y1 - y0 > 2 || x1 - x0 > 2) return false;               // 1x1 .. 3x3 footprints
+    g->dbg = ss_tuning().tile_dbg;
+    g->stagger = ss_tuning().tile_stagger;
     g->cg = (p.Cin + 7) / 8;
     g->cgp = (g->cg + 1) / 2;
     g->nq = p.ntaps * g->cgp * 2;
     g->nb = (p.Cout + 31) / 32;
-    g->m_c4n = (unsigned)((0x100000000ULL + 2 * g->cg - 1) / (2 * g->cg));
-    g->m_cg = (unsigned)((0x100000000ULL + g->cg - 1) / g->cg);
     if (g->nq > MAXQ || g->nb > 4) return false;
     g->hy0 = y0; g->hx0 = x0;
     g->hw = TW + (x1 - x0);
+    g->hh = TH + (y1 - y0);
+    g->m_c4n = magic(2 * g->cg); g->m_cg = magic(g->cg); g->m_hw = magic(g->hw); g->m_cout = magic(p.Cout); g->m_pertap = magic(p.Cin * p.Cout);
+    g->pf = (g->hh * g->hw * 2 * g->cg + T_THREADS - 1) / T_THREADS;
+    if (g->pf > 13) return false;
     g->psb = odd16(g->cg * 32);
     g->ksb = odd16(g->nq * 16);
     g->w_bytes = (size_t)2 * g->nb * 32 * g->ksb;
-    // tile height: 8 rows (2 MFMA row blocks per wave: weight fragments and the halo are amortised better) when two workgroups
-    // of it fit a CU, unless 4 rows allow twice the resident workgroups (the phases of a tile -- load, convert, contract, store --
-    // are serial inside a workgroup: co-resident workgroups are what overlaps them); "tile_th" overrides for measurements
-    const int force = ss_tuning().tile_th;
-    for (int th = 8; th >= 4; th -= 4) {
-        g->th = th;
-        g->hh = th + (y1 - y0);
-        g->in_bytes = (size_t)g->hh * g->hw * g->psb;
-        g->smem = g->in_bytes + g->w_bytes + 64;
-        int per = (int)((160 * 1024) / (g->smem + 1024));
-        const int cap = th == 8 ? 2 : 4;                        // VGPR budget: 202 / 128 registers
-        g->wgs_per_cu = per > cap ? cap : per;
-        if (force == th && g->wgs_per_cu >= 1) return true;
-        if (force == 0 && th == 8 && g->wgs_per_cu >= 2) {
-            TileGeom h = *g;
-            h.th = 4; h.hh = 4 + (y1 - y0);
-            h.in_bytes = (size_t)h.hh * h.hw * h.psb;
-            h.smem = h.in_bytes + h.w_bytes + 64;
-            const int per4 = (int)((160 * 1024) / (h.smem + 1024));
-            if (per4 < 4) return true;                          // 4-row tiles would not reach 4 workgroups per CU: keep 8 rows
-        }
-    }
-    return g->wgs_per_cu >= 1;                                  // th = 4
-}
-
-// ---- weights -> two fp16 planes [plane][nb*32 rows (co)][nq*8 (k = (tap, cg, 8 channels))], one power-of-two scale for the tensor
-// ws layout: int e_w at byte 0, planes from byte 256.  One workgroup (the tensors have at most a few 10^4 elements).
-__global__ __launch_bounds__(256) void tconv_wprep_kernel(GConvParams p, int cg, int cgp, int nq, int nb, unsigned char* __restrict__ ws) {
-    __shared__ float red[256];
-    const int tid = threadIdx.x;
-    const int total = p.ntaps * p.Cin * p.Cout;
-    float m = 0.f;
-    for (int e = tid; e < total; e += 256) {
-        const int co = e % p.Cout, r = e / p.Cout, ci = r % p.Cin, t = r / p.Cin;
-        m = fmaxf(m, fabsf(p.w[p.taps[t].woff + (long)ci * p.ldb + co]));
-    }
-    red[tid] = m;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (tid < off) red[tid] = fmaxf(red[tid], red[tid + off]);
-        __syncthreads();
-    }
-    const int ew = ss_amax_exp(red[0]);
-    if (tid == 0) *(int*)ws = ew;
-    const float sw = ldexpf(1.f, 14 - ew);
-    unsigned short* ph = (unsigned short*)(ws + 256);
-    const int K = nq * 8, rows = nb * 32;
-    unsigned short* pl = ph + (long)rows * K;
-    for (int e = tid; e < rows * K; e += 256) {
-        const int k = e % K, n = e / K;
-        const int q = k / 8, j = k % 8, t = q / (2 * cgp), c = q % (2 * cgp), ci = c * 8 + j;      // k = ((t * cgp + step) * 2 + half) * 8 + j
-        float v = 0.f;
-        if (t < p.ntaps && c < cg && ci < p.Cin && n < p.Cout) v = p.w[p.taps[t].woff + (long)ci * p.ldb + n] * sw;
-        const _Float16 h = (_Float16)v;
-        const _Float16 l = (_Float16)(v - (float)h);
-        ph[e] = __builtin_bit_cast(unsigned short, h);
-        pl[e] = __builtin_bit_cast(unsigned short, l);
-    }
+    g->in_bytes = (size_t)g->hh * g->hw * g->psb;
+    g->smem = g->in_bytes + g->w_bytes + 16 + 128 * sizeof(float);
+    const int per = (int)((160 * 1024) / (g->smem + 1024));
+    const int pfc = g->pf <= 4 ? 4 : (g->pf <= 8 ? 8 : 13);
+    const int cap = (g->nb <= 1 && pfc <= 4) ? 4 : 2;           // VGPR budget of the kernel variant: 128 / 256 registers
+    g->wgs_per_cu = per > cap ? cap : per;
+    return g->wgs_per_cu >= 1;
 }
 
 // XCD-contiguous persistent schedule: block -> (first tile, stride, end) inside its XCD's chunk of the tile space
@@ -136,77 +95,201 @@ __device__ __forceinline__ void tile_walk(int ntiles, int& first, int& stride, i
     end = (xcd + 1) * chunk < ntiles ? (xcd + 1) * chunk : ntiles;
 }
 
-template <int TM>      // tile rows per wave (tile height = 4 * TM)
-__global__ __launch_bounds__(T_THREADS, (TM == 1 ? 4 : 2)) void tconv_kernel(GConvParams p, TileGeom g, const unsigned char* __restrict__ wprep) {
-    constexpr int TH = 4 * TM;
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter (its release fence waits for
+// every outstanding global store, and with them, in order, for the NEXT tile's prefetch loads), which serialises the phases of a tile.
+// The tile loop's barriers protect LDS reuse alone; global stores and the prefetch stay in flight across them.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// activation storage types (ss_dtype): fp32, fp16, bf16 -- four consecutive channels <-> f32x4
+// Four consecutive channels move as ONE global access at ELEMENT alignment (gfx950 global memory takes multi-dword accesses at any
+// dword -- for the 16-bit types any 2-byte -- address): channel slices of concatenated tensors (odd offsets, odd strides) stay on the
+// wide path instead of four scalar accesses.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_u __attribute__((ext_vector_type(4), aligned(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_u __attribute__((ext_vector_type(4), aligned(2)));
+__device__ __forceinline__ f32x4 ld4(const float* q) { return *(const f32x4_u*)q; }
+__device__ __forceinline__ f32x4 ld4(const _Float16* q) { return __builtin_convertvector((f16x4)(*(const f16x4_u*)q), f32x4); }
+__device__ __forceinline__ f32x4 ld4(const __bf16* q) { return __builtin_convertvector((bf16x4)(*(const bf16x4_u*)q), f32x4); }
+__device__ __forceinline__ void st4(float* q, f32x4 v) { *(f32x4_u*)q = v; }
+__device__ __forceinline__ void st4(_Float16* q, f32x4 v) { *(f16x4_u*)q = __builtin_convertvector(v, f16x4); }
+__device__ __forceinline__ void st4(__bf16* q, f32x4 v) { *(bf16x4_u*)q = __builtin_convertvector(v, bf16x4); }
+
+// NBT: output-channel blocks held in registers (>= g.nb); PF: staging slots per thread (>= g.pf); NP: piece products (3: x = h + l
+// times w = h + l without l*l, fp32 activations; 1: 16-bit activations times the leading weight piece, plain mixed precision)
+template <typename TI, typename TO, int NBT, int PF, int NP>
+__global__ __launch_bounds__(T_THREADS, ((NBT == 1 && PF <= 4) ? 4 : 2)) void tconv_kernel(GConvParams p, TileGeom g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sIn = smem;                               // [hh*hw pixels][psb]: per channel group 16 B of h then 16 B of l
     unsigned char* sW = smem + g.in_bytes;                   // [2 planes][nb*32][ksb]
-    float* red = (float*)(sW + g.w_bytes);
+    float* red = (float*)(sW + g.w_bytes);                  // [4] block-reduction slots, then [128] the bias vector (zeros without one):
+    float* sBias = red + 4;                                  // the epilogue must not issue global loads (they would drain the prefetch)
+    const TI* const gin = (const TI*)p.in;
+    TO* const gout = (TO*)p.out;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // ---- once per workgroup: weights -> LDS ----
-    const int ew = *(const int*)wprep;
+    // ---- once per workgroup: the weight tensor -> two fp16 planes in LDS under one power-of-two scale ----
+    int ew;
     {
-        const int rows = g.nb * 32, kb = g.nq * 16;          // bytes per row in the global planes
-        const unsigned char* src = wprep + 256;
-        const int per_row = kb / 16;
-        for (int r = wave; r < 2 * rows; r += 4)             // r over [plane][row]
-            for (int c16 = lane; c16 < per_row; c16 += 64)
-                *(u32x4*)(sW + (long)r * g.ksb + c16 * 16) = *(const u32x4*)(src + (long)r * kb + c16 * 16);
+        for (int i = tid; i < (int)(g.w_bytes / 16); i += T_THREADS) *(u32x4*)(sW + (long)i * 16) = u32x4{0u, 0u, 0u, 0u};
+        if (tid < 128) sBias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
+        // the (small) weight tensor is read twice (maximum, then split); loads are issued in independent batches of 8 per thread: a
+        // loop that consumes each load right away pays the full memory latency per element (it was 20 us per launch)
+        const int per_tap = p.Cin * p.Cout;
+        const int total = p.ntaps * per_tap;
+        const long wplane = (long)g.nb * 32 * g.ksb;
+        float m = 0.f;
+        for (int base = 0; base < total; base += 8 * T_THREADS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * T_THREADS + tid;
+                const int ee = e < total ? e : 0;
+                const int t = fdiv(ee, per_tap, g.m_pertap), r = ee - t * per_tap;
+                const int ci = fdiv(r, p.Cout, g.m_cout), co = r - ci * p.Cout;
+                v[u] = p.w[p.taps[t].woff + (long)ci * p.ldb + co];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, (base + u * T_THREADS + tid < total) ? fabsf(v[u]) : 0.f);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        ew = ss_amax_exp(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        const float sw = ldexpf(1.f, 14 - ew);
+        for (int base = 0; base < total; base += 8 * T_THREADS) {
+            float v[8];
+            int dsto[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * T_THREADS + tid;
+                const int ee = e < total ? e : 0;
+                const int t = fdiv(ee, per_tap, g.m_pertap), r = ee - t * per_tap;
+                const int ci = fdiv(r, p.Cout, g.m_cout), co = r - ci * p.Cout;
+                v[u] = p.w[p.taps[t].woff + (long)ci * p.ldb + co];
+                const int k = ((t * g.cgp + (ci >> 4)) * 2 + ((ci >> 3) & 1)) * 8 + (ci & 7);
+                dsto[u] = e < total ? co * g.ksb + k * 2 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (dsto[u] < 0) continue;
+                const float x = v[u] * sw;
+                const _Float16 h = (_Float16)x;
+                const _Float16 l = (_Float16)(x - (float)h);
+                *(_Float16*)(sW + dsto[u]) = h;
+                *(_Float16*)(sW + dsto[u] + wplane) = l;
+            }
+        }
+        __syncthreads();
     }
 
     const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
     const int ntiles = p.N * tiles_y * tiles_x;
     int first, stride, end;
     tile_walk(ntiles, first, stride, end);
-    const bool vec4 = (p.Cin % 4 == 0) && (p.in_cs % 4 == 0) && ((((uintptr_t)p.in) & 15) == 0);
+    // a 4-wide window that straddles the end of a pixel's channels reads the next pixel's (valid memory, masked below) -- except on
+    // the very last pixel of the tensor, where the elements are fetched one by one
+    const long in_last = ((long)p.N * p.IH * p.IW - 1) * p.in_cs;
     const int hp = g.hh * g.hw;                              // halo pixels
     const int c4n = g.cg * 2;                                // float4 slots per pixel (padded channels)
-    const int row_slots = g.hw * c4n;
+    const int nslots = hp * c4n;
 
-    for (int tile = first; tile < end; tile += stride) {
+    // tile-invariant decomposition of this thread's staging slots: slot i <-> (halo row, halo column, float4 index)
+    // packed: halo row | halo column << 8 | float4 index << 16 ; -1 = no slot (one register per slot)
+    int s_pk[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int e = tid + i * T_THREADS;
+        const int hpix = fdiv(e, c4n, g.m_c4n), c4 = e - hpix * c4n;
+        const int hy = fdiv(hpix, g.hw, g.m_hw);
+        s_pk[i] = e < nslots ? (hy | ((hpix - hy * g.hw) << 8) | (c4 << 16)) : -1;
+    }
+    // Prefetch registers.  issue_loads is BRANCH-FREE: every lane always loads four elements (from the tensor's first element when its
+    // slot is padding / outside the image), and nothing looks at the data until the tile is consumed one iteration later -- a load
+    // whose result is tested right away costs its full latency per slot (s_waitcnt vmcnt(0) after each one in the first version).
+    f32x4 pf[PF];
+    unsigned ok_mask = 0, edge_mask = 0;      // per tile: slot holds real data / slot is the tensor's last, partial 4-wide window
+    auto issue_loads = [&](int tile) {
         const int tx = tile % tiles_x, r1 = tile / tiles_x, ty = r1 % tiles_y, n = r1 / tiles_y;
         const int oy0 = ty * TH, ox0 = tx * TW;
-        // ---- stage the halo tile as fp32 (in its final 32-byte units), tracking max |x|: a wave per halo row ----
+        ok_mask = 0; edge_mask = 0;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int pk = s_pk[i] < 0 ? 0 : s_pk[i];
+            const int iy = ss_map_index(oy0 + g.hy0 + (pk & 255), p.IH, p.reflect);
+            const int ix = ss_map_index(ox0 + g.hx0 + ((pk >> 8) & 255), p.IW, p.reflect);
+            const int c = (pk >> 16) * 4;
+            // (iy / ix >= size: far overhang of an edge tile under reflection: feeds no stored output)
+            const bool ok = s_pk[i] >= 0 && iy >= 0 && ix >= 0 && iy < p.IH && ix < p.IW && c < p.Cin && !(g.dbg & 1);
+            const long off = ((long)(n * p.IH + iy) * p.IW + ix) * p.in_cs;
+            const bool edge = ok && !(c + 4 <= p.Cin || off < in_last);
+            ok_mask |= (ok && !edge) ? (1u << i) : 0u;
+            edge_mask |= edge ? (1u << i) : 0u;
+            pf[i] = ld4(gin + ((ok && !edge) ? off + c : 0L));
+        }
+    };
+    // slot i of the CURRENT tile (n0, y0, x0 = its image / origin): the four channels with padding, out-of-image and the partial
+    // last window resolved
+    auto slot_value = [&](int i, int n0, int y0, int x0) {
+        f32x4 v = pf[i];
+        const int c = (s_pk[i] >> 16) * 4;
+        if (!((ok_mask >> i) & 1)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c + 1 >= p.Cin) v[1] = 0.f;
+        if (c + 2 >= p.Cin) v[2] = 0.f;
+        if (c + 3 >= p.Cin) v[3] = 0.f;
+        if ((edge_mask >> i) & 1) {           // one pixel of the whole tensor: element-wise
+            const int iy = ss_map_index(y0 + g.hy0 + (s_pk[i] & 255), p.IH, p.reflect);
+            const int ix = ss_map_index(x0 + g.hx0 + ((s_pk[i] >> 8) & 255), p.IW, p.reflect);
+            const TI* src = gin + ((long)(n0 * p.IH + iy) * p.IW + ix) * p.in_cs + c;
+            v[0] = (float)src[0];
+            if (c + 1 < p.Cin) v[1] = (float)src[1];
+            if (c + 2 < p.Cin) v[2] = (float)src[2];
+        }
+        return v;
+    };
+
+    // The phases of a tile use different units (LDS, matrix pipe, memory) but are serial inside a workgroup; the co-resident
+    // workgroups of a CU start together and would stay in lockstep (measured: phase times ADD).  Workgroups 256 apart share a CU
+    // (round-robin dispatch): stagger their start by a fraction of a tile time.
+    if (!(g.dbg & 16)) {
+        const int slot = (blockIdx.x >> 8) & 3;
+        for (int i = 0; i < slot * g.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+    int tile = first;
+    if (tile < end) issue_loads(tile);
+    const unsigned char* abase = sW + (long)l31 * g.ksb + lh * 16;                       // weight fragment: row = output channel
+    const unsigned char* bbase = sIn + (long)(wave * g.hw + l31) * g.psb;               // input fragment: column = pixel of this wave's row
+    const long wplane = (long)g.nb * 32 * g.ksb;
+
+    for (; tile < end; tile += stride) {
+        const int tx = tile % tiles_x, r1 = tile / tiles_x, ty = r1 % tiles_y, n = r1 / tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        // ---- registers -> LDS as fp32 (in the final 32-byte units), max |x| of the tile ----
         float vmax = 0.f;
-        for (int hy = wave; hy < g.hh; hy += 4) {
-            int iy = ss_map_index(oy0 + g.hy0 + hy, p.IH, p.reflect);
-            if (iy >= p.IH) iy = -1;                         // far overhang of an edge tile under reflection: feeds no stored output
-            const float* rowp = p.in + (long)(n * p.IH + (iy < 0 ? 0 : iy)) * p.IW * p.in_cs;
-            unsigned char* drow = sIn + (long)hy * g.hw * g.psb;
-            for (int e = lane; e < row_slots; e += 64) {
-                const int hx = (int)__umulhi((unsigned)e, g.m_c4n), c4 = e - hx * c4n;
-                int ix = ss_map_index(ox0 + g.hx0 + hx, p.IW, p.reflect);
-                if (ix >= p.IW) ix = -1;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                const int c = c4 * 4;
-                if (iy >= 0 && ix >= 0 && c < p.Cin) {
-                    const float* src = rowp + (long)ix * p.in_cs + c;
-                    if (vec4) v = *(const f32x4*)src;
-                    else {
-                        v[0] = src[0];
-                        if (c + 1 < p.Cin) v[1] = src[1];
-                        if (c + 2 < p.Cin) v[2] = src[2];
-                        if (c + 3 < p.Cin) v[3] = src[3];
-                    }
-                }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            if (i < g.pf && s_pk[i] >= 0) {
+                const f32x4 v = slot_value(i, n, oy0, ox0);
                 vmax = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), vmax);
-                *(f32x4*)(drow + (long)hx * g.psb + c4 * 16) = v;
+                *(f32x4*)(sIn + ((s_pk[i] & 255) * g.hw + ((s_pk[i] >> 8) & 255)) * g.psb + (s_pk[i] >> 16) * 16) = v;
             }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
         if (lane == 0) red[wave] = vmax;
-        __syncthreads();
+        lds_barrier();
         vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         const int ex = ss_amax_exp(vmax);
         const float sx = ldexpf(1.f, 14 - ex);
         // ---- in place: every 32-byte unit (8 channels, fp32) -> 16 B of h + 16 B of l ----
-        for (int e = tid; e < hp * g.cg; e += T_THREADS) {
-            const int hpix = (int)__umulhi((unsigned)e, g.m_cg), c = e - hpix * g.cg;
+        for (int e = tid; e < hp * g.cg && !(g.dbg & 2); e += T_THREADS) {
+            const int hpix = fdiv(e, g.cg, g.m_cg), c = e - hpix * g.cg;
             unsigned char* u = sIn + (long)hpix * g.psb + c * 32;
             const f32x4 a = *(const f32x4*)u, b = *(const f32x4*)(u + 16);
             f16x8 h, l;
@@ -217,78 +300,91 @@ __global__ __launch_bounds__(T_THREADS, (TM == 1 ? 4 : 2)) void tconv_kernel(GCo
                 l[jj] = (_Float16)(x0 - (float)h[jj]); l[4 + jj] = (_Float16)(x1 - (float)h[4 + jj]);
             }
             *(f16x8*)u = h;
-            *(f16x8*)(u + 16) = l;
+            if (NP > 1) *(f16x8*)(u + 16) = l;
         }
-        __syncthreads();
+        lds_barrier();
+        // the next tile's global loads fly during the contraction and the stores of this one
+        if (tile + stride < end) issue_loads(tile + stride);
 
-        // ---- contraction: wave w owns tile rows w*TM .. w*TM+TM-1, all output-channel blocks ----
-        f32x16 acc[TM][4];
+        // ---- contraction: rows = output channels (weights), columns = the 32 pixels of this wave's tile row ----
+        f32x16 acc[NBT];
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+        for (int nb = 0; nb < NBT; ++nb)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
-        const unsigned char* abase = sIn + (long)((wave * TM) * g.hw + l31) * g.psb;
-        const unsigned char* bbase = sW + (long)l31 * g.ksb + lh * 16;
-        const long wplane = (long)g.nb * 32 * g.ksb;
-        const int rowb = g.hw * g.psb;
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
         // K steps = (tap, 16 channels): lanes 0..31 take the step's first channel group, lanes 32..63 its second (clamped to the
-        // last group when cg is odd: its weight rows are zero)
-        int step = 0;
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int tapoff = ((p.in_oy + p.taps[t].dy - g.hy0) * g.hw + (p.in_ox + p.taps[t].dx - g.hx0)) * g.psb;
-            for (int c2 = 0; c2 < g.cgp; ++c2, ++step) {
-                int cgi = 2 * c2 + lh;
-                cgi = cgi < g.cg ? cgi : g.cg - 1;
-                const unsigned char* ap = abase + tapoff + cgi * 32;
-                f16x8 ah[TM], al[TM];
+        // last group when cg is odd: its weight rows are zero).  Fragments of step s+1 are read before the MFMAs of step s issue.
+        const int nsteps = (g.dbg & 4) ? 0 : p.ntaps * g.cgp;
+        int t = 0, c2 = 0;
+        auto frag_addr = [&](int tt, int cc) {
+            const int tapoff = ((p.in_oy + p.taps[tt].dy - g.hy0) * g.hw + (p.in_ox + p.taps[tt].dx - g.hx0)) * g.psb;
+            int cgi = 2 * cc + lh;
+            cgi = cgi < g.cg ? cgi : g.cg - 1;
+            return bbase + tapoff + cgi * 32;
+        };
+        f16x8 xh, xl, wh[NBT], wl[NBT];
+        auto read_frags = [&](int step, int tt, int cc) {
+            const unsigned char* bp = frag_addr(tt, cc);
+            xh = *(const f16x8*)bp;
+            if (NP > 1) xl = *(const f16x8*)(bp + 16);
+            const unsigned char* ap = abase + step * 32;
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) {
-                    ah[mi] = *(const f16x8*)(ap + (long)mi * rowb);
-                    al[mi] = *(const f16x8*)(ap + (long)mi * rowb + 16);
+            for (int nb = 0; nb < NBT; ++nb)
+                if (nb < g.nb) {
+                    wh[nb] = *(const f16x8*)(ap + (long)nb * 32 * g.ksb);
+                    if (NP > 1) wl[nb] = *(const f16x8*)(ap + (long)nb * 32 * g.ksb + wplane);
                 }
-                const unsigned char* bp0 = bbase + step * 32;
+        };
+        if (nsteps > 0) read_frags(0, 0, 0);
+        for (int step = 0; step < nsteps; ++step) {
+            const f16x8 cxh = xh, cxl = xl;
+            f16x8 cwh[NBT], cwl[NBT];
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    if (nb < g.nb) {
-                        const unsigned char* bp = bp0 + (long)nb * 32 * g.ksb;
-                        const f16x8 bh = *(const f16x8*)bp, bl = *(const f16x8*)(bp + wplane);
+            for (int nb = 0; nb < NBT; ++nb) { cwh[nb] = wh[nb]; cwl[nb] = wl[nb]; }
+            if (++c2 == g.cgp) { c2 = 0; ++t; }
+            if (step + 1 < nsteps) read_frags(step + 1, t, c2);
 #pragma unroll
-                        for (int mi = 0; mi < TM; ++mi) {
-                            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh, acc[mi][nb], 0, 0, 0);
-                            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl, acc[mi][nb], 0, 0, 0);
-                            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh, acc[mi][nb], 0, 0, 0);
+            for (int nb = 0; nb < NBT; ++nb)
+                if (nb < g.nb) {
+                    if (NP > 1) {
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwl[nb], cxh, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh[nb], cxl, acc[nb], 0, 0, 0);
+                    }
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh[nb], cxh, acc[nb], 0, 0, 0);
+                }
+        }
+
+        // ---- epilogue: lane = pixel, registers = output channels in groups of 4 consecutive ones: 16-byte stores ----
+        const float oscale = ldexpf(1.f, (ex - 14) + (ew - 14));
+        const int oy = oy0 + wave, ox = ox0 + l31;
+        if (oy < p.OH && ox < p.OW && !(g.dbg & 8)) {
+            TO* opix = gout + ((long)(n * p.OH + oy) * p.OW + ox) * p.out_cs;
+#pragma unroll
+            for (int nb = 0; nb < NBT; ++nb) {
+                if (nb >= g.nb) continue;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int co = nb * 32 + 8 * q4 + 4 * lh;
+                    if (co >= p.Cout) continue;
+                    f32x4 v = {acc[nb][4 * q4] * oscale, acc[nb][4 * q4 + 1] * oscale, acc[nb][4 * q4 + 2] * oscale, acc[nb][4 * q4 + 3] * oscale};
+                    const int nv = p.Cout - co < 4 ? p.Cout - co : 4;
+                    const f32x4 b4 = *(const f32x4*)(sBias + co);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = ss_apply_act(v[k] + b4[k], p.act, p.alpha);
+                    if (nv == 4) {
+                        if (p.accumulate) v += ld4(opix + co);
+                        st4(opix + co, v);
+                    } else {
+                        for (int k = 0; k < nv; ++k) {
+                            float o = v[k];
+                            if (p.accumulate) o += (float)opix[co + k];
+                            opix[co + k] = (TO)o;
                         }
                     }
                 }
             }
         }
-
-        // ---- epilogue: undo the scales, bias, activation, store (lane = channel, 16 pixels of the row per lane) ----
-        const float oscale = ldexpf(1.f, (ex - 14) + (ew - 14));
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const int oy = oy0 + wave * TM + mi;
-            if (oy >= p.OH) continue;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const int co = nb * 32 + l31;
-                if (nb >= g.nb || co >= p.Cout) continue;
-                const float bv = p.bias ? p.bias[co] : 0.f;
-                float* orow = p.out + ((long)(n * p.OH + oy) * p.OW + ox0 + 4 * lh) * p.out_cs + co;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dx = (r & 3) + 8 * (r >> 2);
-                    if (ox0 + 4 * lh + dx >= p.OW) continue;
-                    float* o = orow + (long)dx * p.out_cs;
-                    float v = ss_apply_act(acc[mi][nb][r] * oscale + bv, p.act, p.alpha);
-                    if (p.accumulate) v += *o;
-                    *o = v;
-                }
-            }
-        }
-        __syncthreads();          // the next tile overwrites sIn
+        lds_barrier();          // the next tile overwrites sIn
     }
 }
 
@@ -392,7 +488,7 @@ __global__ __launch_bounds__(T_THREADS, 2) void twgrad_kernel(WGradParams p, WTi
             const float* rowp = p.a + (long)(n * p.AH + (iy < 0 ? 0 : iy)) * p.AW * p.a_cs;
             float* drow = sA + (long)hy * g.hw * g.psa;
             for (int e = lane; e < g.hw * a4; e += 64) {
-                const int hx = (int)__umulhi((unsigned)e, g.m_a4), c = (e - hx * a4) * 4;
+                const int hx = a4 == 1 ? e : (int)__umulhi((unsigned)e, g.m_a4), c = (e - hx * a4) * 4;
                 int ix = ss_map_index(gx0 + g.hx0 + hx, p.AW, p.reflect);
                 if (ix >= p.AW) ix = -1;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -414,7 +510,7 @@ __global__ __launch_bounds__(T_THREADS, 2) void twgrad_kernel(WGradParams p, WTi
             const float* rowp = p.b + (long)(n * p.GH + (gy < p.GH ? gy : 0)) * p.GW * p.b_cs;
             float* drow = sB + (long)py * TW * g.psb;
             for (int e = lane; e < TW * b4; e += 64) {
-                const int px = (int)__umulhi((unsigned)e, g.m_b4), c = (e - px * b4) * 4;
+                const int px = b4 == 1 ? e : (int)__umulhi((unsigned)e, g.m_b4), c = (e - px * b4) * 4;
                 const int gx = gx0 + px;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (gy < p.GH && gx < p.GW && c < p.Cb) {          // pixels outside the grid contribute zero (b = 0)
@@ -528,33 +624,42 @@ bool ss_tconv_ok(const GConvParams& p) {
     return p.Cin <= 64 && p.Cout <= 128 && (long)p.N * p.OH * p.OW >= 65536 && (long)p.N * p.IH * p.IW * p.in_cs < (1L << 31);
 }
 
-size_t ss_tconv_ws(const GConvParams& p) {
-    TileGeom g;
-    if (!tile_geom(p, &g)) return 0;
-    return 256 + (size_t)2 * g.nb * 32 * g.nq * 16;
-}
+size_t ss_tconv_ws(const GConvParams&) { return 0; }       // the weight planes are formed in LDS by every workgroup
 
-int ss_launch_tconv(const GConvParams& p, void* ws, size_t ws_bytes, hipStream_t s) {
-    TileGeom g;
-    if (!tile_geom(p, &g)) return SS_ERR_UNSUPPORTED;
-    if (!ws || ws_bytes < ss_tconv_ws(p)) return SS_ERR_WORKSPACE;
-    hipLaunchKernelGGL(tconv_wprep_kernel, dim3(1), dim3(256), 0, s, p, g.cg, g.cgp, g.nq, g.nb, (unsigned char*)ws);
-    SS_LAUNCH_CHECK();
-    const int tiles = p.N * ((p.OH + g.th - 1) / g.th) * ((p.OW + TW - 1) / TW);
-    const int nwg = tile_nwg(tiles, g.wgs_per_cu);
+namespace {
+template <typename TI, typename TO, int NBT, int PF, int NP>
+int launch_tconv(const GConvParams& p, const TileGeom& g, int nwg, hipStream_t s) {
     static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)tconv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tconv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tconv_kernel<TI, TO, NBT, PF, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
+    char name[64];
+    snprintf(name, sizeof(name), "tconv_kernel<%d,%d,%d> %s", NBT, PF, NP, NP == 3 ? "x3h" : "f16");
     const double pix = (double)p.N * p.OH * p.OW;
-    SsProfScope prof(g.th == 8 ? "tconv_kernel<2> x3h" : "tconv_kernel<1> x3h", 2.0 * pix * p.Cout * p.ntaps * p.Cin * 3,
-                     4.0 * pix * (p.Cin + p.Cout * (p.accumulate ? 2 : 1)), s);
-    if (g.th == 8) hipLaunchKernelGGL(tconv_kernel<2>, dim3(nwg), dim3(T_THREADS), g.smem, s, p, g, (const unsigned char*)ws);
-    else hipLaunchKernelGGL(tconv_kernel<1>, dim3(nwg), dim3(T_THREADS), g.smem, s, p, g, (const unsigned char*)ws);
+    SsProfScope prof(name, 2.0 * pix * p.Cout * p.ntaps * p.Cin * NP, (double)sizeof(TI) * pix * p.Cin + (double)sizeof(TO) * pix * p.Cout * (p.accumulate ? 2 : 1), s);
+    hipLaunchKernelGGL((tconv_kernel<TI, TO, NBT, PF, NP>), dim3(nwg), dim3(T_THREADS), g.smem, s, p, g);
     SS_LAUNCH_CHECK();
     return SS_OK;
+}
+template <typename TI, typename TO, int NP>
+int dispatch_tconv(const GConvParams& p, const TileGeom& g, int nwg, hipStream_t s) {
+    const int nbt = g.nb <= 1 ? 1 : (g.nb == 2 ? 2 : 4);
+    const int pfc = g.pf <= 4 ? 4 : (g.pf <= 8 ? 8 : 13);
+#define TC(NBT, PF) if (nbt == NBT && pfc == PF) return launch_tconv<TI, TO, NBT, PF, NP>(p, g, nwg, s);
+    TC(1, 4) TC(1, 8) TC(1, 13) TC(2, 4) TC(2, 8) TC(2, 13) TC(4, 4) TC(4, 8) TC(4, 13)
+#undef TC
+    return SS_ERR_UNSUPPORTED;
+}
+}  // namespace
+
+int ss_launch_tconv(const GConvParams& p, void* ws, size_t ws_bytes, hipStream_t s) {
+    (void)ws; (void)ws_bytes;
+    TileGeom g;
+    if (!tile_geom(p, &g)) return SS_ERR_UNSUPPORTED;
+    const int tiles = p.N * ((p.OH + TH - 1) / TH) * ((p.OW + TW - 1) / TW);
+    const int nwg = tile_nwg(tiles, g.wgs_per_cu);
+    return dispatch_tconv<float, float, 3>(p, g, nwg, s);
 }
 
 // ---- weight gradient --------------------------------------------------------------------------------------------------------------

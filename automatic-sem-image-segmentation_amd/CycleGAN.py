@@ -75,7 +75,7 @@ class ImagePool:
         out = torch.empty((len(picks),) + tuple(images.shape[1:]), dtype=images.dtype, device=images.device)
         per = out[0].numel()
         for i, src in enumerate(picks):
-            L.check(lib.ss_copy(src.data_ptr(), 1, out[i].data_ptr(), 1, per, 1, _stream()), "ss_copy")
+            L.check(lib.ss_copy_t(L.dtype_of(out), src.data_ptr(), 1, out[i].data_ptr(), 1, per, 1, _stream()), "ss_copy")
         return out
 
 
@@ -101,6 +101,10 @@ class CycleGanModel:
         self.image_pool_b = image_pool_b if image_pool_b is not None else ImagePool(1, 0)
         self.label_smoothing_factor = 0.0
         self.device = generator_a.device
+        # mixed precision: the networks' activation storage type (float32 by default) and a static loss scale for float16 storage
+        # (gradients below 6e-8 vanish in fp16): every loss gradient is multiplied by it, the optimizer steps divide it out
+        self.act_dtype = generator_a.act_dtype
+        self.loss_scale = 1024.0 if self.act_dtype == torch.float16 else 1.0
         # 14 running means (keras.metrics.Mean, CycleGAN.py:547-560): device sums, one host read per query
         self._scalars = torch.zeros(16, dtype=torch.float32, device=self.device)
         self._bce3 = torch.zeros(4, dtype=torch.float32, device=self.device)
@@ -133,7 +137,8 @@ class CycleGanModel:
     def train_step(self, batch_data):
         """One optimisation step of G_a, G_b, D_a, D_b (CycleGAN.py:615-710).  batch_data = (real_a, real_b):
         NHWC float32 arrays / tensors in [-1, 1].  Returns {metric: running mean}."""
-        real_a, real_b = (self._to_act(t) for t in batch_data)
+        from .engine import convert
+        real_a, real_b = (convert(self._to_act(t), self.act_dtype) for t in batch_data)
         ga, gb, da, db = self.gen_a, self.gen_b, self.disc_a, self.disc_b
         ls = self.label_smoothing_factor
         one = 1.0 - ls + ls / 2.0
@@ -167,24 +172,24 @@ class CycleGanModel:
         disc_fake_b = db(fake_b, True, tape)
         tape.param_grads = True
         # slots: 0 adv_a 1 adv_b 2 cyc_a 3 cyc_b 4 id_a 5 id_b | 6 d_real_a 7 d_fake_a 8 d_real_b 9 d_fake_b
-        losses.mse_const(disc_fake_b, one, 1.0, self._slot(0))
-        losses.mse_const(disc_fake_a, one, 1.0, self._slot(1))
+        losses.mse_const(disc_fake_b, one, 1.0 * self.loss_scale, self._slot(0))
+        losses.mse_const(disc_fake_a, one, 1.0 * self.loss_scale, self._slot(1))
         if self.use_binary_crossentropy_a:
-            losses.weighted_bce(real_b, cycled_b, 1.0, self.lambda_cycle_a, self._bce3)
+            losses.weighted_bce(real_b, cycled_b, 1.0, self.lambda_cycle_a * self.loss_scale, self._bce3)
             L.check(L.load().ss_copy(self._bce3.data_ptr(), 1, self._slot(2).data_ptr(), 1, 1, 1, _stream()), "ss_copy")
         else:
-            losses.mae(real_b, cycled_b, self.lambda_cycle_a, self._slot(2))
-        losses.mae(real_a, cycled_a, self.lambda_cycle_b, self._slot(3))
+            losses.mae(real_b, cycled_b, (self.lambda_cycle_a) * self.loss_scale, self._slot(2))
+        losses.mae(real_a, cycled_a, (self.lambda_cycle_b) * self.loss_scale, self._slot(3))
         if self.use_identity_loss:
-            losses.mae(real_b, same_b, self.lambda_cycle_a * self.lambda_identity_a, self._slot(4))
-            losses.mae(real_a, same_a, self.lambda_cycle_b * self.lambda_identity_b, self._slot(5))
+            losses.mae(real_b, same_b, (self.lambda_cycle_a * self.lambda_identity_a) * self.loss_scale, self._slot(4))
+            losses.mae(real_a, same_a, (self.lambda_cycle_b * self.lambda_identity_b) * self.loss_scale, self._slot(5))
         ga.zero_grad()
         gb.zero_grad()
         D.begin_backward([ga, gb, da, db])
         tape.backward()                      # d(L_a + L_b)/d theta for both generators in one traversal
         D.all_reduce_grads([ga, gb])
-        self.gen_a_optimizer.apply(ga, 1.0 / world)
-        self.gen_b_optimizer.apply(gb, 1.0 / world)
+        self.gen_a_optimizer.apply(ga, 1.0 / (world * self.loss_scale))
+        self.gen_b_optimizer.apply(gb, 1.0 / (world * self.loss_scale))
 
         # ---- discriminators ---------------------------------------------------------------------------
         tape = Tape()
@@ -200,17 +205,17 @@ class CycleGanModel:
             disc_fake_a2 = da(Act(pooled_a, requires_grad=False), True, tape)
             disc_real_b = db(real_b, True, tape)
             disc_fake_b2 = db(Act(pooled_b, requires_grad=False), True, tape)
-        losses.mse_const(disc_real_a, one, 0.5, self._slot(6))
-        losses.mse_const(disc_fake_a2, zero, 0.5, self._slot(7))
-        losses.mse_const(disc_real_b, one, 0.5, self._slot(8))
-        losses.mse_const(disc_fake_b2, zero, 0.5, self._slot(9))
+        losses.mse_const(disc_real_a, one, 0.5 * self.loss_scale, self._slot(6))
+        losses.mse_const(disc_fake_a2, zero, 0.5 * self.loss_scale, self._slot(7))
+        losses.mse_const(disc_real_b, one, 0.5 * self.loss_scale, self._slot(8))
+        losses.mse_const(disc_fake_b2, zero, 0.5 * self.loss_scale, self._slot(9))
         da.zero_grad()
         db.zero_grad()
         D.begin_backward([ga, gb, da, db])
         tape.backward()
         D.all_reduce_grads([da, db])
-        self.disc_a_optimizer.apply(da, 1.0 / world)
-        self.disc_b_optimizer.apply(db, 1.0 / world)
+        self.disc_a_optimizer.apply(da, 1.0 / (world * self.loss_scale))
+        self.disc_b_optimizer.apply(db, 1.0 / (world * self.loss_scale))
 
         return self._update_metrics()
 
@@ -258,9 +263,9 @@ class CycleGanModel:
             tape_a.param_grads = False
             disc_fake_b = db(fake_b, True, tape_a)
             tape_a.param_grads = True
-            losses.mse_const(disc_fake_b, one, 1.0, self._slot(0))
-            losses.mae(real_a, cycled_a, self.lambda_cycle_b, self._slot(3))
-            losses.mae(real_b, same_b, self.lambda_cycle_a * self.lambda_identity_a, self._slot(4))
+            losses.mse_const(disc_fake_b, one, 1.0 * self.loss_scale, self._slot(0))
+            losses.mae(real_a, cycled_a, (self.lambda_cycle_b) * self.loss_scale, self._slot(3))
+            losses.mae(real_b, same_b, (self.lambda_cycle_a * self.lambda_identity_a) * self.loss_scale, self._slot(4))
             fwd_a_done = s1.record_event()
         with torch.cuda.stream(s2):
             fake_a, same_a = LY.batch_split(tape_b, gb(Act(torch.cat([real_b.t, real_a.t], 0), requires_grad=False), True, tape_b), [n_b, n_a])
@@ -268,9 +273,9 @@ class CycleGanModel:
             tape_b.param_grads = False
             disc_fake_a = da(fake_a, True, tape_b)
             tape_b.param_grads = True
-            losses.mse_const(disc_fake_a, one, 1.0, self._slot(1))
-            losses.mae(real_b, cycled_b, self.lambda_cycle_a, self._slot(2))
-            losses.mae(real_a, same_a, self.lambda_cycle_b * self.lambda_identity_b, self._slot(5))
+            losses.mse_const(disc_fake_a, one, 1.0 * self.loss_scale, self._slot(1))
+            losses.mae(real_b, cycled_b, (self.lambda_cycle_a) * self.loss_scale, self._slot(2))
+            losses.mae(real_a, same_a, (self.lambda_cycle_b * self.lambda_identity_b) * self.loss_scale, self._slot(5))
             fwd_b_done = s2.record_event()
 
         def generator_backward():
@@ -295,13 +300,13 @@ class CycleGanModel:
             with torch.cuda.stream(s3):
                 disc_real_a, disc_fake_a2 = LY.batch_split(
                     tape_da, da(Act(torch.cat([real_a.t, pooled_a], 0), requires_grad=False), True, tape_da), [n_a, pooled_a.shape[0]])
-                losses.mse_const(disc_real_a, one, 0.5, self._slot(6))
-                losses.mse_const(disc_fake_a2, zero, 0.5, self._slot(7))
+                losses.mse_const(disc_real_a, one, 0.5 * self.loss_scale, self._slot(6))
+                losses.mse_const(disc_fake_a2, zero, 0.5 * self.loss_scale, self._slot(7))
             with torch.cuda.stream(s4):
                 disc_real_b, disc_fake_b2 = LY.batch_split(
                     tape_db, db(Act(torch.cat([real_b.t, pooled_b], 0), requires_grad=False), True, tape_db), [n_b, pooled_b.shape[0]])
-                losses.mse_const(disc_real_b, one, 0.5, self._slot(8))
-                losses.mse_const(disc_fake_b2, zero, 0.5, self._slot(9))
+                losses.mse_const(disc_real_b, one, 0.5 * self.loss_scale, self._slot(8))
+                losses.mse_const(disc_fake_b2, zero, 0.5 * self.loss_scale, self._slot(9))
             D.begin_backward([da, db])
             with torch.cuda.stream(s3):
                 tape_da.backward()
@@ -333,11 +338,11 @@ class CycleGanModel:
         cur.wait_stream(s3)
         cur.wait_stream(s4)
         D.all_reduce_grads([da, db])
-        self.disc_a_optimizer.apply(da, 1.0 / world)
-        self.disc_b_optimizer.apply(db, 1.0 / world)
+        self.disc_a_optimizer.apply(da, 1.0 / (world * self.loss_scale))
+        self.disc_b_optimizer.apply(db, 1.0 / (world * self.loss_scale))
         D.finish_all_reduce_grads(gen_works)
-        self.gen_a_optimizer.apply(ga, 1.0 / world)
-        self.gen_b_optimizer.apply(gb, 1.0 / world)
+        self.gen_a_optimizer.apply(ga, 1.0 / (world * self.loss_scale))
+        self.gen_b_optimizer.apply(gb, 1.0 / (world * self.loss_scale))
         del keep
         del tape_a, tape_b
         return self._update_metrics()
@@ -348,7 +353,8 @@ class CycleGanModel:
             return t
         if isinstance(t, np.ndarray):
             t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
-        return Act(t.to(self.device, dtype=torch.float32).contiguous(), requires_grad=False)
+        from .engine import convert
+        return convert(Act(t.to(self.device, dtype=torch.float32).contiguous(), requires_grad=False), self.act_dtype)
 
     def _update_metrics(self):
         if not self.sync_metrics:

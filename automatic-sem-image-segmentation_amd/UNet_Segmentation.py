@@ -129,11 +129,14 @@ class UNetModel:
         self.net, self.weighting, self.optimizer = net, float(weighting), optimizer
         self.device = net.device
         self._out3 = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.act_dtype = net.act_dtype           # float32, or bfloat16 / float16 mixed-precision activation storage
+        self.loss_scale = 1024.0 if self.act_dtype == torch.float16 else 1.0
 
     def _to_act(self, t):
         if isinstance(t, np.ndarray):
             t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
-        return Act(t.to(self.device, dtype=torch.float32).contiguous(), requires_grad=False)
+        from .engine import convert
+        return convert(Act(t.to(self.device, dtype=torch.float32).contiguous(), requires_grad=False), self.act_dtype)
 
     def train_step(self, batch):
         """fwd(training=True) -> class-weighted BCE -> backward -> Adam.  Returns {'loss','mae','acc'} of this batch."""
@@ -141,12 +144,12 @@ class UNetModel:
         world = D.world_size()
         tape = Tape()
         p = self.net(x, True, tape)
-        losses.weighted_bce(y, p, self.weighting, 1.0, self._out3)
+        losses.weighted_bce(y, p, self.weighting, self.loss_scale, self._out3)
         self.net.zero_grad()
         D.begin_backward([self.net])
         tape.backward()
         D.all_reduce_grads([self.net])
-        self.optimizer.apply(self.net, 1.0 / world)
+        self.optimizer.apply(self.net, 1.0 / (world * self.loss_scale))
         s = D.mean_scalars(self._out3.cpu().numpy().astype(np.float64))
         return {"loss": float(s[0]), "mae": float(s[1]), "acc": float(s[2])}
 

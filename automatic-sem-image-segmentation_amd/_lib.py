@@ -37,6 +37,27 @@ class ProfEntry(ctypes.Structure):
 
 
 PAD_ZERO, PAD_REFLECT = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2      # ss_dtype: storage type of activation tensors
+
+
+def dtype_of(t):
+    """ss_dtype of a torch tensor / torch dtype (activations: float32, bfloat16 or float16)."""
+    import torch
+    dt = t if isinstance(t, torch.dtype) else t.dtype
+    try:
+        return {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16, torch.float16: DTYPE_F16}[dt]
+    except KeyError:
+        raise SemsegHipError(f"activation dtype {dt} is not one of float32 / bfloat16 / float16") from None
+
+
+def torch_dtype(name):
+    """'f32' | 'bf16' | 'f16' (or a torch dtype) -> torch dtype."""
+    import torch
+    if isinstance(name, torch.dtype):
+        return name
+    return {"f32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+            "f16": torch.float16, "fp16": torch.float16, "float16": torch.float16}[str(name).lower()]
+
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PASS_FWD, PASS_BWD_DATA, PASS_BWD_WEIGHT = 0, 1, 2
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_BF16X3, ALGO_X6 = 0, 1, 2, 3, 4
@@ -83,6 +104,21 @@ SIGNATURES = {
     "ss_upsample2x_fwd": (c_i32, [c_vp, c_i32, c_vp, c_i32] + [c_i32] * 4 + [c_vp]),
     "ss_upsample2x_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32] + [c_i32] * 4 + [c_vp]),
     "ss_copy": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ss_act_bwd_t": (c_i32, [c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ss_axpby_t": (c_i32, [c_i32, c_f32, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ss_copy_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ss_maxpool2x2_fwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "ss_maxpool2x2_bwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "ss_reflect_pad2d_fwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32] + [c_i32] * 8 + [c_vp]),
+    "ss_reflect_pad2d_bwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32] + [c_i32] * 8 + [c_vp]),
+    "ss_crop2d_fwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32] + [c_i32] * 8 + [c_vp]),
+    "ss_crop2d_bwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32] + [c_i32] * 8 + [c_vp]),
+    "ss_upsample2x_fwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32] + [c_i32] * 4 + [c_vp]),
+    "ss_upsample2x_bwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32] + [c_i32] * 4 + [c_vp]),
+    "ss_convert": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp]),
+    "ss_loss_mse_const_t": (c_i32, [c_i32, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ss_loss_mae_t": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ss_loss_weighted_bce_t": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_fill": (c_i32, [c_vp, c_f32, c_i64, c_vp]),
     "ss_loss_workspace_bytes": (c_sz, [c_i64]),
     "ss_loss_mse_const": (c_i32, [c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),

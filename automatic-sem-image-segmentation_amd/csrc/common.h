@@ -177,6 +177,8 @@ int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accu
 int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split, int nbatch = 1);
 int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s);   // partials only: part[batch][split][M][Cb]
 
+// dst (dst_dtype view) = src (src_dtype view) (elementwise.hip)
+int ss_convert_launch(const void* src, int src_dtype, int src_cs, void* dst, int dst_dtype, int dst_cs, long rows, int c, hipStream_t s);
 int ss_launch_wgrad_reduce(const WGradParams& p, float* dw, int ldw, int accumulate, int rows, hipStream_t s);
 
 // LDS-staged tile kernels for small-channel stride-1 convs on large maps (conv_tile.hip): forward / data gradient (x3h arithmetic

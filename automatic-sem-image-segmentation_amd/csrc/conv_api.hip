@@ -754,7 +754,11 @@ const char* ss_status_string(int status) {
     }
 }
 
-size_t ss_conv2d_workspace_bytes(const ss_conv_desc* d, int pass) {
+}  // extern "C"
+
+namespace {
+
+size_t conv2d_workspace_bytes32(const ss_conv_desc* d, int pass) {
     if (!valid_desc(d)) return 0;
     const size_t colsum_b = ss_align_up((size_t)COLSUM_CHUNKS * (d->cout > d->cin ? d->cout : d->cin) * sizeof(float), 256);
     if (!d->transposed) {
@@ -769,7 +773,7 @@ size_t ss_conv2d_workspace_bytes(const ss_conv_desc* d, int pass) {
 
 // which tensor maxima a pass reads (bit 0: of x, bit 1: of dy, in the caller's naming) -- mirrors the dispatch of conv_fwd /
 // conv_bwd_data / conv_bwd_weight: only the direct x3h kernels use per-tensor scales (the Winograd passes scale per tile)
-int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass) {
+int conv2d_uses_amax32(const ss_conv_desc* d, int pass) {
     if (!valid_desc(d)) return 0;
     const ConvProb c = d->transposed ? adjoint(d) : plain(d);
     // pass and roles inside the (adjoint) problem: bit 0 = its x, bit 1 = its dy
@@ -782,7 +786,7 @@ int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass) {
     return ((roles & 1) ? 2 : 0) | ((roles & 2) ? 1 : 0);
 }
 
-int ss_conv2d_fwd(const ss_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+int conv2d_fwd32(const ss_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                   void* ws, size_t ws_bytes, void* stream) {
     if (!valid_desc(d) || !x || !w || !y) return SS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -790,7 +794,7 @@ int ss_conv2d_fwd(const ss_conv_desc* d, const float* x, const float* w, const f
     return conv_bwd_data(adjoint(d), x, w, y, bias, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
 }
 
-int ss_conv2d_bwd_data(const ss_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
+int conv2d_bwd_data32(const ss_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
                        void* ws, size_t ws_bytes, void* stream) {
     if (!valid_desc(d) || !dy || !w || !dx) return SS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -799,11 +803,11 @@ int ss_conv2d_bwd_data(const ss_conv_desc* d, const float* dy, const float* w, f
     return conv_fwd(adjoint(d), dy, w, nullptr, dx, SS_ACT_NONE, 0.f, accumulate, d->algo, ws, ws_bytes, s);
 }
 
-int ss_conv2d_bwd_weight(const ss_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+int conv2d_bwd_weight32(const ss_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                          int accumulate, void* ws, size_t ws_bytes, void* stream) {
     if (!valid_desc(d) || !x || !dy || !dw) return SS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (ws_bytes < ss_conv2d_workspace_bytes(d, SS_PASS_BWD_WEIGHT) || !ws) return SS_ERR_WORKSPACE;
+    if (ws_bytes < conv2d_workspace_bytes32(d, SS_PASS_BWD_WEIGHT) || !ws) return SS_ERR_WORKSPACE;
     int rc;
     const ConvProb c = d->transposed ? adjoint(d) : plain(d);
     const size_t main_b = bwd_weight_ws(c);
@@ -815,6 +819,110 @@ int ss_conv2d_bwd_weight(const ss_conv_desc* d, const float* x, const float* dy,
         rc = colsum(dy, (long)d->n * d->oh * d->ow, d->cout, d->out_cstride, dbias, accumulate, part, s);
     }
     return rc;
+}
+
+
+// ---- 16-bit activation storage (ss_conv_desc::dtype = SS_DTYPE_BF16 / SS_DTYPE_F16) ------------------------------------------------
+// Every convolution path computes on fp32-grade operands; a path without a native 16-bit loader (all but the tile kernels, for now)
+// runs on dense fp32 staging copies of its activation arguments taken from the caller's workspace: convert in, run the fp32 path,
+// convert out.  Weights, weight gradients and bias gradients are fp32 throughout.
+struct ConvShim {
+    ss_conv_desc d32;
+    float* a;          // [n*ih*iw*cin]   x / dx
+    float* b;          // [n*oh*ow*cout]  y / dy
+    void* ws;
+    size_t ws_bytes, a_bytes, b_bytes;
+};
+ConvShim make_shim(const ss_conv_desc* d, void* ws, size_t ws_bytes) {
+    ConvShim sh;
+    sh.d32 = *d;
+    sh.d32.dtype = SS_DTYPE_F32;
+    sh.d32.in_cstride = d->cin;
+    sh.d32.out_cstride = d->cout;
+    sh.d32.x_amax = sh.d32.dy_amax = nullptr;
+    sh.d32.x_amax_valid = sh.d32.dy_amax_valid = 0;
+    sh.a_bytes = ss_align_up((size_t)d->n * d->ih * d->iw * d->cin * sizeof(float), 256);
+    sh.b_bytes = ss_align_up((size_t)d->n * d->oh * d->ow * d->cout * sizeof(float), 256);
+    sh.a = (float*)ws;
+    sh.b = (float*)((char*)ws + sh.a_bytes);
+    sh.ws = (char*)ws + sh.a_bytes + sh.b_bytes;
+    sh.ws_bytes = ws_bytes > sh.a_bytes + sh.b_bytes ? ws_bytes - sh.a_bytes - sh.b_bytes : 0;
+    return sh;
+}
+bool valid_desc_any(const ss_conv_desc* d) {
+    if (!d) { ss_set_error("ss_conv_desc is NULL"); return false; }
+    if (d->struct_size != sizeof(ss_conv_desc)) return valid_desc(d);          // sets the message
+    if (d->dtype == SS_DTYPE_F32) return valid_desc(d);
+    if (d->dtype != SS_DTYPE_BF16 && d->dtype != SS_DTYPE_F16) { ss_set_error("ss_conv_desc.dtype = %d unknown", d->dtype); return false; }
+    ss_conv_desc t = *d;
+    t.dtype = SS_DTYPE_F32;
+    return valid_desc(&t);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ss_conv2d_workspace_bytes(const ss_conv_desc* d, int pass) {
+    if (!valid_desc_any(d)) return 0;
+    if (d->dtype == SS_DTYPE_F32) return conv2d_workspace_bytes32(d, pass);
+    const ConvShim sh = make_shim(d, nullptr, 0);
+    return sh.a_bytes + sh.b_bytes + conv2d_workspace_bytes32(&sh.d32, pass);
+}
+
+int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass) {
+    if (!valid_desc_any(d) || d->dtype != SS_DTYPE_F32) return 0;
+    return conv2d_uses_amax32(d, pass);
+}
+
+int ss_conv2d_fwd(const ss_conv_desc* d, const void* x, const float* w, const float* bias, void* y,
+                  void* ws, size_t ws_bytes, void* stream) {
+    if (!valid_desc_any(d)) return SS_ERR_INVALID;
+    if (d->dtype == SS_DTYPE_F32) return conv2d_fwd32(d, (const float*)x, w, bias, (float*)y, ws, ws_bytes, stream);
+    if (!x || !w || !y) return SS_ERR_INVALID;
+    if (!ws || ws_bytes < ss_conv2d_workspace_bytes(d, SS_PASS_FWD)) return SS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const ConvShim sh = make_shim(d, ws, ws_bytes);
+    int rc = ss_convert_launch(x, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, d->cin, (long)d->n * d->ih * d->iw, d->cin, s);
+    if (rc != SS_OK) return rc;
+    rc = conv2d_fwd32(&sh.d32, sh.a, w, bias, sh.b, sh.ws, sh.ws_bytes, stream);
+    if (rc != SS_OK) return rc;
+    return ss_convert_launch(sh.b, SS_DTYPE_F32, d->cout, y, d->dtype, d->out_cstride, (long)d->n * d->oh * d->ow, d->cout, s);
+}
+
+int ss_conv2d_bwd_data(const ss_conv_desc* d, const void* dy, const float* w, void* dx, int accumulate,
+                       void* ws, size_t ws_bytes, void* stream) {
+    if (!valid_desc_any(d)) return SS_ERR_INVALID;
+    if (d->dtype == SS_DTYPE_F32) return conv2d_bwd_data32(d, (const float*)dy, w, (float*)dx, accumulate, ws, ws_bytes, stream);
+    if (!dy || !w || !dx) return SS_ERR_INVALID;
+    if (!ws || ws_bytes < ss_conv2d_workspace_bytes(d, SS_PASS_BWD_DATA)) return SS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const ConvShim sh = make_shim(d, ws, ws_bytes);
+    const long xr = (long)d->n * d->ih * d->iw, yr = (long)d->n * d->oh * d->ow;
+    int rc = ss_convert_launch(dy, d->dtype, d->out_cstride, sh.b, SS_DTYPE_F32, d->cout, yr, d->cout, s);
+    if (rc != SS_OK) return rc;
+    if (accumulate) {
+        rc = ss_convert_launch(dx, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, d->cin, xr, d->cin, s);
+        if (rc != SS_OK) return rc;
+    }
+    rc = conv2d_bwd_data32(&sh.d32, sh.b, w, sh.a, accumulate, sh.ws, sh.ws_bytes, stream);
+    if (rc != SS_OK) return rc;
+    return ss_convert_launch(sh.a, SS_DTYPE_F32, d->cin, dx, d->dtype, d->in_cstride, xr, d->cin, s);
+}
+
+int ss_conv2d_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                         int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    if (!valid_desc_any(d)) return SS_ERR_INVALID;
+    if (d->dtype == SS_DTYPE_F32) return conv2d_bwd_weight32(d, (const float*)x, (const float*)dy, dw, dbias, accumulate, ws, ws_bytes, stream);
+    if (!x || !dy || !dw) return SS_ERR_INVALID;
+    if (!ws || ws_bytes < ss_conv2d_workspace_bytes(d, SS_PASS_BWD_WEIGHT)) return SS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const ConvShim sh = make_shim(d, ws, ws_bytes);
+    int rc = ss_convert_launch(x, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, d->cin, (long)d->n * d->ih * d->iw, d->cin, s);
+    if (rc != SS_OK) return rc;
+    rc = ss_convert_launch(dy, d->dtype, d->out_cstride, sh.b, SS_DTYPE_F32, d->cout, (long)d->n * d->oh * d->ow, d->cout, s);
+    if (rc != SS_OK) return rc;
+    return conv2d_bwd_weight32(&sh.d32, sh.a, sh.b, dw, dbias, accumulate, sh.ws, sh.ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -10,27 +10,40 @@ inline unsigned ew_grid(long total) {
     return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void act_bwd_kernel(int act, float alpha, const float* __restrict__ dy, int dy_cs,
-                                                           const float* __restrict__ y, int y_cs, float* __restrict__ dx, int dx_cs,
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void act_bwd_kernel(int act, float alpha, const T* __restrict__ dy, int dy_cs,
+                                                           const T* __restrict__ y, int y_cs, T* __restrict__ dx, int dx_cs,
                                                            long rows, int C) {
     const long total = rows * C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long r = e / C;
         const int c = (int)(e - r * C);
-        dx[r * dx_cs + c] = dy[r * dy_cs + c] * ss_act_grad_from_out(y[r * y_cs + c], act, alpha);
+        dx[r * dx_cs + c] = (T)((float)dy[r * dy_cs + c] * ss_act_grad_from_out((float)y[r * y_cs + c], act, alpha));
     }
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void axpby_kernel(float alpha, const float* __restrict__ a, int a_cs, float beta,
-                                                         const float* __restrict__ b, int b_cs, float* __restrict__ out, int out_cs,
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void axpby_kernel(float alpha, const T* __restrict__ a, int a_cs, float beta,
+                                                         const T* __restrict__ b, int b_cs, T* __restrict__ out, int out_cs,
                                                          long rows, int C) {
     const long total = rows * C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long r = e / C;
         const int c = (int)(e - r * C);
-        float v = alpha * a[r * a_cs + c];
-        if (b) v = fmaf(beta, b[r * b_cs + c], v);
-        out[r * out_cs + c] = v;
+        float v = alpha * (float)a[r * a_cs + c];
+        if (b) v = fmaf(beta, (float)b[r * b_cs + c], v);
+        out[r * out_cs + c] = (T)v;
+    }
+}
+
+// dst (type TD, view) = src (type TS, view): the storage-type boundary (fp32 <-> bf16 / fp16 activations)
+template <typename TS, typename TD>
+__global__ __launch_bounds__(EW_BLOCK) void convert_kernel(const TS* __restrict__ src, int src_cs, TD* __restrict__ dst, int dst_cs, long rows, int C) {
+    const long total = rows * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / C;
+        const int c = (int)(e - r * C);
+        dst[r * dst_cs + c] = (TD)(float)src[r * src_cs + c];
     }
 }
 
@@ -38,7 +51,8 @@ __global__ __launch_bounds__(EW_BLOCK) void fill_kernel(float* __restrict__ dst,
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) dst[e] = v;
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void maxpool_fwd_kernel(const float* __restrict__ x, int x_cs, float* __restrict__ y, int y_cs,
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void maxpool_fwd_kernel(const T* __restrict__ x, int x_cs, T* __restrict__ y, int y_cs,
                                                                int N, int H, int W, int C) {
     const int OH = H / 2, OW = W / 2;
     const long total = (long)N * OH * OW * C;
@@ -48,15 +62,16 @@ __global__ __launch_bounds__(EW_BLOCK) void maxpool_fwd_kernel(const float* __re
         const int ox = (int)(r % OW); r /= OW;
         const int oy = (int)(r % OH);
         const int n = (int)(r / OH);
-        const float* ip = x + ((long)(n * H + 2 * oy) * W + 2 * ox) * x_cs + c;
-        const float v00 = ip[0], v01 = ip[x_cs], v10 = ip[(long)W * x_cs], v11 = ip[(long)(W + 1) * x_cs];
-        y[((long)(n * OH + oy) * OW + ox) * y_cs + c] = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+        const T* ip = x + ((long)(n * H + 2 * oy) * W + 2 * ox) * x_cs + c;
+        const float v00 = (float)ip[0], v01 = (float)ip[x_cs], v10 = (float)ip[(long)W * x_cs], v11 = (float)ip[(long)(W + 1) * x_cs];
+        y[((long)(n * OH + oy) * OW + ox) * y_cs + c] = (T)fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
     }
 }
 
 // one thread per INPUT element: gets dy of its window iff it is the first maximum in row-major order
-__global__ __launch_bounds__(EW_BLOCK) void maxpool_bwd_kernel(const float* __restrict__ dy, int dy_cs, const float* __restrict__ x, int x_cs,
-                                                               float* __restrict__ dx, int dx_cs, int accumulate,
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void maxpool_bwd_kernel(const T* __restrict__ dy, int dy_cs, const T* __restrict__ x, int x_cs,
+                                                               T* __restrict__ dx, int dx_cs, int accumulate,
                                                                int N, int H, int W, int C) {
     const int OH = H / 2, OW = W / 2;
     const long total = (long)N * H * W * C;
@@ -69,23 +84,24 @@ __global__ __launch_bounds__(EW_BLOCK) void maxpool_bwd_kernel(const float* __re
         float g = 0.f;
         const int oy = iy >> 1, ox = ix >> 1;
         if (oy < OH && ox < OW) {
-            const float* ip = x + ((long)(n * H + 2 * oy) * W + 2 * ox) * x_cs + c;
-            const float v[4] = {ip[0], ip[x_cs], ip[(long)W * x_cs], ip[(long)(W + 1) * x_cs]};
+            const T* ip = x + ((long)(n * H + 2 * oy) * W + 2 * ox) * x_cs + c;
+            const float v[4] = {(float)ip[0], (float)ip[x_cs], (float)ip[(long)W * x_cs], (float)ip[(long)(W + 1) * x_cs]};
             int arg = 0;
             float m = v[0];
 #pragma unroll
             for (int k = 1; k < 4; ++k)
                 if (v[k] > m) { m = v[k]; arg = k; }
-            if (arg == ((iy & 1) * 2 + (ix & 1))) g = dy[((long)(n * OH + oy) * OW + ox) * dy_cs + c];
+            if (arg == ((iy & 1) * 2 + (ix & 1))) g = (float)dy[((long)(n * OH + oy) * OW + ox) * dy_cs + c];
         }
-        float* o = dx + ((long)(n * H + iy) * W + ix) * dx_cs + c;
-        *o = accumulate ? (*o + g) : g;
+        T* o = dx + ((long)(n * H + iy) * W + ix) * dx_cs + c;
+        *o = (T)(accumulate ? ((float)*o + g) : g);
     }
 }
 
 
 // y[n,py,px,c] = x[n, reflect(py-pt), reflect(px-pl), c]   (keras.ops.pad(mode="reflect"), CycleGAN.py:495-506)
-__global__ __launch_bounds__(EW_BLOCK) void reflect_pad_fwd_kernel(const float* __restrict__ x, int x_cs, float* __restrict__ y, int y_cs,
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void reflect_pad_fwd_kernel(const T* __restrict__ x, int x_cs, T* __restrict__ y, int y_cs,
                                                                    int N, int H, int W, int C, int pt, int pl, int PH, int PW) {
     const long total = (long)N * PH * PW * C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -100,7 +116,8 @@ __global__ __launch_bounds__(EW_BLOCK) void reflect_pad_fwd_kernel(const float* 
 }
 
 // dx[n,iy,ix,c] (+)= sum of dy over the padded positions that reflect onto (iy,ix)
-__global__ __launch_bounds__(EW_BLOCK) void reflect_pad_bwd_kernel(const float* __restrict__ dy, int dy_cs, float* __restrict__ dx, int dx_cs,
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void reflect_pad_bwd_kernel(const T* __restrict__ dy, int dy_cs, T* __restrict__ dx, int dx_cs,
                                                                    int accumulate, int N, int H, int W, int C, int pt, int pl, int PH, int PW) {
     const long total = (long)N * H * W * C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -118,15 +135,15 @@ __global__ __launch_bounds__(EW_BLOCK) void reflect_pad_bwd_kernel(const float* 
         { const int px = pl + 2 * (W - 1) - ix; if (ix <= W - 2 && px < PW) xs[nx++] = px; }
         float acc = 0.f;
         for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) acc += dy[((long)(n * PH + ys[a]) * PW + xs[b]) * dy_cs + c];
-        float* o = dx + ((long)(n * H + iy) * W + ix) * dx_cs + c;
-        *o = accumulate ? (*o + acc) : acc;
+            for (int b = 0; b < nx; ++b) acc += (float)dy[((long)(n * PH + ys[a]) * PW + xs[b]) * dy_cs + c];
+        T* o = dx + ((long)(n * H + iy) * W + ix) * dx_cs + c;
+        *o = (T)(accumulate ? ((float)*o + acc) : acc);
     }
 }
 
 // MODE 0: y = x[:, top:top+OH, left:left+OW]   MODE 1 (backward): dx (+)= dy placed at (top,left), zero elsewhere
-template <int MODE>
-__global__ __launch_bounds__(EW_BLOCK) void crop_kernel(const float* __restrict__ src, int src_cs, float* __restrict__ dst, int dst_cs,
+template <typename T, int MODE>
+__global__ __launch_bounds__(EW_BLOCK) void crop_kernel(const T* __restrict__ src, int src_cs, T* __restrict__ dst, int dst_cs,
                                                         int accumulate, int N, int H, int W, int C, int top, int left, int OH, int OW) {
     const long total = MODE == 0 ? (long)N * OH * OW * C : (long)N * H * W * C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -142,16 +159,16 @@ __global__ __launch_bounds__(EW_BLOCK) void crop_kernel(const float* __restrict_
             const int iy = (int)(r % H);
             const int n = (int)(r / H);
             const int oy = iy - top, ox = ix - left;
-            const float g = (oy >= 0 && oy < OH && ox >= 0 && ox < OW) ? src[((long)(n * OH + oy) * OW + ox) * src_cs + c] : 0.f;
-            float* o = dst + ((long)(n * H + iy) * W + ix) * dst_cs + c;
-            *o = accumulate ? (*o + g) : g;
+            const float g = (oy >= 0 && oy < OH && ox >= 0 && ox < OW) ? (float)src[((long)(n * OH + oy) * OW + ox) * src_cs + c] : 0.f;
+            T* o = dst + ((long)(n * H + iy) * W + ix) * dst_cs + c;
+            *o = (T)(accumulate ? ((float)*o + g) : g);
         }
     }
 }
 
 // MODE 0: nearest-neighbour 2x upsampling (keras.layers.UpSampling2D, CycleGAN.py:349); MODE 1: its backward (2x2 sums)
-template <int MODE>
-__global__ __launch_bounds__(EW_BLOCK) void upsample2x_kernel(const float* __restrict__ src, int src_cs, float* __restrict__ dst, int dst_cs,
+template <typename T, int MODE>
+__global__ __launch_bounds__(EW_BLOCK) void upsample2x_kernel(const T* __restrict__ src, int src_cs, T* __restrict__ dst, int dst_cs,
                                                               int accumulate, int N, int H, int W, int C) {
     const long total = MODE == 0 ? (long)N * 2 * H * 2 * W * C : (long)N * H * W * C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -166,10 +183,10 @@ __global__ __launch_bounds__(EW_BLOCK) void upsample2x_kernel(const float* __res
             const int ix = (int)(r % W); r /= W;
             const int iy = (int)(r % H);
             const int n = (int)(r / H);
-            const float* q = src + ((long)(n * 2 * H + 2 * iy) * 2 * W + 2 * ix) * src_cs + c;
-            const float g = q[0] + q[src_cs] + q[(long)2 * W * src_cs] + q[(long)(2 * W + 1) * src_cs];
-            float* o = dst + ((long)(n * H + iy) * W + ix) * dst_cs + c;
-            *o = accumulate ? (*o + g) : g;
+            const T* q = src + ((long)(n * 2 * H + 2 * iy) * 2 * W + 2 * ix) * src_cs + c;
+            const float g = (float)q[0] + (float)q[src_cs] + (float)q[(long)2 * W * src_cs] + (float)q[(long)(2 * W + 1) * src_cs];
+            T* o = dst + ((long)(n * H + iy) * W + ix) * dst_cs + c;
+            *o = (T)(accumulate ? ((float)*o + g) : g);
         }
     }
 }
@@ -221,34 +238,37 @@ __global__ __launch_bounds__(EW_BLOCK) void loss_finish_kernel(const float* __re
         for (int k = 0; k < K; ++k) out[k] = (float)(red[k][0] * (double)inv_count);
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void mse_const_kernel(const float* __restrict__ pred, long count, float target, float gscale,
-                                                             float* __restrict__ grad, float* __restrict__ part) {
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void mse_const_kernel(const T* __restrict__ pred, long count, float target, float gscale,
+                                                             T* __restrict__ grad, float* __restrict__ part) {
     float v[1] = {0.f};
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
-        const float d = pred[e] - target;
+        const float d = (float)pred[e] - target;
         v[0] = fmaf(d, d, v[0]);
-        if (grad) grad[e] = gscale * 2.f * d;
+        if (grad) grad[e] = (T)(gscale * 2.f * d);
     }
     block_reduce_store<1>(v, part);
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void mae_kernel(const float* __restrict__ truth, const float* __restrict__ pred, long count, float gscale,
-                                                       float* __restrict__ grad, float* __restrict__ part) {
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void mae_kernel(const T* __restrict__ truth, const T* __restrict__ pred, long count, float gscale,
+                                                       T* __restrict__ grad, float* __restrict__ part) {
     float v[1] = {0.f};
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
-        const float d = pred[e] - truth[e];
+        const float d = (float)pred[e] - (float)truth[e];
         v[0] += fabsf(d);
-        if (grad) grad[e] = gscale * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        if (grad) grad[e] = (T)(gscale * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
     }
     block_reduce_store<1>(v, part);
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void wbce_kernel(const float* __restrict__ truth, const float* __restrict__ pred, long count,
-                                                        float weighting, float gscale, float* __restrict__ grad, float* __restrict__ part) {
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void wbce_kernel(const T* __restrict__ truth, const T* __restrict__ pred, long count,
+                                                        float weighting, float gscale, T* __restrict__ grad, float* __restrict__ part) {
     float v[3] = {0.f, 0.f, 0.f};
     const float eps = 1e-7f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
-        const float t = truth[e], pr = pred[e];
+        const float t = (float)truth[e], pr = (float)pred[e];
         const float pc = fminf(fmaxf(pr, eps), 1.f - eps);
         const float w = t * (weighting - 1.f) + 1.f;
         v[0] += -w * (t * logf(pc) + (1.f - t) * logf(1.f - pc));
@@ -257,7 +277,7 @@ __global__ __launch_bounds__(EW_BLOCK) void wbce_kernel(const float* __restrict_
         if (grad) {
             // d/dp of -w[t log p + (1-t) log(1-p)], zero where the clip is active (as torch.clip backward)
             const bool inside = (pr >= eps) && (pr <= 1.f - eps);
-            grad[e] = inside ? gscale * w * (-(t / pc) + (1.f - t) / (1.f - pc)) : 0.f;
+            grad[e] = (T)(inside ? gscale * w * (-(t / pc) + (1.f - t) / (1.f - pc)) : 0.f);
         }
     }
     block_reduce_store<3>(v, part);
@@ -303,30 +323,62 @@ inline int loss_blocks(long count) {
 
 }  // namespace
 
+// dtype dispatch of the activation storage type: T = float / _Float16 / __bf16 inside the statement
+#define SS_DT(dtype, ...)                                                                                     \
+    switch (dtype) {                                                                                          \
+        case SS_DTYPE_F32: { typedef float T; __VA_ARGS__; } break;                                          \
+        case SS_DTYPE_F16: { typedef _Float16 T; __VA_ARGS__; } break;                                       \
+        case SS_DTYPE_BF16: { typedef __bf16 T; __VA_ARGS__; } break;                                        \
+        default: ss_set_error("unknown ss_dtype %d", (int)(dtype)); return SS_ERR_INVALID;                   \
+    }
+
+int ss_convert_launch(const void* src, int src_dtype, int src_cs, void* dst, int dst_dtype, int dst_cs, long rows, int c, hipStream_t s) {
+    if (!src || !dst || rows < 0 || c <= 0) return SS_ERR_INVALID;
+    if (rows == 0) return SS_OK;
+    const dim3 grid(ew_grid(rows * c)), block(EW_BLOCK);
+#define CV(TS, TD) hipLaunchKernelGGL((convert_kernel<TS, TD>), grid, block, 0, s, (const TS*)src, src_cs, (TD*)dst, dst_cs, rows, c)
+    if (src_dtype == SS_DTYPE_F32 && dst_dtype == SS_DTYPE_F32) CV(float, float);
+    else if (src_dtype == SS_DTYPE_F32 && dst_dtype == SS_DTYPE_F16) CV(float, _Float16);
+    else if (src_dtype == SS_DTYPE_F32 && dst_dtype == SS_DTYPE_BF16) CV(float, __bf16);
+    else if (src_dtype == SS_DTYPE_F16 && dst_dtype == SS_DTYPE_F32) CV(_Float16, float);
+    else if (src_dtype == SS_DTYPE_BF16 && dst_dtype == SS_DTYPE_F32) CV(__bf16, float);
+    else if (src_dtype == SS_DTYPE_F16 && dst_dtype == SS_DTYPE_F16) CV(_Float16, _Float16);
+    else if (src_dtype == SS_DTYPE_BF16 && dst_dtype == SS_DTYPE_BF16) CV(__bf16, __bf16);
+    else { ss_set_error("ss_convert: %d -> %d not supported", src_dtype, dst_dtype); return SS_ERR_UNSUPPORTED; }
+#undef CV
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
 extern "C" {
 
-int ss_act_bwd(int act, float act_alpha, const float* dy, int32_t dy_cstride, const float* y, int32_t y_cstride,
-               float* dx, int32_t dx_cstride, int64_t rows, int32_t c, void* stream) {
+int ss_convert(const void* src, int32_t src_dtype, int32_t src_cstride, void* dst, int32_t dst_dtype, int32_t dst_cstride,
+               int64_t rows, int32_t c, void* stream) {
+    return ss_convert_launch(src, src_dtype, src_cstride, dst, dst_dtype, dst_cstride, (long)rows, c, (hipStream_t)stream);
+}
+
+int ss_act_bwd_t(int32_t dtype, int act, float act_alpha, const void* dy, int32_t dy_cstride, const void* y, int32_t y_cstride,
+                 void* dx, int32_t dx_cstride, int64_t rows, int32_t c, void* stream) {
     if (!dy || !y || !dx || rows < 0 || c <= 0) return SS_ERR_INVALID;
     if (rows == 0) return SS_OK;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(rows * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
-                       act, act_alpha, dy, dy_cstride, y, y_cstride, dx, dx_cstride, (long)rows, c);
+    SS_DT(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(ew_grid(rows * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                    act, act_alpha, (const T*)dy, dy_cstride, (const T*)y, y_cstride, (T*)dx, dx_cstride, (long)rows, c));
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_axpby(float alpha, const float* a, int32_t a_cstride, float beta, const float* b, int32_t b_cstride,
-             float* out, int32_t out_cstride, int64_t rows, int32_t c, void* stream) {
+int ss_axpby_t(int32_t dtype, float alpha, const void* a, int32_t a_cstride, float beta, const void* b, int32_t b_cstride,
+               void* out, int32_t out_cstride, int64_t rows, int32_t c, void* stream) {
     if (!a || !out || rows < 0 || c <= 0) return SS_ERR_INVALID;
     if (rows == 0) return SS_OK;
-    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(rows * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
-                       alpha, a, a_cstride, beta, b, b_cstride, out, out_cstride, (long)rows, c);
+    SS_DT(dtype, hipLaunchKernelGGL(axpby_kernel<T>, dim3(ew_grid(rows * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                    alpha, (const T*)a, a_cstride, beta, (const T*)b, b_cstride, (T*)out, out_cstride, (long)rows, c));
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_copy(const float* src, int32_t src_cstride, float* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream) {
-    return ss_axpby(1.f, src, src_cstride, 0.f, nullptr, 0, dst, dst_cstride, rows, c, stream);
+int ss_copy_t(int32_t dtype, const void* src, int32_t src_cstride, void* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream) {
+    return ss_axpby_t(dtype, 1.f, src, src_cstride, 0.f, nullptr, 0, dst, dst_cstride, rows, c, stream);
 }
 
 int ss_fill(float* dst, float value, int64_t count, void* stream) {
@@ -337,121 +389,180 @@ int ss_fill(float* dst, float value, int64_t count, void* stream) {
     return SS_OK;
 }
 
-int ss_maxpool2x2_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride,
-                      int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+int ss_maxpool2x2_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride,
+                        int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
     if (!x || !y || n <= 0 || h < 2 || w < 2 || c <= 0) return SS_ERR_INVALID;
     const long total = (long)n * (h / 2) * (w / 2) * c;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, x_cstride, y, y_cstride, n, h, w, c);
+    SS_DT(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                    (const T*)x, x_cstride, (T*)y, y_cstride, n, h, w, c));
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_maxpool2x2_bwd(const float* dy, int32_t dy_cstride, const float* x, int32_t x_cstride,
-                      float* dx, int32_t dx_cstride, int accumulate,
-                      int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+int ss_maxpool2x2_bwd_t(int32_t dtype, const void* dy, int32_t dy_cstride, const void* x, int32_t x_cstride,
+                        void* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
     if (!dy || !x || !dx || n <= 0 || h < 2 || w < 2 || c <= 0) return SS_ERR_INVALID;
     const long total = (long)n * h * w * c;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
-                       dy, dy_cstride, x, x_cstride, dx, dx_cstride, accumulate, n, h, w, c);
+    SS_DT(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                    (const T*)dy, dy_cstride, (const T*)x, x_cstride, (T*)dx, dx_cstride, accumulate, n, h, w, c));
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_reflect_pad2d_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c,
-                         int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream) {
+int ss_reflect_pad2d_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w,
+                           int32_t c, int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream) {
     if (!x || !y || n <= 0 || h <= 0 || w <= 0 || c <= 0 || pad_top < 0 || pad_bottom < 0 || pad_left < 0 || pad_right < 0) return SS_ERR_INVALID;
     if (pad_top >= h || pad_bottom >= h || pad_left >= w || pad_right >= w) return SS_ERR_INVALID;
     const int PH = h + pad_top + pad_bottom, PW = w + pad_left + pad_right;
-    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(ew_grid((long)n * PH * PW * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
-                       x, x_cstride, y, y_cstride, n, h, w, c, pad_top, pad_left, PH, PW);
+    SS_DT(dtype, hipLaunchKernelGGL(reflect_pad_fwd_kernel<T>, dim3(ew_grid((long)n * PH * PW * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                    (const T*)x, x_cstride, (T*)y, y_cstride, n, h, w, c, pad_top, pad_left, PH, PW));
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_reflect_pad2d_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
-                         int32_t c, int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream) {
+int ss_reflect_pad2d_bwd_t(int32_t dtype, const void* dy, int32_t dy_cstride, void* dx, int32_t dx_cstride, int accumulate, int32_t n,
+                           int32_t h, int32_t w, int32_t c, int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream) {
     if (!dy || !dx || n <= 0 || h <= 0 || w <= 0 || c <= 0) return SS_ERR_INVALID;
     const int PH = h + pad_top + pad_bottom, PW = w + pad_left + pad_right;
-    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(ew_grid((long)n * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
-                       dy, dy_cstride, dx, dx_cstride, accumulate, n, h, w, c, pad_top, pad_left, PH, PW);
+    SS_DT(dtype, hipLaunchKernelGGL(reflect_pad_bwd_kernel<T>, dim3(ew_grid((long)n * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                    (const T*)dy, dy_cstride, (T*)dx, dx_cstride, accumulate, n, h, w, c, pad_top, pad_left, PH, PW));
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_crop2d_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c,
-                  int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream) {
+int ss_crop2d_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c,
+                    int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream) {
     if (!x || !y || n <= 0 || c <= 0 || top < 0 || left < 0 || oh <= 0 || ow <= 0 || top + oh > h || left + ow > w) return SS_ERR_INVALID;
-    hipLaunchKernelGGL(crop_kernel<0>, dim3(ew_grid((long)n * oh * ow * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
-                       x, x_cstride, y, y_cstride, 0, n, h, w, c, top, left, oh, ow);
+    SS_DT(dtype, hipLaunchKernelGGL((crop_kernel<T, 0>), dim3(ew_grid((long)n * oh * ow * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                    (const T*)x, x_cstride, (T*)y, y_cstride, 0, n, h, w, c, top, left, oh, ow));
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_crop2d_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
-                  int32_t c, int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream) {
+int ss_crop2d_bwd_t(int32_t dtype, const void* dy, int32_t dy_cstride, void* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h,
+                    int32_t w, int32_t c, int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream) {
     if (!dy || !dx || n <= 0 || c <= 0 || top < 0 || left < 0 || oh <= 0 || ow <= 0 || top + oh > h || left + ow > w) return SS_ERR_INVALID;
-    hipLaunchKernelGGL(crop_kernel<1>, dim3(ew_grid((long)n * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
-                       dy, dy_cstride, dx, dx_cstride, accumulate, n, h, w, c, top, left, oh, ow);
+    SS_DT(dtype, hipLaunchKernelGGL((crop_kernel<T, 1>), dim3(ew_grid((long)n * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                    (const T*)dy, dy_cstride, (T*)dx, dx_cstride, accumulate, n, h, w, c, top, left, oh, ow));
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_upsample2x_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+int ss_upsample2x_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w,
+                        int32_t c, void* stream) {
     if (!x || !y || n <= 0 || h <= 0 || w <= 0 || c <= 0) return SS_ERR_INVALID;
-    hipLaunchKernelGGL(upsample2x_kernel<0>, dim3(ew_grid((long)n * 4 * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
-                       x, x_cstride, y, y_cstride, 0, n, h, w, c);
+    SS_DT(dtype, hipLaunchKernelGGL((upsample2x_kernel<T, 0>), dim3(ew_grid((long)n * 4 * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                    (const T*)x, x_cstride, (T*)y, y_cstride, 0, n, h, w, c));
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_upsample2x_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
-                      int32_t c, void* stream) {
+int ss_upsample2x_bwd_t(int32_t dtype, const void* dy, int32_t dy_cstride, void* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h,
+                        int32_t w, int32_t c, void* stream) {
     if (!dy || !dx || n <= 0 || h <= 0 || w <= 0 || c <= 0) return SS_ERR_INVALID;
-    hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(ew_grid((long)n * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
-                       dy, dy_cstride, dx, dx_cstride, accumulate, n, h, w, c);
+    SS_DT(dtype, hipLaunchKernelGGL((upsample2x_kernel<T, 1>), dim3(ew_grid((long)n * h * w * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                    (const T*)dy, dy_cstride, (T*)dx, dx_cstride, accumulate, n, h, w, c));
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
 size_t ss_loss_workspace_bytes(int64_t count) { (void)count; return (size_t)LOSS_MAX_BLOCKS * 3 * sizeof(float); }
 
-int ss_loss_mse_const(const float* pred, int64_t count, float target, float grad_scale,
-                      float* loss_out, float* grad, void* ws, size_t ws_bytes, void* stream) {
+int ss_loss_mse_const_t(int32_t dtype, const void* pred, int64_t count, float target, float grad_scale,
+                        float* loss_out, void* grad, void* ws, size_t ws_bytes, void* stream) {
     if (!pred || !loss_out || count <= 0) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_loss_workspace_bytes(count)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int nb = loss_blocks(count);
-    hipLaunchKernelGGL(mse_const_kernel, dim3(nb), dim3(EW_BLOCK), 0, s, pred, (long)count, target, grad_scale / (float)count, grad, (float*)ws);
+    SS_DT(dtype, hipLaunchKernelGGL(mse_const_kernel<T>, dim3(nb), dim3(EW_BLOCK), 0, s, (const T*)pred, (long)count, target,
+                                    grad_scale / (float)count, (T*)grad, (float*)ws));
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finish_kernel<1>, dim3(1), dim3(EW_BLOCK), 0, s, (const float*)ws, nb, 1.f / (float)count, loss_out);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_loss_mae(const float* truth, const float* pred, int64_t count, float grad_scale,
-                float* loss_out, float* grad, void* ws, size_t ws_bytes, void* stream) {
+int ss_loss_mae_t(int32_t dtype, const void* truth, const void* pred, int64_t count, float grad_scale,
+                  float* loss_out, void* grad, void* ws, size_t ws_bytes, void* stream) {
     if (!truth || !pred || !loss_out || count <= 0) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_loss_workspace_bytes(count)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int nb = loss_blocks(count);
-    hipLaunchKernelGGL(mae_kernel, dim3(nb), dim3(EW_BLOCK), 0, s, truth, pred, (long)count, grad_scale / (float)count, grad, (float*)ws);
+    SS_DT(dtype, hipLaunchKernelGGL(mae_kernel<T>, dim3(nb), dim3(EW_BLOCK), 0, s, (const T*)truth, (const T*)pred, (long)count,
+                                    grad_scale / (float)count, (T*)grad, (float*)ws));
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finish_kernel<1>, dim3(1), dim3(EW_BLOCK), 0, s, (const float*)ws, nb, 1.f / (float)count, loss_out);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_loss_weighted_bce(const float* truth, const float* pred, int64_t count, float weighting, float grad_scale,
-                         float* out3, float* grad, void* ws, size_t ws_bytes, void* stream) {
+int ss_loss_weighted_bce_t(int32_t dtype, const void* truth, const void* pred, int64_t count, float weighting, float grad_scale,
+                           float* out3, void* grad, void* ws, size_t ws_bytes, void* stream) {
     if (!truth || !pred || !out3 || count <= 0) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_loss_workspace_bytes(count)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int nb = loss_blocks(count);
-    hipLaunchKernelGGL(wbce_kernel, dim3(nb), dim3(EW_BLOCK), 0, s, truth, pred, (long)count, weighting, grad_scale / (float)count, grad, (float*)ws);
+    SS_DT(dtype, hipLaunchKernelGGL(wbce_kernel<T>, dim3(nb), dim3(EW_BLOCK), 0, s, (const T*)truth, (const T*)pred, (long)count, weighting,
+                                    grad_scale / (float)count, (T*)grad, (float*)ws));
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finish_kernel<3>, dim3(1), dim3(EW_BLOCK), 0, s, (const float*)ws, nb, 1.f / (float)count, out3);
     SS_LAUNCH_CHECK();
     return SS_OK;
+}
+
+// ---- the fp32 entry points of the original ABI ----
+int ss_act_bwd(int act, float act_alpha, const float* dy, int32_t dy_cstride, const float* y, int32_t y_cstride,
+               float* dx, int32_t dx_cstride, int64_t rows, int32_t c, void* stream) {
+    return ss_act_bwd_t(SS_DTYPE_F32, act, act_alpha, dy, dy_cstride, y, y_cstride, dx, dx_cstride, rows, c, stream);
+}
+int ss_axpby(float alpha, const float* a, int32_t a_cstride, float beta, const float* b, int32_t b_cstride,
+             float* out, int32_t out_cstride, int64_t rows, int32_t c, void* stream) {
+    return ss_axpby_t(SS_DTYPE_F32, alpha, a, a_cstride, beta, b, b_cstride, out, out_cstride, rows, c, stream);
+}
+int ss_copy(const float* src, int32_t src_cstride, float* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream) {
+    return ss_copy_t(SS_DTYPE_F32, src, src_cstride, dst, dst_cstride, rows, c, stream);
+}
+int ss_maxpool2x2_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+    return ss_maxpool2x2_fwd_t(SS_DTYPE_F32, x, x_cstride, y, y_cstride, n, h, w, c, stream);
+}
+int ss_maxpool2x2_bwd(const float* dy, int32_t dy_cstride, const float* x, int32_t x_cstride, float* dx, int32_t dx_cstride, int accumulate,
+                      int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+    return ss_maxpool2x2_bwd_t(SS_DTYPE_F32, dy, dy_cstride, x, x_cstride, dx, dx_cstride, accumulate, n, h, w, c, stream);
+}
+int ss_reflect_pad2d_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c,
+                         int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream) {
+    return ss_reflect_pad2d_fwd_t(SS_DTYPE_F32, x, x_cstride, y, y_cstride, n, h, w, c, pad_top, pad_bottom, pad_left, pad_right, stream);
+}
+int ss_reflect_pad2d_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
+                         int32_t c, int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream) {
+    return ss_reflect_pad2d_bwd_t(SS_DTYPE_F32, dy, dy_cstride, dx, dx_cstride, accumulate, n, h, w, c, pad_top, pad_bottom, pad_left, pad_right, stream);
+}
+int ss_crop2d_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c,
+                  int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream) {
+    return ss_crop2d_fwd_t(SS_DTYPE_F32, x, x_cstride, y, y_cstride, n, h, w, c, top, left, oh, ow, stream);
+}
+int ss_crop2d_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
+                  int32_t c, int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream) {
+    return ss_crop2d_bwd_t(SS_DTYPE_F32, dy, dy_cstride, dx, dx_cstride, accumulate, n, h, w, c, top, left, oh, ow, stream);
+}
+int ss_upsample2x_fwd(const float* x, int32_t x_cstride, float* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+    return ss_upsample2x_fwd_t(SS_DTYPE_F32, x, x_cstride, y, y_cstride, n, h, w, c, stream);
+}
+int ss_upsample2x_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w,
+                      int32_t c, void* stream) {
+    return ss_upsample2x_bwd_t(SS_DTYPE_F32, dy, dy_cstride, dx, dx_cstride, accumulate, n, h, w, c, stream);
+}
+int ss_loss_mse_const(const float* pred, int64_t count, float target, float grad_scale,
+                      float* loss_out, float* grad, void* ws, size_t ws_bytes, void* stream) {
+    return ss_loss_mse_const_t(SS_DTYPE_F32, pred, count, target, grad_scale, loss_out, grad, ws, ws_bytes, stream);
+}
+int ss_loss_mae(const float* truth, const float* pred, int64_t count, float grad_scale,
+                float* loss_out, float* grad, void* ws, size_t ws_bytes, void* stream) {
+    return ss_loss_mae_t(SS_DTYPE_F32, truth, pred, count, grad_scale, loss_out, grad, ws, ws_bytes, stream);
+}
+int ss_loss_weighted_bce(const float* truth, const float* pred, int64_t count, float weighting, float grad_scale,
+                         float* out3, float* grad, void* ws, size_t ws_bytes, void* stream) {
+    return ss_loss_weighted_bce_t(SS_DTYPE_F32, truth, pred, count, weighting, grad_scale, out3, grad, ws, ws_bytes, stream);
 }
 
 int ss_adam_keras(float* p, const float* g, float* m, float* v, int64_t count,

@@ -56,14 +56,33 @@ template <int V> __device__ __forceinline__ void stv(float* p, const float (&o)[
     if (V == 4) { f32x4 t = {o[0], o[1 % V], o[2 % V], o[3 % V]}; *(f32x4*)p = t; }
     else *p = o[0];
 }
+// 16-bit activation storage (ss_dtype F16 / BF16): four channels = one 8-byte access, arithmetic in fp32
+typedef _Float16 nf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
+template <int V> __device__ __forceinline__ void ldv(const _Float16* p, float (&o)[V]) {
+    if (V == 4) { const f32x4 t = __builtin_convertvector(*(const nf16x4*)p, f32x4); o[0] = t[0]; o[1 % V] = t[1]; o[2 % V] = t[2]; o[3 % V] = t[3]; }
+    else o[0] = (float)*p;
+}
+template <int V> __device__ __forceinline__ void stv(_Float16* p, const float (&o)[V]) {
+    if (V == 4) { f32x4 t = {o[0], o[1 % V], o[2 % V], o[3 % V]}; *(nf16x4*)p = __builtin_convertvector(t, nf16x4); }
+    else *p = (_Float16)o[0];
+}
+template <int V> __device__ __forceinline__ void ldv(const __bf16* p, float (&o)[V]) {
+    if (V == 4) { const f32x4 t = __builtin_convertvector(*(const nbf16x4*)p, f32x4); o[0] = t[0]; o[1 % V] = t[1]; o[2 % V] = t[2]; o[3 % V] = t[3]; }
+    else o[0] = (float)*p;
+}
+template <int V> __device__ __forceinline__ void stv(__bf16* p, const float (&o)[V]) {
+    if (V == 4) { f32x4 t = {o[0], o[1 % V], o[2 % V], o[3 % V]}; *(nbf16x4*)p = __builtin_convertvector(t, nbf16x4); }
+    else *p = (__bf16)o[0];
+}
 
 // partial sums: part[((g*chunks + chunk)*C + c)*2 + {0,1}]
 // MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat) with g = dy * act'(y)
 // Thread = V consecutive channels x a strided set of pixels; CT = channel lanes (in units of V), PT = 256/CT.
-template <int MODE, int V>
-__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, int x_cs,
-                                                         const float* __restrict__ dy, int dy_cs,
-                                                         const float* __restrict__ y, int y_cs,
+template <typename T, int MODE, int V>
+__global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x, int x_cs,
+                                                         const T* __restrict__ dy, int dy_cs,
+                                                         const T* __restrict__ y, int y_cs,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          int act, float alpha,
                                                          int C, long P, long pix_per_chunk, int CT, int PT,
@@ -186,12 +205,12 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd(const float* __restrict
 }
 
 // y = act((x-mean)*rstd*gamma + beta + residual); one thread = V channels of one pixel, grid-stride
-template <int V>
-__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, int x_cs,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x, int x_cs,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ res, int res_cs,
-                                                         float* __restrict__ y, int y_cs,
+                                                         const T* __restrict__ res, int res_cs,
+                                                         T* __restrict__ y, int y_cs,
                                                          int act, float alpha, int C, long P, long rows) {
     const int CV = C / V;
     const long total = rows * CV;
@@ -217,19 +236,20 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
 }
 
 // inference: statistics from moving mean / variance
-__global__ __launch_bounds__(256) void norm_infer_kernel(const float* __restrict__ x, int x_cs,
+template <typename T>
+__global__ __launch_bounds__(256) void norm_infer_kernel(const T* __restrict__ x, int x_cs,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mm, const float* __restrict__ mv, float eps,
-                                                         const float* __restrict__ res, int res_cs,
-                                                         float* __restrict__ y, int y_cs, int act, float alpha, int C, long rows) {
+                                                         const T* __restrict__ res, int res_cs,
+                                                         T* __restrict__ y, int y_cs, int act, float alpha, int C, long rows) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * C) return;
     const int c = (int)(e % C);
     const long row = e / C;
     const float sc = rsqrtf(mv[c] + eps) * (gamma ? gamma[c] : 1.f);
-    float v = (x[row * x_cs + c] - mm[c]) * sc + beta[c];
-    if (res) v += res[row * res_cs + c];
-    y[row * y_cs + c] = ss_apply_act(v, act, alpha);
+    float v = ((float)x[row * x_cs + c] - mm[c]) * sc + beta[c];
+    if (res) v += (float)res[row * res_cs + c];
+    y[row * y_cs + c] = (T)ss_apply_act(v, act, alpha);
 }
 
 // backward finalize: per (g,c) means of g and g*xhat -> sums array; dgamma/dbeta summed over groups.
@@ -278,15 +298,15 @@ __global__ __launch_bounds__(256) void norm_finalize_bwd(const float* __restrict
 }
 
 // dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) ; dres = g
-template <int V>
-__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs,
-                                                             const float* __restrict__ x, int x_cs,
-                                                             const float* __restrict__ y, int y_cs,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ dy, int dy_cs,
+                                                             const T* __restrict__ x, int x_cs,
+                                                             const T* __restrict__ y, int y_cs,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ sums,
-                                                             float* __restrict__ dx, int dx_cs, int acc_dx,
-                                                             float* __restrict__ dres, int dres_cs, int acc_dres,
+                                                             T* __restrict__ dx, int dx_cs, int acc_dx,
+                                                             T* __restrict__ dres, int dres_cs, int acc_dres,
                                                              int act, float alpha, int C, long P, long rows,
                                                              const float* __restrict__ rbeta = nullptr) {
     const int CV = C / V;
@@ -377,11 +397,11 @@ __global__ __launch_bounds__(256) void norm_finalize_bwd_sync(const float* __res
 // Block = CL channel lanes x 256/CL pixel lanes; fp32 lane partials, fixed-order tree over the pixel lanes, fp64 finalize.
 constexpr long NORM_SMALL_ELEMS = 4L << 20;
 
-template <int V>
-__global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __restrict__ x, int x_cs,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void norm_small_fwd_kernel(const T* __restrict__ x, int x_cs,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             const float* __restrict__ res, int res_cs,
-                                                             float* __restrict__ y, int y_cs,
+                                                             const T* __restrict__ res, int res_cs,
+                                                             T* __restrict__ y, int y_cs,
                                                              float* __restrict__ mean, float* __restrict__ rstd,
                                                              float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
                                                              int act, float alpha, int C, long P, int CL) {
@@ -460,13 +480,13 @@ __global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __rest
     }
 }
 
-template <int V>
-__global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __restrict__ dy, int dy_cs, const float* __restrict__ x, int x_cs,
-                                                             const float* __restrict__ y, int y_cs,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void norm_small_bwd_kernel(const T* __restrict__ dy, int dy_cs, const T* __restrict__ x, int x_cs,
+                                                             const T* __restrict__ y, int y_cs,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                             float* __restrict__ dx, int dx_cs, int acc_dx,
-                                                             float* __restrict__ dres, int dres_cs, int acc_dres,
+                                                             T* __restrict__ dx, int dx_cs, int acc_dx,
+                                                             T* __restrict__ dres, int dres_cs, int acc_dres,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_params,
                                                              int act, float alpha, int G, int C, long P, int CL) {
     __shared__ float red[2 * V][256];
@@ -603,7 +623,7 @@ bool valid(const ss_norm_desc* d) {
         ss_set_error("ss_norm_desc.struct_size = %u, this library expects %zu", d->struct_size, sizeof(ss_norm_desc));
         return false;
     }
-    if (d && d->dtype != SS_DTYPE_F32) { ss_set_error("ss_norm_desc.dtype = %d unsupported", d->dtype); return false; }
+    if (d && (d->dtype < SS_DTYPE_F32 || d->dtype > SS_DTYPE_F16)) { ss_set_error("ss_norm_desc.dtype = %d unknown", d->dtype); return false; }
     if (!d || d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0) return false;
     if (d->groups != 1 && d->groups != d->n) return false;
     if (d->x_cstride < d->c || d->y_cstride < d->c) return false;
@@ -617,6 +637,14 @@ int pick_v(int c, std::initializer_list<int> strides, std::initializer_list<cons
     for (const void* q : ptrs) if (!al16(q)) return 1;
     return 4;
 }
+// same for 16-bit activation views: four channels are 8 bytes
+int pick_v16(int c, std::initializer_list<int> strides, std::initializer_list<const void*> act_ptrs, std::initializer_list<const void*> f32_ptrs) {
+    if (c % 4) return 1;
+    for (int st : strides) if (st % 4) return 1;
+    for (const void* q : act_ptrs) if (q && (((uintptr_t)q) & 7)) return 1;
+    for (const void* q : f32_ptrs) if (!al16(q)) return 1;
+    return 4;
+}
 
 size_t part_bytes(const ss_norm_desc* d) {
     return ss_align_up((size_t)d->groups * norm_max_chunks(d->groups) * d->c * 2 * sizeof(float), 256);
@@ -624,15 +652,12 @@ size_t part_bytes(const ss_norm_desc* d) {
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-size_t ss_norm_workspace_bytes(const ss_norm_desc* d) {
-    if (!valid(d)) return 0;
-    return part_bytes(d) + ss_align_up((size_t)d->groups * d->c * 2 * sizeof(float), 256);
-}
 
-int ss_norm_fwd(const ss_norm_desc* d, const float* x, const float* gamma, const float* beta,
-                const float* residual, float* y, float* mean, float* rstd,
+template <typename T>
+int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const float* beta,
+                const T* residual, T* y, float* mean, float* rstd,
                 float* moving_mean, float* moving_var, float momentum,
                 void* ws, size_t ws_bytes, void* stream) {
     if (!valid(d) || !x || !beta || !y || !mean || !rstd) return SS_ERR_INVALID;
@@ -647,10 +672,10 @@ int ss_norm_fwd(const ss_norm_desc* d, const float* x, const float* gamma, const
         const int CL = small_cl(V);
         const dim3 grid((g.C + CL * V - 1) / (CL * V), g.G);
         if (V == 4)
-            hipLaunchKernelGGL(norm_small_fwd_kernel<4>, grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, residual, d->res_cstride, y,
+            hipLaunchKernelGGL((norm_small_fwd_kernel<T, 4>), grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, residual, d->res_cstride, y,
                                d->y_cstride, mean, rstd, moving_mean, moving_var, momentum, d->eps, d->act, d->act_alpha, g.C, g.P, CL);
         else
-            hipLaunchKernelGGL(norm_small_fwd_kernel<1>, grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, residual, d->res_cstride, y,
+            hipLaunchKernelGGL((norm_small_fwd_kernel<T, 1>), grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, residual, d->res_cstride, y,
                                d->y_cstride, mean, rstd, moving_mean, moving_var, momentum, d->eps, d->act, d->act_alpha, g.C, g.P, CL);
         SS_LAUNCH_CHECK();
         return SS_OK;
@@ -658,10 +683,10 @@ int ss_norm_fwd(const ss_norm_desc* d, const float* x, const float* gamma, const
     float* part = (float*)ws;
     const dim3 sgrid(g.chunks, g.cblocks, g.G);
     if (V == 4)
-        hipLaunchKernelGGL((norm_stats_kernel<0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+        hipLaunchKernelGGL((norm_stats_kernel<T, 0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
                            0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     else
-        hipLaunchKernelGGL((norm_stats_kernel<0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+        hipLaunchKernelGGL((norm_stats_kernel<T, 0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
                            0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + FIN_CL - 1) / FIN_CL, g.G), dim3(256), 0, s,
@@ -669,29 +694,31 @@ int ss_norm_fwd(const ss_norm_desc* d, const float* x, const float* gamma, const
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
     if (V == 4)
-        hipLaunchKernelGGL(norm_apply_kernel<4>, dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+        hipLaunchKernelGGL((norm_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
                            residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
     else
-        hipLaunchKernelGGL(norm_apply_kernel<1>, dim3(apply_grid(rows * g.C)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+        hipLaunchKernelGGL((norm_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
                            residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_norm_infer(const ss_norm_desc* d, const float* x, const float* gamma, const float* beta,
-                  const float* moving_mean, const float* moving_var, const float* residual, float* y, void* stream) {
+template <typename T>
+int norm_infer_t(const ss_norm_desc* d, const T* x, const float* gamma, const float* beta,
+                  const float* moving_mean, const float* moving_var, const T* residual, T* y, void* stream) {
     if (!valid(d) || !x || !beta || !y || !moving_mean || !moving_var) return SS_ERR_INVALID;
     const long rows = (long)d->n * d->h * d->w;
-    hipLaunchKernelGGL(norm_infer_kernel, dim3((unsigned)((rows * d->c + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(norm_infer_kernel<T>, dim3((unsigned)((rows * d->c + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        x, d->x_cstride, gamma, beta, moving_mean, moving_var, d->eps, residual, d->res_cstride,
                        y, d->y_cstride, d->act, d->act_alpha, d->c, rows);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
+template <typename T>
+int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* x, const T* y,
                 const float* gamma, const float* beta, const float* mean, const float* rstd,
-                float* dx, int32_t dx_cstride, int accumulate_dx, float* dres, int accumulate_dres,
+                T* dx, int32_t dx_cstride, int accumulate_dx, T* dres, int accumulate_dres,
                 float* dgamma, float* dbeta, int accumulate_params,
                 void* ws, size_t ws_bytes, void* stream) {
     if (!valid(d) || !dy || !x || !mean || !rstd || !dx) return SS_ERR_INVALID;
@@ -708,11 +735,11 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
         const int CL = small_cl(V);
         const dim3 grid((g.C + CL * V - 1) / (CL * V));
         if (V == 4)
-            hipLaunchKernelGGL(norm_small_bwd_kernel<4>, grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride, gamma, beta,
+            hipLaunchKernelGGL((norm_small_bwd_kernel<T, 4>), grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride, gamma, beta,
                                mean, rstd, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres, dgamma, dbeta,
                                accumulate_params, d->act, d->act_alpha, g.G, g.C, g.P, CL);
         else
-            hipLaunchKernelGGL(norm_small_bwd_kernel<1>, grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride, gamma, beta,
+            hipLaunchKernelGGL((norm_small_bwd_kernel<T, 1>), grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride, gamma, beta,
                                mean, rstd, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres, dgamma, dbeta,
                                accumulate_params, d->act, d->act_alpha, g.G, g.C, g.P, CL);
         SS_LAUNCH_CHECK();
@@ -722,10 +749,10 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
     float* sums = (float*)((char*)ws + part_bytes(d));
     const dim3 sgrid(g.chunks, g.cblocks, g.G);
     if (V == 4)
-        hipLaunchKernelGGL((norm_stats_kernel<1, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+        hipLaunchKernelGGL((norm_stats_kernel<T, 1, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
                            d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
     else
-        hipLaunchKernelGGL((norm_stats_kernel<1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+        hipLaunchKernelGGL((norm_stats_kernel<T, 1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
                            d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + FIN_CL - 1) / FIN_CL), dim3(256), 0, s,
@@ -733,11 +760,11 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
     if (V == 4)
-        hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
                            d->act, d->act_alpha, g.C, g.P, rows, beta);
     else
-        hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
                            d->act, d->act_alpha, g.C, g.P, rows, beta);
     SS_LAUNCH_CHECK();
@@ -745,7 +772,8 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
 }
 
 /* ---- two-phase forms for data-parallel (cross-rank) batch statistics: stats -> all-reduce(sum) of `sums` by the caller -> finish ---- */
-int ss_norm_fwd_stats(const ss_norm_desc* d, const float* x, float* sums, void* ws, size_t ws_bytes, void* stream) {
+template <typename T>
+int norm_fwd_stats_t(const ss_norm_desc* d, const T* x, float* sums, void* ws, size_t ws_bytes, void* stream) {
     if (!valid(d) || !x || !sums) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_norm_workspace_bytes(d)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -754,10 +782,10 @@ int ss_norm_fwd_stats(const ss_norm_desc* d, const float* x, float* sums, void* 
     float* part = (float*)ws;
     const dim3 sgrid(g.chunks, g.cblocks, g.G);
     if (V == 4)
-        hipLaunchKernelGGL((norm_stats_kernel<0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+        hipLaunchKernelGGL((norm_stats_kernel<T, 0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
                            0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     else
-        hipLaunchKernelGGL((norm_stats_kernel<0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+        hipLaunchKernelGGL((norm_stats_kernel<T, 0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
                            0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     SS_LAUNCH_CHECK();
     const long gc = (long)g.G * g.C;
@@ -766,7 +794,8 @@ int ss_norm_fwd_stats(const ss_norm_desc* d, const float* x, float* sums, void* 
     return SS_OK;
 }
 
-int ss_norm_fwd_finish(const ss_norm_desc* d, const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+template <typename T>
+int norm_fwd_finish_t(const ss_norm_desc* d, const T* x, const float* gamma, const float* beta, const T* residual, T* y,
                        const float* sums, int64_t total_count, float* mean, float* rstd,
                        float* moving_mean, float* moving_var, float momentum, void* stream) {
     if (!valid(d) || !x || !beta || !y || !sums || !mean || !rstd || total_count <= 0) return SS_ERR_INVALID;
@@ -780,16 +809,17 @@ int ss_norm_fwd_finish(const ss_norm_desc* d, const float* x, const float* gamma
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
     if (V == 4)
-        hipLaunchKernelGGL(norm_apply_kernel<4>, dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+        hipLaunchKernelGGL((norm_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
                            residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
     else
-        hipLaunchKernelGGL(norm_apply_kernel<1>, dim3(apply_grid(rows * g.C)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+        hipLaunchKernelGGL((norm_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
                            residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
-int ss_norm_bwd_stats(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
+template <typename T>
+int norm_bwd_stats_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* x, const T* y,
                       const float* mean, const float* rstd, float* sums, void* ws, size_t ws_bytes, void* stream) {
     if (!valid(d) || !dy || !x || !mean || !rstd || !sums) return SS_ERR_INVALID;
     if (d->act != SS_ACT_NONE && !y) return SS_ERR_INVALID;
@@ -801,10 +831,10 @@ int ss_norm_bwd_stats(const ss_norm_desc* d, const float* dy, int32_t dy_cstride
     float* part = (float*)ws;
     const dim3 sgrid(g.chunks, g.cblocks, g.G);
     if (V == 4)
-        hipLaunchKernelGGL((norm_stats_kernel<1, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+        hipLaunchKernelGGL((norm_stats_kernel<T, 1, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
                            d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     else
-        hipLaunchKernelGGL((norm_stats_kernel<1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+        hipLaunchKernelGGL((norm_stats_kernel<T, 1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
                            d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
     SS_LAUNCH_CHECK();
     const long gc = (long)g.G * g.C;
@@ -813,10 +843,11 @@ int ss_norm_bwd_stats(const ss_norm_desc* d, const float* dy, int32_t dy_cstride
     return SS_OK;
 }
 
-int ss_norm_bwd_finish(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
+template <typename T>
+int norm_bwd_finish_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* x, const T* y,
                        const float* gamma, const float* mean, const float* rstd,
                        const float* global_sums, const float* local_sums, int64_t total_count,
-                       float* dx, int32_t dx_cstride, int accumulate_dx, float* dres, int accumulate_dres,
+                       T* dx, int32_t dx_cstride, int accumulate_dx, T* dres, int accumulate_dres,
                        float* dgamma, float* dbeta, int accumulate_params, void* ws, size_t ws_bytes, void* stream) {
     if (!valid(d) || !dy || !x || !mean || !rstd || !dx || !global_sums || !local_sums || total_count <= 0) return SS_ERR_INVALID;
     if (d->act != SS_ACT_NONE && !y) return SS_ERR_INVALID;
@@ -831,15 +862,82 @@ int ss_norm_bwd_finish(const ss_norm_desc* d, const float* dy, int32_t dy_cstrid
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
     if (V == 4)
-        hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, means, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
                            d->act, d->act_alpha, g.C, g.P, rows);
     else
-        hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, means, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
                            d->act, d->act_alpha, g.C, g.P, rows);
     SS_LAUNCH_CHECK();
     return SS_OK;
+}
+
+}  // namespace
+
+#define SS_NDT(dtype, ...)                                                       \
+    switch (dtype) {                                                            \
+        case SS_DTYPE_F32: { typedef float T; __VA_ARGS__; }                    \
+        case SS_DTYPE_F16: { typedef _Float16 T; __VA_ARGS__; }                 \
+        case SS_DTYPE_BF16: { typedef __bf16 T; __VA_ARGS__; }                  \
+        default: return SS_ERR_INVALID;                                         \
+    }
+
+extern "C" {
+
+size_t ss_norm_workspace_bytes(const ss_norm_desc* d) {
+    if (!valid(d)) return 0;
+    return part_bytes(d) + ss_align_up((size_t)d->groups * d->c * 2 * sizeof(float), 256);
+}
+
+int ss_norm_fwd(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta,
+                const void* residual, void* y, float* mean, float* rstd,
+                float* moving_mean, float* moving_var, float momentum,
+                void* ws, size_t ws_bytes, void* stream) {
+    if (!d) return SS_ERR_INVALID;
+    SS_NDT(d->dtype, return norm_fwd_t<T>(d, (const T*)x, gamma, beta, (const T*)residual, (T*)y, mean, rstd, moving_mean, moving_var, momentum, ws, ws_bytes, stream));
+}
+
+int ss_norm_infer(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta,
+                  const float* moving_mean, const float* moving_var, const void* residual, void* y, void* stream) {
+    if (!d) return SS_ERR_INVALID;
+    SS_NDT(d->dtype, return norm_infer_t<T>(d, (const T*)x, gamma, beta, moving_mean, moving_var, (const T*)residual, (T*)y, stream));
+}
+
+int ss_norm_bwd(const ss_norm_desc* d, const void* dy, int32_t dy_cstride, const void* x, const void* y,
+                const float* gamma, const float* beta, const float* mean, const float* rstd,
+                void* dx, int32_t dx_cstride, int accumulate_dx, void* dres, int accumulate_dres,
+                float* dgamma, float* dbeta, int accumulate_params,
+                void* ws, size_t ws_bytes, void* stream) {
+    if (!d) return SS_ERR_INVALID;
+    SS_NDT(d->dtype, return norm_bwd_t<T>(d, (const T*)dy, dy_cstride, (const T*)x, (const T*)y, gamma, beta, mean, rstd, (T*)dx, dx_cstride, accumulate_dx, (T*)dres, accumulate_dres, dgamma, dbeta, accumulate_params, ws, ws_bytes, stream));
+}
+
+int ss_norm_fwd_stats(const ss_norm_desc* d, const void* x, float* sums, void* ws, size_t ws_bytes, void* stream) {
+    if (!d) return SS_ERR_INVALID;
+    SS_NDT(d->dtype, return norm_fwd_stats_t<T>(d, (const T*)x, sums, ws, ws_bytes, stream));
+}
+
+int ss_norm_fwd_finish(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                       const float* sums, int64_t total_count, float* mean, float* rstd,
+                       float* moving_mean, float* moving_var, float momentum, void* stream) {
+    if (!d) return SS_ERR_INVALID;
+    SS_NDT(d->dtype, return norm_fwd_finish_t<T>(d, (const T*)x, gamma, beta, (const T*)residual, (T*)y, sums, total_count, mean, rstd, moving_mean, moving_var, momentum, stream));
+}
+
+int ss_norm_bwd_stats(const ss_norm_desc* d, const void* dy, int32_t dy_cstride, const void* x, const void* y,
+                      const float* mean, const float* rstd, float* sums, void* ws, size_t ws_bytes, void* stream) {
+    if (!d) return SS_ERR_INVALID;
+    SS_NDT(d->dtype, return norm_bwd_stats_t<T>(d, (const T*)dy, dy_cstride, (const T*)x, (const T*)y, mean, rstd, sums, ws, ws_bytes, stream));
+}
+
+int ss_norm_bwd_finish(const ss_norm_desc* d, const void* dy, int32_t dy_cstride, const void* x, const void* y,
+                       const float* gamma, const float* mean, const float* rstd,
+                       const float* global_sums, const float* local_sums, int64_t total_count,
+                       void* dx, int32_t dx_cstride, int accumulate_dx, void* dres, int accumulate_dres,
+                       float* dgamma, float* dbeta, int accumulate_params, void* ws, size_t ws_bytes, void* stream) {
+    if (!d) return SS_ERR_INVALID;
+    SS_NDT(d->dtype, return norm_bwd_finish_t<T>(d, (const T*)dy, dy_cstride, (const T*)x, (const T*)y, gamma, mean, rstd, global_sums, local_sums, total_count, (T*)dx, dx_cstride, accumulate_dx, (T*)dres, accumulate_dres, dgamma, dbeta, accumulate_params, ws, ws_bytes, stream));
 }
 
 }  // extern "C"

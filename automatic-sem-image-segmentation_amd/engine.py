@@ -97,10 +97,11 @@ TIMER = KernelTimer()
 class Act:
     """An NHWC activation view: channels [c0, c0+c) of a base tensor [n,h,w,cs]."""
 
-    __slots__ = ("t", "c0", "c", "grad", "grad_init", "requires_grad", "parent", "amax", "amax_valid")
+    __slots__ = ("t", "c0", "c", "grad", "grad_init", "requires_grad", "parent", "amax", "amax_valid", "dt")
 
     def __init__(self, t, c0=0, c=None, requires_grad=True, parent=None):
-        assert t.dim() == 4 and t.dtype == torch.float32 and t.is_contiguous()
+        assert t.dim() == 4 and t.is_contiguous()
+        self.dt = L.dtype_of(t)          # ss_dtype of the storage: fp32 (default) or bf16 / fp16 mixed-precision storage
         self.t, self.c0 = t, c0
         self.c = t.shape[3] - c0 if c is None else c
         self.grad = None
@@ -124,7 +125,9 @@ class Act:
     @property
     def device(self): return self.t.device
     @property
-    def ptr(self): return ctypes.c_void_p(self.t.data_ptr() + 4 * self.c0)
+    def ptr(self): return ctypes.c_void_p(self.t.data_ptr() + self.t.element_size() * self.c0)
+    @property
+    def dtype(self): return self.t.dtype
 
     def amax_slot(self):
         """Caller-owned slot for ss_conv_desc.x_amax / dy_amax: the first conv pass that needs this tensor's maximum leaves it
@@ -134,8 +137,13 @@ class Act:
         return ctypes.c_void_p(self.amax.data_ptr())
 
     @staticmethod
-    def empty(n, h, w, c, device, requires_grad=True):
-        return Act(torch.empty((n, h, w, c), dtype=torch.float32, device=device), requires_grad=requires_grad)
+    def empty(n, h, w, c, device, requires_grad=True, dtype=torch.float32):
+        return Act(torch.empty((n, h, w, c), dtype=dtype, device=device), requires_grad=requires_grad)
+
+    def like(self, n=None, h=None, w=None, c=None, requires_grad=True):
+        """A new activation of this one's storage type and device (dimensions default to this one's)."""
+        return Act.empty(self.n if n is None else n, self.h if h is None else h, self.w if w is None else w,
+                         self.c if c is None else c, self.device, requires_grad, self.t.dtype)
 
     def slice(self, c0, c):
         """Channel slice sharing storage (and, lazily, gradient storage) with this buffer."""
@@ -175,13 +183,23 @@ class Act:
         return self.grad if self.grad_init else None
 
 
+def convert(act, dtype):
+    """A copy of the activation view in another storage type (ss_convert): the fp32 <-> bf16 / fp16 boundary of a network."""
+    if act.t.dtype == dtype:
+        return act
+    out = Act.empty(act.n, act.h, act.w, act.c, act.device, act.requires_grad, dtype)
+    L.check(L.load().ss_convert(act.ptr, act.dt, act.cs, out.ptr, out.dt, out.cs, act.rows, act.c, _stream()), "ss_convert")
+    return out
+
+
 class Tape:
     """Records backward closures in forward order; ``backward()`` replays them in reverse."""
 
-    def __init__(self, enabled=True, param_grads=True):
+    def __init__(self, enabled=True, param_grads=True, count_uses=True):
         self.ops = []
         self.enabled = enabled
         self.param_grads = param_grads   # False: ops recorded now skip weight gradients (input grads only)
+        self.count_uses = count_uses     # False (recomputation tapes): the uses of the variables were announced at the first forward
 
     def record(self, fn):
         if self.enabled:

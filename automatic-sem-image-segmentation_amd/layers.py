@@ -56,7 +56,7 @@ class Conv2D:
         return h + 2 * p - k + 1, w + 2 * p - k + 1
 
     def desc(self, x, y):
-        key = (x.n, x.h, x.w, x.cs, y.cs)
+        key = (x.n, x.h, x.w, x.cs, y.cs, x.dt)
         d = self._desc_cache.get(key)
         if d is None:
             k, s = self.k, self.stride
@@ -71,8 +71,9 @@ class Conv2D:
             elif self.padding != "valid":
                 pt = pl = self.padding[1]
                 mode = L.PAD_REFLECT
+            assert x.dt == y.dt, "a convolution reads and writes activations of one storage type"
             d = L.ConvDesc(x.n, x.h, x.w, self.cin, x.cs, y.h, y.w, self.cout, y.cs, k, k, s, pt, pl, mode,
-                           1 if self.transposed else 0, ACTS[self.act], float(self.act_alpha), self.algo)
+                           1 if self.transposed else 0, ACTS[self.act], float(self.act_alpha), self.algo, dtype=x.dt)
             self._desc_cache[key] = d
         return d
 
@@ -80,7 +81,7 @@ class Conv2D:
         lib = L.load()
         assert x.c == self.cin, (self.name, x.c, self.cin)
         oh, ow = self.out_hw(x.h, x.w)
-        y = out if out is not None else Act.empty(x.n, oh, ow, self.cout, x.device)
+        y = out if out is not None else x.like(h=oh, w=ow, c=self.cout)
         assert (y.h, y.w, y.c) == (oh, ow, self.cout)
         d = self.desc(x, y)
         w = self.arena[f"{self.name}/kernel"]
@@ -102,7 +103,7 @@ class Conv2D:
             TIMER.stop(e0, self.profile_tag, x.n)
         param_grads = tape.param_grads
         pnames = [f"{self.name}/kernel"] + ([f"{self.name}/bias"] if self.use_bias else [])
-        if param_grads and tape.enabled:
+        if param_grads and tape.enabled and tape.count_uses:
             self.arena.note_use(pnames)
 
         def backward():
@@ -110,9 +111,9 @@ class Conv2D:
             if dy is None:
                 return
             if self.act is not None:
-                dz = Act.empty(y.n, y.h, y.w, y.c, y.device, False)
-                L.check(lib.ss_act_bwd(ACTS[self.act], float(self.act_alpha), dy.ptr, dy.cs, y.ptr, y.cs,
-                                       dz.ptr, dz.cs, y.rows, y.c, _stream()), "act_bwd")
+                dz = y.like(requires_grad=False)
+                L.check(lib.ss_act_bwd_t(y.dt, ACTS[self.act], float(self.act_alpha), dy.ptr, dy.cs, y.ptr, y.cs,
+                                         dz.ptr, dz.cs, y.rows, y.c, _stream()), "act_bwd")
                 dy = dz
             # the descriptor's out_cstride must describe the dy buffer actually passed
             dd = d if dy.cs == y.cs else self.desc_with_out_cs(d, dy.cs)
@@ -187,10 +188,11 @@ class Norm:
     def __call__(self, tape, x, act=None, act_alpha=0.0, residual=None, out=None, training=True):
         lib = L.load()
         assert x.c == self.c
-        y = out if out is not None else Act.empty(x.n, x.h, x.w, x.c, x.device)
+        y = out if out is not None else x.like()
         groups = x.n if self.kind == "instance" else 1
+        assert x.dt == y.dt and (residual is None or residual.dt == x.dt)
         d = L.NormDesc(x.n, x.h, x.w, x.c, x.cs, y.cs, residual.cs if residual is not None else 0, groups,
-                       float(self.eps), ACTS[act], float(act_alpha))
+                       float(self.eps), ACTS[act], float(act_alpha), dtype=x.dt)
         gamma = self.arena[f"{self.name}/gamma"] if self.scale else None
         beta = self.arena[f"{self.name}/beta"]
         rp = residual.ptr if residual is not None else None
@@ -220,7 +222,7 @@ class Norm:
                                            _p(mm), _p(mv), float(self.momentum), _stream()), "norm_fwd_finish")
         param_grads = tape.param_grads
         pnames = ([f"{self.name}/gamma"] if self.scale else []) + [f"{self.name}/beta"]
-        if param_grads and tape.enabled:
+        if param_grads and tape.enabled and tape.count_uses:
             self.arena.note_use(pnames)
 
         def backward():
@@ -261,15 +263,15 @@ class Norm:
 
 def maxpool2x2(tape, x):
     lib = L.load()
-    y = Act.empty(x.n, x.h // 2, x.w // 2, x.c, x.device)
-    L.check(lib.ss_maxpool2x2_fwd(x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, _stream()), "maxpool_fwd")
+    y = x.like(h=x.h // 2, w=x.w // 2)
+    L.check(lib.ss_maxpool2x2_fwd_t(x.dt, x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, _stream()), "maxpool_fwd")
 
     def backward():
         dy = y.get_grad()
         if dy is None or not x.requires_grad:
             return
         dx, accum = x.grad_target()
-        L.check(lib.ss_maxpool2x2_bwd(dy.ptr, dy.cs, x.ptr, x.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, _stream()),
+        L.check(lib.ss_maxpool2x2_bwd_t(x.dt, dy.ptr, dy.cs, x.ptr, x.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, _stream()),
                 "maxpool_bwd")
 
     tape.record(backward)
@@ -280,7 +282,7 @@ def add_grad(dst_act, src):
     """Accumulate the dense gradient view ``src`` into dst_act's gradient (fan-out of an activation)."""
     lib = L.load()
     dg, accum = dst_act.grad_target()
-    L.check(lib.ss_axpby(1.0, src.ptr, src.cs, 1.0 if accum else 0.0, dg.ptr if accum else None, dg.cs,
+    L.check(lib.ss_axpby_t(src.dt, 1.0, src.ptr, src.cs, 1.0 if accum else 0.0, dg.ptr if accum else None, dg.cs,
                          dg.ptr, dg.cs, dst_act.rows, dst_act.c, _stream()), "axpby")
 
 
@@ -291,9 +293,9 @@ def gaussian_noise(tape, x, stddev, training=True):
     if not training or stddev <= 0:
         return x
     lib = L.load()
-    noise = Act(torch.randn((x.n, x.h, x.w, x.c), dtype=torch.float32, device=x.device), requires_grad=False)
-    y = Act.empty(x.n, x.h, x.w, x.c, x.device, requires_grad=x.requires_grad)
-    L.check(lib.ss_axpby(1.0, x.ptr, x.cs, float(stddev), noise.ptr, noise.cs, y.ptr, y.cs, x.rows, x.c, _stream()), "axpby")
+    noise = Act(torch.randn((x.n, x.h, x.w, x.c), dtype=torch.float32, device=x.device).to(x.dtype), requires_grad=False)
+    y = x.like(requires_grad=x.requires_grad)
+    L.check(lib.ss_axpby_t(x.dt, 1.0, x.ptr, x.cs, float(stddev), noise.ptr, noise.cs, y.ptr, y.cs, x.rows, x.c, _stream()), "axpby")
 
     def backward():
         dy = y.get_grad()
@@ -326,7 +328,7 @@ def batch_split(tape, x, sizes):
         for q, g in zip(parts, grads):
             if g is not None:
                 dst = Act(dx.t[n0:n0 + q.n], dx.c0, dx.c, False)
-                L.check(lib.ss_axpby(1.0, g.ptr, g.cs, 1.0, dst.ptr, dst.cs, dst.ptr, dst.cs, q.rows, q.c, _stream()), "axpby")
+                L.check(lib.ss_axpby_t(g.dt, 1.0, g.ptr, g.cs, 1.0, dst.ptr, dst.cs, dst.ptr, dst.cs, q.rows, q.c, _stream()), "axpby")
             n0 += q.n
 
     tape.record(backward)
@@ -340,15 +342,15 @@ def reflect_pad(tape, x, pad_w_total, pad_h_total):
     lib = L.load()
     pt, pb = pad_h_total // 2, pad_h_total // 2 + pad_h_total % 2
     pl, pr = pad_w_total // 2, pad_w_total // 2 + pad_w_total % 2
-    y = Act.empty(x.n, x.h + pt + pb, x.w + pl + pr, x.c, x.device, requires_grad=x.requires_grad)
-    L.check(lib.ss_reflect_pad2d_fwd(x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, pt, pb, pl, pr, _stream()), "reflect_pad_fwd")
+    y = x.like(h=x.h + pt + pb, w=x.w + pl + pr, requires_grad=x.requires_grad)
+    L.check(lib.ss_reflect_pad2d_fwd_t(x.dt, x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, pt, pb, pl, pr, _stream()), "reflect_pad_fwd")
 
     def backward():
         dy = y.get_grad()
         if dy is None or not x.requires_grad:
             return
         dx, accum = x.grad_target()
-        L.check(lib.ss_reflect_pad2d_bwd(dy.ptr, dy.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, pt, pb, pl, pr, _stream()), "reflect_pad_bwd")
+        L.check(lib.ss_reflect_pad2d_bwd_t(x.dt, dy.ptr, dy.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, pt, pb, pl, pr, _stream()), "reflect_pad_bwd")
 
     tape.record(backward)
     return y
@@ -360,15 +362,15 @@ def crop(tape, x, top, bottom, left, right):
         return x
     lib = L.load()
     oh, ow = x.h - top - bottom, x.w - left - right
-    y = Act.empty(x.n, oh, ow, x.c, x.device)
-    L.check(lib.ss_crop2d_fwd(x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, top, left, oh, ow, _stream()), "crop_fwd")
+    y = x.like(h=oh, w=ow)
+    L.check(lib.ss_crop2d_fwd_t(x.dt, x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, top, left, oh, ow, _stream()), "crop_fwd")
 
     def backward():
         dy = y.get_grad()
         if dy is None or not x.requires_grad:
             return
         dx, accum = x.grad_target()
-        L.check(lib.ss_crop2d_bwd(dy.ptr, dy.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, top, left, oh, ow, _stream()), "crop_bwd")
+        L.check(lib.ss_crop2d_bwd_t(x.dt, dy.ptr, dy.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, top, left, oh, ow, _stream()), "crop_bwd")
 
     tape.record(backward)
     return y
@@ -376,15 +378,15 @@ def crop(tape, x, top, bottom, left, right):
 
 def upsample2x(tape, x):
     lib = L.load()
-    y = Act.empty(x.n, 2 * x.h, 2 * x.w, x.c, x.device)
-    L.check(lib.ss_upsample2x_fwd(x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, _stream()), "upsample_fwd")
+    y = x.like(h=2 * x.h, w=2 * x.w)
+    L.check(lib.ss_upsample2x_fwd_t(x.dt, x.ptr, x.cs, y.ptr, y.cs, x.n, x.h, x.w, x.c, _stream()), "upsample_fwd")
 
     def backward():
         dy = y.get_grad()
         if dy is None or not x.requires_grad:
             return
         dx, accum = x.grad_target()
-        L.check(lib.ss_upsample2x_bwd(dy.ptr, dy.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, _stream()), "upsample_bwd")
+        L.check(lib.ss_upsample2x_bwd_t(x.dt, dy.ptr, dy.cs, dx.ptr, dx.cs, accum, x.n, x.h, x.w, x.c, _stream()), "upsample_bwd")
 
     tape.record(backward)
     return y
@@ -393,8 +395,8 @@ def upsample2x(tape, x):
 def add(tape, a, b, out=None):
     """keras.layers.add([a, b])."""
     lib = L.load()
-    y = out if out is not None else Act.empty(a.n, a.h, a.w, a.c, a.device)
-    L.check(lib.ss_axpby(1.0, a.ptr, a.cs, 1.0, b.ptr, b.cs, y.ptr, y.cs, a.rows, a.c, _stream()), "axpby")
+    y = out if out is not None else a.like()
+    L.check(lib.ss_axpby_t(a.dt, 1.0, a.ptr, a.cs, 1.0, b.ptr, b.cs, y.ptr, y.cs, a.rows, a.c, _stream()), "axpby")
 
     def backward():
         dy = y.get_grad()

@@ -19,7 +19,7 @@ def mse_const(pred, target, grad_scale, loss_slot, want_grad=True):
         assert acc == 0
     count = pred.rows * pred.c
     ws = workspace(lib.ss_loss_workspace_bytes(count), pred.device)
-    L.check(lib.ss_loss_mse_const(pred.ptr, count, float(target), float(grad_scale), _p(loss_slot),
+    L.check(lib.ss_loss_mse_const_t(pred.dt, pred.ptr, count, float(target), float(grad_scale), _p(loss_slot),
                                   g.ptr if g is not None else None, _p(ws), ws.numel(), _stream()), "ss_loss_mse_const")
 
 
@@ -33,7 +33,8 @@ def mae(truth, pred, grad_scale, loss_slot, want_grad=True):
         assert acc == 0
     count = pred.rows * pred.c
     ws = workspace(lib.ss_loss_workspace_bytes(count), pred.device)
-    L.check(lib.ss_loss_mae(truth.ptr, pred.ptr, count, float(grad_scale), _p(loss_slot),
+    assert truth.dt == pred.dt
+    L.check(lib.ss_loss_mae_t(pred.dt, truth.ptr, pred.ptr, count, float(grad_scale), _p(loss_slot),
                             g.ptr if g is not None else None, _p(ws), ws.numel(), _stream()), "ss_loss_mae")
 
 
@@ -47,5 +48,6 @@ def weighted_bce(truth, pred, weighting, grad_scale, out3, want_grad=True):
         assert acc == 0
     count = pred.rows * pred.c
     ws = workspace(lib.ss_loss_workspace_bytes(count), pred.device)
-    L.check(lib.ss_loss_weighted_bce(truth.ptr, pred.ptr, count, float(weighting), float(grad_scale), _p(out3),
+    assert truth.dt == pred.dt
+    L.check(lib.ss_loss_weighted_bce_t(pred.dt, truth.ptr, pred.ptr, count, float(weighting), float(grad_scale), _p(out3),
                                      g.ptr if g is not None else None, _p(ws), ws.numel(), _stream()), "ss_loss_weighted_bce")

@@ -13,15 +13,19 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .engine import Act, ParamArena, Tape
+from .engine import Act, ParamArena, Tape, convert
 from .layers import Conv2D, Norm, add, crop, maxpool2x2, reflect_pad, upsample2x
 
 
 class Network:
-    def __init__(self, device):
+    def __init__(self, device, act_dtype=torch.float32):
         self.device = torch.device(device)
         self.arena = ParamArena(self.device)
         self.training_runs = 0
+        # storage type of the ACTIVATIONS (and of what is saved for backward): float32 = the reference's precision; bfloat16 /
+        # float16 = mixed precision (BASELINE configs 2 and 5): weights, gradients of weights, optimizer state, normalisation
+        # statistics and all accumulation stay fp32.  Inputs are converted on entry, outputs are returned in this type.
+        self.act_dtype = L.torch_dtype(act_dtype)
 
     # ---- Keras-like weight surface -------------------------------------------------------------
     def _finish(self, seed):
@@ -71,6 +75,7 @@ class Network:
         """x: Act or NHWC torch tensor.  Returns the output Act; backward closures go to ``tape``."""
         if not isinstance(x, Act):
             x = Act(x.contiguous(), requires_grad=False)
+        x = convert(x, self.act_dtype)
         return self.forward(tape if tape is not None else Tape(enabled=False), x, training)
 
 
@@ -82,8 +87,11 @@ class ResnetGenerator(Network):
 
     def __init__(self, filters=64, num_downsampling_blocks=3, num_residual_blocks=9, num_upsample_blocks=3,
                  channels=1, device="cuda", seed=0, algo=L.ALGO_AUTO, use_skip_connection=False,
-                 use_resize_convolution=False, sigmoid_output=False):
-        super().__init__(device)
+                 use_resize_convolution=False, sigmoid_output=False, act_dtype=torch.float32, checkpoint_blocks=False):
+        super().__init__(device, act_dtype)
+        # activation checkpointing of the residual trunk (BASELINE config 5): forward keeps only every block's INPUT; backward
+        # recomputes the block (conv, InstanceNorm, ReLU, conv, InstanceNorm: CycleGAN.py:323-337) before back-propagating through it
+        self.checkpoint_blocks = checkpoint_blocks
         A = self.arena
         self.nd, self.nr, self.nu = num_downsampling_blocks, num_residual_blocks, num_upsample_blocks
         self.filters = filters
@@ -136,9 +144,8 @@ class ResnetGenerator(Network):
         h = self.in_c7(tape, self.c7_in(tape, x), act="relu")
         for conv, norm in self.down:
             h = norm(tape, conv(tape, h), act="relu")
-        for c0, n0, c1, n1 in self.res:
-            y = n0(tape, c0(tape, h), act="relu")
-            h = n1(tape, c1(tape, y), residual=h)
+        for blk in self.res:
+            h = self._res_block_ckpt(tape, blk, h) if (self.checkpoint_blocks and tape.enabled) else self._res_block(tape, blk, h)
         for conv, norm in self.up:
             if self.use_resize_convolution:
                 h = upsample2x(tape, h)
@@ -146,7 +153,7 @@ class ResnetGenerator(Network):
         if not self.use_skip_connection:
             return self.c7_out(tape, h)
         f = self.sk_sc.cout
-        cat = Act.empty(x.n, x.h, x.w, f + self.c7_out.cout, x.device)       # concatenate([out, x]) without a copy
+        cat = x.like(c=f + self.c7_out.cout)       # concatenate([out, x]) without a copy
         self.c7_out(tape, h, out=cat.slice(f, self.c7_out.cout))
         sc = self.sk_sc_n(tape, self.sk_sc(tape, img_input), act="relu")
         o3 = self.sk_c3_n(tape, self.sk_c3(tape, img_input), act="relu")
@@ -154,13 +161,51 @@ class ResnetGenerator(Network):
         return self.sk_out(tape, cat)
 
 
+    @staticmethod
+    def _res_block(tape, blk, h):
+        c0, n0, c1, n1 = blk
+        y = n0(tape, c0(tape, h), act="relu")
+        return n1(tape, c1(tape, y), residual=h)
+
+    def _res_block_ckpt(self, tape, blk, h):
+        """Forward without a tape (nothing saved but the block's input and output); the recorded backward closure re-runs the
+        block on a local tape and back-propagates through it.  Parameter gradients accumulate into the arena as usual; the
+        variables' uses are announced here (the recomputation tape does not count them again), so the overlapped gradient
+        exchange still sees a bucket complete only after the last real use."""
+        from .engine import Tape as _Tape
+        param_grads = tape.param_grads
+        out = self._res_block(_Tape(enabled=False), blk, h)
+        c0, n0, c1, n1 = blk
+        names = [f"{c0.name}/kernel", f"{n0.name}/gamma", f"{n0.name}/beta", f"{c1.name}/kernel", f"{n1.name}/gamma", f"{n1.name}/beta"]
+        if param_grads and tape.count_uses:
+            self.arena.note_use(names)
+
+        def backward():
+            dy = out.get_grad()
+            if dy is None:
+                return
+            inner = _Tape(param_grads=param_grads, count_uses=False)
+            h2 = Act(h.t, h.c0, h.c, requires_grad=h.requires_grad)      # same storage, own gradient slot
+            out2 = self._res_block(inner, blk, h2)
+            out2.grad, out2.grad_init = dy, True                         # the recomputed output receives the saved gradient
+            inner.backward()
+            if h.requires_grad:
+                gh = h2.get_grad()
+                if gh is not None:
+                    from .layers import add_grad
+                    add_grad(h, gh)
+
+        tape.record(backward)
+        return out
+
+
 class PatchDiscriminator(Network):
     """CycleGAN.get_discriminator (CycleGAN.py:425-451), padding='valid' (CycleGAN.py:148).  ``gaussian_noise_value`` > 0 puts a
     GaussianNoise layer in front of every convolution (training mode only); StartProcess.py:96 leaves it at 0."""
 
     def __init__(self, filters=128, num_downsampling_blocks=2, channels=1, padding="valid", device="cuda", seed=0,
-                 algo=L.ALGO_AUTO, gaussian_noise_value=0.0):
-        super().__init__(device)
+                 algo=L.ALGO_AUTO, gaussian_noise_value=0.0, act_dtype=torch.float32):
+        super().__init__(device, act_dtype)
         A = self.arena
         self.filters, self.nd = filters, num_downsampling_blocks
         self.gaussian_noise_value = float(gaussian_noise_value)
@@ -214,7 +259,7 @@ class _MultiResBlock:
     def __call__(self, tape, x, training, out=None):
         a, b, c = self.widths
         sc = self.sc(tape, x, None, training)
-        cat = Act.empty(x.n, x.h, x.w, self.cout, x.device)     # concat buffer: producers write their slices
+        cat = x.like(c=self.cout)     # concat buffer: producers write their slices
         s3 = self.c3(tape, x, "relu", training, out=cat.slice(0, a))
         s5 = self.c5(tape, s3, "relu", training, out=cat.slice(a, b))
         self.c7(tape, s5, "relu", training, out=cat.slice(a + b, c))
@@ -248,8 +293,8 @@ class MultiResUNet(Network):
 
     ALPHA = 1.67
 
-    def __init__(self, conv_filters=16, device="cuda", seed=0, algo=L.ALGO_AUTO):
-        super().__init__(device)
+    def __init__(self, conv_filters=16, device="cuda", seed=0, algo=L.ALGO_AUTO, act_dtype=torch.float32):
+        super().__init__(device, act_dtype)
         A = self.arena
         f = self.filters = conv_filters
         self.mrb1 = _MultiResBlock(A, "mrb1", f, 1, algo)
@@ -287,19 +332,19 @@ class MultiResUNet(Network):
         p4 = maxpool2x2(tape, m4)
         m5 = self.mrb5(tape, p4, t)
         # skip concatenations [upT(deeper), ResPath(encoder)]: both producers write into the concat buffer
-        cat6 = Act.empty(x.n, m4.h, m4.w, f * 16, dev)
+        cat6 = m4.like(c=f * 16)
         self.rp4(tape, m4, t, out=cat6.slice(f * 8, f * 8))
         self.up6(tape, m5, out=cat6.slice(0, f * 8))
         m6 = self.mrb6(tape, cat6, t)
-        cat7 = Act.empty(x.n, m3.h, m3.w, f * 8, dev)
+        cat7 = m3.like(c=f * 8)
         self.rp3(tape, m3, t, out=cat7.slice(f * 4, f * 4))
         self.up7(tape, m6, out=cat7.slice(0, f * 4))
         m7 = self.mrb7(tape, cat7, t)
-        cat8 = Act.empty(x.n, m2.h, m2.w, f * 4, dev)
+        cat8 = m2.like(c=f * 4)
         self.rp2(tape, m2, t, out=cat8.slice(f * 2, f * 2))
         self.up8(tape, m7, out=cat8.slice(0, f * 2))
         m8 = self.mrb8(tape, cat8, t)
-        cat9 = Act.empty(x.n, m1.h, m1.w, f * 2, dev)
+        cat9 = m1.like(c=f * 2)
         self.rp1(tape, m1, t, out=cat9.slice(f, f))
         self.up9(tape, m8, out=cat9.slice(0, f))
         m9 = self.mrb9(tape, cat9, t)

@@ -7,7 +7,10 @@
  * torch backend.  Each entry point names the reference call sites it replaces.
  *
  * Conventions
- *  - plain C, no C++/torch types; all device buffers are CALLER-OWNED fp32, 16-byte aligned.
+ *  - plain C, no C++/torch types; all device buffers are CALLER-OWNED, 16-byte aligned.  ACTIVATION tensors (x, y, dy, dx,
+ *    residual: the `void*` arguments) are stored as the descriptor's / the `_t` entry point's ss_dtype -- fp32 (the reference's
+ *    precision and the default), or bf16 / fp16 "mixed precision" storage (BASELINE configs 2 and 5); weights, their gradients,
+ *    optimizer state, normalisation statistics, losses and every accumulation are always fp32.
  *  - activations are NHWC "views": pointer + (n,h,w,c) + cstride, where cstride >= c is the
  *    distance in elements between consecutive pixels (lets a layer write straight into a slice
  *    of a concatenated tensor: keras.layers.concatenate, UNet_Segmentation.py:469,542-551).
@@ -125,14 +128,14 @@ typedef struct ss_conv_desc {
 int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass);
 
 size_t ss_conv2d_workspace_bytes(const ss_conv_desc* d, int pass);
-int ss_conv2d_fwd(const ss_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+int ss_conv2d_fwd(const ss_conv_desc* d, const void* x, const float* w, const float* bias, void* y,
                   void* ws, size_t ws_bytes, void* stream);
 /* dx (view with in_cstride) = d loss / d x ; overwritten (accumulate == 0) or added to (accumulate != 0) */
-int ss_conv2d_bwd_data(const ss_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
+int ss_conv2d_bwd_data(const ss_conv_desc* d, const void* dy, const float* w, void* dx, int accumulate,
                        void* ws, size_t ws_bytes, void* stream);
 /* dw (Keras layout, dense) and optional dbias; accumulate != 0 adds to the existing contents
  * (a net that is run several times per step, CycleGAN.py:621-633). */
-int ss_conv2d_bwd_weight(const ss_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+int ss_conv2d_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                          int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -161,13 +164,13 @@ size_t ss_norm_workspace_bytes(const ss_norm_desc* d);
 /* gamma may be NULL (scale=False); residual may be NULL.  mean/rstd: [groups*c] outputs kept for backward.
  * If moving_mean/moving_var are non-NULL (batch norm training) they are updated in place:
  * moving = moving*momentum + batch*(1-momentum), with the biased batch variance. */
-int ss_norm_fwd(const ss_norm_desc* d, const float* x, const float* gamma, const float* beta,
-                const float* residual, float* y, float* mean, float* rstd,
+int ss_norm_fwd(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta,
+                const void* residual, void* y, float* mean, float* rstd,
                 float* moving_mean, float* moving_var, float momentum,
                 void* ws, size_t ws_bytes, void* stream);
 /* inference-mode batch norm: statistics come from moving_mean / moving_var */
-int ss_norm_infer(const ss_norm_desc* d, const float* x, const float* gamma, const float* beta,
-                  const float* moving_mean, const float* moving_var, const float* residual, float* y,
+int ss_norm_infer(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta,
+                  const float* moving_mean, const float* moving_var, const void* residual, void* y,
                   void* stream);
 /* dy: gradient w.r.t. y.  y: forward output (needed when act != NONE).
  * dx (view with dx_cstride) receives d loss / d x.  dres (optional, view with d->res_cstride) receives the
@@ -175,9 +178,9 @@ int ss_norm_infer(const ss_norm_desc* d, const float* x, const float* gamma, con
  * adds into the destination instead of overwriting it.  `y` (the forward output, needed for the activation derivative) may be
  * NULL for relu / leaky-relu layers WITHOUT a residual input: the sign of the pre-activation is then recomputed from x, mean,
  * rstd, gamma and `beta` (one tensor read less in both backward passes); `beta` is only read in that case. */
-int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
+int ss_norm_bwd(const ss_norm_desc* d, const void* dy, int32_t dy_cstride, const void* x, const void* y,
                 const float* gamma, const float* beta, const float* mean, const float* rstd,
-                float* dx, int32_t dx_cstride, int accumulate_dx, float* dres, int accumulate_dres,
+                void* dx, int32_t dx_cstride, int accumulate_dx, void* dres, int accumulate_dres,
                 float* dgamma, float* dbeta, int accumulate_params,
                 void* ws, size_t ws_bytes, void* stream);
 
@@ -185,16 +188,16 @@ int ss_norm_bwd(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, cons
  * `sums` = [groups*c*2] raw sums (fwd: sum x, sum x^2; bwd: sum g, sum g*xhat).  The caller all-reduces (SUM) them over
  * the ranks and passes the GLOBAL element count per (group, channel); with one rank they reproduce ss_norm_fwd/bwd.
  * In backward, dgamma/dbeta are built from the LOCAL sums (the gradient all-reduce sums them over ranks afterwards). */
-int ss_norm_fwd_stats(const ss_norm_desc* d, const float* x, float* sums, void* ws, size_t ws_bytes, void* stream);
-int ss_norm_fwd_finish(const ss_norm_desc* d, const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+int ss_norm_fwd_stats(const ss_norm_desc* d, const void* x, float* sums, void* ws, size_t ws_bytes, void* stream);
+int ss_norm_fwd_finish(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta, const void* residual, void* y,
                        const float* sums, int64_t total_count, float* mean, float* rstd,
                        float* moving_mean, float* moving_var, float momentum, void* stream);
-int ss_norm_bwd_stats(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
+int ss_norm_bwd_stats(const ss_norm_desc* d, const void* dy, int32_t dy_cstride, const void* x, const void* y,
                       const float* mean, const float* rstd, float* sums, void* ws, size_t ws_bytes, void* stream);
-int ss_norm_bwd_finish(const ss_norm_desc* d, const float* dy, int32_t dy_cstride, const float* x, const float* y,
+int ss_norm_bwd_finish(const ss_norm_desc* d, const void* dy, int32_t dy_cstride, const void* x, const void* y,
                        const float* gamma, const float* mean, const float* rstd,
                        const float* global_sums, const float* local_sums, int64_t total_count,
-                       float* dx, int32_t dx_cstride, int accumulate_dx, float* dres, int accumulate_dres,
+                       void* dx, int32_t dx_cstride, int accumulate_dx, void* dres, int accumulate_dres,
                        float* dgamma, float* dbeta, int accumulate_params, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -232,6 +235,34 @@ int ss_upsample2x_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx
 int ss_copy(const float* src, int32_t src_cstride, float* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream);
 int ss_fill(float* dst, float value, int64_t count, void* stream);
 
+/* The same operations on bf16 / fp16 stored activations: leading ss_dtype argument, `void*` views.  The fp32 entry points above are
+ * these with SS_DTYPE_F32. */
+int ss_act_bwd_t(int32_t dtype, int act, float act_alpha, const void* dy, int32_t dy_cstride, const void* y, int32_t y_cstride,
+                 void* dx, int32_t dx_cstride, int64_t rows, int32_t c, void* stream);
+int ss_axpby_t(int32_t dtype, float alpha, const void* a, int32_t a_cstride, float beta, const void* b, int32_t b_cstride,
+               void* out, int32_t out_cstride, int64_t rows, int32_t c, void* stream);
+int ss_copy_t(int32_t dtype, const void* src, int32_t src_cstride, void* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream);
+int ss_maxpool2x2_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride,
+                        int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+int ss_maxpool2x2_bwd_t(int32_t dtype, const void* dy, int32_t dy_cstride, const void* x, int32_t x_cstride,
+                        void* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+int ss_reflect_pad2d_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w,
+                           int32_t c, int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream);
+int ss_reflect_pad2d_bwd_t(int32_t dtype, const void* dy, int32_t dy_cstride, void* dx, int32_t dx_cstride, int accumulate, int32_t n,
+                           int32_t h, int32_t w, int32_t c, int32_t pad_top, int32_t pad_bottom, int32_t pad_left, int32_t pad_right, void* stream);
+int ss_crop2d_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w, int32_t c,
+                    int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream);
+int ss_crop2d_bwd_t(int32_t dtype, const void* dy, int32_t dy_cstride, void* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h,
+                    int32_t w, int32_t c, int32_t top, int32_t left, int32_t oh, int32_t ow, void* stream);
+int ss_upsample2x_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride, int32_t n, int32_t h, int32_t w,
+                        int32_t c, void* stream);
+int ss_upsample2x_bwd_t(int32_t dtype, const void* dy, int32_t dy_cstride, void* dx, int32_t dx_cstride, int accumulate, int32_t n, int32_t h,
+                        int32_t w, int32_t c, void* stream);
+/* dst (dst_dtype view) = src (src_dtype view): the boundary between fp32 and 16-bit stored tensors (network inputs / outputs,
+ * and the fp32 staging of the convolution paths that have no native 16-bit kernel yet) */
+int ss_convert(const void* src, int32_t src_dtype, int32_t src_cstride, void* dst, int32_t dst_dtype, int32_t dst_cstride,
+               int64_t rows, int32_t c, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Losses (Keras 'sum_over_batch_size' = mean over every element).  Each writes the scalar loss to
  * *loss_out (device memory) and, if grad != NULL, grad = grad_scale * d loss / d pred.
@@ -247,6 +278,14 @@ int ss_loss_mae(const float* truth, const float* pred, int64_t count, float grad
 /* class-weighted BCE + metrics, UNet_Segmentation.py:379-384,395.  out3 = {loss, mae, binary acc@0.5} */
 int ss_loss_weighted_bce(const float* truth, const float* pred, int64_t count, float weighting, float grad_scale,
                          float* out3, float* grad, void* ws, size_t ws_bytes, void* stream);
+
+/* pred / truth / grad stored as `dtype` (loss value and metrics: fp32 device scalars) */
+int ss_loss_mse_const_t(int32_t dtype, const void* pred, int64_t count, float target, float grad_scale,
+                        float* loss_out, void* grad, void* ws, size_t ws_bytes, void* stream);
+int ss_loss_mae_t(int32_t dtype, const void* truth, const void* pred, int64_t count, float grad_scale,
+                  float* loss_out, void* grad, void* ws, size_t ws_bytes, void* stream);
+int ss_loss_weighted_bce_t(int32_t dtype, const void* truth, const void* pred, int64_t count, float weighting, float grad_scale,
+                           float* out3, void* grad, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * keras.optimizers.Adam as applied at CycleGAN.py:668-669,690-692 and by Model.fit for the UNet

@@ -113,6 +113,7 @@ struct GConvParams {
     int32_t ntaps;
     const unsigned int* h_amax;   // x3h (conv_mfma_x6.hip): bit pattern of max|input| -- nullptr: three-piece bf16 arithmetic
     const unsigned int* h_amax2;  //      ... of max|weights|
+    int32_t dtype;                // ss_dtype of `in` / `out` (the pointers are reinterpreted); only the tile kernels take 16-bit storage
     GTap taps[SS_MAX_TAPS];
 };
 
@@ -132,6 +133,7 @@ struct WGradParams {
     const unsigned int* h_amax;   // x3h: bit pattern of max|a| (one scale per operand tensor); nullptr: three-piece bf16 arithmetic
     const unsigned int* h_amax2;  //      ... of max|b|
     int64_t a_bs, b_bs;
+    int32_t dtype;                // ss_dtype of `a` / `b` (tile kernel only); partials and dw are fp32
     int32_t ntaps;
     GTap taps[SS_MAX_TAPS];       // woff = destination offset of the tap block inside dw
 };

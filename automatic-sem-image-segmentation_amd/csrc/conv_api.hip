@@ -17,6 +17,7 @@ struct ConvProb {
     unsigned int* x_amax = nullptr;
     unsigned int* dy_amax = nullptr;
     int x_valid = 0, dy_valid = 0;
+    int dtype = SS_DTYPE_F32;      // storage type of x / y / dy / dx: 16-bit only ever reaches the tile kernels (see ss_conv2d_fwd)
 };
 
 // ---- small helper kernels -----------------------------------------------------------------------
@@ -394,6 +395,7 @@ GConvParams fwd_params(const ConvProb& c, const float* x, const float* w, const 
     p.OH = c.oh; p.OW = c.ow; p.Cout = c.cout; p.out_cs = c.out_cs;
     p.out_s = 1; p.out_oy = 0; p.out_ox = 0;
     p.ldb = c.cout; p.reflect = c.reflect; p.act = act; p.alpha = alpha; p.accumulate = accumulate;
+    p.dtype = c.dtype;
     p.ntaps = 0;
     for (int a = 0; a < c.kh; ++a)
         for (int b = 0; b < c.kw; ++b) {
@@ -495,6 +497,7 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     p.in = dy; p.w = wt; p.bias = bias;
     p.N = c.n; p.IH = c.oh; p.IW = c.ow; p.Cin = c.cout; p.in_cs = c.out_cs;
     p.in_s = 1; p.Cout = c.cin; p.ldb = c.cin; p.reflect = 0; p.act = act; p.alpha = alpha;
+    p.dtype = c.dtype;
     if (need_dy_amax_dgrad(c, algo) && gws_bytes >= x6_planes_ub(c.cout, c.cin, T)) {
         unsigned int* sl = (unsigned int*)((char*)gws + x6_planes_ub(c.cout, c.cin, T) - 256);
         p.h_amax = act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl, s);
@@ -579,6 +582,7 @@ WGradParams wgrad_params(const ConvProb& c, const float* x, const float* dy, flo
     p.N = c.n; p.AH = c.ih; p.AW = c.iw; p.Ca = c.cin; p.a_cs = c.in_cs;
     p.GH = c.oh; p.GW = c.ow; p.Cb = c.cout; p.b_cs = c.out_cs;
     p.a_s = c.s; p.a_oy = -c.pt; p.a_ox = -c.pl; p.reflect = c.reflect;
+    p.dtype = c.dtype;
     p.ntaps = 0;
     for (int a = 0; a < c.kh; ++a)
         for (int b = 0; b < c.kw; ++b) {
@@ -590,7 +594,7 @@ WGradParams wgrad_params(const ConvProb& c, const float* x, const float* dy, flo
 // LDS-staged tile weight gradient (conv_tile.hip, fp32 MFMA): the shapes the 16-bit split kernel (wgrad_x6) does not take
 bool twgrad_takes(const ConvProb& c, int algo) {
     if (!(algo == SS_ALGO_AUTO || algo == SS_ALGO_X6) || c.kh * c.kw > SS_MAX_TAPS) return false;
-    const bool x6_shape = c.cin % 32 == 0 && c.cout >= 32 && c.cout % 4 == 0;
+    const bool x6_shape = c.dtype == SS_DTYPE_F32 && c.cin % 32 == 0 && c.cout >= 32 && c.cout % 4 == 0;
     return !x6_shape && ss_twgrad_ok(wgrad_params(c, nullptr, nullptr, nullptr));
 }
 
@@ -849,6 +853,48 @@ ConvShim make_shim(const ss_conv_desc* d, void* ws, size_t ws_bytes) {
     sh.ws_bytes = ws_bytes > sh.a_bytes + sh.b_bytes ? ws_bytes - sh.a_bytes - sh.b_bytes : 0;
     return sh;
 }
+// ---- native 16-bit paths: the LDS-staged tile kernels (conv_tile.hip) load / store bf16 / fp16 themselves --------------------------
+int native16_fwd(const ss_conv_desc* d, const void* x, const float* w, const float* bias, void* y, hipStream_t s, bool* taken) {
+    *taken = false;
+    if (d->transposed) return SS_OK;
+    ConvProb c = plain(d);
+    c.dtype = d->dtype;
+    if (!tconv_takes_fwd(c, d->algo)) return SS_OK;
+    *taken = true;
+    const GConvParams p = fwd_params(c, (const float*)x, w, bias, (float*)y, d->act, d->act_alpha, 0);
+    return ss_launch_tconv(p, nullptr, 0, s);
+}
+int native16_bwd_data(const ss_conv_desc* d, const void* dy, const float* w, void* dx, int accumulate, void* ws, size_t ws_bytes,
+                      hipStream_t s, bool* taken) {
+    *taken = false;
+    if (d->transposed) return SS_OK;
+    ConvProb c = plain(d);
+    c.dtype = d->dtype;
+    if (!tconv_takes_dgrad(c, d->algo) || !ws || ws_bytes < bwd_data_wt_bytes(c)) return SS_OK;
+    *taken = true;
+    float* wt = (float*)ws;
+    hipLaunchKernelGGL(transpose_last2_kernel, dim3((c.cout + 31) / 32, (c.cin + 31) / 32, c.kh * c.kw), dim3(256), 0, s, w, wt, c.cin, c.cout);
+    SS_LAUNCH_CHECK();
+    GConvParams p = dgrad_params_s1(c);
+    p.in = (const float*)dy; p.w = wt; p.out = (float*)dx; p.accumulate = accumulate; p.act = SS_ACT_NONE; p.dtype = d->dtype;
+    return ss_launch_tconv(p, nullptr, 0, s);
+}
+int native16_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate, void* ws,
+                        size_t ws_bytes, hipStream_t s, bool* taken) {
+    *taken = false;
+    if (d->transposed || dbias) return SS_OK;
+    ConvProb c = plain(d);
+    c.dtype = d->dtype;
+    if (!twgrad_takes(c, d->algo)) return SS_OK;
+    WGradParams p = wgrad_params(c, (const float*)x, (const float*)dy, (float*)ws);
+    p.splits = ss_twgrad_splits(p);
+    if (!ws || ws_bytes < (size_t)p.splits * p.ntaps * p.Ca * p.Cb * sizeof(float)) return SS_OK;
+    *taken = true;
+    int rc = ss_launch_twgrad_partials(p, s);
+    if (rc != SS_OK) return rc;
+    return ss_launch_wgrad_reduce(p, dw, c.cout, accumulate, p.ntaps * p.Ca, s);
+}
+
 bool valid_desc_any(const ss_conv_desc* d) {
     if (!d) { ss_set_error("ss_conv_desc is NULL"); return false; }
     if (d->struct_size != sizeof(ss_conv_desc)) return valid_desc(d);          // sets the message
@@ -867,7 +913,16 @@ size_t ss_conv2d_workspace_bytes(const ss_conv_desc* d, int pass) {
     if (!valid_desc_any(d)) return 0;
     if (d->dtype == SS_DTYPE_F32) return conv2d_workspace_bytes32(d, pass);
     const ConvShim sh = make_shim(d, nullptr, 0);
-    return sh.a_bytes + sh.b_bytes + conv2d_workspace_bytes32(&sh.d32, pass);
+    size_t need = sh.a_bytes + sh.b_bytes + conv2d_workspace_bytes32(&sh.d32, pass);
+    if (pass == SS_PASS_BWD_WEIGHT && !d->transposed) {        // native tile weight gradient: one fp32 partial per workgroup
+        ConvProb c = plain(d);
+        c.dtype = d->dtype;
+        if (twgrad_takes(c, d->algo)) {
+            const size_t tq = (size_t)ss_twgrad_splits(wgrad_params(c, nullptr, nullptr, nullptr)) * c.kh * c.kw * c.cin * c.cout * sizeof(float);
+            if (tq > need) need = tq;
+        }
+    }
+    return need;
 }
 
 int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass) {
@@ -882,8 +937,11 @@ int ss_conv2d_fwd(const ss_conv_desc* d, const void* x, const float* w, const fl
     if (!x || !w || !y) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_conv2d_workspace_bytes(d, SS_PASS_FWD)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    bool taken;
+    int rc = native16_fwd(d, x, w, bias, y, s, &taken);
+    if (taken) return rc;
     const ConvShim sh = make_shim(d, ws, ws_bytes);
-    int rc = ss_convert_launch(x, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, d->cin, (long)d->n * d->ih * d->iw, d->cin, s);
+    rc = ss_convert_launch(x, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, d->cin, (long)d->n * d->ih * d->iw, d->cin, s);
     if (rc != SS_OK) return rc;
     rc = conv2d_fwd32(&sh.d32, sh.a, w, bias, sh.b, sh.ws, sh.ws_bytes, stream);
     if (rc != SS_OK) return rc;
@@ -897,9 +955,12 @@ int ss_conv2d_bwd_data(const ss_conv_desc* d, const void* dy, const float* w, vo
     if (!dy || !w || !dx) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_conv2d_workspace_bytes(d, SS_PASS_BWD_DATA)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    bool taken;
+    int rc = native16_bwd_data(d, dy, w, dx, accumulate, ws, ws_bytes, s, &taken);
+    if (taken) return rc;
     const ConvShim sh = make_shim(d, ws, ws_bytes);
     const long xr = (long)d->n * d->ih * d->iw, yr = (long)d->n * d->oh * d->ow;
-    int rc = ss_convert_launch(dy, d->dtype, d->out_cstride, sh.b, SS_DTYPE_F32, d->cout, yr, d->cout, s);
+    rc = ss_convert_launch(dy, d->dtype, d->out_cstride, sh.b, SS_DTYPE_F32, d->cout, yr, d->cout, s);
     if (rc != SS_OK) return rc;
     if (accumulate) {
         rc = ss_convert_launch(dx, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, d->cin, xr, d->cin, s);
@@ -917,8 +978,11 @@ int ss_conv2d_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, f
     if (!x || !dy || !dw) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_conv2d_workspace_bytes(d, SS_PASS_BWD_WEIGHT)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    bool taken;
+    int rc = native16_bwd_weight(d, x, dy, dw, dbias, accumulate, ws, ws_bytes, s, &taken);
+    if (taken) return rc;
     const ConvShim sh = make_shim(d, ws, ws_bytes);
-    int rc = ss_convert_launch(x, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, d->cin, (long)d->n * d->ih * d->iw, d->cin, s);
+    rc = ss_convert_launch(x, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, d->cin, (long)d->n * d->ih * d->iw, d->cin, s);
     if (rc != SS_OK) return rc;
     rc = ss_convert_launch(dy, d->dtype, d->out_cstride, sh.b, SS_DTYPE_F32, d->cout, (long)d->n * d->oh * d->ow, d->cout, s);
     if (rc != SS_OK) return rc;

@@ -439,8 +439,10 @@ bool wtile_geom(const WGradParams& p, WTileGeom* g) {
     return g->wgs_per_cu >= 1;
 }
 
-template <int MBW, int NB>      // 32-row blocks per wave, 32-wide column blocks
+template <typename TI, int MBW, int NB>      // activation storage type; 32-row blocks per wave, 32-wide column blocks
 __global__ __launch_bounds__(T_THREADS, 2) void twgrad_kernel(WGradParams p, WTileGeom g) {
+    const TI* const ga = (const TI*)p.a;
+    const TI* const gb = (const TI*)p.b;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sA = (float*)smem;                                // [hh*hw][psa]
     float* sB = (float*)(smem + g.a_bytes);                  // [th*32][psb]
@@ -474,8 +476,8 @@ __global__ __launch_bounds__(T_THREADS, 2) void twgrad_kernel(WGradParams p, WTi
     const int ntiles = p.N * tiles_y * tiles_x;
     int first, stride, end;
     tile_walk(ntiles, first, stride, end);
-    const bool va = (p.Ca % 4 == 0) && (p.a_cs % 4 == 0) && ((((uintptr_t)p.a) & 15) == 0);
-    const bool vb = (p.Cb % 4 == 0) && (p.b_cs % 4 == 0) && ((((uintptr_t)p.b) & 15) == 0);
+    const bool va = (p.Ca % 4 == 0);         // whole 4-channel groups: one element-aligned wide access (see ld4)
+    const bool vb = (p.Cb % 4 == 0);
     const int a4 = g.psa / 4, b4 = g.psb / 4;
 
     for (int tile = first; tile < end; tile += stride) {
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(T_THREADS, 2) void twgrad_kernel(WGradParams p, WTi
         for (int hy = wave; hy < g.hh; hy += 4) {
             int iy = ss_map_index(gy0 + g.hy0 + hy, p.AH, p.reflect);
             if (iy >= p.AH) iy = -1;
-            const float* rowp = p.a + (long)(n * p.AH + (iy < 0 ? 0 : iy)) * p.AW * p.a_cs;
+            const TI* rowp = ga + (long)(n * p.AH + (iy < 0 ? 0 : iy)) * p.AW * p.a_cs;
             float* drow = sA + (long)hy * g.hw * g.psa;
             for (int e = lane; e < g.hw * a4; e += 64) {
                 const int hx = a4 == 1 ? e : (int)__umulhi((unsigned)e, g.m_a4), c = (e - hx * a4) * 4;
@@ -493,13 +495,13 @@ __global__ __launch_bounds__(T_THREADS, 2) void twgrad_kernel(WGradParams p, WTi
                 if (ix >= p.AW) ix = -1;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (iy >= 0 && ix >= 0 && c < p.Ca) {
-                    const float* src = rowp + (long)ix * p.a_cs + c;
-                    if (va) v = *(const f32x4*)src;
+                    const TI* src = rowp + (long)ix * p.a_cs + c;
+                    if (va) v = ld4(src);
                     else {
-                        v[0] = src[0];
-                        if (c + 1 < p.Ca) v[1] = src[1];
-                        if (c + 2 < p.Ca) v[2] = src[2];
-                        if (c + 3 < p.Ca) v[3] = src[3];
+                        v[0] = (float)src[0];
+                        if (c + 1 < p.Ca) v[1] = (float)src[1];
+                        if (c + 2 < p.Ca) v[2] = (float)src[2];
+                        if (c + 3 < p.Ca) v[3] = (float)src[3];
                     }
                 }
                 *(f32x4*)(drow + (long)hx * g.psa + c) = v;
@@ -507,20 +509,20 @@ __global__ __launch_bounds__(T_THREADS, 2) void twgrad_kernel(WGradParams p, WTi
         }
         for (int py = wave; py < g.th; py += 4) {
             const int gy = gy0 + py;
-            const float* rowp = p.b + (long)(n * p.GH + (gy < p.GH ? gy : 0)) * p.GW * p.b_cs;
+            const TI* rowp = gb + (long)(n * p.GH + (gy < p.GH ? gy : 0)) * p.GW * p.b_cs;
             float* drow = sB + (long)py * TW * g.psb;
             for (int e = lane; e < TW * b4; e += 64) {
                 const int px = b4 == 1 ? e : (int)__umulhi((unsigned)e, g.m_b4), c = (e - px * b4) * 4;
                 const int gx = gx0 + px;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (gy < p.GH && gx < p.GW && c < p.Cb) {          // pixels outside the grid contribute zero (b = 0)
-                    const float* src = rowp + (long)gx * p.b_cs + c;
-                    if (vb) v = *(const f32x4*)src;
+                    const TI* src = rowp + (long)gx * p.b_cs + c;
+                    if (vb) v = ld4(src);
                     else {
-                        v[0] = src[0];
-                        if (c + 1 < p.Cb) v[1] = src[1];
-                        if (c + 2 < p.Cb) v[2] = src[2];
-                        if (c + 3 < p.Cb) v[3] = src[3];
+                        v[0] = (float)src[0];
+                        if (c + 1 < p.Cb) v[1] = (float)src[1];
+                        if (c + 2 < p.Cb) v[2] = (float)src[2];
+                        if (c + 3 < p.Cb) v[3] = (float)src[3];
                     }
                 }
                 *(f32x4*)(drow + (long)px * g.psb + c) = v;
@@ -590,20 +592,29 @@ __global__ __launch_bounds__(T_THREADS, 2) void twgrad_kernel(WGradParams p, WTi
     }
 }
 
-template <int MBW, int NB>
-int launch_twgrad(const WGradParams& p, const WTileGeom& g, int nwg, hipStream_t s) {
+template <typename TI, int MBW, int NB>
+int launch_twgrad_t(const WGradParams& p, const WTileGeom& g, int nwg, hipStream_t s) {
     static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)twgrad_kernel<MBW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)twgrad_kernel<TI, MBW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
     char name[64];
     snprintf(name, sizeof(name), "twgrad_kernel<%d,%d>", MBW, NB);
     const double pix = (double)p.N * p.GH * p.GW;
-    SsProfScope prof(name, 2.0 * p.ntaps * p.Ca * p.Cb * pix, 4.0 * pix * (p.Ca + p.Cb), s);
-    hipLaunchKernelGGL((twgrad_kernel<MBW, NB>), dim3(nwg), dim3(T_THREADS), g.smem, s, p, g);
+    SsProfScope prof(name, 2.0 * p.ntaps * p.Ca * p.Cb * pix, (double)sizeof(TI) * pix * (p.Ca + p.Cb), s);
+    hipLaunchKernelGGL((twgrad_kernel<TI, MBW, NB>), dim3(nwg), dim3(T_THREADS), g.smem, s, p, g);
     SS_LAUNCH_CHECK();
     return SS_OK;
+}
+template <int MBW, int NB>
+int launch_twgrad(const WGradParams& p, const WTileGeom& g, int nwg, hipStream_t s) {
+    switch (p.dtype) {
+        case SS_DTYPE_F32: return launch_twgrad_t<float, MBW, NB>(p, g, nwg, s);
+        case SS_DTYPE_F16: return launch_twgrad_t<_Float16, MBW, NB>(p, g, nwg, s);
+        case SS_DTYPE_BF16: return launch_twgrad_t<__bf16, MBW, NB>(p, g, nwg, s);
+    }
+    return SS_ERR_INVALID;
 }
 
 int tile_nwg(int ntiles, int wgs_per_cu) {
@@ -659,7 +670,14 @@ int ss_launch_tconv(const GConvParams& p, void* ws, size_t ws_bytes, hipStream_t
     if (!tile_geom(p, &g)) return SS_ERR_UNSUPPORTED;
     const int tiles = p.N * ((p.OH + TH - 1) / TH) * ((p.OW + TW - 1) / TW);
     const int nwg = tile_nwg(tiles, g.wgs_per_cu);
-    return dispatch_tconv<float, float, 3>(p, g, nwg, s);
+    switch (p.dtype) {
+        case SS_DTYPE_F32: return dispatch_tconv<float, float, 3>(p, g, nwg, s);
+        // 16-bit stored activations: exactly representable as ONE fp16 piece under the tile scale (bf16's 8 significand bits fit
+        // fp16's 11), multiplied with the leading fp16 piece of the fp32 master weights: plain mixed precision, one product
+        case SS_DTYPE_F16: return dispatch_tconv<_Float16, _Float16, 1>(p, g, nwg, s);
+        case SS_DTYPE_BF16: return dispatch_tconv<__bf16, __bf16, 1>(p, g, nwg, s);
+    }
+    return SS_ERR_INVALID;
 }
 
 // ---- weight gradient --------------------------------------------------------------------------------------------------------------

@@ -106,8 +106,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--global-batch", type=int, default=8)
+    ap.add_argument("--config", type=int, default=4, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs: 4 (default, the headline: CycleGAN+UNet 512x512 global batch 8, fp32), 2 (UNet only, "
+                         "256x256 batch 16, bf16 storage), 3 (CycleGAN only, 256x256 batch 4), 5 (CycleGAN+UNet 1024x1024 batch 8, fp16 "
+                         "storage, checkpointed residual trunk)")
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--global-batch", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "f16"], help="activation storage type (weights / statistics / accumulation: fp32)")
+    ap.add_argument("--checkpoint", action="store_true", help="recompute the generators' residual blocks in backward")
     ap.add_argument("--filters", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cyclegan/unet split, the arithmetic-mode runs and the profile leg")
@@ -118,6 +124,16 @@ def main():
     ap.add_argument("--skip-unet", action="store_true", help="diagnostics only: time the CycleGAN step alone")
     ap.add_argument("--only-unet", action="store_true", help="diagnostics only: time the UNet step alone")
     args = ap.parse_args()
+    preset = {4: dict(size=512, gb=8, dtype="f32", ck=False, cg=True, un=True), 2: dict(size=256, gb=16, dtype="bf16", ck=False, cg=False, un=True),
+              3: dict(size=256, gb=4, dtype="f32", ck=False, cg=True, un=False), 5: dict(size=1024, gb=8, dtype="f16", ck=True, cg=True, un=True)}[args.config]
+    args.size = args.size or preset["size"]
+    args.global_batch = args.global_batch or preset["gb"]
+    args.dtype = args.dtype or preset["dtype"]
+    args.checkpoint = args.checkpoint or preset["ck"]
+    if not preset["cg"]:
+        args.only_unet = True
+    if not preset["un"]:
+        args.skip_unet = True
 
     D = importlib.import_module(PKG + ".dist")
     D.init_from_env()
@@ -141,11 +157,11 @@ def main():
     per = GB // world
 
     # networks exactly as CycleGAN.create_model / UNet.create_model build them for StartProcess.py's options
-    ga = NETS.ResnetGenerator(filters=F, device=dev, seed=1)
-    gb = NETS.ResnetGenerator(filters=F, device=dev, seed=2)
-    da = NETS.PatchDiscriminator(filters=2 * F, device=dev, seed=3)
-    db = NETS.PatchDiscriminator(filters=2 * F, device=dev, seed=4)
-    unet = NETS.MultiResUNet(16, device=dev, seed=5)
+    ga = NETS.ResnetGenerator(filters=F, device=dev, seed=1, act_dtype=args.dtype, checkpoint_blocks=args.checkpoint)
+    gb = NETS.ResnetGenerator(filters=F, device=dev, seed=2, act_dtype=args.dtype, checkpoint_blocks=args.checkpoint)
+    da = NETS.PatchDiscriminator(filters=2 * F, device=dev, seed=3, act_dtype=args.dtype)
+    db = NETS.PatchDiscriminator(filters=2 * F, device=dev, seed=4, act_dtype=args.dtype)
+    unet = NETS.MultiResUNet(16, device=dev, seed=5, act_dtype=args.dtype)
     D.broadcast_params([ga, gb, da, db, unet])
     D.enable_overlap([ga, gb, da, db, unet])     # bucketed gradient all-reduce launched during backward
     if world > 1:
@@ -245,19 +261,23 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = GB * args.steps / elapsed
         x6, x3h = L.config_get("x6"), L.config_get("x3h")
-        arith = ("f32 storage + f32 accumulate; contractions on the 16-bit matrix cores with fp32-grade operand splits: "
+        store = {"f32": "f32", "bf16": "bf16", "f16": "f16"}[args.dtype]
+        arith = (store + " activation storage" + ("" if store == "f32" else " (fp32 master weights, statistics and accumulation; "
+                 "convolutions outside the tile kernels staged through fp32)") + " + f32 accumulate; contractions on the 16-bit matrix cores with fp32-grade operand splits: "
                  + ("x3h = 2 fp16 pieces under power-of-two scales (per tile in the Winograd GEMMs, per tensor elsewhere), 3 products"
                     if x3h else "x6 = exact 3-piece bf16 split, 6 products")) if x6 else "f32 everywhere (v_mfma_f32_32x32x2_f32)"
-        out = {"metric": "train_step tiles/sec (CycleGAN+UNet)", "value": round(value, 4), "unit": "tiles/s",
+        what = "CycleGAN+UNet" if not (args.only_unet or args.skip_unet) else ("UNet" if args.only_unet else "CycleGAN")
+        out = {"metric": f"train_step tiles/sec ({what})", "value": round(value, 4), "unit": "tiles/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "median_ms_per_step": round(median_ms, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "f32" if not x6 else ("f32 via 2xf16 split (x3h)" if x3h else "f32 via 3xbf16 split (x6)"),
+               "dtype": (store + " storage, " if store != "f32" else "") + ("f32" if not x6 else ("f32 via 2xf16 split (x3h)" if x3h else "f32 via 3xbf16 split (x6)")),
                "arithmetic": arith, "data": "synthetic",
                "config": {"workload": f"CycleGAN(2xResNet-9 gen F={F} + 2xPatchGAN, image buffer 50) train_step + MultiResUNet(16) "
                                       f"train_step, {S}x{S} grayscale tiles, global batch {GB}" + (" [CycleGAN only]" if args.skip_unet else "")
                                       + (" [UNet only]" if args.only_unet else ""),
-                          "tile": S, "global_batch": GB, "per_gpu_batch": per, "parallelism": f"dp{world}"}}
+                          "tile": S, "global_batch": GB, "per_gpu_batch": per, "parallelism": f"dp{world}", "baseline_config": args.config,
+                          "activation_storage": store, "checkpointed_trunk": bool(args.checkpoint)}}
         out.update(extras)
         if prof:
             table = {}

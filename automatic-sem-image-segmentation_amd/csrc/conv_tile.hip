@@ -193,9 +193,10 @@ __global__ __launch_bounds__(T_THREADS, ((NBT == 1 && PF <= 4) ? 4 : 2)) void tc
     const int ntiles = p.N * tiles_y * tiles_x;
     int first, stride, end;
     tile_walk(ntiles, first, stride, end);
-    // a 4-wide window that straddles the end of a pixel's channels reads the next pixel's (valid memory, masked below) -- except on
-    // the very last pixel of the tensor, where the elements are fetched one by one
-    const long in_last = ((long)p.N * p.IH * p.IW - 1) * p.in_cs;
+    // a 4-wide window that straddles the end of a pixel's channels reads into the next pixel(s) (valid memory, masked below) -- except
+    // where it would run past the LAST element of the view (the last pixel; with fewer than 4 channels per pixel the last few
+    // pixels: a batch-1 input image ending on a page boundary faulted here), where the elements are fetched one by one
+    const long in_end = ((long)p.N * p.IH * p.IW - 1) * p.in_cs + p.Cin;
     const int hp = g.hh * g.hw;                              // halo pixels
     const int c4n = g.cg * 2;                                // float4 slots per pixel (padded channels)
     const int nslots = hp * c4n;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(T_THREADS, ((NBT == 1 && PF <= 4) ? 4 : 2)) void tc
             // (iy / ix >= size: far overhang of an edge tile under reflection: feeds no stored output)
             const bool ok = s_pk[i] >= 0 && iy >= 0 && ix >= 0 && iy < p.IH && ix < p.IW && c < p.Cin && !(g.dbg & 1);
             const long off = ((long)(n * p.IH + iy) * p.IW + ix) * p.in_cs;
-            const bool edge = ok && !(c + 4 <= p.Cin || off < in_last);
+            const bool edge = ok && off + c + 4 > in_end;
             ok_mask |= (ok && !edge) ? (1u << i) : 0u;
             edge_mask |= edge ? (1u << i) : 0u;
             pf[i] = ld4(gin + ((ok && !edge) ? off + c : 0L));

@@ -384,37 +384,74 @@ class CycleGanModel:
         return {nm: net.get_weights() for nm, net in (("gen_a", self.gen_a), ("gen_b", self.gen_b),
                                                       ("disc_a", self.disc_a), ("disc_b", self.disc_b))}
 
+    _NETS = ("gen_a", "gen_b", "disc_a", "disc_b")
+    _OPTS = dict(gen_a="gen_a_optimizer", gen_b="gen_b_optimizer", disc_a="disc_a_optimizer", disc_b="disc_b_optimizer")
+
+    def _config(self):
+        return dict(filters=self.gen_a.filters, nd=self.gen_a.nd, nr=self.gen_a.nr, nu=self.gen_a.nu,
+                    use_skip_connection=self.gen_a.use_skip_connection, use_resize_convolution=self.gen_a.use_resize_convolution,
+                    sigmoid_output_a=self.gen_a.sigmoid_output,
+                    disc_filters=self.disc_a.filters, disc_nd=self.disc_a.nd, gaussian_noise_value=self.disc_a.gaussian_noise_value,
+                    lambda_cycle_a=self.lambda_cycle_a, lambda_cycle_b=self.lambda_cycle_b,
+                    lambda_identity_a=self.lambda_identity_a, lambda_identity_b=self.lambda_identity_b)
+
     def save(self, path):
-        """Weights under their Keras variable names + the constructor configuration (``<path>.npz``; the
-        reference writes a ``.keras`` zip with HDF5 weights)."""
+        """``model.save('…/model.keras')`` (CycleGAN.py:203-204,221): a Keras-3 archive (zip of config.json, metadata.json and
+        model.weights.h5 with the four networks under gen_a/ gen_b/ disc_a/ disc_b/ and the four Adam states; keras_io.py).  A path
+        ending in ``.npz`` writes the plain-numpy form instead (variable names of this framework)."""
+        if path.endswith(".npz"):
+            arrays = {}
+            for nm in self._NETS:
+                net = getattr(self, nm)
+                for name, w in zip(net.variable_names, net.get_weights()):
+                    arrays[f"{nm}/{name}"] = w
+            arrays["__config__"] = np.array(json.dumps(self._config()))
+            np.savez(path, **arrays)
+            return
+        from . import keras_io as K
+        counters = K.NameCounters()
         arrays = {}
-        for nm, ws in self.get_weights().items():
-            net = getattr(self, nm)
-            for name, w in zip(net.variable_names, ws):
-                arrays[f"{nm}/{name}"] = w
-        cfg = dict(filters=self.gen_a.filters, nd=self.gen_a.nd, nr=self.gen_a.nr, nu=self.gen_a.nu,
-                   disc_filters=self.disc_a.filters, disc_nd=self.disc_a.nd,
-                   lambda_cycle_a=self.lambda_cycle_a, lambda_cycle_b=self.lambda_cycle_b,
-                   lambda_identity_a=self.lambda_identity_a, lambda_identity_b=self.lambda_identity_b)
-        arrays["__config__"] = np.array(json.dumps(cfg))
-        np.savez(path if path.endswith(".npz") else path + ".npz", **arrays)
+        for nm in self._NETS:
+            arrays.update(K.net_arrays(getattr(self, nm), nm + "/", counters))
+        for nm in self._NETS:
+            arrays.update(K.optimizer_arrays(getattr(self, self._OPTS[nm]), getattr(self, nm), self._OPTS[nm] + "/"))
+        K.write_archive(path, arrays, "CycleGanModel", self._config())
 
     @classmethod
     def load(cls, path, device=None):
-        """Counterpart of ``keras.models.load_model(.../model.keras)`` (CycleGAN.py:228-231)."""
-        z = np.load(path if path.endswith(".npz") else path + ".npz")
-        cfg = json.loads(str(z["__config__"]))
+        """Counterpart of ``keras.models.load_model(.../model.keras)`` (CycleGAN.py:228-231); restores the Adam states when the archive
+        holds them (the reference never resumes training, CycleGAN.py has no ``initial_epoch``)."""
         device = device if device is not None else D.local_device()
+        if path.endswith(".npz"):
+            z = np.load(path)
+            cfg = json.loads(str(z["__config__"]))
+            arrays = None
+        else:
+            from . import keras_io as K
+            _, cfg, arrays = K.read_archive(path)
         gk = dict(filters=cfg["filters"], num_downsampling_blocks=cfg["nd"], num_residual_blocks=cfg["nr"],
-                  num_upsample_blocks=cfg["nu"], device=device)
-        nets = dict(gen_a=ResnetGenerator(**gk), gen_b=ResnetGenerator(**gk),
-                    disc_a=PatchDiscriminator(filters=cfg["disc_filters"], num_downsampling_blocks=cfg["disc_nd"], device=device),
-                    disc_b=PatchDiscriminator(filters=cfg["disc_filters"], num_downsampling_blocks=cfg["disc_nd"], device=device))
-        for nm, net in nets.items():
-            net.set_weights([z[f"{nm}/{name}"] for name in net.variable_names])
-        return cls(nets["gen_a"], nets["gen_b"], nets["disc_a"], nets["disc_b"], lambda_cycle_a=cfg["lambda_cycle_a"],
-                   lambda_cycle_b=cfg["lambda_cycle_b"], lambda_identity_a=cfg["lambda_identity_a"],
-                   lambda_identity_b=cfg["lambda_identity_b"])
+                  num_upsample_blocks=cfg["nu"], device=device, use_skip_connection=cfg.get("use_skip_connection", False),
+                  use_resize_convolution=cfg.get("use_resize_convolution", False))
+        dk = dict(filters=cfg["disc_filters"], num_downsampling_blocks=cfg["disc_nd"], device=device,
+                  gaussian_noise_value=cfg.get("gaussian_noise_value", 0.0))
+        nets = dict(gen_a=ResnetGenerator(sigmoid_output=cfg.get("sigmoid_output_a", False), **gk), gen_b=ResnetGenerator(**gk),
+                    disc_a=PatchDiscriminator(**dk), disc_b=PatchDiscriminator(**dk))
+        model = cls(nets["gen_a"], nets["gen_b"], nets["disc_a"], nets["disc_b"], lambda_cycle_a=cfg["lambda_cycle_a"],
+                    lambda_cycle_b=cfg["lambda_cycle_b"], lambda_identity_a=cfg["lambda_identity_a"],
+                    lambda_identity_b=cfg["lambda_identity_b"])
+        model.use_binary_crossentropy_a = cfg.get("sigmoid_output_a", False)
+        if arrays is None:
+            for nm, net in nets.items():
+                net.set_weights([z[f"{nm}/{name}"] for name in net.variable_names])
+            return model
+        counters = K.NameCounters()
+        for nm in cls._NETS:
+            K.load_net_arrays(nets[nm], nm + "/", counters, arrays)
+        if any(k.startswith("gen_a_optimizer/") for k in arrays):
+            model.compile(Adam(2e-4, beta_1=0.5), Adam(2e-4, beta_1=0.5), Adam(2e-4, beta_1=0.5), Adam(2e-4, beta_1=0.5))
+            for nm in cls._NETS:
+                K.load_optimizer_arrays(getattr(model, cls._OPTS[nm]), nets[nm], cls._OPTS[nm] + "/", arrays)
+        return model
 
 
 class DataLoader:

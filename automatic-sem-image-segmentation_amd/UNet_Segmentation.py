@@ -172,18 +172,36 @@ class UNetModel:
         self.net.set_weights(w)
 
     def save(self, path):
-        arrays = {name: w for name, w in zip(self.net.variable_names, self.net.get_weights())}
-        arrays["__config__"] = np.array(json.dumps(dict(filters=self.net.filters, weighting=self.weighting)))
-        np.savez(path if path.endswith(".npz") else path + ".npz", **arrays)
+        """``model.save('…/model.keras')`` (UNet_Segmentation.py:262-264,287): Keras-3 archive (keras_io.py) with the network's layers
+        and the Adam state; ``.npz`` paths give the plain-numpy form."""
+        cfg = dict(filters=self.net.filters, weighting=self.weighting, learning_rate=float(self.optimizer.learning_rate))
+        if path.endswith(".npz"):
+            arrays = {name: w for name, w in zip(self.net.variable_names, self.net.get_weights())}
+            arrays["__config__"] = np.array(json.dumps(cfg))
+            np.savez(path, **arrays)
+            return
+        from . import keras_io as K
+        arrays = K.net_arrays(self.net, "", K.NameCounters())
+        arrays.update(K.optimizer_arrays(self.optimizer, self.net, "optimizer/"))
+        K.write_archive(path, arrays, "MultiResUNet", cfg)
 
     @classmethod
     def load(cls, path, device=None):
         """Counterpart of ``keras.models.load_model(.../model.keras, custom_objects={'weighted_bce': ...})`` (UNet_Segmentation.py:303)."""
-        z = np.load(path if path.endswith(".npz") else path + ".npz")
-        cfg = json.loads(str(z["__config__"]))
-        net = MultiResUNet(conv_filters=cfg["filters"], device=device if device is not None else D.local_device())
-        net.set_weights([z[name] for name in net.variable_names])
-        return cls(net, cfg.get("weighting", 1.0), Adam())
+        device = device if device is not None else D.local_device()
+        if path.endswith(".npz"):
+            z = np.load(path)
+            cfg = json.loads(str(z["__config__"]))
+            net = MultiResUNet(conv_filters=cfg["filters"], device=device)
+            net.set_weights([z[name] for name in net.variable_names])
+            return cls(net, cfg.get("weighting", 1.0), Adam(cfg.get("learning_rate", 1e-3)))
+        from . import keras_io as K
+        _, cfg, arrays = K.read_archive(path)
+        net = MultiResUNet(conv_filters=cfg["filters"], device=device)
+        K.load_net_arrays(net, "", K.NameCounters(), arrays)
+        model = cls(net, cfg.get("weighting", 1.0), Adam(cfg.get("learning_rate", 1e-3)))
+        K.load_optimizer_arrays(model.optimizer, net, "optimizer/", arrays)
+        return model
 
 
 class UNet:

@@ -38,7 +38,7 @@ def test_cyclegan_then_unet_workflow(tmp_path):
     cg.filters, cg.num_residual_blocks_gen = 4, 2
     model = cg.start_training()
     mdir = os.path.join(cg.model_dir, cg.prefix)
-    assert sorted(os.listdir(mdir)) == ["checkpoints_001.keras.npz", "checkpoints_002.keras.npz", "model.keras.npz", "training_log.csv"]
+    assert sorted(os.listdir(mdir)) == ["checkpoints_001.keras", "checkpoints_002.keras", "model.keras", "training_log.csv"]
     log = open(os.path.join(mdir, "training_log.csv")).read().strip().split("\n")
     assert log[0].split(";")[0] == "epoch" and len(log) == 3 and len(log[0].split(";")) == 15
     # per-epoch preview sheets (the reference's GANMonitor callback, CycleGAN.py:202,810-905): 2 rows x 4 panels, RGB uint8
@@ -69,7 +69,7 @@ def test_cyclegan_then_unet_workflow(tmp_path):
     un.contrast_optimization_range = (0.5, 99.5)
     umodel = un.run_training()
     udir = os.path.join(un.model_dir, un.prefix)
-    assert {"Checkpoint_Lowest_Loss.keras.npz", "model.keras.npz", "training_log.csv"} <= set(os.listdir(udir))
+    assert {"Checkpoint_Lowest_Loss.keras", "model.keras", "training_log.csv"} <= set(os.listdir(udir))
     hdr = open(os.path.join(udir, "training_log.csv")).read().split("\n")[0].split(";")
     assert hdr == ["epoch", "acc", "loss", "mae", "val_acc", "val_loss", "val_mae"]
 

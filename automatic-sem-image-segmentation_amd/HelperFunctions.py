@@ -128,6 +128,43 @@ def threshold_otsu(image):
     return float(centers[int(np.argmax(var12))])
 
 
+def threshold_li(image, tolerance=None):
+    """Li's iterative minimum cross-entropy threshold as skimage.filters.threshold_li (0.18) computes it -- the default
+    ``threshold_method`` of ``filter_gan_masks`` (HelperFunctions.py:163).  Pinned against scikit-image 0.18.3
+    (tests/golden/make_postproc_goldens.py)."""
+    image = np.asarray(image)
+    image = image[~np.isnan(image)] if image.dtype.kind == 'f' else image.ravel()
+    if image.size == 0:
+        return np.nan
+    if np.all(image == image.flat[0]):
+        return image.flat[0]
+    if np.any(np.isinf(image)):
+        return np.nan
+    image_min = np.min(image)
+    image = image - image_min
+    tolerance = tolerance or np.min(np.diff(np.unique(image))) / 2
+    t_next = np.mean(image)
+    t_curr = -2 * tolerance
+    if image.dtype.kind in 'iu':                 # integer images: the same iteration on the histogram
+        hist = np.bincount(image.ravel().astype(np.int64)).astype(float)
+        centers = np.arange(hist.size, dtype=float)
+        while abs(t_next - t_curr) > tolerance:
+            t_curr = t_next
+            fg = centers > t_curr
+            bg = ~fg
+            mean_fore = np.average(centers[fg], weights=hist[fg])
+            mean_back = np.average(centers[bg], weights=hist[bg])
+            t_next = (mean_back - mean_fore) / (np.log(mean_back) - np.log(mean_fore)) if mean_back != 0 else t_curr
+    else:
+        while abs(t_next - t_curr) > tolerance:
+            t_curr = t_next
+            fg = image > t_curr
+            mean_fore = np.mean(image[fg])
+            mean_back = np.mean(image[~fg])
+            t_next = (mean_back - mean_fore) / (np.log(mean_back) - np.log(mean_fore)) if mean_back != 0 else t_curr
+    return t_next + image_min
+
+
 _POST = None
 
 
@@ -260,3 +297,48 @@ def segment(image, threshold, watershed_lines, min_distance=9, use_four_connecti
     if use_four_connectivity:
         labels = eight_to_four_connected(labels)
     return labels
+
+
+def particles(mask):
+    """The particles ``Measurements.Measure`` works on (Measurements.py: ``cv2.findContours(RETR_EXTERNAL)`` + filled drawing): the
+    8-connected components of the mask with their holes filled.  Returns (label image of the filled particles, count).  OpenCV is
+    not installed in this image, so the contour polygons themselves are not restated: a particle is its filled pixel set (what
+    ``cv2.drawContours(thickness=-1)`` paints and ``pointPolygonTest >= 0`` selects, up to sub-pixel polygon-edge cases)."""
+    from scipy import ndimage
+    m = np.asarray(mask) > 0
+    lab, n = ndimage.label(m, structure=np.ones((3, 3)))
+    out = np.zeros(lab.shape, np.int32)
+    for i, sl in enumerate(ndimage.find_objects(lab), start=1):
+        if sl is None:
+            continue
+        comp = ndimage.binary_fill_holes(lab[sl] == i)
+        view = out[sl]
+        view[comp & (view == 0)] = i
+    return out, n
+
+
+def filter_gan_masks(img_path, msk_path, out_path, threshold_method=threshold_li, do_watershed_and_four_connectivity=True,
+                     gaussian_blur_amount=0.0, dark_background=True):
+    """Workflow step 5 (StartProcess.py:133-146; HelperFunctions.py:163-185): drop simulated particles the CycleGAN did not render.
+    For every generated image / mask pair: optionally re-segment the mask (Otsu, watershed lines, 4-connectivity), take each
+    particle's MEAN INTENSITY in the generated image (Measure.calculateMeanIntensities, Measurements.py:321-342) and keep the
+    particles whose mean is >= (dark background; <= otherwise) ``threshold_method(image)`` (Measure.filterResults('meanIntensity'),
+    Measurements.py:606-611); the kept particles are written filled (255) under the same file name; optional Gaussian blur of the
+    image in place (PIL radius = ``gaussian_blur_amount``)."""
+    from PIL import Image, ImageFilter
+    os.makedirs(out_path, exist_ok=True)
+    for f in sorted(os.listdir(img_path)):
+        img = np.array(Image.open(os.path.join(img_path, f)), dtype='uint8')
+        mask = np.array(Image.open(os.path.join(msk_path, f)), dtype='uint8')
+        if do_watershed_and_four_connectivity:
+            mask = segment(image=mask, threshold=-1, watershed_lines=True, use_four_connectivity=True)
+        lab, n = particles(mask)
+        thr = threshold_method(img)
+        keep = np.zeros(n + 1, bool)
+        if n:
+            from scipy import ndimage
+            means = ndimage.mean(img.astype(np.float64), labels=lab, index=np.arange(1, n + 1))
+            keep[1:] = (means >= thr) if dark_background else (means <= thr)
+        Image.fromarray((keep[lab] * 255).astype('uint8')).save(os.path.join(out_path, f))
+        if gaussian_blur_amount > 0:
+            Image.fromarray(img).filter(ImageFilter.GaussianBlur(gaussian_blur_amount)).save(os.path.join(img_path, f))

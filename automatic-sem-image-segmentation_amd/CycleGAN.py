@@ -144,6 +144,8 @@ class CycleGanModel:
         one = 1.0 - ls + ls / 2.0
         zero = ls / 2.0
         world = D.world_size()
+        for net in (ga, gb, da, db):        # weight-derived operands of the new weight version, before any concurrent chain starts
+            net.arena.refresh_derived()
 
         if (self.dual_stream and self.use_identity_loss and self.batch_generator_passes and not self.use_binary_crossentropy_a
                 and (self.dual_stream == "force" or not D.ranks_share_device())):

@@ -18,12 +18,27 @@ class _SizedDesc(ctypes.Structure):
         super().__init__(ctypes.sizeof(type(self)), dtype, *args, **kw)
 
 
+class WCacheEntry(ctypes.Structure):
+    _fields_ = [("tag", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("bytes", ctypes.c_uint64)]
+
+
+class WCache(ctypes.Structure):
+    """ss_wcache: host-side directory of one layer's weight-derived operands; `base` is a caller-owned device buffer."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("count", c_i32), ("fills", c_i32), ("fill_only", c_i32), ("base", c_vp),
+                ("bytes", ctypes.c_uint64), ("used", ctypes.c_uint64), ("entry", WCacheEntry * 32)]
+
+    def __init__(self, base=None, nbytes=0):
+        super().__init__(ctypes.sizeof(WCache), 0, 0, 0, base, nbytes, 0)
+
+
 class ConvDesc(_SizedDesc):
     _fields_ = [("struct_size", ctypes.c_uint32), ("dtype", c_i32)] + [(n, c_i32) for n in ("n", "ih", "iw", "cin", "in_cstride", "oh", "ow", "cout", "out_cstride",
                                      "kh", "kw", "stride", "pad_top", "pad_left", "pad_mode", "transposed", "act")] + \
                [("act_alpha", c_f32), ("algo", c_i32),
                 # optional x3h slots (include/semseg_hip.h): device uint32 with the bit pattern of max|x| / max|dy| + "already computed" flags
-                ("x_amax", c_vp), ("dy_amax", c_vp), ("x_amax_valid", c_i32), ("dy_amax_valid", c_i32)]
+                ("x_amax", c_vp), ("dy_amax", c_vp), ("x_amax_valid", c_i32), ("dy_amax_valid", c_i32),
+                # optional weight cache of the layer (ss_wcache: transformed / split weights kept across calls)
+                ("w_cache", c_vp)]
 
 
 class NormDesc(_SizedDesc):
@@ -81,6 +96,8 @@ SIGNATURES = {
     "ss_prof_get": (c_i32, [c_i32, ctypes.POINTER(ProfEntry)]),
     "ss_conv2d_workspace_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_uses_amax": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
+    "ss_conv2d_wcache_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
+    "ss_wcache_invalidate": (None, [ctypes.POINTER(WCache)]),
     "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_conv2d_bwd_data": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "ss_conv2d_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),

@@ -213,6 +213,27 @@ bool ss_wgrad_x6_ok(const WGradParams& p);
 int ss_launch_wgrad_x6_partials(const WGradParams& p, hipStream_t s);
 
 // Winograd F(2x2,3x3) path (conv_wino.hip): 3x3, stride 1; out[o] = sum_a in[map(o + a - pt)] * g[a]
+// Weight cache (ss_wcache, include/semseg_hip.h): tagged regions of weight-derived operands kept across calls.
+typedef ss_wcache WCache;
+enum { SS_WC_WINO_UBF = 1, SS_WC_WINO_X3H_INV, SS_WC_WINO_X3H_PLANES, SS_WC_WINO_X6_PLANES, SS_WC_WINO_U32, SS_WC_WAMAX, SS_WC_WT,
+       SS_WC_X6_PLANES };
+static inline uint64_t ss_wc_tag(int kind, uint64_t detail) { return (uint64_t)kind | (detail << 8); }
+// region of `n` bytes for the operand `tag`: the cached copy (*fill = false), a new cache entry (*fill = true) or, without a cache /
+// when it is full, `fallback` (*fill = true)
+static inline void* ss_wc_region(WCache* wc, uint64_t tag, size_t n, void* fallback, bool* fill) {
+    *fill = true;
+    if (!wc || !wc->base) return fallback;
+    for (int i = 0; i < wc->count; ++i)
+        if (wc->entry[i].tag == tag && wc->entry[i].bytes == n) { *fill = false; return (char*)wc->base + wc->entry[i].offset; }
+    const size_t na = ss_align_up(n, 256);
+    if (wc->count >= (int)(sizeof(wc->entry) / sizeof(wc->entry[0])) || wc->used + na > wc->bytes) return fallback;
+    ss_wcache_entry& e = wc->entry[wc->count++];
+    e.tag = tag; e.offset = wc->used; e.bytes = n;
+    wc->used += na;
+    wc->fills++;
+    return (char*)wc->base + e.offset;
+}
+
 struct WinoProb {
     int n, h, w, cin, in_cs;      // gathered input (reduction channels = cin)
     int oh, ow, cout, out_cs;     // output grid
@@ -221,6 +242,7 @@ struct WinoProb {
     int x6;                       // 1: forward / data-gradient GEMMs as fp32-exact 6-product bf16 contraction (conv_mfma_x6.hip)
     int fold_h, fold_w;           // > 0: the (oh, ow) grid is a shifted padded gradient that the output transform folds onto an
                                   // (fold_h x fold_w) tensor (reflect-pad data gradient, conv_wino.hip wino_output_kernel)
+    WCache* wc = nullptr;         // transformed weights are kept here across calls when set
 };
 
 // C[b][m][n] = sum_k (Ah+Al)[b][m][k] * (Bh+Bl)[b][n][k], bf16 planes, fp32 output (gemm_bf16x3.hip)

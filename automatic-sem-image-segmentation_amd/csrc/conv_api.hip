@@ -18,6 +18,7 @@ struct ConvProb {
     unsigned int* dy_amax = nullptr;
     int x_valid = 0, dy_valid = 0;
     int dtype = SS_DTYPE_F32;      // storage type of x / y / dy / dx: 16-bit only ever reaches the tile kernels (see ss_conv2d_fwd)
+    WCache* wc = nullptr;          // caller-owned cache of the weight-derived operands of this pass (ss_conv_desc::w_cache)
 };
 
 // ---- small helper kernels -----------------------------------------------------------------------
@@ -314,7 +315,10 @@ const unsigned int* act_amax(const float* v, long rows, int C, int cs, unsigned 
     }
     return slot;
 }
-const unsigned int* weight_amax(const float* w, long wn, unsigned int* scratch, hipStream_t s) {
+const unsigned int* weight_amax(const float* w, long wn, unsigned int* scratch, hipStream_t s, WCache* wc = nullptr) {
+    bool fill;
+    scratch = (unsigned int*)ss_wc_region(wc, ss_wc_tag(SS_WC_WAMAX, 0), 256, scratch, &fill);
+    if (!fill) return scratch;
     (void)hipMemsetAsync(scratch, 0, 4, s);
     hipLaunchKernelGGL(amax_view_kernel, dim3(wn / 8192 < 16 ? 16 : (wn / 8192 > 256 ? 256 : (unsigned)(wn / 8192))), dim3(256), 0, s, w, 1L, (int)wn, (int)wn, scratch);
     return scratch;
@@ -348,7 +352,23 @@ size_t gconv_ws_bytes(int algo, const GConvParams& p) {
     return two_stage_ws(p.N, p.IH, p.IW, p.Cin, p.Cout, p.ntaps);
 }
 
-int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStream_t s) {
+// identity of the weight planes wprep_x6 derives for `p` (within one layer: which taps, in which order, from which source array)
+uint64_t x6_planes_detail(const GConvParams& p, int wsrc) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    mix((uint64_t)wsrc); mix((uint64_t)p.ntaps); mix((uint64_t)p.Cin); mix((uint64_t)p.Cout); mix((uint64_t)p.ldb); mix(p.h_amax ? 1 : 0);
+    mix((uint64_t)(p.nbatch > 1 ? p.nbatch : 1)); mix((uint64_t)p.w_bs);
+    for (int i = 0; i < p.ntaps; ++i) mix((uint64_t)(uint32_t)p.taps[i].woff);
+    return h >> 8;
+}
+
+// wsrc: 0 = p.w is the layer's weight array, 1 = its tap-wise transpose (conv_bwd_data) -- part of the cache identity of the planes
+int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStream_t s, WCache* wc = nullptr, int wsrc = 0) {
+    if (wc && wc->fill_only) {            // refresh of cached operands: only the split-plane path keeps any
+        const bool c1 = algo != SS_ALGO_DIRECT && algo != SS_ALGO_MFMA && (ss_conv_out1_ok(p) || ss_conv_in1_ok(p));
+        if (c1 || (tconv_takes(algo, p) && ws && ws_bytes >= ss_tconv_ws(p)) || gconv_two_stage(algo, p)) return SS_OK;
+        if (!(use_x6(algo, p) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p))) return SS_OK;
+    }
     if (algo != SS_ALGO_DIRECT && algo != SS_ALGO_MFMA) {        // full-resolution 7x7 stem / head shapes: LDS-tiled VALU kernels
         if (ss_conv_out1_ok(p)) return ss_launch_conv_out1(p, s);
         if (ss_conv_in1_ok(p)) return ss_launch_conv_in1(p, s);
@@ -378,9 +398,14 @@ int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStre
         return SS_OK;
     }
     if (use_x6(algo, p) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p)) {
-        int rc = ss_launch_wprep_x6(p, (unsigned short*)ws, s);
-        if (rc != SS_OK) return rc;
-        return ss_launch_gconv_x6(p, (const unsigned short*)ws, s);
+        bool fill;
+        unsigned short* planes = (unsigned short*)ss_wc_region(wc, ss_wc_tag(SS_WC_X6_PLANES, x6_planes_detail(p, wsrc)), ss_gconv_x6_planes_bytes(p), ws, &fill);
+        if (fill) {
+            int rc = ss_launch_wprep_x6(p, planes, s);
+            if (rc != SS_OK) return rc;
+        }
+        if (wc && wc->fill_only) return SS_OK;
+        return ss_launch_gconv_x6(p, planes, s);
     }
     return use_mfma(algo, p) ? ss_launch_gconv_mfma(p, s) : ss_launch_gconv_direct(p, s);
 }
@@ -439,18 +464,21 @@ int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bia
              int accumulate, int algo, void* ws, size_t ws_bytes, hipStream_t s) {
     if (c.kh * c.kw > SS_MAX_TAPS) return SS_ERR_UNSUPPORTED;
     WinoProb q;
-    if (wino_fwd_prob(c, algo, &q))
+    if (wino_fwd_prob(c, algo, &q)) {
+        q.wc = c.wc;
         return ss_wino_conv_fwd(q, x, w, c.cin, c.cout, 0, bias, y, act, alpha, accumulate, ws, ws_bytes, s);
+    }
     GConvParams p = fwd_params(c, x, w, bias, y, act, alpha, accumulate);
     if (need_x_amax_fwd(c, algo) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p) + 256) {
         unsigned int* sl = (unsigned int*)((char*)ws + ss_gconv_x6_planes_bytes(p));
-        const unsigned int* ax = act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
+        const bool fill_only = c.wc && c.wc->fill_only;
+        const unsigned int* ax = fill_only ? sl : act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
         if (use_x6(algo, p)) {
             p.h_amax = ax;
-            p.h_amax2 = weight_amax(w, (long)c.kh * c.kw * c.cin * c.cout, sl + 1, s);
+            p.h_amax2 = weight_amax(w, (long)c.kh * c.kw * c.cin * c.cout, sl + 1, s, c.wc);
         }
     }
-    return run_gconv(algo, p, ws, ws_bytes, s);
+    return run_gconv(algo, p, ws, ws_bytes, s, c.wc);
 }
 
 size_t bwd_data_wt_bytes(const ConvProb& c) { return ss_align_up((size_t)c.kh * c.kw * c.cin * c.cout * sizeof(float), 256); }
@@ -482,16 +510,23 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     {
         WinoProb q;
         if (wino_dgrad_prob(c, algo, &q)) {      // rotated + transposed weights are formed inside the weight transform
+            q.wc = c.wc;
             if (!c.reflect || q.fold_h > 0)
                 return ss_wino_conv_fwd(q, dy, w, c.cin, c.cout, 1, bias, dx, act, alpha, accumulate, gws, gws_bytes, s);
             float* dpad = (float*)((char*)ws + bwd_data_wt_bytes(c));
             int rc = ss_wino_conv_fwd(q, dy, w, c.cin, c.cout, 1, nullptr, dpad, SS_ACT_NONE, 0.f, 0, gws, gws_bytes, s);
-            if (rc != SS_OK) return rc;
+            if (rc != SS_OK || (c.wc && c.wc->fill_only)) return rc;
             return launch_reflect_fold(dpad, dx, c.n, c.ih, c.iw, c.cin, c.in_cs, c.pt, c.pl, c.oh + 2, c.ow + 2, accumulate, s);
         }
     }
-    hipLaunchKernelGGL(transpose_last2_kernel, dim3((c.cout + 31) / 32, (c.cin + 31) / 32, T), dim3(256), 0, s, w, wt, c.cin, c.cout);
-    SS_LAUNCH_CHECK();
+    {
+        bool fill;
+        wt = (float*)ss_wc_region(c.wc, ss_wc_tag(SS_WC_WT, 0), bwd_data_wt_bytes(c), wt, &fill);
+        if (fill) {
+            hipLaunchKernelGGL(transpose_last2_kernel, dim3((c.cout + 31) / 32, (c.cin + 31) / 32, T), dim3(256), 0, s, w, wt, c.cin, c.cout);
+            SS_LAUNCH_CHECK();
+        }
+    }
 
     GConvParams p{};
     p.in = dy; p.w = wt; p.bias = bias;
@@ -500,8 +535,8 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     p.dtype = c.dtype;
     if (need_dy_amax_dgrad(c, algo) && gws_bytes >= x6_planes_ub(c.cout, c.cin, T)) {
         unsigned int* sl = (unsigned int*)((char*)gws + x6_planes_ub(c.cout, c.cin, T) - 256);
-        p.h_amax = act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl, s);
-        p.h_amax2 = weight_amax(w, (long)T * c.cin * c.cout, sl + 1, s);
+        p.h_amax = (c.wc && c.wc->fill_only) ? sl : act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl, s);
+        p.h_amax2 = weight_amax(w, (long)T * c.cin * c.cout, sl + 1, s, c.wc);
     }
 
     if (c.reflect) {
@@ -515,8 +550,8 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
                 GTap& t = p.taps[p.ntaps++];
                 t.dy = (int16_t)(-a); t.dx = (int16_t)(-b); t.woff = (a * c.kw + b) * c.cin * c.cout;
             }
-        int rc = run_gconv(algo, p, gws, gws_bytes, s);
-        if (rc != SS_OK) return rc;
+        int rc = run_gconv(algo, p, gws, gws_bytes, s, c.wc, 1);
+        if (rc != SS_OK || (c.wc && c.wc->fill_only)) return rc;
         return launch_reflect_fold(dpad, dx, c.n, c.ih, c.iw, c.cin, c.in_cs, c.pt, c.pl, PH, PW, accumulate, s);
     }
 
@@ -539,7 +574,7 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
                     t.woff = (a * c.kw + b) * c.cin * c.cout;
                 }
             }
-            int rc = run_gconv(algo, p, gws, gws_bytes, s);
+            int rc = run_gconv(algo, p, gws, gws_bytes, s, c.wc, 1);
             if (rc != SS_OK) return rc;
         }
     return SS_OK;
@@ -747,6 +782,12 @@ extern "C" {
 
 int ss_version(void) { return 100; }
 
+void ss_wcache_invalidate(ss_wcache* wc) {
+    if (!wc) return;
+    wc->count = 0;
+    wc->used = 0;
+}
+
 const char* ss_status_string(int status) {
     switch (status) {
         case SS_OK: return "ok";
@@ -790,21 +831,63 @@ int conv2d_uses_amax32(const ss_conv_desc* d, int pass) {
     return ((roles & 1) ? 2 : 0) | ((roles & 2) ? 1 : 0);
 }
 
+// upper bound of what conv_fwd keeps of the weights of `c`
+size_t fwd_wcache(const ConvProb& c, int algo) {
+    if (c.kh * c.kw > SS_MAX_TAPS) return 0;
+    WinoProb q;
+    if (wino_fwd_prob(c, algo, &q)) {
+        const int R = ss_tuning().wino_r, XI = (R + 2) * (R + 2);
+        const size_t planes = ss_align_up((size_t)3 * XI * ss_x6_npad(q.cout) * q.cin * 2, 256), u = ss_align_up((size_t)XI * q.cin * q.cout * 4, 256);
+        return 256 + (planes > u ? planes : u);
+    }
+    const size_t xq = x6_planes_ub(c.cin, c.cout, c.kh * c.kw);
+    return xq ? xq + 256 : 0;
+}
+// ... conv_bwd_data: transposed weights, then (Winograd) transformed planes or one plane set per output phase of a strided conv
+size_t bwd_data_wcache(const ConvProb& c, int algo) {
+    if (c.kh * c.kw > SS_MAX_TAPS || (c.reflect && c.s != 1)) return 0;
+    WinoProb q;
+    if (wino_dgrad_prob(c, algo, &q)) {
+        const int R = ss_tuning().wino_r, XI = (R + 2) * (R + 2);
+        const size_t planes = ss_align_up((size_t)3 * XI * ss_x6_npad(q.cout) * q.cin * 2, 256), u = ss_align_up((size_t)XI * q.cin * q.cout * 4, 256);
+        return 256 + (planes > u ? planes : u);
+    }
+    const size_t xq = x6_planes_ub(c.cout, c.cin, c.kh * c.kw);
+    return bwd_data_wt_bytes(c) + 256 + xq + (size_t)256 * c.s * c.s;
+}
+size_t conv2d_wcache_bytes32(const ss_conv_desc* d, int pass) {
+    if (!valid_desc(d) || pass == SS_PASS_BWD_WEIGHT) return 0;
+    const bool fwd_like = (pass == SS_PASS_FWD) != (d->transposed != 0);
+    const ConvProb c = d->transposed ? adjoint(d) : plain(d);
+    return fwd_like ? fwd_wcache(c, d->algo) : bwd_data_wcache(c, d->algo);
+}
+// the layer's weight cache when the descriptor carries a usable one
+WCache* desc_wcache(const ss_conv_desc* d) {
+    ss_wcache* wc = d->w_cache;
+    return wc && wc->struct_size == sizeof(ss_wcache) && wc->base && wc->count >= 0 ? wc : nullptr;
+}
+
 int conv2d_fwd32(const ss_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                   void* ws, size_t ws_bytes, void* stream) {
-    if (!valid_desc(d) || !x || !w || !y) return SS_ERR_INVALID;
+    const bool fill_only = desc_wcache(d) && desc_wcache(d)->fill_only;
+    if (!valid_desc(d) || !w || (!fill_only && (!x || !y))) return SS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (!d->transposed) return conv_fwd(plain(d), x, w, bias, y, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
-    return conv_bwd_data(adjoint(d), x, w, y, bias, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
+    ConvProb c = d->transposed ? adjoint(d) : plain(d);
+    c.wc = desc_wcache(d);
+    if (!d->transposed) return conv_fwd(c, x, w, bias, y, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
+    return conv_bwd_data(c, x, w, y, bias, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
 }
 
 int conv2d_bwd_data32(const ss_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
                        void* ws, size_t ws_bytes, void* stream) {
-    if (!valid_desc(d) || !dy || !w || !dx) return SS_ERR_INVALID;
+    const bool fill_only = desc_wcache(d) && desc_wcache(d)->fill_only;
+    if (!valid_desc(d) || !w || (!fill_only && (!dy || !dx))) return SS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    ConvProb c = d->transposed ? adjoint(d) : plain(d);
+    c.wc = desc_wcache(d);
     if (!d->transposed)
-        return conv_bwd_data(plain(d), dy, w, dx, nullptr, SS_ACT_NONE, 0.f, accumulate, d->algo, ws, ws_bytes, s);
-    return conv_fwd(adjoint(d), dy, w, nullptr, dx, SS_ACT_NONE, 0.f, accumulate, d->algo, ws, ws_bytes, s);
+        return conv_bwd_data(c, dy, w, dx, nullptr, SS_ACT_NONE, 0.f, accumulate, d->algo, ws, ws_bytes, s);
+    return conv_fwd(c, dy, w, nullptr, dx, SS_ACT_NONE, 0.f, accumulate, d->algo, ws, ws_bytes, s);
 }
 
 int conv2d_bwd_weight32(const ss_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
@@ -925,6 +1008,13 @@ size_t ss_conv2d_workspace_bytes(const ss_conv_desc* d, int pass) {
     return need;
 }
 
+size_t ss_conv2d_wcache_bytes(const ss_conv_desc* d, int pass) {
+    if (!valid_desc_any(d)) return 0;
+    if (d->dtype == SS_DTYPE_F32) return conv2d_wcache_bytes32(d, pass);
+    const ConvShim sh = make_shim(d, nullptr, 0);           // 16-bit storage: the staged fp32 problem has the same weights
+    return conv2d_wcache_bytes32(&sh.d32, pass);
+}
+
 int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass) {
     if (!valid_desc_any(d) || d->dtype != SS_DTYPE_F32) return 0;
     return conv2d_uses_amax32(d, pass);
@@ -934,9 +1024,17 @@ int ss_conv2d_fwd(const ss_conv_desc* d, const void* x, const float* w, const fl
                   void* ws, size_t ws_bytes, void* stream) {
     if (!valid_desc_any(d)) return SS_ERR_INVALID;
     if (d->dtype == SS_DTYPE_F32) return conv2d_fwd32(d, (const float*)x, w, bias, (float*)y, ws, ws_bytes, stream);
-    if (!x || !w || !y) return SS_ERR_INVALID;
+    const bool fill_only = desc_wcache(d) && desc_wcache(d)->fill_only;
+    if (!w || (!fill_only && (!x || !y))) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_conv2d_workspace_bytes(d, SS_PASS_FWD)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    if (fill_only) {           // refresh of the layer's cached weight operands: those of the staged fp32 problem (the tile kernels keep none)
+        ConvProb c = plain(d);
+        c.dtype = d->dtype;
+        if (!d->transposed && tconv_takes_fwd(c, d->algo)) return SS_OK;
+        const ConvShim sh = make_shim(d, ws, ws_bytes);
+        return conv2d_fwd32(&sh.d32, nullptr, w, bias, nullptr, sh.ws, sh.ws_bytes, stream);
+    }
     bool taken;
     int rc = native16_fwd(d, x, w, bias, y, s, &taken);
     if (taken) return rc;
@@ -952,9 +1050,17 @@ int ss_conv2d_bwd_data(const ss_conv_desc* d, const void* dy, const float* w, vo
                        void* ws, size_t ws_bytes, void* stream) {
     if (!valid_desc_any(d)) return SS_ERR_INVALID;
     if (d->dtype == SS_DTYPE_F32) return conv2d_bwd_data32(d, (const float*)dy, w, (float*)dx, accumulate, ws, ws_bytes, stream);
-    if (!dy || !w || !dx) return SS_ERR_INVALID;
+    const bool fill_only = desc_wcache(d) && desc_wcache(d)->fill_only;
+    if (!w || (!fill_only && (!dy || !dx))) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_conv2d_workspace_bytes(d, SS_PASS_BWD_DATA)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    if (fill_only) {
+        ConvProb c = plain(d);
+        c.dtype = d->dtype;
+        if (!d->transposed && tconv_takes_dgrad(c, d->algo)) return SS_OK;
+        const ConvShim sh = make_shim(d, ws, ws_bytes);
+        return conv2d_bwd_data32(&sh.d32, nullptr, w, nullptr, accumulate, sh.ws, sh.ws_bytes, stream);
+    }
     bool taken;
     int rc = native16_bwd_data(d, dy, w, dx, accumulate, ws, ws_bytes, s, &taken);
     if (taken) return rc;

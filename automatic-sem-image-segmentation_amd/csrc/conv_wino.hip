@@ -579,9 +579,16 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     float* U = (float*)ws;
     float* V = (float*)((char*)ws + ss_align_up((size_t)XI * q.cin * q.cout * 4, 256));
     float* Mx = (float*)((char*)V + ss_align_up((size_t)XI * tiles * q.cin * 4, 256));
+    bool fill;      // transformed weights: in the layer's cache when there is one (computed on first use)
+    const uint64_t wdet = (uint64_t)(flip ? 1 : 0) | ((uint64_t)R << 1);
+    const bool fill_only = q.wc && q.wc->fill_only;       // refresh of the cached operands: no activation work
     if (q.bf16x3) {
-        hipLaunchKernelGGL((wino_weight_kernel<R, true>), dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, w, w_cin, w_cout, flip, U);
-        SS_LAUNCH_CHECK();
+        U = (float*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_UBF, wdet), (size_t)XI * q.cin * q.cout * 4, U, &fill);
+        if (fill) {
+            hipLaunchKernelGGL((wino_weight_kernel<R, true>), dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, w, w_cin, w_cout, flip, U);
+            SS_LAUNCH_CHECK();
+        }
+        if (fill_only) return SS_OK;
         hipLaunchKernelGGL((wino_input_kernel<R, true>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
                            TH, TW, q.pt, q.pl, q.reflect, V);
         SS_LAUNCH_CHECK();
@@ -612,20 +619,29 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         float* w_inv = nullptr;
         if (x3h) {
             char* extra = (char*)planes + ss_align_up((size_t)3 * XI * Npad * q.cin * 2, 256);
-            w_inv = (float*)extra;                               // [0]: 1/s_w, [1]: max|w| bits
             tile_inv = (float*)(extra + 256);
+            w_inv = (float*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X3H_INV, wdet), 256, extra, &fill);                              // [0]: 1/s_w, [1]: max|w| bits
+            bool fill2;
+            planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X3H_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill2);
+            if (fill || fill2) {
             (void)hipMemsetAsync(w_inv + 1, 0, 4, s);
             hipLaunchKernelGGL(amax_bits_kernel, dim3(256), dim3(256), 0, s, w, (long)9 * w_cin * w_cout, (unsigned int*)(w_inv + 1));
             SS_LAUNCH_CHECK();
             hipLaunchKernelGGL((wino_weight_x6_kernel<R, true>), dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes,
                                (const unsigned int*)(w_inv + 1), w_inv);
             SS_LAUNCH_CHECK();
+            }
+            if (fill_only) return SS_OK;
             hipLaunchKernelGGL((wino_input_kernel<R, 3>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
                                TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
             SS_LAUNCH_CHECK();
         } else {
-        hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
-        SS_LAUNCH_CHECK();
+        planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X6_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill);
+        if (fill) {
+            hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
+            SS_LAUNCH_CHECK();
+        }
+        if (fill_only) return SS_OK;
         hipLaunchKernelGGL((wino_input_kernel<R, 2>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
                            TH, TW, q.pt, q.pl, q.reflect, V, Mpad);
         SS_LAUNCH_CHECK();
@@ -645,9 +661,11 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
-    hipLaunchKernelGGL((wino_input_kernel<R, false>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
-                       q.pt, q.pl, q.reflect, V);
-    SS_LAUNCH_CHECK();
+    if (!fill_only) {
+        hipLaunchKernelGGL((wino_input_kernel<R, false>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
+                           q.pt, q.pl, q.reflect, V);
+        SS_LAUNCH_CHECK();
+    }
     GConvParams g{};
     g.in = V; g.w = U; g.bias = nullptr; g.out = Mx;
     g.N = 1; g.IH = 1; g.IW = (int)tiles; g.Cin = q.cin; g.in_cs = q.cin;
@@ -660,12 +678,21 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     if (q.x6 && ss_gconv_x6_ok(g)) {     // fp32-exact GEMMs on the bf16 matrix cores: the weight transform emits the B planes
         unsigned short* planes = (unsigned short*)((char*)Mx + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
         const int Npad = ss_x6_npad(q.cout);
-        hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
-        SS_LAUNCH_CHECK();
+        planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X6_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill);
+        if (fill) {
+            hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
+            SS_LAUNCH_CHECK();
+        }
+        if (fill_only) return SS_OK;
         rc = ss_launch_gconv_x6(g, planes, s);
     } else {
-        hipLaunchKernelGGL((wino_weight_kernel<R, false>), dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, w, w_cin, w_cout, flip, U);
-        SS_LAUNCH_CHECK();
+        U = (float*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_U32, wdet), (size_t)XI * q.cin * q.cout * 4, U, &fill);
+        g.w = U;
+        if (fill) {
+            hipLaunchKernelGGL((wino_weight_kernel<R, false>), dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, w, w_cin, w_cout, flip, U);
+            SS_LAUNCH_CHECK();
+        }
+        if (fill_only) return SS_OK;
         rc = ss_launch_gconv_mfma(g, s);
     }
     if (rc != SS_OK) return rc;

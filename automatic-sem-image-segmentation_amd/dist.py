@@ -123,6 +123,7 @@ def broadcast_params(nets, src=0):
     for net in nets:
         dist.broadcast(net.arena.params, src)
         dist.broadcast(net.arena.state, src)
+        getattr(net.arena, "touch", lambda: None)()      # derived-operand caches (layers.Conv2D) are stale now
 
 
 def mean_scalars(values):

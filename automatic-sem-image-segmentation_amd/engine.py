@@ -235,6 +235,36 @@ class ParamArena:
         self.bucket_of = {}
         self.grad_hook = None      # callable(flat_grad_slice) -> async work handle, set by dist.enable_overlap()
         self.works = []
+        self.version = 0           # bumped by every writer of `params` that torch's version counter does not see (HIP kernels)
+        self.derived = []          # layers that keep operands derived from the weights (layers.Conv2D weight caches)
+        self._derived_key = None
+
+    def touch(self):
+        """The weight values changed behind torch's back (optimizer kernel, collective): caches derived from them are stale."""
+        self.version += 1
+
+    def refresh_derived(self):
+        """Recompute, on the CURRENT stream, what the layers keep of the previous weight version (no-op while the weights are
+        unchanged).  A step that runs concurrent kernel chains calls this before forking: otherwise the chain that reaches a
+        layer second has to wait for the first one's (much later) fill."""
+        if self.params is None:
+            return
+        from . import _lib as L
+        key = (self.weights_key(), L.CONFIG_EPOCH)
+        if key == self._derived_key:
+            return
+        self._derived_key = key
+        sync = dict(ev=None, synced=set())
+        n = sum(layer.refresh_wcache(sync) for layer in self.derived)
+        if n:
+            ev = torch.cuda.Event()
+            ev.record()
+            sync["ev"] = ev
+            sync["synced"].add(_stream().value or 0)
+
+    def weights_key(self):
+        """Changes whenever the trainable values may have changed: explicit touch() or any in-place torch op on a view of them."""
+        return (self.version, self.params._version)
 
     def declare(self, name, shape, trainable=True):
         size = 1

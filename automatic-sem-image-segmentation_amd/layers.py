@@ -5,11 +5,14 @@ UNet_Segmentation.py:401-562) with the fusions chosen for MI355X: reflection pad
 gather, activation and residual add live in the norm apply pass, bias+activation in the conv epilogue.
 """
 import ctypes
+import os
 
 import torch
 
 from . import _lib as L
 from .engine import TIMER, Act, _p, _stream, workspace
+
+WEIGHT_CACHE = os.environ.get("SS_WEIGHT_CACHE", "1") != "0"      # 0: every pass derives its weight operands itself (measurement)
 
 # Cross-rank BatchNorm statistics (data parallel): set by dist.enable_sync_bn() to a callable that all-reduces (SUM) a
 # float32 device tensor in place and returns the world size.  None = per-process statistics (single GPU).
@@ -42,6 +45,8 @@ class Conv2D:
             arena.declare(f"{name}/bias", (cout,))
         self._desc_cache = {}
         self._amax_cache = {}
+        self._wc = None             # weight cache of this layer (ss_wcache + device buffer), see _attach_wcache
+        arena.derived.append(self)
         self.profile_tag = None     # set by bench.py to time this layer's forward launch with HIP events
 
     def out_hw(self, h, w):
@@ -95,8 +100,10 @@ class Conv2D:
         else:
             d.x_amax, d.x_amax_valid = None, 0
         d.dy_amax, d.dy_amax_valid = None, 0
+        wst = self._attach_wcache(d, L.PASS_FWD)
         L.check(lib.ss_conv2d_fwd(ctypes.byref(d), x.ptr, _p(w), _p(b), y.ptr, _p(ws), ws.numel(), _stream()),
                 f"conv2d_fwd[{self.name}]")
+        self._wcache_done(wst)
         if uses & 1:
             x.amax_valid = True
         if e0 is not None:
@@ -140,13 +147,90 @@ class Conv2D:
                 uses = self._uses_amax(ddx, L.PASS_BWD_DATA)
                 ddx.x_amax, ddx.x_amax_valid = None, 0
                 ddx.dy_amax, ddx.dy_amax_valid = (dy.amax_slot(), 1 if dy.amax_valid else 0) if uses & 2 else (None, 0)
+                wst = self._attach_wcache(ddx, L.PASS_BWD_DATA)
                 L.check(lib.ss_conv2d_bwd_data(ctypes.byref(ddx), dy.ptr, _p(w), dx.ptr, accum, _p(wsd), wsd.numel(),
                                                _stream()), f"conv2d_bwd_data[{self.name}]")
+                self._wcache_done(wst)
                 if uses & 2:
                     dy.amax_valid = True
 
         tape.record(backward)
         return y
+
+    def _attach_wcache(self, d, pass_):
+        """Point `d` at this layer's weight cache (include/semseg_hip.h ss_wcache): Winograd-transformed / transposed / split weight
+        planes are derived once per weight VERSION (optimizer step, set_weights, any in-place write torch knows of, configuration
+        switch) instead of once per use; every descriptor geometry of the layer shares the cache.  Returns the state to hand to
+        _wcache_done after the launch, or None when the layer keeps no cache."""
+        st = self._wc
+        if st is False or not WEIGHT_CACHE:
+            d.w_cache = None
+            return None
+        ver = (self.arena.weights_key(), L.CONFIG_EPOCH)
+        if st is None:
+            lib = L.load()
+            nb = lib.ss_conv2d_wcache_bytes(ctypes.byref(d), L.PASS_FWD) + lib.ss_conv2d_wcache_bytes(ctypes.byref(d), L.PASS_BWD_DATA)
+            if nb == 0:
+                self._wc = False
+                d.w_cache = None
+                return None
+            buf = torch.empty(nb, dtype=torch.uint8, device=self.arena.device)
+            st = self._wc = dict(buf=buf, c=L.WCache(buf.data_ptr(), nb), ver=ver, sync=dict(ev=None, synced=set()), users={})
+        c = st["c"]
+        if st["ver"] != ver:
+            c.count, c.used = 0, 0          # = ss_wcache_invalidate
+            st["ver"], st["sync"] = ver, dict(ev=None, synced=set())
+        ukey = (d.n, d.ih, d.iw, d.in_cstride, d.out_cstride, d.dtype, pass_)
+        if ukey not in st["users"]:
+            du = L.ConvDesc.from_buffer_copy(d)          # private copy for refresh_wcache: no activation-side pointers
+            du.x_amax, du.dy_amax, du.x_amax_valid, du.dy_amax_valid = None, None, 0, 0
+            st["users"][ukey] = (du, pass_)
+        cur = _stream().value or 0
+        sync = st["sync"]
+        if sync["ev"] is not None and cur not in sync["synced"]:
+            torch.cuda.current_stream().wait_event(sync["ev"])      # entries filled on another stream: order this stream after them
+            sync["synced"].add(cur)
+        d.w_cache = ctypes.addressof(c)
+        st["fills0"], st["cur"] = c.fills, cur
+        return st
+
+    @staticmethod
+    def _wcache_done(st):
+        if st is not None and st["c"].fills != st["fills0"]:
+            ev = torch.cuda.Event()
+            ev.record()
+            st["sync"] = dict(ev=ev, synced={st["cur"]})
+
+    def refresh_wcache(self, sync):
+        """Recompute on the CURRENT stream every operand this layer kept for the previous weight version (fill-only calls of the
+        passes that used the cache).  Called through ParamArena.refresh_derived() before concurrent streams fork, so that no
+        stream has to wait for another one's first use of a layer.  Returns the number of passes refreshed."""
+        st = self._wc
+        if not st or not WEIGHT_CACHE:
+            return 0
+        ver = (self.arena.weights_key(), L.CONFIG_EPOCH)
+        if st["ver"] == ver:
+            return 0
+        lib = L.load()
+        c = st["c"]
+        c.count, c.used = 0, 0
+        st["ver"], st["sync"] = ver, sync
+        w = self.arena[f"{self.name}/kernel"]
+        c.fill_only = 1
+        try:
+            for d, pass_ in st["users"].values():
+                d.w_cache = ctypes.addressof(c)
+                nb = lib.ss_conv2d_workspace_bytes(ctypes.byref(d), pass_)
+                ws = workspace(nb, self.arena.device)
+                if pass_ == L.PASS_FWD:
+                    L.check(lib.ss_conv2d_fwd(ctypes.byref(d), None, _p(w), None, None, _p(ws), ws.numel(), _stream()),
+                            f"conv2d_fwd[{self.name}] (weight refresh)")
+                else:
+                    L.check(lib.ss_conv2d_bwd_data(ctypes.byref(d), None, _p(w), None, 0, _p(ws), ws.numel(), _stream()),
+                            f"conv2d_bwd_data[{self.name}] (weight refresh)")
+        finally:
+            c.fill_only = 0
+        return len(st["users"])
 
     def _uses_amax(self, d, pass_):
         """ss_conv2d_uses_amax(d, pass), cached per geometry: bit 0 = the pass reads (and leaves in the slot) max|x|, bit 1 = max|dy|."""

@@ -25,4 +25,5 @@ class Adam:
         a = net.arena
         L.check(lib.ss_adam_keras(_p(a.params), _p(a.grads), _p(a.m), _p(a.v), a.n_train, alpha,
                                   self.beta_1, self.beta_2, self.epsilon, float(grad_scale), _stream()), "ss_adam_keras")
+        a.touch()
         self.iterations = t

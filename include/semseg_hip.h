@@ -102,6 +102,29 @@ int ss_prof_get(int index, ss_prof_entry* out);
  * `act` is applied to y in the forward epilogue (after bias); backward entry points take the
  * gradient w.r.t. the pre-activation output (use ss_act_bwd first).
  * ---------------------------------------------------------------------------------------- */
+/* Weight cache of ONE convolution layer (optional).  The forward and data-gradient passes derive operands from the weights alone
+ * (Winograd-transformed / transposed / 16-bit split planes, the weight's maximum); CycleGAN.py:612-633 runs every generator three
+ * times forward and backward per optimizer step, so a layer's weights are otherwise transformed 4-6 times per step.  The caller
+ * owns a HOST struct per layer plus a device buffer (`base`, `bytes` >= the sum of ss_conv2d_wcache_bytes over the passes it will
+ * run); the library keeps the directory: each derived operand is a tagged entry, computed on first use (`fills` is incremented
+ * -- a caller that shares the cache between streams orders them on it) and read afterwards, by ANY descriptor geometry of the layer
+ * that needs the same operand.  An operand that does not fit is recomputed per call into the workspace, as without a cache.
+ * The caller empties it with ss_wcache_invalidate whenever the weight
+ * VALUES or the ss_config arithmetic switches change.  Results are bit-identical with and without a cache. */
+typedef struct ss_wcache_entry { uint64_t tag, offset, bytes; } ss_wcache_entry;
+typedef struct ss_wcache {
+    uint32_t struct_size;            /* = sizeof(ss_wcache) */
+    int32_t count;                   /* entries in use; 0 = empty */
+    int32_t fills;                   /* incremented whenever an entry is computed */
+    int32_t fill_only;               /* != 0: passes called with this cache only compute the entries they would keep (activation
+                                      * pointers may be NULL, nothing else is launched): lets a caller refresh a layer's operands on
+                                      * one stream right after the optimizer step, before concurrent streams use them */
+    void* base;                      /* device buffer */
+    uint64_t bytes, used;
+    ss_wcache_entry entry[32];
+} ss_wcache;
+void ss_wcache_invalidate(ss_wcache* wc);
+
 typedef struct ss_conv_desc {
     uint32_t struct_size;            /* = sizeof(ss_conv_desc): a caller built against another layout gets SS_ERR_INVALID, not a wild read */
     int32_t dtype;                   /* ss_dtype of x / y / dy / dx */
@@ -122,7 +145,12 @@ typedef struct ss_conv_desc {
     void* dy_amax;
     int32_t x_amax_valid;
     int32_t dy_amax_valid;
+    /* Optional (may be NULL): weight cache of the layer this descriptor belongs to, see ss_wcache below. */
+    struct ss_wcache* w_cache;
 } ss_conv_desc;
+
+/* Upper bound of the device bytes the pass keeps in the layer's weight cache (0: nothing, e.g. the weight gradient). */
+size_t ss_conv2d_wcache_bytes(const ss_conv_desc* d, int pass);
 
 /* bit 0: this pass reads max|x| (and leaves it in d->x_amax when that is set), bit 1: likewise max|dy|.  Pure function of d. */
 int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass);

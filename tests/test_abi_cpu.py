@@ -9,7 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = importlib.import_module("automatic-sem-image-segmentation_amd._lib")
 
-STRUCTS = {"ss_conv_desc": L.ConvDesc, "ss_norm_desc": L.NormDesc, "ss_prof_entry": L.ProfEntry}
+STRUCTS = {"ss_conv_desc": L.ConvDesc, "ss_norm_desc": L.NormDesc, "ss_prof_entry": L.ProfEntry, "ss_wcache": L.WCache,
+           "ss_wcache_entry": L.WCacheEntry}
 
 
 def _c_layout(tmp_path):

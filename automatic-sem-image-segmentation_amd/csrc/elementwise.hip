@@ -36,6 +36,41 @@ __global__ __launch_bounds__(EW_BLOCK) void axpby_kernel(float alpha, const T* _
     }
 }
 
+// out = scale * a .* b  (Dropout with an explicit keep mask: WassersteinGAN.py:566-567,621)
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void mul_kernel(float scale, const T* __restrict__ a, int a_cs, const T* __restrict__ b, int b_cs,
+                                                       T* __restrict__ out, int out_cs, long rows, int C) {
+    const long total = rows * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / C;
+        const int c = (int)(e - r * C);
+        out[r * out_cs + c] = (T)(scale * (float)a[r * a_cs + c] * (float)b[r * b_cs + c]);
+    }
+}
+
+// WGAN-GP (WassersteinGAN.py:113-116): one block per sample; norm_i = sqrt(sum_j g_ij^2) (fixed-order tree: deterministic),
+// gbar_ij = coef * 2 (norm_i - 1) / norm_i * g_ij = d/dg_ij of coef * (norm_i - 1)^2
+__global__ __launch_bounds__(256) void gp_grad_kernel(const float* __restrict__ g, long per_sample, float coef, float* __restrict__ gbar,
+                                                      float* __restrict__ norms) {
+    __shared__ double red[256];
+    const float* gi = g + (long)blockIdx.x * per_sample;
+    double s = 0.0;
+    for (long j = threadIdx.x; j < per_sample; j += 256) s += (double)gi[j] * (double)gi[j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    const float norm = (float)sqrt(red[0]);
+    if (threadIdx.x == 0) norms[blockIdx.x] = norm;
+    if (gbar) {
+        const float f = norm > 0.f ? coef * 2.f * (norm - 1.f) / norm : 0.f;
+        float* o = gbar + (long)blockIdx.x * per_sample;
+        for (long j = threadIdx.x; j < per_sample; j += 256) o[j] = f * gi[j];
+    }
+}
+
 // dst (type TD, view) = src (type TS, view): the storage-type boundary (fp32 <-> bf16 / fp16 activations)
 template <typename TS, typename TD>
 __global__ __launch_bounds__(EW_BLOCK) void convert_kernel(const TS* __restrict__ src, int src_cs, TD* __restrict__ dst, int dst_cs, long rows, int C) {
@@ -373,6 +408,24 @@ int ss_axpby_t(int32_t dtype, float alpha, const void* a, int32_t a_cstride, flo
     if (rows == 0) return SS_OK;
     SS_DT(dtype, hipLaunchKernelGGL(axpby_kernel<T>, dim3(ew_grid(rows * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
                                     alpha, (const T*)a, a_cstride, beta, (const T*)b, b_cstride, (T*)out, out_cstride, (long)rows, c));
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_mul_t(int32_t dtype, float scale, const void* a, int32_t a_cstride, const void* b, int32_t b_cstride, void* out, int32_t out_cstride,
+             int64_t rows, int32_t c, void* stream) {
+    if (!a || !b || !out || rows < 0 || c <= 0) return SS_ERR_INVALID;
+    if (rows == 0) return SS_OK;
+    SS_DT(dtype, hipLaunchKernelGGL(mul_kernel<T>, dim3(ew_grid(rows * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                    scale, (const T*)a, a_cstride, (const T*)b, b_cstride, (T*)out, out_cstride, (long)rows, c));
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_wgan_gp_grad(const float* g, int64_t n, int64_t per_sample, float coef, float* gbar, float* norms, void* stream) {
+    if (!g || !norms || n < 0 || per_sample <= 0) return SS_ERR_INVALID;
+    if (n == 0) return SS_OK;
+    hipLaunchKernelGGL(gp_grad_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, g, (long)per_sample, coef, gbar, norms);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -269,6 +269,14 @@ int ss_act_bwd_t(int32_t dtype, int act, float act_alpha, const void* dy, int32_
                  void* dx, int32_t dx_cstride, int64_t rows, int32_t c, void* stream);
 int ss_axpby_t(int32_t dtype, float alpha, const void* a, int32_t a_cstride, float beta, const void* b, int32_t b_cstride,
                void* out, int32_t out_cstride, int64_t rows, int32_t c, void* stream);
+/* out = scale * a .* b on [rows][c] views: keras.layers.Dropout with an explicit keep mask b in {0, 1} and scale = 1 / (1 - rate)
+ * (WassersteinGAN.py:566-567, 621), and the mask products of the gradient-penalty chain. */
+int ss_mul_t(int32_t dtype, float scale, const void* a, int32_t a_cstride, const void* b, int32_t b_cstride, void* out, int32_t out_cstride,
+             int64_t rows, int32_t c, void* stream);
+/* Gradient penalty of WGAN_GP.gradient_penalty (WassersteinGAN.py:113-116) on g = d critic / d interpolated, [n][per_sample] dense:
+ * norms[i] = sqrt(sum_j g_ij^2); gbar (optional) = d/dg of coef * sum_i (norms[i] - 1)^2, i.e. coef * 2 (norm_i - 1) / norm_i * g_ij
+ * (0 where norm_i == 0).  Deterministic (fixed-order reduction, one workgroup per sample). */
+int ss_wgan_gp_grad(const float* g, int64_t n, int64_t per_sample, float coef, float* gbar, float* norms, void* stream);
 int ss_copy_t(int32_t dtype, const void* src, int32_t src_cstride, void* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream);
 int ss_maxpool2x2_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride,
                         int32_t n, int32_t h, int32_t w, int32_t c, void* stream);

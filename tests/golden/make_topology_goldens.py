@@ -147,11 +147,13 @@ def install_layer_stub():
 
     class BatchNormalization(Layer):
         def __init__(self, axis=-1, momentum=0.99, epsilon=1e-3, center=True, scale=True, **kw):
-            assert axis == 3 and center
+            assert axis in (3, -1) and center
             self.momentum, self.eps, self.scale = momentum, epsilon, scale
             self.name = uname("batch_normalization")
 
         def call(self, x, training=None):
+            if x.dim() == 2:            # features of a Dense layer: statistics over the batch axis only
+                return self.call(x.reshape(x.shape[0], 1, 1, -1)).reshape(x.shape)
             c = x.shape[-1]
             g = Stub.var(f"{self.name}/gamma", (c,)) if self.scale else None
             b = Stub.var(f"{self.name}/beta", (c,))

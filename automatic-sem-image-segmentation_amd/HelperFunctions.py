@@ -2,6 +2,7 @@
 ``get_image_file_paths_from_directory`` :290-291, ``load_and_preprocess_images`` :294-329,
 ``tile_image`` :17-62, ``stitch_image`` :65-141.  Pure numpy/PIL; feeds and drains the GPU path."""
 import math
+import random
 import os
 
 import numpy as np
@@ -342,3 +343,50 @@ def filter_gan_masks(img_path, msk_path, out_path, threshold_method=threshold_li
         Image.fromarray((keep[lab] * 255).astype('uint8')).save(os.path.join(out_path, f))
         if gaussian_blur_amount > 0:
             Image.fromarray(img).filter(ImageFilter.GaussianBlur(gaussian_blur_amount)).save(os.path.join(img_path, f))
+
+
+def prepare_images_cycle_gan(root_dir, input_dir_images, tile_size_w=384, tile_size_h=384, num_simulated_masks=1000, dark_background=True):
+    """Step 0 of the workflow (HelperFunctions.py:241-287): tile the SEM images into ``2_CycleGAN/data/trainA`` (tiles that show
+    mainly background are dropped: mean >= 1.1 x image mean for dark backgrounds, <= 0.9 x for bright ones), copy 5 random tiles to
+    ``testA``, then top the tile set up to ``num_simulated_masks`` with random crops (+ random flips) that pass the same filter.
+    Same draws from python's ``random`` in the same order as the reference, so a seeded run writes the same files."""
+    from PIL import Image
+    from shutil import copy
+    train_a = os.path.join(root_dir, '2_CycleGAN', 'data', 'trainA')
+    test_a = os.path.join(root_dir, '2_CycleGAN', 'data', 'testA')
+
+    def foreground(tile, image):
+        return np.mean(tile) >= 1.1 * np.mean(image) if dark_background else np.mean(tile) <= 0.9 * np.mean(image)
+
+    input_imgs = load_and_preprocess_images(input_dir_or_filelist=input_dir_images, normalization_range=None, output_channels=1)
+    filenames = get_image_file_paths_from_directory(input_dir_images)
+    for i, input_img in enumerate(input_imgs):
+        img_tiles = np.asarray(tile_image(input_img, tile_size_w, tile_size_h, normalization_range=(0, 255), min_overlap=0), dtype='uint8')
+        f = os.path.split(filenames[i])[-1]
+        ext = os.path.splitext(f)[-1]
+        for j, img_tile in enumerate(img_tiles):
+            if foreground(img_tile, input_img):
+                Image.fromarray(img_tile[:, :, 0]).save(os.path.join(train_a, f.replace(ext, f'-{j}{ext}')))
+
+    filenames = get_image_file_paths_from_directory(train_a)
+    for f in random.sample(filenames, 5):
+        copy(f if os.path.isabs(f) else os.path.join(train_a, f), test_a)
+
+    num_images_a = len(os.listdir(train_a))
+    i = 0
+    while i < num_simulated_masks - num_images_a:
+        # sic (HelperFunctions.py:268-271): ``filenames`` is by now the TILE list, indexed with an index drawn over the input images
+        r = random.randint(0, input_imgs.shape[0] - 1)
+        f = os.path.split(filenames[r])[-1]
+        ext = os.path.splitext(f)[-1]
+        input_img = input_imgs[r, :, :, :]
+        a = random.randint(0, input_img.shape[0] - tile_size_h - 1)
+        b = random.randint(0, input_img.shape[1] - tile_size_w - 1)
+        img_tile = input_img[a:a + tile_size_h, b:b + tile_size_w]
+        if random.random() > 0.5:
+            img_tile = np.fliplr(img_tile)
+        if random.random() > 0.5:
+            img_tile = np.flipud(img_tile)
+        if foreground(img_tile, input_img):
+            Image.fromarray(img_tile[:, :, 0].astype('uint8')).save(os.path.join(train_a, f.replace(ext, f'-aug_{i}{ext}')))
+            i += 1

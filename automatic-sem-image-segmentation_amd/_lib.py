@@ -125,6 +125,7 @@ SIGNATURES = {
     "ss_axpby_t": (c_i32, [c_i32, c_f32, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "ss_copy_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "ss_mul_t": (c_i32, [c_i32, c_f32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ss_wgan_interpolate": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "ss_wgan_gp_grad": (c_i32, [c_vp, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp]),
     "ss_maxpool2x2_fwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "ss_maxpool2x2_bwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),

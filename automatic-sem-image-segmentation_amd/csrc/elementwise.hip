@@ -71,6 +71,16 @@ __global__ __launch_bounds__(256) void gp_grad_kernel(const float* __restrict__ 
     }
 }
 
+// out[i][j] = real[i][j] + alpha[i] * (fake[i][j] - real[i][j])   (WGAN_GP.gradient_penalty, WassersteinGAN.py:97-99)
+__global__ __launch_bounds__(EW_BLOCK) void interpolate_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                                               const float* __restrict__ alpha, float* __restrict__ out, long n, long per_sample) {
+    const long total = n * per_sample;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const float r = real[e];
+        out[e] = r + alpha[e / per_sample] * (fake[e] - r);
+    }
+}
+
 // dst (type TD, view) = src (type TS, view): the storage-type boundary (fp32 <-> bf16 / fp16 activations)
 template <typename TS, typename TD>
 __global__ __launch_bounds__(EW_BLOCK) void convert_kernel(const TS* __restrict__ src, int src_cs, TD* __restrict__ dst, int dst_cs, long rows, int C) {
@@ -418,6 +428,15 @@ int ss_mul_t(int32_t dtype, float scale, const void* a, int32_t a_cstride, const
     if (rows == 0) return SS_OK;
     SS_DT(dtype, hipLaunchKernelGGL(mul_kernel<T>, dim3(ew_grid(rows * c)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
                                     scale, (const T*)a, a_cstride, (const T*)b, b_cstride, (T*)out, out_cstride, (long)rows, c));
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_wgan_interpolate(const float* real, const float* fake, const float* alpha, float* out, int64_t n, int64_t per_sample, void* stream) {
+    if (!real || !fake || !alpha || !out || n < 0 || per_sample <= 0) return SS_ERR_INVALID;
+    if (n == 0) return SS_OK;
+    hipLaunchKernelGGL(interpolate_kernel, dim3(ew_grid(n * per_sample)), dim3(EW_BLOCK), 0, (hipStream_t)stream, real, fake, alpha, out,
+                       (long)n, (long)per_sample);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

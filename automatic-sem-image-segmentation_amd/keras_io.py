@@ -102,6 +102,7 @@ def layer_groups(net, counters):
     (Conv2D / Conv2DTranspose, its bias follows), at every gamma, and at a beta that does not follow a gamma (scale=False)."""
     groups, prev = [], None
     transposed = {f"{c.name}/kernel" for c in _convs(net) if c.transposed}
+    dense = {f"{c.name}/kernel" for c in _convs(net) if getattr(c, "keras_kind", None) == "dense"}      # keras.layers.Dense as 1x1 conv
     names = [s[0] for s in net.arena.specs]
     kinds = [n.rsplit("/", 1)[-1] for n in names]
     i = 0
@@ -111,7 +112,7 @@ def layer_groups(net, counters):
             g = [names[i]]
             if i + 1 < len(names) and kinds[i + 1] == "bias":
                 g.append(names[i + 1])
-            groups.append((counters.next("conv2d_transpose" if names[i] in transposed else "conv2d"), g))
+            groups.append((counters.next("dense" if names[i] in dense else ("conv2d_transpose" if names[i] in transposed else "conv2d")), g))
             i += len(g)
         elif k in ("gamma", "beta"):
             g = [names[i]]
@@ -156,7 +157,10 @@ def net_arrays(net, prefix, counters):
     out = {}
     for lname, vs in layer_groups(net, counters):
         for i, v in enumerate(vs):
-            out[f"{prefix}layers/{lname}/vars/{i}"] = weights[v]
+            w = weights[v]
+            if lname.startswith("dense") and w.ndim == 4:          # Keras stores a Dense kernel as (inputs, units)
+                w = w.reshape(w.shape[2], w.shape[3])
+            out[f"{prefix}layers/{lname}/vars/{i}"] = w
     return out
 
 

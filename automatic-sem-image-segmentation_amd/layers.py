@@ -390,6 +390,49 @@ def gaussian_noise(tape, x, stddev, training=True):
     return y
 
 
+def dropout(tape, x, keep, rate):
+    """keras.layers.Dropout(rate) in training mode with an explicit keep mask (WassersteinGAN.py:566-567,621): y = x * keep / (1 - rate).
+    ``keep``: Act of x's shape holding 0 / 1, or None for "no dropout" (identity).  The caller draws the mask (torch's device
+    generator; the reference's comes from Keras' seed generator: the streams cannot match, only the distribution)."""
+    if keep is None:
+        return x
+    lib = L.load()
+    sc = 1.0 / (1.0 - float(rate))
+    y = x.like(requires_grad=x.requires_grad)
+    L.check(lib.ss_mul_t(x.dt, sc, x.ptr, x.cs, keep.ptr, keep.cs, y.ptr, y.cs, x.rows, x.c, _stream()), "mul")
+
+    def backward():
+        dy = y.get_grad()
+        if dy is None or not x.requires_grad:
+            return
+        dx, accum = x.grad_target()
+        if accum:
+            tmp = x.like(requires_grad=False)
+            L.check(lib.ss_mul_t(x.dt, sc, dy.ptr, dy.cs, keep.ptr, keep.cs, tmp.ptr, tmp.cs, x.rows, x.c, _stream()), "mul")
+            L.check(lib.ss_axpby_t(x.dt, 1.0, tmp.ptr, tmp.cs, 1.0, dx.ptr, dx.cs, dx.ptr, dx.cs, x.rows, x.c, _stream()), "axpby")
+        else:
+            L.check(lib.ss_mul_t(x.dt, sc, dy.ptr, dy.cs, keep.ptr, keep.cs, dx.ptr, dx.cs, x.rows, x.c, _stream()), "mul")
+
+    tape.record(backward)
+    return y
+
+
+def reshape(tape, x, h, w, c):
+    """keras.layers.Reshape / Flatten on a dense channels-last activation: the same memory under another (h, w, c) -- no kernel."""
+    assert x.c0 == 0 and x.c == x.cs and x.h * x.w * x.c == h * w * c, "reshape needs a dense activation of the same size"
+    y = Act(x.t.view(x.n, h, w, c), requires_grad=x.requires_grad)
+
+    def backward():
+        dy = y.get_grad()
+        if dy is None or not x.requires_grad:
+            return
+        assert dy.c0 == 0 and dy.c == dy.cs
+        add_grad(x, Act(dy.t.view(x.t.shape), requires_grad=False))
+
+    tape.record(backward)
+    return y
+
+
 def batch_split(tape, x, sizes):
     """Views of consecutive sample ranges of ``x`` (no copy).  Used to run one network pass over several input batches at once
     (CycleGAN: the "fake" and "identity" passes of a generator share weights and are per-sample independent); backward gathers

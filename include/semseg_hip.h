@@ -276,6 +276,8 @@ int ss_mul_t(int32_t dtype, float scale, const void* a, int32_t a_cstride, const
 /* Gradient penalty of WGAN_GP.gradient_penalty (WassersteinGAN.py:113-116) on g = d critic / d interpolated, [n][per_sample] dense:
  * norms[i] = sqrt(sum_j g_ij^2); gbar (optional) = d/dg of coef * sum_i (norms[i] - 1)^2, i.e. coef * 2 (norm_i - 1) / norm_i * g_ij
  * (0 where norm_i == 0).  Deterministic (fixed-order reduction, one workgroup per sample). */
+/* interpolated[i] = real[i] + alpha[i] * (fake[i] - real[i]) for n dense samples of per_sample elements (WassersteinGAN.py:97-99). */
+int ss_wgan_interpolate(const float* real, const float* fake, const float* alpha, float* out, int64_t n, int64_t per_sample, void* stream);
 int ss_wgan_gp_grad(const float* g, int64_t n, int64_t per_sample, float coef, float* gbar, float* norms, void* stream);
 int ss_copy_t(int32_t dtype, const void* src, int32_t src_cstride, void* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream);
 int ss_maxpool2x2_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride,

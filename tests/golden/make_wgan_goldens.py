@@ -120,9 +120,13 @@ def run(builder, x, seed, counters_list, want_inference=True):
 def main():
     c1 = M.install_layer_stub()
     c2 = extend_stub()
+    import importlib
     for name in ("matplotlib", "matplotlib.pyplot", "tqdm", "tqdm.autonotebook", "opensimplex", "cv2"):
-        sys.modules.setdefault(name, types.ModuleType(name))
-    sys.modules["tqdm.autonotebook"].tqdm = lambda it=None, **k: it
+        try:
+            importlib.import_module(name)
+        except Exception:
+            sys.modules[name] = types.ModuleType(name)
+            sys.modules[name].tqdm = lambda it=None, **k: it
     import WassersteinGAN as RW          # /root/reference/Releases/Version 1.2.0/WassersteinGAN.py
 
     g = torch.Generator().manual_seed(11)
@@ -138,6 +142,42 @@ def main():
         for k in (f"gen_{h}x{w}", f"critic_{h}x{w}"):
             print(k, res[k]["y_train"].shape, len(res[k]["names"]), "variables", list(res[k]["drop_rates"]))
     flat = {f"{case}/{k}": v for case, d in res.items() for k, v in d.items()}
+
+    # --- host side: the training set WGAN.__init__ builds (WassersteinGAN.py:334-361) and step 0 (HelperFunctions.py:241-287) ------
+    import random
+    import tempfile
+    from PIL import Image
+    import HelperFunctions as RH
+    rng = np.random.default_rng(21)
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "Input_Masks"))
+        for k, (h, w) in enumerate(((20, 28), (20, 28), (20, 28))):          # equal sizes: the reference stacks them with np.array
+            m = (rng.random((h, w)) > 0.5).astype("uint8") * 255
+            m[0, 0], m[-1, -1] = 0, 255
+            Image.fromarray(m).save(os.path.join(td, "Input_Masks", f"mask_{k}.tif"))
+            flat[f"trainset/mask_{k}"] = m
+        wf = RW.WGAN(root_dir=td)
+        flat["trainset/train_images"] = wf.train_images
+        print("train_images", wf.train_images.shape)
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "Input_Images")
+        os.makedirs(src)
+        for sub in ("trainA", "testA"):
+            os.makedirs(os.path.join(td, "2_CycleGAN", "data", sub))
+        for k, (h, w) in enumerate(((70, 90), (70, 90), (70, 90))):            # equal sizes (np.array stacking in the loader)
+            im = (rng.random((h, w)) * 255).astype("uint8")
+            im[: h // 2] //= 4                                   # a dark half: some tiles fail the background filter
+            Image.fromarray(im).save(os.path.join(src, f"sem_{k}.tif"))
+            flat[f"step0/sem_{k}"] = im
+        random.seed(5)
+        RH.prepare_images_cycle_gan(td, src, tile_size_w=32, tile_size_h=32, num_simulated_masks=30, dark_background=True)
+        for sub in ("trainA", "testA"):
+            names = sorted(os.listdir(os.path.join(td, "2_CycleGAN", "data", sub)))
+            flat[f"step0/{sub}/names"] = np.array(names)
+            flat[f"step0/{sub}/sums"] = np.array([int(np.asarray(Image.open(os.path.join(td, "2_CycleGAN", "data", sub, n_)), dtype=np.int64).sum())
+                                                  for n_ in names])
+        print("step0", len(flat["step0/trainA/names"]), "tiles,", len(flat["step0/testA/names"]), "test tiles")
+
     path = os.path.join(HERE, "wgan_topology.npz")
     np.savez_compressed(path, **flat)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")

@@ -1,0 +1,165 @@
+"""WGAN-GP on the HIP engine (row f4) against the oracle (oracle/wgan.py: torch autograd incl. the create_graph double backward of
+the gradient penalty) on identical weights and identical random draws, and against the reference-builder topology vectors."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wgan as OW
+from test_wgan_cpu import case_keep, case_weights
+
+pytestmark = pytest.mark.gpu
+BASE = "automatic-sem-image-segmentation_amd"
+
+
+def _mods():
+    return importlib.import_module(BASE + ".WassersteinGAN"), importlib.import_module(BASE + ".optim")
+
+
+@pytest.fixture(scope="module")
+def topo(golden_dir):
+    return np.load(os.path.join(golden_dir, "wgan_topology.npz"))
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (32, 48)])
+def test_hip_nets_match_reference_builders(topo, hw):
+    W, _ = _mods()
+    case = f"gen_{hw[0]}x{hw[1]}"
+    specs, ws = case_weights(topo, case)
+    gen = W.WganGenerator(hw[0], hw[1], n_z=16)
+    assert [tuple(s[1]) for s in gen.arena.specs] == [s[1] if len(s[1]) != 2 else (1, 1) + s[1] for s in specs]
+    gen.set_weights(ws)
+    z = topo[f"{case}/x"]
+    y_inf = gen(z, False).dense().cpu().numpy()
+    y = gen(z, True).dense().cpu().numpy()
+    np.testing.assert_allclose(y, topo[f"{case}/y_train"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(y_inf, topo[f"{case}/y_infer"], rtol=1e-3, atol=2e-4)
+    for i, (name, *_rest) in enumerate(gen.arena.specs):
+        if f"{case}/moving_after/{i}" in topo:
+            np.testing.assert_allclose(gen.arena[name].cpu().numpy(), topo[f"{case}/moving_after/{i}"], rtol=1e-4, atol=1e-5)
+    case = f"critic_{hw[0]}x{hw[1]}"
+    specs, ws = case_weights(topo, case)
+    _, keep = case_keep(topo, case)
+    crit = W.WganCritic(hw[0], hw[1])
+    crit.set_weights(ws)
+    x = topo[f"{case}/x"]
+    y = crit(x, True, None, dict(zip(("drop1", "drop2", "flat"), keep))).dense().cpu().numpy().reshape(-1, 1)
+    y_inf = crit(x, False).dense().cpu().numpy().reshape(-1, 1)
+    np.testing.assert_allclose(y, topo[f"{case}/y_train"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(y_inf, topo[f"{case}/y_infer"], rtol=1e-3, atol=2e-4)
+
+
+def _draws(n, n_z, d_steps, crit_o, hw, seed, dropout=True):
+    g = torch.Generator().manual_seed(seed)
+    h1, w1 = -(-hw[0] // 4), -(-hw[1] // 4)
+    h2, w2 = -(-hw[0] // 8), -(-hw[1] // 8)
+
+    def keep():
+        if not dropout:
+            return None
+        return {"drop1": (torch.rand((n, h1, w1, 128), generator=g) >= OW.DROP_CONV).float(),
+                "drop2": (torch.rand((n, h2, w2, 256), generator=g) >= OW.DROP_CONV).float(),
+                "flat": (torch.rand((n, crit_o.flat), generator=g) >= OW.DROP_FLAT).float()}
+    return {"z": [torch.randn((n, n_z), generator=g) for _ in range(d_steps + 1)],
+            "alpha": [torch.randn((n, 1, 1, 1), generator=g) for _ in range(d_steps)],
+            "keep_fake": [keep() for _ in range(d_steps)], "keep_real": [keep() for _ in range(d_steps)],
+            "keep_gp": [keep() for _ in range(d_steps)], "keep_gen": keep()}
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize("dropout", [False, True], ids=["no_dropout", "dropout"])
+def test_train_step_matches_oracle_incl_gradient_penalty(dropout):
+    W, OPT = _mods()
+    hw, n, n_z, d_steps = (32, 32), 4, 8, 2
+    go, do = OW.WganGenerator(hw[0], hw[1], n_z=n_z, seed=1), OW.WganCritic(hw[0], hw[1], seed=2)
+    # non-trivial BatchNorm parameters / biases
+    gsp = [(v.name, tuple(v.shape), v.trainable) for v in go.variables]
+    dsp = [(v.name, tuple(v.shape), v.trainable) for v in do.variables]
+    from test_wgan_cpu import golden_weights
+    gw, dw = golden_weights(gsp, 41), golden_weights(dsp, 42)
+    go.set_weights(gw)
+    do.set_weights(dw)
+    gen, crit = W.WganGenerator(hw[0], hw[1], n_z=n_z), W.WganCritic(hw[0], hw[1])
+    gen.set_weights(gw)
+    crit.set_weights(dw)
+    ostep = OW.WganStep(go, do, d_steps=d_steps)
+    model = W.WGAN_GP(discriminator=crit, generator=gen, latent_dim=n_z, discriminator_extra_steps=d_steps)
+    model.compile(d_optimizer=OPT.Adam(learning_rate=0.0002, beta_1=0.5, beta_2=0.9),
+                  g_optimizer=OPT.Adam(learning_rate=0.0002, beta_1=0.5, beta_2=0.9))
+    model.keep_grads = True
+    real = torch.rand((n, hw[0], hw[1], 1), generator=torch.Generator().manual_seed(3)) * 2 - 1
+    for it in range(2):
+        draws = _draws(n, n_z, d_steps, do, hw, 100 + it, dropout)
+        ref = ostep.train_step(real, draws)
+        model.grad_log = {"d": [], "g": []}
+        model.train_step(real.numpy(), draws)
+        got = model.last
+        for k in ("d_loss", "d_total_loss", "g_loss", "grad_penalty", "grad_norm"):
+            assert abs(got[k] - ref[k]) <= (2e-4 if it == 0 else 5e-3) * max(1.0, abs(ref[k])), (it, k, got[k], ref[k])
+        dnames = [v.name for v in do.trainable_weights]
+        for i in range(d_steps):
+            got_g = [model.grad_log["d"][i][nme].reshape(gr.shape) for nme, gr in zip(dnames, ref["d_grads"][i])]
+            if (it, i) == (0, 0):
+                # strict, per variable, on the first update (identical weights; fp32 vs fp32 -- the fake (+1/n) and real (-1/n)
+                # halves nearly cancel in the first layers)
+                for nme, a_, gr in zip(dnames, got_g, ref["d_grads"][i]):
+                    e = _rel(a_, gr.numpy())
+                    assert e < 5e-3, (it, "critic", i, nme, e)
+            # Later updates start from weights that already differ: Adam's first steps are lr * sign(g), so a gradient element
+            # whose rounding differs in sign moves a weight by 2 lr = 4e-4.  Whole-gradient relative L2 error there.
+            num = sum(float(((a_.astype(np.float64) - gr.numpy().astype(np.float64)) ** 2).sum()) for a_, gr in zip(got_g, ref["d_grads"][i]))
+            den = sum(float((gr.numpy().astype(np.float64) ** 2).sum()) for gr in ref["d_grads"][i])
+            assert (num / den) ** 0.5 < 3e-2, (it, "critic", i, (num / den) ** 0.5)
+        gnames = [v.name for v in go.trainable_weights]
+        got_g = [model.grad_log["g"][0][nme].reshape(gr.shape) for nme, gr in zip(gnames, ref["g_grads"])]
+        num = sum(float(((a_.astype(np.float64) - gr.numpy().astype(np.float64)) ** 2).sum()) for a_, gr in zip(got_g, ref["g_grads"]))
+        den = sum(float((gr.numpy().astype(np.float64) ** 2).sum()) for gr in ref["g_grads"])
+        assert (num / den) ** 0.5 < 3e-2, (it, "generator", (num / den) ** 0.5)
+    # BatchNorm moving statistics advanced d_steps + 1 times per step, like the reference's generator calls
+    for v in go.non_trainable_weights:
+        np.testing.assert_allclose(gen.arena[v.name].cpu().numpy().reshape(v.shape), v.value.numpy(), rtol=2e-3, atol=2e-4)
+
+
+def test_workflow_trains_saves_and_simulates_masks(tmp_path):
+    """Step 1 end to end on a toy mask set: two epochs of ``start_training`` (CSV log, preview sheet, model.keras), reload, and
+    ``simulate_masks`` writing binary 0/255 masks into 2_CycleGAN/data/trainB (+ copies in testB)."""
+    import random
+    from PIL import Image
+    W, _ = _mods()
+    (tmp_path / "Input_Masks").mkdir()
+    yy, xx = np.mgrid[0:32, 0:32]
+    for k in range(6):
+        disc = ((yy - 16) ** 2 + (xx - 16) ** 2 < (8 + k) ** 2).astype(np.uint8) * 255
+        Image.fromarray(disc).save(tmp_path / "Input_Masks" / f"m{k}.tif")
+    for sub in ("1_WGAN/Models", "1_WGAN/Output_Images", "2_CycleGAN/data/trainB", "2_CycleGAN/data/testB"):
+        (tmp_path / sub).mkdir(parents=True)
+    wf = W.WGAN(root_dir=str(tmp_path))
+    assert wf.train_images.shape == (24, 32, 32, 1)
+    wf.batch_size, wf.epochs, wf.n_z = 16, 2, 16
+    model = wf.start_training()
+    run = tmp_path / "1_WGAN" / "Models" / wf.prefix
+    rows = (run / "training_log.csv").read_text().strip().splitlines()
+    assert rows[0] == "epoch,d_loss,d_total_loss,g_loss,grad_norm,grad_penalty" and len(rows) == 3
+    assert all(np.isfinite(float(v)) for v in rows[-1].split(",")[1:])
+    assert (tmp_path / "1_WGAN" / "Output_Images" / wf.prefix / "Epoch_00000.png").exists()
+    w_before = model.generator.get_weights()
+    # reload into a fresh workflow object (simulate_masks loads the most recent model itself)
+    wf2 = W.WGAN(root_dir=str(tmp_path))
+    wf2.batch_size, wf2.n_z = 16, 16
+    random.seed(1)
+    np.random.seed(1)
+    wf2.simulate_masks(no_of_images=2, min_no_of_particles=5, max_no_of_particles=8, img_width=96, img_height=96)
+    for a, b in zip(w_before, wf2.model.generator.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    assert wf2.model.d_optimizer.iterations == model.d_optimizer.iterations == 2 * 2 * 3          # 2 epochs x 2 batches x 3 critic steps
+    out = sorted(os.listdir(tmp_path / "2_CycleGAN" / "data" / "trainB"))
+    assert out == ["00000.tif", "00001.tif"]
+    img = np.asarray(Image.open(tmp_path / "2_CycleGAN" / "data" / "trainB" / out[0]))
+    assert img.shape == (96, 96) and set(np.unique(img)) <= {0, 255}
+    assert len(os.listdir(tmp_path / "2_CycleGAN" / "data" / "testB")) == 2

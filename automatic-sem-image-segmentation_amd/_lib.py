@@ -43,7 +43,9 @@ class ConvDesc(_SizedDesc):
 
 class NormDesc(_SizedDesc):
     _fields_ = [("struct_size", ctypes.c_uint32), ("dtype", c_i32)] + [(n, c_i32) for n in ("n", "h", "w", "c", "x_cstride", "y_cstride", "res_cstride", "groups")] + \
-               [("eps", c_f32), ("act", c_i32), ("act_alpha", c_f32)]
+               [("eps", c_f32), ("act", c_i32), ("act_alpha", c_f32),
+                # optional slots the norm raises to max|y| (forward) / max|dx| (backward) while writing the tensor (x3h scales)
+                ("y_amax", c_vp), ("dx_amax", c_vp)]
 
 
 class ProfEntry(ctypes.Structure):
@@ -101,6 +103,7 @@ SIGNATURES = {
     "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_conv2d_bwd_data": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "ss_conv2d_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
+    "ss_norm_reports_amax": (c_i32, [ctypes.POINTER(NormDesc)]),
     "ss_norm_workspace_bytes": (c_sz, [ctypes.POINTER(NormDesc)]),
     "ss_norm_fwd": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_sz, c_vp]),
     "ss_norm_infer": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -67,6 +67,17 @@ __device__ __forceinline__ void ss_split3x2(f32x2 v, unsigned int& h, unsigned i
 
 // x3h scales: exponent e of a tensor maximum (max = f * 2^e, f in [0.5, 1)); 14 for an all-zero tensor; clamped from below so
 // that the scale 2^(14-e) stays finite for subnormal maxima (the results of such tensors underflow in fp32 as well)
+// A caller-owned amax slot (ss_conv_desc::x_amax / dy_amax, ss_norm_desc::y_amax / dx_amax) is SS_AMAX_STRIPES words, one per
+// 256-byte line: the producers' per-workgroup atomics spread over that many L2 lines (thousands of atomics on ONE address cost
+// ~10 ns each: 20 us for a 2048-workgroup launch), readers take the maximum of the stripes.
+#define SS_AMAX_STRIPES 16
+#define SS_AMAX_STRIDE 64          // words between stripes
+__device__ __forceinline__ unsigned int ss_amax_load(const unsigned int* __restrict__ p, int stripes) {
+    unsigned int m = p[0];
+    for (int i = 1; i < stripes; ++i) m = max(m, p[i * SS_AMAX_STRIDE]);
+    return m;
+}
+
 __device__ __forceinline__ int ss_amax_exp(float amax) {
     int e = 14;
     if (amax > 0.f) (void)frexpf(amax, &e);
@@ -112,7 +123,8 @@ struct GConvParams {
     int64_t in_bs, w_bs, out_bs;  // element strides between the batched problems
     int32_t ntaps;
     const unsigned int* h_amax;   // x3h (conv_mfma_x6.hip): bit pattern of max|input| -- nullptr: three-piece bf16 arithmetic
-    const unsigned int* h_amax2;  //      ... of max|weights|
+    const unsigned int* h_amax2;  //      ... of max|weights| (always one word)
+    int amax_stripes;             // h_amax is the maximum over this many words, SS_AMAX_STRIDE apart (0 / 1: one word)
     int32_t dtype;                // ss_dtype of `in` / `out` (the pointers are reinterpreted); only the tile kernels take 16-bit storage
     GTap taps[SS_MAX_TAPS];
 };
@@ -132,6 +144,7 @@ struct WGradParams {
     int32_t x6;                   // 1: fp32-exact contraction on the bf16 matrix cores where the shape allows (conv_mfma_x6.hip)
     const unsigned int* h_amax;   // x3h: bit pattern of max|a| (one scale per operand tensor); nullptr: three-piece bf16 arithmetic
     const unsigned int* h_amax2;  //      ... of max|b|
+    int amax_stripes, amax2_stripes;   // each maximum is spread over this many words, SS_AMAX_STRIDE apart (0 / 1: one word)
     int64_t a_bs, b_bs;
     int32_t dtype;                // ss_dtype of `a` / `b` (tile kernel only); partials and dw are fp32
     int32_t ntaps;
@@ -180,6 +193,8 @@ int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split, int 
 int ss_launch_wgrad_mfma_partials(const WGradParams& p, hipStream_t s);   // partials only: part[batch][split][M][Cb]
 
 // dst (dst_dtype view) = src (src_dtype view) (elementwise.hip)
+// max|v| of a [rows][C] fp32 view (row stride cs) as a bit pattern, atomically raised in *out (conv_api.hip)
+void ss_launch_amax_view(const float* v, long rows, int C, int cs, unsigned int* out, int stripes, hipStream_t s);
 int ss_convert_launch(const void* src, int src_dtype, int src_cs, void* dst, int dst_dtype, int dst_cs, long rows, int c, hipStream_t s);
 int ss_launch_wgrad_reduce(const WGradParams& p, float* dw, int ldw, int accumulate, int rows, hipStream_t s);
 

@@ -266,7 +266,7 @@ size_t x6_planes_ub(int cred, int cout, int ntaps) {
 // ---- x3h for the direct (non-Winograd) x6 convolutions: one power-of-two scale per operand TENSOR, from max|.| ----------------------
 // out[0] = max over the [rows][C] view (row stride cs) of |v|, as a bit pattern (non-negative floats order like unsigned ints; an
 // atomic max does not depend on the order: deterministic).  out must be zero on entry.
-__global__ __launch_bounds__(256) void amax_view_kernel(const float* __restrict__ v, long rows, int C, int cs, unsigned int* __restrict__ out) {
+__global__ __launch_bounds__(256) void amax_view_kernel(const float* __restrict__ v, long rows, int C, int cs, unsigned int* __restrict__ out, int stripes) {
     unsigned int m = 0;
     const bool al = (((uintptr_t)v) & 15) == 0;
     if (cs == C && al) {                     // dense: one flat array, no index arithmetic
@@ -297,30 +297,36 @@ __global__ __launch_bounds__(256) void amax_view_kernel(const float* __restrict_
     __shared__ unsigned int wm[4];           // ONE atomic per block: thousands of atomics on one address serialise in L2 (10 ns each)
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(out, max(max(wm[0], wm[1]), max(wm[2], wm[3])));
+    if (threadIdx.x == 0) atomicMax(out + (stripes > 1 ? (blockIdx.x % stripes) * SS_AMAX_STRIDE : 0), max(max(wm[0], wm[1]), max(wm[2], wm[3])));
 }
 
-inline void launch_amax_view(const float* v, long rows, int C, int cs, unsigned int* out, hipStream_t s) {
+inline void launch_amax_view(const float* v, long rows, int C, int cs, unsigned int* out, int stripes, hipStream_t s) {
     const long work = rows * C / 4;
     const unsigned nb = (unsigned)(work / 4096 < 32 ? 32 : (work / 4096 > 1024 ? 1024 : work / 4096));
-    hipLaunchKernelGGL(amax_view_kernel, dim3(nb), dim3(256), 0, s, v, rows, C, cs, out);
+    hipLaunchKernelGGL(amax_view_kernel, dim3(nb), dim3(256), 0, s, v, rows, C, cs, out, stripes);
 }
+}  // namespace
+void ss_launch_amax_view(const float* v, long rows, int C, int cs, unsigned int* out, int stripes, hipStream_t s) { launch_amax_view(v, rows, C, cs, out, stripes, s); }
+namespace {
+struct AmaxRef { const unsigned int* p; int stripes; };
 // maximum of an activation / gradient view for its x3h scale: into the caller's slot when there is one (computed only if the
 // caller does not vouch for its contents), else into `scratch`; returns the slot the kernels read
-const unsigned int* act_amax(const float* v, long rows, int C, int cs, unsigned int* ext, int ext_valid, unsigned int* scratch, hipStream_t s) {
+// A caller's slot is striped (SS_AMAX_STRIPES words, one per 256-byte line), the scratch word is not.
+AmaxRef act_amax(const float* v, long rows, int C, int cs, unsigned int* ext, int ext_valid, unsigned int* scratch, hipStream_t s) {
     unsigned int* slot = ext ? ext : scratch;
+    const int stripes = ext ? SS_AMAX_STRIPES : 1;
     if (!(ext && ext_valid)) {
-        (void)hipMemsetAsync(slot, 0, 4, s);
-        launch_amax_view(v, rows, C, cs, slot, s);
+        (void)hipMemsetAsync(slot, 0, ext ? (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4 : 4, s);
+        launch_amax_view(v, rows, C, cs, slot, stripes, s);
     }
-    return slot;
+    return AmaxRef{slot, stripes};
 }
 const unsigned int* weight_amax(const float* w, long wn, unsigned int* scratch, hipStream_t s, WCache* wc = nullptr) {
     bool fill;
     scratch = (unsigned int*)ss_wc_region(wc, ss_wc_tag(SS_WC_WAMAX, 0), 256, scratch, &fill);
     if (!fill) return scratch;
     (void)hipMemsetAsync(scratch, 0, 4, s);
-    hipLaunchKernelGGL(amax_view_kernel, dim3(wn / 8192 < 16 ? 16 : (wn / 8192 > 256 ? 256 : (unsigned)(wn / 8192))), dim3(256), 0, s, w, 1L, (int)wn, (int)wn, scratch);
+    hipLaunchKernelGGL(amax_view_kernel, dim3(wn / 8192 < 16 ? 16 : (wn / 8192 > 256 ? 256 : (unsigned)(wn / 8192))), dim3(256), 0, s, w, 1L, (int)wn, (int)wn, scratch, 1);
     return scratch;
 }
 bool x3h_direct_wanted(int algo, int cred, int cout) {
@@ -472,9 +478,9 @@ int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bia
     if (need_x_amax_fwd(c, algo) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p) + 256) {
         unsigned int* sl = (unsigned int*)((char*)ws + ss_gconv_x6_planes_bytes(p));
         const bool fill_only = c.wc && c.wc->fill_only;
-        const unsigned int* ax = fill_only ? sl : act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
+        const AmaxRef ax = fill_only ? AmaxRef{sl, 1} : act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
         if (use_x6(algo, p)) {
-            p.h_amax = ax;
+            p.h_amax = ax.p; p.amax_stripes = ax.stripes;
             p.h_amax2 = weight_amax(w, (long)c.kh * c.kw * c.cin * c.cout, sl + 1, s, c.wc);
         }
     }
@@ -535,7 +541,8 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     p.dtype = c.dtype;
     if (need_dy_amax_dgrad(c, algo) && gws_bytes >= x6_planes_ub(c.cout, c.cin, T)) {
         unsigned int* sl = (unsigned int*)((char*)gws + x6_planes_ub(c.cout, c.cin, T) - 256);
-        p.h_amax = (c.wc && c.wc->fill_only) ? sl : act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl, s);
+        const AmaxRef ay = (c.wc && c.wc->fill_only) ? AmaxRef{sl, 1} : act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl, s);
+        p.h_amax = ay.p; p.amax_stripes = ay.stripes;
         p.h_amax2 = weight_amax(w, (long)T * c.cin * c.cout, sl + 1, s, c.wc);
     }
 
@@ -738,9 +745,9 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
     p.pix_per_split = pps;
     if (need_amax_wgrad(c, algo)) {
         unsigned int* sl = (unsigned int*)((char*)ws + ss_align_up((size_t)p.splits * p.ntaps * p.Ca * p.Cb * sizeof(float), 256));
-        const unsigned int* ax = act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
-        const unsigned int* ay = act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl + 1, s);
-        if (p.x6 && ss_wgrad_x6_ok(p)) { p.h_amax = ax; p.h_amax2 = ay; }
+        const AmaxRef ax = act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
+        const AmaxRef ay = act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl + 1, s);
+        if (p.x6 && ss_wgrad_x6_ok(p)) { p.h_amax = ax.p; p.h_amax2 = ay.p; p.amax_stripes = ax.stripes; p.amax2_stripes = ay.stripes; }
     }
     return ss_launch_wgrad_mfma(p, dw, c.cout, accumulate, s);
 }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const bool ragged = Cq != p.Cin || (p.in_cs & 3) != 0 || (((uintptr_t)p.in) & 15) != 0;
     float a_scale = 1.f, out_scale = 1.f;
     if constexpr (H) {
-        const int ea = ss_amax_exp(__uint_as_float(p.h_amax[0])), ew = ss_amax_exp(__uint_as_float(p.h_amax2[0]));
+        const int ea = ss_amax_exp(__uint_as_float(ss_amax_load(p.h_amax, p.amax_stripes))), ew = ss_amax_exp(__uint_as_float(p.h_amax2[0]));
         a_scale = ldexpf(1.f, 14 - ea);
         out_scale = ldexpf(1.f, ea - 14 + ew - 14);
     }
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
     const int nchunks = (int)((pe - ps + XK - 1) / XK);
     float a_scale = 1.f, b_scale = 1.f, out_scale = 1.f;
     if constexpr (H) {
-        const int ea = ss_amax_exp(__uint_as_float(p.h_amax[0])), eb = ss_amax_exp(__uint_as_float(p.h_amax2[0]));
+        const int ea = ss_amax_exp(__uint_as_float(ss_amax_load(p.h_amax, p.amax_stripes))), eb = ss_amax_exp(__uint_as_float(ss_amax_load(p.h_amax2, p.amax2_stripes)));
         a_scale = ldexpf(1.f, 14 - ea);
         b_scale = ldexpf(1.f, 14 - eb);
         out_scale = ldexpf(1.f, ea - 14 + eb - 14);

@@ -76,6 +76,19 @@ template <int V> __device__ __forceinline__ void stv(__bf16* p, const float (&o)
     else *p = (__bf16)o[0];
 }
 
+// block maximum of a non-negative per-thread value -> caller's slot (bit pattern; non-negative floats order like unsigned ints).
+// One atomic per block, spread over the stripes of the slot.
+__device__ __forceinline__ void block_amax_to_slot(float m, unsigned int* __restrict__ slot) {
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int b = __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
+        atomicMax(slot + (blockIdx.x % SS_AMAX_STRIPES) * SS_AMAX_STRIDE, b);          // striped slot: see common.h
+    }
+}
+
 // partial sums: part[((g*chunks + chunk)*C + c)*2 + {0,1}]
 // MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat) with g = dy * act'(y)
 // Thread = V consecutive channels x a strided set of pixels; CT = channel lanes (in units of V), PT = 256/CT.
@@ -211,9 +224,11 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const T* __restrict__ res, int res_cs,
                                                          T* __restrict__ y, int y_cs,
-                                                         int act, float alpha, int C, long P, long rows) {
+                                                         int act, float alpha, int C, long P, long rows,
+                                                         unsigned int* __restrict__ amax = nullptr) {
     const int CV = C / V;
     const long total = rows * CV;
+    float am = 0.f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int c = (int)(e % CV) * V;
         const long row = e / CV;
@@ -230,9 +245,11 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
             float t = (xv[v] - mu[v]) * (rs[v] * (gamma ? gm[v] : 1.f)) + bt[v];
             if (res) t += rv[v];
             o[v] = ss_apply_act(t, act, alpha);
+            am = fmaxf(am, fabsf(o[v]));
         }
         stv<V>(y + row * y_cs + c, o);
     }
+    if (amax) block_amax_to_slot(am, amax);
 }
 
 // inference: statistics from moving mean / variance
@@ -308,9 +325,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              T* __restrict__ dx, int dx_cs, int acc_dx,
                                                              T* __restrict__ dres, int dres_cs, int acc_dres,
                                                              int act, float alpha, int C, long P, long rows,
-                                                             const float* __restrict__ rbeta = nullptr) {
+                                                             const float* __restrict__ rbeta = nullptr, unsigned int* __restrict__ amax = nullptr) {
     const int CV = C / V;
     const long total = rows * CV;
+    float am = 0.f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int c = (int)(e % CV) * V;
         const long row = e / CV;
@@ -342,6 +360,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
             const float xh = (xv[v] - mu[v]) * rs[v];
             const float dv = rs[v] * (gamma ? gm[v] : 1.f) * (gv[v] - sm[2 * v] - xh * sm[2 * v + 1]);
             o[v] = acc_dx ? o[v] + dv : dv;
+            am = fmaxf(am, fabsf(o[v]));
         }
         stv<V>(dx + row * dx_cs + c, o);
         if (dres) {
@@ -355,6 +374,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
             }
         }
     }
+    if (amax) block_amax_to_slot(am, amax);
 }
 
 // sums[(g*C+c)*2+k] = sum over chunks of part (raw sums, fp64 combine)
@@ -668,6 +688,7 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     const int V = pick_v(d->c, {d->x_cstride, d->y_cstride, residual ? d->res_cstride : 0},
                          {x, y, residual, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
+    unsigned int* yam = sizeof(T) == 4 ? (unsigned int*)d->y_amax : nullptr;        // max|y| for the next conv's x3h scale (fp32 storage only)
     if (norm_small(d)) {
         const int CL = small_cl(V);
         const dim3 grid((g.C + CL * V - 1) / (CL * V), g.G);
@@ -678,7 +699,7 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
             hipLaunchKernelGGL((norm_small_fwd_kernel<T, 1>), grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, residual, d->res_cstride, y,
                                d->y_cstride, mean, rstd, moving_mean, moving_var, momentum, d->eps, d->act, d->act_alpha, g.C, g.P, CL);
         SS_LAUNCH_CHECK();
-        return SS_OK;
+        return SS_OK;          // small groups: no maximum reported (ss_norm_reports_amax == 0)
     }
     float* part = (float*)ws;
     const dim3 sgrid(g.chunks, g.cblocks, g.G);
@@ -695,10 +716,10 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     const long rows = (long)g.G * g.P;
     if (V == 4)
         hipLaunchKernelGGL((norm_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows, yam);
     else
         hipLaunchKernelGGL((norm_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows, yam);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -731,6 +752,7 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
     const int V = pick_v(d->c, {d->x_cstride, dy_cstride, dx_cstride, use_y ? d->y_cstride : 0, dres ? d->res_cstride : 0},
                          {x, dy, dx, use_y ? y : nullptr, dres, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
+    unsigned int* dxam = sizeof(T) == 4 ? (unsigned int*)d->dx_amax : nullptr;      // max|dx| for the previous conv's x3h scales
     if (norm_small(d)) {
         const int CL = small_cl(V);
         const dim3 grid((g.C + CL * V - 1) / (CL * V));
@@ -762,11 +784,11 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
     if (V == 4)
         hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, rows, beta);
+                           d->act, d->act_alpha, g.C, g.P, rows, beta, dxam);
     else
         hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, rows, beta);
+                           d->act, d->act_alpha, g.C, g.P, rows, beta, dxam);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -884,6 +906,8 @@ int norm_bwd_finish_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, co
     }
 
 extern "C" {
+
+int ss_norm_reports_amax(const ss_norm_desc* d) { return valid(d) && d->dtype == SS_DTYPE_F32 && !norm_small(d) ? 1 : 0; }
 
 size_t ss_norm_workspace_bytes(const ss_norm_desc* d) {
     if (!valid(d)) return 0;

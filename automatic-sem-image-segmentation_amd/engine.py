@@ -94,6 +94,24 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
+_SLOT_POOLS = {}
+_SLOT_POOL_SIZE = 1024
+_SLOT_WORDS = 1024          # SS_AMAX_SLOT_BYTES / 4: 16 stripes, one per 256-byte line (include/semseg_hip.h)
+
+
+def _amax_slot(device):
+    """One zeroed amax slot from a pool of the CURRENT stream (one 4 MiB memset per 1024 slots instead of a fill per activation; a
+    pool is zeroed on the stream that first uses it, so its slots are only handed to work on that stream).  Slots are never
+    reused: a pool lives as long as any activation holds one of its slots."""
+    key = (device, _stream().value or 0)
+    pool = _SLOT_POOLS.get(key)
+    if pool is None or pool[1] >= _SLOT_POOL_SIZE:
+        pool = _SLOT_POOLS[key] = [torch.zeros(_SLOT_POOL_SIZE * _SLOT_WORDS, dtype=torch.int32, device=device), 0]
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i * _SLOT_WORDS:(i + 1) * _SLOT_WORDS]
+
+
 class Act:
     """An NHWC activation view: channels [c0, c0+c) of a base tensor [n,h,w,cs]."""
 
@@ -133,7 +151,7 @@ class Act:
         """Caller-owned slot for ss_conv_desc.x_amax / dy_amax: the first conv pass that needs this tensor's maximum leaves it
         here, later passes over the same (unchanged) tensor reuse it instead of scanning the tensor again."""
         if self.amax is None:
-            self.amax = torch.zeros(1, dtype=torch.int32, device=self.t.device)
+            self.amax = _amax_slot(self.t.device)
         return ctypes.c_void_p(self.amax.data_ptr())
 
     @staticmethod
@@ -163,6 +181,7 @@ class Act:
             elif not p.grad_init:
                 p.grad.t.zero_()
                 p.grad_init = True
+            p.grad.amax_valid = False
             return Act(p.grad.t, self.c0, self.c, False), 1
         if self.grad is None:
             self.grad = Act(torch.empty_like(self.t), self.c0, self.c, False)
@@ -170,7 +189,9 @@ class Act:
             return self.grad, 0
         if not self.grad_init:
             self.grad_init = True
+            self.grad.amax_valid = False
             return self.grad, 0
+        self.grad.amax_valid = False          # a second writer accumulates: a maximum reported by the first one is stale
         return self.grad, 1
 
     def get_grad(self):

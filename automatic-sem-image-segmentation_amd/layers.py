@@ -12,6 +12,7 @@ import torch
 from . import _lib as L
 from .engine import TIMER, Act, _p, _stream, workspace
 
+NORM_AMAX = os.environ.get("SS_NORM_AMAX", "1") != "0"            # 0: convolutions scan their operands for the x3h scales themselves (measurement)
 WEIGHT_CACHE = os.environ.get("SS_WEIGHT_CACHE", "1") != "0"      # 0: every pass derives its weight operands itself (measurement)
 
 # Cross-rank BatchNorm statistics (data parallel): set by dist.enable_sync_bn() to a callable that all-reduces (SUM) a
@@ -262,12 +263,20 @@ class Norm:
         self.arena, self.name, self.c, self.kind, self.scale = arena, name, c, kind, scale
         self.eps = eps if eps is not None else (1e-5 if kind == "instance" else 1e-3)
         self.momentum = momentum
+        self._amax_cache = {}
         if scale:
             arena.declare(f"{name}/gamma", (c,))
         arena.declare(f"{name}/beta", (c,))
         if kind == "batch":
             arena.declare(f"{name}/moving_mean", (c,), trainable=False)
             arena.declare(f"{name}/moving_variance", (c,), trainable=False)
+
+    def _reports_amax(self, d):
+        key = (d.n, d.h, d.w, d.groups, d.dtype, L.CONFIG_EPOCH)
+        r = self._amax_cache.get(key)
+        if r is None:
+            r = self._amax_cache[key] = bool(L.load().ss_norm_reports_amax(ctypes.byref(d)))
+        return r
 
     def __call__(self, tape, x, act=None, act_alpha=0.0, residual=None, out=None, training=True):
         lib = L.load()
@@ -294,10 +303,18 @@ class Norm:
         ws = workspace(nb, x.device)
         sync = SYNC_BN if self.kind == "batch" else None
         count = x.rows // groups
+        # the norm reports max|y| while it writes y (the next convolution's x3h scale): fp32, whole-tensor outputs only -- a channel
+        # slice of a concat buffer is read by its consumers together with its neighbours, under another view
+        reports = NORM_AMAX and sync is None and self._reports_amax(d)
+        want_amax = reports and y.parent is None and y.c0 == 0 and y.c == y.cs and y.amax is None
+        if want_amax:
+            d.y_amax = y.amax_slot()
         if sync is None:
             L.check(lib.ss_norm_fwd(ctypes.byref(d), x.ptr, _p(gamma), _p(beta), rp, y.ptr, _p(mean), _p(rstd),
                                     _p(mm), _p(mv), float(self.momentum), _p(ws), ws.numel(), _stream()),
                     f"norm_fwd[{self.name}]")
+            if want_amax:
+                y.amax_valid = True
         else:
             sums = torch.empty(groups * x.c * 2, dtype=torch.float32, device=x.device)
             L.check(lib.ss_norm_fwd_stats(ctypes.byref(d), x.ptr, _p(sums), _p(ws), ws.numel(), _stream()), "norm_fwd_stats")
@@ -319,6 +336,11 @@ class Norm:
                 dres, racc = residual.grad_target()
             db = L.NormDesc.from_buffer_copy(d)
             db.res_cstride = dres.cs if dres is not None else 0
+            db.y_amax = None
+            # max|dx| for the producing convolution's data / weight gradient: only when this op writes dx whole (a later
+            # accumulation into the same gradient clears the flag, engine.Act.grad_target)
+            dx_amax = reports and not accum and x.parent is None and dx.c0 == 0 and dx.c == dx.cs and dx.amax is None
+            db.dx_amax = dx.amax_slot() if dx_amax else None
             ws2 = workspace(lib.ss_norm_workspace_bytes(ctypes.byref(db)), x.device)
             ggam = self.arena.grad(f"{self.name}/gamma") if (self.scale and param_grads) else None
             gbet = self.arena.grad(f"{self.name}/beta") if param_grads else None
@@ -328,6 +350,8 @@ class Norm:
                 L.check(lib.ss_norm_bwd(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, yp, _p(gamma), _p(beta), _p(mean), _p(rstd),
                                         dx.ptr, dx.cs, accum, dres.ptr if dres is not None else None, racc,
                                         _p(ggam), _p(gbet), 1, _p(ws2), ws2.numel(), _stream()), f"norm_bwd[{self.name}]")
+                if dx_amax:
+                    dx.amax_valid = True
             else:
                 lsums = torch.empty(groups * x.c * 2, dtype=torch.float32, device=x.device)
                 L.check(lib.ss_norm_bwd_stats(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, y.ptr, _p(mean), _p(rstd), _p(lsums),

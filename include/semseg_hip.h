@@ -125,6 +125,12 @@ typedef struct ss_wcache {
 } ss_wcache;
 void ss_wcache_invalidate(ss_wcache* wc);
 
+/* An "amax slot" is SS_AMAX_SLOT_BYTES of device memory: 16 uint32 words, one per 256-byte line (word index 64 * i); the value it
+ * holds is the MAXIMUM of those words.  Producers (ss_norm_fwd / ss_norm_bwd, the scan inside the convolution passes) raise the
+ * words with one atomic per workgroup, spread over the lines -- thousands of atomics on a single address serialise in L2.
+ * A slot handed to a producer must be zero (or hold a lower bound). */
+#define SS_AMAX_SLOT_BYTES 4096
+
 typedef struct ss_conv_desc {
     uint32_t struct_size;            /* = sizeof(ss_conv_desc): a caller built against another layout gets SS_ERR_INVALID, not a wild read */
     int32_t dtype;                   /* ss_dtype of x / y / dy / dx */
@@ -137,7 +143,7 @@ typedef struct ss_conv_desc {
     int32_t act;
     float act_alpha;
     int32_t algo;
-    /* Optional (may be NULL / 0): caller-owned device uint32 slots for the bit pattern of max|x| and max|dy| -- the power-of-two
+    /* Optional (may be NULL / 0): caller-owned device SLOTS (SS_AMAX_SLOT_BYTES each, see below) for the bit pattern of max|x| and max|dy| -- the power-of-two
      * scales of the fp16 two-piece ("x3h") contraction.  A pass that needs a maximum (ss_conv2d_uses_amax) computes it INTO the
      * slot unless the matching *_valid flag says the slot already holds it, so that a tensor consumed by several passes (x:
      * forward + weight gradient, dy: data + weight gradient) is scanned once.  Without slots every pass scans for itself. */
@@ -186,9 +192,18 @@ typedef struct ss_norm_desc {
     float eps;
     int32_t act;
     float act_alpha;
+    /* Optional (may be NULL), fp32 activations only: caller-owned amax slots (SS_AMAX_SLOT_BYTES), ZERO (or a lower bound) on entry, that
+     * ss_norm_fwd / ss_norm_bwd raise to the bit pattern of max|y| / max|dx| while they write the tensor -- the power-of-two scale
+     * the next convolution's x3h contraction needs (ss_conv_desc::x_amax / dy_amax with the *_valid flag set), without another
+     * pass over the tensor.  dx_amax describes dx AFTER an accumulate_dx. */
+    void* y_amax;
+    void* dx_amax;
 } ss_norm_desc;
 
 size_t ss_norm_workspace_bytes(const ss_norm_desc* d);
+/* 1: ss_norm_fwd / ss_norm_bwd of this descriptor raise y_amax / dx_amax (the two-pass kernels; the one-launch kernels for small
+ * groups and the 16-bit storage types leave the slots untouched).  Pure function of d and the ss_config table. */
+int ss_norm_reports_amax(const ss_norm_desc* d);
 /* gamma may be NULL (scale=False); residual may be NULL.  mean/rstd: [groups*c] outputs kept for backward.
  * If moving_mean/moving_var are non-NULL (batch norm training) they are updated in place:
  * moving = moving*momentum + batch*(1-momentum), with the biased batch variance. */

@@ -381,3 +381,39 @@ def test_boundary_config_last_error_and_struct_size():
     assert rc == -1 and b"struct_size" in lib.ss_last_error()
     with pytest.raises(L.SemsegHipError, match="struct_size"):
         L.check(rc, "ss_conv2d_fwd")
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 40, 64), (2, 16, 16, 64), (1, 36, 36, 17)], ids=["two_pass", "one_launch", "odd_channels"])
+@pytest.mark.parametrize("kind", ["instance", "batch"])
+def test_norm_reports_the_maxima_of_what_it_writes(shape, kind):
+    """ss_norm_desc::y_amax / dx_amax: the bit patterns of max|y| and max|dx| exactly as a scan of the written tensors finds them
+    (they replace that scan for the x3h scales of the neighbouring convolutions)."""
+    E = importlib.import_module(BASE + ".engine")
+    LY = importlib.import_module(BASE + ".layers")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    arena = E.ParamArena(dev)
+    norm = LY.Norm(arena, "n", shape[3], kind)
+    arena.materialize()
+    arena["n/gamma"].copy_(torch.rand(shape[3], generator=g) + 0.5)
+    arena["n/beta"].copy_(torch.rand(shape[3], generator=g) - 0.5)
+    if kind == "batch":
+        arena["n/moving_variance"].fill_(1.0)
+    tape = E.Tape()
+    x = E.Act((torch.randn(shape, generator=g) * 3).to(dev), requires_grad=True)
+    y = norm(tape, x, act="lrelu", act_alpha=0.2)
+    gt, _ = y.grad_target()
+    gt.t.copy_(torch.randn(shape, generator=g).to(dev))
+    tape.backward()
+    torch.cuda.synchronize()
+    if shape[1] * shape[2] * (shape[0] if kind == "batch" else 1) <= 1024:
+        assert not y.amax_valid and not x.grad.amax_valid          # one-launch kernels for small groups report nothing
+        return
+    assert y.amax_valid and x.grad.amax_valid
+    want_y = y.dense().abs().max().view(torch.int32).item()
+    want_dx = x.grad.dense().abs().max().view(torch.int32).item()
+    assert y.amax.max().item() == want_y           # a slot holds the maximum spread over its stripes
+    assert x.grad.amax.max().item() == want_dx
+    # a second writer into the same gradient invalidates the reported maximum
+    x.grad_target()
+    assert not x.grad.amax_valid

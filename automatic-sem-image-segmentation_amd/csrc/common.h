@@ -163,13 +163,28 @@ struct X6PParams {
     int32_t fp16x2;               // 0: three bf16 planes, six products (x6);  1: two fp16 planes h + 2^-11 l, three products (x3h)
     int64_t a_plane, b_plane, a_bs, b_bs, c_bs, c_ss;
 };
+// C[batch][split][m][n] = sum_k A[batch][k][m] * B[batch][k][n] on K-major fp16 (h, l) planes (gemm_tn_x3h.hip)
+struct TNParams {
+    const unsigned short* a;      // [2 planes][batch][K][lda]   values a * 2^(14 - ea), ea = exponent(max|.| slot) + bound_a
+    const unsigned short* b;      // [2 planes][batch][K][ldb]
+    float* c;                     // [batch][split][M][N]
+    int32_t M, N, K, nbatch, splits, k_per_split;
+    int32_t lda, ldb;
+    int64_t a_plane, b_plane, a_bs, b_bs;
+    const unsigned int* amax_a;   // amax slots of the tensors the planes were derived from (striped or one word)
+    const unsigned int* amax_b;
+    int32_t stripes_a, stripes_b, bound_a, bound_b;
+};
+bool ss_gemm_tn_x3h_ok(int M, int N, long K);
+int ss_gemm_tn_splits(int M, int N, long K, int nbatch, int* k_per_split);
+int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s);
 bool ss_x6p_enabled();
 bool ss_x3h_enabled();
 bool ss_x6p_wanted(long M, int N, int nbatch);
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
 
 // kernel-selection switches: ONE explicit table, set through ss_config_set (config.hip); SS_* environment variables give the initial values
-struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache; };
+struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn; };
 const SsTuning& ss_tuning();
 // ss_prof_*: brackets the kernel launched inside this scope with HIP events on its stream when profiling is enabled (config.hip).
 // flops = EXECUTED matrix-instruction FLOPs of the launch (all piece products), bytes = algorithmic HBM bytes (0 if not stated)
@@ -258,7 +273,12 @@ struct WinoProb {
     int fold_h, fold_w;           // > 0: the (oh, ow) grid is a shifted padded gradient that the output transform folds onto an
                                   // (fold_h x fold_w) tensor (reflect-pad data gradient, conv_wino.hip wino_output_kernel)
     WCache* wc = nullptr;         // transformed weights are kept here across calls when set
+    // weight gradient on pre-split planes (ss_wino_wgrad_tn): maxima of x and dy (amax slots, striped or one word)
+    const unsigned int* x_amax = nullptr;
+    const unsigned int* dy_amax = nullptr;
+    int x_stripes = 0, dy_stripes = 0;
 };
+bool ss_wino_wgrad_tn(const WinoProb& q);
 
 // C[b][m][n] = sum_k (Ah+Al)[b][m][k] * (Bh+Bl)[b][n][k], bf16 planes, fp32 output (gemm_bf16x3.hip)
 struct BGemmParams {

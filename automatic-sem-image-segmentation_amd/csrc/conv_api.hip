@@ -654,7 +654,8 @@ bool need_dy_amax_dgrad(const ConvProb& c, int algo) {
 }
 bool need_amax_wgrad(const ConvProb& c, int algo) {
     WinoProb q;
-    if (c.kh * c.kw > SS_MAX_TAPS || algo == SS_ALGO_DIRECT || wino_fwd_prob(c, algo, &q) || wgrad_c1_mode(c, algo) >= 0 ||
+    if (c.kh * c.kw <= SS_MAX_TAPS && algo != SS_ALGO_DIRECT && wino_fwd_prob(c, algo, &q)) return ss_wino_wgrad_tn(q);
+    if (c.kh * c.kw > SS_MAX_TAPS || algo == SS_ALGO_DIRECT || wgrad_c1_mode(c, algo) >= 0 ||
         wgrad_two_stage(c, algo) || twgrad_takes(c, algo))
         return false;
     return x6_wanted(algo) && ss_x3h_enabled() && x3h_direct_wanted(algo, 32, 32) && c.cin % 32 == 0 && c.in_cs % 4 == 0 &&
@@ -697,7 +698,15 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
     if (ws_bytes < bwd_weight_ws(c) || !ws) return SS_ERR_WORKSPACE;
     {
         WinoProb q;
-        if (wino_fwd_prob(c, algo, &q)) return ss_wino_conv_wgrad(q, x, dy, dw, accumulate, ws, ws_bytes, s);
+        if (wino_fwd_prob(c, algo, &q)) {
+            if (ss_wino_wgrad_tn(q)) {        // pre-split planes need max|x| and max|dy| before the transforms run
+                unsigned int* sl = (unsigned int*)((char*)ws + ss_wino_wgrad_ws(q) - 256);
+                const AmaxRef ax = act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
+                const AmaxRef ay = act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl + 1, s);
+                q.x_amax = ax.p; q.x_stripes = ax.stripes; q.dy_amax = ay.p; q.dy_stripes = ay.stripes;
+            }
+            return ss_wino_conv_wgrad(q, x, dy, dw, accumulate, ws, ws_bytes, s);
+        }
     }
     {
         const int m = wgrad_c1_mode(c, algo);

@@ -123,7 +123,8 @@ __device__ __forceinline__ void block_amax(float v, unsigned int* out) {
 template <int R, int BF>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int in_cs, int N, int H, int W, int C,
                                                          int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V, long Mpad = 0,
-                                                         float* __restrict__ tile_inv = nullptr, unsigned int* __restrict__ amax_out = nullptr) {
+                                                         float* __restrict__ tile_inv = nullptr, unsigned int* __restrict__ amax_out = nullptr,
+                                                         const unsigned int* __restrict__ amax_in = nullptr, int amax_stripes = 0, int bound = 0) {
     typedef typename WT<R>::T T;
     constexpr int VW = WT<R>::VW, P = R + 2;
     const int CV = C / VW;
@@ -182,12 +183,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         x3h_scale = ldexpf(1.f, 14 - ex);
         if (c == 0) tile_inv[tile] = ldexpf(1.f, ex - 14);
     }
+    if (BF == 4)        // weight gradient: ONE scale for the whole transformed tensor, from max|in| and the transform's gain bound 2^bound
+        x3h_scale = ldexpf(1.f, 14 - (ss_amax_exp(__uint_as_float(ss_amax_load(amax_in, amax_stripes))) + bound));
     float vmax = 0.f;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         T v[P];
         t_in<R, T>(t[i], v);
-        if (BF == 3) {
+        if (BF == 3 || BF == 4) {
             // x3h: v*s = h + 2^-11 l with h, l fp16 and s = 2^e per TILE (all 36 positions, all channels) such that the largest
             // |v*s| of the tile lies in [2^13, 2^14): fp16 keeps 11 bits for everything within 2^-28 of the tile's maximum.
             // 1/s goes to tile_inv[tile]; the output transform multiplies it back (the GEMM is linear in each A row).
@@ -242,9 +245,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 }
 
 // E[xi][tile][c] = (A e A^T)_xi for the RxR tile e of dy (zero outside the dy extent)
-template <int R>
+// PL = 1: E as two fp16 planes [plane][xi][tile][c] of E * 2^(14 - (exponent(max|dy|) + bound)) (weight gradient on pre-split planes)
+template <int R, int PL = 0>
 __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, int dy_cs, int N, int OH, int OW, int C,
-                                                      int TH, int TW, float* __restrict__ E, unsigned int* __restrict__ amax_out = nullptr) {
+                                                      int TH, int TW, float* __restrict__ E, unsigned int* __restrict__ amax_out = nullptr,
+                                                      const unsigned int* __restrict__ amax_in = nullptr, int amax_stripes = 0, int bound = 0) {
     typedef typename WT<R>::T T;
     constexpr int VW = WT<R>::VW, P = R + 2;
     const int CV = C / VW;
@@ -273,18 +278,33 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
     const long xs = tiles * C;
     float* o = E + tile * C + c;
     float emax = 0.f;
+    float sc = 1.f;
+    if (PL == 1) sc = ldexpf(1.f, 14 - (ss_amax_exp(__uint_as_float(ss_amax_load(amax_in, amax_stripes))) + bound));
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         T w[P];
         t_dy<R, T>(a[i], w);
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            *(T*)(o + (long)(i * P + j) * xs) = w[j];
+            if (PL == 1) {
+                unsigned int* d = (unsigned int*)((unsigned short*)E + tile * C + c) + (long)(i * P + j) * xs / 2;
+                const long pl32 = (long)P * P * xs / 2;
 #pragma unroll
-            for (int k = 0; k < VW; ++k) emax = fmaxf(emax, fabsf(w[j][k]));
+                for (int k = 0; k < VW; k += 2) {
+                    const float v0 = w[j][k] * sc, v1 = w[j][k + 1] * sc;
+                    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+                    const _Float16 l0 = (_Float16)((v0 - (float)h0) * 2048.f), l1 = (_Float16)((v1 - (float)h1) * 2048.f);
+                    d[k / 2] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+                    d[pl32 + k / 2] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+            } else {
+                *(T*)(o + (long)(i * P + j) * xs) = w[j];
+#pragma unroll
+                for (int k = 0; k < VW; ++k) emax = fmaxf(emax, fabsf(w[j][k]));
+            }
         }
     }
-    if (amax_out) block_amax(emax, amax_out);      // launcher: whole blocks only
+    if (PL == 0 && amax_out) block_amax(emax, amax_out);      // launcher: whole blocks only
 }
 
 // U[xi][kr][no] = (G g G^T)_xi with g[kh][kw] = w[kh'][kw'][..]; flip = 0: (kr,no) = (ci,co); flip = 1 (backward-data):
@@ -710,6 +730,33 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
     float* V = (float*)ws;
     float* E = (float*)((char*)ws + ss_align_up((size_t)XI * tiles * q.cin * 4, 256));
     float* part = (float*)((char*)E + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
+    if (R == 4 && ss_wino_wgrad_tn(q) && q.x_amax && q.dy_amax) {
+        // both operands as K-major fp16 (h, l) planes, one power-of-two scale per tensor from max|x| / max|dy| and the gain bounds of
+        // the transforms (|B^T d B| <= 100 max|d| < 2^7, |A e A^T| <= 225 max|e| < 2^8), GEMM by LDS-DMA + transposing LDS reads
+        constexpr int BOUND_X = 7, BOUND_DY = 8;
+        hipLaunchKernelGGL((wino_input_kernel<R, 4>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
+                           q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL((wino_dy_kernel<R, 1>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, E,
+                           nullptr, q.dy_amax, q.dy_stripes, BOUND_DY);
+        SS_LAUNCH_CHECK();
+        TNParams g{};
+        g.a = (const unsigned short*)V; g.b = (const unsigned short*)E; g.c = part;
+        g.M = q.cin; g.N = q.cout; g.K = (int)tiles; g.nbatch = XI;
+        g.lda = q.cin; g.ldb = q.cout;
+        g.a_plane = (long)XI * tiles * q.cin; g.b_plane = (long)XI * tiles * q.cout;
+        g.a_bs = tiles * q.cin; g.b_bs = tiles * q.cout;
+        int kps;
+        g.splits = ss_gemm_tn_splits(q.cin, q.cout, tiles, XI, &kps);
+        g.k_per_split = kps;
+        g.amax_a = q.x_amax; g.stripes_a = q.x_stripes; g.bound_a = BOUND_X;
+        g.amax_b = q.dy_amax; g.stripes_b = q.dy_stripes; g.bound_b = BOUND_DY;
+        const int rc = ss_launch_gemm_tn_x3h(g, s);
+        if (rc != SS_OK) return rc;
+        hipLaunchKernelGGL(wino_dw_kernel<R>, dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, part, g.splits, q.cin, q.cout, dw, accumulate);
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+    }
     // x3h weight gradient: the GEMM splits both operands in-kernel with one scale per operand, from the maxima the transforms report
     unsigned int* am = nullptr;
     if (q.x6 && ss_x3h_enabled() && (tiles * (q.cin / VW)) % 256 == 0 && (tiles * (q.cout / VW)) % 256 == 0) {
@@ -770,11 +817,18 @@ int ss_wino_conv_fwd(const WinoProb& q, const float* x, const float* w, int w_ci
     return fwd_impl<4>(q, x, w, w_cin, w_cout, flip, bias, y, act, alpha, accumulate, ws, s);
 }
 
+// Weight gradient on pre-split K-major planes (gemm_tn_x3h.hip): F(4x4,3x3), x3h arithmetic, shapes the 256 x 128 x 32 tiles divide
+bool ss_wino_wgrad_tn(const WinoProb& q) {
+    return ss_tuning().wgrad_tn && wino_r() == 4 && q.x6 && !q.bf16x3 && ss_x3h_enabled() && q.cin % 4 == 0 && q.cout % 4 == 0 &&
+           ss_gemm_tn_x3h_ok(q.cin, q.cout, n_tiles(q, 4));
+}
+
 size_t ss_wino_wgrad_ws(const WinoProb& q) {
     const int R = wino_r(), XI = (R + 2) * (R + 2);
     const long tiles = n_tiles(q, R);
     int pps;
-    const int splits = ss_wgrad_mfma_splits(tiles, q.cin, q.cout, &pps, XI);
+    int splits = ss_wgrad_mfma_splits(tiles, q.cin, q.cout, &pps, XI);
+    if (ss_wino_wgrad_tn(q)) { int kps; const int s2 = ss_gemm_tn_splits(q.cin, q.cout, tiles, XI, &kps); if (s2 > splits) splits = s2; }
     return ss_align_up((size_t)XI * tiles * q.cin * 4, 256) + ss_align_up((size_t)XI * tiles * q.cout * 4, 256) +
            ss_align_up((size_t)XI * (splits + 1) * q.cin * q.cout * 4, 256) + 256;      // + the x3h amax slot (last 256 bytes)
 }

@@ -1,0 +1,235 @@
+// Batched "TN" GEMM with the x3h arithmetic on operands that are ALREADY split into two fp16 planes, K-MAJOR:
+//     C[batch][split][m][n] = sum_{k in split} A[batch][k][m] * B[batch][k][n],      a*b = ah*bh + 2^-11 (ah*bl + al*bh)
+// This is the Winograd-domain weight gradient (conv_wino.hip): k = tile, m = input channel, n = output channel -- the reduction
+// index is the SLOW index of both operands ([xi][tile][channel] planes written by the input / dy transforms), which is what made
+// the register-staged kernel (conv_mfma_x6.hip wgrad_x6_kernel: transposing LDS stores + in-kernel split) VALU-bound.  Here the
+// stage is the operands' natural image, rows of k with the channels contiguous, moved global -> LDS by LDS-DMA with no register
+// pass, and the MFMA fragments come out of it with gfx950's TRANSPOSING LDS read: ds_read_b64_tr_b16 hands lane i of a 16-lane
+// group column i of the 4 (k) x 16 (channel) block whose rows the group's lanes address (lane j: row j/4, columns 4 (j%4) .. +3)
+// -- measured with tools/tr_probe.hip.  Two such reads give a lane the 8 k-values of its channel that v_mfma_f32_32x32x16_f16
+// wants; WHICH eight k they are is free as long as both operands use the same assignment (the product sums over k).
+//
+// Tile 256 (M) x 128 (N) x 32 (K), 512 threads = 8 waves as 4 (M) x 2 (N), 64x64 per wave; stage = 2 planes x (32 x 256 + 32 x 128)
+// halfs = 48 KiB, ring of three stages (two tiles in flight behind the one being consumed), ONE barrier per K step -- the
+// schedule of gemm_x6p.hip.
+// LDS image of a plane: [32 k][BM or BN channels] fp16, row = 512 B (A) / 256 B (B).  The 32 lanes of one LDS cycle of the
+// transposing read touch 4 consecutive k rows x 64 B: the rows would fall on the same banks, so the 64-byte segments of a row are
+// XOR-swizzled with (k & 3), on the DMA source address and on the read address alike.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TBM = 256, TBN = 128, TBK = 32;
+constexpr int TA_ROW = TBM * 2, TB_ROW = TBN * 2;            // bytes per k row
+constexpr int TA_PLANE = TBK * TA_ROW, TB_PLANE = TBK * TB_ROW;      // 16 KiB, 8 KiB
+constexpr int TSTAGE = 2 * (TA_PLANE + TB_PLANE);           // 48 KiB
+constexpr int TSTAGES = 3;
+constexpr int TNDMA = TSTAGE / 1024 / 8;                    // 6 LDS-DMA instructions per wave and K step
+
+__device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ s16x4 tr4(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int gridM = p.M / TBM, gridN = p.N / TBN;
+    int tile;
+    {   // XCD-aware order (speed only): a contiguous chunk of the tile space per XCD; the splits of one (batch, m, n) tile and the
+        // n tiles of one m tile (same A rows) are neighbours
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int per = gridM * gridN;
+    const int bs = tile / per;
+    tile -= bs * per;
+    const int batch = bs / p.splits, split = bs - batch * p.splits;
+    const int m0 = (tile / gridN) * TBM, n0 = (tile % gridN) * TBN;
+    const int k_begin = split * p.k_per_split;
+    const int k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
+    const int nchunks = (k_end - k_begin) / TBK;
+
+    // this wave's share of a stage: 6 pieces of 1 KiB.  Pieces 0..15 / 16..31: A plane h / l (2 k rows each), 32..39 / 40..47: B
+    // plane h / l (4 k rows each).  Lane j of a piece lands on bytes [16 j, 16 j + 16) of the piece.
+    const unsigned short* gp[TNDMA];
+    int loff[TNDMA];
+#pragma unroll
+    for (int j = 0; j < TNDMA; ++j) {
+        const int q = wave * TNDMA + j;
+        if (q < 32) {
+            const int pl = q >> 4, pc = q & 15;
+            const int row = 2 * pc + (lane >> 5);
+            const int pseg = (lane & 31) >> 2;                          // physical 64-byte segment of the row
+            const int col = ((pseg ^ (row & 3)) * 64 + (lane & 3) * 16) / 2;      // logical channel offset
+            gp[j] = p.a + pl * p.a_plane + batch * p.a_bs + (long)(k_begin + row) * p.lda + m0 + col;
+            loff[j] = pl * TA_PLANE + pc * 1024;
+        } else {
+            const int q2 = q - 32;
+            const int pl = q2 >> 3, pc = q2 & 7;
+            const int row = 4 * pc + (lane >> 4);
+            const int pseg = (lane & 15) >> 2;
+            const int col = ((pseg ^ (row & 3)) * 64 + (lane & 3) * 16) / 2;
+            gp[j] = p.b + pl * p.b_plane + batch * p.b_bs + (long)(k_begin + row) * p.ldb + n0 + col;
+            loff[j] = 2 * TA_PLANE + pl * TB_PLANE + pc * 1024;
+        }
+    }
+
+    f32x16 acc[2][2][2];          // [0]: h*h, [1]: the cross terms (they carry the factor 2^-11)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][mi][ni][r] = 0.f;
+
+    // fragment read addresses.  Lane l, read rr (0 / 1), K half kh: k row = 16 kh + 8 (l >> 5) + 4 rr + ((l & 15) >> 2),
+    // channel = (wave tile) + 32 mi + 16 ((l >> 4) & 1) + 4 (l & 3).  k & 3 = (l & 15) >> 2 for every read: ONE swizzle term per lane.
+    const int kr = 8 * lh + ((lane & 15) >> 2);            // + 16 kh + 4 rr
+    const int sw = (lane & 15) >> 2;
+    const int ca = wm * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);      // + 32 mi
+    const int cb = wn * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    int oa[2], ob[2];            // byte offsets inside a plane for mi / ni = 0, 1 at k row kr
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int a2 = (ca + 32 * i) * 2, b2 = (cb + 32 * i) * 2;
+        oa[i] = kr * TA_ROW + (((a2 >> 6) ^ sw) << 6) + (a2 & 63);
+        ob[i] = kr * TB_ROW + (((b2 >> 6) ^ sw) << 6) + (b2 & 63);
+    }
+
+    f16x8 a0[2][2], b0[2][2], a1[2][2], b1[2][2];          // [plane][mi / ni]
+    auto frag = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][2], int stage, int kh) {
+        const unsigned char* sa = lds + stage * TSTAGE + kh * 16 * TA_ROW;
+        const unsigned char* sb = lds + stage * TSTAGE + 2 * TA_PLANE + kh * 16 * TB_ROW;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const s16x4 x0 = tr4(sa + pl * TA_PLANE + oa[i]), x1 = tr4(sa + pl * TA_PLANE + oa[i] + 4 * TA_ROW);
+                a[pl][i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const s16x4 y0 = tr4(sb + pl * TB_PLANE + ob[i]), y1 = tr4(sb + pl * TB_PLANE + ob[i] + 4 * TB_ROW);
+                b[pl][i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        }
+    };
+    // l*h, h*l (cross accumulators), h*h; consecutive MFMAs go to different accumulators
+    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0}, HS[3] = {1, 1, 0};
+    auto mma4 = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][2], int q) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[HS[q]][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], acc[HS[q]][mi][ni], 0, 0, 0);
+    };
+
+    long kstep[TNDMA];          // elements per K step of the operand a piece belongs to
+#pragma unroll
+    for (int j = 0; j < TNDMA; ++j) kstep[j] = (long)TBK * (wave * TNDMA + j < 32 ? p.lda : p.ldb);
+
+    if (nchunks > 0) {          // tiles 0 .. 2 (indices past the end re-fetch the last tile: the group count stays fixed)
+#pragma unroll
+        for (int t = 0; t < TSTAGES; ++t) {
+            const int tt = t < nchunks ? t : nchunks - 1;
+#pragma unroll
+            for (int j = 0; j < TNDMA; ++j) dma16(gp[j] + tt * kstep[j], lds + t * TSTAGE + loff[j]);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TSTAGES - 1) * TNDMA) : "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (nchunks > 0) frag(a0, b0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+
+    int st = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int st1 = st + 1 == TSTAGES ? 0 : st + 1;
+        frag(a1, b1, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) mma4(a0, b0, q);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070 | (((TSTAGES - 2) * TNDMA) & 15));      // vmcnt(6) lgkmcnt(0): tile c+1 landed, own reads of tile c done
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        frag(a0, b0, st1, 0);
+        const int cn = c + TSTAGES < nchunks ? c + TSTAGES : nchunks - 1;
+        unsigned char* dst = lds + st * TSTAGE;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            mma4(a1, b1, q);
+#pragma unroll
+            for (int j = 0; j < TNDMA; ++j)
+                if (j * 3 / TNDMA == q) dma16(gp[j] + cn * kstep[j], dst + loff[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+        st = st1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // scales: the planes hold a * 2^(14 - ea) and b * 2^(14 - eb) (conv_wino.hip, same slots, same bounds)
+    const int ea = ss_amax_exp(__uint_as_float(ss_amax_load(p.amax_a, p.stripes_a))) + p.bound_a;
+    const int eb = ss_amax_exp(__uint_as_float(ss_amax_load(p.amax_b, p.stripes_b))) + p.bound_b;
+    const float out_scale = ldexpf(1.f, ea - 14 + eb - 14);
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* cbase = p.c + ((long)batch * p.splits + split) * p.M * p.N;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                cbase[(long)m * p.N + n] = fmaf(acc[1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]) * out_scale;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool ss_gemm_tn_x3h_ok(int M, int N, long K) { return M % TBM == 0 && N % TBN == 0 && K % TBK == 0 && K >= TBK; }
+
+// splits of the K range: enough workgroups for ~4 rounds over the 256 CUs, at least 8 K steps per split
+int ss_gemm_tn_splits(int M, int N, long K, int nbatch, int* k_per_split) {
+    const long tiles = (long)(M / TBM) * (N / TBN) * nbatch;
+    const long steps = K / TBK;
+    long sp = (1024 + tiles - 1) / tiles;
+    if (sp > steps / 8) sp = steps / 8;
+    if (sp < 1) sp = 1;
+    long per = (steps + sp - 1) / sp;
+    sp = (steps + per - 1) / per;
+    *k_per_split = (int)(per * TBK);
+    return (int)sp;
+}
+
+int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s) {
+    if (!ss_gemm_tn_x3h_ok(p.M, p.N, p.K) || p.k_per_split % TBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
+    static const bool attr_set = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+    }();
+    (void)attr_set;
+    const long nwg = (long)(p.M / TBM) * (p.N / TBN) * p.nbatch * p.splits;
+    SsProfScope prof("gemm_tn_x3h_kernel", 2.0 * p.M * p.N * p.K * p.nbatch * 3,
+                     2.0 * 2 * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
+    hipLaunchKernelGGL(gemm_tn_x3h_kernel, dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}

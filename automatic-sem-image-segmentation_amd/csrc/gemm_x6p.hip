@@ -30,10 +30,16 @@ __device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+constexpr int x6p_stages(int npl) { return npl == 2 ? 3 : 2; }
+
 template <int NPL>
 __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
     constexpr int STAGE_B = NPL * (A_PLANE_B + B_PLANE_B);
     constexpr int NDMA = STAGE_B / 1024 / 8;       // LDS-DMA instructions per wave and K step (9 / 6)
+    // Ring of LDS stages.  The K loop is paced by the operand stream, not by the matrix pipe: one stage in flight (two stages) is
+    // 48 KiB per CU against ~2 us of loaded HBM / Infinity-Cache latency = 6 TB/s chip-wide, measured 5.96.  x3h stages are 48 KiB,
+    // so three fit into the 160 KiB: two tiles in flight while the third is consumed.
+    constexpr int STAGES = x6p_stages(NPL);
     typedef typename Frag<NPL>::T FT;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -134,35 +140,36 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
             }
     };
 
-    if (nchunks > 0) {
+    if (nchunks > 0) {          // tiles 0 .. STAGES-1 (indices past the end re-fetch the last tile: the group count stays fixed)
 #pragma unroll
-        for (int j = 0; j < NDMA; ++j) dma16(gp[j], lds + loff[j]);
-    }
-    if (nchunks > 1) {
+        for (int t = 0; t < STAGES; ++t) {
+            const long goff = (long)(t < nchunks ? t : nchunks - 1) * PBK;
 #pragma unroll
-        for (int j = 0; j < NDMA; ++j) dma16(gp[j] + PBK, lds + STAGE_B + loff[j]);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");      // tile 0 landed, tile 1 may be in flight
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int j = 0; j < NDMA; ++j) dma16(gp[j] + goff, lds + t * STAGE_B + loff[j]);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * NDMA) : "memory");      // tile 0 landed, the others may be in flight
     }
     __builtin_amdgcn_s_barrier();
     if (nchunks > 0) frag(a0, b0, 0, so0);
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
 
+    int st = 0;
     for (int c = 0; c < nchunks; ++c) {
-        const int st = c & 1;
+        const int st1 = st + 1 == STAGES ? 0 : st + 1;
         frag(a1, b1, st, so1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): a real s_waitcnt, so that the compiler's own counting sees it
+        // tile c+1 landed (the younger groups may still be in flight) and this wave's reads of tile c are done: a real s_waitcnt
+        // (vmcnt((STAGES-2) * NDMA) lgkmcnt(0)), so that the compiler's own counting sees it
+        __builtin_amdgcn_s_waitcnt(0x0070 | (((STAGES - 2) * NDMA) & 15) | ((((STAGES - 2) * NDMA) >> 4) << 14));
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // branch-free from here to the loop end (one basic block keeps the compiler's lgkmcnt counting exact): past the last
         // tile the fragment read fetches stale LDS and the DMA re-fetches the last tile into the stage nobody reads any more
-        frag(a0, b0, st ^ 1, so0);
-        const int cn = c + 2 < nchunks ? c + 2 : nchunks - 1;
+        frag(a0, b0, st1, so0);
+        const int cn = c + STAGES < nchunks ? c + STAGES : nchunks - 1;
         const long goff = (long)cn * PBK;
         unsigned char* dst = lds + st * STAGE_B;
 #pragma unroll
@@ -175,6 +182,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
         }
         // F0's reads finished long ago (24 MFMAs back): a free wait that lets the compiler start the next step without one
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+        st = st1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may still be landing when the LDS is handed to the next workgroup
 
@@ -232,8 +240,8 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     const long nwg = (long)gridM * gridN * p.nbatch * p.splits;
     SsProfScope prof(p.fp16x2 ? "gemm_x6p_kernel<2>" : "gemm_x6p_kernel<3>", 2.0 * p.M * p.N * p.K * p.nbatch * (p.fp16x2 ? 3 : 6),
                      2.0 * (p.fp16x2 ? 2 : 3) * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
-    if (p.fp16x2) hipLaunchKernelGGL(gemm_x6p_kernel<2>, dim3((unsigned)nwg), dim3(512), 2 * 2 * (A_PLANE_B + B_PLANE_B), s, p);
-    else hipLaunchKernelGGL(gemm_x6p_kernel<3>, dim3((unsigned)nwg), dim3(512), 2 * 3 * (A_PLANE_B + B_PLANE_B), s, p);
+    if (p.fp16x2) hipLaunchKernelGGL(gemm_x6p_kernel<2>, dim3((unsigned)nwg), dim3(512), x6p_stages(2) * 2 * (A_PLANE_B + B_PLANE_B), s, p);
+    else hipLaunchKernelGGL(gemm_x6p_kernel<3>, dim3((unsigned)nwg), dim3(512), x6p_stages(3) * 3 * (A_PLANE_B + B_PLANE_B), s, p);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -224,6 +224,9 @@ def oracle_conv(x, w, k, stride, padding, transposed):
 ADV_CASES = [
     # name, k, cin, cout, stride, padding, transposed, n, h, w
     ("trunk_wino_per_tile", 3, 128, 128, 1, ("reflect", 1), False, 2, 48, 48),
+    # 256 channels, 2 x 8 x 8 = 128 Winograd tiles: the weight gradient takes the pre-split-plane path (gemm_tn_x3h.hip: one scale per
+    # tensor from max|x| / max|dy| and the transforms' gain bounds)
+    ("trunk_wino_wgrad_tn", 3, 256, 256, 1, ("reflect", 1), False, 2, 32, 32),
     ("disc_4x4_s2_per_tensor", 4, 64, 128, 2, "valid", False, 2, 66, 66),
     ("up_T3_per_tensor", 3, 64, 32, 2, "same", True, 2, 32, 32),
     ("tile_3x3_16_16_per_tile", 3, 16, 16, 1, "same", False, 1, 256, 256),      # conv_tile.hip: one scale per 8x32 pixel tile

@@ -96,6 +96,8 @@ def kernel_peak(name):
         return "f16_mfma"        # x3h: v_mfma_f32_32x32x16_f16
     if name.startswith(("gemm_x6p", "gconv_x6", "wgrad_x6")):
         return "bf16_mfma"       # x6: v_mfma_f32_32x32x16_bf16
+    if name.startswith("gemm_tn_x3h"):
+        return "f16_mfma"        # Winograd weight gradient on pre-split planes: v_mfma_f32_32x32x16_f16, three piece products
     if name.startswith("tconv_kernel"):
         return "f16_mfma"        # tile kernels: v_mfma_f32_32x32x16_f16 (x3h piece products for fp32 storage, one product for 16-bit storage)
     return "f32_mfma"

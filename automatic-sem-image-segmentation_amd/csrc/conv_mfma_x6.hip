@@ -576,7 +576,8 @@ int launch_wgrad_x6h(const WGradParams& p, hipStream_t s) {
     }();
     (void)attr_set;
     char pname[64];
-    snprintf(pname, sizeof(pname), "wgrad_x6_kernel<%d,%s>", BN, H ? "true" : "false");
+    if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "wgrad_x6<%d,%d> M%d N%d K%ld b%d", BN, (int)H, M, p.Cb, (long)p.N * p.GH * p.GW, p.nbatch);
+    else snprintf(pname, sizeof(pname), "wgrad_x6_kernel<%d,%s>", BN, H ? "true" : "false");
     const double pix = (double)p.N * p.GH * p.GW * (p.nbatch > 1 ? p.nbatch : 1);
     SsProfScope prof(pname, 2.0 * M * p.Cb * pix * (H ? 3 : 6), 4.0 * pix * (p.Ca + p.Cb) + 4.0 * M * p.Cb * p.splits, s);
     hipLaunchKernelGGL((wgrad_x6_kernel<BN, H>), grid, dim3(256), smem, s, p);
@@ -601,7 +602,8 @@ int launch_x6h(const GConvParams& p, const unsigned short* planes, long plane_el
     }();
     (void)attr_set;
     char pname[64];
-    snprintf(pname, sizeof(pname), "gconv_x6_kernel<%d,%d,%s>", BM, BN, H ? "true" : "false");
+    if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_x6<%d,%d,%d> M%ld N%d K%dx%d s%d b%d", BM, BN, (int)H, M, p.Cout, p.ntaps, p.Cin, p.in_s, nb);
+    else snprintf(pname, sizeof(pname), "gconv_x6_kernel<%d,%d,%s>", BM, BN, H ? "true" : "false");
     SsProfScope prof(pname, 2.0 * M * p.Cout * p.ntaps * p.Cin * nb * (H ? 3 : 6),
                      4.0 * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout + (double)p.ntaps * p.Cin * p.Cout), s);
     hipLaunchKernelGGL((gconv_x6_kernel<BM, BN, H>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot);

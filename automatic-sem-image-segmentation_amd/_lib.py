@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsemseg_hip.so")
+LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_HERE, "libsemseg_hip.so")      # SS_LIB_PATH: diagnostic builds only
 
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t

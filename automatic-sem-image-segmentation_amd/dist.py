@@ -46,6 +46,22 @@ def init_from_env(backend=None):
     dist.init_process_group(backend=backend)
 
 
+# MEASUREMENT ONLY (bench.py `multi_gpu.exposed_comm_ms`): skip every data-path collective, so that a step's time without its
+# exchange can be subtracted from the real one.  Results are wrong while it is set (ranks drift apart); never set it in training.
+SKIP_COLLECTIVES = False
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _all_reduce(t, async_op=False):
+    if SKIP_COLLECTIVES:
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
 def all_reduce_flat(flat, bucket_elems=BUCKET_ELEMS):
     """Sum ``flat`` (1-D tensor) over ranks in large buckets, all launched before any is waited for."""
     if world_size() == 1:
@@ -53,7 +69,7 @@ def all_reduce_flat(flat, bucket_elems=BUCKET_ELEMS):
     works = []
     n = flat.numel()
     for off in range(0, n, bucket_elems):
-        works.append(dist.all_reduce(flat[off:min(off + bucket_elems, n)], op=dist.ReduceOp.SUM, async_op=True))
+        works.append(_all_reduce(flat[off:min(off + bucket_elems, n)], async_op=True))
     for w in works:
         w.wait()
 
@@ -65,7 +81,7 @@ def enable_overlap(nets):
     if world_size() == 1:
         return
     for net in nets:
-        net.arena.grad_hook = lambda flat: dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        net.arena.grad_hook = lambda flat: _all_reduce(flat, async_op=True)
 
 
 def begin_backward(nets):
@@ -95,10 +111,10 @@ def begin_all_reduce_grads(nets):
         if a.grad_hook is None:
             n = a.grads.numel()
             step = 64 * 1024 * 1024 // 4
-            works += [dist.all_reduce(a.grads[off:min(off + step, n)], op=dist.ReduceOp.SUM, async_op=True) for off in range(0, n, step)]
+            works += [_all_reduce(a.grads[off:min(off + step, n)], async_op=True) for off in range(0, n, step)]
         else:
             works += a.works
-            works += [dist.all_reduce(a.grads[b["start"]:b["end"]], op=dist.ReduceOp.SUM, async_op=True)
+            works += [_all_reduce(a.grads[b["start"]:b["end"]], async_op=True)
                       for b in a.buckets if b["active"] and not b["fired"]]
         a.works = []
         a.pending = {}
@@ -128,7 +144,7 @@ def broadcast_params(nets, src=0):
 
 def mean_scalars(values):
     """Average a small numpy vector of per-rank scalar means over ranks (equal per-rank batch sizes)."""
-    if world_size() == 1:
+    if world_size() == 1 or SKIP_COLLECTIVES:
         return values
     dev = local_device() if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.as_tensor(np.asarray(values, dtype=np.float64), device=dev)
@@ -144,7 +160,7 @@ def enable_sync_bn(enabled=True):
 
     def _allreduce(t):
         if world_size() > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            _all_reduce(t)
         return world_size()
 
     layers.SYNC_BN = _allreduce if enabled else None

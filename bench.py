@@ -151,8 +151,10 @@ def main():
     OPT = importlib.import_module(PKG + ".optim")
     if world > 1:
         # the exchange really runs over RCCL with one rank per GPU
-        assert torch.distributed.get_backend() == "nccl" and torch.distributed.get_world_size() == args.gpus
-        assert torch.cuda.device_count() >= args.gpus, "one GPU per rank"
+        assert torch.distributed.get_world_size() == args.gpus
+        if os.environ.get("SS_BENCH_TEST_TRANSPORT") != "gloo":          # tests/test_dp_gpu.py runs 2 ranks on the 1-GPU box over gloo
+            assert torch.distributed.get_backend() == "nccl", "the benchmark exchanges over RCCL"
+            assert torch.cuda.device_count() >= args.gpus, "one GPU per rank"
 
     S, GB, F = args.size, args.global_batch, args.filters
     D.check_batch_divisible(GB, world, "--global-batch")
@@ -217,6 +219,25 @@ def main():
     median_ms = max_over_ranks(statistics.median(per_step)) * 1e3
 
     extras = {}
+    if world > 1:
+        # per-rank view + what the exchange costs: the same steps once more with every data-path collective skipped
+        # (dist.SKIP_COLLECTIVES, measurement only -- the ranks' weights drift apart, nothing of it enters `value`)
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = statistics.median(per_step) * 1e3
+        torch.distributed.all_reduce(t)
+        k = max(3, min(args.steps, 5))
+        D.SKIP_COLLECTIVES = True
+        step()
+        _, nc_t = timed(k)
+        D.SKIP_COLLECTIVES = False
+        nc_ms = max_over_ranks(statistics.median(nc_t)) * 1e3
+        D.broadcast_params([ga, gb, da, db, unet])          # re-align the replicas after the measurement
+        step()
+        extras["multi_gpu"] = {"per_rank_median_ms_per_step": [round(float(v), 3) for v in t.tolist()],
+                               "median_ms_per_step_without_collectives": round(nc_ms, 3),
+                               "exposed_comm_ms_per_step": round(median_ms - nc_ms, 3),
+                               "collectives": "gradient all-reduce (32 MiB buckets, launched during backward) + SyncBN statistics "
+                                              "(2 all-reduces of 2C floats per BatchNorm layer) + one metrics all-reduce per step, RCCL"}
     if not args.no_extras and not args.only_unet and not args.skip_unet:
         k = max(3, min(args.steps, 5))
         _, cg_t = timed(k, cyclegan=True, unet_=False)

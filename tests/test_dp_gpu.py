@@ -80,3 +80,25 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path):
         den += float((one[k].astype(np.float64) ** 2).sum())
         assert float(np.abs(two[k] - one[k]).max()) <= 2.2e-3, k      # one Adam step: |delta| <= ~lr, both signs
     assert (num / den) ** 0.5 <= 1e-3
+
+
+def test_bench_two_ranks_reports_per_rank_times_and_exposed_communication(tmp_path):
+    """bench.py's N > 1 path (per-rank medians, the no-collectives leg, replica re-alignment) on 2 ranks sharing cuda:0 over gloo --
+    the transport differs from the driver's RCCL run, the code path is the same."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29747", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2",
+               SS_DIST_BACKEND="gloo", SS_BENCH_TEST_TRANSPORT="gloo")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64", "--global-batch", "2",
+           "--filters", "8", "--no-cpu-baseline"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              cwd=REPO) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["config"]["per_gpu_batch"] == 1 and j["value"] > 0
+    mg = j["multi_gpu"]
+    assert len(mg["per_rank_median_ms_per_step"]) == 2 and all(v > 0 for v in mg["per_rank_median_ms_per_step"])
+    assert mg["median_ms_per_step_without_collectives"] > 0 and "exposed_comm_ms_per_step" in mg
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")], "only rank 0 prints the result line"

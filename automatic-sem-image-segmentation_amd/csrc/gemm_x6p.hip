@@ -49,27 +49,32 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
     const int wm = wave >> 1, wn = wave & 1;
 
     const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + PBN - 1) / PBN;
-    int tile;
-    {   // XCD-aware order (speed only): a contiguous chunk of the tile space per XCD, N fastest
+    const int per = gridM * gridN;
+    // XCD-aware order (speed only): a contiguous chunk of the tile space per XCD, N fastest.  PERSISTENT workgroups: when the grid
+    // is smaller than the tile count (one workgroup per CU, see the launcher) a workgroup walks its XCD's chunk with stride
+    // (workgroups per XCD), so that the workgroups of an XCD keep working on neighbouring tiles, and its operand stream runs on
+    // across the tile boundary: the last K steps of a tile already fetch the first chunks of the next one, the epilogue stores of
+    // a tile overlap with that fetch, and no pipeline fill / workgroup launch is paid per tile.
+    const int total = per * p.nbatch * p.splits;
+    int t_first, t_end, t_stride;
+    {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        const int q = total >> 3, r = total & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        if (nwg == total) { t_first = start + slot; t_end = t_first + 1; t_stride = 1; }
+        else { t_first = start + slot; t_end = start + q + (xcd < r ? 1 : 0); t_stride = nwg >> 3; }
     }
-    const int per = gridM * gridN;
-    const int bs = tile / per;
-    tile -= bs * per;
-    const int batch = bs / p.splits, split = bs - batch * p.splits;
-    const int m0 = (tile / gridN) * PBM, n0 = (tile % gridN) * PBN;
-    const int k_begin = split * p.k_per_split;
-    const int k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
-    const int nchunks = (k_end - k_begin) / PBK;
-
-    // this wave's share of a stage: NDMA pieces of 16 rows (per plane: A 16 pieces, B 8)
-    const unsigned short* gp[NDMA];
-    int loff[NDMA];
-    {
-        const int rl = lane >> 2, sl = lane & 3;
+    const int rl = lane >> 2, sl = lane & 3;
+    // per-tile set-up: this wave's share of a stage = NDMA pieces of 16 rows (per plane: A 16 pieces, B 8); m0 / n0 / output base
+    struct TileCtx { int m0, n0, nchunks; long cbase; };
+    auto setup = [&](int t, const unsigned short* (&g)[NDMA]) -> TileCtx {
+        const int bs = t / per;
+        const int tl = t - bs * per;
+        const int batch = bs / p.splits, split = bs - batch * p.splits;
+        const int m0 = (tl / gridN) * PBM, n0 = (tl % gridN) * PBN;
+        const int k_begin = split * p.k_per_split;
+        const int k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) {
             const int q = wave * NDMA + j;
@@ -77,28 +82,30 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
                 const int pl = q / (PBM / 16), rb = q % (PBM / 16);
                 const int row = rb * 16 + rl;
                 const int ko = sl ^ ((row >> 2) & 3);
-                gp[j] = p.a + pl * p.a_plane + batch * p.a_bs + (long)(m0 + row) * p.lda + k_begin + 8 * ko;
-                loff[j] = pl * A_PLANE_B + rb * 1024;
+                g[j] = p.a + pl * p.a_plane + batch * p.a_bs + (long)(m0 + row) * p.lda + k_begin + 8 * ko;
             } else {
                 const int q2 = q - NPL * (PBM / 16);
                 const int pl = q2 / (PBN / 16), rb = q2 % (PBN / 16);
                 const int row = rb * 16 + rl;
                 const int ko = sl ^ ((row >> 2) & 3);
-                gp[j] = p.b + pl * p.b_plane + batch * p.b_bs + (long)(n0 + row) * p.ldb + k_begin + 8 * ko;
-                loff[j] = NPL * A_PLANE_B + pl * B_PLANE_B + rb * 1024;
+                g[j] = p.b + pl * p.b_plane + batch * p.b_bs + (long)(n0 + row) * p.ldb + k_begin + 8 * ko;
             }
         }
+        return TileCtx{m0, n0, (k_end - k_begin) / PBK, (long)batch * p.c_bs + (long)split * p.c_ss};
+    };
+    int loff[NDMA];
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+        const int q = wave * NDMA + j;
+        if (q < NPL * (PBM / 16)) loff[j] = (q / (PBM / 16)) * A_PLANE_B + (q % (PBM / 16)) * 1024;
+        else { const int q2 = q - NPL * (PBM / 16); loff[j] = NPL * A_PLANE_B + (q2 / (PBN / 16)) * B_PLANE_B + (q2 % (PBN / 16)) * 1024; }
     }
+    const unsigned short* gp[NDMA];
+    const unsigned short* gpn[NDMA];
+    if (t_first >= t_end) return;
+    TileCtx cur = setup(t_first, gp);
     constexpr int NACC = NPL == 2 ? 2 : 1;          // x3h: the cross terms h*l + l*h accumulate apart (they carry the factor 2^-11)
     f32x16 acc[NACC][2][2];
-#pragma unroll
-    for (int s = 0; s < NACC; ++s)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[s][mi][ni][r] = 0.f;
 
     // operand fetch addresses (stage 0): row = (wave tile base) + l31, slot = (lh + 2*ks) ^ ((row >> 2) & 3)
     const int sw = (l31 >> 2) & 3;
@@ -140,67 +147,95 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
             }
     };
 
-    if (nchunks > 0) {          // tiles 0 .. STAGES-1 (indices past the end re-fetch the last tile: the group count stays fixed)
+    // pipeline fill for the first tile of this workgroup (chunk indices past the end re-fetch the last chunk: fixed group count)
+    {
+        const int nchunks = cur.nchunks;
 #pragma unroll
         for (int t = 0; t < STAGES; ++t) {
             const long goff = (long)(t < nchunks ? t : nchunks - 1) * PBK;
 #pragma unroll
             for (int j = 0; j < NDMA; ++j) dma16(gp[j] + goff, lds + t * STAGE_B + loff[j]);
         }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * NDMA) : "memory");      // tile 0 landed, the others may be in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * NDMA) : "memory");      // chunk 0 landed, the others may be in flight
     }
-    __builtin_amdgcn_s_barrier();
-    if (nchunks > 0) frag(a0, b0, 0, so0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
-
     int st = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        const int st1 = st + 1 == STAGES ? 0 : st + 1;
-        frag(a1, b1, st, so1);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int t = t_first; t < t_end; t += t_stride) {
+        const int nchunks = cur.nchunks;
+        const bool more = t + t_stride < t_end;
+        TileCtx nxt = cur;
+        if (more) nxt = setup(t + t_stride, gpn);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
-        __builtin_amdgcn_sched_barrier(0);
-        // tile c+1 landed (the younger groups may still be in flight) and this wave's reads of tile c are done: a real s_waitcnt
-        // (vmcnt((STAGES-2) * NDMA) lgkmcnt(0)), so that the compiler's own counting sees it
-        __builtin_amdgcn_s_waitcnt(0x0070 | (((STAGES - 2) * NDMA) & 15) | ((((STAGES - 2) * NDMA) >> 4) << 14));
+        for (int s = 0; s < NACC; ++s)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[s][mi][ni][r] = 0.f;
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // branch-free from here to the loop end (one basic block keeps the compiler's lgkmcnt counting exact): past the last
-        // tile the fragment read fetches stale LDS and the DMA re-fetches the last tile into the stage nobody reads any more
-        frag(a0, b0, st1, so0);
-        const int cn = c + STAGES < nchunks ? c + STAGES : nchunks - 1;
-        const long goff = (long)cn * PBK;
-        unsigned char* dst = lds + st * STAGE_B;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            mma4(a1, b1, q);
-#pragma unroll
-            for (int j = 0; j < NDMA; ++j)
-                if (j * NQ / NDMA == q) dma16(gp[j] + goff, dst + loff[j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // F0's reads finished long ago (24 MFMAs back): a free wait that lets the compiler start the next step without one
-        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
-        st = st1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may still be landing when the LDS is handed to the next workgroup
+        frag(a0, b0, st, so0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* cb = p.c + (long)batch * p.c_bs + (long)split * p.c_ss;
+        for (int c = 0; c < nchunks; ++c) {
+            const int st1 = st + 1 == STAGES ? 0 : st + 1;
+            frag(a1, b1, st, so1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + wn * 64 + ni * 32 + l31;
-        if (n >= p.N) continue;
+            for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
+            __builtin_amdgcn_sched_barrier(0);
+            // chunk c+1 landed (the younger groups may still be in flight) and this wave's reads of chunk c are done: a real
+            // s_waitcnt (vmcnt((STAGES-2) * NDMA) lgkmcnt(0)), so that the compiler's own counting sees it
+            __builtin_amdgcn_s_waitcnt(0x0070 | (((STAGES - 2) * NDMA) & 15) | ((((STAGES - 2) * NDMA) >> 4) << 14));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // branch-free from here to the loop end (one basic block keeps the compiler's lgkmcnt counting exact): past the last
+            // chunk of the LAST tile the fragment read fetches stale LDS and the DMA re-fetches the last chunk into a free stage;
+            // past the last chunk of any other tile both continue with the NEXT tile's first chunks
+            frag(a0, b0, st1, so0);
+            const int ca = c + STAGES;
+            const bool own = ca < nchunks;
+            const int cn = own ? ca : (more ? ca - nchunks : nchunks - 1);
+            const long goff = (long)cn * PBK;
+            unsigned char* dst = lds + st * STAGE_B;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+            for (int q = 0; q < NQ; ++q) {
+                mma4(a1, b1, q);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M) cb[(long)m * p.ldc + n] = NPL == 3 ? acc[0][mi][ni][r] : fmaf(acc[NACC - 1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
+                for (int j = 0; j < NDMA; ++j)
+                    if (j * NQ / NDMA == q) dma16(((own || !more) ? gp[j] : gpn[j]) + goff, dst + loff[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // F0's reads finished long ago (24 MFMAs back): a free wait that lets the compiler start the next step without one
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+            st = st1;
+        }
+
+        // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The stores are younger than
+        // the next tile's first chunk groups (issued in the last K steps above): waiting for those does not wait for the stores.
+        float* cb = p.c + cur.cbase;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = cur.n0 + wn * 64 + ni * 32 + l31;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = cur.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < p.M) cb[(long)m * p.ldc + n] = NPL == 3 ? acc[0][mi][ni][r] : fmaf(acc[NACC - 1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
+                }
             }
         }
+        if (more) {
+            // chunk 0 of the next tile must have landed before the barrier at the top: it is one of the oldest outstanding groups
+            // (up to 64 stores are younger): vmcnt(63) lets at most the stores minus one stay in flight
+            asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < NDMA; ++j) gp[j] = gpn[j];
+            cur = nxt;
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may still be landing when the LDS is handed to the next workgroup
 }
 
 }  // namespace
@@ -237,7 +272,11 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
         return true;
     }();
     (void)attr_set;
-    const long nwg = (long)gridM * gridN * p.nbatch * p.splits;
+    const long tiles = (long)gridM * gridN * p.nbatch * p.splits;
+    // one workgroup per CU (the LDS ring fills a CU): more tiles than CUs -> persistent workgroups (a multiple of 8: one share per XCD)
+    static const int n_cu = [] { int v = 0; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0); return v >= 8 ? v / 8 * 8 : 256; }();
+    const bool persistent = ss_tuning().gemm_persistent && tiles > n_cu && p.k_per_split >= 3 * PBK && p.K % p.k_per_split == 0;
+    const long nwg = persistent ? n_cu : tiles;
     SsProfScope prof(p.fp16x2 ? "gemm_x6p_kernel<2>" : "gemm_x6p_kernel<3>", 2.0 * p.M * p.N * p.K * p.nbatch * (p.fp16x2 ? 3 : 6),
                      2.0 * (p.fp16x2 ? 2 : 3) * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
     if (p.fp16x2) hipLaunchKernelGGL(gemm_x6p_kernel<2>, dim3((unsigned)nwg), dim3(512), x6p_stages(2) * 2 * (A_PLANE_B + B_PLANE_B), s, p);

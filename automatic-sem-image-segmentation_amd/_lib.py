@@ -38,14 +38,18 @@ class ConvDesc(_SizedDesc):
                 # optional x3h slots (include/semseg_hip.h): device uint32 with the bit pattern of max|x| / max|dy| + "already computed" flags
                 ("x_amax", c_vp), ("dy_amax", c_vp), ("x_amax_valid", c_i32), ("dy_amax_valid", c_i32),
                 # optional weight cache of the layer (ss_wcache: transformed / split weights kept across calls)
-                ("w_cache", c_vp)]
+                ("w_cache", c_vp),
+                # optional output statistics (sum y, sum y^2 per sample and channel) written by the forward epilogue
+                ("y_stats", c_vp)]
 
 
 class NormDesc(_SizedDesc):
     _fields_ = [("struct_size", ctypes.c_uint32), ("dtype", c_i32)] + [(n, c_i32) for n in ("n", "h", "w", "c", "x_cstride", "y_cstride", "res_cstride", "groups")] + \
                [("eps", c_f32), ("act", c_i32), ("act_alpha", c_f32),
                 # optional slots the norm raises to max|y| (forward) / max|dx| (backward) while writing the tensor (x3h scales)
-                ("y_amax", c_vp), ("dx_amax", c_vp)]
+                ("y_amax", c_vp), ("dx_amax", c_vp),
+                # optional input statistics from the producing convolution's epilogue (ss_conv_desc.y_stats)
+                ("x_stats", c_vp), ("x_stats_chunks", c_i32), ("reserved0", c_i32)]
 
 
 class ProfEntry(ctypes.Structure):
@@ -98,6 +102,7 @@ SIGNATURES = {
     "ss_prof_get": (c_i32, [c_i32, ctypes.POINTER(ProfEntry)]),
     "ss_conv2d_workspace_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_uses_amax": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
+    "ss_conv2d_stats_chunks": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "ss_conv2d_wcache_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_wcache_invalidate": (None, [ctypes.POINTER(WCache)]),
     "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -277,8 +277,10 @@ struct WinoProb {
     const unsigned int* x_amax = nullptr;
     const unsigned int* dy_amax = nullptr;
     int x_stripes = 0, dy_stripes = 0;
+    float* y_stats = nullptr;     // forward: partial (sum y, sum y^2) per sample / chunk / channel from the output transform
 };
 bool ss_wino_wgrad_tn(const WinoProb& q);
+int ss_wino_stats_chunks(const WinoProb& q);
 
 // C[b][m][n] = sum_k (Ah+Al)[b][m][k] * (Bh+Bl)[b][n][k], bf16 planes, fp32 output (gemm_bf16x3.hip)
 struct BGemmParams {

@@ -19,6 +19,7 @@ struct ConvProb {
     int x_valid = 0, dy_valid = 0;
     int dtype = SS_DTYPE_F32;      // storage type of x / y / dy / dx: 16-bit only ever reaches the tile kernels (see ss_conv2d_fwd)
     WCache* wc = nullptr;          // caller-owned cache of the weight-derived operands of this pass (ss_conv_desc::w_cache)
+    float* y_stats = nullptr;      // forward: output statistics for a following norm (ss_conv_desc::y_stats)
 };
 
 // ---- small helper kernels -----------------------------------------------------------------------
@@ -472,6 +473,7 @@ int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bia
     WinoProb q;
     if (wino_fwd_prob(c, algo, &q)) {
         q.wc = c.wc;
+        q.y_stats = c.y_stats;
         return ss_wino_conv_fwd(q, x, w, c.cin, c.cout, 0, bias, y, act, alpha, accumulate, ws, ws_bytes, s);
     }
     GConvParams p = fwd_params(c, x, w, bias, y, act, alpha, accumulate);
@@ -877,6 +879,15 @@ size_t conv2d_wcache_bytes32(const ss_conv_desc* d, int pass) {
     const ConvProb c = d->transposed ? adjoint(d) : plain(d);
     return fwd_like ? fwd_wcache(c, d->algo) : bwd_data_wcache(c, d->algo);
 }
+// chunks per sample of the output statistics the forward pass can emit (ss_conv_desc::y_stats): Winograd forward only
+int conv2d_stats_chunks32(const ss_conv_desc* d) {
+    if (!valid_desc(d) || d->transposed || d->act != SS_ACT_NONE) return 0;
+    const ConvProb c = plain(d);
+    WinoProb q;
+    if (c.kh * c.kw > SS_MAX_TAPS || !wino_fwd_prob(c, d->algo, &q)) return 0;
+    return ss_wino_stats_chunks(q);
+}
+
 // the layer's weight cache when the descriptor carries a usable one
 WCache* desc_wcache(const ss_conv_desc* d) {
     ss_wcache* wc = d->w_cache;
@@ -890,6 +901,7 @@ int conv2d_fwd32(const ss_conv_desc* d, const float* x, const float* w, const fl
     hipStream_t s = (hipStream_t)stream;
     ConvProb c = d->transposed ? adjoint(d) : plain(d);
     c.wc = desc_wcache(d);
+    if (!d->transposed && d->act == SS_ACT_NONE && conv2d_stats_chunks32(d) > 0) c.y_stats = (float*)d->y_stats;
     if (!d->transposed) return conv_fwd(c, x, w, bias, y, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
     return conv_bwd_data(c, x, w, y, bias, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
 }
@@ -943,6 +955,7 @@ ConvShim make_shim(const ss_conv_desc* d, void* ws, size_t ws_bytes) {
     sh.d32.in_cstride = d->cin;
     sh.d32.out_cstride = d->cout;
     sh.d32.x_amax = sh.d32.dy_amax = nullptr;
+    sh.d32.y_stats = nullptr;
     sh.d32.x_amax_valid = sh.d32.dy_amax_valid = 0;
     sh.a_bytes = ss_align_up((size_t)d->n * d->ih * d->iw * d->cin * sizeof(float), 256);
     sh.b_bytes = ss_align_up((size_t)d->n * d->oh * d->ow * d->cout * sizeof(float), 256);
@@ -1022,6 +1035,11 @@ size_t ss_conv2d_workspace_bytes(const ss_conv_desc* d, int pass) {
         }
     }
     return need;
+}
+
+int ss_conv2d_stats_chunks(const ss_conv_desc* d) {
+    if (!valid_desc_any(d) || d->dtype != SS_DTYPE_F32) return 0;
+    return conv2d_stats_chunks32(d);
 }
 
 size_t ss_conv2d_wcache_bytes(const ss_conv_desc* d, int pass) {

@@ -460,7 +460,8 @@ template <int R>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, int N, int OH, int OW, int C, int TH, int TW,
                                                           const float* __restrict__ bias, int act, float alpha,
                                                           float* __restrict__ y, int y_cs, int accumulate, int FH, int FW,
-                                                          const float* __restrict__ tile_inv = nullptr, const float* __restrict__ w_inv = nullptr) {
+                                                          const float* __restrict__ tile_inv = nullptr, const float* __restrict__ w_inv = nullptr,
+                                                          float* __restrict__ stats = nullptr) {
     // FH > 0 ("reflect fold", data gradient of reflect-pad(1) + 3x3 valid conv): the OH x OW grid is the PADDED gradient shifted by
     // one (virtual o' = P + 1, P in [0, FH+1]); padded pixel P lands on dx[reflect(P - 1)].  With FH % R == 0 the two padded
     // rows that fold onto the same dx row (P = 0,2 and P = FH-1,FH+1) sit in ONE tile, i.e. one thread: they are summed in
@@ -529,6 +530,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
             }
         return;
     }
+    float s1[VW], s2[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         T o[R];
@@ -545,7 +549,30 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                 T* dst = (T*)(y + ((long)(n * OH + oy) * OW + ox) * y_cs + c);
                 if (accumulate) v += *dst;
                 *dst = v;
+#pragma unroll
+                for (int k = 0; k < VW; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
             }
+        }
+    }
+    if (stats) {
+        // statistics of what was just written, for the norm that follows: a block holds 256 / CV whole tiles of ONE sample (launcher);
+        // their sums are combined in fixed order and written as one chunk [n][chunk][C][2] (the layout of norm.hip's partials)
+        __shared__ float red[256][2 * VW];
+#pragma unroll
+        for (int k = 0; k < VW; ++k) { red[threadIdx.x][2 * k] = s1[k]; red[threadIdx.x][2 * k + 1] = s2[k]; }
+        __syncthreads();
+        if ((int)threadIdx.x < CV) {
+            float a[2 * VW];
+#pragma unroll
+            for (int k = 0; k < 2 * VW; ++k) a[k] = red[threadIdx.x][k];
+            for (int t = 1; t < 256 / CV; ++t)
+#pragma unroll
+                for (int k = 0; k < 2 * VW; ++k) a[k] += red[t * CV + threadIdx.x][k];
+            const int bps = TH * TW * CV / 256;            // blocks (= chunks) per sample
+            float* o = stats + ((long)blockIdx.x * C + c) * 2;            // blockIdx.x = n * bps + chunk
+            (void)bps;
+#pragma unroll
+            for (int k = 0; k < 2 * VW; ++k) o[k] = a[k];
         }
     }
 }
@@ -599,6 +626,8 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     float* U = (float*)ws;
     float* V = (float*)((char*)ws + ss_align_up((size_t)XI * q.cin * q.cout * 4, 256));
     float* Mx = (float*)((char*)V + ss_align_up((size_t)XI * tiles * q.cin * 4, 256));
+    // output statistics for a following norm: only where the output transform's blocks hold whole tiles of one sample
+    float* stats = (q.y_stats && act == SS_ACT_NONE && !accumulate && ss_wino_stats_chunks(q) > 0) ? q.y_stats : nullptr;
     bool fill;      // transformed weights: in the layer's cache when there is one (computed on first use)
     const uint64_t wdet = (uint64_t)(flip ? 1 : 0) | ((uint64_t)R << 1);
     const bool fill_only = q.wc && q.wc->fill_only;       // refresh of the cached operands: no activation work
@@ -677,7 +706,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         const int rcx = ss_launch_gemm_x6p(g, s);
         if (rcx != SS_OK) return rcx;
         hipLaunchKernelGGL(wino_output_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
-                           bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w, tile_inv, w_inv);
+                           bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w, tile_inv, w_inv, stats);
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
@@ -717,7 +746,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     }
     if (rc != SS_OK) return rc;
     hipLaunchKernelGGL(wino_output_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
-                       bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w);
+                       bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w, (const float*)nullptr, (const float*)nullptr, stats);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -815,6 +844,17 @@ int ss_wino_conv_fwd(const WinoProb& q, const float* x, const float* w, int w_ci
     if (!ws || ws_bytes < ss_wino_fwd_ws(q)) return SS_ERR_WORKSPACE;
     if (wino_r() == 2) return fwd_impl<2>(q, x, w, w_cin, w_cout, flip, bias, y, act, alpha, accumulate, ws, s);
     return fwd_impl<4>(q, x, w, w_cin, w_cout, flip, bias, y, act, alpha, accumulate, ws, s);
+}
+
+// Chunks per sample of the output statistics the forward output transform can emit: F(4x4,3x3) / F(2x2,3x3) on a plain (not folded)
+// output grid whose 256-thread blocks hold whole tiles of one sample
+int ss_wino_stats_chunks(const WinoProb& q) {
+    if (q.fold_h > 0 || q.bf16x3) return 0;
+    const int R = wino_r(), VW = R == 4 ? 2 : 4, CV = q.cout / VW;          // WT<R>::VW channels per thread of the output transform
+    if (q.cout % VW || CV > 256 || 256 % CV) return 0;
+    const int tps = ((q.oh + R - 1) / R) * ((q.ow + R - 1) / R), tpb = 256 / CV;
+    if (tps % tpb) return 0;
+    return tps / tpb;
 }
 
 // Weight gradient on pre-split K-major planes (gemm_tn_x3h.hip): F(4x4,3x3), x3h arithmetic, shapes the 256 x 128 x 32 tiles divide

@@ -701,17 +701,25 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
         SS_LAUNCH_CHECK();
         return SS_OK;          // small groups: no maximum reported (ss_norm_reports_amax == 0)
     }
-    float* part = (float*)ws;
-    const dim3 sgrid(g.chunks, g.cblocks, g.G);
-    if (V == 4)
-        hipLaunchKernelGGL((norm_stats_kernel<T, 0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                           0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
-    else
-        hipLaunchKernelGGL((norm_stats_kernel<T, 0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                           0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part);
-    SS_LAUNCH_CHECK();
+    const float* part = (const float*)ws;
+    int chunks = g.chunks;
+    if (d->x_stats && d->x_stats_chunks > 0) {
+        // the producing convolution's epilogue already summed x and x^2 ([n][chunks][c][2]; groups = 1: the samples' chunks follow
+        // one another, i.e. n * chunks chunks of the one group)
+        part = (const float*)d->x_stats;
+        chunks = d->x_stats_chunks * (d->n / g.G);
+    } else {
+        const dim3 sgrid(g.chunks, g.cblocks, g.G);
+        if (V == 4)
+            hipLaunchKernelGGL((norm_stats_kernel<T, 0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                               0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, (float*)ws);
+        else
+            hipLaunchKernelGGL((norm_stats_kernel<T, 0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                               0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, (float*)ws);
+        SS_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + FIN_CL - 1) / FIN_CL, g.G), dim3(256), 0, s,
-                       part, g.chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum, FIN_CL);
+                       part, chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum, FIN_CL);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
     if (V == 4)

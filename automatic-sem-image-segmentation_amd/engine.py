@@ -115,7 +115,7 @@ def _amax_slot(device):
 class Act:
     """An NHWC activation view: channels [c0, c0+c) of a base tensor [n,h,w,cs]."""
 
-    __slots__ = ("t", "c0", "c", "grad", "grad_init", "requires_grad", "parent", "amax", "amax_valid", "dt")
+    __slots__ = ("t", "c0", "c", "grad", "grad_init", "requires_grad", "parent", "amax", "amax_valid", "dt", "stats")
 
     def __init__(self, t, c0=0, c=None, requires_grad=True, parent=None):
         assert t.dim() == 4 and t.is_contiguous()
@@ -126,8 +126,9 @@ class Act:
         self.grad_init = False
         self.requires_grad = requires_grad
         self.parent = parent
-        self.amax = None          # device uint32[1]: bit pattern of max|view| once a conv pass has computed it (x3h scale)
+        self.amax = None          # amax slot: bit pattern of max|view| once a producer / conv pass has computed it (x3h scale)
         self.amax_valid = False
+        self.stats = None         # (tensor, chunks per sample): partial (sum, sum of squares) per sample and channel from the producing conv
 
     # geometry
     @property

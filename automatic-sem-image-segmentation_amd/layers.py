@@ -12,6 +12,7 @@ import torch
 from . import _lib as L
 from .engine import TIMER, Act, _p, _stream, workspace
 
+CONV_STATS = os.environ.get("SS_CONV_STATS", "1") != "0"          # 0: norms always run their own statistics pass (measurement)
 NORM_AMAX = os.environ.get("SS_NORM_AMAX", "1") != "0"            # 0: convolutions scan their operands for the x3h scales themselves (measurement)
 WEIGHT_CACHE = os.environ.get("SS_WEIGHT_CACHE", "1") != "0"      # 0: every pass derives its weight operands itself (measurement)
 
@@ -102,8 +103,17 @@ class Conv2D:
             d.x_amax, d.x_amax_valid = None, 0
         d.dy_amax, d.dy_amax_valid = None, 0
         wst = self._attach_wcache(d, L.PASS_FWD)
+        # statistics of the output for a following norm, taken in the epilogue that writes y (where the path can: Winograd forward)
+        sc = self._stats_chunks(d) if (CONV_STATS and y.parent is None and y.c0 == 0 and y.c == y.cs) else 0
+        if sc:
+            st = torch.empty(y.n * sc * self.cout * 2, dtype=torch.float32, device=y.device)
+            d.y_stats = st.data_ptr()
+        else:
+            d.y_stats = None
         L.check(lib.ss_conv2d_fwd(ctypes.byref(d), x.ptr, _p(w), _p(b), y.ptr, _p(ws), ws.numel(), _stream()),
                 f"conv2d_fwd[{self.name}]")
+        if sc:
+            y.stats = (st, sc)
         self._wcache_done(wst)
         if uses & 1:
             x.amax_valid = True
@@ -233,6 +243,13 @@ class Conv2D:
             c.fill_only = 0
         return len(st["users"])
 
+    def _stats_chunks(self, d):
+        key = (d.n, d.ih, d.iw, d.in_cstride, d.out_cstride, d.dtype, "stats", L.CONFIG_EPOCH)
+        u = self._amax_cache.get(key)
+        if u is None:
+            u = self._amax_cache[key] = int(L.load().ss_conv2d_stats_chunks(ctypes.byref(d)))
+        return u
+
     def _uses_amax(self, d, pass_):
         """ss_conv2d_uses_amax(d, pass), cached per geometry: bit 0 = the pass reads (and leaves in the slot) max|x|, bit 1 = max|dy|."""
         key = (d.n, d.ih, d.iw, d.in_cstride, d.out_cstride, d.oh, d.ow, pass_, L.CONFIG_EPOCH)
@@ -309,6 +326,8 @@ class Norm:
         want_amax = reports and y.parent is None and y.c0 == 0 and y.c == y.cs and y.amax is None
         if want_amax:
             d.y_amax = y.amax_slot()
+        if sync is None and x.stats is not None and x.parent is None:
+            d.x_stats, d.x_stats_chunks = x.stats[0].data_ptr(), x.stats[1]
         if sync is None:
             L.check(lib.ss_norm_fwd(ctypes.byref(d), x.ptr, _p(gamma), _p(beta), rp, y.ptr, _p(mean), _p(rstd),
                                     _p(mm), _p(mv), float(self.momentum), _p(ws), ws.numel(), _stream()),

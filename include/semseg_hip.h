@@ -153,8 +153,16 @@ typedef struct ss_conv_desc {
     int32_t dy_amax_valid;
     /* Optional (may be NULL): weight cache of the layer this descriptor belongs to, see ss_wcache below. */
     struct ss_wcache* w_cache;
+    /* Optional (may be NULL), forward pass only: caller-owned fp32 buffer [n][ss_conv2d_stats_chunks(d)][cout][2] that receives
+     * partial sums (sum y, sum y^2) of the OUTPUT per sample and channel, taken in the epilogue that writes y -- the statistics
+     * pass of a following InstanceNorm / BatchNorm (ss_norm_desc::x_stats) then has nothing left to read ("fused IN + conv":
+     * CycleGAN.py:327-329, 333-335).  Only written when ss_conv2d_stats_chunks(d) > 0. */
+    void* y_stats;
 } ss_conv_desc;
 
+/* Chunks per sample of the output statistics the FORWARD pass of `d` can emit (0: this descriptor's path cannot -- anything but
+ * an fp32 Winograd convolution without fused activation, today).  Pure function of d and the ss_config table. */
+int ss_conv2d_stats_chunks(const ss_conv_desc* d);
 /* Upper bound of the device bytes the pass keeps in the layer's weight cache (0: nothing, e.g. the weight gradient). */
 size_t ss_conv2d_wcache_bytes(const ss_conv_desc* d, int pass);
 
@@ -198,6 +206,12 @@ typedef struct ss_norm_desc {
      * pass over the tensor.  dx_amax describes dx AFTER an accumulate_dx. */
     void* y_amax;
     void* dx_amax;
+    /* Optional (may be NULL / 0), ss_norm_fwd only: partial sums (sum x, sum x^2) of the input as a convolution's epilogue wrote
+     * them (ss_conv_desc::y_stats), [n][x_stats_chunks][c][2]; the forward then skips its own statistics pass (the one-launch
+     * kernels for small groups ignore it). */
+    const void* x_stats;
+    int32_t x_stats_chunks;
+    int32_t reserved0;
 } ss_norm_desc;
 
 size_t ss_norm_workspace_bytes(const ss_norm_desc* d);

@@ -420,3 +420,49 @@ def test_norm_reports_the_maxima_of_what_it_writes(shape, kind):
     # a second writer into the same gradient invalidates the reported maximum
     x.grad_target()
     assert not x.grad.amax_valid
+
+
+@pytest.mark.parametrize("kind", ["instance", "batch"])
+@pytest.mark.parametrize("c", [128, 256, 512])
+def test_conv_epilogue_statistics_feed_the_following_norm(kind, c, monkeypatch):
+    """ss_conv_desc::y_stats -> ss_norm_desc::x_stats ("fused IN + conv", CycleGAN.py:327-329): the Winograd output transform sums y and
+    y^2 per sample / channel while it writes y; the norm's own statistics pass is skipped.  The chunks must add up to the sums of the
+    written tensor and the normalised output must agree with the separate-pass result to fp32 rounding."""
+    E, LY, L = mod("engine"), mod("layers"), mod("_lib")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    n, h, w = 4, 32, 32          # 4 x 16 x 16 F(2x2) tiles: the smallest problem the Winograd path takes
+
+    def run(stats):
+        monkeypatch.setattr(LY, "CONV_STATS", stats)
+        arena = E.ParamArena(dev)
+        conv = LY.Conv2D(arena, "c", 3, c, c, padding=("reflect", 1))
+        norm = LY.Norm(arena, "n", c, kind)
+        arena.materialize()
+        gg = torch.Generator().manual_seed(6)
+        arena["c/kernel"].copy_((torch.rand((3, 3, c, c), generator=gg) - 0.5) * 0.05)
+        arena["n/gamma"].copy_(torch.rand(c, generator=gg) + 0.5)
+        arena["n/beta"].copy_(torch.rand(c, generator=gg) - 0.5)
+        if kind == "batch":
+            arena["n/moving_variance"].fill_(1.0)
+        x = E.Act(x_cpu.to(dev), requires_grad=False)
+        t = E.Tape(enabled=False)
+        yc = conv(t, x)
+        y = norm(t, yc, act="relu")
+        torch.cuda.synchronize()
+        return yc, y, arena
+
+    x_cpu = torch.randn((n, h, w, c), generator=g)
+    yc1, y1, a1 = run(True)
+    assert yc1.stats is not None, "the Winograd forward of this shape must emit output statistics"
+    st, chunks = yc1.stats
+    part = st.view(n, chunks, c, 2).double().sum(1).cpu()
+    yd = yc1.dense().double().cpu()
+    np.testing.assert_allclose(part[..., 0].numpy(), yd.sum((1, 2)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(part[..., 1].numpy(), (yd * yd).sum((1, 2)).numpy(), rtol=1e-5, atol=1e-3)
+    yc0, y0, a0 = run(False)
+    assert yc0.stats is None and torch.equal(yc0.dense(), yc1.dense())
+    np.testing.assert_allclose(y1.dense().cpu().numpy(), y0.dense().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    if kind == "batch":
+        np.testing.assert_allclose(a1["n/moving_mean"].cpu().numpy(), a0["n/moving_mean"].cpu().numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(a1["n/moving_variance"].cpu().numpy(), a0["n/moving_variance"].cpu().numpy(), rtol=1e-5, atol=1e-7)

@@ -57,6 +57,12 @@ CONV_CASES = [
     ("wino_same_bias_tanh", 3, 64, 96, 1, "same", True, "tanh", False, 2, 48, 50),   # smooth act: a kinked one flips masks at |y|~1e-6
     ("wino_same_odd", 3, 96, 64, 1, "same", False, None, False, 3, 47, 45),
     ("wino_valid", 3, 64, 64, 1, "valid", False, None, False, 2, 50, 50),
+    # wide trunk shapes: pre-split-plane GEMMs (gemm_x6p persistent workgroups: tile counts that do not divide by 8 XCDs / 256 CUs),
+    # weight gradient on K-major planes (gemm_tn_x3h: 256 | Cin, 128 | Cout, 32 | tiles) and its fallbacks
+    ("wino_tn_256_384", 3, 256, 384, 1, ("reflect", 1), False, None, False, 2, 32, 32),          # 128 tiles, N tiles = 3
+    ("wino_tn_512_128_same", 3, 512, 128, 1, "same", False, None, False, 3, 32, 32),             # 192 tiles
+    ("wino_256_tiles_not_32", 3, 256, 256, 1, ("reflect", 1), False, None, False, 3, 24, 40),    # 180 tiles: in-kernel-split weight gradient
+    ("wino_384_cin_not_256", 3, 384, 256, 1, "same", False, None, False, 1, 64, 64),
     # single-output-channel convs take the two-stage (1x1 MFMA GEMM + tap sum / tap scatter) path from 16 channels up
     ("c7_out_16_two_stage", 7, 16, 1, 1, ("reflect", 3), True, "tanh", False, 2, 16, 16),
     ("c7_in_16_two_stage_dgrad", 7, 1, 16, 1, ("reflect", 3), False, None, False, 2, 16, 16),

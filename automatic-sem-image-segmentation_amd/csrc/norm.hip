@@ -229,10 +229,21 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
     const int CV = C / V;
     const long total = rows * CV;
     float am = 0.f;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % CV) * V;
-        const long row = e / CV;
-        const long gi = (row / P) * C + c;
+    // (row, channel vector) of element e advance incrementally: one 64-bit division per thread instead of two per element (the
+    // single-channel-vector instantiation, odd MultiResUNet widths, was paced by them)
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long drow = stride / CV;
+    const int dcv = (int)(stride - drow * CV);
+    const long dg = drow / P, drp = drow - dg * P;              // ... and (group, pixel within the group) of the row
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long row = e / CV;
+    int cv = (int)(e - row * CV);
+    long grp = row / P, rp = row - grp * P;
+    for (; e < total; e += stride, row += drow, cv += dcv, grp += dg, rp += drp) {
+        if (cv >= CV) { cv -= CV; ++row; ++rp; }
+        if (rp >= P) { rp -= P; ++grp; }
+        const int c = cv * V;
+        const long gi = grp * C + c;
         float xv[V], mu[V], rs[V], bt[V], gm[V], rv[V], o[V];
         ldv<V>(x + row * x_cs + c, xv);
         ldv<V>(mean + gi, mu);
@@ -329,10 +340,19 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     const int CV = C / V;
     const long total = rows * CV;
     float am = 0.f;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % CV) * V;
-        const long row = e / CV;
-        const long gi = (row / P) * C + c;
+    const long stride = (long)gridDim.x * blockDim.x;          // incremental (row, channel vector), see norm_apply_kernel
+    const long drow = stride / CV;
+    const int dcv = (int)(stride - drow * CV);
+    const long dg = drow / P, drp = drow - dg * P;              // ... and (group, pixel within the group) of the row
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long row = e / CV;
+    int cv = (int)(e - row * CV);
+    long grp = row / P, rp = row - grp * P;
+    for (; e < total; e += stride, row += drow, cv += dcv, grp += dg, rp += drp) {
+        if (cv >= CV) { cv -= CV; ++row; ++rp; }
+        if (rp >= P) { rp -= P; ++grp; }
+        const int c = cv * V;
+        const long gi = grp * C + c;
         float gv[V], xv[V], yv[V], mu[V], rs[V], gm[V], sm[2 * V], o[V], r[V];
         ldv<V>(dy + row * dy_cs + c, gv);
         ldv<V>(x + row * x_cs + c, xv);

@@ -578,7 +578,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 }
 
 // dw[kh][kw][ci][co] (+)= (G^T S G) with S_xi[ci][co] = sum_splits part[xi][split][ci][co]
-template <int R>
+// SP > 0: the split count as a compile-time constant (all loads of a column in flight at once; the runtime loop serialised them:
+// 73 us for 151 MB), same summation order
+template <int R, int SP = 0>
 __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ part, int splits, int Cin, int Cout, float* __restrict__ dw,
                                                       int accumulate) {
     constexpr int P = R + 2;
@@ -589,11 +591,26 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         float col[P], o[3];
+        if (SP > 0) {
+            float v[P][SP > 0 ? SP : 1];
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int sp = 0; sp < SP; ++sp) v[i][sp] = part[((long)(i * P + j) * SP + sp) * cc + e];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int sp = 0; sp < SP; ++sp) acc += v[i][sp];
+                col[i] = acc;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             float acc = 0.f;
             for (int sp = 0; sp < splits; ++sp) acc += part[((long)(i * P + j) * splits + sp) * cc + e];
             col[i] = acc;
+        }
         }
         t_dw<R>(col, o);
 #pragma unroll
@@ -612,6 +629,18 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 }
 
 inline unsigned g256(long total) { return (unsigned)((total + 255) / 256); }
+
+template <int R>
+void launch_wino_dw(const float* part, int splits, int cin, int cout, float* dw, int accumulate, hipStream_t s) {
+    const dim3 grid(g256((long)cin * cout)), block(256);
+    switch (splits) {
+        case 1: hipLaunchKernelGGL((wino_dw_kernel<R, 1>), grid, block, 0, s, part, splits, cin, cout, dw, accumulate); break;
+        case 2: hipLaunchKernelGGL((wino_dw_kernel<R, 2>), grid, block, 0, s, part, splits, cin, cout, dw, accumulate); break;
+        case 3: hipLaunchKernelGGL((wino_dw_kernel<R, 3>), grid, block, 0, s, part, splits, cin, cout, dw, accumulate); break;
+        case 4: hipLaunchKernelGGL((wino_dw_kernel<R, 4>), grid, block, 0, s, part, splits, cin, cout, dw, accumulate); break;
+        default: hipLaunchKernelGGL((wino_dw_kernel<R, 0>), grid, block, 0, s, part, splits, cin, cout, dw, accumulate); break;
+    }
+}
 
 // output tile size: F(4x4,3x3) by default (4x fewer multiplies), F(2x2,3x3) with SS_WINO_R=2
 inline int wino_r() { return ss_tuning().wino_r; }
@@ -782,7 +811,7 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
         g.amax_b = q.dy_amax; g.stripes_b = q.dy_stripes; g.bound_b = BOUND_DY;
         const int rc = ss_launch_gemm_tn_x3h(g, s);
         if (rc != SS_OK) return rc;
-        hipLaunchKernelGGL(wino_dw_kernel<R>, dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, part, g.splits, q.cin, q.cout, dw, accumulate);
+        launch_wino_dw<R>(part, g.splits, q.cin, q.cout, dw, accumulate, s);
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
@@ -813,7 +842,7 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
     p.nbatch = XI; p.a_bs = tiles * q.cin; p.b_bs = tiles * q.cout;
     int rc = ss_launch_wgrad_mfma_partials(p, s);
     if (rc != SS_OK) return rc;
-    hipLaunchKernelGGL(wino_dw_kernel<R>, dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, part, p.splits, q.cin, q.cout, dw, accumulate);
+    launch_wino_dw<R>(part, p.splits, q.cin, q.cout, dw, accumulate, s);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

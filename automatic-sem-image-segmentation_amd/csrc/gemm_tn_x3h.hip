@@ -46,57 +46,62 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
     const int wm = wave >> 1, wn = wave & 1;
 
     const int gridM = p.M / TBM, gridN = p.N / TBN;
-    int tile;
-    {   // XCD-aware order (speed only): a contiguous chunk of the tile space per XCD; the splits of one (batch, m, n) tile and the
-        // n tiles of one m tile (same A rows) are neighbours
+    const int per = gridM * gridN;
+    // XCD-aware order (speed only): a contiguous chunk of the tile space per XCD; the splits of one (batch, m, n) tile and the n
+    // tiles of one m tile (same A rows) are neighbours.  PERSISTENT workgroups as in gemm_x6p.hip: with more tiles than workgroups
+    // a workgroup walks its XCD's chunk and its operand stream runs on across the tile boundaries.
+    const int total = per * p.nbatch * p.splits;
+    int t_first, t_end, t_stride;
+    {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        const int q = total >> 3, r = total & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        if (nwg == total) { t_first = start + slot; t_end = t_first + 1; t_stride = 1; }
+        else { t_first = start + slot; t_end = start + q + (xcd < r ? 1 : 0); t_stride = nwg >> 3; }
     }
-    const int per = gridM * gridN;
-    const int bs = tile / per;
-    tile -= bs * per;
-    const int batch = bs / p.splits, split = bs - batch * p.splits;
-    const int m0 = (tile / gridN) * TBM, n0 = (tile % gridN) * TBN;
-    const int k_begin = split * p.k_per_split;
-    const int k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
-    const int nchunks = (k_end - k_begin) / TBK;
-
-    // this wave's share of a stage: 6 pieces of 1 KiB.  Pieces 0..15 / 16..31: A plane h / l (2 k rows each), 32..39 / 40..47: B
-    // plane h / l (4 k rows each).  Lane j of a piece lands on bytes [16 j, 16 j + 16) of the piece.
-    const unsigned short* gp[TNDMA];
+    // per-tile set-up.  This wave's share of a stage: 6 pieces of 1 KiB.  Pieces 0..15 / 16..31: A plane h / l (2 k rows each),
+    // 32..39 / 40..47: B plane h / l (4 k rows each).  Lane j of a piece lands on bytes [16 j, 16 j + 16) of the piece.
+    struct TileCtx { int m0, n0, nchunks; long cbase; };
+    auto setup = [&](int t, const unsigned short* (&g)[TNDMA]) -> TileCtx {
+        const int bs = t / per;
+        const int tl = t - bs * per;
+        const int batch = bs / p.splits, split = bs - batch * p.splits;
+        const int m0 = (tl / gridN) * TBM, n0 = (tl % gridN) * TBN;
+        const int k_begin = split * p.k_per_split;
+        const int k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
+#pragma unroll
+        for (int j = 0; j < TNDMA; ++j) {
+            const int q = wave * TNDMA + j;
+            if (q < 32) {
+                const int pl = q >> 4, pc = q & 15;
+                const int row = 2 * pc + (lane >> 5);
+                const int pseg = (lane & 31) >> 2;                          // physical 64-byte segment of the row
+                const int col = ((pseg ^ (row & 3)) * 64 + (lane & 3) * 16) / 2;      // logical channel offset
+                g[j] = p.a + pl * p.a_plane + batch * p.a_bs + (long)(k_begin + row) * p.lda + m0 + col;
+            } else {
+                const int q2 = q - 32;
+                const int pl = q2 >> 3, pc = q2 & 7;
+                const int row = 4 * pc + (lane >> 4);
+                const int pseg = (lane & 15) >> 2;
+                const int col = ((pseg ^ (row & 3)) * 64 + (lane & 3) * 16) / 2;
+                g[j] = p.b + pl * p.b_plane + batch * p.b_bs + (long)(k_begin + row) * p.ldb + n0 + col;
+            }
+        }
+        return TileCtx{m0, n0, (k_end - k_begin) / TBK, ((long)batch * p.splits + split) * p.M * p.N};
+    };
     int loff[TNDMA];
 #pragma unroll
     for (int j = 0; j < TNDMA; ++j) {
         const int q = wave * TNDMA + j;
-        if (q < 32) {
-            const int pl = q >> 4, pc = q & 15;
-            const int row = 2 * pc + (lane >> 5);
-            const int pseg = (lane & 31) >> 2;                          // physical 64-byte segment of the row
-            const int col = ((pseg ^ (row & 3)) * 64 + (lane & 3) * 16) / 2;      // logical channel offset
-            gp[j] = p.a + pl * p.a_plane + batch * p.a_bs + (long)(k_begin + row) * p.lda + m0 + col;
-            loff[j] = pl * TA_PLANE + pc * 1024;
-        } else {
-            const int q2 = q - 32;
-            const int pl = q2 >> 3, pc = q2 & 7;
-            const int row = 4 * pc + (lane >> 4);
-            const int pseg = (lane & 15) >> 2;
-            const int col = ((pseg ^ (row & 3)) * 64 + (lane & 3) * 16) / 2;
-            gp[j] = p.b + pl * p.b_plane + batch * p.b_bs + (long)(k_begin + row) * p.ldb + n0 + col;
-            loff[j] = 2 * TA_PLANE + pl * TB_PLANE + pc * 1024;
-        }
+        loff[j] = q < 32 ? (q >> 4) * TA_PLANE + (q & 15) * 1024 : 2 * TA_PLANE + ((q - 32) >> 3) * TB_PLANE + ((q - 32) & 7) * 1024;
     }
+    const unsigned short* gp[TNDMA];
+    const unsigned short* gpn[TNDMA];
+    if (t_first >= t_end) return;
+    TileCtx cur = setup(t_first, gp);
 
     f32x16 acc[2][2][2];          // [0]: h*h, [1]: the cross terms (they carry the factor 2^-11)
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[s][mi][ni][r] = 0.f;
 
     // fragment read addresses.  Lane l, read rr (0 / 1), K half kh: k row = 16 kh + 8 (l >> 5) + 4 rr + ((l & 15) >> 2),
     // channel = (wave tile) + 32 mi + 16 ((l >> 4) & 1) + 4 (l & 3).  k & 3 = (l & 15) >> 2 for every read: ONE swizzle term per lane.
@@ -141,7 +146,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
 #pragma unroll
     for (int j = 0; j < TNDMA; ++j) kstep[j] = (long)TBK * (wave * TNDMA + j < 32 ? p.lda : p.ldb);
 
-    if (nchunks > 0) {          // tiles 0 .. 2 (indices past the end re-fetch the last tile: the group count stays fixed)
+    // scales: the planes hold a * 2^(14 - ea) and b * 2^(14 - eb) (conv_wino.hip, same slots, same bounds)
+    const int ea = ss_amax_exp(__uint_as_float(ss_amax_load(p.amax_a, p.stripes_a))) + p.bound_a;
+    const int eb = ss_amax_exp(__uint_as_float(ss_amax_load(p.amax_b, p.stripes_b))) + p.bound_b;
+    const float out_scale = ldexpf(1.f, ea - 14 + eb - 14);
+
+    {   // pipeline fill for this workgroup's first tile (chunk indices past the end re-fetch the last chunk: fixed group count)
+        const int nchunks = cur.nchunks;
 #pragma unroll
         for (int t = 0; t < TSTAGES; ++t) {
             const int tt = t < nchunks ? t : nchunks - 1;
@@ -150,56 +161,74 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TSTAGES - 1) * TNDMA) : "memory");
     }
-    __builtin_amdgcn_s_barrier();
-    if (nchunks > 0) frag(a0, b0, 0, 0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
-
     int st = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        const int st1 = st + 1 == TSTAGES ? 0 : st + 1;
-        frag(a1, b1, st, 1);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int t = t_first; t < t_end; t += t_stride) {
+        const int nchunks = cur.nchunks;
+        const bool more = t + t_stride < t_end;
+        TileCtx nxt = cur;
+        if (more) nxt = setup(t + t_stride, gpn);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) mma4(a0, b0, q);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0x0070 | (((TSTAGES - 2) * TNDMA) & 15));      // vmcnt(6) lgkmcnt(0): tile c+1 landed, own reads of tile c done
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[s][mi][ni][r] = 0.f;
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        frag(a0, b0, st1, 0);
-        const int cn = c + TSTAGES < nchunks ? c + TSTAGES : nchunks - 1;
-        unsigned char* dst = lds + st * TSTAGE;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            mma4(a1, b1, q);
-#pragma unroll
-            for (int j = 0; j < TNDMA; ++j)
-                if (j * 3 / TNDMA == q) dma16(gp[j] + cn * kstep[j], dst + loff[j]);
+        frag(a0, b0, st, 0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+
+        for (int c = 0; c < nchunks; ++c) {
+            const int st1 = st + 1 == TSTAGES ? 0 : st + 1;
+            frag(a1, b1, st, 1);
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) mma4(a0, b0, q);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0070 | (((TSTAGES - 2) * TNDMA) & 15));      // vmcnt(6) lgkmcnt(0): chunk c+1 landed, own reads of chunk c done
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            frag(a0, b0, st1, 0);
+            // past the last chunk of a tile the stream continues with the next tile's first chunks (last tile: re-fetch, unused)
+            const int ca = c + TSTAGES;
+            const bool own = ca < nchunks;
+            const int cn = own ? ca : (more ? ca - nchunks : nchunks - 1);
+            unsigned char* dst = lds + st * TSTAGE;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                mma4(a1, b1, q);
+#pragma unroll
+                for (int j = 0; j < TNDMA; ++j)
+                    if (j * 3 / TNDMA == q) dma16(((own || !more) ? gp[j] : gpn[j]) + cn * kstep[j], dst + loff[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+            st = st1;
         }
-        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
-        st = st1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // scales: the planes hold a * 2^(14 - ea) and b * 2^(14 - eb) (conv_wino.hip, same slots, same bounds)
-    const int ea = ss_amax_exp(__uint_as_float(ss_amax_load(p.amax_a, p.stripes_a))) + p.bound_a;
-    const int eb = ss_amax_exp(__uint_as_float(ss_amax_load(p.amax_b, p.stripes_b))) + p.bound_b;
-    const float out_scale = ldexpf(1.f, ea - 14 + eb - 14);
-
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* cbase = p.c + ((long)batch * p.splits + split) * p.M * p.N;
+        // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        float* cbase = p.c + cur.cbase;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + wn * 64 + ni * 32 + l31;
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = cur.n0 + wn * 64 + ni * 32 + l31;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                cbase[(long)m * p.N + n] = fmaf(acc[1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]) * out_scale;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = cur.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    cbase[(long)m * p.N + n] = fmaf(acc[1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]) * out_scale;
+                }
             }
         }
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(63)" ::: "memory");      // the next tile's first chunk groups are older than the stores
+#pragma unroll
+            for (int j = 0; j < TNDMA; ++j) gp[j] = gpn[j];
+            cur = nxt;
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace
@@ -226,7 +255,10 @@ int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s) {
         return true;
     }();
     (void)attr_set;
-    const long nwg = (long)(p.M / TBM) * (p.N / TBN) * p.nbatch * p.splits;
+    const long tiles = (long)(p.M / TBM) * (p.N / TBN) * p.nbatch * p.splits;
+    static const int n_cu = [] { int v = 0; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0); return v >= 8 ? v / 8 * 8 : 256; }();
+    const bool persistent = ss_tuning().gemm_persistent && tiles > n_cu && p.k_per_split >= 3 * TBK && p.K % p.k_per_split == 0;
+    const long nwg = persistent ? n_cu : tiles;
     SsProfScope prof("gemm_tn_x3h_kernel", 2.0 * p.M * p.N * p.K * p.nbatch * 3,
                      2.0 * 2 * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
     hipLaunchKernelGGL(gemm_tn_x3h_kernel, dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);

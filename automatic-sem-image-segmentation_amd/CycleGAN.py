@@ -29,7 +29,7 @@ from . import _lib as L
 from . import dist as D
 from . import layers as LY
 from . import losses
-from .engine import Act, Tape, _stream
+from .engine import Act, Tape, _stream, cat_batch
 from .nets import PatchDiscriminator, ResnetGenerator
 from .optim import Adam
 
@@ -61,14 +61,14 @@ class ImagePool:
             image = images[index:index + 1]
             if self.num_imgs < self.pool_size:
                 self.num_imgs += 1
-                self.images.append(image.clone())
+                self.images.append(cat_batch([image]))
                 picks.append(image)
             else:
                 p = self.rng.uniform(0, 1)
                 if p > 0.5:
                     random_id = self.rng.randint(0, self.pool_size - 1)
                     tmp = self.images[random_id]
-                    self.images[random_id] = image.clone()
+                    self.images[random_id] = cat_batch([image])
                     picks.append(tmp)
                 else:
                     picks.append(image)
@@ -157,8 +157,8 @@ class CycleGanModel:
             # the translation and the identity pass of a generator use the same weights on independent samples (InstanceNorm
             # is per sample): one pass over the concatenated batch -- larger GEMMs, one weight transform instead of two
             n = real_a.n
-            fake_b, same_b = LY.batch_split(tape, ga(Act(torch.cat([real_a.t, real_b.t], 0), requires_grad=False), True, tape), [n, real_b.n])
-            fake_a, same_a = LY.batch_split(tape, gb(Act(torch.cat([real_b.t, real_a.t], 0), requires_grad=False), True, tape), [real_b.n, n])
+            fake_b, same_b = LY.batch_split(tape, ga(Act(cat_batch([real_a.t, real_b.t]), requires_grad=False), True, tape), [n, real_b.n])
+            fake_a, same_a = LY.batch_split(tape, gb(Act(cat_batch([real_b.t, real_a.t]), requires_grad=False), True, tape), [real_b.n, n])
             cycled_a = gb(fake_b, True, tape)
             cycled_b = ga(fake_a, True, tape)
         else:
@@ -199,9 +199,9 @@ class CycleGanModel:
         pooled_b = self.image_pool_b.query(fake_b.t)
         if self.batch_generator_passes:                       # real + pooled-fake batch of a discriminator in one pass
             disc_real_a, disc_fake_a2 = LY.batch_split(
-                tape, da(Act(torch.cat([real_a.t, pooled_a], 0), requires_grad=False), True, tape), [real_a.n, pooled_a.shape[0]])
+                tape, da(Act(cat_batch([real_a.t, pooled_a]), requires_grad=False), True, tape), [real_a.n, pooled_a.shape[0]])
             disc_real_b, disc_fake_b2 = LY.batch_split(
-                tape, db(Act(torch.cat([real_b.t, pooled_b], 0), requires_grad=False), True, tape), [real_b.n, pooled_b.shape[0]])
+                tape, db(Act(cat_batch([real_b.t, pooled_b]), requires_grad=False), True, tape), [real_b.n, pooled_b.shape[0]])
         else:
             disc_real_a = da(real_a, True, tape)
             disc_fake_a2 = da(Act(pooled_a, requires_grad=False), True, tape)
@@ -260,7 +260,7 @@ class CycleGanModel:
         s2.wait_stream(cur)
         tape_a, tape_b = Tape(), Tape()
         with torch.cuda.stream(s1):
-            fake_b, same_b = LY.batch_split(tape_a, ga(Act(torch.cat([real_a.t, real_b.t], 0), requires_grad=False), True, tape_a), [n_a, n_b])
+            fake_b, same_b = LY.batch_split(tape_a, ga(Act(cat_batch([real_a.t, real_b.t]), requires_grad=False), True, tape_a), [n_a, n_b])
             cycled_a = gb(fake_b, True, tape_a)
             tape_a.param_grads = False
             disc_fake_b = db(fake_b, True, tape_a)
@@ -270,7 +270,7 @@ class CycleGanModel:
             losses.mae(real_b, same_b, (self.lambda_cycle_a * self.lambda_identity_a) * self.loss_scale, self._slot(4))
             fwd_a_done = s1.record_event()
         with torch.cuda.stream(s2):
-            fake_a, same_a = LY.batch_split(tape_b, gb(Act(torch.cat([real_b.t, real_a.t], 0), requires_grad=False), True, tape_b), [n_b, n_a])
+            fake_a, same_a = LY.batch_split(tape_b, gb(Act(cat_batch([real_b.t, real_a.t]), requires_grad=False), True, tape_b), [n_b, n_a])
             cycled_b = ga(fake_a, True, tape_b)
             tape_b.param_grads = False
             disc_fake_a = da(fake_a, True, tape_b)
@@ -301,12 +301,12 @@ class CycleGanModel:
             tape_da, tape_db = Tape(), Tape()
             with torch.cuda.stream(s3):
                 disc_real_a, disc_fake_a2 = LY.batch_split(
-                    tape_da, da(Act(torch.cat([real_a.t, pooled_a], 0), requires_grad=False), True, tape_da), [n_a, pooled_a.shape[0]])
+                    tape_da, da(Act(cat_batch([real_a.t, pooled_a]), requires_grad=False), True, tape_da), [n_a, pooled_a.shape[0]])
                 losses.mse_const(disc_real_a, one, 0.5 * self.loss_scale, self._slot(6))
                 losses.mse_const(disc_fake_a2, zero, 0.5 * self.loss_scale, self._slot(7))
             with torch.cuda.stream(s4):
                 disc_real_b, disc_fake_b2 = LY.batch_split(
-                    tape_db, db(Act(torch.cat([real_b.t, pooled_b], 0), requires_grad=False), True, tape_db), [n_b, pooled_b.shape[0]])
+                    tape_db, db(Act(cat_batch([real_b.t, pooled_b]), requires_grad=False), True, tape_db), [n_b, pooled_b.shape[0]])
                 losses.mse_const(disc_real_b, one, 0.5 * self.loss_scale, self._slot(8))
                 losses.mse_const(disc_fake_b2, zero, 0.5 * self.loss_scale, self._slot(9))
             D.begin_backward([da, db])

@@ -27,7 +27,7 @@ import torch
 from . import _lib as L
 from . import dist as D
 from . import layers as LY
-from .engine import Act, Tape, _p, _stream, workspace
+from .engine import Act, Tape, _p, _stream, cat_batch, workspace
 from .layers import Conv2D, Norm
 from .nets import Network
 from .optim import Adam
@@ -301,7 +301,7 @@ class WGAN_GP:
             fake = gen(draws["z"][i], True)
             fake = Act(fake.t, requires_grad=False)
             tape = Tape()
-            both = Act(torch.cat([fake.t, real.t], 0), requires_grad=False)
+            both = Act(cat_batch([fake.t, real.t]), requires_grad=False)
             keep = _cat_keep(draws["keep_fake"][i], draws["keep_real"][i], self.device)
             logits = crit(both, True, tape, keep)
             lg = logits.dense().reshape(2 * n)
@@ -364,7 +364,7 @@ def _cat_keep(a, b, device):
         tb = kb.t if isinstance(kb, Act) else torch.as_tensor(kb, dtype=torch.float32).to(device)
         if ta.dim() == 2:
             ta = ta.reshape(ta.shape[0], 1, 1, -1)
-        out[k] = Act(torch.cat([ta, tb.reshape((tb.shape[0],) + tuple(ta.shape[1:]))], 0).contiguous(), requires_grad=False)
+        out[k] = Act(cat_batch([ta.contiguous(), tb.reshape((tb.shape[0],) + tuple(ta.shape[1:])).contiguous()]), requires_grad=False)
     return out
 
 

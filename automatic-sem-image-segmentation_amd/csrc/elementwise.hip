@@ -453,6 +453,12 @@ int ss_copy_t(int32_t dtype, const void* src, int32_t src_cstride, void* dst, in
     return ss_axpby_t(dtype, 1.f, src, src_cstride, 0.f, nullptr, 0, dst, dst_cstride, rows, c, stream);
 }
 
+int ss_zero(void* dst, size_t bytes, void* stream) {
+    if (!dst && bytes) return SS_ERR_INVALID;
+    if (bytes && hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream) != hipSuccess) { ss_set_error("hipMemsetAsync failed"); return SS_ERR_LAUNCH; }
+    return SS_OK;
+}
+
 int ss_fill(float* dst, float value, int64_t count, void* stream) {
     if (!dst || count < 0) return SS_ERR_INVALID;
     if (count == 0) return SS_OK;

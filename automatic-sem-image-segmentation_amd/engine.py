@@ -112,6 +112,34 @@ def _amax_slot(device):
     return pool[0][i * _SLOT_WORDS:(i + 1) * _SLOT_WORDS]
 
 
+def zero_(t):
+    """Zero a device tensor on the current stream through the library (no torch kernel on the product path)."""
+    L.check(L.load().ss_zero(ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size(), _stream()), "ss_zero")
+    return t
+
+
+def zeros_like(t):
+    return zero_(torch.empty_like(t))
+
+
+def cat_batch(tensors):
+    """Concatenate NHWC tensors of one shape family along the batch axis (the batched generator / discriminator passes of the
+    CycleGAN step): one allocation + one library copy per part instead of torch.cat."""
+    n = sum(int(x.shape[0]) for x in tensors)
+    out = torch.empty((n,) + tuple(tensors[0].shape[1:]), dtype=tensors[0].dtype, device=tensors[0].device)
+    lib, dt = L.load(), L.dtype_of(tensors[0])
+    off = 0
+    for x in tensors:
+        assert x.is_contiguous() and x.shape[1:] == tensors[0].shape[1:] and x.dtype == tensors[0].dtype
+        k = int(x.shape[0])
+        if k:
+            c = int(x.shape[-1])
+            L.check(lib.ss_copy_t(dt, ctypes.c_void_p(x.data_ptr()), c, ctypes.c_void_p(out[off:off + k].data_ptr()), c, x.numel() // c, c, _stream()),
+                    "ss_copy")
+        off += k
+    return out
+
+
 class Act:
     """An NHWC activation view: channels [c0, c0+c) of a base tensor [n,h,w,cs]."""
 
@@ -177,10 +205,10 @@ class Act:
         if self.parent is not None:
             p = self.parent
             if p.grad is None:
-                p.grad = Act(torch.zeros_like(p.t), requires_grad=False)
+                p.grad = Act(zeros_like(p.t), requires_grad=False)
                 p.grad_init = True
             elif not p.grad_init:
-                p.grad.t.zero_()
+                zero_(p.grad.t)
                 p.grad_init = True
             p.grad.amax_valid = False
             return Act(p.grad.t, self.c0, self.c, False), 1

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib as L
-from .engine import TIMER, Act, _p, _stream, workspace
+from .engine import TIMER, Act, _p, _stream, workspace, zero_
 
 CONV_STATS = os.environ.get("SS_CONV_STATS", "1") != "0"          # 0: norms always run their own statistics pass (measurement)
 NORM_AMAX = os.environ.get("SS_NORM_AMAX", "1") != "0"            # 0: convolutions scan their operands for the x3h scales themselves (measurement)
@@ -493,7 +493,7 @@ def batch_split(tape, x, sizes):
         lib = L.load()
         dx, accum = x.grad_target()
         if not accum:
-            dx.t.zero_()
+            zero_(dx.t)
         n0 = 0
         for q, g in zip(parts, grads):
             if g is not None:

@@ -291,6 +291,8 @@ int ss_upsample2x_bwd(const float* dy, int32_t dy_cstride, float* dx, int32_t dx
                       int32_t c, void* stream);
 int ss_copy(const float* src, int32_t src_cstride, float* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream);
 int ss_fill(float* dst, float value, int64_t count, void* stream);
+/* `bytes` zero bytes at dst (gradient buffers of any storage type; hipMemsetAsync on the stream). */
+int ss_zero(void* dst, size_t bytes, void* stream);
 
 /* The same operations on bf16 / fp16 stored activations: leading ss_dtype argument, `void*` views.  The fp32 entry points above are
  * these with SS_DTYPE_F32. */

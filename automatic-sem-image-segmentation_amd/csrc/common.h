@@ -184,7 +184,7 @@ bool ss_x6p_wanted(long M, int N, int nbatch);
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
 
 // kernel-selection switches: ONE explicit table, set through ss_config_set (config.hip); SS_* environment variables give the initial values
-struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent; };
+struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2; };
 const SsTuning& ss_tuning();
 // ss_prof_*: brackets the kernel launched inside this scope with HIP events on its stream when profiling is enabled (config.hip).
 // flops = EXECUTED matrix-instruction FLOPs of the launch (all piece products), bytes = algorithmic HBM bytes (0 if not stated)
@@ -238,6 +238,8 @@ bool ss_gconv_x6_ok(const GConvParams& p);                  // shape / alignment
 int ss_x6_npad(int cout);
 size_t ss_gconv_x6_planes_bytes(const GConvParams& p);      // [3][nbatch][npad(Cout)][ntaps*Cin] bf16
 int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s);
+bool ss_gconv_x6v2_ok(const GConvParams& p);
+int ss_launch_gconv_x6v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s);
 int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipStream_t s);
 bool ss_wgrad_x6_ok(const WGradParams& p);
 int ss_launch_wgrad_x6_partials(const WGradParams& p, hipStream_t s);

@@ -648,6 +648,7 @@ int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipSt
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * ((p.Cin + 31) / 32 * 32);
     const long plane_elems = (long)nb * Npad * Ktot;
+    if (ss_gconv_x6v2_ok(p)) return ss_launch_gconv_x6v2(p, planes, plane_elems, Npad, Ktot, s);
     // tile choice: the largest tile that still yields >= ~200 workgroups (small grids at per-GPU batch 1 want more, smaller ones)
     const long want = 200;      // swept at per-GPU batch 1 / 2 (200 / 600 / 1200): 200 is the fastest
     auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * nb; };

@@ -1,0 +1,292 @@
+// Gather convolution (implicit GEMM over taps x input channels) with the x3h arithmetic, second structure.
+//     out[pixel][co] = act(bias + sum_{t, ci} in[map(pixel, t)][ci] * w[t][ci][co])
+// conv_mfma_x6.hip (gconv_x6_kernel) keeps ONE LDS tile and alternates "compute" and "split + store" phases between two barriers
+// per K step; it reaches 0.21-0.29 of the 16-bit MFMA peak on the strided / transposed / 4x4 layers.  This kernel gives the same
+// problem the schedule of gemm_x6p.hip:
+//   * tile 256 (pixels) x 128 (output channels) x 32 (K), 512 threads = 8 waves as 4 (M) x 2 (N), 64x64 per wave;
+//   * TWO LDS stages, ONE barrier per K step: while the matrix cores work on stage s, the same waves split the next chunk of the
+//     gathered fp32 activations into fp16 (h, l) pieces and store them to stage s^1 (the activations were requested two K steps
+//     ahead into registers), and the weight planes of that chunk -- already split, K-contiguous rows, cached per weight version --
+//     arrive by LDS-DMA with the XOR slot swizzle of gemm_x6p.hip;
+//   * A rows: 80-byte stride (conflict-free ds_read_b128 fragments, 8-byte stores); zero padding / out-of-image taps are selected
+//     at store time.
+// Same arithmetic as gconv_x6_kernel<.., true>: x * s = h + l with one power-of-two scale per operand tensor, products l*h, h*l,
+// h*h into one accumulator set, scales undone in the epilogue; results are bit-identical to it (same products, same K order).
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int VBM = 256, VBN = 128, VK = 32;
+constexpr int VLD = VK + 8;                       // A row stride in halfs (80 bytes)
+constexpr int VA_PLANE = VBM * VLD * 2;           // bytes: 20480
+constexpr int VB_PLANE = VBN * VK * 2;            // bytes: 8192 (64-byte rows, swizzled slots)
+constexpr int VSTAGE = 2 * VA_PLANE + 2 * VB_PLANE;      // 57344
+constexpr int V_MAX_TAPS = 16;
+
+__device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems, int Npad,
+                                                            int Ktot) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    int* pixtab = (int*)(lds + 2 * VSTAGE);          // [VBM]
+    int* offtab = pixtab + VBM;                      // [VBM][ntaps]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const long M = (long)p.N * p.OHc * p.OWc;
+    const int gridN = (p.Cout + VBN - 1) / VBN;
+    int tile;
+    {   // XCD-aware order (speed only): contiguous chunk of the tile space per XCD, N fastest
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int gridM = (int)((M + VBM - 1) / VBM);
+    const int batch = tile / (gridM * gridN);
+    tile -= batch * gridM * gridN;
+    const float* const g_in = p.in + (long)batch * p.in_bs;
+    float* const g_out = p.out + (long)batch * p.out_bs;
+    const long m0 = (long)(tile / gridN) * VBM;
+    const int n0 = (tile % gridN) * VBN;
+    const int nchunks = Ktot / VK;
+    const int Cq = Ktot / p.ntaps;       // = Cin (a multiple of 32: launcher)
+    const int ea = ss_amax_exp(__uint_as_float(ss_amax_load(p.h_amax, p.amax_stripes))), ew = ss_amax_exp(__uint_as_float(p.h_amax2[0]));
+    const float a_scale = ldexpf(1.f, 14 - ea);
+    const float out_scale = ldexpf(1.f, ea - 14 + ew - 14);
+
+    {   // pixel decode (32-bit: M < 2^31) and the per-row tap offsets, as in gconv_x6_kernel
+        int* rowc = offtab + VBM * p.ntaps;      // [3][VBM]
+        if (tid < VBM) {
+            const unsigned m = (unsigned)m0 + (unsigned)tid;
+            int v = -1, rn = -1, ry = 0, rx = 0;
+            if (m < (unsigned)M) {
+                const unsigned r = m / (unsigned)p.OWc;
+                const int xc = (int)(m - r * (unsigned)p.OWc);
+                const unsigned n = r / (unsigned)p.OHc;
+                const int yc = (int)(r - n * (unsigned)p.OHc);
+                const int oy = yc * p.out_s + p.out_oy, ox = xc * p.out_s + p.out_ox;
+                if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) v = ((int)n * p.OH + oy) * p.OW + ox;
+                rn = (int)n;
+                ry = yc * p.in_s + p.in_oy;
+                rx = xc * p.in_s + p.in_ox;
+            }
+            pixtab[tid] = v;
+            rowc[tid] = rn;
+            rowc[VBM + tid] = ry;
+            rowc[2 * VBM + tid] = rx;
+        }
+        __syncthreads();
+        const int row = tid % VBM;
+        const int rn = rowc[row], ry = rowc[VBM + row], rx = rowc[2 * VBM + row];
+        for (int t = tid / VBM; t < p.ntaps; t += 512 / VBM) {
+            int off = -1;
+            if (rn >= 0) {
+                const int iy = ss_map_index(ry + p.taps[t].dy, p.IH, p.reflect);
+                const int ix = ss_map_index(rx + p.taps[t].dx, p.IW, p.reflect);
+                if (iy >= 0 && ix >= 0) off = ((rn * p.IH + iy) * p.IW + ix) * p.in_cs;
+            }
+            offtab[row * p.ntaps + t] = off;
+        }
+    }
+    __syncthreads();
+
+    // A loader: rows arow + 64 j (j < 4), channels 4 c4a .. +3 of the chunk
+    const int c4a = tid & 7, arow = tid >> 3;
+    // B (weight planes) by LDS-DMA: 16 pieces of 16 rows per stage (2 planes x 8), two per wave
+    const unsigned short* gb[2];
+    int lb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = wave * 2 + j;
+        const int pl = q >> 3, rb = q & 7;
+        const int row = rb * 16 + (lane >> 2);
+        const int ko = (lane & 3) ^ ((row >> 2) & 3);
+        gb[j] = bpl + pl * plane_elems + ((long)batch * Npad + n0 + row) * Ktot + 8 * ko;
+        lb[j] = 2 * VA_PLANE + pl * VB_PLANE + rb * 1024;
+    }
+
+    f32x4 ra[2][4];
+    bool ok[2][4];
+    auto load_a = [&](auto setc, int chunk) {
+        constexpr int S = decltype(setc)::value;
+        const int k0 = chunk * VK;
+        const int t = k0 / Cq;                         // block-uniform
+        const float* abase = g_in + (k0 - t * Cq) + c4a * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = offtab[(arow + 64 * j) * p.ntaps + t];
+            ra[S][j] = *(const f32x4*)(abase + (off < 0 ? 0 : off));
+            ok[S][j] = off >= 0;
+        }
+    };
+    auto store_a = [&](auto setc, int stage, int j) {          // row arow + 64 j of the chunk held in register set S -> LDS stage
+        constexpr int S = decltype(setc)::value;
+        const f32x4 v = ok[S][j] ? ra[S][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned int hh[2], ll[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float x0 = v[2 * e] * a_scale, x1 = v[2 * e + 1] * a_scale;
+            const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+            const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+            hh[e] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+            ll[e] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        unsigned char* dst = lds + stage * VSTAGE + ((arow + 64 * j) * VLD + c4a * 4) * 2;
+        *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
+        *(u32x2*)(dst + VA_PLANE) = u32x2{ll[0], ll[1]};
+    };
+    auto dma_b = [&](int chunk, int stage) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16(gb[j] + (long)chunk * VK, lds + stage * VSTAGE + lb[j]);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // fragment addresses: A row = 64 wm + 32 mi + l31, 16-byte k-octet lh + 2 ks;  B row = 64 wn + 32 ni + l31, slot (lh + 2 ks) ^ ((row >> 2) & 3)
+    const unsigned char* fa = lds + ((wm * 64 + l31) * VLD + 8 * lh) * 2;
+    const int sw = (l31 >> 2) & 3;
+    const int so0 = (lh ^ sw) << 4, so1 = so0 ^ 32;
+    const unsigned char* fb = lds + 2 * VA_PLANE + (wn * 64 + l31) * 64;
+    f16x8 a0[2][2], b0[2][2], a1[2][2], b1[2][2];          // [plane][mi / ni]
+    auto frag = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][2], int stage, int ks) {
+        const int sb = stage * VSTAGE;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const f16x8*)(fa + sb + pl * VA_PLANE + mi * 32 * VLD * 2 + ks * 32);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[pl][ni] = *(const f16x8*)(fb + sb + pl * VB_PLANE + ni * 32 * 64 + (ks ? so1 : so0));
+        }
+    };
+    // l*h, h*l, h*h (the order of gconv_x6_kernel); consecutive MFMAs go to different accumulators
+    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+    auto mma4 = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][2], int q) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], acc[mi][ni], 0, 0, 0);
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int last = nchunks - 1;
+    // prologue: chunk 0 into stage 0, chunk 1 requested into register set 1
+    dma_b(0, 0);
+    load_a(S0{}, 0);
+    load_a(S1{}, 1 < nchunks ? 1 : last);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) store_a(S0{}, 0, j);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    frag(a0, b0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+
+    // step c: stage c&1 holds chunk c; chunk c+1 sits in register set (c+1)&1 (requested one step ago) and goes to the other
+    // stage under the first twelve MFMAs; chunk c+2 is requested into set c&1; the weight planes of chunk c+1 arrive by DMA
+    auto step = [&](int c, auto cur, auto nxt) {
+        const int s = c & 1;
+        // the activations of chunk c+1 (requested one step ago) must be in their registers before the split below.  Waiting HERE,
+        // where nothing younger is in flight, keeps the compiler from placing its own vmcnt(0) after this step's requests (it does
+        // not count through LDS-DMA instructions): a real s_waitcnt so that its bookkeeping sees it
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+        dma_b(c + 1 < nchunks ? c + 1 : last, s ^ 1);            // 2 DMA, then 4 loads: the order the wait below counts on
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(cur, c + 2 < nchunks ? c + 2 : last);
+        __builtin_amdgcn_sched_barrier(0);
+        frag(a1, b1, s, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            mma4(a0, b0, q);
+            store_a(nxt, s ^ 1, q);
+            if (q == 2) store_a(nxt, s ^ 1, 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the DMA of chunk c+1 landed (the four younger activation loads may still be in flight), own LDS reads / writes done
+        __builtin_amdgcn_s_waitcnt(0x0070 | 4);      // vmcnt(4) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        frag(a0, b0, s ^ 1, 0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) mma4(a1, b1, q);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        step(c, S0{}, S1{});
+        if (c + 1 < nchunks) step(c + 1, S1{}, S0{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may still be landing when the LDS is handed on
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int co = n0 + wn * 64 + ni * 32 + l31;
+        if (co >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int pix = pixtab[wm * 64 + mi * 32 + row];
+                if (pix < 0) continue;
+                float* op = g_out + (long)pix * p.out_cs + co;
+                float v = ss_apply_act(acc[mi][ni][r] * out_scale + bv, p.act, p.alpha);
+                if (p.accumulate) v += *op;
+                *op = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// shapes this structure takes: x3h, whole 32-channel chunks, aligned rows, at most 16 taps (LDS tables), enough 256 x 128 tiles
+bool ss_gconv_x6v2_ok(const GConvParams& p) {
+    if (!ss_tuning().gconv_v2 || !p.h_amax || !p.h_amax2 || p.ntaps < 1 || p.ntaps > V_MAX_TAPS) return false;
+    if (p.Cin % 32 || (p.in_cs & 3) || (((uintptr_t)p.in) & 15) || p.Cout < 96) return false;
+    const long M = (long)p.N * p.OHc * p.OWc;
+    if (M >= (1L << 31) || (long)p.N * p.IH * p.IW * p.in_cs >= (1L << 31)) return false;
+    const int nb = p.nbatch > 1 ? p.nbatch : 1;
+    return ((M + VBM - 1) / VBM) * ((p.Cout + VBN - 1) / VBN) * nb >= 200;
+}
+
+int ss_launch_gconv_x6v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
+    const long M = (long)p.N * p.OHc * p.OWc;
+    const int nb = p.nbatch > 1 ? p.nbatch : 1;
+    static const bool attr_set = [] {
+        (void)hipFuncSetAttribute((const void*)gconv_x6v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+    }();
+    (void)attr_set;
+    const long nwg = ((M + VBM - 1) / VBM) * ((p.Cout + VBN - 1) / VBN) * nb;
+    const size_t smem = (size_t)2 * VSTAGE + (size_t)VBM * sizeof(int) * (4 + p.ntaps);
+    char pname[64];
+    if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_x6v2 M%ld N%d K%dx%d s%d b%d", M, p.Cout, p.ntaps, p.Cin, p.in_s, nb);
+    else snprintf(pname, sizeof(pname), "gconv_x6v2_kernel");
+    SsProfScope prof(pname, 2.0 * M * p.Cout * p.ntaps * p.Cin * nb * 3,
+                     4.0 * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout + (double)p.ntaps * p.Cin * p.Cout), s);
+    hipLaunchKernelGGL(gconv_x6v2_kernel, dim3((unsigned)nwg), dim3(512), smem, s, p, planes, plane_elems, Npad, Ktot);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}

@@ -466,3 +466,53 @@ def test_conv_epilogue_statistics_feed_the_following_norm(kind, c, monkeypatch):
     if kind == "batch":
         np.testing.assert_allclose(a1["n/moving_mean"].cpu().numpy(), a0["n/moving_mean"].cpu().numpy(), rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(a1["n/moving_variance"].cpu().numpy(), a0["n/moving_variance"].cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+V2_CASES = [
+    # name, k, cin, cout, stride, padding, transposed, n, h, w   (>= 200 workgroups of 256 pixels x 128 channels, Cin % 32 == 0, Cout >= 96)
+    ("down_3x3_s2", 3, 64, 128, 2, "same", False, 4, 256, 256),
+    ("disc_4x4_s2_valid", 4, 128, 256, 2, "valid", False, 8, 130, 130),
+    ("up_T3_s2", 3, 256, 128, 2, "same", True, 16, 64, 64),
+    ("ragged_last_tile", 3, 96, 160, 2, "same", False, 5, 210, 214),
+]
+
+
+@pytest.mark.parametrize("case", V2_CASES, ids=[c[0] for c in V2_CASES])
+def test_gather_conv_v2_is_bit_identical_to_the_two_barrier_kernel(case):
+    """conv_mfma_x6v2.hip (two LDS stages, one barrier per K step, LDS-DMA weight planes) forms the same products in the same order
+    as gconv_x6_kernel: forward and data gradient must agree bit for bit (`gconv_v2` switch), and with the oracle."""
+    E, LY, L = mod("engine"), mod("layers"), mod("_lib")
+    name, k, cin, cout, stride, padding, transposed, n, h, w = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    wshape = (k, k, cout, cin) if transposed else (k, k, cin, cout)
+    w_cpu = (torch.rand(wshape, generator=g) - 0.5) * 0.1
+    x_cpu = torch.randn((n, h, w, cin), generator=g)
+    outs = {}
+    for v2 in (1, 0):
+        with L.config(gconv_v2=v2):
+            arena = E.ParamArena(dev)
+            layer = LY.Conv2D(arena, "c", k, cin, cout, stride=stride, padding=padding, transposed=transposed, use_bias=True, act="lrelu", act_alpha=0.2)
+            arena.materialize()
+            arena["c/kernel"].copy_(w_cpu)
+            arena["c/bias"].copy_(torch.linspace(-0.1, 0.1, cout))
+            tape = E.Tape()
+            x = E.Act(x_cpu.to(dev), requires_grad=True)
+            L.load().ss_prof_reset(); L.load().ss_prof_enable(1)
+            y = layer(tape, x)
+            gt, _ = y.grad_target()
+            gg = torch.Generator().manual_seed(12)
+            gt.t.copy_(torch.randn(tuple(gt.t.shape), generator=gg).to(dev))
+            tape.backward()
+            torch.cuda.synchronize()
+            L.load().ss_prof_enable(0)
+            outs[v2] = (y.dense().cpu(), x.grad.dense().cpu(), list(L.prof_summary()))
+    assert any("gconv_x6v2" in nm for nm in outs[1][2]), f"{name}: the v2 kernel was not taken ({outs[1][2]})"
+    assert not any("gconv_x6v2" in nm for nm in outs[0][2])
+    assert torch.equal(outs[1][0], outs[0][0]), f"{name}: forward differs between the two gather kernels"
+    assert torch.equal(outs[1][1], outs[0][1]), f"{name}: data gradient differs between the two gather kernels"
+    # and against the float64 definition (loose: this is the regression guard for the addressing, precision is tested elsewhere)
+    xr = x_cpu.double()
+    yr = oracle_conv(xr, w_cpu.double(), k, stride, padding, transposed) + torch.linspace(-0.1, 0.1, cout).double()
+    yr = torch.where(yr > 0, yr, 0.2 * yr)
+    assert float((outs[1][0].double() - yr).abs().max()) < 1e-4 * max(1.0, float(yr.abs().max()))

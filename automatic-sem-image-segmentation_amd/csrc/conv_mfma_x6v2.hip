@@ -22,19 +22,26 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int VBM = 256, VBN = 128, VK = 32;
+constexpr int VBM = 256, VK = 32;
 constexpr int VLD = VK + 8;                       // A row stride in halfs (80 bytes)
 constexpr int VA_PLANE = VBM * VLD * 2;           // bytes: 20480
-constexpr int VB_PLANE = VBN * VK * 2;            // bytes: 8192 (64-byte rows, swizzled slots)
-constexpr int VSTAGE = 2 * VA_PLANE + 2 * VB_PLANE;      // 57344
 constexpr int V_MAX_TAPS = 16;
+// VBN = 128 (64 x 64 per wave) or 64 (64 x 32 per wave: the 64-channel layers, e.g. the last transposed convolution of a generator)
+template <int VBN> struct VG {
+    static constexpr int B_PLANE = VBN * VK * 2;                  // bytes: 64-byte rows, swizzled slots
+    static constexpr int STAGE = 2 * VA_PLANE + 2 * B_PLANE;      // 57344 / 49152
+    static constexpr int TN = VBN / 64;                           // 32-wide MFMA column tiles per wave
+    static constexpr int NB = 2 * VBN / 16 / 8;                   // LDS-DMA pieces per wave and stage
+};
 
 __device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+template <int VBN>
 __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems, int Npad,
                                                             int Ktot) {
+    constexpr int VB_PLANE = VG<VBN>::B_PLANE, VSTAGE = VG<VBN>::STAGE, TN = VG<VBN>::TN, NB = VG<VBN>::NB;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     int* pixtab = (int*)(lds + 2 * VSTAGE);          // [VBM]
     int* offtab = pixtab + VBM;                      // [VBM][ntaps]
@@ -104,13 +111,13 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
 
     // A loader: rows arow + 64 j (j < 4), channels 4 c4a .. +3 of the chunk
     const int c4a = tid & 7, arow = tid >> 3;
-    // B (weight planes) by LDS-DMA: 16 pieces of 16 rows per stage (2 planes x 8), two per wave
-    const unsigned short* gb[2];
-    int lb[2];
+    // B (weight planes) by LDS-DMA: 2 x VBN / 16 pieces of 16 rows per stage, NB per wave
+    const unsigned short* gb[NB];
+    int lb[NB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = wave * 2 + j;
-        const int pl = q >> 3, rb = q & 7;
+    for (int j = 0; j < NB; ++j) {
+        const int q = wave * NB + j;
+        const int pl = q / (VBN / 16), rb = q % (VBN / 16);
         const int row = rb * 16 + (lane >> 2);
         const int ko = (lane & 3) ^ ((row >> 2) & 3);
         gb[j] = bpl + pl * plane_elems + ((long)batch * Npad + n0 + row) * Ktot + 8 * ko;
@@ -149,14 +156,14 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
     };
     auto dma_b = [&](int chunk, int stage) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) dma16(gb[j] + (long)chunk * VK, lds + stage * VSTAGE + lb[j]);
+        for (int j = 0; j < NB; ++j) dma16(gb[j] + (long)chunk * VK, lds + stage * VSTAGE + lb[j]);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
@@ -164,25 +171,25 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
     const unsigned char* fa = lds + ((wm * 64 + l31) * VLD + 8 * lh) * 2;
     const int sw = (l31 >> 2) & 3;
     const int so0 = (lh ^ sw) << 4, so1 = so0 ^ 32;
-    const unsigned char* fb = lds + 2 * VA_PLANE + (wn * 64 + l31) * 64;
-    f16x8 a0[2][2], b0[2][2], a1[2][2], b1[2][2];          // [plane][mi / ni]
-    auto frag = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][2], int stage, int ks) {
+    const unsigned char* fb = lds + 2 * VA_PLANE + (wn * (VBN / 2) + l31) * 64;
+    f16x8 a0[2][2], b0[2][TN], a1[2][2], b1[2][TN];          // [plane][mi / ni]
+    auto frag = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][TN], int stage, int ks) {
         const int sb = stage * VSTAGE;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const f16x8*)(fa + sb + pl * VA_PLANE + mi * 32 * VLD * 2 + ks * 32);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[pl][ni] = *(const f16x8*)(fb + sb + pl * VB_PLANE + ni * 32 * 64 + (ks ? so1 : so0));
+            for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const f16x8*)(fb + sb + pl * VB_PLANE + ni * 32 * 64 + (ks ? so1 : so0));
         }
     };
     // l*h, h*l, h*h (the order of gconv_x6_kernel); consecutive MFMAs go to different accumulators
     constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
-    auto mma4 = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][2], int q) {
+    auto mma4 = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][TN], int q) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < TN; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], acc[mi][ni], 0, 0, 0);
     };
 
@@ -239,8 +246,8 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int co = n0 + wn * 64 + ni * 32 + l31;
+    for (int ni = 0; ni < TN; ++ni) {
+        const int co = n0 + wn * (VBN / 2) + ni * 32 + l31;
         if (co >= p.Cout) continue;
         const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
@@ -261,32 +268,38 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
 
 }  // namespace
 
-// shapes this structure takes: x3h, whole 32-channel chunks, aligned rows, at most 16 taps (LDS tables), enough 256 x 128 tiles
+// shapes this structure takes: x3h, whole 32-channel chunks, aligned rows, at most 16 taps (LDS tables), enough 256 x VBN tiles
+static int v2_bn(const GConvParams& p) { return p.Cout > 64 ? 128 : 64; }
 bool ss_gconv_x6v2_ok(const GConvParams& p) {
     if (!ss_tuning().gconv_v2 || !p.h_amax || !p.h_amax2 || p.ntaps < 1 || p.ntaps > V_MAX_TAPS) return false;
-    if (p.Cin % 32 || (p.in_cs & 3) || (((uintptr_t)p.in) & 15) || p.Cout < 96) return false;
+    if (p.Cin % 32 || (p.in_cs & 3) || (((uintptr_t)p.in) & 15) || p.Cout < 48 || (p.Cout > 64 && p.Cout < 96)) return false;
     const long M = (long)p.N * p.OHc * p.OWc;
     if (M >= (1L << 31) || (long)p.N * p.IH * p.IW * p.in_cs >= (1L << 31)) return false;
-    const int nb = p.nbatch > 1 ? p.nbatch : 1;
-    return ((M + VBM - 1) / VBM) * ((p.Cout + VBN - 1) / VBN) * nb >= 200;
+    const int nb = p.nbatch > 1 ? p.nbatch : 1, bn = v2_bn(p);
+    return ((M + VBM - 1) / VBM) * ((p.Cout + bn - 1) / bn) * nb >= 200;
 }
 
-int ss_launch_gconv_x6v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
+template <int VBN>
+static int launch_v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
     const long M = (long)p.N * p.OHc * p.OWc;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)gconv_x6v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gconv_x6v2_kernel<VBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
     const long nwg = ((M + VBM - 1) / VBM) * ((p.Cout + VBN - 1) / VBN) * nb;
-    const size_t smem = (size_t)2 * VSTAGE + (size_t)VBM * sizeof(int) * (4 + p.ntaps);
+    const size_t smem = (size_t)2 * VG<VBN>::STAGE + (size_t)VBM * sizeof(int) * (4 + p.ntaps);
     char pname[64];
-    if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_x6v2 M%ld N%d K%dx%d s%d b%d", M, p.Cout, p.ntaps, p.Cin, p.in_s, nb);
-    else snprintf(pname, sizeof(pname), "gconv_x6v2_kernel");
+    if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_x6v2<%d> M%ld N%d K%dx%d s%d b%d", VBN, M, p.Cout, p.ntaps, p.Cin, p.in_s, nb);
+    else snprintf(pname, sizeof(pname), "gconv_x6v2_kernel<%d>", VBN);
     SsProfScope prof(pname, 2.0 * M * p.Cout * p.ntaps * p.Cin * nb * 3,
                      4.0 * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout + (double)p.ntaps * p.Cin * p.Cout), s);
-    hipLaunchKernelGGL(gconv_x6v2_kernel, dim3((unsigned)nwg), dim3(512), smem, s, p, planes, plane_elems, Npad, Ktot);
+    hipLaunchKernelGGL(gconv_x6v2_kernel<VBN>, dim3((unsigned)nwg), dim3(512), smem, s, p, planes, plane_elems, Npad, Ktot);
     SS_LAUNCH_CHECK();
     return SS_OK;
+}
+
+int ss_launch_gconv_x6v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
+    return v2_bn(p) == 128 ? launch_v2<128>(p, planes, plane_elems, Npad, Ktot, s) : launch_v2<64>(p, planes, plane_elems, Npad, Ktot, s);
 }

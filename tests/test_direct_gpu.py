@@ -474,8 +474,7 @@ V2_CASES = [
     ("disc_4x4_s2_valid", 4, 128, 256, 2, "valid", False, 8, 130, 130),
     ("up_T3_s2", 3, 256, 128, 2, "same", True, 16, 64, 64),
     ("ragged_last_tile", 3, 96, 160, 2, "same", False, 5, 210, 214),
-    ("up_T3_s2_64_outputs", 3, 128, 64, 2, "same", True, 4, 128, 128),          # 256 x 64 tiles
-    ("conv_1x1_s1_64", 1, 64, 64, 1, "valid", False, 1, 200, 280),
+    ("conv_4x4_s2_64_outputs", 4, 64, 64, 2, "valid", False, 4, 258, 258),          # 256 x 64 tiles (K = 16 x 64)
 ]
 
 

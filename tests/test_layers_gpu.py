@@ -1,6 +1,7 @@
 """GPU parity of every C-ABI op (through the layer/tape engine) against the oracle ops on the same seeded
 inputs.  fp32 tolerances: forward |d| <= 1e-4*max|ref| (+1e-5 abs), gradients rel-L2 <= 1e-4."""
 import os
+import zlib
 import importlib
 
 import numpy as np
@@ -111,7 +112,7 @@ def test_conv_fwd_bwd(case, algo):
     if algo == "mfma" and (cout < 2):
         pytest.skip("Cout==1 heads are direct-kernel shapes")
     dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)          # stable across processes (hash() is salted per process)
     arena = E.ParamArena(dev)
     layer = LY.Conv2D(arena, "c", k, cin, cout, stride=stride, padding=padding, use_bias=bias, act=act,
                       act_alpha=0.2, transposed=transposed,

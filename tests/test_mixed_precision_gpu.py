@@ -2,6 +2,7 @@
 bfloat16 / float16, fp32 master weights, fp32 normalisation statistics, fp32 accumulation; activation checkpointing of the
 generator's residual trunk.  Criterion: outputs / losses against the FP32 oracle with rel-L2 <= 2e-2, reported."""
 import importlib
+import zlib
 import random
 
 import numpy as np
@@ -52,7 +53,7 @@ def test_conv_16bit_storage_vs_fp32_oracle(case, dt):
     E, LY, L = mod("engine"), mod("layers"), mod("_lib")
     name, k, cin, cout, stride, padding, bias, transposed, n, h, w = case
     dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(abs(hash(name)) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     arena = E.ParamArena(dev)
     layer = LY.Conv2D(arena, "c", k, cin, cout, stride=stride, padding=padding, use_bias=bias, transposed=transposed)
     arena.materialize()

@@ -24,10 +24,10 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def assert_close(got, ref, what, rtol=1e-4):
+def assert_close(got, ref, what, rtol=1e-4, atol=0.0):
     got, ref = np.asarray(got), np.asarray(ref)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
-    tol = rtol * max(float(np.abs(ref).max()), 1e-6) + 1e-6
+    tol = rtol * max(float(np.abs(ref).max()), 1e-6) + 1e-6 + atol
     err = float(np.abs(got - ref).max())
     assert err <= tol, f"{what}: max|d|={err:.3e} tol={tol:.3e} relL2={rel_l2(got, ref):.3e}"
 
@@ -146,7 +146,9 @@ def test_conv_fwd_bwd(case, algo):
     assert_close(x.get_grad().dense().cpu(), xr.grad, f"{name}/{algo} dx", rtol=2e-4)
     assert_close(arena.grad("c/kernel").cpu(), wr.grad, f"{name}/{algo} dw", rtol=2e-4)
     if bias:
-        assert_close(arena.grad("c/bias").cpu(), br.grad, f"{name}/{algo} db", rtol=2e-4)
+        # a bias gradient is a sum over every output pixel: for a one-channel layer it can land near zero, where a tolerance relative
+        # to the value itself is smaller than fp32 summation noise -- floor it at 1e-7 of the sum of magnitudes
+        assert_close(arena.grad("c/bias").cpu(), br.grad, f"{name}/{algo} db", rtol=2e-4, atol=1e-7 * float(gy.abs().sum()) / max(cout, 1))
 
 
 @pytest.mark.parametrize("hw", [(12, 12), (192, 200)], ids=["small", "tile_kernels"])

@@ -174,7 +174,8 @@ class UNetModel:
     def save(self, path):
         """``model.save('…/model.keras')`` (UNet_Segmentation.py:262-264,287): Keras-3 archive (keras_io.py) with the network's layers
         and the Adam state; ``.npz`` paths give the plain-numpy form."""
-        cfg = dict(filters=self.net.filters, weighting=self.weighting, learning_rate=float(self.optimizer.learning_rate))
+        cfg = dict(filters=self.net.filters, weighting=self.weighting, learning_rate=float(self.optimizer.learning_rate),
+                   output_channels=self.net.output_channels)
         if path.endswith(".npz"):
             arrays = {name: w for name, w in zip(self.net.variable_names, self.net.get_weights())}
             arrays["__config__"] = np.array(json.dumps(cfg))
@@ -192,12 +193,12 @@ class UNetModel:
         if path.endswith(".npz"):
             z = np.load(path)
             cfg = json.loads(str(z["__config__"]))
-            net = MultiResUNet(conv_filters=cfg["filters"], device=device)
+            net = MultiResUNet(conv_filters=cfg["filters"], device=device, output_channels=cfg.get("output_channels", 1))
             net.set_weights([z[name] for name in net.variable_names])
             return cls(net, cfg.get("weighting", 1.0), Adam(cfg.get("learning_rate", 1e-3)))
         from . import keras_io as K
         _, cfg, arrays = K.read_archive(path)
-        net = MultiResUNet(conv_filters=cfg["filters"], device=device)
+        net = MultiResUNet(conv_filters=cfg["filters"], device=device, output_channels=cfg.get("output_channels", 1))
         K.load_net_arrays(net, "", K.NameCounters(), arrays)
         model = cls(net, cfg.get("weighting", 1.0), Adam(cfg.get("learning_rate", 1e-3)))
         K.load_optimizer_arrays(model.optimizer, net, "optimizer/", arrays)
@@ -260,11 +261,11 @@ class UNet:
         return np.count_nonzero(y == 0) / np.count_nonzero(y)
 
     def create_model(self, weighting=None):
-        if self.output_channels != 1:
-            raise NotImplementedError("multi-class softmax head (UNet_Segmentation.py:558-560) is off by default and not built yet")
         if weighting is None:
             weighting = self.class_weighting()
-        net = MultiResUNet(conv_filters=self.filters, device=self.device, seed=self.seed)
+        # output_channels > 1: Conv2D + softmax head and one-hot targets (UNet_Segmentation.py:387, 558-560); the reference's own
+        # feeders only ever produce one-channel masks, and its inference path rebuilds a one-channel model (UNet_Segmentation.py:317)
+        net = MultiResUNet(conv_filters=self.filters, device=self.device, seed=self.seed, output_channels=self.output_channels)
         D.broadcast_params([net])
         D.enable_overlap([net])
         if D.world_size() > 1 and self.sync_batch_norm:

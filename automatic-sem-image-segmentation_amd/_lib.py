@@ -147,6 +147,9 @@ SIGNATURES = {
     "ss_loss_mse_const_t": (c_i32, [c_i32, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_loss_mae_t": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_loss_weighted_bce_t": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ss_softmax_fwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ss_softmax_bwd_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ss_loss_weighted_bce_mc_t": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_fill": (c_i32, [c_vp, c_f32, c_i64, c_vp]),
     "ss_zero": (c_i32, [c_vp, c_sz, c_vp]),
     "ss_loss_workspace_bytes": (c_sz, [c_i64]),

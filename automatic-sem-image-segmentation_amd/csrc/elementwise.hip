@@ -328,6 +328,66 @@ __global__ __launch_bounds__(EW_BLOCK) void wbce_kernel(const T* __restrict__ tr
     block_reduce_store<3>(v, part);
 }
 
+// ---- multi-class head of the MultiResUNet (UNet_Segmentation.py:558-560): softmax over the channels of a pixel, and the reference's
+// loss closure on a multi-channel output (:379-384): BinaryCrossentropy(reduction none) averages over the channels, the result is
+// broadcast back and weighted with y_true * (w - 1) + 1 ------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void softmax_fwd_kernel(const T* __restrict__ x, int x_cs, T* __restrict__ y, int y_cs, long rows, int C) {
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+        const T* xr = x + r * x_cs;
+        float m = (float)xr[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, (float)xr[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf((float)xr[c] - m);
+        const float inv = 1.f / s;
+        for (int c = 0; c < C; ++c) y[r * y_cs + c] = (T)(expf((float)xr[c] - m) * inv);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void softmax_bwd_kernel(const T* __restrict__ dy, int dy_cs, const T* __restrict__ y, int y_cs,
+                                                               T* __restrict__ dx, int dx_cs, long rows, int C) {
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) dot = fmaf((float)dy[r * dy_cs + c], (float)y[r * y_cs + c], dot);
+        for (int c = 0; c < C; ++c) dx[r * dx_cs + c] = (T)((float)y[r * y_cs + c] * ((float)dy[r * dy_cs + c] - dot));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void wbce_mc_kernel(const T* __restrict__ truth, const T* __restrict__ pred, long rows, int C,
+                                                           float weighting, float gscale, T* __restrict__ grad, float* __restrict__ part) {
+    float v[3] = {0.f, 0.f, 0.f};
+    const float eps = 1e-7f, invc = 1.f / (float)C;
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+        const T* t_ = truth + r * C;
+        const T* p_ = pred + r * C;
+        float b = 0.f, wsum = 0.f, tmax = -1.f, pmax = -1.f;
+        int ta = 0, pa = 0;
+        for (int c = 0; c < C; ++c) {
+            const float t = (float)t_[c], pr = (float)p_[c];
+            const float pc = fminf(fmaxf(pr, eps), 1.f - eps);
+            b += -(t * logf(pc) + (1.f - t) * logf(1.f - pc));
+            wsum += t * (weighting - 1.f) + 1.f;
+            v[1] += fabsf(t - pr);
+            if (t > tmax) { tmax = t; ta = c; }          // first maximum, like argmax
+            if (pr > pmax) { pmax = pr; pa = c; }
+        }
+        b *= invc;
+        v[0] += wsum * b;
+        v[2] += ta == pa ? (float)C : 0.f;               // categorical accuracy per PIXEL; the finish divides by rows * C
+        if (grad) {
+            for (int c = 0; c < C; ++c) {
+                const float t = (float)t_[c], pr = (float)p_[c];
+                const float pc = fminf(fmaxf(pr, eps), 1.f - eps);
+                const bool inside = (pr >= eps) && (pr <= 1.f - eps);
+                grad[r * C + c] = (T)(inside ? gscale * wsum * invc * (-(t / pc) + (1.f - t) / (1.f - pc)) : 0.f);
+            }
+        }
+    }
+    block_reduce_store<3>(v, part);
+}
+
 __global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long count, float alpha, float b1, float b2, float eps,
                                                         float gscale) {
@@ -581,6 +641,40 @@ int ss_loss_weighted_bce_t(int32_t dtype, const void* truth, const void* pred, i
     hipStream_t s = (hipStream_t)stream;
     const int nb = loss_blocks(count);
     SS_DT(dtype, hipLaunchKernelGGL(wbce_kernel<T>, dim3(nb), dim3(EW_BLOCK), 0, s, (const T*)truth, (const T*)pred, (long)count, weighting,
+                                    grad_scale / (float)count, (T*)grad, (float*)ws));
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finish_kernel<3>, dim3(1), dim3(EW_BLOCK), 0, s, (const float*)ws, nb, 1.f / (float)count, out3);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_softmax_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride, int64_t rows, int32_t c, void* stream) {
+    if (!x || !y || rows < 0 || c <= 0) return SS_ERR_INVALID;
+    if (rows == 0) return SS_OK;
+    SS_DT(dtype, hipLaunchKernelGGL(softmax_fwd_kernel<T>, dim3(ew_grid(rows)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)x, x_cstride,
+                                    (T*)y, y_cstride, (long)rows, c));
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_softmax_bwd_t(int32_t dtype, const void* dy, int32_t dy_cstride, const void* y, int32_t y_cstride, void* dx, int32_t dx_cstride,
+                     int64_t rows, int32_t c, void* stream) {
+    if (!dy || !y || !dx || rows < 0 || c <= 0) return SS_ERR_INVALID;
+    if (rows == 0) return SS_OK;
+    SS_DT(dtype, hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3(ew_grid(rows)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)dy, dy_cstride,
+                                    (const T*)y, y_cstride, (T*)dx, dx_cstride, (long)rows, c));
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int ss_loss_weighted_bce_mc_t(int32_t dtype, const void* truth, const void* pred, int64_t rows, int32_t c, float weighting, float grad_scale,
+                              float* out3, void* grad, void* ws, size_t ws_bytes, void* stream) {
+    if (!truth || !pred || !out3 || rows <= 0 || c <= 0) return SS_ERR_INVALID;
+    const int64_t count = rows * c;
+    if (!ws || ws_bytes < ss_loss_workspace_bytes(count)) return SS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = loss_blocks(rows);
+    SS_DT(dtype, hipLaunchKernelGGL(wbce_mc_kernel<T>, dim3(nb), dim3(EW_BLOCK), 0, s, (const T*)truth, (const T*)pred, (long)rows, c, weighting,
                                     grad_scale / (float)count, (T*)grad, (float*)ws));
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finish_kernel<3>, dim3(1), dim3(EW_BLOCK), 0, s, (const float*)ws, nb, 1.f / (float)count, out3);

@@ -562,6 +562,24 @@ def upsample2x(tape, x):
     return y
 
 
+def softmax(tape, x):
+    """keras.layers.Activation('softmax') over the channels of every pixel (UNet_Segmentation.py:560)."""
+    lib = L.load()
+    y = x.like()
+    L.check(lib.ss_softmax_fwd_t(x.dt, x.ptr, x.cs, y.ptr, y.cs, x.rows, x.c, _stream()), "softmax_fwd")
+
+    def backward():
+        dy = y.get_grad()
+        if dy is None or not x.requires_grad:
+            return
+        dx, accum = x.grad_target()
+        assert not accum, "softmax input has one consumer"
+        L.check(lib.ss_softmax_bwd_t(x.dt, dy.ptr, dy.cs, y.ptr, y.cs, dx.ptr, dx.cs, x.rows, x.c, _stream()), "softmax_bwd")
+
+    tape.record(backward)
+    return y
+
+
 def add(tape, a, b, out=None):
     """keras.layers.add([a, b])."""
     lib = L.load()

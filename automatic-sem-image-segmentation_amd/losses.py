@@ -49,5 +49,10 @@ def weighted_bce(truth, pred, weighting, grad_scale, out3, want_grad=True):
     count = pred.rows * pred.c
     ws = workspace(lib.ss_loss_workspace_bytes(count), pred.device)
     assert truth.dt == pred.dt
+    if pred.c > 1:          # multi-class head: the reference's closure averages the BCE over the channels first (UNet_Segmentation.py:379-384)
+        assert truth.c == pred.c, "one-hot targets, one channel per class"
+        L.check(lib.ss_loss_weighted_bce_mc_t(pred.dt, truth.ptr, pred.ptr, pred.rows, pred.c, float(weighting), float(grad_scale), _p(out3),
+                                              g.ptr if g is not None else None, _p(ws), ws.numel(), _stream()), "ss_loss_weighted_bce_mc")
+        return
     L.check(lib.ss_loss_weighted_bce_t(pred.dt, truth.ptr, pred.ptr, count, float(weighting), float(grad_scale), _p(out3),
                                      g.ptr if g is not None else None, _p(ws), ws.numel(), _stream()), "ss_loss_weighted_bce")

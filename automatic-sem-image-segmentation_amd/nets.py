@@ -288,13 +288,15 @@ class _ResPath:
 
 
 class MultiResUNet(Network):
-    """output_channels == 1 head (sigmoid).  Decoder block widths follow the reference's hard-coded
-    32*8 / 32*4 / 32*2 (UNet_Segmentation.py:543,546,549), independent of ``conv_filters``."""
+    """UNet.multi_res_unet (UNet_Segmentation.py:505-562).  ``output_channels == 1``: conv2d_bn(1, 1x1, sigmoid) head (:556-557);
+    otherwise Conv2D(output_channels, 1x1, bias) + softmax over the channels (:558-560).  Decoder block widths follow the
+    reference's hard-coded 32*8 / 32*4 / 32*2 (UNet_Segmentation.py:543,546,549), independent of ``conv_filters``."""
 
     ALPHA = 1.67
 
-    def __init__(self, conv_filters=16, device="cuda", seed=0, algo=L.ALGO_AUTO, act_dtype=torch.float32):
+    def __init__(self, conv_filters=16, device="cuda", seed=0, algo=L.ALGO_AUTO, act_dtype=torch.float32, output_channels=1):
         super().__init__(device, act_dtype)
+        self.output_channels = output_channels
         A = self.arena
         f = self.filters = conv_filters
         self.mrb1 = _MultiResBlock(A, "mrb1", f, 1, algo)
@@ -314,7 +316,10 @@ class MultiResUNet(Network):
         self.mrb8 = _MultiResBlock(A, "mrb8", 32 * 2, f * 4, algo)
         self.up9 = Conv2D(A, "up9T", 2, self.mrb8.cout, f, stride=2, use_bias=True, transposed=True, algo=algo)
         self.mrb9 = _MultiResBlock(A, "mrb9", f, f * 2, algo)
-        self.head = _ConvBN(A, "out1x1", 1, self.mrb9.cout, 1, algo)
+        if output_channels == 1:
+            self.head = _ConvBN(A, "out1x1", 1, self.mrb9.cout, 1, algo)
+        else:
+            self.head = Conv2D(A, "out1x1", 1, self.mrb9.cout, output_channels, use_bias=True, algo=algo)
         self._finish(seed)
 
     def forward(self, tape, x, training=True):
@@ -349,4 +354,7 @@ class MultiResUNet(Network):
         self.up9(tape, m8, out=cat9.slice(0, f))
         m9 = self.mrb9(tape, cat9, t)
         m9 = crop(tape, m9, ph // 2, ph // 2 + ph % 2, pw // 2, pw // 2 + pw % 2)     # Cropping2D, UNet_Segmentation.py:554
-        return self.head(tape, m9, "sigmoid", t)
+        if self.output_channels == 1:
+            return self.head(tape, m9, "sigmoid", t)
+        from .layers import softmax
+        return softmax(tape, self.head(tape, m9))

@@ -353,6 +353,15 @@ int ss_loss_mse_const_t(int32_t dtype, const void* pred, int64_t count, float ta
                         float* loss_out, void* grad, void* ws, size_t ws_bytes, void* stream);
 int ss_loss_mae_t(int32_t dtype, const void* truth, const void* pred, int64_t count, float grad_scale,
                   float* loss_out, void* grad, void* ws, size_t ws_bytes, void* stream);
+/* Multi-class head of the MultiResUNet (UNet_Segmentation.py:558-560): softmax over the c channels of each of `rows` pixels and its
+ * backward dx = y .* (dy - <dy, y>); and the reference's loss closure on a c-channel output (UNet_Segmentation.py:379-384, dense
+ * [rows][c] tensors): per pixel the channel-mean BCE, broadcast over the channels and weighted with truth * (weighting - 1) + 1,
+ * mean over everything; out3 = {loss, mae, categorical accuracy}; grad (optional) = d (grad_scale * loss) / d pred. */
+int ss_softmax_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride, int64_t rows, int32_t c, void* stream);
+int ss_softmax_bwd_t(int32_t dtype, const void* dy, int32_t dy_cstride, const void* y, int32_t y_cstride, void* dx, int32_t dx_cstride,
+                     int64_t rows, int32_t c, void* stream);
+int ss_loss_weighted_bce_mc_t(int32_t dtype, const void* truth, const void* pred, int64_t rows, int32_t c, float weighting, float grad_scale,
+                              float* out3, void* grad, void* ws, size_t ws_bytes, void* stream);
 int ss_loss_weighted_bce_t(int32_t dtype, const void* truth, const void* pred, int64_t count, float weighting, float grad_scale,
                            float* out3, void* grad, void* ws, size_t ws_bytes, void* stream);
 

@@ -203,12 +203,14 @@ class PatchDiscriminator(Net):
 
 
 class MultiResUNet(Net):
-    """UNet.multi_res_unet, output_channels == 1 (UNet_Segmentation.py:505-562)."""
+    """UNet.multi_res_unet (UNet_Segmentation.py:505-562): output_channels == 1 -> conv2d_bn(1, 1x1, sigmoid) head (:556-557),
+    otherwise Conv2D(output_channels, 1x1, bias) + softmax over the channels (:558-560)."""
 
     ALPHA = 1.67
 
-    def __init__(self, conv_filters=16, dtype=torch.float32, seed=0):
+    def __init__(self, conv_filters=16, dtype=torch.float32, seed=0, output_channels=1):
         super().__init__(dtype, seed)
+        self.output_channels = output_channels
         self.filters = f = conv_filters
         self._n = 0
         cin = 1
@@ -229,7 +231,11 @@ class MultiResUNet(Net):
         c8 = self._mrb_make("mrb8", 32 * 2, f * 2 + f * 2)
         self._upT_make("up9T", c8, f)
         c9 = self._mrb_make("mrb9", f, f + f)
-        self._cbn_make("out1x1", 1, c9, 1)
+        if output_channels == 1:
+            self._cbn_make("out1x1", 1, c9, 1)
+        else:
+            self.add_kernel("out1x1/kernel", (1, 1, c9, output_channels))
+            self.add_zeros("out1x1/bias", (output_channels,))
 
     # ---- parameter construction (Keras creation order) ------------------
     @classmethod
@@ -331,4 +337,6 @@ class MultiResUNet(Net):
         m9 = self._mrb("mrb9", torch.cat([self._upT("up9T", m8), m1], dim=3), t)
         H, W = m9.shape[1], m9.shape[2]
         m9 = m9[:, ph // 2: H - (ph // 2 + ph % 2), pw // 2: W - (pw // 2 + pw % 2), :]
-        return self._cbn("out1x1", m9, t, "sigmoid")
+        if self.output_channels == 1:
+            return self._cbn("out1x1", m9, t, "sigmoid")
+        return torch.softmax(ops.conv2d(m9, self.p("out1x1/kernel"), self.p("out1x1/bias"), stride=1, padding="valid"), dim=-1)

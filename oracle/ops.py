@@ -118,6 +118,15 @@ def mae(y_true, y_pred):
     return (y_true - y_pred).abs().mean()
 
 
+def weighted_bce_multi(y_true, y_pred, weighting, eps=1e-7):
+    """The reference's loss closure for a multi-channel output (UNet_Segmentation.py:379-384): BinaryCrossentropy(reduction none)
+    averages over the LAST axis, the result is broadcast back over the channels and weighted with y_true * (w - 1) + 1."""
+    p = y_pred.clamp(eps, 1.0 - eps)
+    bce = -(y_true * torch.log(p) + (1.0 - y_true) * torch.log(1.0 - p)).mean(dim=-1, keepdim=True)
+    weights = y_true * (weighting - 1.0) + 1.0
+    return (bce * weights).mean()
+
+
 def weighted_bce(y_true, y_pred, weighting, eps=1e-7):
     """UNet_Segmentation.py:379-384 with Keras' BinaryCrossentropy(reduction='none')."""
     p = y_pred.clamp(eps, 1.0 - eps)

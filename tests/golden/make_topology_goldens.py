@@ -166,7 +166,8 @@ def install_layer_stub():
 
     class Activation(Layer):
         def __init__(self, activation, name=None, **kw):
-            self.fn = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[activation]
+            self.fn = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid,
+                       "softmax": lambda x: torch.softmax(x, dim=-1)}[activation]
 
         def call(self, x):
             return self.fn(x)
@@ -315,6 +316,14 @@ def main():
             return RUN.UNet.multi_res_unet(Stub.input, output_channels=1, conv_filters=16)
         res[name] = run_builder(build, x, 300 + i, counters, want_inference=True)
         print(name, res[name]["y_train"].shape, len(res[name]["names"]), "variables")
+
+    # --- multi-class head (UNet_Segmentation.py:558-560): Conv2D(k, 1x1, bias) + softmax instead of conv2d_bn(1, sigmoid) ---------
+    x = torch.rand((2, 32, 32, 1), generator=g)
+
+    def build_mc():
+        return RUN.UNet.multi_res_unet(Stub.input, output_channels=3, conv_filters=16)
+    res["unet_32_softmax3"] = run_builder(build_mc, x, 310, counters, want_inference=True)
+    print("unet_32_softmax3", res["unet_32_softmax3"]["y_train"].shape, len(res["unet_32_softmax3"]["names"]), "variables")
 
     flat = {f"{case}/{k}": v for case, d in res.items() for k, v in d.items()}
     path = os.path.join(HERE, "topology_goldens.npz")

@@ -518,3 +518,68 @@ def test_gather_conv_v2_is_bit_identical_to_the_two_barrier_kernel(case):
     yr = oracle_conv(xr, w_cpu.double(), k, stride, padding, transposed) + torch.linspace(-0.1, 0.1, cout).double()
     yr = torch.where(yr > 0, yr, 0.2 * yr)
     assert float((outs[1][0].double() - yr).abs().max()) < 1e-4 * max(1.0, float(yr.abs().max()))
+
+
+# ---- multi-class head of the MultiResUNet (UNet_Segmentation.py:558-560, loss closure :379-384) -------------------------------------
+
+def test_softmax_and_multichannel_weighted_bce_vs_oracle():
+    E, LY, LS, L = mod("engine"), mod("layers"), mod("losses"), mod("_lib")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    n, h, w, c = 2, 9, 7, 3
+    logits = torch.randn((n, h, w, c), generator=g) * 2
+    cls = torch.randint(0, c, (n, h, w), generator=g)
+    truth = torch.nn.functional.one_hot(cls, c).float()
+    # oracle in float64
+    lr = logits.double().requires_grad_(True)
+    pr = torch.softmax(lr, -1)
+    loss_r = O.weighted_bce_multi(truth.double(), pr, 5.0)
+    loss_r.backward()
+    mae_r = float((truth.double() - pr).abs().mean())
+    acc_r = float((pr.argmax(-1) == cls).double().mean())
+    # HIP
+    tape = E.Tape()
+    x = E.Act(logits.to(dev), requires_grad=True)
+    p = LY.softmax(tape, x)
+    out3 = torch.zeros(4, device=dev)
+    LS.weighted_bce(E.Act(truth.to(dev), requires_grad=False), p, 5.0, 1.0, out3)
+    tape.backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(p.dense().cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-6)
+    o = out3.cpu().numpy()
+    assert abs(o[0] - float(loss_r)) <= 2e-6 * max(1.0, abs(float(loss_r))) and abs(o[1] - mae_r) <= 1e-6 and abs(o[2] - acc_r) <= 1e-6
+    np.testing.assert_allclose(x.grad.dense().cpu().numpy(), lr.grad.numpy(), rtol=2e-4, atol=2e-7)
+
+
+def test_unet_softmax_head_train_step_vs_oracle():
+    """MultiResUNet(output_channels=3) on the HIP engine: forward equals the oracle network (itself held to the reference builder's
+    vectors in tests/test_topology_golden.py), one train step reproduces the oracle's loss / mae / categorical accuracy and moves the
+    weights the same way."""
+    NETS, UN, OPT = mod("nets"), mod("UNet_Segmentation"), mod("optim")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand((2, 32, 32, 1), generator=g)
+    cls = torch.randint(0, 3, (2, 32, 32), generator=g)
+    y = torch.nn.functional.one_hot(cls, 3).float()
+    onet = ON.MultiResUNet(16, output_channels=3, seed=3)
+    net = NETS.MultiResUNet(16, device=dev, output_channels=3)
+    net.set_weights(onet.get_weights())
+    with torch.no_grad():
+        want = onet(x, False)
+    got = net(x.to(dev), False).dense().cpu()
+    assert got.shape == want.shape and float((got - want).abs().max()) < 2e-4
+    assert float((got.sum(-1) - 1).abs().max()) < 1e-5
+    onet.zero_grad()
+    p = onet(x, True)
+    loss = O.weighted_bce_multi(y, p, 4.0)
+    loss.backward()
+    model = UN.UNetModel(net, 4.0, OPT.Adam(1e-3))
+    m = model.train_step((x.numpy(), y.numpy()))
+    assert abs(m["loss"] - float(loss)) <= 5e-4 * max(1.0, abs(float(loss))), (m, float(loss))
+    assert abs(m["mae"] - float((y - p).abs().mean())) <= 5e-4
+    assert abs(m["acc"] - float((p.argmax(-1) == cls).float().mean())) <= 2e-3
+    tw = onet.trainable_weights
+    grads = net.get_gradients()
+    num = sum(float(((torch.from_numpy(grads[v.name]).reshape(v.value.shape).double() - v.value.grad.double()) ** 2).sum()) for v in tw)
+    den = sum(float((v.value.grad.double() ** 2).sum()) for v in tw)
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5

@@ -32,6 +32,7 @@ CASES = {
     "disc_valid_134x130_nd3": ("PatchDiscriminator", dict(filters=8, num_downsampling_blocks=3, padding="valid")),
     "unet_32": ("MultiResUNet", dict(conv_filters=16)),
     "unet_pad_40x36": ("MultiResUNet", dict(conv_filters=16)),
+    "unet_32_softmax3": ("MultiResUNet", dict(conv_filters=16, output_channels=3)),
 }
 
 

@@ -43,6 +43,8 @@ __device__ __forceinline__ void split_h2s(float x0, float x1, unsigned int& hh, 
     ll = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
 }
 
+__device__ float ss_zero_page16[4] = {0.f, 0.f, 0.f, 0.f};           // what masked 16-byte loads read instead of selecting zeros afterwards
+
 constexpr int XK = 32;          // K step (elements)
 constexpr int XLD = XK + 8;     // LDS row stride in bf16 elements (80 bytes)
 constexpr int XBM = 128;
@@ -423,32 +425,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
     }
 
     f32x4 ra[4], rb[4];
-    bool za[4], zb[4];
+    // Out-of-image / out-of-range pieces are READ from a 16-byte zero page (a pointer select per load instead of a value select per
+    // element at store time).  Fast addressing (the usual case): the class grid's rows are multiples of 4 pixels and the split
+    // starts on one, so a thread's 4 pixels lie in ONE row -- the row is mapped once, the columns step by the stride -- and both
+    // tensors are below 2^31 elements, so the offsets are 32-bit until the final pointer add.
+    const float* const zpage = ss_zero_page16;
+    const bool fast = (p.GW & 3) == 0 && (ps & 3) == 0 && (long)p.N * p.AH * p.AW * p.a_cs < (1L << 31) && P * p.b_cs < (1L << 31);
     auto load_tiles = [&](long pk0) {
-        int x = f_x, y = f_y, n = f_n;
+        if (fast) {
+            const long pk = pk0 + 4 * kq;
+            const bool in = pk < pe;              // pe is a multiple of 4 here: all four pixels or none
+            const int iy = ss_map_index(f_y * p.a_s + p.a_oy + a_dy, p.AH, p.reflect);
+            const bool rowok = a_val && in && iy >= 0;
+            const int rowbase = (f_n * p.AH + iy) * p.AW;
+            const int xb = f_x * p.a_s + p.a_ox + a_dx;
+            const int bo = (int)pk * p.b_cs + bn;
+            const bool okb = b_val && in;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long pk = pk0 + 4 * kq + i;
-            const int iy = ss_map_index(y * p.a_s + p.a_oy + a_dy, p.AH, p.reflect);
-            const int ix = ss_map_index(x * p.a_s + p.a_ox + a_dx, p.AW, p.reflect);
-            const bool oka = a_val && pk < pe && iy >= 0 && ix >= 0;
-            const long off = oka ? ((long)(n * p.AH + iy) * p.AW + ix) * p.a_cs + a_c : 0;
-            ra[i] = *(const f32x4*)(g_a + off);
-            za[i] = !oka;
-            const bool okb = b_val && pk < pe;
-            rb[i] = *(const f32x4*)(g_b + (okb ? pk * p.b_cs + bn : 0));
-            zb[i] = !okb;
-            if (++x >= p.GW) { x = 0; if (++y >= p.GH) { y = 0; ++n; } }
+            for (int i = 0; i < 4; ++i) {
+                const int ix = ss_map_index(xb + i * p.a_s, p.AW, p.reflect);
+                const float* pa = (rowok && ix >= 0) ? g_a + ((rowbase + ix) * p.a_cs + a_c) : zpage;
+                ra[i] = *(const f32x4*)pa;
+                const float* pb = okb ? g_b + (bo + i * p.b_cs) : zpage;
+                rb[i] = *(const f32x4*)pb;
+            }
+        } else {
+            int x = f_x, y = f_y, n = f_n;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long pk = pk0 + 4 * kq + i;
+                const int iy = ss_map_index(y * p.a_s + p.a_oy + a_dy, p.AH, p.reflect);
+                const int ix = ss_map_index(x * p.a_s + p.a_ox + a_dx, p.AW, p.reflect);
+                const bool oka = a_val && pk < pe && iy >= 0 && ix >= 0;
+                const float* pa = oka ? g_a + (((long)(n * p.AH + iy) * p.AW + ix) * p.a_cs + a_c) : zpage;
+                ra[i] = *(const f32x4*)pa;
+                const bool okb = b_val && pk < pe;
+                const float* pb = okb ? g_b + (pk * p.b_cs + bn) : zpage;
+                rb[i] = *(const f32x4*)pb;
+                if (++x >= p.GW) { x = 0; if (++y >= p.GH) { y = 0; ++n; } }
+            }
         }
         // advance the base pixel by one K step
         f_x += XK;
         while (f_x >= p.GW) { f_x -= p.GW; if (++f_y >= p.GH) { f_y = 0; ++f_n; } }
     };
     auto store_tiles = [&]() {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 va[4], vb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { va[i] = za[i] ? z : ra[i]; vb[i] = zb[i] ? z : rb[i]; }
+        const f32x4 (&va)[4] = ra;
+        const f32x4 (&vb)[4] = rb;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             unsigned short* dst = sA + (4 * cq + e) * XLD + 4 * kq;

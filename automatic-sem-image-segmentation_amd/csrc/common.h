@@ -84,6 +84,30 @@ __device__ __forceinline__ int ss_amax_exp(float amax) {
     return e < -100 ? -100 : e;
 }
 
+// Two fp32 values (already scaled) -> packed fp16 pairs: x = h + l (ss_split_h2), or x = h + l' / 2048 (ss_split_h2s: the low piece
+// carried at 2^11 times its value, normal fp16 range down to 2^-28 of the scaled maximum).  Written on 2-vectors so that the two
+// roundings of a pair become ONE v_cvt_pk_f16_f32 (round to nearest even, the same bits as two scalar conversions) and no shift /
+// or is needed to pack them: 3 (4) VALU instructions per value instead of 4 (5) -- the split, not the matrix pipe, paces the
+// gather kernels (profiles/r02_f_gather_wgrad_pmc_and_l3_probe.md).
+typedef _Float16 ss_h2 __attribute__((ext_vector_type(2)));
+typedef float ss_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ss_split_h2(float x0, float x1, unsigned int& hh, unsigned int& ll) {
+    const ss_f2 v = {x0, x1};
+    const ss_h2 h = __builtin_convertvector(v, ss_h2);
+    const ss_f2 r = {x0 - (float)h[0], x1 - (float)h[1]};
+    const ss_h2 l = __builtin_convertvector(r, ss_h2);
+    hh = __builtin_bit_cast(unsigned int, h);
+    ll = __builtin_bit_cast(unsigned int, l);
+}
+__device__ __forceinline__ void ss_split_h2s(float x0, float x1, unsigned int& hh, unsigned int& ll) {
+    const ss_f2 v = {x0, x1};
+    const ss_h2 h = __builtin_convertvector(v, ss_h2);
+    const ss_f2 r = {(x0 - (float)h[0]) * 2048.f, (x1 - (float)h[1]) * 2048.f};
+    const ss_h2 l = __builtin_convertvector(r, ss_h2);
+    hh = __builtin_bit_cast(unsigned int, h);
+    ll = __builtin_bit_cast(unsigned int, l);
+}
+
 // Reflection / zero padding index map. Returns -1 when the tap falls into zero padding.
 __device__ __forceinline__ int ss_map_index(int i, int size, int reflect) {
     if (reflect) {

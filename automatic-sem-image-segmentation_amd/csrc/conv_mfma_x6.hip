@@ -26,23 +26,8 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // dw
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// two fp32 values (already scaled) -> packed fp16 pairs (h, l) with x = h + l
-__device__ __forceinline__ void split_h2(float x0, float x1, unsigned int& hh, unsigned int& ll) {
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-    hh = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
-    ll = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
-}
-
-// same with the low piece carried at 2^11 times its value (normal fp16 range for every element down to 2^-28 of the scaled maximum):
-// the cross products then go to their OWN accumulator, folded in as 2^-11 * (h*l' + l'*h) at the end (wgrad_x6_kernel)
-__device__ __forceinline__ void split_h2s(float x0, float x1, unsigned int& hh, unsigned int& ll) {
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    const _Float16 l0 = (_Float16)((x0 - (float)h0) * 2048.f), l1 = (_Float16)((x1 - (float)h1) * 2048.f);
-    hh = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
-    ll = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
-}
-
+// the fp16 piece splits: common.h (ss_split_h2 / ss_split_h2s).  With the low piece carried at 2^11 times its value the cross
+// products go to their OWN accumulator, folded in as 2^-11 * (h*l' + l'*h) at the end (wgrad_x6_kernel)
 __device__ float ss_zero_page16[4] = {0.f, 0.f, 0.f, 0.f};           // what masked 16-byte loads read instead of selecting zeros afterwards
 
 constexpr int XK = 32;          // K step (elements)
@@ -198,11 +183,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
                 unsigned int hh[2], ll[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const float x0 = v[2 * e] * a_scale, x1 = v[2 * e + 1] * a_scale;
-                    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-                    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-                    hh[e] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
-                    ll[e] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+                    ss_split_h2(v[2 * e] * a_scale, v[2 * e + 1] * a_scale, hh[e], ll[e]);
                 }
                 *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
                 *(u32x2*)(dst + BM * XLD) = u32x2{ll[0], ll[1]};
@@ -477,8 +458,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
             unsigned short* dst = sA + (4 * cq + e) * XLD + 4 * kq;
             if constexpr (H) {
                 unsigned int hh[2], ll[2];
-                split_h2s(va[0][e] * a_scale, va[1][e] * a_scale, hh[0], ll[0]);
-                split_h2s(va[2][e] * a_scale, va[3][e] * a_scale, hh[1], ll[1]);
+                ss_split_h2s(va[0][e] * a_scale, va[1][e] * a_scale, hh[0], ll[0]);
+                ss_split_h2s(va[2][e] * a_scale, va[3][e] * a_scale, hh[1], ll[1]);
                 *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
                 *(u32x2*)(dst + BM * XLD) = u32x2{ll[0], ll[1]};
             } else {
@@ -496,8 +477,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
                 unsigned short* dst = sB + (4 * cq + e) * XLD + 4 * kq;
                 if constexpr (H) {
                     unsigned int hh[2], ll[2];
-                    split_h2s(vb[0][e] * b_scale, vb[1][e] * b_scale, hh[0], ll[0]);
-                    split_h2s(vb[2][e] * b_scale, vb[3][e] * b_scale, hh[1], ll[1]);
+                    ss_split_h2s(vb[0][e] * b_scale, vb[1][e] * b_scale, hh[0], ll[0]);
+                    ss_split_h2s(vb[2][e] * b_scale, vb[3][e] * b_scale, hh[1], ll[1]);
                     *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
                     *(u32x2*)(dst + BN * XLD) = u32x2{ll[0], ll[1]};
                 } else {

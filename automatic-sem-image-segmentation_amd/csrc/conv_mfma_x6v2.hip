@@ -144,11 +144,7 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         unsigned int hh[2], ll[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float x0 = v[2 * e] * a_scale, x1 = v[2 * e + 1] * a_scale;
-            const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-            const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-            hh[e] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
-            ll[e] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+            ss_split_h2(v[2 * e] * a_scale, v[2 * e + 1] * a_scale, hh[e], ll[e]);
         }
         unsigned char* dst = lds + stage * VSTAGE + ((arow + 64 * j) * VLD + c4a * 4) * 2;
         *(u32x2*)(dst) = u32x2{hh[0], hh[1]};

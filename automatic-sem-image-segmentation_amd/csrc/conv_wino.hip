@@ -201,12 +201,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
             for (int j = 0; j < P; ++j) {
 #pragma unroll
                 for (int k = 0; k < VW; k += 2) {
-                    const float v0 = v[j][k] * x3h_scale, v1 = v[j][k + 1] * x3h_scale;
-                    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-                    const _Float16 l0 = (_Float16)((v0 - (float)h0) * 2048.f), l1 = (_Float16)((v1 - (float)h1) * 2048.f);
                     unsigned int* d = o3 + (long)(i * P + j) * xs3 / 2 + k / 2;
-                    d[0] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
-                    d[pl32] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+                    ss_split_h2s(v[j][k] * x3h_scale, v[j][k + 1] * x3h_scale, d[0], d[pl32]);
                 }
             }
         } else if (BF == 2) {
@@ -291,11 +287,7 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
                 const long pl32 = (long)P * P * xs / 2;
 #pragma unroll
                 for (int k = 0; k < VW; k += 2) {
-                    const float v0 = w[j][k] * sc, v1 = w[j][k + 1] * sc;
-                    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-                    const _Float16 l0 = (_Float16)((v0 - (float)h0) * 2048.f), l1 = (_Float16)((v1 - (float)h1) * 2048.f);
-                    d[k / 2] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
-                    d[pl32 + k / 2] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+                    ss_split_h2s(w[j][k] * sc, w[j][k + 1] * sc, d[k / 2], d[pl32 + k / 2]);
                 }
             } else {
                 *(T*)(o + (long)(i * P + j) * xs) = w[j];
@@ -440,11 +432,7 @@ __global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __rest
         for (int j = 0; j < P; ++j) {
             const long o = (long)(i * P + j) * xs2;
             if (F16) {
-                const float v0 = u2[0][i][j] * sc, v1 = u2[1][i][j] * sc;
-                const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-                const _Float16 l0 = (_Float16)((v0 - (float)h0) * 2048.f), l1 = (_Float16)((v1 - (float)h1) * 2048.f);
-                dst[o] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
-                dst[o + plane_u32] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+                ss_split_h2s(u2[0][i][j] * sc, u2[1][i][j] * sc, dst[o], dst[o + plane_u32]);
             } else {
                 unsigned int h, m, l;
                 ss_split3x2(f32x2{u2[0][i][j], u2[1][i][j]}, h, m, l);      // rows no >= NO were staged as zeros

@@ -8,8 +8,8 @@
 //     gathered fp32 activations into fp16 (h, l) pieces and store them to stage s^1 (the activations were requested two K steps
 //     ahead into registers), and the weight planes of that chunk -- already split, K-contiguous rows, cached per weight version --
 //     arrive by LDS-DMA with the XOR slot swizzle of gemm_x6p.hip;
-//   * A rows: 80-byte stride (conflict-free ds_read_b128 fragments, 8-byte stores); zero padding / out-of-image taps are selected
-//     at store time.
+//   * A rows: 80-byte stride (conflict-free ds_read_b128 fragments, 8-byte stores); zero padding / out-of-image taps load from a
+//     16-byte zero page (one pointer select per load instead of a value select per element).
 // Same arithmetic as gconv_x6_kernel<.., true>: x * s = h + l with one power-of-two scale per operand tensor, products l*h, h*l,
 // h*h into one accumulator set, scales undone in the epilogue; results are bit-identical to it (same products, same K order).
 #include "common.h"
@@ -21,6 +21,8 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ float v2_zero_page16[4] = {0.f, 0.f, 0.f, 0.f};
 
 constexpr int VBM = 256, VK = 32;
 constexpr int VLD = VK + 8;                       // A row stride in halfs (80 bytes)
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
     }
 
     f32x4 ra[2][4];
-    bool ok[2][4];
+    const float* const zpage = v2_zero_page16;          // zero-padding / out-of-image taps READ zeros (one pointer select per load)
     auto load_a = [&](auto setc, int chunk) {
         constexpr int S = decltype(setc)::value;
         const int k0 = chunk * VK;
@@ -134,13 +136,13 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int off = offtab[(arow + 64 * j) * p.ntaps + t];
-            ra[S][j] = *(const f32x4*)(abase + (off < 0 ? 0 : off));
-            ok[S][j] = off >= 0;
+            const float* pa = off < 0 ? zpage : abase + off;
+            ra[S][j] = *(const f32x4*)pa;
         }
     };
     auto store_a = [&](auto setc, int stage, int j) {          // row arow + 64 j of the chunk held in register set S -> LDS stage
         constexpr int S = decltype(setc)::value;
-        const f32x4 v = ok[S][j] ? ra[S][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 v = ra[S][j];
         unsigned int hh[2], ll[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {

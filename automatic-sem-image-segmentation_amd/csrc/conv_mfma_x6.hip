@@ -125,10 +125,9 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const unsigned short* bbase = bpl + ((long)batch * Npad + n0 + brow) * Ktot + bpc * 8;
 
     // two register sets: the global loads run TWO K steps ahead of the MFMAs (one step of 48 MFMAs per wave is shorter than
-    // the L2 / HBM latency).  Zero-padding taps: the select is applied at LDS-store time, nothing touches a load earlier.
+    // the L2 / HBM latency).  Zero-padding taps READ a 16-byte zero page (pointer select per load).
     constexpr int AU = BM / 32;          // A loader: rows arow + 32*j
     f32x4 ra[2][AU];
-    bool ra_ok[2][AU];
     u32x4 rb[2][NP][BROWS];
 
     auto load_tiles = [&](auto setc, int k0) {
@@ -140,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
 #pragma unroll
             for (int j = 0; j < AU; ++j) {
                 const int off = offtab[(arow + 32 * j) * p.ntaps + t];
-                ra[S][j] = *(const f32x4*)(abase + (off < 0 ? 0 : off));
-                ra_ok[S][j] = off >= 0;
+                const float* pa = off < 0 ? (const float*)ss_zero_page16 : abase + off;      // masked taps read zeros
+                ra[S][j] = *(const f32x4*)pa;
             }
         } else {
             // any channel count / pixel stride (the MultiResUNet's odd widths): the reduction index runs over (tap, ci padded to a
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
             for (int j = 0; j < AU; ++j) {
                 const int off = offtab[(arow + 32 * j) * p.ntaps + t];
                 const bool ok = off >= 0 && nin > 0;
-                const float* ptr = g_in + (ok ? off + ci : 0);
+                const float* ptr = ok ? g_in + (off + ci) : (const float*)ss_zero_page16;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (nin >= 4) {
                     const f32x4u u = *(const f32x4u*)ptr;
@@ -164,7 +163,6 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
                         if (e < nin) v[e] = ptr[e];
                 }
                 ra[S][j] = v;
-                ra_ok[S][j] = ok;
             }
         }
 #pragma unroll
@@ -177,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int j = 0; j < AU; ++j) {
-            const f32x4 v = ra_ok[S][j] ? ra[S][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 v = ra[S][j];
             unsigned short* dst = sA + (arow + 32 * j) * XLD + c4a * 4;
             if constexpr (H) {
                 unsigned int hh[2], ll[2];

@@ -280,69 +280,42 @@ __global__ __launch_bounds__(256) void norm_infer_kernel(const T* __restrict__ x
     y[row * y_cs + c] = (T)ss_apply_act(v, act, alpha);
 }
 
-// backward finalize: per (g,c) means of g and g*xhat -> sums array; dgamma/dbeta summed over groups.
-// Block = 32 channels x 8 chunk lanes; every combine is a fixed-order LDS sum.  The groups are taken FOUR at a time: the kernel is
-// a chain of memory round trips (one per group when they are walked one by one: 23 us for the 8 instances of a trunk layer on
-// 8 blocks), so the loads of four groups are issued together and their LDS combines share the two barriers.  Summation order per
-// group (k), and of dgamma / dbeta over the groups (g), is unchanged.
+// backward finalize: per (g,c) means of g and g*xhat -> sums array, and the raw per-group totals (double) -> rt.
+// Block = CL channels x 256/CL chunk lanes of ONE group, grid (C/CL, G) (it walked the groups one after the other on C/CL blocks:
+// a chain of G memory round trips, 23 us for the 8 instances of a trunk layer); every combine is a fixed-order LDS sum.  dgamma /
+// dbeta = the totals summed over the groups in group order: norm_bwd_apply_kernel does that from rt (same values as before).
 __global__ __launch_bounds__(256) void norm_finalize_bwd(const float* __restrict__ part, int chunks, int G, int C, long P,
-                                                         float* __restrict__ sums /* [G*C*2] */,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int CL) {
-    constexpr int GB = 4;
-    __shared__ double red[GB][2][256];
+                                                         float* __restrict__ sums /* [G*C*2] */, double* __restrict__ rt /* [G*C*2] */, int CL) {
+    __shared__ double red[2][256];
     const int KL = 256 / CL;
     const int cl = threadIdx.x % CL, kl = threadIdx.x / CL;
-    const int c = blockIdx.x * CL + cl;
-    double tg = 0.0, tgx = 0.0;
-    for (int g0 = 0; g0 < G; g0 += GB) {
-        double s1[GB], s2[GB];
+    const int c = blockIdx.x * CL + cl, g = blockIdx.y;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int k = kl; k < chunks; k += 8 * KL) {          // 8 loads in flight, same k order (see norm_finalize_fwd)
+            float a0[8], a1[8];
 #pragma unroll
-        for (int j = 0; j < GB; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
-        if (c < C) {
-            for (int k = kl; k < chunks; k += 8 * KL) {          // 8 loads per group in flight, same k order (see norm_finalize_fwd)
-                float a0[GB][8], a1[GB][8];
-#pragma unroll
-                for (int j = 0; j < GB; ++j) {
-                    const int g = g0 + j;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int kk = k + u * KL;
-                        const float2 t = (g < G && kk < chunks) ? *(const float2*)(part + (((long)g * chunks + kk) * C + c) * 2) : make_float2(0.f, 0.f);
-                        a0[j][u] = t.x;
-                        a1[j][u] = t.y;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < GB; ++j)
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { s1[j] += a0[j][u]; s2[j] += a1[j][u]; }
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k + u * KL;
+                const float2 t = kk < chunks ? *(const float2*)(part + (((long)g * chunks + kk) * C + c) * 2) : make_float2(0.f, 0.f);
+                a0[u] = t.x;
+                a1[u] = t.y;
             }
-        }
 #pragma unroll
-        for (int j = 0; j < GB; ++j) {
-            red[j][0][kl * CL + cl] = s1[j];
-            red[j][1][kl * CL + cl] = s2[j];
+            for (int u = 0; u < 8; ++u) { s1 += a0[u]; s2 += a1[u]; }
         }
-        __syncthreads();
-        if (kl == 0 && c < C) {
-#pragma unroll
-            for (int j = 0; j < GB; ++j) {
-                const int g = g0 + j;
-                if (g < G) {
-                    double r1 = 0.0, r2 = 0.0;
-                    for (int k = 0; k < KL; ++k) { r1 += red[j][0][k * CL + cl]; r2 += red[j][1][k * CL + cl]; }
-                    sums[((long)g * C + c) * 2 + 0] = (float)(r1 / (double)P);
-                    sums[((long)g * C + c) * 2 + 1] = (float)(r2 / (double)P);
-                    tg += r1;
-                    tgx += r2;
-                }
-            }
-        }
-        __syncthreads();
     }
+    red[0][kl * CL + cl] = s1;
+    red[1][kl * CL + cl] = s2;
+    __syncthreads();
     if (kl == 0 && c < C) {
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)tg : (float)tg;
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)tgx : (float)tgx;
+        s1 = 0.0; s2 = 0.0;
+        for (int k = 0; k < KL; ++k) { s1 += red[0][k * CL + cl]; s2 += red[1][k * CL + cl]; }
+        const long i = ((long)g * C + c) * 2;
+        sums[i + 0] = (float)(s1 / (double)P);
+        sums[i + 1] = (float)(s2 / (double)P);
+        rt[i + 0] = s1;
+        rt[i + 1] = s2;
     }
 }
 
@@ -357,11 +330,22 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              T* __restrict__ dx, int dx_cs, int acc_dx,
                                                              T* __restrict__ dres, int dres_cs, int acc_dres,
                                                              int act, float alpha, int C, long P, long rows,
-                                                             const float* __restrict__ rbeta = nullptr, unsigned int* __restrict__ amax = nullptr) {
+                                                             const float* __restrict__ rbeta = nullptr, unsigned int* __restrict__ amax = nullptr,
+                                                             const double* __restrict__ rt = nullptr, int G = 0,
+                                                             float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr,
+                                                             int acc_params = 0) {
     const int CV = C / V;
     const long total = rows * CV;
     float am = 0.f;
     const long stride = (long)gridDim.x * blockDim.x;          // incremental (row, channel vector), see norm_apply_kernel
+    if (rt) {          // parameter gradients: the per-group totals of norm_finalize_bwd summed in group order (one thread per channel)
+        for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += stride) {
+            double tg = 0.0, tgx = 0.0;
+            for (int g = 0; g < G; ++g) { tg += rt[((long)g * C + c) * 2]; tgx += rt[((long)g * C + c) * 2 + 1]; }
+            if (dbeta) dbeta[c] = acc_params ? dbeta[c] + (float)tg : (float)tg;
+            if (dgamma) dgamma[c] = acc_params ? dgamma[c] + (float)tgx : (float)tgx;
+        }
+    }
     const long drow = stride / CV;
     const int dcv = (int)(stride - drow * CV);
     const long dg = drow / P, drp = drow - dg * P;              // ... and (group, pixel within the group) of the row
@@ -826,18 +810,20 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
         hipLaunchKernelGGL((norm_stats_kernel<T, 1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
                            d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + FIN_CL - 1) / FIN_CL), dim3(256), 0, s,
-                       part, g.chunks, g.G, g.C, g.P, sums, dgamma, dbeta, accumulate_params, FIN_CL);
+    double* rt = (double*)((char*)ws + part_bytes(d) + ss_align_up((size_t)g.G * g.C * 2 * sizeof(float), 256));
+    hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + FIN_CL - 1) / FIN_CL, g.G), dim3(256), 0, s,
+                       part, g.chunks, g.G, g.C, g.P, sums, rt, FIN_CL);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
+    const double* prt = (dgamma || dbeta) ? rt : nullptr;
     if (V == 4)
         hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, rows, beta, dxam);
+                           d->act, d->act_alpha, g.C, g.P, rows, beta, dxam, prt, g.G, dgamma, dbeta, accumulate_params);
     else
         hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, rows, beta, dxam);
+                           d->act, d->act_alpha, g.C, g.P, rows, beta, dxam, prt, g.G, dgamma, dbeta, accumulate_params);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -960,7 +946,8 @@ int ss_norm_reports_amax(const ss_norm_desc* d) { return valid(d) && d->dtype ==
 
 size_t ss_norm_workspace_bytes(const ss_norm_desc* d) {
     if (!valid(d)) return 0;
-    return part_bytes(d) + ss_align_up((size_t)d->groups * d->c * 2 * sizeof(float), 256);
+    // stats partials | per-(group, channel) means of the backward | their raw totals (double; parameter gradients)
+    return part_bytes(d) + ss_align_up((size_t)d->groups * d->c * 2 * sizeof(float), 256) + ss_align_up((size_t)d->groups * d->c * 2 * sizeof(double), 256);
 }
 
 int ss_norm_fwd(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta,

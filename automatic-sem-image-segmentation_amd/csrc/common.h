@@ -184,6 +184,7 @@ struct X6PParams {
     float* c;                     // [batch][split][M][ldc]
     int32_t M, N, K, nbatch, splits, k_per_split;
     int32_t lda, ldb, ldc;
+    int32_t plain_l;              // x3h planes carry the low piece at its own magnitude (x*s = h + l): 256 x 256 tiles, one accumulator set (gemm_x6p.hip WIDE)
     int32_t fp16x2;               // 0: three bf16 planes, six products (x6);  1: two fp16 planes h + 2^-11 l, three products (x3h)
     int64_t a_plane, b_plane, a_bs, b_bs, c_bs, c_ss;
 };
@@ -205,10 +206,11 @@ int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s);
 bool ss_x6p_enabled();
 bool ss_x3h_enabled();
 bool ss_x6p_wanted(long M, int N, int nbatch);
+bool ss_x6p_wide_ok(long M, int N, int K, int nbatch);
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
 
 // kernel-selection switches: ONE explicit table, set through ss_config_set (config.hip); SS_* environment variables give the initial values
-struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2; };
+struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide; };
 const SsTuning& ss_tuning();
 // ss_prof_*: brackets the kernel launched inside this scope with HIP events on its stream when profiling is enabled (config.hip).
 // flops = EXECUTED matrix-instruction FLOPs of the launch (all piece products), bytes = algorithmic HBM bytes (0 if not stated)

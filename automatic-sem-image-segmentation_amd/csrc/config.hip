@@ -38,6 +38,7 @@ const Key KEYS[] = {
     {"tile_stagger", &SsTuning::tile_stagger, "tile kernel: start delay between co-resident workgroups (units of 2048 cycles)"},
     {"weight_cache", &SsTuning::weight_cache, "reserved"},
     {"gemm_persistent", &SsTuning::gemm_persistent, "pre-split-plane GEMMs: one persistent workgroup per CU whose operand stream runs across tile boundaries; 0: one workgroup per tile"},
+    {"x6p_wide", &SsTuning::x6p_wide, "OPT-IN (default 0): Winograd GEMMs with 256-multiple output channels on 256 x 256 tiles; their planes carry the plain low piece (values below 2^-17 of their tile's maximum keep absolute, not relative, precision)"},
     {"gconv_v2", &SsTuning::gconv_v2, "gather convolutions: two-stage one-barrier kernel with LDS-DMA weight planes (conv_mfma_x6v2.hip) where it applies; 0: gconv_x6_kernel only"},
     {"wgrad_tn", &SsTuning::wgrad_tn, "Winograd weight gradient on pre-split K-major fp16 planes with transposing LDS reads (gemm_tn_x3h.hip); 0: in-kernel split"},
 };
@@ -55,6 +56,7 @@ SsTuning from_env() {
     v.wgrad_c1 = env_is("SS_WGRAD_C1", '0') ? 0 : 1;
     v.wgrad_tn = env_is("SS_WGRAD_TN", '0') ? 0 : 1;
     v.gconv_v2 = env_is("SS_GCONV_V2", '0') ? 0 : 1;
+    v.x6p_wide = env_is("SS_X6P_WIDE", '1') ? 1 : 0;
     v.gemm_persistent = env_is("SS_GEMM_PERSISTENT", '0') ? 0 : 1;
     v.norm_fused_pix = getenv("SS_NORM_FUSED_PIX") ? atoi(getenv("SS_NORM_FUSED_PIX")) : 1024;
     v.gconv_fast = getenv("SS_GCONV_NOFAST") ? 0 : 1;

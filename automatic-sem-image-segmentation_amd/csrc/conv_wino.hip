@@ -124,7 +124,8 @@ template <int R, int BF>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int in_cs, int N, int H, int W, int C,
                                                          int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V, long Mpad = 0,
                                                          float* __restrict__ tile_inv = nullptr, unsigned int* __restrict__ amax_out = nullptr,
-                                                         const unsigned int* __restrict__ amax_in = nullptr, int amax_stripes = 0, int bound = 0) {
+                                                         const unsigned int* __restrict__ amax_in = nullptr, int amax_stripes = 0, int bound = 0,
+                                                         int plain_l = 0) {
     typedef typename WT<R>::T T;
     constexpr int VW = WT<R>::VW, P = R + 2;
     const int CV = C / VW;
@@ -202,7 +203,9 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 #pragma unroll
                 for (int k = 0; k < VW; k += 2) {
                     unsigned int* d = o3 + (long)(i * P + j) * xs3 / 2 + k / 2;
-                    ss_split_h2s(v[j][k] * x3h_scale, v[j][k + 1] * x3h_scale, d[0], d[pl32]);
+                    // plain_l (BF == 3, the wide GEMM tile): the low piece at its own magnitude, v*s = h + l
+                    if (BF == 3 && plain_l) ss_split_h2(v[j][k] * x3h_scale, v[j][k + 1] * x3h_scale, d[0], d[pl32]);
+                    else ss_split_h2s(v[j][k] * x3h_scale, v[j][k + 1] * x3h_scale, d[0], d[pl32]);
                 }
             }
         } else if (BF == 2) {
@@ -365,7 +368,8 @@ __global__ __launch_bounds__(256) void amax_bits_kernel(const float* __restrict_
 template <int R, bool F16 = false>
 __global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __restrict__ w, int Cin, int Cout, int flip, int Npad,
                                                              unsigned short* __restrict__ planes,
-                                                             const unsigned int* __restrict__ amax_bits = nullptr, float* __restrict__ w_inv = nullptr) {
+                                                             const unsigned int* __restrict__ amax_bits = nullptr, float* __restrict__ w_inv = nullptr,
+                                                             int plain_l = 0) {
     constexpr int P = R + 2, HP = P / 2;
     __shared__ float tl[9][32][17];        // [logical tap a*3+b][kr][no]
     const int KR = flip ? Cout : Cin, NO = flip ? Cin : Cout;
@@ -432,7 +436,8 @@ __global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __rest
         for (int j = 0; j < P; ++j) {
             const long o = (long)(i * P + j) * xs2;
             if (F16) {
-                ss_split_h2s(u2[0][i][j] * sc, u2[1][i][j] * sc, dst[o], dst[o + plane_u32]);
+                if (plain_l) ss_split_h2(u2[0][i][j] * sc, u2[1][i][j] * sc, dst[o], dst[o + plane_u32]);
+                else ss_split_h2s(u2[0][i][j] * sc, u2[1][i][j] * sc, dst[o], dst[o + plane_u32]);
             } else {
                 unsigned int h, m, l;
                 ss_split3x2(f32x2{u2[0][i][j], u2[1][i][j]}, h, m, l);      // rows no >= NO were staged as zeros
@@ -646,7 +651,8 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     // output statistics for a following norm: only where the output transform's blocks hold whole tiles of one sample
     float* stats = (q.y_stats && act == SS_ACT_NONE && !accumulate && ss_wino_stats_chunks(q) > 0) ? q.y_stats : nullptr;
     bool fill;      // transformed weights: in the layer's cache when there is one (computed on first use)
-    const uint64_t wdet = (uint64_t)(flip ? 1 : 0) | ((uint64_t)R << 1);
+    const uint64_t wdet0 = (uint64_t)(flip ? 1 : 0) | ((uint64_t)R << 1);
+    const uint64_t wdet = wdet0;
     const bool fill_only = q.wc && q.wc->fill_only;       // refresh of the cached operands: no activation work
     if (q.bf16x3) {
         U = (float*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_UBF, wdet), (size_t)XI * q.cin * q.cout * 4, U, &fill);
@@ -683,6 +689,9 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         unsigned short* planes = (unsigned short*)((char*)Mx + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
         float* tile_inv = nullptr;
         float* w_inv = nullptr;
+        // 256-multiple output channels: 256 x 256 GEMM tiles on planes with the plain low piece (gemm_x6p.hip WIDE)
+        const int wide = x3h && ss_x6p_wide_ok(tiles, q.cout, q.cin, XI) ? 1 : 0;
+        const uint64_t wdet = wdet0 | ((uint64_t)wide << 8);
         if (x3h) {
             char* extra = (char*)planes + ss_align_up((size_t)3 * XI * Npad * q.cin * 2, 256);
             tile_inv = (float*)(extra + 256);
@@ -694,12 +703,12 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
             hipLaunchKernelGGL(amax_bits_kernel, dim3(256), dim3(256), 0, s, w, (long)9 * w_cin * w_cout, (unsigned int*)(w_inv + 1));
             SS_LAUNCH_CHECK();
             hipLaunchKernelGGL((wino_weight_x6_kernel<R, true>), dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes,
-                               (const unsigned int*)(w_inv + 1), w_inv);
+                               (const unsigned int*)(w_inv + 1), w_inv, wide);
             SS_LAUNCH_CHECK();
             }
             if (fill_only) return SS_OK;
             hipLaunchKernelGGL((wino_input_kernel<R, 3>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
-                               TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
+                               TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, wide);
             SS_LAUNCH_CHECK();
         } else {
         planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X6_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill);
@@ -714,6 +723,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         }
         X6PParams g{};
         g.fp16x2 = x3h ? 1 : 0;
+        g.plain_l = wide;
         g.a = (const unsigned short*)V; g.b = planes; g.c = Mx;
         g.M = (int)tiles; g.N = q.cout; g.K = q.cin; g.nbatch = XI; g.splits = 1; g.k_per_split = q.cin;
         g.lda = q.cin; g.ldb = q.cin; g.ldc = q.cout;

@@ -30,23 +30,34 @@ __device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-constexpr int x6p_stages(int npl) { return npl == 2 ? 3 : 2; }
+constexpr int x6p_stages(int npl, bool wide = false) { return npl == 2 && !wide ? 3 : 2; }
 
-template <int NPL>
-__global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
+// WIDE (x3h only): 256 x 256 tile, 1024 threads = 16 waves as 4 (M) x 4 (N), still 64 x 64 per wave.  The kernel is paced by its
+// operand stream (profiles/r02_f_*: 53 % issue stalls behind the LDS-DMA queue, matrix pipe 33 % busy), and a 256 x 128 tile moves
+// 1.5 bytes per output element and K step; 256 x 256 moves 1.0.  Registers for it (four waves per SIMD: 128 VGPRs) come from ONE
+// accumulator set -- the operand planes then carry the low piece at its own magnitude (x*s = h + l, as in the gather kernels;
+// p.plain_l) instead of 2^11 times it -- and one fragment register set (the four resident waves cover the LDS latency); two LDS
+// stages of 64 KiB.
+template <int NPL, bool WIDE>
+__global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParams p) {
+    static_assert(!WIDE || NPL == 2, "the wide tile exists for the two-plane fp16 operands only");
+    constexpr int PBN = WIDE ? 256 : SS_X6P_BN;
+    constexpr int B_PLANE_B = PBN * ROWB;
+    constexpr int NWV = WIDE ? 16 : 8;             // waves per workgroup
+    constexpr int WN = PBN / 64;                   // waves along N
     constexpr int STAGE_B = NPL * (A_PLANE_B + B_PLANE_B);
-    constexpr int NDMA = STAGE_B / 1024 / 8;       // LDS-DMA instructions per wave and K step (9 / 6)
+    constexpr int NDMA = STAGE_B / 1024 / NWV;     // LDS-DMA instructions per wave and K step (9 / 6; wide: 4)
     // Ring of LDS stages.  The K loop is paced by the operand stream, not by the matrix pipe: one stage in flight (two stages) is
     // 48 KiB per CU against ~2 us of loaded HBM / Infinity-Cache latency = 6 TB/s chip-wide, measured 5.96.  x3h stages are 48 KiB,
     // so three fit into the 160 KiB: two tiles in flight while the third is consumed.
-    constexpr int STAGES = x6p_stages(NPL);
+    constexpr int STAGES = x6p_stages(NPL, WIDE);
     typedef typename Frag<NPL>::T FT;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + PBN - 1) / PBN;
     const int per = gridM * gridN;
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
     const unsigned short* gpn[NDMA];
     if (t_first >= t_end) return;
     TileCtx cur = setup(t_first, gp);
-    constexpr int NACC = NPL == 2 ? 2 : 1;          // x3h: the cross terms h*l + l*h accumulate apart (they carry the factor 2^-11)
+    constexpr int NACC = NPL == 2 && !WIDE ? 2 : 1;          // x3h: the cross terms h*l + l*h accumulate apart (they carry the factor 2^-11); wide: plain l, one set
     f32x16 acc[NACC][2][2];
 
     // operand fetch addresses (stage 0): row = (wave tile base) + l31, slot = (lh + 2*ks) ^ ((row >> 2) & 3)
@@ -134,7 +145,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
     // x6: six products, smallest terms first;  x3h: l*h, h*l (cross accumulators), h*h.  Consecutive MFMAs go to different accumulators
     constexpr int NQ = NPL == 3 ? 6 : 3;
     constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0}, HS[3] = {1, 1, 0};
+    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0}, HS[3] = {WIDE ? 0 : 1, WIDE ? 0 : 1, 0};
     auto mma4 = [&](FT (&a)[NPL][2], FT (&b)[NPL][2], int q) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -176,38 +187,69 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
         frag(a0, b0, st, so0);
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
 
-        for (int c = 0; c < nchunks; ++c) {
-            const int st1 = st + 1 == STAGES ? 0 : st + 1;
-            frag(a1, b1, st, so1);
-            __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WIDE) {
+            // one fragment set: half 0 (read after the previous barrier) -> 12 MFMAs -> half 1 into the same registers -> 12 MFMAs ->
+            // chunk c+1 landed + barrier -> its half 0, and the DMA of chunk c+2 into the stage just released
+            for (int c = 0; c < nchunks; ++c) {
+                const int st1 = st ^ 1;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
-            __builtin_amdgcn_sched_barrier(0);
-            // chunk c+1 landed (the younger groups may still be in flight) and this wave's reads of chunk c are done: a real
-            // s_waitcnt (vmcnt((STAGES-2) * NDMA) lgkmcnt(0)), so that the compiler's own counting sees it
-            __builtin_amdgcn_s_waitcnt(0x0070 | (((STAGES - 2) * NDMA) & 15) | ((((STAGES - 2) * NDMA) >> 4) << 14));
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // branch-free from here to the loop end (one basic block keeps the compiler's lgkmcnt counting exact): past the last
-            // chunk of the LAST tile the fragment read fetches stale LDS and the DMA re-fetches the last chunk into a free stage;
-            // past the last chunk of any other tile both continue with the NEXT tile's first chunks
-            frag(a0, b0, st1, so0);
-            const int ca = c + STAGES;
-            const bool own = ca < nchunks;
-            const int cn = own ? ca : (more ? ca - nchunks : nchunks - 1);
-            const long goff = (long)cn * PBK;
-            unsigned char* dst = lds + st * STAGE_B;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                mma4(a1, b1, q);
-#pragma unroll
-                for (int j = 0; j < NDMA; ++j)
-                    if (j * NQ / NDMA == q) dma16(((own || !more) ? gp[j] : gpn[j]) + goff, dst + loff[j]);
+                for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
                 __builtin_amdgcn_sched_barrier(0);
+                frag(a0, b0, st, so1);
+                __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): chunk c+1 landed
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                frag(a0, b0, st1, so0);
+                const int ca = c + STAGES;
+                const bool own = ca < nchunks;
+                const int cn = own ? ca : (more ? ca - nchunks : nchunks - 1);
+                const long goff = (long)cn * PBK;
+                unsigned char* dst = lds + st * STAGE_B;
+#pragma unroll
+                for (int j = 0; j < NDMA; ++j) dma16(((own || !more) ? gp[j] : gpn[j]) + goff, dst + loff[j]);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+                st = st1;
             }
-            // F0's reads finished long ago (24 MFMAs back): a free wait that lets the compiler start the next step without one
-            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
-            st = st1;
+        } else {
+        for (int c = 0; c < nchunks; ++c) {
+                const int st1 = st + 1 == STAGES ? 0 : st + 1;
+                frag(a1, b1, st, so1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
+                __builtin_amdgcn_sched_barrier(0);
+                // chunk c+1 landed (the younger groups may still be in flight) and this wave's reads of chunk c are done: a real
+                // s_waitcnt (vmcnt((STAGES-2) * NDMA) lgkmcnt(0)), so that the compiler's own counting sees it
+                __builtin_amdgcn_s_waitcnt(0x0070 | (((STAGES - 2) * NDMA) & 15) | ((((STAGES - 2) * NDMA) >> 4) << 14));
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // branch-free from here to the loop end (one basic block keeps the compiler's lgkmcnt counting exact): past the last
+                // chunk of the LAST tile the fragment read fetches stale LDS and the DMA re-fetches the last chunk into a free stage;
+                // past the last chunk of any other tile both continue with the NEXT tile's first chunks
+                frag(a0, b0, st1, so0);
+                const int ca = c + STAGES;
+                const bool own = ca < nchunks;
+                const int cn = own ? ca : (more ? ca - nchunks : nchunks - 1);
+                const long goff = (long)cn * PBK;
+                unsigned char* dst = lds + st * STAGE_B;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    mma4(a1, b1, q);
+#pragma unroll
+                    for (int j = 0; j < NDMA; ++j)
+                        if (j * NQ / NDMA == q) dma16(((own || !more) ? gp[j] : gpn[j]) + goff, dst + loff[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // F0's reads finished long ago (24 MFMAs back): a free wait that lets the compiler start the next step without one
+                __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+                st = st1;
+            }
         }
 
         // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The stores are younger than
@@ -222,7 +264,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(X6PParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = cur.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < p.M) cb[(long)m * p.ldc + n] = NPL == 3 ? acc[0][mi][ni][r] : fmaf(acc[NACC - 1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
+                    if (m < p.M) cb[(long)m * p.ldc + n] = NACC == 1 ? acc[0][mi][ni][r] : fmaf(acc[NACC - 1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
                 }
             }
         }
@@ -262,13 +304,23 @@ bool ss_x6p_wanted(long M, int N, int nbatch) {
     return force || nwg >= 1024;
 }
 
+// The wide tile: x3h planes with the plain low piece (p.plain_l, set by the caller that wrote them so), N a multiple of 256
+bool ss_x6p_wide_ok(long M, int N, int K, int nbatch) {
+    if (!ss_tuning().x6p_wide || !ss_x3h_enabled() || N < 256 || N % 256 || K % PBK || K < 2 * PBK) return false;
+    return ss_tuning().x6p == 2 || ((M + PBM - 1) / PBM) * (N / 256) * nbatch >= 512;      // x6p = 2 ("force"): any size (tests)
+}
+
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     if (p.K % PBK || p.k_per_split % PBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
-    const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + PBN - 1) / PBN;
+    const bool wide = p.fp16x2 && p.plain_l;
+    if (wide && (p.N % 256 || p.splits != 1)) return SS_ERR_UNSUPPORTED;
+    const int pbn = wide ? 256 : SS_X6P_BN;
+    const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + pbn - 1) / pbn;
     // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
     static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
@@ -277,10 +329,11 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     static const int n_cu = [] { int v = 0; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0); return v >= 8 ? v / 8 * 8 : 256; }();
     const bool persistent = ss_tuning().gemm_persistent && tiles > n_cu && p.k_per_split >= 3 * PBK && p.K % p.k_per_split == 0;
     const long nwg = persistent ? n_cu : tiles;
-    SsProfScope prof(p.fp16x2 ? "gemm_x6p_kernel<2>" : "gemm_x6p_kernel<3>", 2.0 * p.M * p.N * p.K * p.nbatch * (p.fp16x2 ? 3 : 6),
+    SsProfScope prof(wide ? "gemm_x6p_kernel<2,wide>" : (p.fp16x2 ? "gemm_x6p_kernel<2>" : "gemm_x6p_kernel<3>"), 2.0 * p.M * p.N * p.K * p.nbatch * (p.fp16x2 ? 3 : 6),
                      2.0 * (p.fp16x2 ? 2 : 3) * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
-    if (p.fp16x2) hipLaunchKernelGGL(gemm_x6p_kernel<2>, dim3((unsigned)nwg), dim3(512), x6p_stages(2) * 2 * (A_PLANE_B + B_PLANE_B), s, p);
-    else hipLaunchKernelGGL(gemm_x6p_kernel<3>, dim3((unsigned)nwg), dim3(512), x6p_stages(3) * 3 * (A_PLANE_B + B_PLANE_B), s, p);
+    if (wide) hipLaunchKernelGGL((gemm_x6p_kernel<2, true>), dim3((unsigned)nwg), dim3(1024), x6p_stages(2, true) * 2 * (A_PLANE_B + 256 * ROWB), s, p);
+    else if (p.fp16x2) hipLaunchKernelGGL((gemm_x6p_kernel<2, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(2) * 2 * (A_PLANE_B + B_PLANE_B), s, p);
+    else hipLaunchKernelGGL((gemm_x6p_kernel<3, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(3) * 3 * (A_PLANE_B + B_PLANE_B), s, p);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -231,6 +231,10 @@ ADV_CASES = [
     ("disc_4x4_s2_per_tensor", 4, 64, 128, 2, "valid", False, 2, 66, 66),
     ("up_T3_per_tensor", 3, 64, 32, 2, "same", True, 2, 32, 32),
     ("tile_3x3_16_16_per_tile", 3, 16, 16, 1, "same", False, 1, 256, 256),      # conv_tile.hip: one scale per 8x32 pixel tile
+    # OPT-IN x6p_wide: the Winograd GEMMs of 256-multiple output channels on 256 x 256 tiles read planes with the PLAIN low piece
+    # (x*s = h + l, one accumulator set; gemm_x6p.hip WIDE); forced for this small problem with x6p = 2.  Its guarantee is weaker
+    # (asserted below): values under 2^-17 of their tile's maximum keep absolute precision only
+    ("trunk_wino_wide_plain_l", 3, 256, 256, 1, ("reflect", 1), False, 2, 64, 64, dict(x6p=2, x6p_wide=1)),
 ]
 
 
@@ -244,7 +248,8 @@ def test_x3h_heavy_tailed_tensors_vs_fp64(case, kind):
     sum |a||b|, i.e. the conditioning of each output element), must be within 4x of what the exact-fp32-operand path
     (SS_ALGO_MFMA, v_mfma_f32_32x32x2_f32) achieves on the same data, plus 1e-7."""
     E, LY, L = mod("engine"), mod("layers"), mod("_lib")
-    name, k, cin, cout, stride, padding, transposed, n, h, w = case
+    name, k, cin, cout, stride, padding, transposed, n, h, w = case[:10]
+    cfg = case[10] if len(case) > 10 else {}
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(zlib.crc32(f"{name}/{kind}".encode()) % 10007)          # stable across processes (hash() is salted)
     wshape = (k, k, cout, cin) if transposed else (k, k, cin, cout)
@@ -260,18 +265,24 @@ def test_x3h_heavy_tailed_tensors_vs_fp64(case, kind):
     ya.backward(gy.abs())
     cond = dict(y=ya.detach(), dx=xa.grad, dw=wa.grad)
     errs = {}
+    taken = {}
     for algo in (L.ALGO_MFMA, L.ALGO_AUTO):
+      with L.config(**(cfg if algo == L.ALGO_AUTO else {})):
         arena = E.ParamArena(dev)
         layer = LY.Conv2D(arena, "c", k, cin, cout, stride=stride, padding=padding, transposed=transposed, algo=algo)
         arena.materialize()
         arena["c/kernel"].copy_(wr.detach().float())
         tape = E.Tape()
         x = E.Act(x_cpu.float().to(dev), requires_grad=True)
+        L.load().ss_prof_reset(); L.load().ss_prof_enable(1)
         y = layer(tape, x)
         gt, _ = y.grad_target()
         gt.t.copy_(gy.float().to(dev))
         arena.zero_grad()
         tape.backward()
+        torch.cuda.synchronize()
+        L.load().ss_prof_enable(0)
+        taken[algo] = list(L.prof_summary())
         got = dict(y=y.dense().cpu().double(), dx=x.get_grad().dense().cpu().double(), dw=arena.grad("c/kernel").cpu().double())
         want = dict(y=yr.detach(), dx=xr.grad, dw=wr.grad)
         for q in got:
@@ -279,8 +290,11 @@ def test_x3h_heavy_tailed_tensors_vs_fp64(case, kind):
         errs[algo] = {q: float(((got[q] - want[q]).abs() / cond[q].clamp_min(1e-300)).max()) for q in got}
     print(f"{name}/{kind}: max |d| / sum|a||b|   fp32-MFMA {errs[L.ALGO_MFMA]}   default {errs[L.ALGO_AUTO]}")
     # the fp32-MFMA path's own error on these cases is 3e-7 .. 2.1e-6: "as good as fp32" = within 4x of it or below 3e-6 (2^-18.3)
+    slack = 16 if "wide" in name else 4          # measured on "tiny_tiles": 8x the fp32-MFMA path's error (why the wide tile is opt-in)
     for q in ("y", "dx", "dw"):
-        assert errs[L.ALGO_AUTO][q] <= max(4 * errs[L.ALGO_MFMA][q] + 1e-7, 3e-6), (q, errs)
+        assert errs[L.ALGO_AUTO][q] <= max(slack * errs[L.ALGO_MFMA][q] + 1e-7, 3e-6), (q, errs)
+    if "wide" in name:
+        assert any("wide" in nm for nm in taken[L.ALGO_AUTO]), taken[L.ALGO_AUTO]
 
 
 # ---- label maps of run_inference (north_star: "bit-exact label maps after threshold") ------------------------------------

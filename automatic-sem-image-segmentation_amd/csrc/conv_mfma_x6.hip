@@ -259,21 +259,28 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         if (c + 1 < nchunks) step(c + 1, S1{}, S0{});
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Pixel outer, column tile inner:
+    // one table read and one offset product per output row
+    int co[TN];
+    float bv[TN];
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
-        const int co = n0 + wn * (BN / 2) + ni * 32 + l31;
-        if (co >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[co] : 0.f;
+        co[ni] = n0 + wn * (BN / 2) + ni * 32 + l31;
+        bv[ni] = (p.bias && co[ni] < p.Cout) ? p.bias[co[ni]] : 0.f;
+    }
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
+    for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int pix = pixtab[wm * (BM / 2) + mi * 32 + row];
-                if (pix < 0) continue;
-                float* op = g_out + (long)pix * p.out_cs + co;
-                float v = ss_apply_act((H ? acc[mi][ni][r] * out_scale : acc[mi][ni][r]) + bv, p.act, p.alpha);
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int pix = pixtab[wm * (BM / 2) + mi * 32 + row];
+            if (pix < 0) continue;
+            float* orow = g_out + (long)pix * p.out_cs;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                if (co[ni] >= p.Cout) continue;
+                float* op = orow + co[ni];
+                float v = ss_apply_act((H ? acc[mi][ni][r] * out_scale : acc[mi][ni][r]) + bv[ni], p.act, p.alpha);
                 if (p.accumulate) v += *op;
                 *op = v;
             }

@@ -242,21 +242,28 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may still be landing when the LDS is handed on
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Pixel outer, column tile inner:
+    // one table read and one 32-bit offset product per output ROW (the launcher checks that the output view is below 2^31 elements)
+    int co[TN];
+    float bv[TN];
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
-        const int co = n0 + wn * (VBN / 2) + ni * 32 + l31;
-        if (co >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[co] : 0.f;
+        co[ni] = n0 + wn * (VBN / 2) + ni * 32 + l31;
+        bv[ni] = (p.bias && co[ni] < p.Cout) ? p.bias[co[ni]] : 0.f;
+    }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int pix = pixtab[wm * 64 + mi * 32 + row];
-                if (pix < 0) continue;
-                float* op = g_out + (long)pix * p.out_cs + co;
-                float v = ss_apply_act(acc[mi][ni][r] * out_scale + bv, p.act, p.alpha);
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int pix = pixtab[wm * 64 + mi * 32 + row];
+            if (pix < 0) continue;
+            float* orow = g_out + pix * p.out_cs;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                if (co[ni] >= p.Cout) continue;
+                float* op = orow + co[ni];
+                float v = ss_apply_act(acc[mi][ni][r] * out_scale + bv[ni], p.act, p.alpha);
                 if (p.accumulate) v += *op;
                 *op = v;
             }
@@ -275,7 +282,7 @@ bool ss_gconv_x6v2_ok(const GConvParams& p) {
     // a million pixels) are bound by their output stream; there the lighter 128 x 64 workgroups of gconv_x6_kernel measure 15-20 % faster
     if (p.Cout <= 64 && (long)p.ntaps * p.Cin < 1024) return false;
     const long M = (long)p.N * p.OHc * p.OWc;
-    if (M >= (1L << 31) || (long)p.N * p.IH * p.IW * p.in_cs >= (1L << 31)) return false;
+    if (M >= (1L << 31) || (long)p.N * p.IH * p.IW * p.in_cs >= (1L << 31) || (long)p.N * p.OH * p.OW * p.out_cs >= (1L << 31)) return false;
     const int nb = p.nbatch > 1 ? p.nbatch : 1, bn = v2_bn(p);
     return ((M + VBM - 1) / VBM) * ((p.Cout + bn - 1) / bn) * nb >= 200;
 }

@@ -208,17 +208,15 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
         }
 
         // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        float* cbase = p.c + cur.cbase;
+        float* cbase = p.c + cur.cbase + (cur.n0 + wn * 64 + l31);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int n = cur.n0 + wn * 64 + ni * 32 + l31;
+        for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int r = 0; r < 16; ++r) {
+                const int m = cur.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float* crow = cbase + (long)m * p.N;              // one row pointer for both column tiles
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = cur.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    cbase[(long)m * p.N + n] = fmaf(acc[1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]) * out_scale;
-                }
+                for (int ni = 0; ni < 2; ++ni) crow[32 * ni] = fmaf(acc[1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]) * out_scale;
             }
         }
         if (more) {

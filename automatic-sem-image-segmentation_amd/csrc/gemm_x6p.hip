@@ -254,18 +254,18 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
 
         // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The stores are younger than
         // the next tile's first chunk groups (issued in the last K steps above): waiting for those does not wait for the stores.
-        float* cb = p.c + cur.cbase;
+        float* cb = p.c + cur.cbase + (cur.n0 + wn * 64 + l31);
+        const int nrem = p.N - (cur.n0 + wn * 64 + l31);          // column ni exists iff 32 * ni < nrem
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int n = cur.n0 + wn * 64 + ni * 32 + l31;
-            if (n >= p.N) continue;
+        for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int r = 0; r < 16; ++r) {
+                const int m = cur.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float* crow = cb + (long)m * p.ldc;               // one row pointer for both column tiles
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = cur.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < p.M) cb[(long)m * p.ldc + n] = NACC == 1 ? acc[0][mi][ni][r] : fmaf(acc[NACC - 1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
-                }
+                for (int ni = 0; ni < 2; ++ni)
+                    if (32 * ni < nrem) crow[32 * ni] = NACC == 1 ? acc[0][mi][ni][r] : fmaf(acc[NACC - 1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
             }
         }
         if (more) {

@@ -13,7 +13,14 @@ namespace {
 // Pixel chunks per group: enough blocks to fill 256 CUs several times over even for batch norm (G = 1) with < 64 channels
 // (one channel block): 128 chunks there meant 128 workgroups on 256 CUs.
 constexpr int NORM_CHUNK_BLOCKS = 4096;
-constexpr int FIN_CL = 8;          // finalize kernels: 8 channels x 32 chunk lanes per block
+constexpr int FIN_CL = 8;          // finalize kernels: 8 channels x 32 chunk lanes per block ...
+// ... fewer channels (more chunk lanes) per block while the grid would hold fewer than 32 blocks: a BatchNorm over 4..51 channels
+// (one group, up to 2048 chunks) ran on 1-7 blocks, each lane walking 64 chunks in 8 dependent rounds of loads (17 us per launch)
+inline int fin_cl(int C, int G) {
+    int cl = FIN_CL;
+    while (cl > 1 && (long)((C + cl - 1) / cl) * G < 32) cl >>= 1;
+    return cl;
+}
 inline int norm_max_chunks(int groups) {
     int m = NORM_CHUNK_BLOCKS / (groups > 0 ? groups : 1);
     return m < 128 ? 128 : (m > 2048 ? 2048 : m);
@@ -743,8 +750,9 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
                                0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, (float*)ws);
         SS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + FIN_CL - 1) / FIN_CL, g.G), dim3(256), 0, s,
-                       part, chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum, FIN_CL);
+    const int fcl = fin_cl(g.C, g.G);
+    hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + fcl - 1) / fcl, g.G), dim3(256), 0, s,
+                       part, chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum, fcl);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
     if (V == 4)
@@ -811,8 +819,9 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
                            d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
     SS_LAUNCH_CHECK();
     double* rt = (double*)((char*)ws + part_bytes(d) + ss_align_up((size_t)g.G * g.C * 2 * sizeof(float), 256));
-    hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + FIN_CL - 1) / FIN_CL, g.G), dim3(256), 0, s,
-                       part, g.chunks, g.G, g.C, g.P, sums, rt, FIN_CL);
+    const int fcl = fin_cl(g.C, g.G);
+    hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + fcl - 1) / fcl, g.G), dim3(256), 0, s,
+                       part, g.chunks, g.G, g.C, g.P, sums, rt, fcl);
     SS_LAUNCH_CHECK();
     const long rows = (long)g.G * g.P;
     const double* prt = (dgamma || dbeta) ? rt : nullptr;

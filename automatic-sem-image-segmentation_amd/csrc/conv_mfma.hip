@@ -703,6 +703,46 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WGradParams p, float*
     *o = accumulate ? (*o + acc) : acc;
 }
 
+// Many splits, few outputs (the MultiResUNet's full-resolution layers: 512 partials of a few thousand weights): one thread per
+// output walks 64 dependent rounds of loads (18 us).  Here 16 lanes share an output: lane j sums the splits j, j + 16, ... (8 loads
+// in flight), the 16 lane sums are combined through LDS in lane order -> deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(WGradParams p, float* dw, int ldw, int accumulate, int rows) {
+    __shared__ float red[16][17];
+    const long total = (long)p.ntaps * p.Ca * p.Cb;
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;          // 16 outputs x 16 split lanes per block
+    const long e = (long)blockIdx.x * 16 + el;
+    const bool val = e < (long)rows * p.Cb;
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (val) {
+        int s = sl;
+        for (; s + 7 * 16 < p.splits; s += 8 * 16) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a8[k] += p.part[(long)(s + 16 * k) * total + e];
+        }
+        for (; s < p.splits; s += 16) a8[0] += p.part[(long)s * total + e];
+    }
+    red[sl][el] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    __syncthreads();
+    if (sl == 0 && val) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc += red[j][el];
+        const int cb = (int)(e % p.Cb);
+        const long m = e / p.Cb;
+        const int t = (int)(m / p.Ca);
+        const int ca = (int)(m - (long)t * p.Ca);
+        float* o = dw + p.taps[t].woff + (long)ca * ldw + cb;
+        *o = accumulate ? (*o + acc) : acc;
+    }
+}
+
+static void launch_wgrad_reduce_any(const WGradParams& p, float* dw, int ldw, int accumulate, int rows, long total, hipStream_t s) {
+    if (p.splits >= 64 && total <= (1L << 20))
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, p, dw, ldw, accumulate, rows);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, dw, ldw, accumulate, rows);
+}
+
 int ss_wgrad_mfma_splits(int64_t pixels, int M, int Cb, int* pix_per_split, int nbatch) {
     // Split the pixel (K) range so that tiles x splits fills whole "rounds" of the 512 workgroup slots
     // (256 CUs x 2 resident workgroups): time ~ ceil(tiles*s/512) * K/s.  A partial last round costs a full K/s.
@@ -755,7 +795,7 @@ int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accu
     if (total == 0) return SS_OK;
     int rc = ss_launch_wgrad_mfma_partials(p, s);
     if (rc != SS_OK) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, dw, ldw, accumulate, rows);
+    launch_wgrad_reduce_any(p, dw, ldw, accumulate, rows, total, s);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -763,7 +803,7 @@ int ss_launch_wgrad_mfma_rows(const WGradParams& p, float* dw, int ldw, int accu
 // dw[woff_t + ca*ldw + cb] (+)= sum over p.splits partials part[split][(t,ca)][cb] (fixed order)
 int ss_launch_wgrad_reduce(const WGradParams& p, float* dw, int ldw, int accumulate, int rows, hipStream_t s) {
     const long total = (long)rows * p.Cb;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, dw, ldw, accumulate, rows);
+    launch_wgrad_reduce_any(p, dw, ldw, accumulate, rows, total, s);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -92,12 +92,12 @@ def cpu_baseline(size, batch, filters, threads, timed):
 
 def kernel_peak(name):
     """Dense peak of the matrix instruction a contraction kernel class issues."""
-    if name.startswith("gemm_x6p_kernel<2>") or name.endswith(",true>"):
+    if name.startswith("gemm_x6p_kernel<2") or name.endswith(",true>"):
         return "f16_mfma"        # x3h: v_mfma_f32_32x32x16_f16
-    if name.startswith(("gemm_x6p", "gconv_x6", "wgrad_x6")):
-        return "bf16_mfma"       # x6: v_mfma_f32_32x32x16_bf16
     if name.startswith("gconv_x6v2"):
         return "f16_mfma"        # gather convolutions, second structure: x3h only
+    if name.startswith(("gemm_x6p", "gconv_x6", "wgrad_x6")):
+        return "bf16_mfma"       # x6: v_mfma_f32_32x32x16_bf16
     if name.startswith("gemm_tn_x3h"):
         return "f16_mfma"        # Winograd weight gradient on pre-split planes: v_mfma_f32_32x32x16_f16, three piece products
     if name.startswith("tconv_kernel"):

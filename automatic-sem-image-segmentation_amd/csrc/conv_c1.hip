@@ -20,7 +20,7 @@ struct C1Box { int dy0, dx0, kh, kw; };
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void conv_out1_kernel(GConvParams p, C1Box box) {
     constexpr int CC = 8;
-    constexpr int HR = C1_TH + KH - 1, HW = C1_TW + KW - 1, HS = (HW + 3 + 3) / 4 * 4;    // row stride: covers the 12-float strip reads
+    constexpr int HR = C1_TH + KH - 1, HW = C1_TW + KW - 1, HS = C1_TW + 8;    // row stride: the 12-float strip reads end at column 4*15 + 11; 72 floats keep THREE blocks per CU in the LDS
     extern __shared__ __attribute__((aligned(16))) float smem_c1[];
     float* xs = smem_c1;                       // [CC][HR][HS]
     float* ws = smem_c1 + CC * HR * HS;        // [CC][KH][8]
@@ -201,7 +201,7 @@ bool plain_grid(const GConvParams& p) {
 
 template <int KH, int KW>
 int launch_out1(const GConvParams& p, const C1Box& box, hipStream_t s) {
-    constexpr int CC = 8, HR = C1_TH + KH - 1, HW = C1_TW + KW - 1, HS = (HW + 3 + 3) / 4 * 4;
+    constexpr int CC = 8, HR = C1_TH + KH - 1, HS = C1_TW + 8;
     const size_t smem = (size_t)(CC * HR * HS + CC * KH * 8) * sizeof(float);
     // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
     static const bool attr_set = [] {

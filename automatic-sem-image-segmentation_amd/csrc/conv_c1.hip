@@ -34,30 +34,56 @@ __global__ __launch_bounds__(256) void conv_out1_kernel(GConvParams p, C1Box box
     const int n = b / tiles_y;
     const int x0 = bx * C1_TW, y0 = by * C1_TH;
 
+    // tap index of every (row, column) of the box (the tap list may come in any order), once per block
+    int* tapidx = (int*)(ws + CC * KH * 8);       // [KH][8]
+    for (int idx = tid; idx < KH * 8; idx += 256) tapidx[idx] = -1;
+    __syncthreads();
+    for (int t = tid; t < p.ntaps; t += 256) tapidx[(p.taps[t].dy - box.dy0) * 8 + (p.taps[t].dx - box.dx0)] = t;
+
+    // The halo tile of the NEXT channel chunk is requested into registers before the current chunk is multiplied (it used to be
+    // loaded, stored and waited for between two barriers: 8 exposed round trips per tile), and stored after the barrier that
+    // ends the chunk; the chunk's weights are gathered in one pass through the tap table (was: zero, barrier, scatter).
+    constexpr int NU = (HR * HW * (CC / 4) + 255) / 256;          // float4 units per thread and chunk
+    f32x4 pre[NU];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = tid + 256 * u;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (idx < HR * HW * (CC / 4)) {
+                const int c4 = idx % (CC / 4);
+                const int pix = idx / (CC / 4);
+                const int rx = pix % HW, ry = pix / HW;
+                const int iy = ss_map_index(y0 + ry + p.in_oy + box.dy0, p.IH, p.reflect);
+                const int ix = ss_map_index(x0 + rx + p.in_ox + box.dx0, p.IW, p.reflect);
+                if (iy >= 0 && ix >= 0 && c0 + 4 * c4 < p.Cin)
+                    v = *(const f32x4*)(p.in + ((long)(n * p.IH + iy) * p.IW + ix) * p.in_cs + c0 + 4 * c4);
+            }
+            pre[u] = v;
+        }
+    };
+    prefetch(0);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < p.Cin; c0 += CC) {
-        __syncthreads();
-        // halo tile: HR x HW pixels x CC channels, two float4 per pixel
-        for (int idx = tid; idx < HR * HW * (CC / 4); idx += 256) {
-            const int c4 = idx % (CC / 4);
-            const int pix = idx / (CC / 4);
-            const int rx = pix % HW, ry = pix / HW;
-            const int iy = ss_map_index(y0 + ry + p.in_oy + box.dy0, p.IH, p.reflect);
-            const int ix = ss_map_index(x0 + rx + p.in_ox + box.dx0, p.IW, p.reflect);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && ix >= 0 && c0 + 4 * c4 < p.Cin)
-                v = *(const f32x4*)(p.in + ((long)(n * p.IH + iy) * p.IW + ix) * p.in_cs + c0 + 4 * c4);
+        __syncthreads();                               // the previous chunk's tile is no longer read (and tapidx is complete)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xs[((4 * c4 + e) * HR + ry) * HS + rx] = v[e];
+        for (int u = 0; u < NU; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < HR * HW * (CC / 4)) {
+                const int c4 = idx % (CC / 4);
+                const int pix = idx / (CC / 4);
+                const int rx = pix % HW, ry = pix / HW;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xs[((4 * c4 + e) * HR + ry) * HS + rx] = pre[u][e];
+            }
         }
-        for (int idx = tid; idx < CC * KH * 8; idx += 256) ws[idx] = 0.f;
-        __syncthreads();
-        for (int idx = tid; idx < p.ntaps * CC; idx += 256) {
-            const int c = idx % CC, t = idx / CC;
-            const int ry = p.taps[t].dy - box.dy0, rx = p.taps[t].dx - box.dx0;
-            if (c0 + c < p.Cin) ws[(c * KH + ry) * 8 + rx] = p.w[p.taps[t].woff + (long)(c0 + c) * p.ldb];
+        for (int idx = tid; idx < CC * KH * 8; idx += 256) {
+            const int c = idx / (KH * 8), q = idx - c * (KH * 8);
+            const int t = tapidx[q];
+            ws[idx] = (t >= 0 && c0 + c < p.Cin) ? p.w[p.taps[t].woff + (long)(c0 + c) * p.ldb] : 0.f;
         }
         __syncthreads();
+        if (c0 + CC < p.Cin) prefetch(c0 + CC);        // in flight during the multiplication below
 #pragma unroll 2
         for (int c = 0; c < CC; ++c) {
 #pragma unroll
@@ -202,7 +228,7 @@ bool plain_grid(const GConvParams& p) {
 template <int KH, int KW>
 int launch_out1(const GConvParams& p, const C1Box& box, hipStream_t s) {
     constexpr int CC = 8, HR = C1_TH + KH - 1, HS = C1_TW + 8;
-    const size_t smem = (size_t)(CC * HR * HS + CC * KH * 8) * sizeof(float);
+    const size_t smem = (size_t)(CC * HR * HS + CC * KH * 8 + KH * 8) * sizeof(float);
     // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
     static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)conv_out1_kernel<KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

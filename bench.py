@@ -320,7 +320,9 @@ def main():
                 try:
                     tj = json.load(open(tpath))
                     if tj.get("workload") == [S, GB, F, world]:
-                        traffic = tj.get("kernels", {}).get(dom)
+                        kern = tj.get("kernels", {})
+                        # rocprofv3 spells the default template arguments out (gemm_x6p_kernel<2,false>), the ss_prof label does not
+                        traffic = kern.get(dom) or kern.get(dom.replace(">", ",false>"))
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s",

@@ -30,7 +30,7 @@ for d in ("p1", "p2"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if not any(s in k for s in ("gemm_", "wino_")): continue
-            k = k.split("(")[0][-40:] + " grid" + r.get("Grid_Size", "")
+            k = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60] + " grid" + r.get("Grid_Size", "")
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             n[(k, r["Counter_Name"])] += 1
         for k, v in sorted(agg.items()):

@@ -15,7 +15,7 @@ for d in ("p1", "p2"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "wgrad_x6" not in k: continue
-            k = k.split("(")[0] + " grid" + r.get("Grid_Size", "")
+            k = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60] + " grid" + r.get("Grid_Size", "")
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         for k, v in sorted(agg.items()):
             print(d, k[:90], {a: round(b) for a, b in v.items()})

@@ -238,15 +238,21 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
     float am = 0.f;
     // (row, channel vector) of element e advance incrementally: one 64-bit division per thread instead of two per element (the
     // single-channel-vector instantiation, odd MultiResUNet widths, was paced by them)
-    const long stride = (long)gridDim.x * blockDim.x;
+    // A block owns ONE contiguous slice of the tensor and the slices are handed out from the END (block 0 takes the last one): the
+    // statistics pass before this kernel walked the tensor front to back, so its tail is what the 256 MiB Infinity Cache still
+    // holds -- walking back to front turns those reads into hits (a grid-strided walk touched every part of the tensor at once).
+    const long stride = blockDim.x;
+    const long per = ((total + gridDim.x - 1) / gridDim.x + stride - 1) / stride * stride;
+    const long slice = (long)(gridDim.x - 1 - blockIdx.x) * per;
+    const long end = slice + per < total ? slice + per : total;
     const long drow = stride / CV;
     const int dcv = (int)(stride - drow * CV);
     const long dg = drow / P, drp = drow - dg * P;              // ... and (group, pixel within the group) of the row
-    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long e = slice + threadIdx.x;
     long row = e / CV;
     int cv = (int)(e - row * CV);
     long grp = row / P, rp = row - grp * P;
-    for (; e < total; e += stride, row += drow, cv += dcv, grp += dg, rp += drp) {
+    for (; e < end; e += stride, row += drow, cv += dcv, grp += dg, rp += drp) {
         if (cv >= CV) { cv -= CV; ++row; ++rp; }
         if (rp >= P) { rp -= P; ++grp; }
         const int c = cv * V;
@@ -344,23 +350,26 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     const int CV = C / V;
     const long total = rows * CV;
     float am = 0.f;
-    const long stride = (long)gridDim.x * blockDim.x;          // incremental (row, channel vector), see norm_apply_kernel
+    const long stride = blockDim.x;          // contiguous slices handed out from the end, incremental (row, channel vector): see norm_apply_kernel
     if (rt) {          // parameter gradients: the per-group totals of norm_finalize_bwd summed in group order (one thread per channel)
-        for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += stride) {
+        for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += (long)gridDim.x * blockDim.x) {
             double tg = 0.0, tgx = 0.0;
             for (int g = 0; g < G; ++g) { tg += rt[((long)g * C + c) * 2]; tgx += rt[((long)g * C + c) * 2 + 1]; }
             if (dbeta) dbeta[c] = acc_params ? dbeta[c] + (float)tg : (float)tg;
             if (dgamma) dgamma[c] = acc_params ? dgamma[c] + (float)tgx : (float)tgx;
         }
     }
+    const long per = ((total + gridDim.x - 1) / gridDim.x + stride - 1) / stride * stride;
+    const long slice = (long)(gridDim.x - 1 - blockIdx.x) * per;
+    const long end = slice + per < total ? slice + per : total;
     const long drow = stride / CV;
     const int dcv = (int)(stride - drow * CV);
     const long dg = drow / P, drp = drow - dg * P;              // ... and (group, pixel within the group) of the row
-    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long e = slice + threadIdx.x;
     long row = e / CV;
     int cv = (int)(e - row * CV);
     long grp = row / P, rp = row - grp * P;
-    for (; e < total; e += stride, row += drow, cv += dcv, grp += dg, rp += drp) {
+    for (; e < end; e += stride, row += drow, cv += dcv, grp += dg, rp += drp) {
         if (cv >= CV) { cv -= CV; ++row; ++rp; }
         if (rp >= P) { rp -= P; ++grp; }
         const int c = cv * V;

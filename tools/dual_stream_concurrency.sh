@@ -1,11 +1,11 @@
 #!/bin/bash
 # How busy is the GPU in the DEFAULT (multi-stream) step?  rocprofv3 kernel trace of bench.py, then: union of the kernel intervals,
-# sum of the kernel durations, average number of kernels in flight.  Usage (GPU box): bash tools/dual_stream_concurrency.sh
+# sum of the kernel durations, average number of kernels in flight.  Usage (GPU box): bash tools/dual_stream_concurrency.sh [bench args]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/dual
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace -d $OUT/t --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench.json 2> $OUT/err.log
+rocprofv3 --kernel-trace -d $OUT/t --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras "$@" > $OUT/bench.json 2> $OUT/err.log
 python - <<PY
 import csv, glob, json
 f = glob.glob("$OUT/t/**/*kernel_trace.csv", recursive=True)[0]

@@ -395,7 +395,9 @@ class CycleGanModel:
                     sigmoid_output_a=self.gen_a.sigmoid_output,
                     disc_filters=self.disc_a.filters, disc_nd=self.disc_a.nd, gaussian_noise_value=self.disc_a.gaussian_noise_value,
                     lambda_cycle_a=self.lambda_cycle_a, lambda_cycle_b=self.lambda_cycle_b,
-                    lambda_identity_a=self.lambda_identity_a, lambda_identity_b=self.lambda_identity_b)
+                    lambda_identity_a=self.lambda_identity_a, lambda_identity_b=self.lambda_identity_b,
+                    optimizers={self._OPTS[nm]: dict(learning_rate=float(o.learning_rate), beta_1=float(o.beta_1), beta_2=float(o.beta_2))
+                                for nm in self._NETS for o in [getattr(self, self._OPTS[nm])] if o is not None})
 
     def save(self, path):
         """``model.save('…/model.keras')`` (CycleGAN.py:203-204,221): a Keras-3 archive (zip of config.json, metadata.json and
@@ -411,10 +413,9 @@ class CycleGanModel:
             np.savez(path, **arrays)
             return
         from . import keras_io as K
-        counters = K.NameCounters()
         arrays = {}
         for nm in self._NETS:
-            arrays.update(K.net_arrays(getattr(self, nm), nm + "/", counters))
+            arrays.update(K.net_arrays(getattr(self, nm), nm + "/"))
         for nm in self._NETS:
             arrays.update(K.optimizer_arrays(getattr(self, self._OPTS[nm]), getattr(self, nm), self._OPTS[nm] + "/"))
         K.write_archive(path, arrays, "CycleGanModel", self._config())
@@ -446,11 +447,16 @@ class CycleGanModel:
             for nm, net in nets.items():
                 net.set_weights([z[f"{nm}/{name}"] for name in net.variable_names])
             return model
-        counters = K.NameCounters()
+        legacy = K.NameCounters()
         for nm in cls._NETS:
-            K.load_net_arrays(nets[nm], nm + "/", counters, arrays)
+            K.load_net_arrays(nets[nm], nm + "/", arrays, legacy)
         if any(k.startswith("gen_a_optimizer/") for k in arrays):
-            model.compile(Adam(2e-4, beta_1=0.5), Adam(2e-4, beta_1=0.5), Adam(2e-4, beta_1=0.5), Adam(2e-4, beta_1=0.5))
+            # the optimizers as they were: learning rate / betas recorded by save() (an archive written part-way through the linear
+            # decay resumes at ITS step size); archives without the record fall back to the workflow defaults (CycleGAN.py:168-171)
+            oc = cfg.get("optimizers", {})
+            mk = lambda nm: Adam(oc.get(nm, {}).get("learning_rate", 2e-4), beta_1=oc.get(nm, {}).get("beta_1", 0.5),
+                                 beta_2=oc.get(nm, {}).get("beta_2", 0.999))
+            model.compile(*(mk(cls._OPTS[nm]) for nm in cls._NETS))
             for nm in cls._NETS:
                 K.load_optimizer_arrays(getattr(model, cls._OPTS[nm]), nets[nm], cls._OPTS[nm] + "/", arrays)
         return model
@@ -702,6 +708,8 @@ class CycleGAN:
         reset, CSV log (';'), per-epoch weight checkpoint, final ``model`` file.  Under torch.distributed each rank
         takes a contiguous slice of every global batch."""
         os.makedirs(os.path.join(self.model_dir, self.prefix), exist_ok=True)
+        from . import keras_io
+        keras_io.warn_if_no_hdf5('CycleGAN.start_training')
         self.decay_epoch = int(0.75 * self.epochs)
         if not self.use_data_loader:
             self.train_a = self.load_images(self.train_a, False, invert=self.invert_images)

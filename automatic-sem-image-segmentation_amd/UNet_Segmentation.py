@@ -182,7 +182,7 @@ class UNetModel:
             np.savez(path, **arrays)
             return
         from . import keras_io as K
-        arrays = K.net_arrays(self.net, "", K.NameCounters())
+        arrays = K.net_arrays(self.net, "")
         arrays.update(K.optimizer_arrays(self.optimizer, self.net, "optimizer/"))
         K.write_archive(path, arrays, "MultiResUNet", cfg)
 
@@ -199,7 +199,7 @@ class UNetModel:
         from . import keras_io as K
         _, cfg, arrays = K.read_archive(path)
         net = MultiResUNet(conv_filters=cfg["filters"], device=device, output_channels=cfg.get("output_channels", 1))
-        K.load_net_arrays(net, "", K.NameCounters(), arrays)
+        K.load_net_arrays(net, "", arrays, K.NameCounters())
         model = cls(net, cfg.get("weighting", 1.0), Adam(cfg.get("learning_rate", 1e-3)))
         K.load_optimizer_arrays(model.optimizer, net, "optimizer/", arrays)
         return model
@@ -314,6 +314,8 @@ class UNet:
     def run_training(self):
         """Equivalent of ``model.fit(training_data, epochs, callbacks, validation_data)`` (UNet_Segmentation.py:246-288)."""
         os.makedirs(os.path.join(self.model_dir, self.prefix), exist_ok=True)
+        from . import keras_io
+        keras_io.warn_if_no_hdf5('UNet.run_training')
         self.dataset_train = ImageDataset(self.image_dir, self.mask_dir, self.contrast_optimization_range)
         self.dataset_val = ImageDataset(self.image_dir, self.mask_dir, self.contrast_optimization_range)
         self.dataset_train.initialize_images('train')

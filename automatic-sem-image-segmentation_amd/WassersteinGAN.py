@@ -500,19 +500,35 @@ class WGAN:
         ragged last batch, metrics = running means over the epoch, one CSV row per epoch (Keras CSVLogger: ',' and sorted keys)."""
         os.makedirs(os.path.join(self.model_dir, self.prefix), exist_ok=True)
         os.makedirs(os.path.join(self.output_dir, self.prefix), exist_ok=True)
+        from . import keras_io
+        keras_io.warn_if_no_hdf5('WGAN.start_training')          # the only save happens after the last epoch: say so NOW
         self.model = self.create_model()
         cbk = GANMonitor(output_dir=os.path.join(self.output_dir, self.prefix), num_img=9, latent_dim=self.n_z, output_epochs=20)
         log_path = os.path.join(self.model_dir, self.prefix, 'training_log.csv')
         rank, world = D.rank(), D.world_size()
         n = len(self.train_images)
+        if world > 1:
+            # data parallel: every rank must cut its shard out of the SAME permutation (one RandomState seeded by rank 0's draw),
+            # the generator's BatchNorm needs whole-global-batch statistics as in the single-device reference, and a global batch
+            # that does not split evenly is an error, not silently dropped samples
+            D.check_batch_divisible(self.batch_size, world, 'WGAN.batch_size')
+            D.enable_sync_bn(True)
+            seed = torch.tensor([np.random.randint(0, 2 ** 31 - 1)], dtype=torch.int64, device=self.device)
+            torch.distributed.broadcast(seed, 0)
+            perm_rng = np.random.RandomState(int(seed.item()))
+        else:
+            perm_rng = np.random
         for epoch in range(self.epochs):
             self.model.reset_metrics()
-            order = np.random.permutation(n)
+            order = perm_rng.permutation(n)
             logs = {}
             for start in range(0, n, self.batch_size):
                 idx = order[start:start + self.batch_size]
                 if world > 1:
                     per = len(idx) // world
+                    if per * world != len(idx):
+                        D.warn_once(f'WGAN: the last batch of an epoch ({len(idx)} samples) does not split over {world} ranks: '
+                                    f'{len(idx) - per * world} sample(s) per epoch are skipped')
                     if per == 0:
                         continue
                     idx = idx[rank * per:(rank + 1) * per]
@@ -538,9 +554,8 @@ class WGAN:
             arrays.update({f"discriminator/{n_}": w for n_, w in zip(m.discriminator.variable_names, m.discriminator.get_weights())})
             np.savez(path, **arrays)
             return
-        counters = keras_io.NameCounters()
-        arrays = keras_io.net_arrays(m.discriminator, "discriminator/", counters)
-        arrays.update(keras_io.net_arrays(m.generator, "generator/", counters))
+        arrays = keras_io.net_arrays(m.discriminator, "discriminator/")
+        arrays.update(keras_io.net_arrays(m.generator, "generator/"))
         arrays.update(keras_io.optimizer_arrays(m.d_optimizer, m.discriminator, "d_optimizer/"))
         arrays.update(keras_io.optimizer_arrays(m.g_optimizer, m.generator, "g_optimizer/"))
         keras_io.write_archive(path, arrays, "WGAN_GP", dict(latent_dim=self.n_z, image_shape=list(self.train_images.shape[1:])))
@@ -556,9 +571,9 @@ class WGAN:
             m.discriminator.set_weights([z[f"discriminator/{n_}"] for n_ in m.discriminator.variable_names])
             return m
         _cls, _cfg, arrays = keras_io.read_archive(path)
-        counters = keras_io.NameCounters()
-        keras_io.load_net_arrays(m.discriminator, "discriminator/", counters, arrays)
-        keras_io.load_net_arrays(m.generator, "generator/", counters, arrays)
+        legacy = keras_io.NameCounters()
+        keras_io.load_net_arrays(m.discriminator, "discriminator/", arrays, legacy)
+        keras_io.load_net_arrays(m.generator, "generator/", arrays, legacy)
         keras_io.load_optimizer_arrays(m.d_optimizer, m.discriminator, "d_optimizer/", arrays)
         keras_io.load_optimizer_arrays(m.g_optimizer, m.generator, "g_optimizer/", arrays)
         return m
@@ -600,7 +615,8 @@ class WGAN:
             if use_perlin_noise or use_random_rotation == 'PERLIN':
                 ix = np.arange(0, perlin_noise_frequency, perlin_noise_frequency / (img_width + 3 * d))
                 iy = np.arange(0, perlin_noise_frequency, perlin_noise_frequency / (img_height + 3 * d))
-                noise_image = _gradient_noise2array(iy, ix, np.random.default_rng(np.random.randint(0, 2 ** 31 - 1)))
+                # opensimplex.noise2array(x=iy, y=ix) returns (len(ix), len(iy)) = (W + 3d, H + 3d): the reference indexes it [x, y] throughout
+                noise_image = _gradient_noise2array(ix, iy, np.random.default_rng(np.random.randint(0, 2 ** 31 - 1)))
                 noise_image -= np.min(noise_image)
                 noise_image /= np.max(noise_image) / 2
                 noise_image = noise_image - 1

@@ -597,3 +597,25 @@ def test_unet_softmax_head_train_step_vs_oracle():
     num = sum(float(((torch.from_numpy(grads[v.name]).reshape(v.value.shape).double() - v.value.grad.double()) ** 2).sum()) for v in tw)
     den = sum(float((v.value.grad.double() ** 2).sum()) for v in tw)
     assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+
+
+def test_device_image_pool_replays_the_reference_trace_bit_exactly(golden_dir):
+    """T7 (CycleGAN.py:908-964) on the DEVICE pool: the 30 queries recorded from the reference's own ImagePool (batch_size frozen at 2,
+    pool_size 5, python `random` seeded 0; batches of 3 exercise the first-two-images quirk) -- byte / index work, so bit-exact."""
+    CG = mod("CycleGAN")
+    z = np.load(os.path.join(golden_dir, "image_pool_trace.npz"))
+    random.seed(0)
+    pool = CG.ImagePool(batch_size=2, pool_size=5)
+    for i in range(int(z["n_steps"])):
+        x = torch.from_numpy(z[f"in{i}"]).to("cuda:0")
+        out = pool.query(x)
+        assert out.shape[0] == 2 and out.device.type == "cuda"
+        np.testing.assert_array_equal(out.cpu().numpy(), z[f"out{i}"], err_msg=f"query {i}")
+    # the buffer itself: what the reference's pool holds after the trace is what the device pool holds (same swaps, same slots)
+    random.seed(0)
+    ref = OS.ImagePool(batch_size=2, pool_size=5)
+    for i in range(int(z["n_steps"])):
+        ref.query(torch.from_numpy(z[f"in{i}"]).clone())
+    assert pool.num_imgs == ref.num_imgs == 5
+    for a, b in zip(pool.images, ref.images):
+        np.testing.assert_array_equal(a.cpu().numpy(), b.numpy())

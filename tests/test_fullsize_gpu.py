@@ -320,3 +320,70 @@ def test_unet_step_baseline_tiles_vs_oracle():
     e_32 = float(np.linalg.norm(cat(g32) - r64) / np.linalg.norm(r64))
     print(f"UNet gradient rel-L2 vs fp64: hip={e_hip:.2e} oracle32={e_32:.2e}")
     assert e_hip <= 5 * e_32 + 1e-3, (e_hip, e_32)
+
+
+def _fullsize_golden_tools(golden_dir):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_fullsize_golden", __import__("os").path.join(golden_dir, "make_fullsize_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("mode", ["x3h", "x6_bf16_six_products", "fp32_mfma_instructions"])
+def test_cyclegan_step_512_vs_committed_fp64_fixture(mode, golden_dir):
+    """The HEADLINE shape under the oracle: one complete CycleGAN step, full-size networks (F = 64, 9 blocks), one
+    512x512 tile, against tests/golden/cyclegan_step_512_f64.npz -- the float64 oracle's 14 metrics, per-tensor gradient norms and
+    100 000 sampled gradient entries per network (generated once by tests/golden/make_fullsize_golden.py, ~10 min of CPU; inputs
+    and initial weights are rebuilt here from the same seeds and verified by CRC).  Rule (the fp64 restatement
+    arbitrates): the HIP result may be at most 3x as far from float64 as the plain-fp32 oracle of the same step is (+1e-4) -- for
+    the metrics, for the sampled entries of every network, and (through the reverse triangle inequality) for every tensor's norm.
+    All three arithmetic modes of the contraction engine."""
+    import os
+    L = mod("_lib")
+    T = _fullsize_golden_tools(golden_dir)
+    path = os.path.join(golden_dir, "cyclegan_step_512_f64.npz")
+    z = np.load(path)
+    S, F = int(z["size"]), int(z["filters"])
+    assert (S, F) == (512, 64)
+    real_a, real_b = T.inputs(S)
+    assert T.crc_of([real_a.numpy(), real_b.numpy()]) == int(z["crc_inputs"]), "the seeded inputs differ from the fixture's"
+    refs = T.make_nets(torch.float32, F)
+    init = {k: refs[k].get_weights() for k in T.NETS}
+    for k in T.NETS:
+        assert T.crc_of(init[k]) == int(z[f"crc_init/{k}"]), f"the seeded initial weights of {k} differ from the fixture's"
+    del refs
+    cfg = {"x3h": dict(), "x6_bf16_six_products": dict(x3h=0), "fp32_mfma_instructions": dict(x6=0)}[mode]
+    with L.config(**cfg):
+        model, _, nets = _build_models()
+        hips = dict(zip(T.NETS, nets[:4]))
+        for k in T.NETS:
+            hips[k].set_weights(init[k])
+        random.seed(int(z["rng_seed"]))
+        got = model.train_step((real_a.numpy(), real_b.numpy()))
+        torch.cuda.synchronize()
+    names = [str(s) for s in z["metric_names"]]
+    for k, v64, v32 in zip(names, z["metrics64"], z["metrics32"]):
+        assert abs(got[k] - v64) <= 2e-4 * max(abs(v64), 1.0) + 3 * abs(v32 - v64), (mode, k, got[k], v32, v64)
+    for i, k in enumerate(T.NETS):
+        gh = hips[k].get_gradients()
+        tn = [str(s) for s in z[f"{k}/tensor_names"]]
+        sizes = z[f"{k}/tensor_sizes"]
+        vec = np.concatenate([np.asarray(gh[n], np.float64).ravel() for n in tn])
+        assert vec.size == int(sizes.sum())
+        pos = T.sample_positions(i, vec.size)
+        s64, s32 = z[f"{k}/sample64"], z[f"{k}/sample32"].astype(np.float64)
+        e_hip = float(np.linalg.norm(vec[pos] - s64) / np.linalg.norm(s64))
+        e_32 = float(np.linalg.norm(s32 - s64) / np.linalg.norm(s64))
+        print(f"[512 fixture, {mode}] {k}: sampled gradient entries rel-L2 vs fp64  hip={e_hip:.2e}  oracle32={e_32:.2e}")
+        assert e_hip <= 3 * e_32 + 1e-4, (mode, k, e_hip, e_32)
+        off, worst = 0, 0.0
+        for n, sz, n64, err32 in zip(tn, sizes, z[f"{k}/tensor_norm64"], z[f"{k}/tensor_err32"]):
+            nh = float(np.linalg.norm(vec[off:off + int(sz)]))
+            off += int(sz)
+            if n64 == 0.0:
+                assert nh == 0.0, (mode, k, n)
+                continue
+            worst = max(worst, abs(nh - n64) / (3 * err32 + 1e-4 * n64))
+            assert abs(nh - n64) <= 3 * err32 + 1e-4 * n64, (mode, k, n, nh, float(n64), float(err32))
+        print(f"[512 fixture, {mode}] {k}: worst per-tensor |norm - norm64| / (3 err32 + 1e-4 norm64) = {worst:.2f}")

@@ -92,8 +92,16 @@ def run_net_fwd_bwd(net_hip, make_ref, x_cpu, gen, grad_tol=None, noise_mult=3, 
         e_hip_all, e_32_all = rel_l2(cat(grads), cat(gw64)), rel_l2(cat(gw32), cat(gw64))
         print(f'aggregate gradient error: hip={e_hip_all:.3e} oracle32={e_32_all:.3e}')
         assert e_hip_all <= noise_mult * e_32_all + 1e-3, (e_hip_all, e_32_all)
+        # per tensor: at most 10x the fp32 oracle's OWN distance to fp64 for that tensor, floored at the network's median per-tensor
+        # distance (one tensor's oracle error can be luckily small) -- a wrong or missing term in ONE tensor (rel-L2 0.1 .. 1) fails
+        # here even when the whole-vector criterion above would absorb it
+        per32 = {k: rel_l2(gw32[k], gw64[k]) for k in names}
+        floor = float(np.median(list(per32.values())))
+        worst = max(((rel_l2(grads[k], gw64[k]) / (10 * max(per32[k], floor)), k) for k in names))
+        print(f'per-tensor gradient error / (10 x fp32-oracle distance): worst {worst[0]:.2f} at {worst[1]} (median oracle distance {floor:.2e})')
         for k in names:
-            assert rel_l2(grads[k], gw64[k]) <= max(0.05, 30 * noise), k
+            e_k = rel_l2(grads[k], gw64[k])
+            assert e_k <= 10 * max(per32[k], floor), (k, e_k, per32[k], floor)
         return ref32, ref64
     for name in gw64:
         if float(gw64[name].abs().max()) < 1e-9:
@@ -180,11 +188,23 @@ def test_cyclegan_train_step_vs_reference_goldens(golden_dir, fname):
         # step 0 depends on forward passes only; later steps also on Adam updates, whose sign-like first steps
         # amplify rounding-level gradient differences on near-zero gradients
         np.testing.assert_allclose(got, z[f"step{s}/metrics"], rtol=2e-4 if s == 0 else 2e-3, atol=1e-6, err_msg=f"metrics step {s}")
+    lr, flipped, total = 2e-4, 0, 0
     for nm, net in nets.items():
         for i, (name, w) in enumerate(zip(net.variable_names, net.get_weights())):
-            # after 2-3 Adam steps each element has moved by <= ~3*lr; elements whose gradient is in the rounding
-            # noise may take a different sign step, hence the absolute escape of 2*lr
-            check_tensor(w, z[f"final/{nm}/{i}"], f"{nm}/{name}", 1e-3, atol=4.5e-4)
+            # Adam's first steps are sign-like (|step| ~ lr whatever the gradient's size): an element whose gradient is in the
+            # rounding noise may take a step of the other sign.  Such elements are COUNTED (|difference| > lr / 2 = a flipped step)
+            # and bounded in number; every other element must agree to lr / 2, and nothing may differ by more than the 2 * lr per
+            # step that two opposite sign steps can produce.  A tensor at rel-L2 <= 1e-3 passes outright.
+            ref = z[f"final/{nm}/{i}"]
+            assert w.shape == ref.shape, (nm, name)
+            d = np.abs(np.asarray(w, np.float64) - ref)
+            n_flip = int((d > 0.5 * lr).sum())
+            flipped, total = flipped + n_flip, total + d.size
+            assert float(d.max()) <= 2 * lr * n_steps * 1.05, (nm, name, float(d.max()))
+            if rel_l2(w, ref) > 1e-3:
+                assert n_flip <= max(2, 0.02 * d.size), f"{nm}/{name}: {n_flip} of {d.size} elements took a different Adam sign step"
+    print(f"{fname}: {flipped} of {total} weights ({flipped / total:.2e}) differ from the reference by more than lr / 2 after {n_steps} steps")
+    assert flipped <= 2e-3 * total
     # aggregate: all weights together
     allg = np.concatenate([w.ravel() for net in nets.values() for w in net.get_weights()])
     allr = np.concatenate([z[f"final/{nm}/{i}"].ravel() for nm, net in nets.items() for i in range(len(net.variable_names))])

@@ -377,13 +377,18 @@ def test_cyclegan_step_512_vs_committed_fp64_fixture(mode, golden_dir):
         e_32 = float(np.linalg.norm(s32 - s64) / np.linalg.norm(s64))
         print(f"[512 fixture, {mode}] {k}: sampled gradient entries rel-L2 vs fp64  hip={e_hip:.2e}  oracle32={e_32:.2e}")
         assert e_hip <= 3 * e_32 + 1e-4, (mode, k, e_hip, e_32)
-        off, worst = 0, 0.0
+        # per tensor, through the norms (| |a| - |b| | <= |a - b|): the fp32 oracle's own error of that tensor, floored at the
+        # network-wide relative error of the fp32 oracle applied to the tensor (a one-element tensor such as the head's bias can be
+        # luckily exact in one fp32 evaluation: 1e-5 there, 2e-4 in another fp32 evaluation of the same chaotic network)
+        net_rel32 = float(z[f"{k}/total_err32"]) / float(z[f"{k}/total_norm64"])
+        off, worst = 0, (0.0, "")
         for n, sz, n64, err32 in zip(tn, sizes, z[f"{k}/tensor_norm64"], z[f"{k}/tensor_err32"]):
             nh = float(np.linalg.norm(vec[off:off + int(sz)]))
             off += int(sz)
             if n64 == 0.0:
                 assert nh == 0.0, (mode, k, n)
                 continue
-            worst = max(worst, abs(nh - n64) / (3 * err32 + 1e-4 * n64))
-            assert abs(nh - n64) <= 3 * err32 + 1e-4 * n64, (mode, k, n, nh, float(n64), float(err32))
-        print(f"[512 fixture, {mode}] {k}: worst per-tensor |norm - norm64| / (3 err32 + 1e-4 norm64) = {worst:.2f}")
+            allow = 3 * max(float(err32), net_rel32 * float(n64)) + 1e-4 * float(n64)
+            worst = max(worst, (abs(nh - n64) / allow, n))
+            assert abs(nh - n64) <= allow, (mode, k, n, nh, float(n64), float(err32), net_rel32)
+        print(f"[512 fixture, {mode}] {k}: worst per-tensor |norm - norm64| / allowance = {worst[0]:.2f} at {worst[1]}")

@@ -92,16 +92,16 @@ def run_net_fwd_bwd(net_hip, make_ref, x_cpu, gen, grad_tol=None, noise_mult=3, 
         e_hip_all, e_32_all = rel_l2(cat(grads), cat(gw64)), rel_l2(cat(gw32), cat(gw64))
         print(f'aggregate gradient error: hip={e_hip_all:.3e} oracle32={e_32_all:.3e}')
         assert e_hip_all <= noise_mult * e_32_all + 1e-3, (e_hip_all, e_32_all)
-        # per tensor: at most 10x the fp32 oracle's OWN distance to fp64 for that tensor, floored at the network's median per-tensor
+        # per tensor: at most 3x the fp32 oracle's OWN distance to fp64 for that tensor, floored at the network's median per-tensor
         # distance (one tensor's oracle error can be luckily small) -- a wrong or missing term in ONE tensor (rel-L2 0.1 .. 1) fails
         # here even when the whole-vector criterion above would absorb it
         per32 = {k: rel_l2(gw32[k], gw64[k]) for k in names}
         floor = float(np.median(list(per32.values())))
-        worst = max(((rel_l2(grads[k], gw64[k]) / (10 * max(per32[k], floor)), k) for k in names))
-        print(f'per-tensor gradient error / (10 x fp32-oracle distance): worst {worst[0]:.2f} at {worst[1]} (median oracle distance {floor:.2e})')
+        worst = max(((rel_l2(grads[k], gw64[k]) / (3 * max(per32[k], floor)), k) for k in names))
+        print(f'per-tensor gradient error / (3 x fp32-oracle distance): worst {worst[0]:.2f} at {worst[1]} (median oracle distance {floor:.2e})')
         for k in names:
             e_k = rel_l2(grads[k], gw64[k])
-            assert e_k <= 10 * max(per32[k], floor), (k, e_k, per32[k], floor)
+            assert e_k <= 3 * max(per32[k], floor), (k, e_k, per32[k], floor)
         return ref32, ref64
     for name in gw64:
         if float(gw64[name].abs().max()) < 1e-9:
@@ -203,8 +203,22 @@ def test_cyclegan_train_step_vs_reference_goldens(golden_dir, fname):
             assert float(d.max()) <= 2 * lr * n_steps * 1.05, (nm, name, float(d.max()))
             if rel_l2(w, ref) > 1e-3:
                 assert n_flip <= max(2, 0.02 * d.size), f"{nm}/{name}: {n_flip} of {d.size} elements took a different Adam sign step"
-    print(f"{fname}: {flipped} of {total} weights ({flipped / total:.2e}) differ from the reference by more than lr / 2 after {n_steps} steps")
-    assert flipped <= 2e-3 * total
+    # the noise model for that count: the SAME steps through the float64 oracle -- the golden run was plain fp32 (torch CPU), so the
+    # number of weights on which float64 and the golden disagree by a flipped step is what fp32 rounding alone produces
+    refs64 = dict(gen_a=ON.ResnetGenerator(filters=filters, seed=1, dtype=torch.float64), gen_b=ON.ResnetGenerator(filters=filters, seed=2, dtype=torch.float64),
+                  disc_a=ON.PatchDiscriminator(filters=2 * filters, seed=3, dtype=torch.float64),
+                  disc_b=ON.PatchDiscriminator(filters=2 * filters, seed=4, dtype=torch.float64))
+    for nm, net in refs64.items():
+        net.set_weights([z[f"init/{nm}/{i}"] for i in range(len(nets[nm].variable_names))])
+    random.seed(seed)
+    ostep = OS.CycleGanStep(refs64["gen_a"], refs64["gen_b"], refs64["disc_a"], refs64["disc_b"], OS.ImagePool(2, 3), OS.ImagePool(2, 3))
+    for s in range(n_steps):
+        ostep.train_step((torch.from_numpy(z[f"step{s}/real_a"]).double(), torch.from_numpy(z[f"step{s}/real_b"]).double()))
+    noise_flips = sum(int((np.abs(np.asarray(w, np.float64) - z[f"final/{nm}/{i}"]) > 0.5 * lr).sum())
+                      for nm, net in refs64.items() for i, w in enumerate(net.get_weights()))
+    print(f"{fname}: {flipped} of {total} weights ({flipped / total:.2e}) differ from the reference by more than lr / 2 after {n_steps} steps; "
+          f"float64 oracle vs the same reference: {noise_flips} ({noise_flips / total:.2e})")
+    assert flipped <= 3 * noise_flips + 1e-4 * total, (flipped, noise_flips, total)
     # aggregate: all weights together
     allg = np.concatenate([w.ravel() for net in nets.values() for w in net.get_weights()])
     allr = np.concatenate([z[f"final/{nm}/{i}"].ravel() for nm, net in nets.items() for i in range(len(net.variable_names))])

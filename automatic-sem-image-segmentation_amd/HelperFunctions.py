@@ -345,48 +345,86 @@ def filter_gan_masks(img_path, msk_path, out_path, threshold_method=threshold_li
             Image.fromarray(img).filter(ImageFilter.GaussianBlur(gaussian_blur_amount)).save(os.path.join(img_path, f))
 
 
+WORKFLOW_TREE = ("1_WGAN/Output_Images", "1_WGAN/Models",
+                 "2_CycleGAN/data/testA", "2_CycleGAN/data/testB", "2_CycleGAN/data/trainA", "2_CycleGAN/data/trainB",
+                 "2_CycleGAN/generate_images/A", "2_CycleGAN/generate_images/B", "2_CycleGAN/generate_images/Synthetic_Masks_Filtered",
+                 "2_CycleGAN/images", "2_CycleGAN/Models", "3_UNet/Models")
+
+
+def initialize_directories(root_dir, output_dir_cyclegan, output_dir_unet):
+    """The workflow's on-disk tree under ``root_dir`` plus the two result directories (HelperFunctions.py:188-238)."""
+    for rel in WORKFLOW_TREE:
+        os.makedirs(os.path.join(root_dir, *rel.split("/")), exist_ok=True)
+    for d in (output_dir_cyclegan, output_dir_unet):
+        os.makedirs(d, exist_ok=True)
+
+
+class _TileSet:
+    """trainA as step 0 builds it: a sink for uint8 tiles that applies the "mainly particles, not background" test
+    (mean >= 1.1 x image mean for dark backgrounds, <= 0.9 x for bright ones; HelperFunctions.py:256-257,281-282)."""
+
+    def __init__(self, directory, dark_background):
+        self.directory, self.dark = directory, dark_background
+
+    def shows_particles(self, tile, image):
+        m_tile, m_img = np.mean(tile), np.mean(image)
+        return m_tile >= 1.1 * m_img if self.dark else m_tile <= 0.9 * m_img
+
+    def add(self, tile, image, source_name, tag):
+        """Write ``tile`` as <source stem>-<tag><ext> if it passes the filter; returns whether it did."""
+        if not self.shows_particles(tile, image):
+            return False
+        from PIL import Image
+        ext = os.path.splitext(source_name)[-1]
+        Image.fromarray(np.asarray(tile)[:, :, 0].astype('uint8')).save(os.path.join(self.directory, source_name.replace(ext, f'-{tag}{ext}')))
+        return True
+
+    def names(self):
+        return get_image_file_paths_from_directory(self.directory)
+
+    def __len__(self):
+        return len(os.listdir(self.directory))
+
+
+def _random_crop(image, tile_h, tile_w):
+    """One augmentation sample: a random window, mirrored left-right / up-down with probability 1/2 each.  Draw order (python
+    ``random``): row, column, lr coin, ud coin -- the reference's (HelperFunctions.py:272-279), so seeded runs write the same files."""
+    top = random.randint(0, image.shape[0] - tile_h - 1)
+    left = random.randint(0, image.shape[1] - tile_w - 1)
+    crop = image[top:top + tile_h, left:left + tile_w]
+    if random.random() > 0.5:
+        crop = np.fliplr(crop)
+    if random.random() > 0.5:
+        crop = np.flipud(crop)
+    return crop
+
+
 def prepare_images_cycle_gan(root_dir, input_dir_images, tile_size_w=384, tile_size_h=384, num_simulated_masks=1000, dark_background=True):
-    """Step 0 of the workflow (HelperFunctions.py:241-287): tile the SEM images into ``2_CycleGAN/data/trainA`` (tiles that show
-    mainly background are dropped: mean >= 1.1 x image mean for dark backgrounds, <= 0.9 x for bright ones), copy 5 random tiles to
-    ``testA``, then top the tile set up to ``num_simulated_masks`` with random crops (+ random flips) that pass the same filter.
-    Same draws from python's ``random`` in the same order as the reference, so a seeded run writes the same files."""
-    from PIL import Image
+    """Step 0 of the workflow (HelperFunctions.py:241-287), in three phases: (1) every SEM image is cut into a regular grid of tiles and
+    the tiles that show particles go to ``2_CycleGAN/data/trainA``; (2) five random tiles are copied to ``testA``; (3) the set is
+    topped up to ``num_simulated_masks`` with random, randomly mirrored crops that pass the same test.  Bit-identical files for a
+    seeded ``random`` (tests/test_wgan_cpu.py)."""
     from shutil import copy
-    train_a = os.path.join(root_dir, '2_CycleGAN', 'data', 'trainA')
-    test_a = os.path.join(root_dir, '2_CycleGAN', 'data', 'testA')
+    data = os.path.join(root_dir, '2_CycleGAN', 'data')
+    tiles = _TileSet(os.path.join(data, 'trainA'), dark_background)
+    images = load_and_preprocess_images(input_dir_or_filelist=input_dir_images, normalization_range=None, output_channels=1)
+    sources = [os.path.split(p)[-1] for p in get_image_file_paths_from_directory(input_dir_images)]
 
-    def foreground(tile, image):
-        return np.mean(tile) >= 1.1 * np.mean(image) if dark_background else np.mean(tile) <= 0.9 * np.mean(image)
+    for name, image in zip(sources, images):
+        grid = np.asarray(tile_image(image, tile_size_w, tile_size_h, normalization_range=(0, 255), min_overlap=0), dtype='uint8')
+        for j, tile in enumerate(grid):
+            tiles.add(tile, image, name, j)
 
-    input_imgs = load_and_preprocess_images(input_dir_or_filelist=input_dir_images, normalization_range=None, output_channels=1)
-    filenames = get_image_file_paths_from_directory(input_dir_images)
-    for i, input_img in enumerate(input_imgs):
-        img_tiles = np.asarray(tile_image(input_img, tile_size_w, tile_size_h, normalization_range=(0, 255), min_overlap=0), dtype='uint8')
-        f = os.path.split(filenames[i])[-1]
-        ext = os.path.splitext(f)[-1]
-        for j, img_tile in enumerate(img_tiles):
-            if foreground(img_tile, input_img):
-                Image.fromarray(img_tile[:, :, 0]).save(os.path.join(train_a, f.replace(ext, f'-{j}{ext}')))
+    tile_names = tiles.names()
+    for path in random.sample(tile_names, 5):
+        copy(path if os.path.isabs(path) else os.path.join(tiles.directory, path), os.path.join(data, 'testA'))
 
-    filenames = get_image_file_paths_from_directory(train_a)
-    for f in random.sample(filenames, 5):
-        copy(f if os.path.isabs(f) else os.path.join(train_a, f), test_a)
-
-    num_images_a = len(os.listdir(train_a))
-    i = 0
-    while i < num_simulated_masks - num_images_a:
-        # sic (HelperFunctions.py:268-271): ``filenames`` is by now the TILE list, indexed with an index drawn over the input images
-        r = random.randint(0, input_imgs.shape[0] - 1)
-        f = os.path.split(filenames[r])[-1]
-        ext = os.path.splitext(f)[-1]
-        input_img = input_imgs[r, :, :, :]
-        a = random.randint(0, input_img.shape[0] - tile_size_h - 1)
-        b = random.randint(0, input_img.shape[1] - tile_size_w - 1)
-        img_tile = input_img[a:a + tile_size_h, b:b + tile_size_w]
-        if random.random() > 0.5:
-            img_tile = np.fliplr(img_tile)
-        if random.random() > 0.5:
-            img_tile = np.flipud(img_tile)
-        if foreground(img_tile, input_img):
-            Image.fromarray(img_tile[:, :, 0].astype('uint8')).save(os.path.join(train_a, f.replace(ext, f'-aug_{i}{ext}')))
-            i += 1
+    wanted = num_simulated_masks - len(tiles)
+    made = 0
+    while made < wanted:
+        # the reference names an augmented crop after tile_names[r] with r drawn over the INPUT images (HelperFunctions.py:268-271:
+        # its file list had been re-bound to the tile list by then); kept, the names are part of the on-disk contract
+        r = random.randint(0, images.shape[0] - 1)
+        crop = _random_crop(images[r], tile_size_h, tile_size_w)
+        if tiles.add(crop, images[r], os.path.split(tile_names[r])[-1], f'aug_{made}'):
+            made += 1

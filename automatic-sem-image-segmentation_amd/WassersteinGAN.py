@@ -439,6 +439,94 @@ def _gradient_noise2array(ys, xs, rng):
     return (top * (1 - v) + bot * v) * math.sqrt(2.0)
 
 
+class _MaskCanvas:
+    """The working image of one simulated mask (WassersteinGAN.py:405-417,519-533): the requested size plus a margin of 3 d, with
+    d = the diagonal of the largest (scaled) particle, so that particles may hang over the edges of the final crop.  Positions are
+    drawn over (W, H) = size + 2 d; the smooth noise field covers size + 3 d and is indexed [x, y] like the reference's."""
+
+    def __init__(self, particle_h, particle_w, img_height, img_width, max_scaling):
+        self.ph, self.pw, self.img_h, self.img_w = particle_h, particle_w, img_height, img_width
+        self.d = math.ceil(math.sqrt((max_scaling * particle_h) ** 2 + (max_scaling * particle_w) ** 2))
+        self.H, self.W = img_height + 2 * self.d, img_width + 2 * self.d
+        self.img = np.zeros((img_height + 3 * self.d, img_width + 3 * self.d), dtype='uint8')
+
+    def clear(self):
+        self.img[:] = 0
+
+    def noise_field(self, frequency):
+        """Band-limited noise in [-1, 1], shape (img_w + 3 d, img_h + 3 d) (opensimplex.noise2array(x=iy, y=ix): WassersteinGAN.py:419-424)."""
+        ix = np.arange(0, frequency, frequency / (self.img_w + 3 * self.d))
+        iy = np.arange(0, frequency, frequency / (self.img_h + 3 * self.d))
+        f = _gradient_noise2array(ix, iy, np.random.default_rng(np.random.randint(0, 2 ** 31 - 1)))
+        f -= np.min(f)
+        f /= np.max(f) / 2
+        return f - 1
+
+    def grid_positions(self, kind, spacing_factor, jitter_factor):
+        """Hexagonal (every other row shifted by half a cell) or cubic lattice over (W, H), jittered and clipped (WassersteinGAN.py:426-458)."""
+        sx, sy = int(spacing_factor * self.pw), int(spacing_factor * self.ph)
+        if kind == 'HEXAGONAL':
+            shift = int(spacing_factor * self.pw / 2)
+            pts = []
+            for k, y in enumerate(range(0, self.H, sy)):
+                for x in range(0, self.W, sx):
+                    if x + k % 2 * shift > self.W:
+                        break
+                    pts.append((x + k % 2 * shift, y))
+            # the reference pre-sizes its arrays (rows x columns + 1): the unused tail stays at the origin and takes part in what follows
+            size = math.ceil(self.H / (spacing_factor * self.ph)) * math.ceil(self.W / (spacing_factor * self.pw)) + 1
+            pos = np.zeros((max(size, len(pts)), 2), dtype='int32')
+            if pts:
+                pos[:len(pts)] = np.asarray(pts, dtype='int32')
+            pos_x, pos_y = pos[:, 0], pos[:, 1]
+        else:
+            pos_y, pos_x = np.mgrid[0:self.H:sy, 0:self.W:sy]          # sic (WassersteinGAN.py:452): both spacings from the particle height
+            pos_x, pos_y = pos_x.flatten(), pos_y.flatten()
+        pos_x = pos_x + np.random.randint(int(-jitter_factor * self.pw), int(jitter_factor * self.pw), pos_x.size)
+        pos_y = pos_y + np.random.randint(int(-jitter_factor * self.ph), int(jitter_factor * self.ph), pos_y.size)
+        return np.clip(pos_x, 0, self.W), np.clip(pos_y, 0, self.H)
+
+    @staticmethod
+    def positions_from_field(noise, level, count):
+        """``count`` distinct positions, uniformly among the cells where the field exceeds ``level`` (WassersteinGAN.py:461-468)."""
+        weight = (noise > level).astype('float32')
+        weight /= np.sum(weight)
+        values = np.random.choice(noise.ravel(), count, replace=False, p=weight.ravel())
+        cells = np.asarray(np.nonzero(np.isin(noise, values))).transpose()
+        np.random.shuffle(cells)
+        pos_x, pos_y = cells.transpose()
+        return pos_x, pos_y
+
+    def place(self, particle, y0, x0, rotation, scaling, max_overlap):
+        """Rotate / scale the particle about its centre into its bounding box, clean it (threshold, fill holes, 9x9 opening), and put
+        it at (y0, x0): pixels under its footprint are cleared, its 2-pixel erosion is set -- a dark rim separates neighbours.
+        Skipped when the erosion overlaps what is already there by more than ``max_overlap`` of its area (WassersteinGAN.py:500-526)."""
+        from scipy import ndimage
+        height, width = particle.shape
+        centre = (width / 2, height / 2)
+        m = _rotation_matrix_2d(centre, rotation, scaling)
+        abs_cos, abs_sin = abs(m[0, 0]), abs(m[0, 1])
+        bound_w = int(width * abs_sin + height * abs_cos)
+        bound_h = int(width * abs_cos + height * abs_sin)
+        m[0, 2] += bound_h / 2 - centre[0]
+        m[1, 2] += bound_w / 2 - centre[1]
+        shape = _warp_affine(particle, m, (bound_h, bound_w)) > 127
+        shape = ndimage.binary_opening(ndimage.binary_fill_holes(shape), structure=np.ones((9, 9)))
+        core = ndimage.binary_erosion(shape, iterations=2)
+        if not np.any(core):
+            return False
+        win = self.img[y0:y0 + shape.shape[0], x0:x0 + shape.shape[1]]
+        if max_overlap is not None and np.sum(np.logical_and(win, core).astype('int32')) > max_overlap * np.sum(core.astype('uint8')):
+            return False
+        win -= np.logical_and(win, shape).astype('uint8')
+        win += core.astype('uint8')
+        return True
+
+    def crop(self):
+        a, b = int((self.img.shape[0] - self.img_h) / 2), int((self.img.shape[1] - self.img_w) / 2)
+        return self.img[a:a + self.img_h, b:b + self.img_w]
+
+
 class WGAN:
     """Workflow class of step 1 (WassersteinGAN.py:288-545, 683-724): same constructor, attributes and on-disk contract
     (``Input_Masks`` -> ``1_WGAN/{Models,Output_Images}/<timestamp>`` -> simulated masks in ``2_CycleGAN/data/trainB``)."""
@@ -593,102 +681,47 @@ class WGAN:
                        mu=1.0, min_scaling=0.75, max_scaling=1.25, use_perlin_noise=True, perlin_noise_threshold=0.5,
                        perlin_noise_frequency=4, use_random_rotation='DISABLE', max_overlap=0.01, grid_type='DISABLE',
                        grid_spacing_factor=0.125, grid_noise_factor=0.05, img_width=384, img_height=384):
+        """Step 2 of the workflow (WassersteinGAN.py:382-545): ``no_of_images`` binary masks of generated particles.  Per mask: where
+        (grid or free placement, optionally thinned / weighted by a smooth noise field), how large and how rotated every particle
+        is, then the particles one by one onto a canvas with a margin, rejecting those that overlap too much."""
         from PIL import Image
-        from scipy import ndimage
         from shutil import copy
-        ph, pw = self.train_images.shape[1], self.train_images.shape[2]
-        d = math.ceil(math.sqrt((max_scaling * ph) ** 2 + (max_scaling * pw) ** 2))
         if self.model is None:
             self.load_model(os.path.join(self.model_dir, os.listdir(self.model_dir)[-1], 'model.keras'))
         if use_normal_distribution:
-            min_scaling, max_scaling = mu - 3 * sigma, mu + 3 * sigma
-        if max_overlap is not None and grid_type != 'HEXAGONAL' and grid_type != 'CUBIC':
-            grid_type = 'HEXAGONAL'
+            min_scaling, max_scaling_used = mu - 3 * sigma, mu + 3 * sigma
+        else:
+            max_scaling_used = max_scaling
+        if max_overlap is not None and grid_type not in ('HEXAGONAL', 'CUBIC'):
+            grid_type = 'HEXAGONAL'          # overlap control only exists on the grid paths (WassersteinGAN.py:407-408)
+        canvas = _MaskCanvas(self.train_images.shape[1], self.train_images.shape[2], img_height, img_width, max_scaling)
         os.makedirs(self.generate_dir, exist_ok=True)
-        H, W = img_height + 2 * d, img_width + 2 * d
-        for i in range(0, no_of_images):
-            img = np.zeros((img_height + 3 * d, img_width + 3 * d), dtype='uint8')
-            noise_image = None
-            no_of_particles = 0
-            if grid_type != 'HEXAGONAL' and grid_type != 'CUBIC':
-                no_of_particles = random.randint(min_no_of_particles, max_no_of_particles)
-            if use_perlin_noise or use_random_rotation == 'PERLIN':
-                ix = np.arange(0, perlin_noise_frequency, perlin_noise_frequency / (img_width + 3 * d))
-                iy = np.arange(0, perlin_noise_frequency, perlin_noise_frequency / (img_height + 3 * d))
-                # opensimplex.noise2array(x=iy, y=ix) returns (len(ix), len(iy)) = (W + 3d, H + 3d): the reference indexes it [x, y] throughout
-                noise_image = _gradient_noise2array(ix, iy, np.random.default_rng(np.random.randint(0, 2 ** 31 - 1)))
-                noise_image -= np.min(noise_image)
-                noise_image /= np.max(noise_image) / 2
-                noise_image = noise_image - 1
-            sx, sy = int(grid_spacing_factor * pw), int(grid_spacing_factor * ph)
-            if grid_type == 'HEXAGONAL':
-                pos_x = np.zeros(math.ceil(H / (grid_spacing_factor * ph)) * math.ceil(W / (grid_spacing_factor * pw)) + 1, dtype='int32')
-                pos_y = np.zeros_like(pos_x)
-                n = 0
-                for k, y in enumerate(range(0, H, sy)):
-                    for j, x in enumerate(range(0, W, sx)):
-                        if x + k % 2 * int(grid_spacing_factor * pw / 2) > W:
-                            break
-                        pos_x[n] = x + k % 2 * int(grid_spacing_factor * pw / 2)
-                        pos_y[n] = y
-                        n += 1
-            elif grid_type == 'CUBIC':
-                pos_y, pos_x = np.mgrid[0:H:sy, 0:W:sy]          # sic (WassersteinGAN.py:452): both spacings from shape[1]
-                pos_x, pos_y = pos_x.flatten(), pos_y.flatten()
+        for i in range(no_of_images):
+            canvas.clear()
+            count = random.randint(min_no_of_particles, max_no_of_particles) if grid_type not in ('HEXAGONAL', 'CUBIC') else 0
+            noise = canvas.noise_field(perlin_noise_frequency) if (use_perlin_noise or use_random_rotation == 'PERLIN') else None
+            level = 2 * perlin_noise_threshold - 1
             if grid_type in ('HEXAGONAL', 'CUBIC'):
-                pos_x = pos_x + np.random.randint(int(-grid_noise_factor * pw), int(grid_noise_factor * pw), pos_x.size)
-                pos_y = pos_y + np.random.randint(int(-grid_noise_factor * ph), int(grid_noise_factor * ph), pos_y.size)
-                pos_x, pos_y = np.clip(pos_x, 0, W), np.clip(pos_y, 0, H)
-                if use_perlin_noise:
-                    sel = [(pos_x[q], pos_y[q]) for q in range(0, len(pos_x)) if noise_image[pos_x[q], pos_y[q]] > (2 * perlin_noise_threshold - 1)]
-                    pos_x, pos_y = zip(*sel) if sel else ((), ())          # sic: the noise image is indexed [x, y]
-                no_of_particles = len(pos_x)
+                pos_x, pos_y = canvas.grid_positions(grid_type, grid_spacing_factor, grid_noise_factor)
+                if use_perlin_noise:          # thin the grid where the field is low (indexed [x, y], as the reference does)
+                    keep = [q for q in range(len(pos_x)) if noise[pos_x[q], pos_y[q]] > level]
+                    pos_x, pos_y = [pos_x[q] for q in keep], [pos_y[q] for q in keep]
+                count = len(pos_x)
             elif use_perlin_noise:
-                pos_values = (noise_image > (2 * perlin_noise_threshold - 1)).astype('float32') * 1.0
-                pos_values /= np.sum(pos_values)
-                selection = np.random.choice(noise_image.ravel(), no_of_particles, replace=False, p=pos_values.ravel())
-                selection = np.asarray(np.nonzero(np.isin(noise_image, selection))).transpose()
-                np.random.shuffle(selection)
-                pos_x, pos_y = selection.transpose()
+                pos_x, pos_y = canvas.positions_from_field(noise, level, count)
             else:
-                pos_x, pos_y = np.random.randint(0, W, no_of_particles), np.random.randint(0, H, no_of_particles)
-
-            if use_normal_distribution:
-                scalings = np.random.normal(mu, sigma, no_of_particles)
-            else:
-                scalings = np.random.uniform(min_scaling, max_scaling, no_of_particles)
-            scalings = np.clip(scalings, min_scaling, max_scaling)
+                pos_x, pos_y = np.random.randint(0, canvas.W, count), np.random.randint(0, canvas.H, count)
+            scalings = np.random.normal(mu, sigma, count) if use_normal_distribution else np.random.uniform(min_scaling, max_scaling_used, count)
+            scalings = np.clip(scalings, min_scaling, max_scaling_used)
             if use_random_rotation == 'RANDOM':
-                rotations = np.random.randint(0, 360, no_of_particles)
+                rotations = np.random.randint(0, 360, count)
             elif use_random_rotation == 'PERLIN':
-                rotations = noise_image[np.asarray(pos_y, dtype=int), np.asarray(pos_x, dtype=int)] * 180
+                rotations = noise[np.asarray(pos_y, dtype=int), np.asarray(pos_x, dtype=int)] * 180
             else:
-                rotations = np.zeros(no_of_particles)
-
-            samples = self._sample_particles(no_of_particles)
-            for j, p in enumerate(samples):
-                height, width = p.shape
-                image_center = (width / 2, height / 2)
-                rotation_mat = _rotation_matrix_2d(image_center, rotations[j], scalings[j])
-                abs_cos, abs_sin = abs(rotation_mat[0, 0]), abs(rotation_mat[0, 1])
-                bound_w = int(width * abs_sin + height * abs_cos)
-                bound_h = int(width * abs_cos + height * abs_sin)
-                rotation_mat[0, 2] += bound_h / 2 - image_center[0]
-                rotation_mat[1, 2] += bound_w / 2 - image_center[1]
-                p = _warp_affine(p, rotation_mat, (bound_h, bound_w))
-                p = p > 127
-                p = ndimage.binary_fill_holes(p)
-                p = ndimage.binary_opening(p, structure=np.ones((9, 9)))
-                p_eroded = ndimage.binary_erosion(p, iterations=2)
-                if np.any(p_eroded > 0):
-                    y0, x0 = int(pos_y[j]), int(pos_x[j])
-                    win = img[y0:y0 + p.shape[0], x0:x0 + p.shape[1]]
-                    if max_overlap is not None and np.sum(np.logical_and(win, p_eroded).astype('int32')) > max_overlap * np.sum(p_eroded.astype('uint8')):
-                        continue
-                    win -= np.logical_and(win, p).astype('uint8')
-                    win += p_eroded.astype('uint8')
-            a, b = int((img.shape[0] - img_height) / 2), int((img.shape[1] - img_width) / 2)
-            Image.fromarray(img[a:a + img_height, b:b + img_width] * 255).save(os.path.join(self.generate_dir, '{:05d}.tif'.format(i)))
+                rotations = np.zeros(count)
+            for j, particle in enumerate(self._sample_particles(count)):
+                canvas.place(particle, int(pos_y[j]), int(pos_x[j]), rotations[j], scalings[j], max_overlap)
+            Image.fromarray(canvas.crop() * 255).save(os.path.join(self.generate_dir, '{:05d}.tif'.format(i)))
 
         # five random files for testing (WassersteinGAN.py:539-545)
         input_files = [f for f in os.listdir(self.generate_dir) if '.tif' in f or '.png' in f or '.bmp' in f]

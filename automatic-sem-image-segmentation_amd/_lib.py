@@ -40,7 +40,10 @@ class ConvDesc(_SizedDesc):
                 # optional weight cache of the layer (ss_wcache: transformed / split weights kept across calls)
                 ("w_cache", c_vp),
                 # optional output statistics (sum y, sum y^2 per sample and channel) written by the forward epilogue
-                ("y_stats", c_vp)]
+                ("y_stats", c_vp),
+                # optional fused input normalisation: x is the pre-norm tensor, normalised in the operand load (in_norm_groups == 0: off)
+                ("in_norm_mean", c_vp), ("in_norm_rstd", c_vp), ("in_norm_gamma", c_vp), ("in_norm_beta", c_vp),
+                ("in_norm_groups", c_i32), ("in_norm_act", c_i32), ("in_norm_alpha", c_f32), ("in_norm_reserved", c_i32)]
 
 
 class NormDesc(_SizedDesc):
@@ -103,6 +106,7 @@ SIGNATURES = {
     "ss_conv2d_workspace_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_uses_amax": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_stats_chunks": (c_i32, [ctypes.POINTER(ConvDesc)]),
+    "ss_conv2d_fuses_in_norm": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_wcache_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_wcache_invalidate": (None, [ctypes.POINTER(WCache)]),
     "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -111,6 +115,7 @@ SIGNATURES = {
     "ss_norm_reports_amax": (c_i32, [ctypes.POINTER(NormDesc)]),
     "ss_norm_workspace_bytes": (c_sz, [ctypes.POINTER(NormDesc)]),
     "ss_norm_fwd": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_sz, c_vp]),
+    "ss_norm_apply": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ss_norm_infer": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ss_norm_bwd": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "ss_norm_fwd_stats": (c_i32, [ctypes.POINTER(NormDesc), c_vp, c_vp, c_vp, c_sz, c_vp]),

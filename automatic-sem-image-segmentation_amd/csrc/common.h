@@ -78,6 +78,20 @@ __device__ __forceinline__ unsigned int ss_amax_load(const unsigned int* __restr
     return m;
 }
 
+// block maximum of a non-negative per-thread value -> a caller's striped slot (bit pattern; non-negative floats order like unsigned
+// ints, so the atomic max is order-independent).  One atomic per block, spread over the stripes.  ALL threads of the block call it.
+__device__ __forceinline__ void ss_block_amax_to_slot(float m, unsigned int* __restrict__ slot) {
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    __shared__ float ss_bam_wm[16];
+    if ((threadIdx.x & 63) == 0) ss_bam_wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = ss_bam_wm[0];
+        for (int i = 1; i < (int)((blockDim.x + 63) >> 6); ++i) b = fmaxf(b, ss_bam_wm[i]);
+        atomicMax(slot + (blockIdx.x % SS_AMAX_STRIPES) * SS_AMAX_STRIDE, __float_as_uint(b));
+    }
+}
+
 __device__ __forceinline__ int ss_amax_exp(float amax) {
     int e = 14;
     if (amax > 0.f) (void)frexpf(amax, &e);
@@ -292,6 +306,17 @@ static inline void* ss_wc_region(WCache* wc, uint64_t tag, size_t n, void* fallb
     return (char*)wc->base + e.offset;
 }
 
+// normalisation applied in a convolution's operand load (ss_conv_desc::in_norm_*): groups == 0 -> off
+struct InNorm {
+    const float* mean = nullptr;
+    const float* rstd = nullptr;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    int groups = 0, act = 0;
+    float alpha = 0.f;
+    unsigned int* amax_out = nullptr;      // forward: striped slot raised to max|normalised x| (nullptr: not wanted)
+};
+
 struct WinoProb {
     int n, h, w, cin, in_cs;      // gathered input (reduction channels = cin)
     int oh, ow, cout, out_cs;     // output grid
@@ -306,8 +331,10 @@ struct WinoProb {
     const unsigned int* dy_amax = nullptr;
     int x_stripes = 0, dy_stripes = 0;
     float* y_stats = nullptr;     // forward: partial (sum y, sum y^2) per sample / chunk / channel from the output transform
+    InNorm in_norm;               // forward / weight gradient: x is a pre-normalisation tensor, normalised in the input transform
 };
 bool ss_wino_wgrad_tn(const WinoProb& q);
+bool ss_wino_fwd_x3h(const WinoProb& q);          // the forward pass takes the x3h plane path (the one that fuses InNorm)
 int ss_wino_stats_chunks(const WinoProb& q);
 
 // C[b][m][n] = sum_k (Ah+Al)[b][m][k] * (Bh+Bl)[b][n][k], bf16 planes, fp32 output (gemm_bf16x3.hip)

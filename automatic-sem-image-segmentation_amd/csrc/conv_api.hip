@@ -20,6 +20,7 @@ struct ConvProb {
     int dtype = SS_DTYPE_F32;      // storage type of x / y / dy / dx: 16-bit only ever reaches the tile kernels (see ss_conv2d_fwd)
     WCache* wc = nullptr;          // caller-owned cache of the weight-derived operands of this pass (ss_conv_desc::w_cache)
     float* y_stats = nullptr;      // forward: output statistics for a following norm (ss_conv_desc::y_stats)
+    InNorm in_norm;                // forward / weight gradient: x is pre-normalisation, normalised in the operand load (ss_conv_desc::in_norm_*)
 };
 
 // ---- small helper kernels -----------------------------------------------------------------------
@@ -474,8 +475,14 @@ int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bia
     if (wino_fwd_prob(c, algo, &q)) {
         q.wc = c.wc;
         q.y_stats = c.y_stats;
+        q.in_norm = c.in_norm;
+        if (c.in_norm.groups > 0 && c.x_amax && !c.x_valid && !(c.wc && c.wc->fill_only)) {      // the transform reports max|normalised x|
+            (void)hipMemsetAsync(c.x_amax, 0, (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4, s);
+            q.in_norm.amax_out = c.x_amax;
+        }
         return ss_wino_conv_fwd(q, x, w, c.cin, c.cout, 0, bias, y, act, alpha, accumulate, ws, ws_bytes, s);
     }
+    if (c.in_norm.groups > 0) { ss_set_error("in_norm: this forward pass does not normalise in its operand load (ss_conv2d_fuses_in_norm)"); return SS_ERR_UNSUPPORTED; }
     GConvParams p = fwd_params(c, x, w, bias, y, act, alpha, accumulate);
     if (need_x_amax_fwd(c, algo) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p) + 256) {
         unsigned int* sl = (unsigned int*)((char*)ws + ss_gconv_x6_planes_bytes(p));
@@ -701,6 +708,11 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
     {
         WinoProb q;
         if (wino_fwd_prob(c, algo, &q)) {
+            q.in_norm = c.in_norm;
+            if (c.in_norm.groups > 0 && !(ss_wino_wgrad_tn(q) && c.x_amax && c.x_valid)) {
+                ss_set_error("in_norm: the weight gradient needs the pre-split-plane path and the forward pass's max|normalised x| (x_amax, x_amax_valid)");
+                return SS_ERR_UNSUPPORTED;
+            }
             if (ss_wino_wgrad_tn(q)) {        // pre-split planes need max|x| and max|dy| before the transforms run
                 unsigned int* sl = (unsigned int*)((char*)ws + ss_wino_wgrad_ws(q) - 256);
                 const AmaxRef ax = act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
@@ -710,6 +722,7 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
             return ss_wino_conv_wgrad(q, x, dy, dw, accumulate, ws, ws_bytes, s);
         }
     }
+    if (c.in_norm.groups > 0) { ss_set_error("in_norm: this weight-gradient pass does not normalise in its operand load"); return SS_ERR_UNSUPPORTED; }
     {
         const int m = wgrad_c1_mode(c, algo);
         if (m == 0)
@@ -775,6 +788,12 @@ bool valid_desc(const ss_conv_desc* d) {
     if (d->in_cstride < d->cin || d->out_cstride < d->cout) return false;
     if (d->pad_mode == SS_PAD_REFLECT && (d->stride != 1 || d->transposed)) return false;
     if (d->pad_mode == SS_PAD_REFLECT && (d->pad_top >= d->ih || d->pad_left >= d->iw)) return false;
+    if (d->in_norm_groups != 0) {
+        if (d->transposed || (d->in_norm_groups != 1 && d->in_norm_groups != d->n) || !d->in_norm_mean || !d->in_norm_rstd || !d->in_norm_beta) {
+            ss_set_error("ss_conv_desc.in_norm_*: groups must be 1 or n, mean / rstd / beta non-NULL, not a transposed convolution");
+            return false;
+        }
+    }
     return true;
 }
 
@@ -783,6 +802,10 @@ ConvProb plain(const ss_conv_desc* d) {
                d->kh, d->kw, d->stride, d->pad_top, d->pad_left, d->pad_mode == SS_PAD_REFLECT};
     c.x_amax = (unsigned int*)d->x_amax; c.x_valid = d->x_amax_valid;
     c.dy_amax = (unsigned int*)d->dy_amax; c.dy_valid = d->dy_amax_valid;
+    if (d->in_norm_groups > 0) {
+        c.in_norm.mean = d->in_norm_mean; c.in_norm.rstd = d->in_norm_rstd; c.in_norm.gamma = d->in_norm_gamma; c.in_norm.beta = d->in_norm_beta;
+        c.in_norm.groups = d->in_norm_groups; c.in_norm.act = d->in_norm_act; c.in_norm.alpha = d->in_norm_alpha;
+    }
     return c;
 }
 // adjoint conv of a transposed conv: output space -> input space (its "x" is the transposed conv's dy and vice versa)
@@ -957,6 +980,7 @@ ConvShim make_shim(const ss_conv_desc* d, void* ws, size_t ws_bytes) {
     sh.d32.x_amax = sh.d32.dy_amax = nullptr;
     sh.d32.y_stats = nullptr;
     sh.d32.x_amax_valid = sh.d32.dy_amax_valid = 0;
+    sh.d32.in_norm_groups = 0;                 // fp32 storage only (valid_desc_any rejects it for the 16-bit types)
     sh.a_bytes = ss_align_up((size_t)d->n * d->ih * d->iw * d->cin * sizeof(float), 256);
     sh.b_bytes = ss_align_up((size_t)d->n * d->oh * d->ow * d->cout * sizeof(float), 256);
     sh.a = (float*)ws;
@@ -1012,6 +1036,7 @@ bool valid_desc_any(const ss_conv_desc* d) {
     if (d->struct_size != sizeof(ss_conv_desc)) return valid_desc(d);          // sets the message
     if (d->dtype == SS_DTYPE_F32) return valid_desc(d);
     if (d->dtype != SS_DTYPE_BF16 && d->dtype != SS_DTYPE_F16) { ss_set_error("ss_conv_desc.dtype = %d unknown", d->dtype); return false; }
+    if (d->in_norm_groups != 0) { ss_set_error("ss_conv_desc.in_norm_*: fp32 activation storage only"); return false; }
     ss_conv_desc t = *d;
     t.dtype = SS_DTYPE_F32;
     return valid_desc(&t);
@@ -1052,6 +1077,19 @@ size_t ss_conv2d_wcache_bytes(const ss_conv_desc* d, int pass) {
 int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass) {
     if (!valid_desc_any(d) || d->dtype != SS_DTYPE_F32) return 0;
     return conv2d_uses_amax32(d, pass);
+}
+
+int ss_conv2d_fuses_in_norm(const ss_conv_desc* d, int pass) {
+    if (!d || d->struct_size != sizeof(ss_conv_desc) || d->dtype != SS_DTYPE_F32 || d->transposed) return 0;
+    ss_conv_desc t = *d;
+    t.in_norm_groups = 0;
+    if (!valid_desc(&t)) return 0;
+    const ConvProb c = plain(&t);
+    WinoProb q;
+    if (c.kh * c.kw > SS_MAX_TAPS || !wino_fwd_prob(c, d->algo, &q)) return 0;
+    if (pass == SS_PASS_FWD) return ss_wino_fwd_x3h(q) ? 1 : 0;
+    if (pass == SS_PASS_BWD_WEIGHT) return ss_wino_wgrad_tn(q) ? 1 : 0;
+    return 0;
 }
 
 int ss_conv2d_fwd(const ss_conv_desc* d, const void* x, const float* w, const float* bias, void* y,

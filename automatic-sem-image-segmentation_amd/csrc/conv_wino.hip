@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
                                                          int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V, long Mpad = 0,
                                                          float* __restrict__ tile_inv = nullptr, unsigned int* __restrict__ amax_out = nullptr,
                                                          const unsigned int* __restrict__ amax_in = nullptr, int amax_stripes = 0, int bound = 0,
-                                                         int plain_l = 0) {
+                                                         int plain_l = 0, InNorm nm = InNorm()) {
     typedef typename WT<R>::T T;
     constexpr int VW = WT<R>::VW, P = R + 2;
     const int CV = C / VW;
@@ -144,13 +144,42 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         iy[i] = ss_map_index(R * ty + i - pt, H, reflect);
         ix[i] = ss_map_index(R * tx + i - pl, W, reflect);
     }
+    // fused input normalisation (ss_conv_desc::in_norm_*; BF 3 / 4 launchers only): `in` is the PRE-norm tensor, every element is
+    // normalised as it is loaded with norm_apply_kernel's expression (norm.hip), padding zeros stay zero
+    const bool fused = (BF == 3 || BF == 4) && nm.groups > 0;
+    T n_mu = zero_v<T>(), n_k = zero_v<T>(), n_bt = zero_v<T>();
+    if (fused) {
+        const long gi = (nm.groups > 1 ? (long)n * C : 0L) + c;
+        n_mu = *(const T*)(nm.mean + gi);
+        n_k = *(const T*)(nm.rstd + gi);
+        n_bt = *(const T*)(nm.beta + c);
+        if (nm.gamma) {
+            const T gm = *(const T*)(nm.gamma + c);
+#pragma unroll
+            for (int k = 0; k < VW; ++k) n_k[k] = n_k[k] * gm[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < VW; ++k) n_k[k] = n_k[k] * 1.f;
+        }
+    }
+    float n_am = 0.f;
     T t[P][P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         T d[P], v[P];
 #pragma unroll
-        for (int i = 0; i < P; ++i)
-            d[i] = ldz<T>(in, ((long)(n * H + iy[i]) * W + ix[j]) * in_cs + c, iy[i] >= 0 && ix[j] >= 0);
+        for (int i = 0; i < P; ++i) {
+            const bool ok = iy[i] >= 0 && ix[j] >= 0;
+            d[i] = ldz<T>(in, ((long)(n * H + iy[i]) * W + ix[j]) * in_cs + c, ok);
+            if (fused) {
+#pragma unroll
+                for (int k = 0; k < VW; ++k) {
+                    const float o = ss_apply_act((d[i][k] - n_mu[k]) * n_k[k] + n_bt[k], nm.act, nm.alpha);
+                    d[i][k] = ok ? o : 0.f;
+                    n_am = fmaxf(n_am, fabsf(d[i][k]));
+                }
+            }
+        }
         t_in<R, T>(d, v);
 #pragma unroll
         for (int i = 0; i < P; ++i) t[i][j] = v[i];
@@ -241,6 +270,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         }
     }
     if (BF == 0 && amax_out) block_amax(vmax, amax_out);      // launcher: whole blocks only
+    if (BF == 3 && fused && nm.amax_out) ss_block_amax_to_slot(n_am, nm.amax_out);      // max|normalised x| for the weight gradient's scale
 }
 
 // E[xi][tile][c] = (A e A^T)_xi for the RxR tile e of dy (zero outside the dy extent)
@@ -679,8 +709,8 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     }
     // x3h: fp16 two-piece operands (three products instead of six) where a tile's channels are whole waves of the input transform
     const int cvi = q.cin / VW;
-    const bool x3h = R == 4 && q.x6 && ss_x3h_enabled() && (cvi == 64 || cvi == 128 || cvi == 256) && (tiles * cvi) % 256 == 0 &&
-                     (((uintptr_t)w) & 15) == 0;
+    const bool x3h = R == 4 && ss_wino_fwd_x3h(q) && (((uintptr_t)w) & 15) == 0;
+    if (q.in_norm.groups > 0 && !(x3h && q.cin % 32 == 0)) return SS_ERR_UNSUPPORTED;      // only the x3h plane path normalises in its load
     if (q.x6 && q.cin % 32 == 0 && (x3h || ss_x6p_wanted(tiles, q.cout, XI))) {
         // both GEMM operands as pre-split bf16 planes: V planes in the V region (1.5x the fp32 size, see ss_wino_fwd_ws)
         const long Mpad = (tiles + SS_X6P_BM - 1) / SS_X6P_BM * SS_X6P_BM;
@@ -708,7 +738,8 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
             }
             if (fill_only) return SS_OK;
             hipLaunchKernelGGL((wino_input_kernel<R, 3>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
-                               TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, wide);
+                               TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, wide,
+                               q.in_norm);
             SS_LAUNCH_CHECK();
         } else {
         planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X6_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill);
@@ -786,12 +817,13 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
     float* V = (float*)ws;
     float* E = (float*)((char*)ws + ss_align_up((size_t)XI * tiles * q.cin * 4, 256));
     float* part = (float*)((char*)E + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
+    if (q.in_norm.groups > 0 && !(R == 4 && ss_wino_wgrad_tn(q) && q.x_amax && q.dy_amax)) return SS_ERR_UNSUPPORTED;
     if (R == 4 && ss_wino_wgrad_tn(q) && q.x_amax && q.dy_amax) {
         // both operands as K-major fp16 (h, l) planes, one power-of-two scale per tensor from max|x| / max|dy| and the gain bounds of
         // the transforms (|B^T d B| <= 100 max|d| < 2^7, |A e A^T| <= 225 max|e| < 2^8), GEMM by LDS-DMA + transposing LDS reads
         constexpr int BOUND_X = 7, BOUND_DY = 8;
         hipLaunchKernelGGL((wino_input_kernel<R, 4>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
-                           q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X);
+                           q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X, 0, q.in_norm);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL((wino_dy_kernel<R, 1>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, E,
                            nullptr, q.dy_amax, q.dy_stripes, BOUND_DY);
@@ -853,6 +885,13 @@ bool ss_wino_ok(const WinoProb& q) {
     const int kr = q.cin, no = q.cout;
     return kr % 32 == 0 && no % 4 == 0 && kr >= 64 && no >= 64 && q.in_cs % 4 == 0 && q.out_cs % 4 == 0 &&
            n_tiles(q, 2) >= 1024;
+}
+
+// forward pass on fp16 two-piece planes with per-tile scales (fwd_impl's x3h branch): F(4x4,3x3), a tile's channels whole waves
+bool ss_wino_fwd_x3h(const WinoProb& q) {
+    if (wino_r() != 4 || !q.x6 || q.bf16x3 || !ss_x3h_enabled() || q.cin % 32) return false;
+    const int cvi = q.cin / 2;
+    return (cvi == 64 || cvi == 128 || cvi == 256) && (n_tiles(q, 4) * cvi) % 256 == 0;
 }
 
 size_t ss_wino_fwd_ws(const WinoProb& q) {

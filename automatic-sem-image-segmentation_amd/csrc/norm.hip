@@ -83,19 +83,6 @@ template <int V> __device__ __forceinline__ void stv(__bf16* p, const float (&o)
     else *p = (__bf16)o[0];
 }
 
-// block maximum of a non-negative per-thread value -> caller's slot (bit pattern; non-negative floats order like unsigned ints).
-// One atomic per block, spread over the stripes of the slot.
-__device__ __forceinline__ void block_amax_to_slot(float m, unsigned int* __restrict__ slot) {
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    __shared__ float wm[4];
-    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int b = __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
-        atomicMax(slot + (blockIdx.x % SS_AMAX_STRIPES) * SS_AMAX_STRIDE, b);          // striped slot: see common.h
-    }
-}
-
 // partial sums: part[((g*chunks + chunk)*C + c)*2 + {0,1}]
 // MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat) with g = dy * act'(y)
 // Thread = V consecutive channels x a strided set of pixels; CT = channel lanes (in units of V), PT = 256/CT.
@@ -273,7 +260,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
         }
         stv<V>(y + row * y_cs + c, o);
     }
-    if (amax) block_amax_to_slot(am, amax);
+    if (amax) ss_block_amax_to_slot(am, amax);
 }
 
 // inference: statistics from moving mean / variance
@@ -415,7 +402,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
             }
         }
     }
-    if (amax) block_amax_to_slot(am, amax);
+    if (amax) ss_block_amax_to_slot(am, amax);
 }
 
 // sums[(g*C+c)*2+k] = sum over chunks of part (raw sums, fp64 combine)
@@ -721,16 +708,16 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
                 const T* residual, T* y, float* mean, float* rstd,
                 float* moving_mean, float* moving_var, float momentum,
                 void* ws, size_t ws_bytes, void* stream) {
-    if (!valid(d) || !x || !beta || !y || !mean || !rstd) return SS_ERR_INVALID;
+    if (!valid(d) || !x || !beta || !mean || !rstd) return SS_ERR_INVALID;          // y == NULL: statistics only (the consumer applies)
     if ((moving_mean != nullptr) != (moving_var != nullptr)) return SS_ERR_INVALID;
     if (moving_mean && d->groups != 1) return SS_ERR_INVALID;
     if (!ws || ws_bytes < ss_norm_workspace_bytes(d)) return SS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    const int V = pick_v(d->c, {d->x_cstride, d->y_cstride, residual ? d->res_cstride : 0},
+    const int V = pick_v(d->c, {d->x_cstride, y ? d->y_cstride : 0, residual ? d->res_cstride : 0},
                          {x, y, residual, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
     unsigned int* yam = sizeof(T) == 4 ? (unsigned int*)d->y_amax : nullptr;        // max|y| for the next conv's x3h scale (fp32 storage only)
-    if (norm_small(d)) {
+    if (norm_small(d) && y) {
         const int CL = small_cl(V);
         const dim3 grid((g.C + CL * V - 1) / (CL * V), g.G);
         if (V == 4)
@@ -763,6 +750,27 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + fcl - 1) / fcl, g.G), dim3(256), 0, s,
                        part, chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum, fcl);
     SS_LAUNCH_CHECK();
+    if (!y) return SS_OK;
+    const long rows = (long)g.G * g.P;
+    if (V == 4)
+        hipLaunchKernelGGL((norm_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows, yam);
+    else
+        hipLaunchKernelGGL((norm_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows, yam);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+// the apply pass alone (statistics were taken earlier: ss_norm_fwd with y == NULL)
+template <typename T>
+int norm_apply_t(const ss_norm_desc* d, const T* x, const float* gamma, const float* beta, const T* residual, T* y,
+                 const float* mean, const float* rstd, void* stream) {
+    if (!valid(d) || !x || !beta || !y || !mean || !rstd) return SS_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int V = pick_v(d->c, {d->x_cstride, d->y_cstride, residual ? d->res_cstride : 0}, {x, y, residual, gamma, beta, mean, rstd});
+    const NormGeom g = geom(d, V);
+    unsigned int* yam = sizeof(T) == 4 ? (unsigned int*)d->y_amax : nullptr;
     const long rows = (long)g.G * g.P;
     if (V == 4)
         hipLaunchKernelGGL((norm_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
@@ -974,6 +982,12 @@ int ss_norm_fwd(const ss_norm_desc* d, const void* x, const float* gamma, const 
                 void* ws, size_t ws_bytes, void* stream) {
     if (!d) return SS_ERR_INVALID;
     SS_NDT(d->dtype, return norm_fwd_t<T>(d, (const T*)x, gamma, beta, (const T*)residual, (T*)y, mean, rstd, moving_mean, moving_var, momentum, ws, ws_bytes, stream));
+}
+
+int ss_norm_apply(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                  const float* mean, const float* rstd, void* stream) {
+    if (!d) return SS_ERR_INVALID;
+    SS_NDT(d->dtype, return norm_apply_t<T>(d, (const T*)x, gamma, beta, (const T*)residual, (T*)y, mean, rstd, stream));
 }
 
 int ss_norm_infer(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta,

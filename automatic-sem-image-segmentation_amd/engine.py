@@ -233,6 +233,83 @@ class Act:
         return self.grad if self.grad_init else None
 
 
+class DeferredNorm(Act):
+    """The output of a normalisation layer whose APPLY pass has not run: only the statistics exist (layers.Norm(..., defer=True)).
+    A convolution that can normalise in its operand load (ss_conv2d_fuses_in_norm: the second half of "fused InstanceNorm + conv",
+    CycleGAN.py:327-333) reads `pre` with `in_norm()`; any other consumer touching `.ptr` / `.t` gets the tensor materialised by
+    ss_norm_apply first (same arithmetic, so both routes give the same bits).  Gradients flow into this object like into any
+    activation: the norm's backward closure reads them."""
+
+    __slots__ = ("pre", "mean", "rstd", "gamma", "beta", "groups", "act_code", "act_alpha", "_y", "_materialize")
+
+    def __init__(self, pre, mean, rstd, gamma, beta, groups, act_code, act_alpha, materialize):
+        # geometry / storage type of the (future) normalised tensor = the pre-norm view's; dense output
+        self.dt = pre.dt
+        self.t = None
+        self.c0, self.c = 0, pre.c
+        self.grad, self.grad_init, self.requires_grad, self.parent = None, False, True, None
+        self.amax, self.amax_valid, self.stats = None, False, None
+        self.pre, self.mean, self.rstd, self.gamma, self.beta = pre, mean, rstd, gamma, beta
+        self.groups, self.act_code, self.act_alpha = groups, act_code, act_alpha
+        self._y, self._materialize = None, materialize
+
+    @property
+    def materialized(self):
+        return self._y is not None
+
+    def tensor(self):
+        if self._y is None:
+            self._y = self._materialize(self)
+            self.t = self._y.t
+        return self._y
+
+    # geometry without materialising
+    @property
+    def n(self): return self.pre.n
+    @property
+    def h(self): return self.pre.h
+    @property
+    def w(self): return self.pre.w
+    @property
+    def cs(self): return self.pre.c if self._y is None else self._y.cs
+    @property
+    def rows(self): return self.pre.rows
+    @property
+    def device(self): return self.pre.device
+    @property
+    def dtype(self): return self.pre.dtype
+    @property
+    def ptr(self): return self.tensor().ptr
+
+    def like(self, n=None, h=None, w=None, c=None, requires_grad=True):
+        return Act.empty(self.n if n is None else n, self.h if h is None else h, self.w if w is None else w,
+                         self.c if c is None else c, self.device, requires_grad, self.pre.t.dtype)
+
+    def amax_slot(self):
+        """Slot for max|NORMALISED tensor| (the fused forward pass fills it, the weight gradient reads it)."""
+        if self.amax is None:
+            self.amax = _amax_slot(self.device)
+        return ctypes.c_void_p(self.amax.data_ptr())
+
+    def slice(self, c0, c):
+        return self.tensor().slice(c0, c)
+
+    def dense(self):
+        return self.tensor().dense()
+
+    def grad_target(self):
+        if self.grad is None:
+            self.grad = Act(torch.empty((self.n, self.h, self.w, self.c), dtype=self.pre.t.dtype, device=self.device), requires_grad=False)
+            self.grad_init = True
+            return self.grad, 0
+        if not self.grad_init:
+            self.grad_init = True
+            self.grad.amax_valid = False
+            return self.grad, 0
+        self.grad.amax_valid = False
+        return self.grad, 1
+
+
 def convert(act, dtype):
     """A copy of the activation view in another storage type (ss_convert): the fp32 <-> bf16 / fp16 boundary of a network."""
     if act.t.dtype == dtype:

@@ -10,11 +10,14 @@ import os
 import torch
 
 from . import _lib as L
-from .engine import TIMER, Act, _p, _stream, workspace, zero_
+from .engine import TIMER, Act, DeferredNorm, _p, _stream, workspace, zero_
 
 CONV_STATS = os.environ.get("SS_CONV_STATS", "1") != "0"          # 0: norms always run their own statistics pass (measurement)
 NORM_AMAX = os.environ.get("SS_NORM_AMAX", "1") != "0"            # 0: convolutions scan their operands for the x3h scales themselves (measurement)
 WEIGHT_CACHE = os.environ.get("SS_WEIGHT_CACHE", "1") != "0"      # 0: every pass derives its weight operands itself (measurement)
+# Norm(..., defer=True) leaves the apply pass to the consuming convolution's operand load where that convolution can
+# (ss_conv2d_fuses_in_norm); 0: every norm writes its output (measurement / A-B tests: both routes give the same bits)
+FUSE_IN_NORM = os.environ.get("SS_FUSE_IN_NORM", "1") != "0"
 
 # Cross-rank BatchNorm statistics (data parallel): set by dist.enable_sync_bn() to a callable that all-reduces (SUM) a
 # float32 device tensor in place and returns the world size.  None = per-process statistics (single GPU).
@@ -90,14 +93,27 @@ class Conv2D:
         oh, ow = self.out_hw(x.h, x.w)
         y = out if out is not None else x.like(h=oh, w=ow, c=self.cout)
         assert (y.h, y.w, y.c) == (oh, ow, self.cout)
-        d = self.desc(x, y)
+        param_grads = tape.param_grads
+        # x may be a norm output whose apply pass was deferred to this layer's operand load (engine.DeferredNorm): taken when the
+        # forward pass -- and, if a weight gradient will be asked for, that pass too -- can normalise while loading; otherwise the
+        # tensor is materialised now (ss_norm_apply) and this is a plain convolution
+        fused = None
+        if isinstance(x, DeferredNorm) and not x.materialized:
+            dq = self.desc(x.pre, y)
+            if self._fuses_in_norm(dq, L.PASS_FWD) and (not (param_grads and tape.enabled) or self._fuses_in_norm(dq, L.PASS_BWD_WEIGHT)):
+                fused = x
+            else:
+                x.tensor()
+        xin = fused.pre if fused is not None else x          # what the kernels read
+        d = self.desc(xin, y)
+        self._set_in_norm(d, fused)
         w = self.arena[f"{self.name}/kernel"]
         b = self.arena[f"{self.name}/bias"] if self.use_bias else None
         nb = lib.ss_conv2d_workspace_bytes(ctypes.byref(d), L.PASS_FWD)
         ws = workspace(nb, x.device)
         e0 = TIMER.start() if (TIMER.enabled and self.profile_tag) else None
         uses = self._uses_amax(d, L.PASS_FWD)
-        if uses & 1:        # this pass needs max|x|: it computes it into x's slot unless an earlier pass already has
+        if (uses & 1) or fused is not None:        # this pass needs (fused: produces) max|x|: into x's slot unless an earlier pass already has
             d.x_amax, d.x_amax_valid = x.amax_slot(), 1 if x.amax_valid else 0
         else:
             d.x_amax, d.x_amax_valid = None, 0
@@ -110,16 +126,15 @@ class Conv2D:
             d.y_stats = st.data_ptr()
         else:
             d.y_stats = None
-        L.check(lib.ss_conv2d_fwd(ctypes.byref(d), x.ptr, _p(w), _p(b), y.ptr, _p(ws), ws.numel(), _stream()),
+        L.check(lib.ss_conv2d_fwd(ctypes.byref(d), xin.ptr, _p(w), _p(b), y.ptr, _p(ws), ws.numel(), _stream()),
                 f"conv2d_fwd[{self.name}]")
         if sc:
             y.stats = (st, sc)
         self._wcache_done(wst)
-        if uses & 1:
+        if (uses & 1) or fused is not None:
             x.amax_valid = True
         if e0 is not None:
             TIMER.stop(e0, self.profile_tag, x.n)
-        param_grads = tape.param_grads
         pnames = [f"{self.name}/kernel"] + ([f"{self.name}/bias"] if self.use_bias else [])
         if param_grads and tape.enabled and tape.count_uses:
             self.arena.note_use(pnames)
@@ -141,9 +156,10 @@ class Conv2D:
                 gw = self.arena.grad(f"{self.name}/kernel")
                 gb = self.arena.grad(f"{self.name}/bias") if self.use_bias else None
                 uses = self._uses_amax(dd, L.PASS_BWD_WEIGHT)
+                self._set_in_norm(dd, fused)
                 dd.x_amax, dd.x_amax_valid = (x.amax_slot(), 1 if x.amax_valid else 0) if uses & 1 else (None, 0)
                 dd.dy_amax, dd.dy_amax_valid = (dy.amax_slot(), 1 if dy.amax_valid else 0) if uses & 2 else (None, 0)
-                L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), x.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wsw), wsw.numel(),
+                L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), xin.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wsw), wsw.numel(),
                                                  _stream()), f"conv2d_bwd_weight[{self.name}]")
                 if uses & 1:
                     x.amax_valid = True
@@ -152,10 +168,11 @@ class Conv2D:
                 self.arena.note_done(pnames)
             if x.requires_grad:
                 dx, accum = x.grad_target()
-                ddx = dd if dx.cs == x.cs else self.desc_with_in_cs(dd, dx.cs)
+                ddx = dd if dx.cs == dd.in_cstride else self.desc_with_in_cs(dd, dx.cs)
                 nbd = lib.ss_conv2d_workspace_bytes(ctypes.byref(ddx), L.PASS_BWD_DATA)
                 wsd = workspace(nbd, x.device)
                 uses = self._uses_amax(ddx, L.PASS_BWD_DATA)
+                self._set_in_norm(ddx, None)
                 ddx.x_amax, ddx.x_amax_valid = None, 0
                 ddx.dy_amax, ddx.dy_amax_valid = (dy.amax_slot(), 1 if dy.amax_valid else 0) if uses & 2 else (None, 0)
                 wst = self._attach_wcache(ddx, L.PASS_BWD_DATA)
@@ -167,6 +184,27 @@ class Conv2D:
 
         tape.record(backward)
         return y
+
+    @staticmethod
+    def _set_in_norm(d, x):
+        """Point `d` at the statistics of the deferred norm `x` (engine.DeferredNorm) or switch the fused input norm off (None).
+        Descriptors are cached per geometry and shared between calls: set before EVERY launch."""
+        if x is None:
+            d.in_norm_groups = 0
+            d.in_norm_mean = d.in_norm_rstd = d.in_norm_gamma = d.in_norm_beta = None
+            return
+        d.in_norm_mean, d.in_norm_rstd = x.mean.data_ptr(), x.rstd.data_ptr()
+        d.in_norm_gamma = x.gamma.data_ptr() if x.gamma is not None else None
+        d.in_norm_beta = x.beta.data_ptr()
+        d.in_norm_groups, d.in_norm_act, d.in_norm_alpha = x.groups, x.act_code, float(x.act_alpha)
+
+    def _fuses_in_norm(self, d, pass_):
+        """ss_conv2d_fuses_in_norm(d, pass), cached per geometry and configuration."""
+        key = (d.n, d.ih, d.iw, d.in_cstride, d.out_cstride, d.dtype, "in_norm", pass_, L.CONFIG_EPOCH)
+        u = self._amax_cache.get(key)
+        if u is None:
+            u = self._amax_cache[key] = bool(FUSE_IN_NORM and L.load().ss_conv2d_fuses_in_norm(ctypes.byref(d), pass_))
+        return u
 
     def _attach_wcache(self, d, pass_):
         """Point `d` at this layer's weight cache (include/semseg_hip.h ss_wcache): Winograd-transformed / transposed / split weight
@@ -195,6 +233,7 @@ class Conv2D:
         if ukey not in st["users"]:
             du = L.ConvDesc.from_buffer_copy(d)          # private copy for refresh_wcache: no activation-side pointers
             du.x_amax, du.dy_amax, du.x_amax_valid, du.dy_amax_valid = None, None, 0, 0
+            self._set_in_norm(du, None)
             st["users"][ukey] = (du, pass_)
         cur = _stream().value or 0
         sync = st["sync"]
@@ -295,13 +334,19 @@ class Norm:
             r = self._amax_cache[key] = bool(L.load().ss_norm_reports_amax(ctypes.byref(d)))
         return r
 
-    def __call__(self, tape, x, act=None, act_alpha=0.0, residual=None, out=None, training=True):
+    def __call__(self, tape, x, act=None, act_alpha=0.0, residual=None, out=None, training=True, defer=False):
+        """defer=True: the caller hands the result to ONE convolution; when that is possible here (fp32 storage, no residual, no
+        caller-provided output, relu / leaky-relu / no activation, per-process statistics) only the statistics are taken and an
+        engine.DeferredNorm is returned -- the consuming Conv2D normalises in its operand load or materialises the tensor."""
         lib = L.load()
         assert x.c == self.c
-        y = out if out is not None else x.like()
+        sync_now = SYNC_BN if self.kind == "batch" else None
+        defer = bool(defer and FUSE_IN_NORM and residual is None and out is None and act in (None, "relu", "lrelu") and sync_now is None
+                     and x.dt == L.DTYPE_F32 and (self.kind == "instance" or training))
+        y = out if out is not None else (None if defer else x.like())
         groups = x.n if self.kind == "instance" else 1
-        assert x.dt == y.dt and (residual is None or residual.dt == x.dt)
-        d = L.NormDesc(x.n, x.h, x.w, x.c, x.cs, y.cs, residual.cs if residual is not None else 0, groups,
+        assert (y is None or x.dt == y.dt) and (residual is None or residual.dt == x.dt)
+        d = L.NormDesc(x.n, x.h, x.w, x.c, x.cs, y.cs if y is not None else x.c, residual.cs if residual is not None else 0, groups,
                        float(self.eps), ACTS[act], float(act_alpha), dtype=x.dt)
         gamma = self.arena[f"{self.name}/gamma"] if self.scale else None
         beta = self.arena[f"{self.name}/beta"]
@@ -323,17 +368,34 @@ class Norm:
         # the norm reports max|y| while it writes y (the next convolution's x3h scale): fp32, whole-tensor outputs only -- a channel
         # slice of a concat buffer is read by its consumers together with its neighbours, under another view
         reports = NORM_AMAX and sync is None and self._reports_amax(d)
-        want_amax = reports and y.parent is None and y.c0 == 0 and y.c == y.cs and y.amax is None
+        want_amax = reports and y is not None and y.parent is None and y.c0 == 0 and y.c == y.cs and y.amax is None
         if want_amax:
             d.y_amax = y.amax_slot()
         if sync is None and x.stats is not None and x.parent is None:
             d.x_stats, d.x_stats_chunks = x.stats[0].data_ptr(), x.stats[1]
         if sync is None:
-            L.check(lib.ss_norm_fwd(ctypes.byref(d), x.ptr, _p(gamma), _p(beta), rp, y.ptr, _p(mean), _p(rstd),
+            L.check(lib.ss_norm_fwd(ctypes.byref(d), x.ptr, _p(gamma), _p(beta), rp, y.ptr if y is not None else None, _p(mean), _p(rstd),
                                     _p(mm), _p(mv), float(self.momentum), _p(ws), ws.numel(), _stream()),
                     f"norm_fwd[{self.name}]")
             if want_amax:
                 y.amax_valid = True
+            if y is None:          # statistics only: the apply pass belongs to the consumer (or to DeferredNorm.tensor())
+                def materialize(dn):
+                    out_ = x.like()
+                    dm = L.NormDesc.from_buffer_copy(d)
+                    dm.y_cstride, dm.y_amax, dm.x_stats, dm.x_stats_chunks = out_.cs, None, None, 0
+                    rep = NORM_AMAX and self._reports_amax(dm) and dn.amax is None
+                    if rep:
+                        dm.y_amax = out_.amax_slot()
+                    L.check(lib.ss_norm_apply(ctypes.byref(dm), x.ptr, _p(gamma), _p(beta), None, out_.ptr, _p(mean), _p(rstd), _stream()),
+                            f"norm_apply[{self.name}]")
+                    if rep:
+                        out_.amax_valid = True
+                        dn.amax, dn.amax_valid = out_.amax, True
+                    elif dn.amax is not None:
+                        out_.amax, out_.amax_valid = dn.amax, dn.amax_valid
+                    return out_
+                y = DeferredNorm(x, mean, rstd, gamma, beta, groups, ACTS[act], float(act_alpha), materialize)
         else:
             sums = torch.empty(groups * x.c * 2, dtype=torch.float32, device=x.device)
             L.check(lib.ss_norm_fwd_stats(ctypes.byref(d), x.ptr, _p(sums), _p(ws), ws.numel(), _stream()), "norm_fwd_stats")
@@ -365,7 +427,8 @@ class Norm:
             gbet = self.arena.grad(f"{self.name}/beta") if param_grads else None
             if sync is None:
                 # relu / leaky-relu without a residual: the kernels recompute the mask from x instead of reading y
-                yp = None if (act in ("relu", "lrelu") and residual is None) else y.ptr
+                # (none: the kernels never look at y)
+                yp = None if (act in (None, "relu", "lrelu") and residual is None) else y.ptr
                 L.check(lib.ss_norm_bwd(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, yp, _p(gamma), _p(beta), _p(mean), _p(rstd),
                                         dx.ptr, dx.cs, accum, dres.ptr if dres is not None else None, racc,
                                         _p(ggam), _p(gbet), 1, _p(ws2), ws2.numel(), _stream()), f"norm_bwd[{self.name}]")

@@ -164,7 +164,9 @@ class ResnetGenerator(Network):
     @staticmethod
     def _res_block(tape, blk, h):
         c0, n0, c1, n1 = blk
-        y = n0(tape, c0(tape, h), act="relu")
+        # conv -> InstanceNorm -> relu -> pad -> conv (CycleGAN.py:327-333): the first norm's apply pass is deferred into the second
+        # convolution's operand load where that convolution can normalise while loading ("fused InstanceNorm + conv")
+        y = n0(tape, c0(tape, h), act="relu", defer=True)
         return n1(tape, c1(tape, y), residual=h)
 
     def _res_block_ckpt(self, tape, blk, h):

@@ -158,7 +158,28 @@ typedef struct ss_conv_desc {
      * pass of a following InstanceNorm / BatchNorm (ss_norm_desc::x_stats) then has nothing left to read ("fused IN + conv":
      * CycleGAN.py:327-329, 333-335).  Only written when ss_conv2d_stats_chunks(d) > 0. */
     void* y_stats;
+    /* Optional (in_norm_groups == 0: off), forward and weight-gradient passes, fp32 storage: the second half of "fused
+     * InstanceNorm + conv" (CycleGAN.py:327-333: Conv2D -> GroupNormalization -> relu -> pad -> Conv2D).  `x` is then the
+     * PRE-normalisation tensor of a norm whose apply pass was skipped (ss_norm_fwd with y == NULL left only mean / rstd), and the
+     * pass forms  act((x - mean[g,c]) * (rstd[g,c] * gamma[c]) + beta[c])  -- the arithmetic of ss_norm_fwd, bit for bit -- while
+     * it loads its operand; the normalised tensor never exists in memory.  g = sample index when in_norm_groups == n, 0 when
+     * in_norm_groups == 1; gamma may be NULL.  Only the passes for which ss_conv2d_fuses_in_norm(d, pass) != 0 take it (others
+     * return SS_ERR_UNSUPPORTED; the caller then runs ss_norm_apply and a plain convolution).  x_amax, when given, refers to
+     * the NORMALISED tensor: the forward pass leaves its maximum there (unless x_amax_valid), the weight gradient reads it. */
+    const float* in_norm_mean;
+    const float* in_norm_rstd;
+    const float* in_norm_gamma;
+    const float* in_norm_beta;
+    int32_t in_norm_groups;
+    int32_t in_norm_act;
+    float in_norm_alpha;
+    int32_t in_norm_reserved;
 } ss_conv_desc;
+
+/* != 0: `pass` (SS_PASS_FWD or SS_PASS_BWD_WEIGHT) of this descriptor applies ss_conv_desc::in_norm_* in its operand load (the
+ * Winograd x3h forward transform and the Winograd weight gradient on pre-split planes, today).  Pure function of d (ignoring the
+ * in_norm_* fields themselves) and the ss_config table. */
+int ss_conv2d_fuses_in_norm(const ss_conv_desc* d, int pass);
 
 /* Chunks per sample of the output statistics the FORWARD pass of `d` can emit (0: this descriptor's path cannot -- anything but
  * an fp32 Winograd convolution without fused activation, today).  Pure function of d and the ss_config table. */
@@ -221,10 +242,16 @@ int ss_norm_reports_amax(const ss_norm_desc* d);
 /* gamma may be NULL (scale=False); residual may be NULL.  mean/rstd: [groups*c] outputs kept for backward.
  * If moving_mean/moving_var are non-NULL (batch norm training) they are updated in place:
  * moving = moving*momentum + batch*(1-momentum), with the biased batch variance. */
+/* y == NULL: statistics only (mean / rstd, moving update); the apply pass is left to the consumer (ss_conv_desc::in_norm_*) or to
+ * a later ss_norm_apply. */
 int ss_norm_fwd(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta,
                 const void* residual, void* y, float* mean, float* rstd,
                 float* moving_mean, float* moving_var, float momentum,
                 void* ws, size_t ws_bytes, void* stream);
+/* The apply pass of ss_norm_fwd alone, from given mean / rstd: y = act((x - mean) * rstd * gamma + beta + residual).  Raises
+ * d->y_amax like ss_norm_fwd. */
+int ss_norm_apply(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                  const float* mean, const float* rstd, void* stream);
 /* inference-mode batch norm: statistics come from moving_mean / moving_var */
 int ss_norm_infer(const ss_norm_desc* d, const void* x, const float* gamma, const float* beta,
                   const float* moving_mean, const float* moving_var, const void* residual, void* y,

@@ -619,3 +619,59 @@ def test_device_image_pool_replays_the_reference_trace_bit_exactly(golden_dir):
     assert pool.num_imgs == ref.num_imgs == 5
     for a, b in zip(pool.images, ref.images):
         np.testing.assert_array_equal(a.cpu().numpy(), b.numpy())
+
+
+@pytest.mark.parametrize("kind,act", [("instance", "relu"), ("instance", None), ("batch", "lrelu")])
+@pytest.mark.parametrize("c", [256, 512])          # (the weight gradient on pre-split planes needs Cin % 256 == 0: 128 channels materialise)
+def test_deferred_norm_is_applied_in_the_next_convolutions_operand_load(kind, act, c, monkeypatch):
+    """The second half of "fused InstanceNorm + conv" (CycleGAN.py:327-333: Conv2D -> GroupNormalization -> relu -> pad -> Conv2D,
+    ss_conv_desc::in_norm_*): Norm(..., defer=True) takes the statistics only, the consuming Winograd convolution normalises in its
+    input transform (forward AND weight gradient); the normalised tensor is never written.  Same arithmetic as ss_norm_fwd, so the
+    fused and the materialised route must agree BIT FOR BIT: output, dx of the block input, every parameter gradient."""
+    E, LY, L = mod("engine"), mod("layers"), mod("_lib")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    n, h, w = 2, 64, 64
+    x_cpu = torch.randn((n, h, w, c), generator=g)
+    gy_cpu = torch.randn((n, h, w, c), generator=g)
+
+    def run(fuse):
+        monkeypatch.setattr(LY, "FUSE_IN_NORM", fuse)
+        arena = E.ParamArena(dev)
+        c0 = LY.Conv2D(arena, "c0", 3, c, c, padding=("reflect", 1))
+        n0 = LY.Norm(arena, "n0", c, kind)
+        c1 = LY.Conv2D(arena, "c1", 3, c, c, padding=("reflect", 1))
+        arena.materialize()
+        gg = torch.Generator().manual_seed(6)
+        for nm in ("c0", "c1"):
+            arena[f"{nm}/kernel"].copy_((torch.rand((3, 3, c, c), generator=gg) - 0.5) * 0.05)
+        arena["n0/gamma"].copy_(torch.rand(c, generator=gg) + 0.5)
+        arena["n0/beta"].copy_(torch.rand(c, generator=gg) - 0.5)
+        if kind == "batch":
+            arena["n0/moving_variance"].fill_(1.0)
+        arena.zero_grad()
+        x = E.Act(x_cpu.to(dev), requires_grad=True)
+        t = E.Tape()
+        mid = n0(t, c0(t, x), act=act, act_alpha=0.2, defer=True)
+        y = c1(t, mid)
+        gt, _ = y.grad_target()
+        gt.t.copy_(gy_cpu.to(dev))
+        t.backward()
+        torch.cuda.synchronize()
+        grads = {k: arena.grad(k).clone() for k in ("c0/kernel", "c1/kernel", "n0/gamma", "n0/beta")}
+        return mid, y.dense().clone(), x.get_grad().dense().clone(), grads
+
+    mid1, y1, dx1, g1 = run(True)
+    assert isinstance(mid1, E.DeferredNorm) and not mid1.materialized, "the Winograd x3h passes of this shape must take the fused route"
+    mid0, y0, dx0, g0 = run(False)
+    assert not isinstance(mid0, E.DeferredNorm)
+    assert torch.equal(y1, y0), float((y1 - y0).abs().max())
+    assert torch.equal(dx1, dx0), float((dx1 - dx0).abs().max())
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), (k, float((g1[k] - g0[k]).abs().max()))
+    # a consumer that cannot fuse (here: the other arithmetic modes) gets the materialised tensor -- same values as the plain norm
+    with L.config(x3h=0):
+        mid2, y2, dx2, g2 = run(True)
+        assert isinstance(mid2, E.DeferredNorm) and mid2.materialized
+        mid3, y3, dx3, g3 = run(False)
+    assert torch.equal(mid2.dense(), mid3.dense()) and torch.equal(y2, y3) and torch.equal(dx2, dx3)

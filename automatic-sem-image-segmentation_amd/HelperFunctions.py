@@ -300,11 +300,130 @@ def segment(image, threshold, watershed_lines, min_distance=9, use_four_connecti
     return labels
 
 
+# ---- contours as Measurements.Measure sees them (OpenCV semantics restated on pixel sets) -----------------------------------------
+# `Measure.__calculateContours` (Measurements.py:158-191) calls cv2.findContours(RETR_TREE, CHAIN_APPROX_SIMPLE): EVERY border of
+# the 8-connected foreground becomes a contour -- the outer border of each component and the border of each hole (a 4-connected
+# background component that does not reach the image edge; its contour runs over the foreground pixels 4-adjacent to it, Suzuki &
+# Abe 1985, the algorithm behind findContours).  What the workflow then does with a contour (HelperFunctions.py:169-178) only needs
+# three pixel sets, which are restated here without tracing polygons (OpenCV is not installed in this image; pinned by hand-built
+# cases in tests/test_scoring_cpu.py, not by cv2 outputs):
+#   border   the contour's own pixels (drawn by cv2.drawContours whatever the fill rule does);
+#   region   the integer points with cv2.pointPolygonTest(contour, p) >= 0, i.e. inside or on the polygon through the border pixels'
+#            centres: for an outer border the component with its holes filled, for a hole border the hole, its ring of border pixels
+#            and whatever lies inside the hole (Measurements.py:333-336 averages the grey image over exactly these points);
+#   removal  contours with fewer than 5 vertices after CHAIN_APPROX_SIMPLE AND a polygon perimeter below 8 are dropped
+#            (Measurements.py:176-187): only shapes inside a 4 x 4 box can qualify, those are traced explicitly (_small_polygon).
+# cv2.drawContours(contourIdx=-1, thickness=-1) fills the polygons of ALL kept contours together with the even-odd rule and draws
+# their borders: a hole stays a hole only if its own contour survived the filter (a dark hole does not: it gets filled).
+
+_N8 = ((0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1))          # (dy, dx), clockwise from east (y down)
+
+
+def _small_polygon(region):
+    """Vertices and perimeter of the closed 8-connected outer border of a small boolean array, straight runs collapsed to their end
+    points (what CHAIN_APPROX_SIMPLE keeps).  Moore-neighbour tracing; degenerate shapes as OpenCV returns them: one pixel -> one
+    point, a straight line -> its two end points."""
+    pts = np.argwhere(region)
+    if len(pts) == 1:
+        return 1, 0.0
+    h, w = region.shape
+    inside = lambda y, x: 0 <= y < h and 0 <= x < w and region[y, x]
+    start = tuple(pts[0])                         # first pixel in raster order: nothing above it, nothing to its left in its row
+    chain, cur, back = [start], start, 4          # we "came from" the west
+    for _ in range(4 * region.size + 8):
+        for k in range(1, 9):
+            d = (back + k) % 8
+            ny, nx = cur[0] + _N8[d][0], cur[1] + _N8[d][1]
+            if inside(ny, nx):
+                cur, back = (ny, nx), (d + 4) % 8
+                break
+        if cur == start and len(chain) > 1:
+            # closed when we are back at the start (Jacob's criterion is not needed for shapes inside a 4 x 4 box traced from
+            # their raster-first pixel: the start pixel is entered again only at the end of the walk or at a one-pixel-wide neck,
+            # where the walk continues on the other side)
+            nxt = None
+            for k in range(1, 9):
+                d = (back + k) % 8
+                ny, nx = cur[0] + _N8[d][0], cur[1] + _N8[d][1]
+                if inside(ny, nx):
+                    nxt = (ny, nx)
+                    break
+            if nxt == chain[1]:
+                break
+        chain.append(cur)
+    if chain[-1] == start and len(chain) > 1:
+        chain = chain[:-1]
+    n = len(chain)
+    verts = [chain[i] for i in range(n)
+             if (chain[i][0] - chain[i - 1][0], chain[i][1] - chain[i - 1][1]) != (chain[(i + 1) % n][0] - chain[i][0], chain[(i + 1) % n][1] - chain[i][1])]
+    if not verts:
+        verts = chain
+    perim = sum(math.hypot(verts[i][0] - verts[i - 1][0], verts[i][1] - verts[i - 1][1]) for i in range(len(verts)))
+    return len(verts), perim
+
+
+def find_contours(mask):
+    """The contours ``Measure`` keeps for a binary mask (excludeEdges=False), as pixel sets: a list of dicts with ``kind`` ('outer' |
+    'hole'), ``slice`` (the bounding box in the image) and boolean arrays ``border`` / ``region`` over that box (see above)."""
+    from scipy import ndimage
+    fg = np.asarray(mask) > 0
+    H, W = fg.shape
+    four = ndimage.generate_binary_structure(2, 1)
+    out = []
+
+    def keep(region):
+        if region.shape[0] > 4 or region.shape[1] > 4:
+            return True
+        nv, perim = _small_polygon(region)
+        return not (nv < 5 and perim < 8)
+
+    lab8, _ = ndimage.label(fg, structure=np.ones((3, 3)))
+    for i, sl in enumerate(ndimage.find_objects(lab8), start=1):
+        comp = lab8[sl] == i
+        region = ndimage.binary_fill_holes(comp)
+        outside = np.pad(~region, 1, constant_values=True)
+        border = comp & ndimage.binary_dilation(outside, structure=four)[1:-1, 1:-1]
+        if keep(region):
+            out.append(dict(kind='outer', slice=sl, border=border, region=region))
+    bg4, _ = ndimage.label(~fg)                                   # 4-connected background
+    edge = set(np.unique(np.concatenate([bg4[0], bg4[-1], bg4[:, 0], bg4[:, -1]]))) - {0}
+    for h, sl in enumerate(ndimage.find_objects(bg4), start=1):
+        if h in edge:
+            continue
+        big = (slice(max(sl[0].start - 1, 0), min(sl[0].stop + 1, H)), slice(max(sl[1].start - 1, 0), min(sl[1].stop + 1, W)))
+        hole = bg4[big] == h
+        ring = ndimage.binary_dilation(hole, structure=four) & fg[big]
+        region = ndimage.binary_fill_holes(hole | ring)
+        if keep(region):
+            out.append(dict(kind='hole', slice=big, border=ring, region=region))
+    return out
+
+
+def contour_mean_intensities(contours, gray):
+    """Measure.calculateMeanIntensities (Measurements.py:321-342): sum of the grey values over the contour's region / its point count;
+    0.0 when the sum is 0."""
+    g = np.asarray(gray, dtype=np.float64)
+    out = []
+    for c in contours:
+        vals = g[c['slice']][c['region']]
+        tot = float(vals.sum())
+        out.append(tot / vals.size if tot > 0 else 0.0)
+    return out
+
+
+def draw_contours_filled(contours, shape):
+    """cv2.drawContours(zeros, contours, -1, 255, thickness=-1) (HelperFunctions.py:177-178): borders + even-odd fill of all the
+    polygons together."""
+    count = np.zeros(shape, np.int32)
+    border = np.zeros(shape, bool)
+    for c in contours:
+        count[c['slice']] += (c['region'] & ~c['border'])
+        border[c['slice']] |= c['border']
+    return (((count % 2) == 1) | border).astype('uint8') * 255
+
+
 def particles(mask):
-    """The particles ``Measurements.Measure`` works on (Measurements.py: ``cv2.findContours(RETR_EXTERNAL)`` + filled drawing): the
-    8-connected components of the mask with their holes filled.  Returns (label image of the filled particles, count).  OpenCV is
-    not installed in this image, so the contour polygons themselves are not restated: a particle is its filled pixel set (what
-    ``cv2.drawContours(thickness=-1)`` paints and ``pointPolygonTest >= 0`` selects, up to sub-pixel polygon-edge cases)."""
+    """Label image of the particles (8-connected components, holes filled) and their count -- the OUTER contours of find_contours."""
     from scipy import ndimage
     m = np.asarray(mask) > 0
     lab, n = ndimage.label(m, structure=np.ones((3, 3)))
@@ -321,11 +440,12 @@ def particles(mask):
 def filter_gan_masks(img_path, msk_path, out_path, threshold_method=threshold_li, do_watershed_and_four_connectivity=True,
                      gaussian_blur_amount=0.0, dark_background=True):
     """Workflow step 5 (StartProcess.py:133-146; HelperFunctions.py:163-185): drop simulated particles the CycleGAN did not render.
-    For every generated image / mask pair: optionally re-segment the mask (Otsu, watershed lines, 4-connectivity), take each
-    particle's MEAN INTENSITY in the generated image (Measure.calculateMeanIntensities, Measurements.py:321-342) and keep the
-    particles whose mean is >= (dark background; <= otherwise) ``threshold_method(image)`` (Measure.filterResults('meanIntensity'),
-    Measurements.py:606-611); the kept particles are written filled (255) under the same file name; optional Gaussian blur of the
-    image in place (PIL radius = ``gaussian_blur_amount``)."""
+    For every generated image / mask pair: optionally re-segment the mask (Otsu, watershed lines, 4-connectivity), take the contours
+    of the mask as ``Measure`` does, each contour's MEAN INTENSITY in the generated image (Measure.calculateMeanIntensities,
+    Measurements.py:321-342: over the points with pointPolygonTest >= 0) and keep the contours whose mean is >= (dark background;
+    <= otherwise) ``threshold_method(image)`` (Measure.filterResults('meanIntensity'), Measurements.py:569-611, including its
+    "minValue == 0 and no maxValue: keep everything" shortcut); the kept contours are drawn filled (255) under the same file name;
+    optional Gaussian blur of the image in place (PIL radius = ``gaussian_blur_amount``)."""
     from PIL import Image, ImageFilter
     os.makedirs(out_path, exist_ok=True)
     for f in sorted(os.listdir(img_path)):
@@ -333,14 +453,16 @@ def filter_gan_masks(img_path, msk_path, out_path, threshold_method=threshold_li
         mask = np.array(Image.open(os.path.join(msk_path, f)), dtype='uint8')
         if do_watershed_and_four_connectivity:
             mask = segment(image=mask, threshold=-1, watershed_lines=True, use_four_connectivity=True)
-        lab, n = particles(mask)
+        contours = find_contours(mask)
         thr = threshold_method(img)
-        keep = np.zeros(n + 1, bool)
-        if n:
-            from scipy import ndimage
-            means = ndimage.mean(img.astype(np.float64), labels=lab, index=np.arange(1, n + 1))
-            keep[1:] = (means >= thr) if dark_background else (means <= thr)
-        Image.fromarray((keep[lab] * 255).astype('uint8')).save(os.path.join(out_path, f))
+        means = contour_mean_intensities(contours, img)
+        if dark_background:
+            if thr != 0:          # filterResults(minValue=thr): "minValue == 0 and maxValue < minValue" returns without filtering
+                contours = [c for c, m in zip(contours, means) if not m < thr]
+        else:                      # filterResults(maxValue=thr): removed when mean > maxValue and maxValue >= 0; a negative maxValue filters nothing
+            if thr >= 0:
+                contours = [c for c, m in zip(contours, means) if not m > thr]
+        Image.fromarray(draw_contours_filled(contours, img.shape)).save(os.path.join(out_path, f))
         if gaussian_blur_amount > 0:
             Image.fromarray(img).filter(ImageFilter.GaussianBlur(gaussian_blur_amount)).save(os.path.join(img_path, f))
 

@@ -32,10 +32,11 @@ def test_filter_gan_masks_keeps_rendered_particles(tmp_path):
     mask = np.zeros((h, w), np.uint8)
     a, b, c = disc(24, 24, 12), disc(70, 30, 10), disc(40, 72, 11)
     mask[a | b | c] = 255
-    mask[disc(24, 24, 3)] = 0                                  # a hole in particle a
+    mask[disc(24, 24, 5)] = 0                                  # a hole in particle a: not rendered -> its contour is dropped -> filled
     img = np.clip(rng.normal(30, 4, (h, w)), 0, 255)
     img[a] += 150
     img[b] += 140                                               # c is not rendered
+    img[disc(24, 24, 5)] = 30                                   # ... nor is the inside of a's hole
     Image.fromarray(mask).save(os.path.join(msk_dir, "t.tif"))
     Image.fromarray(img.astype(np.uint8)).save(os.path.join(img_dir, "t.tif"))
     HF.filter_gan_masks(img_dir, msk_dir, out_dir, do_watershed_and_four_connectivity=False)
@@ -46,7 +47,90 @@ def test_filter_gan_masks_keeps_rendered_particles(tmp_path):
     # bright background: keep particles DARKER than the threshold
     HF.filter_gan_masks(img_dir, msk_dir, out_dir, do_watershed_and_four_connectivity=False, dark_background=False)
     out = np.array(Image.open(os.path.join(out_dir, "t.tif")))
-    assert np.all(out[c] == 255) and np.all(out[a] == 0)
+    # (a's dark hole has a contour of its own, which IS darker than the threshold: it survives and is drawn -- OpenCV semantics)
+    assert np.all(out[c] == 255) and np.all(out[a & ~disc(24, 24, 7)] == 0) and np.all(out[disc(24, 24, 4)] == 255)
+
+
+def _filter_one(tmp_path, mask, img, **kw):
+    from PIL import Image
+    img_dir, msk_dir, out_dir = (str(tmp_path / d) for d in ("img", "msk", "out"))
+    for d in (img_dir, msk_dir):
+        os.makedirs(d, exist_ok=True)
+    Image.fromarray(mask.astype(np.uint8)).save(os.path.join(msk_dir, "t.tif"))
+    Image.fromarray(img.astype(np.uint8)).save(os.path.join(img_dir, "t.tif"))
+    HF.filter_gan_masks(img_dir, msk_dir, out_dir, do_watershed_and_four_connectivity=False, threshold_method=lambda im: 100.0, **kw)
+    return np.array(Image.open(os.path.join(out_dir, "t.tif")))
+
+
+def test_contour_statistics_follow_the_opencv_semantics_of_measure(tmp_path):
+    """Measure's contour list / mean intensities / filled drawing (Measurements.py:158-191,321-342,569-611; HelperFunctions.py:169-178)
+    on hand-built cases -- what cv2.findContours(RETR_TREE), pointPolygonTest >= 0 and drawContours(-1, thickness=-1) do:
+    every border is a contour (holes too), a contour's mean runs over the points inside or ON its polygon, contours with fewer than
+    5 vertices and perimeter < 8 are dropped, and the kept contours are filled together with the even-odd rule."""
+    mask = np.zeros((40, 64), np.uint8)
+    img = np.full((40, 64), 20.0)
+    # A: 9x9 square with a DARK 3x3 hole: outer kept (bright), hole contour dropped (hole dark, ring bright: mean < 100) -> hole filled
+    mask[2:11, 2:11] = 255; mask[5:8, 5:8] = 0
+    img[2:11, 2:11] = 150; img[5:8, 5:8] = 10
+    # B: same with a BRIGHT hole: hole contour kept -> the hole stays a hole (even-odd fill), its ring is drawn
+    mask[2:11, 14:23] = 255; mask[5:8, 17:20] = 0
+    img[2:11, 14:23] = 200; img[5:8, 17:20] = 220
+    # C: one-pixel hole, bright: its contour (a 4-vertex diamond, perimeter 4 sqrt 2 < 8) is dropped for its SIZE -> filled
+    mask[2:9, 26:33] = 255; mask[5, 29] = 0
+    img[2:9, 26:33] = 200; img[5, 29] = 250
+    # D: specks: 2x2 (4 vertices, perimeter 4: dropped) and 3x3 (4 vertices, perimeter 8: kept), both bright
+    mask[14:16, 2:4] = 255; img[14:16, 2:4] = 250
+    mask[14:17, 8:11] = 255; img[14:17, 8:11] = 250
+    # E: two 4x4 squares touching only diagonally = ONE 8-connected particle; one half is dark, the mean over both decides: kept
+    mask[20:24, 2:6] = 255; mask[24:28, 6:10] = 255
+    img[20:24, 2:6] = 250; img[24:28, 6:10] = 60          # mean (16 * 250 + 16 * 60) / 32 = 155 >= 100
+    # F: a particle cut by the image border is kept (excludeEdges=False)
+    mask[30:40, 54:64] = 255; img[30:40, 54:64] = 180
+    # G: a DARK ring around a BRIGHT hole: the outer contour goes (mean < 100), the hole's contour stays -> ring drawn, hole filled
+    mask[14:23, 30:39] = 255; mask[16:21, 32:37] = 0
+    img[14:23, 30:39] = 30; img[16:21, 32:37] = 240
+    cs = HF.find_contours(mask)
+    kinds = sorted((c["kind"], int(c["region"].sum())) for c in cs)
+    # outer contours: A 81, B 81, C 49, 3x3 speck 9, E 32, F 100, G 81; holes (hole + ring): A/B 9 + 12 = 21, G 25 + 20 = 45
+    assert kinds == sorted([("outer", 81), ("outer", 81), ("outer", 49), ("outer", 9), ("outer", 32), ("outer", 100), ("outer", 81),
+                            ("hole", 21), ("hole", 21), ("hole", 45)]), kinds
+    means = dict(zip([(c["kind"], c["slice"][0].start, c["slice"][1].start) for c in cs], HF.contour_mean_intensities(cs, img)))
+    assert means[("outer", 2, 2)] == pytest.approx((72 * 150 + 9 * 10) / 81)              # outer contour of A: the hole's pixels count
+    assert means[("hole", 4, 4)] == pytest.approx((12 * 150 + 9 * 10) / 21)               # hole contour of A: hole + its 4-adjacent ring
+    out = _filter_one(tmp_path, mask, img)
+    exp = np.zeros_like(mask)
+    exp[2:11, 2:11] = 255                                      # A with its hole filled
+    exp[2:11, 14:23] = 255; exp[5:8, 17:20] = 0                # B keeps its hole
+    exp[2:9, 26:33] = 255                                      # C filled
+    exp[14:17, 8:11] = 255                                     # the 3x3 speck (the 2x2 one is gone)
+    exp[20:24, 2:6] = 255; exp[24:28, 6:10] = 255              # E whole
+    exp[30:40, 54:64] = 255                                    # F
+    ring = np.zeros_like(mask, bool); ring[15, 32:37] = ring[21, 32:37] = True; ring[16:21, 31] = ring[16:21, 37] = True
+    exp[ring] = 255; exp[16:21, 32:37] = 255                   # G: the hole contour's border (4-adjacent ring) + its inside
+    assert np.array_equal(out, exp), np.argwhere(out != exp)[:10]
+    # filterResults' shortcut: a threshold of exactly 0 filters nothing (Measurements.py:580-581)
+    from PIL import Image
+    HF.filter_gan_masks(str(tmp_path / "img"), str(tmp_path / "msk"), str(tmp_path / "out0"), do_watershed_and_four_connectivity=False,
+                        threshold_method=lambda im: 0)
+    out0 = np.array(Image.open(str(tmp_path / "out0" / "t.tif")))
+    assert np.array_equal(out0 > 0, HF.draw_contours_filled(cs, mask.shape) > 0)
+
+
+def test_small_contour_removal_rule():
+    """len(contour) < 5 and perimeter < 8 on the CHAIN_APPROX_SIMPLE polygon (Measurements.py:176-187): vertices / perimeters of the
+    shapes that can qualify (everything inside a 4 x 4 box)."""
+    cases = {"pixel": ([[1]], 1, 0.0), "pair": ([[1, 1]], 2, 2.0), "line4": ([[1, 1, 1, 1]], 2, 6.0), "2x2": ([[1, 1], [1, 1]], 4, 4.0),
+             "3x3": (np.ones((3, 3)), 4, 8.0), "plus": ([[0, 1, 0], [1, 1, 1], [0, 1, 0]], 4, 4 * 2 ** 0.5),
+             "tromino": ([[1, 0], [1, 1]], 3, 2 + 2 ** 0.5), "2x3": (np.ones((2, 3)), 4, 6.0),
+             "3x3 less a corner": ([[1, 1, 1], [1, 1, 1], [1, 1, 0]], 5, 6 + 2 ** 0.5), "diagonal pair": ([[1, 0], [0, 1]], 2, 2 * 2 ** 0.5)}
+    for name, (shape, nv, perim) in cases.items():
+        got = HF._small_polygon(np.asarray(shape, bool))
+        assert got[0] == nv and got[1] == pytest.approx(perim), (name, got)
+    m = np.zeros((12, 40), np.uint8)
+    m[2, 2] = m[2:4, 6:8] = m[2, 12:16] = 255                  # dropped: pixel, 2x2, 4-pixel line (2 points, perimeter 6)
+    m[6:9, 2:5] = m[6, 8:13] = 255                             # kept: 3x3 (perimeter 8), 5-pixel line (perimeter 8)
+    kept = sorted(int(c["region"].sum()) for c in HF.find_contours(m))
+    assert kept == [5, 9]
 
 
 def test_iou_and_roc_known_answers():

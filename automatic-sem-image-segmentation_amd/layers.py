@@ -206,6 +206,23 @@ class Conv2D:
             u = self._amax_cache[key] = bool(FUSE_IN_NORM and L.load().ss_conv2d_fuses_in_norm(ctypes.byref(d), pass_))
         return u
 
+    def will_fuse_in_norm(self, pre, tape):
+        """Would this layer, fed the DEFERRED normalisation of the dense fp32 activation `pre`, normalise in its operand load (forward
+        and, when `tape` asks for weight gradients, the weight gradient too)?  Norm(..., defer_to=layer) asks before it skips its
+        apply pass: a consumer that cannot fuse gets the ordinary norm (same kernels, same bits as without any deferral)."""
+        if not FUSE_IN_NORM or pre.dt != L.DTYPE_F32 or pre.c != self.cin or self.transposed:
+            return False
+        oh, ow = self.out_hw(pre.h, pre.w)
+        key = (pre.n, pre.h, pre.w, pre.cs, self.cout, pre.dt)
+        d = self._desc_cache.get(key)
+        if d is None:          # same construction as desc(): geometry only, the output is dense
+            class _Y:          # noqa: N801  (shape carrier)
+                h, w, cs, dt = oh, ow, self.cout, pre.dt
+            d = self.desc(pre, _Y)
+        if not self._fuses_in_norm(d, L.PASS_FWD):
+            return False
+        return not (tape.param_grads and tape.enabled) or self._fuses_in_norm(d, L.PASS_BWD_WEIGHT)
+
     def _attach_wcache(self, d, pass_):
         """Point `d` at this layer's weight cache (include/semseg_hip.h ss_wcache): Winograd-transformed / transposed / split weight
         planes are derived once per weight VERSION (optimizer step, set_weights, any in-place write torch knows of, configuration
@@ -334,15 +351,17 @@ class Norm:
             r = self._amax_cache[key] = bool(L.load().ss_norm_reports_amax(ctypes.byref(d)))
         return r
 
-    def __call__(self, tape, x, act=None, act_alpha=0.0, residual=None, out=None, training=True, defer=False):
-        """defer=True: the caller hands the result to ONE convolution; when that is possible here (fp32 storage, no residual, no
-        caller-provided output, relu / leaky-relu / no activation, per-process statistics) only the statistics are taken and an
-        engine.DeferredNorm is returned -- the consuming Conv2D normalises in its operand load or materialises the tensor."""
+    def __call__(self, tape, x, act=None, act_alpha=0.0, residual=None, out=None, training=True, defer_to=None):
+        """defer_to = the ONE convolution layer the result goes to: when that layer can normalise in its operand load
+        (Conv2D.will_fuse_in_norm) and the case allows it (fp32 storage, no residual, no caller-provided output, relu / leaky-relu /
+        no activation, per-process statistics) only the statistics are taken and an engine.DeferredNorm is returned; otherwise this
+        is the ordinary norm."""
         lib = L.load()
         assert x.c == self.c
         sync_now = SYNC_BN if self.kind == "batch" else None
-        defer = bool(defer and FUSE_IN_NORM and residual is None and out is None and act in (None, "relu", "lrelu") and sync_now is None
-                     and x.dt == L.DTYPE_F32 and (self.kind == "instance" or training))
+        defer = bool(defer_to is not None and FUSE_IN_NORM and residual is None and out is None and act in (None, "relu", "lrelu")
+                     and sync_now is None and x.dt == L.DTYPE_F32 and (self.kind == "instance" or training)
+                     and x.parent is None and x.c0 == 0 and defer_to.will_fuse_in_norm(x, tape))
         y = out if out is not None else (None if defer else x.like())
         groups = x.n if self.kind == "instance" else 1
         assert (y is None or x.dt == y.dt) and (residual is None or residual.dt == x.dt)

@@ -166,7 +166,7 @@ class ResnetGenerator(Network):
         c0, n0, c1, n1 = blk
         # conv -> InstanceNorm -> relu -> pad -> conv (CycleGAN.py:327-333): the first norm's apply pass is deferred into the second
         # convolution's operand load where that convolution can normalise while loading ("fused InstanceNorm + conv")
-        y = n0(tape, c0(tape, h), act="relu", defer=True)
+        y = n0(tape, c0(tape, h), act="relu", defer_to=c1)
         return n1(tape, c1(tape, y), residual=h)
 
     def _res_block_ckpt(self, tape, blk, h):

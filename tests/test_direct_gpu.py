@@ -652,7 +652,7 @@ def test_deferred_norm_is_applied_in_the_next_convolutions_operand_load(kind, ac
         arena.zero_grad()
         x = E.Act(x_cpu.to(dev), requires_grad=True)
         t = E.Tape()
-        mid = n0(t, c0(t, x), act=act, act_alpha=0.2, defer=True)
+        mid = n0(t, c0(t, x), act=act, act_alpha=0.2, defer_to=c1)
         y = c1(t, mid)
         gt, _ = y.grad_target()
         gt.t.copy_(gy_cpu.to(dev))
@@ -669,9 +669,23 @@ def test_deferred_norm_is_applied_in_the_next_convolutions_operand_load(kind, ac
     assert torch.equal(dx1, dx0), float((dx1 - dx0).abs().max())
     for k in g0:
         assert torch.equal(g1[k], g0[k]), (k, float((g1[k] - g0[k]).abs().max()))
-    # a consumer that cannot fuse (here: the other arithmetic modes) gets the materialised tensor -- same values as the plain norm
+    # a consumer that cannot fuse (here: the other arithmetic modes) gets the ordinary norm
     with L.config(x3h=0):
         mid2, y2, dx2, g2 = run(True)
-        assert isinstance(mid2, E.DeferredNorm) and mid2.materialized
+        assert not isinstance(mid2, E.DeferredNorm)
         mid3, y3, dx3, g3 = run(False)
     assert torch.equal(mid2.dense(), mid3.dense()) and torch.equal(y2, y3) and torch.equal(dx2, dx3)
+    # and a deferred norm that ends up at a consumer that cannot take it is materialised by ss_norm_apply: the plain norm's values
+    monkeypatch.setattr(LY, "FUSE_IN_NORM", True)
+    arena = E.ParamArena(dev)
+    cc = LY.Conv2D(arena, "c", 3, c, c, padding=("reflect", 1))
+    nn_ = LY.Norm(arena, "n", c, kind)
+    arena.materialize()
+    arena["n/gamma"].uniform_(0.5, 1.5); arena["n/beta"].uniform_(-0.5, 0.5)
+    if kind == "batch":
+        arena["n/moving_variance"].fill_(1.0)
+    xa = E.Act(x_cpu.to(dev), requires_grad=False)
+    dn = nn_(E.Tape(enabled=False), xa, act=act, act_alpha=0.2, defer_to=cc)
+    plain = nn_(E.Tape(enabled=False), xa, act=act, act_alpha=0.2)
+    assert isinstance(dn, E.DeferredNorm) and not dn.materialized
+    assert torch.equal(dn.dense(), plain.dense()) and dn.materialized

@@ -1,0 +1,180 @@
+"""End-to-end convergence evidence on SYNTHETIC data (VERDICT r2 missing 1 / next 8): the whole workflow of StartProcess.py -- step 0
+tiling, WGAN-GP on example particle masks, mask simulation, CycleGAN training, fake-image generation + CycleGAN segmentation, mask
+filtering, MultiResUNet training, UNet segmentation -- through the package's driver (StartProcess.Workflow) on the HIP path, scored
+with the publication's metrics (Scoring.py = Calculate_Scores.py) against the ground truth the synthetic images were rendered from.
+
+The reference's data set (CC BY-NC-ND, 40 SEM images + manual masks) cannot be vendored and is not on the GPU box, so this is NOT the
+README's 0.87 / 0.85 IoU table; it shows that training under the x3h arithmetic, the two-chain step and the fused kernels converges
+to a working segmentation, and records the loss curves.
+
+    python tools/convergence_run.py --out gpurun_out/convergence [--cyclegan-epochs 60] [--unet-epochs 30] [--wgan-epochs 200]
+
+Writes <out>/convergence.json (+ .md) and leaves the run directory (logs, models, masks) under <out>/run.
+"""
+import argparse
+import csv
+import glob
+import importlib
+import json
+import os
+import random
+import shutil
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+PKG = "automatic-sem-image-segmentation_amd"
+
+
+def render_scene(rng, h, w, n_particles, r_lo=7, r_hi=13):
+    """Bright particles with a brighter rim on a dark noisy background (the look of secondary-electron SEM images of TiO2
+    agglomerates: edge effect, shot noise); returns (uint8 image, uint8 {0,255} ground-truth mask)."""
+    from scipy import ndimage
+    yy, xx = np.mgrid[0:h, 0:w]
+    mask = np.zeros((h, w), bool)
+    # uneven illumination / charging: a smooth background between 0.05 and 0.45 -- no global threshold separates the classes
+    bg = ndimage.gaussian_filter(rng.normal(0, 1, (h, w)), 40)
+    bg = 0.05 + 0.40 * (bg - bg.min()) / (bg.max() - bg.min())
+    img = bg.copy()
+    for _ in range(n_particles):
+        cy, cx = rng.uniform(0, h), rng.uniform(0, w)
+        a, b = rng.uniform(r_lo, r_hi), rng.uniform(r_lo, r_hi)
+        th = rng.uniform(0, np.pi)
+        u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+        v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        rr = (u / a) ** 2 + (v / b) ** 2
+        inside = rr <= 1.0
+        level = rng.uniform(0.22, 0.34)
+        img[inside] = np.maximum(img[inside], bg[inside] + level + 0.25 * rr[inside] ** 2)          # brighter towards the edge
+        mask |= inside
+    img = ndimage.gaussian_filter(img, 0.8) + rng.normal(0, 0.035, (h, w))
+    return (np.clip(img, 0, 1) * 255).astype(np.uint8), mask.astype(np.uint8) * 255
+
+
+def single_particle_masks(rng, count, size=64):
+    out = []
+    yy, xx = np.mgrid[0:size, 0:size]
+    for _ in range(count):
+        a, b = rng.uniform(9, 20), rng.uniform(9, 20)
+        th = rng.uniform(0, np.pi)
+        u = (xx - size / 2) * np.cos(th) + (yy - size / 2) * np.sin(th)
+        v = -(xx - size / 2) * np.sin(th) + (yy - size / 2) * np.cos(th)
+        out.append((((u / a) ** 2 + (v / b) ** 2) <= 1.0).astype(np.uint8) * 255)
+    return out
+
+
+def read_csv(path, delimiter):
+    with open(path) as f:
+        rows = list(csv.reader(f, delimiter=delimiter))
+    head, body = rows[0], rows[1:]
+    return {k: [float(r[i]) for r in body] for i, k in enumerate(head) if k}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/convergence")
+    ap.add_argument("--tile", type=int, default=128)
+    ap.add_argument("--images", type=int, default=6)
+    ap.add_argument("--masks", type=int, default=96, help="NUM_SIMULATED_MASKS")
+    ap.add_argument("--wgan-epochs", type=int, default=200)
+    ap.add_argument("--cyclegan-epochs", type=int, default=60)
+    ap.add_argument("--cyclegan-filters", type=int, default=32)
+    ap.add_argument("--unet-epochs", type=int, default=30)
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--run-dir", default=None, help="where the workflow tree goes (default: under --out)")
+    a = ap.parse_args()
+    from PIL import Image
+    import torch
+    SP = importlib.import_module(PKG + ".StartProcess")
+    SC = importlib.import_module(PKG + ".Scoring")
+    HF = importlib.import_module(PKG + ".HelperFunctions")
+    rng = np.random.default_rng(a.seed)
+    random.seed(a.seed); np.random.seed(a.seed); torch.manual_seed(a.seed)
+    root = os.path.join(a.run_dir or os.path.abspath(a.out), "run")
+    shutil.rmtree(root, ignore_errors=True)
+    os.makedirs(os.path.join(root, "Input_Images")); os.makedirs(os.path.join(root, "Input_Masks")); os.makedirs(os.path.join(root, "Ground_Truth"))
+    H, W = 3 * a.tile, 4 * a.tile
+    for i in range(a.images):
+        img, gt = render_scene(rng, H, W, int(H * W / 1500))
+        Image.fromarray(img).save(os.path.join(root, "Input_Images", f"scene{i:02d}.tif"))
+        Image.fromarray(gt).save(os.path.join(root, "Ground_Truth", f"scene{i:02d}.tif"))
+    for i, m in enumerate(single_particle_masks(rng, 48)):
+        Image.fromarray(m).save(os.path.join(root, "Input_Masks", f"p{i:02d}.tif"))
+
+    o = SP.WorkflowOptions(ROOT_DIR=root, TILE_SIZE_W=a.tile, TILE_SIZE_H=a.tile, NUM_SIMULATED_MASKS=a.masks, WGAN_EPOCHS=a.wgan_epochs,
+                           WGAN_BATCH_SIZE=64, CYCLEGAN_BATCH_SIZE=4, CYCLEGAN_EPOCHS=a.cyclegan_epochs, CYCLEGAN_FILTERS=a.cyclegan_filters,
+                           UNET_BATCH_SIZE=5, UNET_EPOCHS=a.unet_epochs, USE_DATALOADER=False, RUN_INFERENCE_ON_WHOLE_IMAGE=True,
+                           USE_GPU_FOR_WHOLE_IMAGE_INFERENCE=True, MAX_PARTICLE_OVERLAP=0.3,
+                           MIN_NO_OF_PARTICLES=max(4, a.tile * a.tile // 1800), MAX_NO_OF_PARTICLES=max(8, a.tile * a.tile // 1100))
+    wf = SP.Workflow(o)
+    times = {}
+    for key in wf.ORDER:
+        t0 = time.time()
+        wf.run_step(key)
+        torch.cuda.synchronize()
+        times[key] = round(time.time() - t0, 1)
+        print(f"step {key}: {times[key]} s", flush=True)
+
+    def score(out_dir):
+        ious, inst, youden = [], [], []
+        for gt_path in sorted(glob.glob(os.path.join(root, "Ground_Truth", "*.tif"))):
+            name = os.path.basename(gt_path)
+            cand = os.path.join(out_dir, name)
+            if not os.path.exists(cand):
+                continue
+            pred = np.array(Image.open(cand)) > 127
+            gt = np.array(Image.open(gt_path)) > 127
+            ious.append(float(SC.whole_image_iou(pred, gt)))
+            inst.append(float(SC.instance_iou(pred.astype(np.uint8), gt.astype(np.uint8), 9)))
+            tpr, tnr, fpr, fnr = SC.roc(pred, gt)
+            youden.append(float(tpr + tnr - 1))
+        return dict(images=len(ious), iou_whole=float(np.mean(ious)) if ious else None, iou_instance=float(np.mean(inst)) if inst else None,
+                    youden=float(np.mean(youden)) if youden else None, per_image_iou=[round(v, 4) for v in ious])
+
+    res = dict(settings={k: getattr(o, k) for k in ("TILE_SIZE_W", "NUM_SIMULATED_MASKS", "WGAN_EPOCHS", "CYCLEGAN_EPOCHS", "CYCLEGAN_FILTERS",
+                                                    "CYCLEGAN_BATCH_SIZE", "UNET_EPOCHS", "UNET_BATCH_SIZE", "UNET_FILTERS")},
+               data=f"{a.images} synthetic {H}x{W} scenes rendered from known ellipse masks (tools/convergence_run.py render_scene), 48 example particle masks",
+               step_seconds=times, unet=score(o.OUTPUT_DIR_UNET), cyclegan=score(o.OUTPUT_DIR_CYCLEGAN))
+    # a trivial baseline for scale: Otsu threshold of the raw image
+    base = []
+    for gt_path in sorted(glob.glob(os.path.join(root, "Ground_Truth", "*.tif"))):
+        img = np.array(Image.open(os.path.join(root, "Input_Images", os.path.basename(gt_path))))
+        base.append(float(SC.whole_image_iou(img > HF.threshold_otsu(img), np.array(Image.open(gt_path)) > 127)))
+    res["otsu_of_raw_image_iou_whole"] = float(np.mean(base))
+    logs = {}
+    for name, pat, delim in (("wgan", "1_WGAN/Models/*/training_log.csv", ","), ("cyclegan", "2_CycleGAN/Models/*/training_log.csv", ";"),
+                             ("unet", "3_UNet/Models/*/training_log.csv", ",")):
+        hits = sorted(glob.glob(os.path.join(root, pat)))
+        if hits:
+            try:
+                logs[name] = {k: [round(v, 5) for v in vals] for k, vals in read_csv(hits[-1], delim).items()}
+            except Exception as e:          # noqa: BLE001
+                logs[name] = {"error": repr(e)}
+    res["training_logs_per_epoch"] = logs
+    os.makedirs(a.out, exist_ok=True)
+    with open(os.path.join(a.out, "convergence.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    with open(os.path.join(a.out, "convergence.md"), "w") as f:
+        f.write("# Synthetic end-to-end workflow run (tools/convergence_run.py)\n\n")
+        f.write(f"settings: {json.dumps(res['settings'])}\n\ndata: {res['data']}\n\nstep times (s): {json.dumps(times)}\n\n")
+        f.write("| segmentation | images | IoU (whole image) | IoU (instance) | Youden |\n|---|---|---|---|---|\n")
+        for k in ("unet", "cyclegan"):
+            r = res[k]
+            f.write(f"| {k} | {r['images']} | {r['iou_whole']} | {r['iou_instance']} | {r['youden']} |\n")
+        f.write(f"| Otsu threshold of the raw image (scale) | {len(base)} | {res['otsu_of_raw_image_iou_whole']:.4f} | | |\n\n")
+        for name, lg in logs.items():
+            keys = [k for k in lg if k != "epoch"][:8]
+            f.write(f"## {name}: per-epoch log (first / middle / last epoch)\n\n| metric | first | middle | last |\n|---|---|---|---|\n")
+            for k in keys:
+                v = lg[k]
+                if isinstance(v, list) and v:
+                    f.write(f"| {k} | {v[0]} | {v[len(v) // 2]} | {v[-1]} |\n")
+            f.write("\n")
+    print(json.dumps({k: res[k] for k in ("unet", "cyclegan", "otsu_of_raw_image_iou_whole", "step_seconds")}))
+
+
+if __name__ == "__main__":
+    main()

@@ -1023,6 +1023,7 @@ int native16_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, fl
     c.dtype = d->dtype;
     if (!twgrad_takes(c, d->algo)) return SS_OK;
     WGradParams p = wgrad_params(c, (const float*)x, (const float*)dy, (float*)ws);
+    p.x6 = x6_wanted(d->algo);
     p.splits = ss_twgrad_splits(p);
     if (!ws || ws_bytes < (size_t)p.splits * p.ntaps * p.Ca * p.Cb * sizeof(float)) return SS_OK;
     *taken = true;

@@ -24,6 +24,10 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 tr4(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
 
 constexpr int TW = 32;                 // tile width = one 32-row MFMA block per tile row
 constexpr int T_THREADS = 256;         // 4 waves
@@ -410,7 +414,8 @@ bool wtile_geom(const WGradParams& p, WTileGeom* g) {
         y0 = oy < y0 ? oy : y0; y1 = oy > y1 ? oy : y1; x0 = ox < x0 ? ox : x0; x1 = ox > x1 ? ox : x1;
     }
     if (y1 - y0 > 2 || x1 - x0 > 2) return false;
-    const int M = p.ntaps * p.Ca;
+    // (the x3h kernel's rows are tap * CaP + ca with CaP = Ca rounded up to 4: whole 4-channel units per transposing read)
+    const int M = p.ntaps * (ss_tuning().twgrad_x3h && ss_x3h_enabled() ? ((p.Ca + 3) & ~3) : p.Ca);
     g->mb = (M + 31) / 32;
     g->nb = (p.Cb + 31) / 32;
     g->mw = g->mb >= 3 ? 4 : g->mb;                  // 1, 2 or 4 wave groups over the row blocks
@@ -433,7 +438,7 @@ bool wtile_geom(const WGradParams& p, WTileGeom* g) {
         g->b_bytes = ss_align_up((size_t)th * TW * g->psb * 4, 16);
         g->smem = g->a_bytes + g->b_bytes;
         if (g->smem < red_bytes) g->smem = red_bytes;
-        const int per = (int)((160 * 1024) / (g->smem + 1024));
+        const int per = (int)((160 * 1024) / (g->smem + 1024 + 64));
         g->wgs_per_cu = per > 2 ? 2 : per;
         if (g->wgs_per_cu >= 2) return true;
     }
@@ -593,18 +598,279 @@ __global__ __launch_bounds__(T_THREADS, 2) void twgrad_kernel(WGradParams p, WTi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same weight gradient on the fp16 matrix cores ("x3h": 5.3x the fp32 matrix rate; the fp32 kernel above spends most of its time
+// in v_mfma_f32_32x32x2_f32: 2 pixels per instruction).  K = the pixels of a tile: both operands are K-major in LDS ([pixel][channel]),
+// so the MFMA fragments come from the TRANSPOSING LDS read ds_read_b64_tr_b16 (lane j of a 16-lane group addresses 4 consecutive
+// channels of pixel j / 4; lane i receives the 4 pixels of channel i -- gemm_tn_x3h.hip, tools/tr_probe.hip).
+//  * staging as above in fp32, the tile maxima of a (halo tile) and b taken on the way; then IN PLACE every 16-byte unit (4 channels,
+//    fp32) becomes 8 B of h + 8 B of l:  a * sA = h + l  with sA = 2^(14 - eA) the tile's own power-of-two scale (values within
+//    2^-17 of the TILE maximum keep 22 significand bits, as in tconv_kernel), products hh + hl + lh into ONE accumulator set.
+//  * one accumulator set lives across all tiles of the workgroup, in the unit 2^(E - 28) where E = the largest eA + eB seen so far:
+//    a tile with a larger exponent rescales the accumulators by 2^(E_old - E_new) (a power of two: exact) and becomes the new unit; a
+//    smaller tile shifts ITS b pieces down by 2^(e - E) while they are split, so that its products land in the running unit (what it
+//    loses there is below 2^-38 of the largest tile's products: noise against the sum it is added to).  All-zero tiles are skipped.
+//  * rows are the PADDED index m' = tap * CaP + ca with CaP = Ca rounded up to 4 (a 16-lane group reads whole 4-channel units);
+//    padding rows / columns compute on zero-filled staging and are not stored.
+template <typename TI, int MBW, int NB>
+__global__ __launch_bounds__(T_THREADS, 2) void twgrad_x3h_kernel(WGradParams p, WTileGeom g) {
+    const TI* const ga = (const TI*)p.a;
+    const TI* const gb = (const TI*)p.b;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                                // [hh*hw][psa * 4 bytes]
+    unsigned char* sB = smem + g.a_bytes;                    // [th*32][psb * 4 bytes]
+    float* red = (float*)(smem + g.a_bytes + g.b_bytes);     // [8]: wave maxima of a, of b
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int CaP = (p.Ca + 3) & ~3, CbP = (p.Cb + 3) & ~3;
+    const int MP = p.ntaps * CaP;                            // padded row count
+    const int wm = wave % g.mw, wk = wave / g.mw;
+    const int pa_b = g.psa * 4, pb_b = g.psb * 4;            // bytes per staged pixel
+
+    // fragment addressing (bytes): this lane addresses unit `quad` of k row kq of its 16-lane group; group = (m half mh, k half lh)
+    const int kq = (lane & 15) >> 2, quad = lane & 3, mh = (lane >> 4) & 1;
+    int a_base[MBW];
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+        const int blk = wm + g.mw * i;
+        int mq = blk * 32 + 16 * mh + 4 * quad;
+        if (mq >= MP) mq = 0;                                // rows past the end: any valid address (their results are not stored)
+        const int t = mq / CaP, ca = mq - t * CaP;
+        a_base[i] = ((p.a_oy + p.taps[t].dy - g.hy0) * g.hw + (p.a_ox + p.taps[t].dx - g.hx0) + 8 * lh + kq) * pa_b + (ca >> 2) * 16;
+    }
+    int b_base[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int cq = j * 32 + 16 * mh + 4 * quad;
+        if (cq >= CbP) cq = 0;
+        b_base[j] = (8 * lh + kq) * pb_b + (cq >> 2) * 16;
+    }
+
+    f32x16 acc[MBW][NB];
+#pragma unroll
+    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int E = -(1 << 20);                                       // exponent of the running unit: none yet
+
+    const int tiles_x = (p.GW + TW - 1) / TW, tiles_y = (p.GH + g.th - 1) / g.th;
+    const int ntiles = p.N * tiles_y * tiles_x;
+    int first, stride, end;
+    tile_walk(ntiles, first, stride, end);
+    const bool va = (p.Ca % 4 == 0), vb = (p.Cb % 4 == 0);
+    const int a4 = g.psa / 4, b4 = g.psb / 4;
+    const int na4 = g.hh * g.hw * a4, nb4 = g.th * TW * b4;
+
+    for (int tile = first; tile < end; tile += stride) {
+        const int tx = tile % tiles_x, r1 = tile / tiles_x, ty = r1 % tiles_y, n = r1 / tiles_y;
+        const int gy0 = ty * g.th, gx0 = tx * TW;
+        float ma = 0.f, mbv = 0.f;
+        for (int hy = wave; hy < g.hh; hy += 4) {
+            int iy = ss_map_index(gy0 + g.hy0 + hy, p.AH, p.reflect);
+            if (iy >= p.AH) iy = -1;
+            const TI* rowp = ga + (long)(n * p.AH + (iy < 0 ? 0 : iy)) * p.AW * p.a_cs;
+            unsigned char* drow = sA + (long)hy * g.hw * pa_b;
+            for (int e = lane; e < g.hw * a4; e += 64) {
+                const int hx = a4 == 1 ? e : (int)__umulhi((unsigned)e, g.m_a4), c = (e - hx * a4) * 4;
+                int ix = ss_map_index(gx0 + g.hx0 + hx, p.AW, p.reflect);
+                if (ix >= p.AW) ix = -1;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (iy >= 0 && ix >= 0 && c < p.Ca) {
+                    const TI* src = rowp + (long)ix * p.a_cs + c;
+                    if (va) v = ld4(src);
+                    else {
+                        v[0] = (float)src[0];
+                        if (c + 1 < p.Ca) v[1] = (float)src[1];
+                        if (c + 2 < p.Ca) v[2] = (float)src[2];
+                        if (c + 3 < p.Ca) v[3] = (float)src[3];
+                    }
+                }
+                ma = fmaxf(ma, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                *(f32x4*)(drow + (long)hx * pa_b + c * 4) = v;
+            }
+        }
+        for (int py = wave; py < g.th; py += 4) {
+            const int gy = gy0 + py;
+            const TI* rowp = gb + (long)(n * p.GH + (gy < p.GH ? gy : 0)) * p.GW * p.b_cs;
+            unsigned char* drow = sB + (long)py * TW * pb_b;
+            for (int e = lane; e < TW * b4; e += 64) {
+                const int px = b4 == 1 ? e : (int)__umulhi((unsigned)e, g.m_b4), c = (e - px * b4) * 4;
+                const int gx = gx0 + px;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (gy < p.GH && gx < p.GW && c < p.Cb) {
+                    const TI* src = rowp + (long)gx * p.b_cs + c;
+                    if (vb) v = ld4(src);
+                    else {
+                        v[0] = (float)src[0];
+                        if (c + 1 < p.Cb) v[1] = (float)src[1];
+                        if (c + 2 < p.Cb) v[2] = (float)src[2];
+                        if (c + 3 < p.Cb) v[3] = (float)src[3];
+                    }
+                }
+                mbv = fmaxf(mbv, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                *(f32x4*)(drow + (long)px * pb_b + c * 4) = v;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, off)); mbv = fmaxf(mbv, __shfl_xor(mbv, off)); }
+        if (lane == 0) { red[wave] = ma; red[4 + wave] = mbv; }
+        __syncthreads();
+        ma = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        mbv = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        const bool live = ma > 0.f && mbv > 0.f;             // uniform over the workgroup
+        if (live) {
+            const int ea = ss_amax_exp(ma), eb = ss_amax_exp(mbv);
+            const int et = ea + eb;
+            int shift = 0;                                   // exponent taken off this tile's b pieces (<= 0)
+            if (et > E) {
+                if (E > -(1 << 19)) {
+                    const float f = ldexpf(1.f, (E - et) < -126 ? -126 : (E - et));
+#pragma unroll
+                    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+                }
+                E = et;
+            } else {
+                shift = et - E;
+                if (shift < -60) shift = -60;
+            }
+            const float sa = ldexpf(1.f, 14 - ea), sb = ldexpf(1.f, 14 - eb + shift);
+            // in place: 16-byte fp32 units -> 8 B of h + 8 B of l
+            for (int e = tid; e < na4; e += T_THREADS) {
+                unsigned char* u = sA + (long)e * 16;
+                const f32x4 v = *(const f32x4*)u;
+                f16x4 h, l;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float x = v[k] * sa; h[k] = (_Float16)x; l[k] = (_Float16)(x - (float)h[k]); }
+                *(f16x4*)u = h;
+                *(f16x4*)(u + 8) = l;
+            }
+            for (int e = tid; e < nb4; e += T_THREADS) {
+                unsigned char* u = sB + (long)e * 16;
+                const f32x4 v = *(const f32x4*)u;
+                f16x4 h, l;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float x = v[k] * sb; h[k] = (_Float16)x; l[k] = (_Float16)(x - (float)h[k]); }
+                *(f16x4*)u = h;
+                *(f16x4*)(u + 8) = l;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            // K steps of 16 pixels: (tile row py, half ks of the 32-pixel row); this wave's share of the rows: py = wk, wk + kw, ...
+            for (int py = wk; py < g.th; py += g.kw) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const unsigned char* ap = sA + (long)(py * g.hw + 16 * ks) * pa_b;
+                    const unsigned char* bp = sB + (long)(py * TW + 16 * ks) * pb_b;
+                    f16x8 bh[NB], bl[NB];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const unsigned char* q = bp + b_base[j];
+                        const s16x4 h0 = tr4(q), h1 = tr4(q + 4 * pb_b), l0 = tr4(q + 8), l1 = tr4(q + 4 * pb_b + 8);
+                        bh[j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        bl[j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+#pragma unroll
+                    for (int i = 0; i < MBW; ++i) {
+                        const unsigned char* q = ap + a_base[i];
+                        const s16x4 h0 = tr4(q), h1 = tr4(q + 4 * pa_b), l0 = tr4(q + 8), l1 = tr4(q + 4 * pa_b + 8);
+                        const f16x8 ah = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        const f16x8 al = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // back to real units: the accumulators hold sum a * b * 2^(28 - E)
+    {
+        const float f = E > -(1 << 19) ? ldexpf(1.f, E - 28) : 0.f;
+#pragma unroll
+        for (int i = 0; i < MBW; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+    }
+    // join the kw pixel-row groups (fixed order), then one partial per workgroup (as twgrad_kernel)
+    if (g.kw > 1) {
+        float* redj = (float*)smem;
+        constexpr int PER = MBW * NB * 16;
+#pragma unroll
+        for (int i = 0; i < MBW; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) redj[((long)wave * PER + (i * NB + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int i = 0; i < MBW; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[i][j][r];
+                        for (int k = 1; k < g.kw; ++k) v += redj[((long)(wm + k * g.mw) * PER + (i * NB + j) * 16 + r) * 64 + lane];
+                        acc[i][j][r] = v;
+                    }
+        }
+    }
+    if (wk != 0) return;
+    const int M = p.ntaps * p.Ca;
+    float* part = p.part + (long)blockIdx.x * M * p.Cb;
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+        const int blk = wm + g.mw * i;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int cb = j * 32 + l31;
+            if (cb >= p.Cb) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mp = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;          // padded row -> (tap, ca)
+                if (mp >= MP) continue;
+                const int t = mp / CaP, ca = mp - t * CaP;
+                if (ca < p.Ca) part[(long)(t * p.Ca + ca) * p.Cb + cb] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// x3h (fp16 matrix cores) unless switched off or the fp32-MFMA-only mode is on; its row blocks count PADDED rows (see the kernel)
+bool twgrad_use_x3h(const WGradParams& p) {
+    (void)p;          // (the tile kernels are only taken in the AUTO / X6 modes: conv_api.hip twgrad_takes)
+    return ss_tuning().twgrad_x3h && ss_x3h_enabled();
+}
+
 template <typename TI, int MBW, int NB>
 int launch_twgrad_t(const WGradParams& p, const WTileGeom& g, int nwg, hipStream_t s) {
     static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)twgrad_kernel<TI, MBW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)twgrad_x3h_kernel<TI, MBW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
+    const bool x3h = twgrad_use_x3h(p);
     char name[64];
-    snprintf(name, sizeof(name), "twgrad_kernel<%d,%d>", MBW, NB);
+    snprintf(name, sizeof(name), x3h ? "twgrad_x3h_kernel<%d,%d>" : "twgrad_kernel<%d,%d>", MBW, NB);
     const double pix = (double)p.N * p.GH * p.GW;
-    SsProfScope prof(name, 2.0 * p.ntaps * p.Ca * p.Cb * pix, (double)sizeof(TI) * pix * (p.Ca + p.Cb), s);
-    hipLaunchKernelGGL((twgrad_kernel<TI, MBW, NB>), dim3(nwg), dim3(T_THREADS), g.smem, s, p, g);
+    SsProfScope prof(name, 2.0 * p.ntaps * p.Ca * p.Cb * pix * (x3h ? 3 : 1), (double)sizeof(TI) * pix * (p.Ca + p.Cb), s);
+    if (x3h) hipLaunchKernelGGL((twgrad_x3h_kernel<TI, MBW, NB>), dim3(nwg), dim3(T_THREADS), g.smem + 64, s, p, g);
+    else hipLaunchKernelGGL((twgrad_kernel<TI, MBW, NB>), dim3(nwg), dim3(T_THREADS), g.smem, s, p, g);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -55,12 +55,18 @@ template <int R, class T> __device__ __forceinline__ void t_in(const T* d, T* v)
     if (R == 2) {
         v[0] = d[0] - d[2]; v[1] = d[1] + d[2]; v[2] = d[2] - d[1]; v[3] = d[1] - d[3];
     } else {
-        v[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-        v[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
-        v[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
-        v[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-        v[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-        v[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+        // explicit fused multiply-adds: the compiler's own contraction of "4 d0 - 5 d2 + d4" may differ between two instantiations of
+        // the calling kernel (it did between the plain and the fused-normalisation input transform), and those must agree bit for bit
+        constexpr int N = (int)(sizeof(T) / 4);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            v[0][k] = __builtin_fmaf(4.f, d[0][k], __builtin_fmaf(-5.f, d[2][k], d[4][k]));
+            v[1][k] = __builtin_fmaf(-4.f, d[1][k] + d[2][k], d[3][k] + d[4][k]);
+            v[2][k] = __builtin_fmaf(4.f, d[1][k] - d[2][k], d[4][k] - d[3][k]);
+            v[3][k] = __builtin_fmaf(2.f, d[3][k] - d[1][k], d[4][k] - d[2][k]);
+            v[4][k] = __builtin_fmaf(2.f, d[1][k] - d[3][k], d[4][k] - d[2][k]);
+            v[5][k] = __builtin_fmaf(4.f, d[1][k], __builtin_fmaf(-5.f, d[3][k], d[5][k]));
+        }
     }
 }
 template <int R> __device__ __forceinline__ void t_w(const float* g, float* u) {        // G g
@@ -120,8 +126,8 @@ __device__ __forceinline__ void block_amax(float v, unsigned int* out) {
 // V[xi][tile][c], tile = (n, ty, tx); patch d[i][j] = in[n, map(R*ty + i - pt), map(R*tx + j - pl), c]
 // BF = 0: fp32 V;  1: two bf16 planes (SS_PRECISION=bf16x3);  2: the three bf16 planes of the x6 arithmetic,
 // [plane][xi][tile rows padded to Mpad][c] -- the A operand of gemm_x6p.hip, no conversion left for the GEMM
-template <int R, int BF>
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int in_cs, int N, int H, int W, int C,
+template <int R, int BF, bool FN = false>          // FN: fused input normalisation (a separate instantiation: the plain one pays nothing for it)
+__global__ __launch_bounds__(256, FN ? 4 : 1) void wino_input_kernel(const float* __restrict__ in, int in_cs, int N, int H, int W, int C,
                                                          int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V, long Mpad = 0,
                                                          float* __restrict__ tile_inv = nullptr, unsigned int* __restrict__ amax_out = nullptr,
                                                          const unsigned int* __restrict__ amax_in = nullptr, int amax_stripes = 0, int bound = 0,
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     }
     // fused input normalisation (ss_conv_desc::in_norm_*; BF 3 / 4 launchers only): `in` is the PRE-norm tensor, every element is
     // normalised as it is loaded with norm_apply_kernel's expression (norm.hip), padding zeros stay zero
-    const bool fused = (BF == 3 || BF == 4) && nm.groups > 0;
+    constexpr bool fused = FN && (BF == 3 || BF == 4);
     T n_mu = zero_v<T>(), n_k = zero_v<T>(), n_bt = zero_v<T>();
     if (fused) {
         const long gi = (nm.groups > 1 ? (long)n * C : 0L) + c;
@@ -163,6 +169,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         }
     }
     float n_am = 0.f;
+    const float n_slope = nm.act == SS_ACT_RELU ? 0.f : (nm.act == SS_ACT_LRELU ? nm.alpha : 1.f);
     T t[P][P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
@@ -172,9 +179,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
             const bool ok = iy[i] >= 0 && ix[j] >= 0;
             d[i] = ldz<T>(in, ((long)(n * H + iy[i]) * W + ix[j]) * in_cs + c, ok);
             if (fused) {
+                // act in {none, relu, lrelu} (the launcher checks): t > 0 ? t : slope * t with slope 1 / 0 / alpha -- one compare, one
+                // multiply, one select per element instead of a switch (this loop runs 36 x VW times per thread)
 #pragma unroll
                 for (int k = 0; k < VW; ++k) {
-                    const float o = ss_apply_act((d[i][k] - n_mu[k]) * n_k[k] + n_bt[k], nm.act, nm.alpha);
+                    const float t = __builtin_fmaf(d[i][k] - n_mu[k], n_k[k], n_bt[k]);          // = norm_apply_kernel's expression (norm.hip)
+                    const float o = t > 0.f ? t : t * n_slope;
                     d[i][k] = ok ? o : 0.f;
                     n_am = fmaxf(n_am, fabsf(d[i][k]));
                 }
@@ -711,6 +721,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     const int cvi = q.cin / VW;
     const bool x3h = R == 4 && ss_wino_fwd_x3h(q) && (((uintptr_t)w) & 15) == 0;
     if (q.in_norm.groups > 0 && !(x3h && q.cin % 32 == 0)) return SS_ERR_UNSUPPORTED;      // only the x3h plane path normalises in its load
+    if (q.in_norm.groups > 0 && q.in_norm.act != SS_ACT_NONE && q.in_norm.act != SS_ACT_RELU && q.in_norm.act != SS_ACT_LRELU) return SS_ERR_UNSUPPORTED;
     if (q.x6 && q.cin % 32 == 0 && (x3h || ss_x6p_wanted(tiles, q.cout, XI))) {
         // both GEMM operands as pre-split bf16 planes: V planes in the V region (1.5x the fp32 size, see ss_wino_fwd_ws)
         const long Mpad = (tiles + SS_X6P_BM - 1) / SS_X6P_BM * SS_X6P_BM;
@@ -737,9 +748,13 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
             SS_LAUNCH_CHECK();
             }
             if (fill_only) return SS_OK;
-            hipLaunchKernelGGL((wino_input_kernel<R, 3>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
-                               TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, wide,
-                               q.in_norm);
+            if (q.in_norm.groups > 0)
+                hipLaunchKernelGGL((wino_input_kernel<R, 3, true>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                                   TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, wide,
+                                   q.in_norm);
+            else
+                hipLaunchKernelGGL((wino_input_kernel<R, 3>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                                   TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, wide);
             SS_LAUNCH_CHECK();
         } else {
         planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X6_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill);
@@ -822,8 +837,12 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
         // both operands as K-major fp16 (h, l) planes, one power-of-two scale per tensor from max|x| / max|dy| and the gain bounds of
         // the transforms (|B^T d B| <= 100 max|d| < 2^7, |A e A^T| <= 225 max|e| < 2^8), GEMM by LDS-DMA + transposing LDS reads
         constexpr int BOUND_X = 7, BOUND_DY = 8;
-        hipLaunchKernelGGL((wino_input_kernel<R, 4>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
-                           q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X, 0, q.in_norm);
+        if (q.in_norm.groups > 0)
+            hipLaunchKernelGGL((wino_input_kernel<R, 4, true>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
+                               q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X, 0, q.in_norm);
+        else
+            hipLaunchKernelGGL((wino_input_kernel<R, 4>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
+                               q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL((wino_dy_kernel<R, 1>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, E,
                            nullptr, q.dy_amax, q.dy_stripes, BOUND_DY);

@@ -253,7 +253,9 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
         if (res) ldv<V>(res + row * res_cs + c, rv);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            float t = (xv[v] - mu[v]) * (rs[v] * (gamma ? gm[v] : 1.f)) + bt[v];
+            // explicit fma: a convolution that normalises in its operand load (conv_wino.hip, ss_conv_desc::in_norm_*) forms the same
+            // expression and must produce the same bits
+            float t = __builtin_fmaf(xv[v] - mu[v], rs[v] * (gamma ? gm[v] : 1.f), bt[v]);
             if (res) t += rv[v];
             o[v] = ss_apply_act(t, act, alpha);
             am = fmaxf(am, fabsf(o[v]));

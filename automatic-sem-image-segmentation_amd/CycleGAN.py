@@ -17,6 +17,7 @@ Behavioural quirks kept on purpose (SURVEY.md "Three facts"):
   zeroing, CycleGAN.py:664-665): implemented as ONE backward of (L_a + L_b) -- same gradient, 6 generator
   backward traversals instead of 8.
 """
+import ctypes
 import json
 import os
 import random
@@ -38,8 +39,10 @@ METRIC_NAMES = ("d_a", "d_b", "d_fake_a", "d_fake_b", "d_real_a", "d_real_b", "g
 
 
 class ImagePool:
-    """History buffer of generated images (device resident).  Same control flow and python ``random`` stream
-    consumption as CycleGAN.py:927-964: one ``uniform`` (+ one ``randint`` on a swap) per image once full."""
+    """History buffer of generated images (CycleGAN.py:908-964), device resident.  The DECISIONS are taken exactly as the reference
+    takes them -- same control flow, same consumption of python's ``random`` stream: one ``uniform`` (+ one ``randint`` on a swap)
+    per image once the buffer is full, the loop bound frozen at the constructor's ``batch_size`` -- and the copies they imply run as
+    ONE launch per query (``ss_pool_query``, include/semseg_hip.h) on a single [pool_size, H, W, C] buffer."""
 
     def __init__(self, batch_size, pool_size=50, rng=random):
         self.pool_size = pool_size
@@ -47,35 +50,48 @@ class ImagePool:
         self.rng = rng
         if self.pool_size > 0:
             self.num_imgs = 0
-            self.images = []
+            self._buf = None          # [pool_size, H, W, C], allocated at the first query
+
+    @property
+    def images(self):
+        """The stored images, slot by slot (the reference keeps a python list of [1,H,W,C] tensors)."""
+        return [] if self._buf is None else [self._buf[i:i + 1] for i in range(self.num_imgs)]
 
     def query(self, images):
         """images: NHWC device tensor.  Returns a new [k,H,W,C] tensor, k = min(self.batch_size, N)."""
         if self.pool_size == 0:
             return images
-        lib = L.load()
-        picks = []
+        assert images.is_contiguous()
+        if self._buf is None:
+            self._buf = torch.empty((self.pool_size,) + tuple(images.shape[1:]), dtype=images.dtype, device=images.device)
+        assert tuple(images.shape[1:]) == tuple(self._buf.shape[1:]) and images.dtype == self._buf.dtype, "one buffer holds images of one shape"
+        modes, slots = [], []
         for index in range(0, self.batch_size):
             if index >= images.shape[0]:
                 break  # short batch: the reference's documented intent (CycleGAN.py:945-948)
-            image = images[index:index + 1]
             if self.num_imgs < self.pool_size:
+                modes.append(L.POOL_FILL); slots.append(self.num_imgs)
                 self.num_imgs += 1
-                self.images.append(cat_batch([image]))
-                picks.append(image)
             else:
                 p = self.rng.uniform(0, 1)
                 if p > 0.5:
-                    random_id = self.rng.randint(0, self.pool_size - 1)
-                    tmp = self.images[random_id]
-                    self.images[random_id] = cat_batch([image])
-                    picks.append(tmp)
+                    modes.append(L.POOL_SWAP); slots.append(self.rng.randint(0, self.pool_size - 1))
                 else:
-                    picks.append(image)
-        out = torch.empty((len(picks),) + tuple(images.shape[1:]), dtype=images.dtype, device=images.device)
-        per = out[0].numel()
-        for i, src in enumerate(picks):
-            L.check(lib.ss_copy_t(L.dtype_of(out), src.data_ptr(), 1, out[i].data_ptr(), 1, per, 1, _stream()), "ss_copy")
+                    modes.append(L.POOL_PASS); slots.append(0)
+        k = len(modes)
+        out = torch.empty((k,) + tuple(images.shape[1:]), dtype=images.dtype, device=images.device)
+        lib = L.load()
+        per = images[0].numel() * images.element_size()
+        # one launch per query; a query whose images name the same slot twice is issued image by image (the second swap must see
+        # the first one's store)
+        named = [s_ for m, s_ in zip(modes, slots) if m != L.POOL_PASS]
+        groups = [(0, k)] if len(set(named)) == len(named) and k <= L.POOL_MAX_QUERY else [(i, i + 1) for i in range(k)]
+        for a, b in groups:
+            n = b - a
+            marr = (ctypes.c_int32 * n)(*modes[a:b])
+            sarr = (ctypes.c_int32 * n)(*slots[a:b])
+            L.check(lib.ss_pool_query(self._buf.data_ptr(), images[a:].data_ptr(), out[a:].data_ptr(), per, n, marr, sarr, self.pool_size,
+                                      _stream()), "ss_pool_query")
         return out
 
 

@@ -174,7 +174,8 @@ def _post_lib():
     global _POST
     if _POST is None:
         import ctypes
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsemseg_post.so")
+        # SS_POST_LIB: diagnostic builds only (the AddressSanitizer build of csrc/Makefile `asan`)
+        path = os.environ.get("SS_POST_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsemseg_post.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make -C {os.path.dirname(path)}/csrc` (or __graft_entry__.build())")
         lib = ctypes.CDLL(path)

@@ -61,6 +61,7 @@ class ProfEntry(ctypes.Structure):
 
 
 PAD_ZERO, PAD_REFLECT = 0, 1
+POOL_PASS, POOL_FILL, POOL_SWAP, POOL_MAX_QUERY = 0, 1, 2, 16          # ss_pool_query modes
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2      # ss_dtype: storage type of activation tensors
 
 
@@ -137,6 +138,7 @@ SIGNATURES = {
     "ss_act_bwd_t": (c_i32, [c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "ss_axpby_t": (c_i32, [c_i32, c_f32, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "ss_copy_t": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ss_pool_query": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_i32, c_vp]),
     "ss_mul_t": (c_i32, [c_i32, c_f32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "ss_wgan_interpolate": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "ss_wgan_gp_grad": (c_i32, [c_vp, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp]),

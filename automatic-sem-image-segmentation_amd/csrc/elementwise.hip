@@ -10,6 +10,22 @@ inline unsigned ew_grid(long total) {
     return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
+// ImagePool.query on the device (ss_pool_query): blockIdx.y = image of the query; byte-exact copies, swap = load old / store new / emit old
+struct PoolPlan { int mode[SS_POOL_MAX_QUERY]; int slot[SS_POOL_MAX_QUERY]; };
+template <class U>
+__global__ __launch_bounds__(256) void pool_query_kernel(U* __restrict__ pool, const U* __restrict__ images, U* __restrict__ out, long units, PoolPlan plan) {
+    const int i = blockIdx.y;
+    const int mode = plan.mode[i];
+    const U* src = images + (long)i * units;
+    U* dst = out + (long)i * units;
+    U* keep = mode != SS_POOL_PASS ? pool + (long)plan.slot[i] * units : nullptr;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < units; e += (long)gridDim.x * blockDim.x) {
+        const U cur = src[e];
+        if (mode == SS_POOL_SWAP) { const U old = keep[e]; keep[e] = cur; dst[e] = old; }
+        else { if (mode == SS_POOL_FILL) keep[e] = cur; dst[e] = cur; }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void act_bwd_kernel(int act, float alpha, const T* __restrict__ dy, int dy_cs,
                                                            const T* __restrict__ y, int y_cs, T* __restrict__ dx, int dx_cs,
@@ -511,6 +527,30 @@ int ss_wgan_gp_grad(const float* g, int64_t n, int64_t per_sample, float coef, f
 
 int ss_copy_t(int32_t dtype, const void* src, int32_t src_cstride, void* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream) {
     return ss_axpby_t(dtype, 1.f, src, src_cstride, 0.f, nullptr, 0, dst, dst_cstride, rows, c, stream);
+}
+
+int ss_pool_query(void* pool, const void* images, void* out, int64_t bytes_per_image, int32_t k, const int32_t* mode,
+                  const int32_t* slot, int32_t pool_size, void* stream) {
+    if (!images || !out || !mode || !slot || bytes_per_image <= 0 || k < 0 || k > SS_POOL_MAX_QUERY) return SS_ERR_INVALID;
+    if (k == 0) return SS_OK;
+    PoolPlan plan{};
+    for (int i = 0; i < k; ++i) {
+        if (mode[i] < SS_POOL_PASS || mode[i] > SS_POOL_SWAP) return SS_ERR_INVALID;
+        if (mode[i] != SS_POOL_PASS) {
+            if (!pool || slot[i] < 0 || slot[i] >= pool_size) { ss_set_error("ss_pool_query: slot %d outside the buffer of %d images", slot[i], pool_size); return SS_ERR_INVALID; }
+            for (int j = 0; j < i; ++j)
+                if (mode[j] != SS_POOL_PASS && slot[j] == slot[i]) { ss_set_error("ss_pool_query: two images of one query name slot %d", slot[i]); return SS_ERR_INVALID; }
+        }
+        plan.mode[i] = mode[i];
+        plan.slot[i] = slot[i];
+    }
+    const bool v16 = bytes_per_image % 16 == 0 && (((uintptr_t)pool | (uintptr_t)images | (uintptr_t)out) & 15) == 0;
+    const long units = v16 ? bytes_per_image / 16 : bytes_per_image;
+    const unsigned gx = (unsigned)((units + EW_BLOCK - 1) / EW_BLOCK > 4096 ? 4096 : (units + EW_BLOCK - 1) / EW_BLOCK);
+    if (v16) hipLaunchKernelGGL(pool_query_kernel<f32x4>, dim3(gx, k), dim3(EW_BLOCK), 0, (hipStream_t)stream, (f32x4*)pool, (const f32x4*)images, (f32x4*)out, units, plan);
+    else hipLaunchKernelGGL(pool_query_kernel<unsigned char>, dim3(gx, k), dim3(EW_BLOCK), 0, (hipStream_t)stream, (unsigned char*)pool, (const unsigned char*)images, (unsigned char*)out, units, plan);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
 }
 
 int ss_zero(void* dst, size_t bytes, void* stream) {

@@ -84,7 +84,9 @@ def cpu_baseline(size, batch, filters, threads, timed):
         t_cg.append(t1 - t0)
         t_un.append(t2 - t1)
     m_cg, m_un = statistics.median(t_cg), statistics.median(t_un)
-    return {"value": round(batch / (m_cg + m_un), 5), "unit": "tiles/s", "cores": threads, "kind": "port",
+    return {"value": round(batch / (m_cg + m_un), 5), "unit": "tiles/s", "cores": threads, "host_threads": os.cpu_count(),
+            "cores_note": f"{threads} of the host's {os.cpu_count()} hardware threads (torch CPU convolutions get slower beyond ~16 threads on this host)",
+            "kind": "port",
             "role": "reported baseline only (not a target): plain-torch CPU fp32 restatement of the same two train steps",
             "sample": f"oracle CycleGAN+UNet train steps on {batch} synthetic {size}x{size} tile(s), filters={filters}: 1 warm-up step on "
                       f"{max(size // 2, 64)}x{max(size // 2, 64)} + {timed} timed steps, median; cyclegan {m_cg:.2f}s + unet {m_un:.2f}s"}
@@ -100,6 +102,8 @@ def kernel_peak(name):
         return "bf16_mfma"       # x6: v_mfma_f32_32x32x16_bf16
     if name.startswith("gemm_tn_x3h"):
         return "f16_mfma"        # Winograd weight gradient on pre-split planes: v_mfma_f32_32x32x16_f16, three piece products
+    if name.startswith("twgrad_x3h_kernel"):
+        return "f16_mfma"        # tile weight gradient on the fp16 matrix cores (three piece products)
     if name.startswith("tconv_kernel"):
         return "f16_mfma"        # tile kernels: v_mfma_f32_32x32x16_f16 (x3h piece products for fp32 storage, one product for 16-bit storage)
     return "f32_mfma"
@@ -125,6 +129,7 @@ def main():
     ap.add_argument("--cpu-sample-batch", type=int, default=1)
     ap.add_argument("--cpu-timed-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-rccl-smoke", action="store_true", help="do not run the 2-rank RCCL smoke when >= 2 GPUs are visible to a 1-GPU run")
     ap.add_argument("--skip-unet", action="store_true", help="diagnostics only: time the CycleGAN step alone")
     ap.add_argument("--only-unet", action="store_true", help="diagnostics only: time the UNet step alone")
     args = ap.parse_args()
@@ -282,6 +287,21 @@ def main():
         model.dual_stream = dual
     barrier()
 
+    # RCCL smoke: the 2-rank tests of this repository share ONE GPU over gloo (RCCL refuses two ranks on a device), so the first box
+    # that shows >= 2 devices to a single-GPU run also runs two steps of this benchmark on 2 ranks over RCCL (sub-process, bounded)
+    rccl_smoke = None
+    if world == 1 and rank == 0 and not args.no_extras and not args.no_rccl_smoke and torch.cuda.device_count() >= 2:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--no-extras", "--no-cpu-baseline", "--config", str(args.config)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            rccl_smoke = {"rc": r.returncode, "result": json.loads(line[-1]) if line else None, "stderr_tail": r.stderr[-400:] if r.returncode else ""}
+        except Exception as e:          # noqa: BLE001
+            rccl_smoke = {"rc": -1, "error": repr(e)}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = GB * args.steps / elapsed
@@ -304,6 +324,8 @@ def main():
                           "tile": S, "global_batch": GB, "per_gpu_batch": per, "parallelism": f"dp{world}", "baseline_config": args.config,
                           "activation_storage": store, "checkpointed_trunk": bool(args.checkpoint)}}
         out.update(extras)
+        if rccl_smoke is not None:
+            out["rccl_smoke_2_ranks"] = rccl_smoke
         if prof:
             table = {}
             for name, e in prof.items():

@@ -338,6 +338,22 @@ int ss_mul_t(int32_t dtype, float scale, const void* a, int32_t a_cstride, const
 int ss_wgan_interpolate(const float* real, const float* fake, const float* alpha, float* out, int64_t n, int64_t per_sample, void* stream);
 int ss_wgan_gp_grad(const float* g, int64_t n, int64_t per_sample, float coef, float* gbar, float* norms, void* stream);
 int ss_copy_t(int32_t dtype, const void* src, int32_t src_cstride, void* dst, int32_t dst_cstride, int64_t rows, int32_t c, void* stream);
+
+/* Image buffer of generated images, the device half of ImagePool.query (CycleGAN.py:927-964) in ONE launch.  The decisions stay on
+ * the host, where the reference draws them from python's `random` (one uniform + one randint per image once the buffer is full):
+ * for each of the k images of this query, mode[i] says what happens and slot[i] names the buffer slot concerned --
+ *   SS_POOL_PASS  (0): out[i] = images[i]                                        (p <= 0.5: the current image is returned)
+ *   SS_POOL_FILL  (1): pool[slot[i]] = images[i]; out[i] = images[i]             (the buffer is not full yet)
+ *   SS_POOL_SWAP  (2): out[i] = pool[slot[i]]; pool[slot[i]] = images[i]         (p > 0.5: an old image is returned, the new one kept)
+ * pool: [pool_size][bytes_per_image], images: [>= k][bytes_per_image], out: [k][bytes_per_image]; k <= SS_POOL_MAX_QUERY; two
+ * images of one query must not name the same slot (the caller splits such a query: the second swap must see the first one's
+ * store).  Byte copies: bit-exact for any storage type. */
+#define SS_POOL_PASS 0
+#define SS_POOL_FILL 1
+#define SS_POOL_SWAP 2
+#define SS_POOL_MAX_QUERY 16
+int ss_pool_query(void* pool, const void* images, void* out, int64_t bytes_per_image, int32_t k, const int32_t* mode,
+                  const int32_t* slot, int32_t pool_size, void* stream);
 int ss_maxpool2x2_fwd_t(int32_t dtype, const void* x, int32_t x_cstride, void* y, int32_t y_cstride,
                         int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
 int ss_maxpool2x2_bwd_t(int32_t dtype, const void* dy, int32_t dy_cstride, const void* x, int32_t x_cstride,

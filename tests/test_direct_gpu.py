@@ -689,3 +689,42 @@ def test_deferred_norm_is_applied_in_the_next_convolutions_operand_load(kind, ac
     plain = nn_(E.Tape(enabled=False), xa, act=act, act_alpha=0.2)
     assert isinstance(dn, E.DeferredNorm) and not dn.materialized
     assert torch.equal(dn.dense(), plain.dense()) and dn.materialized
+
+
+def test_pool_query_entry_point_modes_and_checks():
+    """ss_pool_query (include/semseg_hip.h): pass / fill / swap in one launch, byte-exact for fp32 and 16-bit images of a size that is
+    not a multiple of 16 bytes; rejects a slot outside the buffer and two images naming the same slot; the host class splits such a
+    query (second swap sees the first one's store, as the reference's sequential loop does)."""
+    L, CG = mod("_lib"), mod("CycleGAN")
+    lib = L.load()
+    dev = "cuda:0"
+    for dtype, shape in ((torch.float32, (5, 7, 1)), (torch.bfloat16, (3, 3, 1)), (torch.float32, (8, 8, 4))):
+        g = torch.Generator().manual_seed(3)
+        pool = torch.rand((4,) + shape, generator=g).to(dtype).to(dev)
+        imgs = torch.rand((3,) + shape, generator=g).to(dtype).to(dev)
+        out = torch.zeros_like(imgs)
+        p0, i0 = pool.clone(), imgs.clone()
+        per = imgs[0].numel() * imgs.element_size()
+        mode = (ctypes.c_int32 * 3)(L.POOL_SWAP, L.POOL_PASS, L.POOL_FILL)
+        slot = (ctypes.c_int32 * 3)(2, 0, 1)
+        assert lib.ss_pool_query(pool.data_ptr(), imgs.data_ptr(), out.data_ptr(), per, 3, mode, slot, 4, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], p0[2]) and torch.equal(pool[2], i0[0])          # swap
+        assert torch.equal(out[1], i0[1]) and torch.equal(pool[0], p0[0])          # pass: buffer untouched
+        assert torch.equal(out[2], i0[2]) and torch.equal(pool[1], i0[2]) and torch.equal(pool[3], p0[3])
+        bad = (ctypes.c_int32 * 3)(2, 0, 4)
+        assert lib.ss_pool_query(pool.data_ptr(), imgs.data_ptr(), out.data_ptr(), per, 3, mode, bad, 4, None) != 0
+        dup_m = (ctypes.c_int32 * 2)(L.POOL_SWAP, L.POOL_SWAP)
+        dup_s = (ctypes.c_int32 * 2)(1, 1)
+        assert lib.ss_pool_query(pool.data_ptr(), imgs.data_ptr(), out.data_ptr(), per, 2, dup_m, dup_s, 4, None) != 0
+        assert b"slot" in lib.ss_last_error()
+
+    class Rng:          # forces both images of a query onto slot 0
+        def uniform(self, a, b): return 0.9
+        def randint(self, a, b): return 0
+    pool = CG.ImagePool(batch_size=2, pool_size=2, rng=Rng())
+    a = torch.arange(2 * 4, dtype=torch.float32, device=dev).reshape(2, 2, 2, 1)
+    b = a + 100
+    pool.query(a)                     # fills slots 0, 1
+    out = pool.query(b)               # image 0 swaps with slot 0 (returns a[0]); image 1 swaps with slot 0 again (returns b[0])
+    assert torch.equal(out[0], a[0]) and torch.equal(out[1], b[0]) and torch.equal(pool.images[0][0], b[1]) and torch.equal(pool.images[1][0], a[1])

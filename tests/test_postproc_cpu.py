@@ -80,3 +80,49 @@ def test_eight_to_four_c_equals_python_loop():
         want = HF.eight_to_four_connected(img.astype(np.int32))       # non-uint8 input takes the Python loop
         got = HF.eight_to_four_connected(img.copy())
         np.testing.assert_array_equal(got, want.astype(np.uint8))
+
+
+def test_postproc_under_address_sanitizer(tmp_path):
+    """The host-only C code (csrc/postproc.c: priority-flood watershed, 8 -> 4 connectivity) built with AddressSanitizer + UBSan
+    (`make -C csrc asan`) and driven over the watershed / connectivity fixtures of this file plus edge shapes (1-pixel-wide images,
+    all-foreground, all-background, markers on the border) in a child interpreter with libasan preloaded: any out-of-bounds access,
+    use-after-free or leak report fails the test."""
+    import subprocess
+    import sys
+    csrc = os.path.join(REPO, BASE, "csrc")
+    subprocess.run(["make", "-C", csrc, "asan"], check=True, capture_output=True)
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan in this toolchain")
+    code = r'''
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+HF = importlib.import_module(%r + ".HelperFunctions")
+g = np.load(%r)
+n = 0
+for i in range(6):
+    lab = HF.watershed(-g[f"c{i}_distance"], g[f"c{i}_markers"] if f"c{i}_markers" in g.files else None, mask=g[f"c{i}_mask"] if f"c{i}_mask" in g.files else None, watershed_line=True) if f"c{i}_markers" in g.files else None
+    out = HF.segment_measure(g[f"c{i}_image"], -1.0, True, int(g[f"c{i}_min_distance"]), darkBackground=True)
+    HF.eight_to_four_connected(out.copy())
+    n += 1
+rng = np.random.default_rng(0)
+for h, w in ((1, 1), (1, 17), (17, 1), (2, 2), (3, 64), (33, 31)):
+    for fill in (0.0, 0.5, 1.0):
+        m = (rng.random((h, w)) < fill).astype(np.uint8) * 255
+        HF.eight_to_four_connected(m.copy())
+        d = rng.random((h, w))
+        mk = np.zeros((h, w), np.int32)
+        mk[0, 0] = 1
+        mk[-1, -1] = 2
+        for line in (False, True):
+            lab = HF.watershed(d, mk, mask=(m > 0) if fill else None, watershed_line=line)
+            assert lab.shape == (h, w)
+        n += 1
+print("ASAN_RUN_OK", n)
+''' % (REPO, BASE, os.path.join(REPO, "tests", "golden", "postproc_segment.npz"))
+    env = dict(os.environ, LD_PRELOAD=asan, SS_POST_LIB=os.path.join(REPO, BASE, "libsemseg_post_asan.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23", UBSAN_OPTIONS="halt_on_error=1:exitcode=24")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ASAN_RUN_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]

@@ -1,6 +1,8 @@
 """Mixed-precision storage (BASELINE configs 2 and 5): activations and everything saved for backward stored as
 bfloat16 / float16, fp32 master weights, fp32 normalisation statistics, fp32 accumulation; activation checkpointing of the
-generator's residual trunk.  Criterion: outputs / losses against the FP32 oracle with rel-L2 <= 2e-2, reported."""
+generator's residual trunk.  Criterion: outputs / losses against the FP32 oracle with rel-L2 <= 2e-2, reported.  Stated per storage type: fp16
+meets 2e-2 everywhere; bf16 meets it for the CycleGAN metrics but NOT for the MultiResUNet probability map (4e-2 measured, asserted at
+6e-2 and documented as unmet in DESIGN.md section 7: bf16 is supported for memory, fp16 is the 16-bit type that meets the target)."""
 import importlib
 import zlib
 import random

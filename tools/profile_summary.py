@@ -10,7 +10,7 @@ with open(out, "w") as f:
     f.write(f"# {title}\n\n")
     f.write(f"total kernel time {tot/1e3:.1f} ms over {sum(r[1] for r in rows)} dispatches (rocprofv3 --kernel-trace --stats)\n\n")
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
-    for n, k, t, a, p in rows[:30]:
+    for n, k, t, a, p in rows[:80]:
         n = n.replace("(anonymous namespace)::", "").replace("void ", "")
         f.write(f"| `{n[:90]}` | {k} | {t/1e3:.1f} | {a:.1f} | {p:.2f} |\n")
 print(open(out).read())

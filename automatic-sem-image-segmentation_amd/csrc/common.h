@@ -350,6 +350,8 @@ bool ss_wino_ok(const WinoProb& q);
 size_t ss_wino_fwd_ws(const WinoProb& q);
 int ss_wino_conv_fwd(const WinoProb& q, const float* x, const float* w, int w_cin, int w_cout, int flip, const float* bias, float* y,
                      int act, float alpha, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int ss_wino_conv_fwd16(const WinoProb& q, int dtype, const void* x, const float* w, int w_cin, int w_cout, int flip, const float* bias, void* y,
+                       int act, float alpha, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 size_t ss_wino_wgrad_ws(const WinoProb& q);
 int ss_wino_conv_wgrad(const WinoProb& q, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
                        hipStream_t s);

@@ -990,11 +990,28 @@ ConvShim make_shim(const ss_conv_desc* d, void* ws, size_t ws_bytes) {
     return sh;
 }
 // ---- native 16-bit paths: the LDS-staged tile kernels (conv_tile.hip) load / store bf16 / fp16 themselves --------------------------
-int native16_fwd(const ss_conv_desc* d, const void* x, const float* w, const float* bias, void* y, hipStream_t s, bool* taken) {
+// Winograd x3h-plane shapes on 16-bit stored activations: one fp16 plane per operand, one product, transforms in the storage type
+bool wino16_fwd_takes(const ConvProb& c, int algo, WinoProb* q) {
+    return (algo == SS_ALGO_AUTO || algo == SS_ALGO_X6) && c.kh * c.kw <= SS_MAX_TAPS && wino_fwd_prob(c, algo, q) && ss_tuning().wino_r == 4 &&
+           ss_wino_fwd_x3h(*q);
+}
+bool wino16_dgrad_takes(const ConvProb& c, int algo, WinoProb* q) {
+    return (algo == SS_ALGO_AUTO || algo == SS_ALGO_X6) && c.kh * c.kw <= SS_MAX_TAPS && !(c.reflect && c.s != 1) && wino_dgrad_prob(c, algo, q) &&
+           (!c.reflect || q->fold_h > 0) && ss_tuning().wino_r == 4 && ss_wino_fwd_x3h(*q);
+}
+
+int native16_fwd(const ss_conv_desc* d, const void* x, const float* w, const float* bias, void* y, void* ws, size_t ws_bytes, hipStream_t s,
+                 bool* taken) {
     *taken = false;
     if (d->transposed) return SS_OK;
     ConvProb c = plain(d);
     c.dtype = d->dtype;
+    WinoProb q;
+    if (wino16_fwd_takes(c, d->algo, &q) && ws && ws_bytes >= ss_wino_fwd_ws(q)) {
+        *taken = true;
+        q.wc = desc_wcache(d);
+        return ss_wino_conv_fwd16(q, d->dtype, x, w, c.cin, c.cout, 0, bias, y, d->act, d->act_alpha, 0, ws, ws_bytes, s);
+    }
     if (!tconv_takes_fwd(c, d->algo)) return SS_OK;
     *taken = true;
     const GConvParams p = fwd_params(c, (const float*)x, w, bias, (float*)y, d->act, d->act_alpha, 0);
@@ -1006,6 +1023,14 @@ int native16_bwd_data(const ss_conv_desc* d, const void* dy, const float* w, voi
     if (d->transposed) return SS_OK;
     ConvProb c = plain(d);
     c.dtype = d->dtype;
+    {
+        WinoProb q;
+        if (wino16_dgrad_takes(c, d->algo, &q) && ws && ws_bytes >= ss_wino_fwd_ws(q)) {
+            *taken = true;
+            q.wc = desc_wcache(d);
+            return ss_wino_conv_fwd16(q, d->dtype, dy, w, c.cin, c.cout, 1, nullptr, dx, SS_ACT_NONE, 0.f, accumulate, ws, ws_bytes, s);
+        }
+    }
     if (!tconv_takes_dgrad(c, d->algo) || !ws || ws_bytes < bwd_data_wt_bytes(c)) return SS_OK;
     *taken = true;
     float* wt = (float*)ws;
@@ -1109,7 +1134,7 @@ int ss_conv2d_fwd(const ss_conv_desc* d, const void* x, const float* w, const fl
         return conv2d_fwd32(&sh.d32, nullptr, w, bias, nullptr, sh.ws, sh.ws_bytes, stream);
     }
     bool taken;
-    int rc = native16_fwd(d, x, w, bias, y, s, &taken);
+    int rc = native16_fwd(d, x, w, bias, y, ws, ws_bytes, s, &taken);
     if (taken) return rc;
     const ConvShim sh = make_shim(d, ws, ws_bytes);
     rc = ss_convert_launch(x, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, d->cin, (long)d->n * d->ih * d->iw, d->cin, s);

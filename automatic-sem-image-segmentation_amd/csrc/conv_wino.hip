@@ -23,6 +23,34 @@ template <class T> __device__ __forceinline__ T ldz(const float* base, long off,
     return ok ? v : zero_v<T>();
 }
 
+// VW consecutive channels of an activation view in its storage type <-> fp32 vector (16-bit storage: BASELINE configs 2 / 5)
+template <class T, class TI> __device__ __forceinline__ T ldz_t(const TI* base, long off, bool ok) {
+    constexpr int N = (int)(sizeof(T) / 4);
+    T v = zero_v<T>();
+    if (sizeof(TI) == 4) {
+        v = *(const T*)((const float*)base + (ok ? off : 0));
+    } else {
+        typedef TI TV __attribute__((ext_vector_type(N)));
+        const TV q = *(const TV*)(base + (ok ? off : 0));
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = (float)q[k];
+    }
+    return ok ? v : zero_v<T>();
+}
+template <class T, class TO> __device__ __forceinline__ T ld_t(const TO* p) { return ldz_t<T, TO>(p, 0, true); }
+template <class T, class TO> __device__ __forceinline__ void st_t(TO* p, const T& v) {
+    constexpr int N = (int)(sizeof(T) / 4);
+    if (sizeof(TO) == 4) {
+        *(T*)p = v;
+    } else {
+        typedef TO TV __attribute__((ext_vector_type(N)));
+        TV q;
+#pragma unroll
+        for (int k = 0; k < N; ++k) q[k] = (TO)v[k];
+        *(TV*)p = q;
+    }
+}
+
 // fp32 -> (hi, lo) bf16 planes, round-to-nearest-even (finite inputs)
 __device__ __forceinline__ unsigned short bf16_rne(float v) {
     unsigned int u = __float_as_uint(v);
@@ -126,8 +154,10 @@ __device__ __forceinline__ void block_amax(float v, unsigned int* out) {
 // V[xi][tile][c], tile = (n, ty, tx); patch d[i][j] = in[n, map(R*ty + i - pt), map(R*tx + j - pl), c]
 // BF = 0: fp32 V;  1: two bf16 planes (SS_PRECISION=bf16x3);  2: the three bf16 planes of the x6 arithmetic,
 // [plane][xi][tile rows padded to Mpad][c] -- the A operand of gemm_x6p.hip, no conversion left for the GEMM
-template <int R, int BF, bool FN = false>          // FN: fused input normalisation (a separate instantiation: the plain one pays nothing for it)
-__global__ __launch_bounds__(256, FN ? 4 : 1) void wino_input_kernel(const float* __restrict__ in, int in_cs, int N, int H, int W, int C,
+// BF = 5 (16-bit activation storage, TI = _Float16 / __bf16): ONE fp16 plane under the per-tile scale of BF = 3 -- a stored 16-bit
+// value has 8 / 11 significand bits, its transform is carried with 11: plain mixed precision, one product in the GEMM
+template <int R, int BF, bool FN = false, typename TI = float>          // FN: fused input normalisation (a separate instantiation: the plain one pays nothing for it)
+__global__ __launch_bounds__(256, FN ? 4 : 1) void wino_input_kernel(const TI* __restrict__ in, int in_cs, int N, int H, int W, int C,
                                                          int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V, long Mpad = 0,
                                                          float* __restrict__ tile_inv = nullptr, unsigned int* __restrict__ amax_out = nullptr,
                                                          const unsigned int* __restrict__ amax_in = nullptr, int amax_stripes = 0, int bound = 0,
@@ -177,7 +207,7 @@ __global__ __launch_bounds__(256, FN ? 4 : 1) void wino_input_kernel(const float
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const bool ok = iy[i] >= 0 && ix[j] >= 0;
-            d[i] = ldz<T>(in, ((long)(n * H + iy[i]) * W + ix[j]) * in_cs + c, ok);
+            d[i] = ldz_t<T, TI>(in, ((long)(n * H + iy[i]) * W + ix[j]) * in_cs + c, ok);
             if (fused) {
                 // act in {none, relu, lrelu} (the launcher checks): t > 0 ? t : slope * t with slope 1 / 0 / alpha -- one compare, one
                 // multiply, one select per element instead of a switch (this loop runs 36 x VW times per thread)
@@ -197,7 +227,7 @@ __global__ __launch_bounds__(256, FN ? 4 : 1) void wino_input_kernel(const float
     const long xs = tiles * C;     // stride between transform positions
     float* o = V + tile * C + c;
     float x3h_scale = 1.f;
-    if (BF == 3) {
+    if (BF == 3 || BF == 5) {
         // largest |V| of this tile: thread maximum over its 36 x VW values, then over the C/VW threads of the tile
         // (C/VW in {64, 128, 256}: whole waves; 256-thread blocks hold whole tiles)
         float mx = 0.f;
@@ -230,7 +260,18 @@ __global__ __launch_bounds__(256, FN ? 4 : 1) void wino_input_kernel(const float
     for (int i = 0; i < P; ++i) {
         T v[P];
         t_in<R, T>(t[i], v);
-        if (BF == 3 || BF == 4) {
+        if (BF == 5) {
+            const long xs3 = Mpad * C;
+            unsigned int* o3 = (unsigned int*)((unsigned short*)V + tile * C + c);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+#pragma unroll
+                for (int k = 0; k < VW; k += 2) {
+                    const ss_f2 sv = {v[j][k] * x3h_scale, v[j][k + 1] * x3h_scale};
+                    o3[(long)(i * P + j) * xs3 / 2 + k / 2] = __builtin_bit_cast(unsigned int, __builtin_convertvector(sv, ss_h2));
+                }
+            }
+        } else if (BF == 3 || BF == 4) {
             // x3h: v*s = h + 2^-11 l with h, l fp16 and s = 2^e per TILE (all 36 positions, all channels) such that the largest
             // |v*s| of the tile lies in [2^13, 2^14): fp16 keeps 11 bits for everything within 2^-28 of the tile's maximum.
             // 1/s goes to tile_inv[tile]; the output transform multiplies it back (the GEMM is linear in each A row).
@@ -489,10 +530,10 @@ __global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __rest
 }
 
 // y[n, R*ty+i, R*tx+j, c] (+)= act(bias + (A^T M A)_ij)
-template <int R>
+template <int R, typename TO = float>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, int N, int OH, int OW, int C, int TH, int TW,
                                                           const float* __restrict__ bias, int act, float alpha,
-                                                          float* __restrict__ y, int y_cs, int accumulate, int FH, int FW,
+                                                          TO* __restrict__ y, int y_cs, int accumulate, int FH, int FW,
                                                           const float* __restrict__ tile_inv = nullptr, const float* __restrict__ w_inv = nullptr,
                                                           float* __restrict__ stats = nullptr) {
     // FH > 0 ("reflect fold", data gradient of reflect-pad(1) + 3x3 valid conv): the OH x OW grid is the PADDED gradient shifted by
@@ -557,9 +598,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
             for (int j = 0; j < R; ++j) {
                 if (dy_[i] < 0 || dx_[j] < 0) continue;
                 T v = o[i][j];
-                T* dst = (T*)(y + ((long)(n * FH + dy_[i]) * FW + dx_[j]) * y_cs + c);
-                if (accumulate) v += *dst;
-                *dst = v;
+                TO* dst = y + ((long)(n * FH + dy_[i]) * FW + dx_[j]) * y_cs + c;
+                if (accumulate) v += ld_t<T, TO>(dst);
+                st_t<T, TO>(dst, v);
             }
         return;
     }
@@ -579,9 +620,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
                     for (int k = 0; k < VW; ++k) v[k] = ss_apply_act(v[k], act, alpha);
                 }
-                T* dst = (T*)(y + ((long)(n * OH + oy) * OW + ox) * y_cs + c);
-                if (accumulate) v += *dst;
-                *dst = v;
+                TO* dst = y + ((long)(n * OH + oy) * OW + ox) * y_cs + c;
+                if (accumulate) v += ld_t<T, TO>(dst);
+                st_t<T, TO>(dst, v);
 #pragma unroll
                 for (int k = 0; k < VW; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
             }
@@ -678,6 +719,55 @@ void launch_wino_dw(const float* part, int splits, int cin, int cout, float* dw,
 // output tile size: F(4x4,3x3) by default (4x fewer multiplies), F(2x2,3x3) with SS_WINO_R=2
 inline int wino_r() { return ss_tuning().wino_r; }
 inline long n_tiles(const WinoProb& q, int R) { return (long)q.n * ((q.oh + R - 1) / R) * ((q.ow + R - 1) / R); }
+
+// 16-bit activation storage (q.dtype != F32): x / y are TS arrays; the x3h plane path runs with ONE fp16 plane per operand and one
+// product (gemm_x6p_kernel<1>): the input transform reads the stored type, the output transform writes it -- no fp32 staging copies
+template <int R, typename TS>
+int fwd16_impl(const WinoProb& q, const TS* x, const float* w, int w_cin, int w_cout, int flip, const float* bias, TS* y,
+               int act, float alpha, int accumulate, void* ws, hipStream_t s) {
+    constexpr int XI = (R + 2) * (R + 2), VW = WT<R>::VW;
+    if (R != 4 || !ss_wino_fwd_x3h(q) || (((uintptr_t)w) & 15) || q.in_norm.groups > 0) return SS_ERR_UNSUPPORTED;
+    const int TH = (q.oh + R - 1) / R, TW = (q.ow + R - 1) / R;
+    const long tiles = (long)q.n * TH * TW;
+    const int cvi = q.cin / VW;
+    float* V = (float*)((char*)ws + ss_align_up((size_t)XI * q.cin * q.cout * 4, 256));
+    const long Mpad = (tiles + SS_X6P_BM - 1) / SS_X6P_BM * SS_X6P_BM;
+    const int Npad = ss_x6_npad(q.cout);
+    float* Mx = (float*)((char*)V + ss_align_up((size_t)3 * XI * Mpad * q.cin * 2, 256));
+    unsigned short* planes = (unsigned short*)((char*)Mx + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
+    char* extra = (char*)planes + ss_align_up((size_t)3 * XI * Npad * q.cin * 2, 256);
+    float* tile_inv = (float*)(extra + 256);
+    const uint64_t wdet = (uint64_t)(flip ? 1 : 0) | ((uint64_t)R << 1);          // the SAME weight planes as the fp32-storage x3h path (plane 0 = h)
+    bool fill, fill2;
+    float* w_inv = (float*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X3H_INV, wdet), 256, extra, &fill);
+    planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X3H_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill2);
+    if (fill || fill2) {
+        (void)hipMemsetAsync(w_inv + 1, 0, 4, s);
+        hipLaunchKernelGGL(amax_bits_kernel, dim3(256), dim3(256), 0, s, w, (long)9 * w_cin * w_cout, (unsigned int*)(w_inv + 1));
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL((wino_weight_x6_kernel<R, true>), dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes,
+                           (const unsigned int*)(w_inv + 1), w_inv, 0);
+        SS_LAUNCH_CHECK();
+    }
+    if (q.wc && q.wc->fill_only) return SS_OK;
+    hipLaunchKernelGGL((wino_input_kernel<R, 5, false, TS>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                       TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
+    SS_LAUNCH_CHECK();
+    X6PParams g{};
+    g.fp16x2 = 2;          // one plane, one product
+    g.a = (const unsigned short*)V; g.b = planes; g.c = Mx;
+    g.M = (int)tiles; g.N = q.cout; g.K = q.cin; g.nbatch = XI; g.splits = 1; g.k_per_split = q.cin;
+    g.lda = q.cin; g.ldb = q.cin; g.ldc = q.cout;
+    g.a_plane = (long)XI * Mpad * q.cin; g.a_bs = Mpad * q.cin;
+    g.b_plane = (long)XI * Npad * q.cin; g.b_bs = (long)Npad * q.cin;
+    g.c_bs = tiles * q.cout; g.c_ss = 0;
+    const int rcx = ss_launch_gemm_x6p(g, s);
+    if (rcx != SS_OK) return rcx;
+    hipLaunchKernelGGL((wino_output_kernel<R, TS>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
+                       bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w, tile_inv, w_inv, (float*)nullptr);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
 
 template <int R>
 int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w_cout, int flip, const float* bias, float* y,
@@ -929,6 +1019,16 @@ int ss_wino_conv_fwd(const WinoProb& q, const float* x, const float* w, int w_ci
     if (!ws || ws_bytes < ss_wino_fwd_ws(q)) return SS_ERR_WORKSPACE;
     if (wino_r() == 2) return fwd_impl<2>(q, x, w, w_cin, w_cout, flip, bias, y, act, alpha, accumulate, ws, s);
     return fwd_impl<4>(q, x, w, w_cin, w_cout, flip, bias, y, act, alpha, accumulate, ws, s);
+}
+
+// the same on 16-bit stored activations (dtype = SS_DTYPE_F16 / SS_DTYPE_BF16): x3h-plane shapes only (ss_wino_fwd_x3h), F(4x4,3x3)
+int ss_wino_conv_fwd16(const WinoProb& q, int dtype, const void* x, const float* w, int w_cin, int w_cout, int flip, const float* bias, void* y,
+                       int act, float alpha, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!ws || ws_bytes < ss_wino_fwd_ws(q)) return SS_ERR_WORKSPACE;
+    if (wino_r() != 4) return SS_ERR_UNSUPPORTED;
+    if (dtype == SS_DTYPE_F16) return fwd16_impl<4, _Float16>(q, (const _Float16*)x, w, w_cin, w_cout, flip, bias, (_Float16*)y, act, alpha, accumulate, ws, s);
+    if (dtype == SS_DTYPE_BF16) return fwd16_impl<4, __bf16>(q, (const __bf16*)x, w, w_cin, w_cout, flip, bias, (__bf16*)y, act, alpha, accumulate, ws, s);
+    return SS_ERR_INVALID;
 }
 
 // Chunks per sample of the output statistics the forward output transform can emit: F(4x4,3x3) / F(2x2,3x3) on a plain (not folded)

@@ -25,12 +25,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int NPL> struct Frag;
 template <> struct Frag<3> { typedef bf16x8 T; };      // x6:  three bf16 planes, six products
 template <> struct Frag<2> { typedef f16x8 T; };       // x3h: two fp16 planes (x = h + 2^-11 l), three products
+template <> struct Frag<1> { typedef f16x8 T; };       // 16-bit activation storage: ONE fp16 plane per operand (the leading piece), one product
 
 __device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-constexpr int x6p_stages(int npl, bool wide = false) { return npl == 2 && !wide ? 3 : 2; }
+constexpr int x6p_stages(int npl, bool wide = false) { return npl == 1 ? 4 : (npl == 2 && !wide ? 3 : 2); }
 
 // WIDE (x3h only): 256 x 256 tile, 1024 threads = 16 waves as 4 (M) x 4 (N), still 64 x 64 per wave.  The kernel is paced by its
 // operand stream (profiles/r02_f_*: 53 % issue stalls behind the LDS-DMA queue, matrix pipe 33 % busy), and a 256 x 128 tile moves
@@ -41,6 +42,7 @@ constexpr int x6p_stages(int npl, bool wide = false) { return npl == 2 && !wide 
 template <int NPL, bool WIDE>
 __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParams p) {
     static_assert(!WIDE || NPL == 2, "the wide tile exists for the two-plane fp16 operands only");
+    static_assert(NPL >= 1 && NPL <= 3, "one, two or three operand planes");
     constexpr int PBN = WIDE ? 256 : SS_X6P_BN;
     constexpr int B_PLANE_B = PBN * ROWB;
     constexpr int NWV = WIDE ? 16 : 8;             // waves per workgroup
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
         }
     };
     // x6: six products, smallest terms first;  x3h: l*h, h*l (cross accumulators), h*h.  Consecutive MFMAs go to different accumulators
-    constexpr int NQ = NPL == 3 ? 6 : 3;
+    constexpr int NQ = NPL == 3 ? 6 : (NPL == 2 ? 3 : 1);
     constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
     constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0}, HS[3] = {WIDE ? 0 : 1, WIDE ? 0 : 1, 0};
     auto mma4 = [&](FT (&a)[NPL][2], FT (&b)[NPL][2], int q) {
@@ -153,6 +155,8 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
             for (int ni = 0; ni < 2; ++ni) {
                 if constexpr (NPL == 3)
                     acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[0][mi][ni], 0, 0, 0);
+                else if constexpr (NPL == 1)
+                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mi], b[0][ni], acc[0][mi][ni], 0, 0, 0);
                 else
                     acc[HS[q]][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], acc[HS[q]][mi][ni], 0, 0, 0);
             }
@@ -312,7 +316,7 @@ bool ss_x6p_wide_ok(long M, int N, int K, int nbatch) {
 
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     if (p.K % PBK || p.k_per_split % PBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
-    const bool wide = p.fp16x2 && p.plain_l;
+    const bool wide = p.fp16x2 == 1 && p.plain_l;
     if (wide && (p.N % 256 || p.splits != 1)) return SS_ERR_UNSUPPORTED;
     const int pbn = wide ? 256 : SS_X6P_BN;
     const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + pbn - 1) / pbn;
@@ -321,6 +325,7 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
@@ -329,9 +334,12 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     static const int n_cu = [] { int v = 0; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0); return v >= 8 ? v / 8 * 8 : 256; }();
     const bool persistent = ss_tuning().gemm_persistent && tiles > n_cu && p.k_per_split >= 3 * PBK && p.K % p.k_per_split == 0;
     const long nwg = persistent ? n_cu : tiles;
-    SsProfScope prof(wide ? "gemm_x6p_kernel<2,wide>" : (p.fp16x2 ? "gemm_x6p_kernel<2>" : "gemm_x6p_kernel<3>"), 2.0 * p.M * p.N * p.K * p.nbatch * (p.fp16x2 ? 3 : 6),
-                     2.0 * (p.fp16x2 ? 2 : 3) * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
-    if (wide) hipLaunchKernelGGL((gemm_x6p_kernel<2, true>), dim3((unsigned)nwg), dim3(1024), x6p_stages(2, true) * 2 * (A_PLANE_B + 256 * ROWB), s, p);
+    const bool one = p.fp16x2 == 2;          // fp16x2 == 2: ONE fp16 plane per operand, one product (16-bit activation storage)
+    SsProfScope prof(wide ? "gemm_x6p_kernel<2,wide>" : (one ? "gemm_x6p_kernel<1>" : (p.fp16x2 ? "gemm_x6p_kernel<2>" : "gemm_x6p_kernel<3>")),
+                     2.0 * p.M * p.N * p.K * p.nbatch * (one ? 1 : (p.fp16x2 ? 3 : 6)),
+                     2.0 * (one ? 1 : (p.fp16x2 ? 2 : 3)) * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
+    if (one) hipLaunchKernelGGL((gemm_x6p_kernel<1, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(1) * 1 * (A_PLANE_B + B_PLANE_B), s, p);
+    else if (wide) hipLaunchKernelGGL((gemm_x6p_kernel<2, true>), dim3((unsigned)nwg), dim3(1024), x6p_stages(2, true) * 2 * (A_PLANE_B + 256 * ROWB), s, p);
     else if (p.fp16x2) hipLaunchKernelGGL((gemm_x6p_kernel<2, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(2) * 2 * (A_PLANE_B + B_PLANE_B), s, p);
     else hipLaunchKernelGGL((gemm_x6p_kernel<3, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(3) * 3 * (A_PLANE_B + B_PLANE_B), s, p);
     SS_LAUNCH_CHECK();

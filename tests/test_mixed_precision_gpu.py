@@ -33,7 +33,11 @@ CONV_CASES = [
     # name, k, cin, cout, stride, padding, bias, transposed, n, h, w
     ("tile_native_3x3_16_16", 3, 16, 16, 1, "same", False, False, 1, 256, 256),      # conv_tile.hip, native 16-bit loads / stores
     ("tile_native_1x1_25_51_bias", 1, 25, 51, 1, "same", True, False, 1, 256, 256),
-    ("trunk_wino_reflect", 3, 128, 128, 1, ("reflect", 1), False, False, 2, 48, 48),  # fp32 staging around the Winograd path
+    # Winograd x3h-plane shapes: native 16-bit transforms, ONE fp16 plane per operand, one product (gemm_x6p_kernel<1>); the weight
+    # gradient still runs on fp32 staging copies
+    ("trunk_wino_reflect", 3, 128, 128, 1, ("reflect", 1), False, False, 2, 48, 48),
+    ("trunk_wino_512_reflect", 3, 512, 512, 1, ("reflect", 1), False, False, 2, 64, 64),
+    ("wino_same_256", 3, 256, 256, 1, "same", False, False, 2, 32, 32),
     ("down_s2", 3, 32, 64, 2, "same", False, False, 2, 64, 64),
     ("up_T3", 3, 64, 32, 2, "same", False, True, 2, 32, 32),
     ("stem7_reflect", 7, 1, 16, 1, ("reflect", 3), False, False, 1, 64, 64),
@@ -86,7 +90,8 @@ def test_conv_16bit_storage_vs_fp32_oracle(case, dt):
     e_dw = rel_l2(arena.grad("c/kernel").cpu(), wr.grad)
     print(f"{name}/{dt}: rel-L2 y={e_y:.2e} dx={e_dx:.2e} dw={e_dw:.2e}")
     # one rounding to the storage type per output element: 2^-9 (bf16) / 2^-12 (fp16) relative, far inside 2e-2
-    tol = 6e-3 if dt == "bf16" else 1e-3
+    # (the one-product Winograd path also rounds the TRANSFORMED operands to fp16's 11 bits: 2e-3 instead of 1e-3 there)
+    tol = 6e-3 if dt == "bf16" else (2e-3 if "wino" in name else 1e-3)
     assert e_y <= tol and e_dx <= tol, (e_y, e_dx)
     assert e_dw <= 1e-3, e_dw           # fp32 weight gradient of exactly representable operands
     if bias:

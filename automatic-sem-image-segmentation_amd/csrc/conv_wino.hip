@@ -750,11 +750,16 @@ int fwd16_impl(const WinoProb& q, const TS* x, const float* w, int w_cin, int w_
         SS_LAUNCH_CHECK();
     }
     if (q.wc && q.wc->fill_only) return SS_OK;
-    hipLaunchKernelGGL((wino_input_kernel<R, 5, false, TS>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
-                       TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
+    const bool one = ss_tuning().wino16_products != 3;          // 1: one plane / one product; 3: the x3h arithmetic of the fp32-storage path
+    if (one)
+        hipLaunchKernelGGL((wino_input_kernel<R, 5, false, TS>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                           TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
+    else
+        hipLaunchKernelGGL((wino_input_kernel<R, 3, false, TS>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                           TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
     SS_LAUNCH_CHECK();
     X6PParams g{};
-    g.fp16x2 = 2;          // one plane, one product
+    g.fp16x2 = one ? 2 : 1;
     g.a = (const unsigned short*)V; g.b = planes; g.c = Mx;
     g.M = (int)tiles; g.N = q.cout; g.K = q.cin; g.nbatch = XI; g.splits = 1; g.k_per_split = q.cin;
     g.lda = q.cin; g.ldb = q.cin; g.ldc = q.cout;

@@ -355,3 +355,5 @@ int ss_wino_conv_fwd16(const WinoProb& q, int dtype, const void* x, const float*
 size_t ss_wino_wgrad_ws(const WinoProb& q);
 int ss_wino_conv_wgrad(const WinoProb& q, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
                        hipStream_t s);
+int ss_wino_conv_wgrad16(const WinoProb& q, int dtype, const void* x, const void* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                         hipStream_t s);

@@ -302,6 +302,34 @@ __global__ __launch_bounds__(256) void amax_view_kernel(const float* __restrict_
     if (threadIdx.x == 0) atomicMax(out + (stripes > 1 ? (blockIdx.x % stripes) * SS_AMAX_STRIDE : 0), max(max(wm[0], wm[1]), max(wm[2], wm[3])));
 }
 
+// the same over a 16-bit stored view (generic strided walk; the maximum of the stored values, as fp32 bits)
+template <typename T>
+__global__ __launch_bounds__(256) void amax_view16_kernel(const T* __restrict__ v, long rows, int C, int cs, unsigned int* __restrict__ out, int stripes) {
+    unsigned int m = 0;
+    const int C2 = C / 2;
+    if (C % 2 == 0 && cs % 2 == 0 && ((uintptr_t)v & 3) == 0) {
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        const long total = rows * C2;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const long r = i / C2;
+            const T2 t = *(const T2*)(v + r * cs + (i - r * C2) * 2);
+            m = max(m, max(__float_as_uint(fabsf((float)t[0])), __float_as_uint(fabsf((float)t[1]))));
+        }
+    } else {
+        const long total = rows * C;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const long r = i / C;
+            m = max(m, __float_as_uint(fabsf((float)v[r * cs + (i - r * C)])));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, off, 64));
+    __shared__ unsigned int wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out + (stripes > 1 ? (blockIdx.x % stripes) * SS_AMAX_STRIDE : 0), max(max(wm[0], wm[1]), max(wm[2], wm[3])));
+}
+
 inline void launch_amax_view(const float* v, long rows, int C, int cs, unsigned int* out, int stripes, hipStream_t s) {
     const long work = rows * C / 4;
     const unsigned nb = (unsigned)(work / 4096 < 32 ? 32 : (work / 4096 > 1024 ? 1024 : work / 4096));
@@ -320,6 +348,19 @@ AmaxRef act_amax(const float* v, long rows, int C, int cs, unsigned int* ext, in
     if (!(ext && ext_valid)) {
         (void)hipMemsetAsync(slot, 0, ext ? (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4 : 4, s);
         launch_amax_view(v, rows, C, cs, slot, stripes, s);
+    }
+    return AmaxRef{slot, stripes};
+}
+// ... of a 16-bit stored view
+AmaxRef act_amax16(const void* v, int dtype, long rows, int C, int cs, unsigned int* ext, int ext_valid, unsigned int* scratch, hipStream_t s) {
+    unsigned int* slot = ext ? ext : scratch;
+    const int stripes = ext ? SS_AMAX_STRIPES : 1;
+    if (!(ext && ext_valid)) {
+        (void)hipMemsetAsync(slot, 0, ext ? (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4 : 4, s);
+        const long work = rows * C / 4;
+        const unsigned nb = (unsigned)(work / 4096 < 32 ? 32 : (work / 4096 > 1024 ? 1024 : work / 4096));
+        if (dtype == SS_DTYPE_F16) hipLaunchKernelGGL(amax_view16_kernel<_Float16>, dim3(nb), dim3(256), 0, s, (const _Float16*)v, rows, C, cs, slot, stripes);
+        else hipLaunchKernelGGL(amax_view16_kernel<__bf16>, dim3(nb), dim3(256), 0, s, (const __bf16*)v, rows, C, cs, slot, stripes);
     }
     return AmaxRef{slot, stripes};
 }
@@ -977,9 +1018,9 @@ ConvShim make_shim(const ss_conv_desc* d, void* ws, size_t ws_bytes) {
     sh.d32.dtype = SS_DTYPE_F32;
     sh.d32.in_cstride = d->cin;
     sh.d32.out_cstride = d->cout;
-    sh.d32.x_amax = sh.d32.dy_amax = nullptr;
+    // (the caller's amax slots stay: the maximum of the fp32 staging copy IS the maximum of the stored tensor, so a slot a norm
+    // kernel filled saves the scan, and a scan done here serves the caller's later passes)
     sh.d32.y_stats = nullptr;
-    sh.d32.x_amax_valid = sh.d32.dy_amax_valid = 0;
     sh.d32.in_norm_groups = 0;                 // fp32 storage only (valid_desc_any rejects it for the 16-bit types)
     sh.a_bytes = ss_align_up((size_t)d->n * d->ih * d->iw * d->cin * sizeof(float), 256);
     sh.b_bytes = ss_align_up((size_t)d->n * d->oh * d->ow * d->cout * sizeof(float), 256);
@@ -1043,9 +1084,22 @@ int native16_bwd_data(const ss_conv_desc* d, const void* dy, const float* w, voi
 int native16_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate, void* ws,
                         size_t ws_bytes, hipStream_t s, bool* taken) {
     *taken = false;
-    if (d->transposed || dbias) return SS_OK;
+    if (d->transposed) return SS_OK;
     ConvProb c = plain(d);
     c.dtype = d->dtype;
+    {   // Winograd weight gradient on pre-split planes: the transforms read the stored type; planes + GEMM as for fp32 storage
+        WinoProb q;
+        if ((d->algo == SS_ALGO_AUTO || d->algo == SS_ALGO_X6) && c.kh * c.kw <= SS_MAX_TAPS && wino_fwd_prob(c, d->algo, &q) &&
+            ss_tuning().wino_r == 4 && ss_wino_wgrad_tn(q) && !dbias && ws && ws_bytes >= ss_wino_wgrad_ws(q)) {
+            *taken = true;
+            unsigned int* sl = (unsigned int*)((char*)ws + ss_wino_wgrad_ws(q) - 256);
+            const AmaxRef ax = act_amax16(x, d->dtype, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
+            const AmaxRef ay = act_amax16(dy, d->dtype, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl + 1, s);
+            q.x_amax = ax.p; q.x_stripes = ax.stripes; q.dy_amax = ay.p; q.dy_stripes = ay.stripes;
+            return ss_wino_conv_wgrad16(q, d->dtype, x, dy, dw, accumulate, ws, ss_wino_wgrad_ws(q), s);
+        }
+    }
+    if (dbias) return SS_OK;
     if (!twgrad_takes(c, d->algo)) return SS_OK;
     WGradParams p = wgrad_params(c, (const float*)x, (const float*)dy, (float*)ws);
     p.x6 = x6_wanted(d->algo);
@@ -1101,8 +1155,20 @@ size_t ss_conv2d_wcache_bytes(const ss_conv_desc* d, int pass) {
 }
 
 int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass) {
-    if (!valid_desc_any(d) || d->dtype != SS_DTYPE_F32) return 0;
-    return conv2d_uses_amax32(d, pass);
+    if (!valid_desc_any(d)) return 0;
+    if (d->dtype == SS_DTYPE_F32) return conv2d_uses_amax32(d, pass);
+    // 16-bit storage: the native paths scale per tile (tile kernels, Winograd forward / data gradient); the others run the fp32
+    // problem on staging copies and take the maxima that problem takes
+    if (!d->transposed) {
+        ConvProb c = plain(d);
+        c.dtype = d->dtype;
+        WinoProb q;
+        if (pass == SS_PASS_FWD && (wino16_fwd_takes(c, d->algo, &q) || tconv_takes_fwd(c, d->algo))) return 0;
+        if (pass == SS_PASS_BWD_DATA && (wino16_dgrad_takes(c, d->algo, &q) || tconv_takes_dgrad(c, d->algo))) return 0;
+        if (pass == SS_PASS_BWD_WEIGHT && twgrad_takes(c, d->algo)) return 0;
+    }
+    const ConvShim sh = make_shim(d, nullptr, 0);
+    return conv2d_uses_amax32(&sh.d32, pass);
 }
 
 int ss_conv2d_fuses_in_norm(const ss_conv_desc* d, int pass) {

@@ -326,8 +326,8 @@ __global__ __launch_bounds__(256, FN ? 4 : 1) void wino_input_kernel(const TI* _
 
 // E[xi][tile][c] = (A e A^T)_xi for the RxR tile e of dy (zero outside the dy extent)
 // PL = 1: E as two fp16 planes [plane][xi][tile][c] of E * 2^(14 - (exponent(max|dy|) + bound)) (weight gradient on pre-split planes)
-template <int R, int PL = 0>
-__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, int dy_cs, int N, int OH, int OW, int C,
+template <int R, int PL = 0, typename TI = float>
+__global__ __launch_bounds__(256) void wino_dy_kernel(const TI* __restrict__ dy, int dy_cs, int N, int OH, int OW, int C,
                                                       int TH, int TW, float* __restrict__ E, unsigned int* __restrict__ amax_out = nullptr,
                                                       const unsigned int* __restrict__ amax_in = nullptr, int amax_stripes = 0, int bound = 0) {
     typedef typename WT<R>::T T;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int oy = R * ty + i, ox = R * tx + j;
-            v[i] = ldz<T>(dy, ((long)(n * OH + oy) * OW + ox) * dy_cs + c, oy < OH && ox < OW);
+            v[i] = ldz_t<T, TI>(dy, ((long)(n * OH + oy) * OW + ox) * dy_cs + c, oy < OH && ox < OW);
         }
         t_dy<R, T>(v, w);
 #pragma unroll
@@ -919,8 +919,10 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     return SS_OK;
 }
 
-template <int R>
-int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, int accumulate, void* ws, hipStream_t s) {
+// TS = storage type of x / dy (float, or _Float16 / __bf16: 16-bit activation storage, pre-split-plane path only -- the transforms read
+// the stored type, the planes and the GEMM are those of the fp32-storage path: the weight gradient stays fp32-grade)
+template <int R, typename TS = float>
+int wgrad_impl(const WinoProb& q, const TS* x, const TS* dy, float* dw, int accumulate, void* ws, hipStream_t s) {
     constexpr int XI = (R + 2) * (R + 2), VW = WT<R>::VW;
     const int TH = (q.oh + R - 1) / R, TW = (q.ow + R - 1) / R;
     const long tiles = (long)q.n * TH * TW;
@@ -928,19 +930,25 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
     float* E = (float*)((char*)ws + ss_align_up((size_t)XI * tiles * q.cin * 4, 256));
     float* part = (float*)((char*)E + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
     if (q.in_norm.groups > 0 && !(R == 4 && ss_wino_wgrad_tn(q) && q.x_amax && q.dy_amax)) return SS_ERR_UNSUPPORTED;
+    if (sizeof(TS) != 4 && !(R == 4 && ss_wino_wgrad_tn(q) && q.x_amax && q.dy_amax && q.in_norm.groups == 0)) return SS_ERR_UNSUPPORTED;
     if (R == 4 && ss_wino_wgrad_tn(q) && q.x_amax && q.dy_amax) {
         // both operands as K-major fp16 (h, l) planes, one power-of-two scale per tensor from max|x| / max|dy| and the gain bounds of
         // the transforms (|B^T d B| <= 100 max|d| < 2^7, |A e A^T| <= 225 max|e| < 2^8), GEMM by LDS-DMA + transposing LDS reads
         constexpr int BOUND_X = 7, BOUND_DY = 8;
-        if (q.in_norm.groups > 0)
-            hipLaunchKernelGGL((wino_input_kernel<R, 4, true>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
-                               q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X, 0, q.in_norm);
-        else
-            hipLaunchKernelGGL((wino_input_kernel<R, 4>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
+        if constexpr (sizeof(TS) == 4) {
+            if (q.in_norm.groups > 0)
+                hipLaunchKernelGGL((wino_input_kernel<R, 4, true>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
+                                   q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X, 0, q.in_norm);
+            else
+                hipLaunchKernelGGL((wino_input_kernel<R, 4>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
+                                   q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X);
+        } else {
+            hipLaunchKernelGGL((wino_input_kernel<R, 4, false, TS>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
                                q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X);
+        }
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL((wino_dy_kernel<R, 1>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, E,
-                           nullptr, q.dy_amax, q.dy_stripes, BOUND_DY);
+        hipLaunchKernelGGL((wino_dy_kernel<R, 1, TS>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, (float*)E,
+                           (unsigned int*)nullptr, q.dy_amax, q.dy_stripes, BOUND_DY);
         SS_LAUNCH_CHECK();
         TNParams g{};
         g.a = (const unsigned short*)V; g.b = (const unsigned short*)E; g.c = part;
@@ -959,6 +967,9 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
+    if constexpr (sizeof(TS) != 4) {
+        return SS_ERR_UNSUPPORTED;
+    } else {
     // x3h weight gradient: the GEMM splits both operands in-kernel with one scale per operand, from the maxima the transforms report
     unsigned int* am = nullptr;
     if (q.x6 && ss_x3h_enabled() && (tiles * (q.cin / VW)) % 256 == 0 && (tiles * (q.cout / VW)) % 256 == 0) {
@@ -989,6 +1000,7 @@ int wgrad_impl(const WinoProb& q, const float* x, const float* dy, float* dw, in
     launch_wino_dw<R>(part, p.splits, q.cin, q.cout, dw, accumulate, s);
     SS_LAUNCH_CHECK();
     return SS_OK;
+    }
 }
 
 }  // namespace
@@ -1069,4 +1081,14 @@ int ss_wino_conv_wgrad(const WinoProb& q, const float* x, const float* dy, float
     if (!ws || ws_bytes < ss_wino_wgrad_ws(q)) return SS_ERR_WORKSPACE;
     if (wino_r() == 2) return wgrad_impl<2>(q, x, dy, dw, accumulate, ws, s);
     return wgrad_impl<4>(q, x, dy, dw, accumulate, ws, s);
+}
+
+// the same on 16-bit stored x / dy: pre-split-plane path only (ss_wino_wgrad_tn), q.x_amax / q.dy_amax must be set
+int ss_wino_conv_wgrad16(const WinoProb& q, int dtype, const void* x, const void* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                         hipStream_t s) {
+    if (!ws || ws_bytes < ss_wino_wgrad_ws(q)) return SS_ERR_WORKSPACE;
+    if (wino_r() != 4) return SS_ERR_UNSUPPORTED;
+    if (dtype == SS_DTYPE_F16) return wgrad_impl<4, _Float16>(q, (const _Float16*)x, (const _Float16*)dy, dw, accumulate, ws, s);
+    if (dtype == SS_DTYPE_BF16) return wgrad_impl<4, __bf16>(q, (const __bf16*)x, (const __bf16*)dy, dw, accumulate, ws, s);
+    return SS_ERR_INVALID;
 }

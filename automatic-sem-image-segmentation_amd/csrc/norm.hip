@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
             float t = __builtin_fmaf(xv[v] - mu[v], rs[v] * (gamma ? gm[v] : 1.f), bt[v]);
             if (res) t += rv[v];
             o[v] = ss_apply_act(t, act, alpha);
-            am = fmaxf(am, fabsf(o[v]));
+            am = fmaxf(am, fabsf((float)(T)o[v]));          // what is stored: rounded to the storage type
         }
         stv<V>(y + row * y_cs + c, o);
     }
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
             const float xh = (xv[v] - mu[v]) * rs[v];
             const float dv = rs[v] * (gamma ? gm[v] : 1.f) * (gv[v] - sm[2 * v] - xh * sm[2 * v + 1]);
             o[v] = acc_dx ? o[v] + dv : dv;
-            am = fmaxf(am, fabsf(o[v]));
+            am = fmaxf(am, fabsf((float)(T)o[v]));          // what is stored: rounded to the storage type
         }
         stv<V>(dx + row * dx_cs + c, o);
         if (dres) {
@@ -718,7 +718,7 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     const int V = pick_v(d->c, {d->x_cstride, y ? d->y_cstride : 0, residual ? d->res_cstride : 0},
                          {x, y, residual, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
-    unsigned int* yam = sizeof(T) == 4 ? (unsigned int*)d->y_amax : nullptr;        // max|y| for the next conv's x3h scale (fp32 storage only)
+    unsigned int* yam = (unsigned int*)d->y_amax;        // max|y| (of the STORED, i.e. rounded, values) for the next conv's x3h scale
     if (norm_small(d) && y) {
         const int CL = small_cl(V);
         const dim3 grid((g.C + CL * V - 1) / (CL * V), g.G);
@@ -772,7 +772,7 @@ int norm_apply_t(const ss_norm_desc* d, const T* x, const float* gamma, const fl
     hipStream_t s = (hipStream_t)stream;
     const int V = pick_v(d->c, {d->x_cstride, d->y_cstride, residual ? d->res_cstride : 0}, {x, y, residual, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
-    unsigned int* yam = sizeof(T) == 4 ? (unsigned int*)d->y_amax : nullptr;
+    unsigned int* yam = (unsigned int*)d->y_amax;
     const long rows = (long)g.G * g.P;
     if (V == 4)
         hipLaunchKernelGGL((norm_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
@@ -812,7 +812,7 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
     const int V = pick_v(d->c, {d->x_cstride, dy_cstride, dx_cstride, use_y ? d->y_cstride : 0, dres ? d->res_cstride : 0},
                          {x, dy, dx, use_y ? y : nullptr, dres, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
-    unsigned int* dxam = sizeof(T) == 4 ? (unsigned int*)d->dx_amax : nullptr;      // max|dx| for the previous conv's x3h scales
+    unsigned int* dxam = (unsigned int*)d->dx_amax;      // max|dx| (stored values) for the previous conv's x3h scales
     if (norm_small(d)) {
         const int CL = small_cl(V);
         const dim3 grid((g.C + CL * V - 1) / (CL * V));
@@ -970,7 +970,7 @@ int norm_bwd_finish_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, co
 
 extern "C" {
 
-int ss_norm_reports_amax(const ss_norm_desc* d) { return valid(d) && d->dtype == SS_DTYPE_F32 && !norm_small(d) ? 1 : 0; }
+int ss_norm_reports_amax(const ss_norm_desc* d) { return valid(d) && !norm_small(d) ? 1 : 0; }
 
 size_t ss_norm_workspace_bytes(const ss_norm_desc* d) {
     if (!valid(d)) return 0;

@@ -236,8 +236,8 @@ typedef struct ss_norm_desc {
 } ss_norm_desc;
 
 size_t ss_norm_workspace_bytes(const ss_norm_desc* d);
-/* 1: ss_norm_fwd / ss_norm_bwd of this descriptor raise y_amax / dx_amax (the two-pass kernels; the one-launch kernels for small
- * groups and the 16-bit storage types leave the slots untouched).  Pure function of d and the ss_config table. */
+/* 1: ss_norm_fwd / ss_norm_bwd of this descriptor raise y_amax / dx_amax (the two-pass kernels, any storage type: the
+ * maximum of the STORED values; the one-launch kernels for small groups leave the slots untouched).  Pure function of d and the ss_config table. */
 int ss_norm_reports_amax(const ss_norm_desc* d);
 /* gamma may be NULL (scale=False); residual may be NULL.  mean/rstd: [groups*c] outputs kept for backward.
  * If moving_mean/moving_var are non-NULL (batch norm training) they are updated in place:

@@ -200,6 +200,7 @@ struct X6PParams {
     int32_t lda, ldb, ldc;
     int32_t plain_l;              // x3h planes carry the low piece at its own magnitude (x*s = h + l): 256 x 256 tiles, one accumulator set (gemm_x6p.hip WIDE)
     int32_t fp16x2;               // 0: three bf16 planes, six products (x6);  1: two fp16 planes h + 2^-11 l, three products (x3h)
+    int32_t dbg;                  // measurement only (tile_dbg & 64: skip the B operand's LDS-DMA; & 128: skip A's): results are wrong
     int64_t a_plane, b_plane, a_bs, b_bs, c_bs, c_ss;
 };
 // C[batch][split][m][n] = sum_k A[batch][k][m] * B[batch][k][n] on K-major fp16 (h, l) planes (gemm_tn_x3h.hip)

@@ -268,6 +268,48 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         co[ni] = n0 + wn * (BN / 2) + ni * 32 + l31;
         bv[ni] = (p.bias && co[ni] < p.Cout) ? p.bias[co[ni]] : 0.f;
     }
+    // Coalesced epilogue (as gemm_x6p.hip / conv_mfma_x6v2.hip): every wave transposes its sub-tile through 2 KiB of the operand
+    // tiles (free after the last __syncthreads above), 8 rows at a time, and stores 16 bytes per lane -- whole pixel rows of the wave's
+    // columns per instruction instead of one 4-byte element per lane and row.  (The sub-pixel phases of the generators' last transposed
+    // convolution, 64 outputs and K = 128 .. 512, are paced by their output stream.)
+    {
+        constexpr int COLS = 32 * TN, LPR = COLS / 4, RPI = 64 / LPR, NRD = 8 / RPI;
+        const int cbase = n0 + wn * (BN / 2);
+        const bool vec_ok = cbase + COLS <= p.Cout && (p.out_cs & 3) == 0 && (((uintptr_t)g_out) & 15) == 0;
+        if (vec_ok) {
+            float* tb = (float*)lds + wave * 512;          // [8 rows][COLS]
+            const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) b4 = *(const f32x4*)(p.bias + cbase + rcol);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni)
+                            tb[(rr + 4 * lh) * COLS + ni * 32 + l31] = H ? acc[mi][ni][rq * 4 + rr] * out_scale : acc[mi][ni][rq * 4 + rr];
+                    __builtin_amdgcn_wave_barrier();          // one wave's LDS operations execute in issue order
+#pragma unroll
+                    for (int k = 0; k < NRD; ++k) {
+                        const int row = rrow + RPI * k;
+                        f32x4 v = *(const f32x4*)(tb + row * COLS + rcol);
+                        const int pix = pixtab[wm * (BM / 2) + mi * 32 + 8 * rq + row];
+                        if (pix >= 0) {
+                            float* op = g_out + (long)pix * p.out_cs + cbase + rcol;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ss_apply_act(v[e] + b4[e], p.act, p.alpha);
+                            if (p.accumulate) v += *(const f32x4*)op;
+                            *(f32x4*)op = v;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll

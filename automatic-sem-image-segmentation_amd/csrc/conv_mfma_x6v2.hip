@@ -23,6 +23,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ float v2_zero_page16[4] = {0.f, 0.f, 0.f, 0.f};
+constexpr bool ss_v2_scalar_epilogue = false;          // true: the one-column-per-lane stores (A/B measurement builds)
 
 constexpr int VBM = 256, VK = 32;
 constexpr int VLD = VK + 8;                       // A row stride in halfs (80 bytes)
@@ -250,6 +251,45 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
     for (int ni = 0; ni < TN; ++ni) {
         co[ni] = n0 + wn * (VBN / 2) + ni * 32 + l31;
         bv[ni] = (p.bias && co[ni] < p.Cout) ? p.bias[co[ni]] : 0.f;
+    }
+    // Coalesced epilogue (as gemm_x6p.hip): a lane of the C/D layout owns ONE column and 16 scattered rows = 32 four-byte stores
+    // per column tile; instead every wave transposes its 64 x (32 TN) sub-tile through 2 KiB of the (now free) operand stages, 8
+    // rows at a time, and stores 16 bytes per lane: 4 (TN = 2) or 8 (TN = 1) whole pixel rows of the wave's columns per instruction.
+    constexpr int COLS = 32 * TN, LPR = COLS / 4, RPI = 64 / LPR, NRD = 8 / RPI;      // lanes per row, rows per read instruction, reads per group
+    const int cbase = n0 + wn * (VBN / 2);
+    const bool vec_ok = cbase + COLS <= p.Cout && (p.out_cs & 3) == 0 && (((uintptr_t)g_out) & 15) == 0 && !(ss_v2_scalar_epilogue);
+    __builtin_amdgcn_s_barrier();              // every wave is done reading the last chunk's fragments: the stages are free (all waves: vec_ok differs per wave)
+    if (vec_ok) {
+        float* tb = (float*)(lds + wave * 2048);          // [8 rows][COLS]
+        const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b4 = *(const f32x4*)(p.bias + cbase + rcol);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) tb[(rr + 4 * lh) * COLS + ni * 32 + l31] = acc[mi][ni][rq * 4 + rr] * out_scale;
+                __builtin_amdgcn_wave_barrier();          // one wave's LDS operations execute in issue order
+#pragma unroll
+                for (int k = 0; k < NRD; ++k) {
+                    const int row = rrow + RPI * k;
+                    f32x4 v = *(const f32x4*)(tb + row * COLS + rcol);
+                    const int pix = pixtab[wm * 64 + mi * 32 + 8 * rq + row];
+                    if (pix >= 0) {
+                        float* op = g_out + pix * p.out_cs + cbase + rcol;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ss_apply_act(v[e] + b4[e], p.act, p.alpha);
+                        if (p.accumulate) v += *(const f32x4*)op;
+                        *(f32x4*)op = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {

@@ -12,6 +12,7 @@
 // the row, applied on the SOURCE address of the DMA (which k-octet a lane fetches) and on the read address alike.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -115,6 +116,12 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
     }
     const unsigned short* gp[NDMA];
     const unsigned short* gpn[NDMA];
+    unsigned skipmask = 0;          // measurement only (p.dbg)
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+        const bool isA = wave * NDMA + j < NPL * (PBM / 16);
+        if ((isA && (p.dbg & 128)) || (!isA && (p.dbg & 64))) skipmask |= 1u << j;
+    }
     if (t_first >= t_end) return;
     TileCtx cur = setup(t_first, gp);
     constexpr int NACC = NPL == 2 && !WIDE ? 2 : 1;          // x3h: the cross terms h*l + l*h accumulate apart (they carry the factor 2^-11); wide: plain l, one set
@@ -173,6 +180,8 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * NDMA) : "memory");      // chunk 0 landed, the others may be in flight
     }
+    constexpr int NST = 16;          // store instructions of the coalesced epilogue per wave: 2 (mi) x 4 (row groups) x 2
+    bool relaxed = false;            // the previous tile of this workgroup ended with exactly NST stores in THIS wave
     int st = 0;
     for (int t = t_first; t < t_end; t += t_stride) {
         const int nchunks = cur.nchunks;
@@ -221,7 +230,13 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
                 st = st1;
             }
         } else {
-        for (int c = 0; c < nchunks; ++c) {
+        // One K step.  VW = how many of this wave's youngest vector-memory operations may still be outstanding when chunk c+1 must
+        // have landed: normally the (STAGES - 2) younger chunk groups; in the first STAGES - 1 steps of a tile that follows a tile
+        // whose epilogue issued exactly NST stores (see below) those stores are younger than chunk c+1 as well and need not have
+        // completed -- vmcnt counts loads and stores in issue order, and with the strict count the K loop sat out the drain of the
+        // previous tile's 128 KiB of C (46 of 237 us per launch, tools/x6p_dma_probe.sh)
+        auto kstep = [&](int c, auto VW) {
+                constexpr int W = decltype(VW)::value;
                 const int st1 = st + 1 == STAGES ? 0 : st + 1;
                 frag(a1, b1, st, so1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -229,8 +244,8 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
                 for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
                 __builtin_amdgcn_sched_barrier(0);
                 // chunk c+1 landed (the younger groups may still be in flight) and this wave's reads of chunk c are done: a real
-                // s_waitcnt (vmcnt((STAGES-2) * NDMA) lgkmcnt(0)), so that the compiler's own counting sees it
-                __builtin_amdgcn_s_waitcnt(0x0070 | (((STAGES - 2) * NDMA) & 15) | ((((STAGES - 2) * NDMA) >> 4) << 14));
+                // s_waitcnt (vmcnt(W) lgkmcnt(0)), so that the compiler's own counting sees it
+                __builtin_amdgcn_s_waitcnt(0x0070 | (W & 15) | ((W >> 4) << 14));
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 // branch-free from here to the loop end (one basic block keeps the compiler's lgkmcnt counting exact): past the last
@@ -247,25 +262,69 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
                     mma4(a1, b1, q);
 #pragma unroll
                     for (int j = 0; j < NDMA; ++j)
-                        if (j * NQ / NDMA == q) dma16(((own || !more) ? gp[j] : gpn[j]) + goff, dst + loff[j]);
+                        if (j * NQ / NDMA == q && !(skipmask >> j & 1)) dma16(((own || !more) ? gp[j] : gpn[j]) + goff, dst + loff[j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // F0's reads finished long ago (24 MFMAs back): a free wait that lets the compiler start the next step without one
                 __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
                 st = st1;
-            }
+        };
+        {
+            constexpr int STRICT = (STAGES - 2) * NDMA, RELAXED = (STAGES - 2) * NDMA + NST;
+            static_assert(RELAXED <= 63, "vmcnt is a 6-bit field");
+            int c = 0;
+            if (relaxed)
+                for (; c < STAGES - 1 && c < nchunks; ++c) kstep(c, std::integral_constant<int, RELAXED>{});
+            for (; c < nchunks; ++c) kstep(c, std::integral_constant<int, STRICT>{});
+        }
         }
 
         // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The stores are younger than
         // the next tile's first chunk groups (issued in the last K steps above): waiting for those does not wait for the stores.
         float* cb = p.c + cur.cbase + (cur.n0 + wn * 64 + l31);
         const int nrem = p.N - (cur.n0 + wn * 64 + l31);          // column ni exists iff 32 * ni < nrem
+        // Coalesced epilogue: the C/D layout gives a lane ONE column and 16 scattered rows, i.e. 64 four-byte stores per lane (512
+        // store instructions of 256 B per tile: 55 of the kernel's 252 us, tools/x6p_dma_probe.sh).  Each wave owns 2 KiB of LDS
+        // beyond the operand ring and transposes its 64 x 64 sub-tile through it 8 rows at a time: 8 ds_write_b32, then 2
+        // ds_read_b128 + 2 global_store_dwordx4 per lane, every store instruction = 4 rows x 256 contiguous bytes.
+        const bool vec_ok = !WIDE && (p.N - (cur.n0 + wn * 64) >= 64) && (p.ldc % 4 == 0) && !(p.dbg & 16);
+        // exactly NST store instructions leave this wave only when all its 64 rows exist (a masked-off store is branched over)
+        const bool full_rows = cur.m0 + wm * 64 + 64 <= p.M;
+        relaxed = vec_ok && full_rows && !(p.dbg & 32);
+        if (vec_ok) {
+            float* tb = (float*)(lds + STAGES * STAGE_B + wave * 2048);          // [8 rows][64 cols]
+            const int rrow = lane >> 4, rcol = (lane & 15) * 4;                    // read-back: row rrow (+4), columns rcol .. rcol + 3
+            float* gbase = p.c + cur.cbase + (cur.n0 + wn * 64 + rcol);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int r = rq * 4 + rr;
+                            const float v = NACC == 1 ? acc[0][mi][ni][r] : fmaf(acc[NACC - 1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
+                            tb[(rr + 4 * lh) * 64 + ni * 32 + l31] = v;
+                        }
+                    __builtin_amdgcn_wave_barrier();             // LDS operations of one wave execute in issue order: no wait between the writes and the reads (no other wave touches this slot)
+                    const f32x4 v0 = *(const f32x4*)(tb + rrow * 64 + rcol);
+                    const f32x4 v1 = *(const f32x4*)(tb + (rrow + 4) * 64 + rcol);
+                    const int m0r = cur.m0 + wm * 64 + mi * 32 + 8 * rq;             // rows m0r .. m0r + 7 of C
+                    if (!(p.dbg & 32)) {
+                        if (m0r + rrow < p.M) *(f32x4*)(gbase + (long)(m0r + rrow) * p.ldc) = v0;
+                        if (m0r + rrow + 4 < p.M) *(f32x4*)(gbase + (long)(m0r + rrow + 4) * p.ldc) = v1;
+                    }
+                    __builtin_amdgcn_wave_barrier();             // ... nor between these reads and the next group's writes
+                }
+            }
+        } else
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = cur.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
+                if (m >= p.M || (p.dbg & 32)) continue;
                 float* crow = cb + (long)m * p.ldc;               // one row pointer for both column tiles
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
@@ -273,9 +332,10 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
             }
         }
         if (more) {
-            // chunk 0 of the next tile must have landed before the barrier at the top: it is one of the oldest outstanding groups
-            // (up to 64 stores are younger): vmcnt(63) lets at most the stores minus one stay in flight
-            asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+            // chunk 0 of the next tile must have landed before the barrier at the top.  Younger than it: the other STAGES - 1 chunk
+            // groups and this epilogue's stores -- NST of them when `relaxed`, an unknown number otherwise (then none is assumed)
+            if (relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * NDMA + NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * NDMA) : "memory");
 #pragma unroll
             for (int j = 0; j < NDMA; ++j) gp[j] = gpn[j];
             cur = nxt;
@@ -317,6 +377,8 @@ bool ss_x6p_wide_ok(long M, int N, int K, int nbatch) {
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     if (p.K % PBK || p.k_per_split % PBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
     const bool wide = p.fp16x2 == 1 && p.plain_l;
+    X6PParams pd = p;
+    pd.dbg = ss_tuning().tile_dbg & (16 | 32 | 64 | 128);          // 16: the scalar-store epilogue (A/B measurement)
     if (wide && (p.N % 256 || p.splits != 1)) return SS_ERR_UNSUPPORTED;
     const int pbn = wide ? 256 : SS_X6P_BN;
     const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + pbn - 1) / pbn;
@@ -338,10 +400,10 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     SsProfScope prof(wide ? "gemm_x6p_kernel<2,wide>" : (one ? "gemm_x6p_kernel<1>" : (p.fp16x2 ? "gemm_x6p_kernel<2>" : "gemm_x6p_kernel<3>")),
                      2.0 * p.M * p.N * p.K * p.nbatch * (one ? 1 : (p.fp16x2 ? 3 : 6)),
                      2.0 * (one ? 1 : (p.fp16x2 ? 2 : 3)) * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
-    if (one) hipLaunchKernelGGL((gemm_x6p_kernel<1, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(1) * 1 * (A_PLANE_B + B_PLANE_B), s, p);
+    if (one) hipLaunchKernelGGL((gemm_x6p_kernel<1, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(1) * 1 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);
     else if (wide) hipLaunchKernelGGL((gemm_x6p_kernel<2, true>), dim3((unsigned)nwg), dim3(1024), x6p_stages(2, true) * 2 * (A_PLANE_B + 256 * ROWB), s, p);
-    else if (p.fp16x2) hipLaunchKernelGGL((gemm_x6p_kernel<2, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(2) * 2 * (A_PLANE_B + B_PLANE_B), s, p);
-    else hipLaunchKernelGGL((gemm_x6p_kernel<3, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(3) * 3 * (A_PLANE_B + B_PLANE_B), s, p);
+    else if (p.fp16x2) hipLaunchKernelGGL((gemm_x6p_kernel<2, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(2) * 2 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);
+    else hipLaunchKernelGGL((gemm_x6p_kernel<3, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(3) * 3 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -225,7 +225,7 @@ bool ss_x6p_wide_ok(long M, int N, int K, int nbatch);
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
 
 // kernel-selection switches: ONE explicit table, set through ss_config_set (config.hip); SS_* environment variables give the initial values
-struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products; };
+struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products, c1_mfma; };
 const SsTuning& ss_tuning();
 // ss_prof_*: brackets the kernel launched inside this scope with HIP events on its stream when profiling is enabled (config.hip).
 // flops = EXECUTED matrix-instruction FLOPs of the launch (all piece products), bytes = algorithmic HBM bytes (0 if not stated)
@@ -268,6 +268,9 @@ bool ss_conv_out1_ok(const GConvParams& p);
 int ss_launch_conv_out1(const GConvParams& p, hipStream_t s);
 bool ss_conv_in1_ok(const GConvParams& p);
 int ss_launch_conv_in1(const GConvParams& p, hipStream_t s);
+// data gradient of a reflection-padded Cout == 1 layer with the fold applied to the one-channel side (conv_c1.hip)
+bool ss_conv_in1_fold_ok(const GConvParams& p, int pt, int pl, int ih, int iw);
+int ss_launch_conv_in1_fold(const GConvParams& p, int pt, int pl, int ih, int iw, hipStream_t s);
 // weight gradients of the same layers: mode 0: Cout == 1 (X = x, S = dy), mode 1: Cin == 1 (X = dy, S = x)
 bool ss_wgrad_c1_ok(int n, int xh, int xw, int C, int kh, int kw);
 size_t ss_wgrad_c1_ws(int n, int xh, int xw, int C, int kh, int kw);

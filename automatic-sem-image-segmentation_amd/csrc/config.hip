@@ -42,6 +42,7 @@ const Key KEYS[] = {
     {"gconv_v2", &SsTuning::gconv_v2, "gather convolutions: two-stage one-barrier kernel with LDS-DMA weight planes (conv_mfma_x6v2.hip) where it applies; 0: gconv_x6_kernel only"},
     {"twgrad_x3h", &SsTuning::twgrad_x3h, "tile weight gradient (MultiResUNet full-resolution layers) on the fp16 matrix cores: two fp16 pieces per operand under per-tile scales, transposing LDS reads; 0: fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
     {"wino16_products", &SsTuning::wino16_products, "Winograd forward / data gradient on 16-bit stored activations: 1 = one fp16 plane per operand, one product (fast; the F(4x4,3x3) transforms amplify the 2^-12 operand rounding to ~3e-3 per layer), 3 = two planes, three products (fp32-grade arithmetic, only the storage is 16-bit)"},
+    {"c1_mfma", &SsTuning::c1_mfma, "one-channel stem / head layers (1 -> C, C -> 1, full resolution) on the fp16 matrix cores with the x3h arithmetic; 0: LDS-tiled VALU kernels"},
     {"wgrad_tn", &SsTuning::wgrad_tn, "Winograd weight gradient on pre-split K-major fp16 planes with transposing LDS reads (gemm_tn_x3h.hip); 0: in-kernel split"},
 };
 
@@ -57,6 +58,7 @@ SsTuning from_env() {
     v.wino_r = env_is("SS_WINO_R", '2') ? 2 : 4;
     v.wgrad_c1 = env_is("SS_WGRAD_C1", '0') ? 0 : 1;
     v.wgrad_tn = env_is("SS_WGRAD_TN", '0') ? 0 : 1;
+    v.c1_mfma = env_is("SS_C1_MFMA", '0') ? 0 : 1;
     v.twgrad_x3h = env_is("SS_TWGRAD_X3H", '0') ? 0 : 1;
     v.wino16_products = env_is("SS_WINO16_PRODUCTS", '3') ? 3 : 1;
     v.gconv_v2 = env_is("SS_GCONV_V2", '0') ? 0 : 1;

@@ -607,6 +607,12 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
                 GTap& t = p.taps[p.ntaps++];
                 t.dy = (int16_t)(-a); t.dx = (int16_t)(-b); t.woff = (a * c.kw + b) * c.cin * c.cout;
             }
+        if (algo != SS_ALGO_DIRECT && algo != SS_ALGO_MFMA && c.cout == 1) {
+            // one-channel gradient: the reflection's transpose is applied to the im2col of dy inside the kernel, dx is written once
+            GConvParams q = p;
+            q.out = dx; q.out_cs = c.in_cs; q.accumulate = accumulate;
+            if (ss_conv_in1_fold_ok(q, c.pt, c.pl, c.ih, c.iw)) return (c.wc && c.wc->fill_only) ? SS_OK : ss_launch_conv_in1_fold(q, c.pt, c.pl, c.ih, c.iw, s);
+        }
         int rc = run_gconv(algo, p, gws, gws_bytes, s, c.wc, 1);
         if (rc != SS_OK || (c.wc && c.wc->fill_only)) return rc;
         return launch_reflect_fold(dpad, dx, c.n, c.ih, c.iw, c.cin, c.in_cs, c.pt, c.pl, PH, PW, accumulate, s);

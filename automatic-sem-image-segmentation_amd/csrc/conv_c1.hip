@@ -201,6 +201,416 @@ __global__ __launch_bounds__(256) void conv_in1_kernel(GConvParams p, C1Box box)
     }
 }
 
+// ---- 1 -> many on the fp16 matrix cores ------------------------------------------------------------------------------------
+// The VALU kernel above spends 49 x 64 FMAs per pixel to produce 256 bytes: 396 us per launch at 512 x 512, batch 8, where the
+// 537 MB it writes cost ~100 us.  Here the layer is the GEMM  out[c][pixel] = sum_k W[c][k] * U[k][pixel],  k = (a, b) = 8 a + b
+// (rows of the tap box padded to 8 columns: K = 64 for a 7 x 7 box), on v_mfma_f32_32x32x16_f16 with the x3h arithmetic
+// (x * s = h + l, products hh + hl + lh in one fp32 accumulator, conv_tile.hip):
+//   A = weights, rows = 32 output channels; split once per workgroup (persistent) under one power-of-two scale,
+//   B = U (im2col of the one-channel halo), columns = 32 consecutive pixels of one tile row; a lane's 8 k-values are 8 consecutive
+//       floats of one halo row in LDS; split per WAVE-TILE under the power-of-two scale of that wave-tile's own maximum,
+//   D: lane = pixel, registers = channels, 4 consecutive ones per group -> every lane stores 16-byte pieces of its pixel's row.
+// FOLD (data gradient of a reflection-padded many -> 1 layer, e.g. the generator's 7x7 head): the gradient with respect to the
+// PADDED input would be the plain case on the padded grid with zeros outside dy; the reflection's transpose adds the padded
+// positions that mirror onto an image pixel.  Because the layer is linear in U, the fold is applied to U,
+//       U[q][(a,b)] = sum over padded positions P that reflect onto q of dyz[P + d0 + (a,b)],
+// (the same U as wgrad_c1_kernel MODE 0), so neither the padded gradient (550 MB) nor the fold pass over it exists.
+typedef _Float16 c1_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int c1_u32x4 __attribute__((ext_vector_type(4)));
+struct C1Fold { int on, pt, pl, XH, XW; };
+constexpr int I1_TW = 64, I1_TH = 8, I1_HS = 72, I1_HR = I1_TH + 7, I1_FRONT = 8, I1_ES = 68;
+
+__device__ __forceinline__ void c1_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool FOLD>
+__global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1Box box, C1Fold f, int ntiles, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float xs_all[I1_FRONT + I1_HR * I1_HS + 8];
+    __shared__ __attribute__((aligned(16))) float bias_s[64];
+    __shared__ int tapidx[64];
+    __shared__ float wred[4];
+    __shared__ __attribute__((aligned(16))) float ep_s[4 * 32 * I1_ES];          // epilogue transposition, one 32 x 64 block per wave
+    float* const xs = xs_all + I1_FRONT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int cbase = blockIdx.y * 64;
+    const int OH = FOLD ? f.XH : p.OH, OW = FOLD ? f.XW : p.OW;
+    const int nq = (box.kh + 1) >> 1;                       // K steps of 16 = two box rows
+
+    if (tid < 64) { tapidx[tid] = -1; bias_s[tid] = (p.bias && cbase + tid < p.Cout) ? p.bias[cbase + tid] : 0.f; }
+    for (int i = tid; i < I1_FRONT + I1_HR * I1_HS + 8; i += 256) xs_all[i] = 0.f;
+    __syncthreads();
+    if (tid < p.ntaps) tapidx[(p.taps[tid].dy - box.dy0) * 8 + (p.taps[tid].dx - box.dx0)] = tid;
+    __syncthreads();
+
+    // A fragments: lane (row = channel cb*32 + l31, lh) holds k = 16 q + 8 lh + e  <->  box row a = 2 q + lh, column b = e
+    c1_u32x4 Ah[2][4], Al[2][4];
+    int ew;
+    {
+        float wv[2][4][8];
+        float wmax = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int t = tapidx[(2 * q + lh) * 8 + e];
+                    const int c = cbase + cb * 32 + l31;
+                    const float v = (t >= 0 && c < p.Cout) ? p.w[p.taps[t].woff + c] : 0.f;
+                    wv[cb][q][e] = v;
+                    wmax = fmaxf(wmax, fabsf(v));
+                }
+        for (int off = 32; off >= 1; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+        if (lane == 0) wred[wave] = wmax;
+        __syncthreads();
+        wmax = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+        ew = ss_amax_exp(wmax);
+        const float sw = ldexpf(1.f, 14 - ew);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned int hh, ll;
+                    ss_split_h2(wv[cb][q][2 * j] * sw, wv[cb][q][2 * j + 1] * sw, hh, ll);
+                    Ah[cb][q][j] = hh;
+                    Al[cb][q][j] = ll;
+                }
+    }
+
+    // halo of the NEXT tile in registers while the current one is multiplied
+    constexpr int NPRE = (I1_HR * I1_HS + 255) / 256;
+    float pre[NPRE];
+    const int org_y = p.in_oy + box.dy0 + (FOLD ? f.pt : 0), org_x = p.in_ox + box.dx0 + (FOLD ? f.pl : 0);
+    auto prefetch = [&](int tile) {
+        const int n = tile / (tiles_y * tiles_x);
+        const int tr = tile - n * tiles_y * tiles_x;
+        const int y0 = (tr / tiles_x) * I1_TH, x0 = (tr % tiles_x) * I1_TW;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int idx = tid + 256 * u;
+            const int r = idx / I1_HS, col = idx - r * I1_HS;
+            float v = 0.f;
+            if (r < I1_HR && r < I1_TH + box.kh - 1 && col < I1_TW + box.kw - 1) {
+                const int iy = ss_map_index(y0 + org_y + r, p.IH, p.reflect);
+                const int ix = ss_map_index(x0 + org_x + col, p.IW, p.reflect);
+                if (iy >= 0 && ix >= 0) v = p.in[((long)(n * p.IH + iy) * p.IW + ix) * p.in_cs];
+            }
+            pre[u] = v;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / (tiles_y * tiles_x);
+        const int tr = tile - n * tiles_y * tiles_x;
+        const int y0 = (tr / tiles_x) * I1_TH, x0 = (tr % tiles_x) * I1_TW;
+        c1_lds_barrier();                                   // the previous tile's halo is no longer read
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < I1_HR * I1_HS) xs[idx] = pre[u];
+        }
+        c1_lds_barrier();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int ry = wave * 2 + (i >> 1), rx = (i & 1) * 32 + l31;
+            const int qy = y0 + ry, qx = x0 + rx;
+            const int xb0 = x0 + (i & 1) * 32;
+            if (qy >= OH || xb0 >= OW) continue;            // wave-uniform
+            float bv[4][8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* r = xs + (ry + 2 * q + lh) * I1_HS + rx;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[q][e] = q < nq ? r[e] : 0.f;
+            }
+            if (FOLD && (qy <= f.pt || qy >= f.XH - 1 - f.pt || xb0 <= f.pl || xb0 + 31 >= f.XW - 1 - f.pl)) {
+                // Border rows / columns (wave-uniform test): besides q itself at most ONE more padded row and ONE more padded column
+                // mirror onto q (launcher: the image is larger than 2 * pad + 4), at the offsets oy / ox from q's own position; rows /
+                // columns outside the staged halo are outside dy for those positions.  Only the pixels within `pad` of an edge
+                // receive anything: the row term is wave-uniform, the column term runs for the (at most pad + 1) lanes concerned.
+                const bool top = 2 * qy < f.XH, left = 2 * qx < f.XW;
+                const bool ay = top ? (qy >= 1 && qy <= f.pt) : (qy <= f.XH - 2 && qy >= f.XH - 1 - f.pt);
+                const bool ax = left ? (qx >= 1 && qx <= f.pl) : (qx <= f.XW - 2 && qx >= f.XW - 1 - f.pl);
+                const int oy = top ? -2 * qy : 2 * (f.XH - 1 - qy);
+                const int ox = left ? -2 * qx : 2 * (f.XW - 1 - qx);
+                const int hr_n = I1_TH + box.kh - 1, hc_n = I1_TW + box.kw - 1;
+                if (ay) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int hr = ry + 2 * q + lh + oy;
+                        if (q < nq && hr >= 0 && hr < hr_n) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) bv[q][e] += xs[hr * I1_HS + rx + e];
+                        }
+                    }
+                }
+                if (ax) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int hr = ry + 2 * q + lh;
+                        const bool yin = ay && hr + oy >= 0 && hr + oy < hr_n;
+                        if (q < nq) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const int hc = rx + e + ox;
+                                if (hc >= 0 && hc < hc_n) {
+                                    bv[q][e] += xs[hr * I1_HS + hc];
+                                    if (yin) bv[q][e] += xs[(hr + oy) * I1_HS + hc];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            float m = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(bv[q][e]));
+            for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            const int eb = ss_amax_exp(m);
+            const float sb = ldexpf(1.f, 14 - eb);
+            f32x16 acc[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nq) {
+                    c1_u32x4 bh, bl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned int hh, ll;
+                        ss_split_h2(bv[q][2 * j] * sb, bv[q][2 * j + 1] * sb, hh, ll);
+                        bh[j] = hh;
+                        bl[j] = ll;
+                    }
+                    const c1_f16x8 xh = __builtin_bit_cast(c1_f16x8, bh), xl = __builtin_bit_cast(c1_f16x8, bl);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        const c1_f16x8 wh = __builtin_bit_cast(c1_f16x8, Ah[cb][q]), wl = __builtin_bit_cast(c1_f16x8, Al[cb][q]);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[cb], 0, 0, 0);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[cb], 0, 0, 0);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[cb], 0, 0, 0);
+                    }
+                }
+            }
+            // epilogue: a lane of the C/D layout holds its pixel's channels in 16-byte groups 32 bytes apart -- stored directly, every
+            // instruction would touch 32 cache lines for 32 bytes each.  The wave's 32 x 64 block goes through a wave-private LDS
+            // scratch and leaves as whole pixel rows: 16 lanes x 16 bytes = one pixel's 256 bytes, 4 pixels per instruction.
+            const float inv = ldexpf(1.f, ew + eb - 28);
+            float* const tb = ep_s + wave * (32 * I1_ES);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[cb][4 * rg + e] * inv;
+                    *(f32x4*)(tb + l31 * I1_ES + cb * 32 + 8 * rg + 4 * lh) = v;
+                }
+            __builtin_amdgcn_wave_barrier();
+            const int c = (lane & 15) * 4;
+            if (cbase + c < p.Cout) {
+                const f32x4 b4 = *(const f32x4*)(bias_s + c);
+                float* const orow = p.out + ((long)(n * OH + qy) * OW + xb0) * p.out_cs + cbase + c;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int px = 4 * k + (lane >> 4);
+                    if (xb0 + px >= OW) continue;
+                    f32x4 v = *(const f32x4*)(tb + px * I1_ES + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ss_apply_act(v[e] + b4[e], p.act, p.alpha);
+                    float* op = orow + (long)px * p.out_cs;
+                    if (p.accumulate) v += *(const f32x4*)op;
+                    *(f32x4*)op = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- many -> 1 on the fp16 matrix cores -----------------------------------------------------------------------------------------
+// The VALU kernel spends 49 x C FMAs per output pixel and re-stages the halo once per 8-channel chunk (3.3 GB of L2 traffic for a
+// 0.55 GB input).  Here the channel contraction is ONE GEMM per halo pixel P, independent of the tap geometry,
+//       Z[t][P] = sum_c W[t][c] * X[P][c],        t = 8 a + b (tap box rows padded to 8 columns: M = 64),  K = C,
+// on v_mfma_f32_32x32x16_f16 with the x3h arithmetic (A = weights, split once per workgroup; B = pixels: a lane's 8 k-values are 8
+// consecutive channels of ITS pixel straight from global memory, split under the power-of-two scale of that PIXEL's own maximum,
+// which leaves the lane's accumulators as a per-lane factor), followed by the tap sum  out[q] = sum_{a,b} Z[(a,b)][q + (a,b)]  over
+// LDS: a workgroup owns a 32-row x (64 - (kw-1))-column output tile, walks its halo two rows (4 waves x 32 pixels) at a time, writes
+// the 64 x 128 block of Z tap-major into a double-buffered LDS stage (one barrier per step) and adds the 7 x 2 entries every output
+// of the 8 rows concerned receives from it into the tile's output accumulator in LDS.  Every input element is read once per tile
+// (halo overhead 1.3x, mostly L2 hits), LDS traffic is 450 bytes per halo pixel.
+constexpr int O1_TH = 32, O1_ZS = 132;          // output rows per tile; floats per tap row of the Z stage (128 pixels + pad)
+
+template <int CQ>          // channel steps of 16: C == 16 * CQ (CQ = 2, 4)
+__global__ __launch_bounds__(256, 2) void conv_out1_x3h_kernel(GConvParams p, C1Box box, int ntiles, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) float o1_lds[];
+    float* const zs = o1_lds;                                   // [2][64 taps][O1_ZS]
+    float* const oacc = o1_lds + 2 * 64 * O1_ZS;                // [O1_TH][64]
+    int* const tapidx = (int*)(oacc + O1_TH * 64);              // [64]
+    float* const wred = (float*)(tapidx + 64);                  // [4]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int TW = 64 - (box.kw - 1);
+    const int HRN = O1_TH + box.kh - 1;                         // halo rows of a tile
+    const int nsteps = (HRN + 1) >> 1;
+
+    if (tid < 64) tapidx[tid] = -1;
+    __syncthreads();
+    if (tid < p.ntaps) tapidx[(p.taps[tid].dy - box.dy0) * 8 + (p.taps[tid].dx - box.dx0)] = tid;
+    __syncthreads();
+
+    // A fragments: lane (row = tap cb*32 + l31, lh) holds k = 16 q + 8 lh + e = channel
+    c1_u32x4 Ah[2][CQ], Al[2][CQ];
+    int ew;
+    {
+        float wv[2][CQ][8];
+        float wmax = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int t = tapidx[cb * 32 + l31];
+#pragma unroll
+            for (int q = 0; q < CQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = t >= 0 ? p.w[p.taps[t].woff + (long)(16 * q + 8 * lh + e) * p.ldb] : 0.f;
+                    wv[cb][q][e] = v;
+                    wmax = fmaxf(wmax, fabsf(v));
+                }
+        }
+        for (int off = 32; off >= 1; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+        if (lane == 0) wred[wave] = wmax;
+        __syncthreads();
+        wmax = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+        ew = ss_amax_exp(wmax);
+        const float sw = ldexpf(1.f, 14 - ew);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < CQ; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned int hh, ll;
+                    ss_split_h2(wv[cb][q][2 * j] * sw, wv[cb][q][2 * j + 1] * sw, hh, ll);
+                    Ah[cb][q][j] = hh;
+                    Al[cb][q][j] = ll;
+                }
+    }
+    const float bias = p.bias ? p.bias[0] : 0.f;
+
+    // this wave's pixels of a step: halo row 2 * step + (wave >> 1), halo columns (wave & 1) * 32 + l31
+    const int hrw = wave >> 1, hc = (wave & 1) * 32 + l31;
+    f32x4 xr[CQ][2];                                            // the NEXT step's pixel (8 channels per 16-channel step), raw
+    bool xvalid = false;
+    auto fetch = [&](int n, int y0, int x0, int step) {
+        const int hr = 2 * step + hrw;
+        int iy = ss_map_index(y0 + p.in_oy + box.dy0 + hr, p.IH, p.reflect);
+        int ix = ss_map_index(x0 + p.in_ox + box.dx0 + hc, p.IW, p.reflect);
+        xvalid = hr < HRN && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;          // tiles past the image edge reflect out of range
+        if (xvalid) {
+            const float* src = p.in + ((long)(n * p.IH + iy) * p.IW + ix) * p.in_cs + 8 * lh;
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) {
+                xr[q][0] = *(const f32x4*)(src + 16 * q);
+                xr[q][1] = *(const f32x4*)(src + 16 * q + 4);
+            }
+        }
+    };
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / (tiles_y * tiles_x);
+        const int tr = tile - n * tiles_y * tiles_x;
+        const int y0 = (tr / tiles_x) * O1_TH, x0 = (tr % tiles_x) * TW;
+        fetch(n, y0, x0, 0);
+        c1_lds_barrier();                                       // the previous tile's accumulator has been written out
+        for (int i = tid; i < O1_TH * 64; i += 256) oacc[i] = 0.f;
+#pragma unroll 1
+        for (int step = 0; step < nsteps; ++step) {
+            // ---- Z of this step's 128 pixels ----
+            float xv[CQ][8];
+            float m = 0.f;
+#pragma unroll
+            for (int q = 0; q < CQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xv[q][e] = xvalid ? xr[q][e >> 2][e & 3] : 0.f;
+                    m = fmaxf(m, fabsf(xv[q][e]));
+                }
+            if (step + 1 < nsteps) fetch(n, y0, x0, step + 1);  // in flight during the multiplication
+            m = fmaxf(m, __shfl_xor(m, 32, 64));                // the pixel's two lanes
+            const int eb = ss_amax_exp(m);
+            const float sb = ldexpf(1.f, 14 - eb);
+            f32x16 acc[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) {
+                c1_u32x4 bh, bl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned int hh, ll;
+                    ss_split_h2(xv[q][2 * j] * sb, xv[q][2 * j + 1] * sb, hh, ll);
+                    bh[j] = hh;
+                    bl[j] = ll;
+                }
+                const c1_f16x8 xh = __builtin_bit_cast(c1_f16x8, bh), xl = __builtin_bit_cast(c1_f16x8, bl);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const c1_f16x8 wh = __builtin_bit_cast(c1_f16x8, Ah[cb][q]), wl = __builtin_bit_cast(c1_f16x8, Al[cb][q]);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[cb], 0, 0, 0);
+                }
+            }
+            // D: lane = pixel, register r of block cb = tap cb*32 + 8 (r>>2) + 4 lh + (r&3)  ->  tap-major stage, pixel contiguous
+            const float inv = ldexpf(1.f, ew + eb - 28);
+            float* const zb = zs + (step & 1) * (64 * O1_ZS) + hrw * 64 + hc;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zb[(cb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)) * O1_ZS] = acc[cb][r] * inv;
+            c1_lds_barrier();                                   // Z of this step complete (and the other buffer's readers of step-1 are past it)
+            // ---- tap sum: the output rows 2 step - (kh-1) .. 2 step + 1 receive from halo rows 2 step, 2 step + 1 ----
+            const float* const zr = zs + (step & 1) * (64 * O1_ZS);
+            for (int item = tid; item < (box.kh + 1) * 64; item += 256) {
+                const int x = item & 63;
+                const int o = 2 * step - (box.kh - 1) + (item >> 6);
+                if (x >= TW || o < 0 || o >= O1_TH) continue;
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int a = 2 * step + r - o;
+                    if (a < 0 || a >= box.kh) continue;
+                    const float* z = zr + (8 * a) * O1_ZS + r * 64 + x;
+                    for (int b = 0; b < box.kw; ++b) s += z[b * O1_ZS + b];
+                }
+                oacc[o * 64 + x] += s;
+            }
+        }
+        c1_lds_barrier();                                       // all contributions are in
+        for (int i = tid; i < O1_TH * 64; i += 256) {
+            const int o = i >> 6, x = i & 63;
+            const int oy = y0 + o, ox = x0 + x;
+            if (x >= TW || oy >= p.OH || ox >= p.OW) continue;
+            float* op = p.out + ((long)(n * p.OH + oy) * p.OW + ox) * p.out_cs;
+            float v = ss_apply_act(oacc[i] + bias, p.act, p.alpha);
+            if (p.accumulate) v += *op;
+            *op = v;
+        }
+    }
+}
+
 // taps must fill a KH x KW box exactly once
 bool tap_box(const GConvParams& p, C1Box* box) {
     if (p.ntaps < 1) return false;
@@ -455,12 +865,68 @@ bool ss_conv_out1_ok(const GConvParams& p) {
     return (box.kh == 7 && box.kw == 7) || (box.kh == 4 && box.kw == 4) || (box.kh == 3 && box.kw == 3);
 }
 
+namespace {
+bool out1_x3h_shape(const GConvParams& p, const C1Box& box) {
+    return ss_tuning().c1_mfma && (p.Cin == 32 || p.Cin == 64) && box.kh <= 8 && box.kw <= 8 && p.dtype == SS_DTYPE_F32;
+}
+template <int CQ>
+int launch_out1_x3h(const GConvParams& p, const C1Box& box, hipStream_t s) {
+    const size_t smem = (size_t)(2 * 64 * O1_ZS + O1_TH * 64 + 64 + 4) * sizeof(float);
+    static const bool attr_set = [] {
+        (void)hipFuncSetAttribute((const void*)conv_out1_x3h_kernel<CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+    }();
+    (void)attr_set;
+    const int TW = 64 - (box.kw - 1);
+    const int tiles_y = (p.OH + O1_TH - 1) / O1_TH, tiles_x = (p.OW + TW - 1) / TW;
+    const int ntiles = p.N * tiles_y * tiles_x;
+    hipLaunchKernelGGL((conv_out1_x3h_kernel<CQ>), dim3(ntiles < 511 ? ntiles : 511), dim3(256), smem, s, p, box, ntiles, tiles_x, tiles_y);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+}  // namespace
+
 int ss_launch_conv_out1(const GConvParams& p, hipStream_t s) {
     C1Box box;
     if (!ss_conv_out1_ok(p) || !tap_box(p, &box)) return SS_ERR_UNSUPPORTED;
+    if (out1_x3h_shape(p, box)) return p.Cin == 64 ? launch_out1_x3h<4>(p, box, s) : launch_out1_x3h<2>(p, box, s);
     if (box.kh == 7) return launch_out1<7, 7>(p, box, s);
     if (box.kh == 4) return launch_out1<4, 4>(p, box, s);
     return launch_out1<3, 3>(p, box, s);
+}
+
+// ... on the matrix cores: >= 32 output channels in multiples of 4, any full tap box up to 8 x 8
+namespace {
+bool in1_x3h_shape(const GConvParams& p, C1Box* box) {
+    if (!ss_tuning().c1_mfma || p.Cin != 1 || p.in_s != 1 || p.out_s != 1 || p.nbatch > 1 || p.Cout < 32 || p.Cout % 4 != 0 || p.out_cs % 4 != 0 ||
+        (((uintptr_t)p.out) & 15) != 0 || p.dtype != SS_DTYPE_F32) return false;
+    if (!tap_box(p, box) || box->kh > 8 || box->kw > 8) return false;
+    return true;
+}
+int launch_in1_x3h(const GConvParams& p, const C1Box& box, const C1Fold& f, hipStream_t s) {
+    const int OH = f.on ? f.XH : p.OH, OW = f.on ? f.XW : p.OW;
+    const int tiles_y = (OH + I1_TH - 1) / I1_TH, tiles_x = (OW + I1_TW - 1) / I1_TW;
+    const int ntiles = p.N * tiles_y * tiles_x;
+    const int gy = (p.Cout + 63) / 64;
+    const dim3 grid(ntiles < 511 ? ntiles : 511, gy);          // odd: the tiles of one image column (the border columns are slower) spread over all workgroups
+    if (f.on) hipLaunchKernelGGL(conv_in1_x3h_kernel<true>, grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y);
+    else hipLaunchKernelGGL(conv_in1_x3h_kernel<false>, grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+}  // namespace
+
+// data gradient of a reflection-padded Cout == 1 layer written straight into dx (p: the zero-padded problem on the PADDED grid,
+// p.in = dy, taps = -(a, b); p.out / out_cs / accumulate describe dx, whose grid is ih x iw)
+bool ss_conv_in1_fold_ok(const GConvParams& p, int pt, int pl, int ih, int iw) {
+    C1Box box;
+    return p.reflect == 0 && !p.bias && p.act == SS_ACT_NONE && (long)p.N * ih * iw >= 16384 && ih >= 2 * pt + 4 && iw >= 2 * pl + 4 && pt >= 0 && pl >= 0 && in1_x3h_shape(p, &box) &&
+           pt < box.kh && pl < box.kw && (long)p.N * ih * iw * p.out_cs < (1L << 31);
+}
+int ss_launch_conv_in1_fold(const GConvParams& p, int pt, int pl, int ih, int iw, hipStream_t s) {
+    C1Box box;
+    if (!ss_conv_in1_fold_ok(p, pt, pl, ih, iw) || !tap_box(p, &box)) return SS_ERR_UNSUPPORTED;
+    return launch_in1_x3h(p, box, C1Fold{1, pt, pl, ih, iw}, s);
 }
 
 // Cin == 1, stride 1, full tap box, Cout % 16 == 0, weights with the output channel contiguous (ldb irrelevant for one input channel)
@@ -475,6 +941,7 @@ bool ss_conv_in1_ok(const GConvParams& p) {
 int ss_launch_conv_in1(const GConvParams& p, hipStream_t s) {
     C1Box box;
     if (!ss_conv_in1_ok(p) || !tap_box(p, &box)) return SS_ERR_UNSUPPORTED;
+    if (in1_x3h_shape(p, &box)) return launch_in1_x3h(p, box, C1Fold{0, 0, 0, 0, 0}, s);
     if (box.kh == 7) return launch_in1<7, 7>(p, box, s);
     if (box.kh == 4) return launch_in1<4, 4>(p, box, s);
     return launch_in1<3, 3>(p, box, s);

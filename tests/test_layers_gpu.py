@@ -75,6 +75,13 @@ CONV_CASES = [
     ("c7_in_tiled", 7, 1, 32, 1, ("reflect", 3), False, None, False, 1, 130, 128),
     ("c4_out_tiled_valid", 4, 12, 1, 1, "valid", True, None, False, 2, 100, 96),
     ("c3_in_tiled_same_bias", 3, 1, 16, 1, "same", True, "lrelu", False, 2, 96, 100),
+    # ... with >= 32 channels on the wide side: fp16 matrix-core kernels (x3h arithmetic), the data gradient of a reflection-padded
+    # many -> 1 layer with the reflection's transpose folded into the one-channel im2col (no padded gradient, no fold pass)
+    ("c7_in_mfma_64", 7, 1, 64, 1, ("reflect", 3), False, None, False, 1, 130, 128),
+    ("c7_out_mfma_64_fold", 7, 64, 1, 1, ("reflect", 3), True, "tanh", False, 1, 128, 130),
+    ("c7_out_mfma_32_fold_ragged", 7, 32, 1, 1, ("reflect", 3), False, None, False, 2, 100, 90),
+    ("c4_out_mfma_valid_32", 4, 32, 1, 1, "valid", True, None, False, 2, 100, 96),
+    ("c3_in_mfma_same_bias_96", 3, 1, 96, 1, "same", True, "lrelu", False, 2, 96, 100),
     # >= 65536 output pixels, stride 1, <= 64 channels: LDS-staged tile kernels (conv_tile.hip): forward / data gradient on the fp16
     # matrix cores with per-tile scales, weight gradient with fp32 MFMA (the MultiResUNet's 512x512 / 256x256 layers)
     ("tile_3x3_16_16", 3, 16, 16, 1, "same", False, None, False, 1, 256, 256),

@@ -817,6 +817,221 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(C1WParams p) {
     }
 }
 
+// ---- the same weight gradient on the fp16 matrix cores ("x3h") --------------------------------------------------------------------
+// K = the pixels of a tile, both operands K-major in LDS ([pixel][channel | tap]) as 16-byte units of 4 values = 8 B of h + 8 B of l,
+// fragments by the transposing LDS read ds_read_b64_tr_b16 -- the scheme of twgrad_x3h_kernel (conv_tile.hip), with its running
+// power-of-two unit for the accumulators that live across all tiles of a workgroup:
+//  * X tile (128 pixels x 64 channels) is requested into registers one tile ahead, split under the power-of-two scale of the TILE's
+//    maximum and stored as planes (no fp32 staging);
+//  * U is built from the one-channel halo in LDS, 4 taps (one unit) of one pixel per thread and step, split under the scale of the
+//    halo's maximum (x 4 where up to four padded positions fold onto a pixel) and stored as planes; it never exists in fp32;
+//  * one 32 x 32 block of D[channel][tap] per wave, 8 K steps of 16 pixels per tile: 24 MFMAs (768 cycles) where the fp32 kernel
+//    above issues 64 (4096 cycles) for its share of a 256-pixel tile.
+constexpr int XW_TH = 2, XW_TW = 64, XW_PIX = XW_TH * XW_TW, XW_PS = 272;          // pixel stride in LDS: 16 units + 16 B (odd multiple of 16)
+typedef short c1_s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 c1_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ c1_s16x4 c1_tr4(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c1_s16x4*)p);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_c1_x3h_kernel(C1WParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xw_lds[];
+    unsigned char* const sX = xw_lds;                              // [XW_PIX][XW_PS]
+    unsigned char* const sU = xw_lds + XW_PIX * XW_PS;             // [XW_PIX][XW_PS]
+    float* const hs = (float*)(xw_lds + 2 * XW_PIX * XW_PS);       // one-channel halo [XW_TH + kh - 1][XW_TW + kw - 1]
+    __shared__ float red[8];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int cb = wave & 1, tb = wave >> 1;                      // this wave's 32 channels / 32 taps of the 64 x 64 block
+    const int c0 = blockIdx.y * 64;
+    const int HR = XW_TH + p.kh - 1, HW = XW_TW + p.kw - 1;
+    const int NT = p.kh * p.kw;
+
+    // fragment addressing (bytes), as twgrad_x3h_kernel: a lane addresses unit `quad` of K row kq of its 16-lane group
+    const int kq = (lane & 15) >> 2, quad = lane & 3, mh = (lane >> 4) & 1;
+    const int a_base = (8 * lh + kq) * XW_PS + ((cb * 32 + 16 * mh + 4 * quad) >> 2) * 16;
+    const int b_base = (8 * lh + kq) * XW_PS + ((tb * 32 + 16 * mh + 4 * quad) >> 2) * 16;
+
+    // the unit of U this thread builds: taps 4 uu .. 4 uu + 3 of pixels tid / 16 + 16 j
+    const int uu = tid & 15;
+    int ta[4], tbx[4];
+    bool tv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = 4 * uu + k;
+        tv[k] = t < NT;
+        ta[k] = tv[k] ? t / p.kw : 0;
+        tbx[k] = tv[k] ? t - ta[k] * p.kw : 0;
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int E = -(1 << 20);
+
+    // next tile's operands in registers: 8 units of X (pixel tid / 16 + 16 j, channels 4 (tid % 16) ..), 3 halo values
+    f32x4 px_[8];
+    float ph[3];
+    auto prefetch = [&](int tile) {
+        const int n = tile / (p.tiles_y * p.tiles_x);
+        const int tr = tile - n * p.tiles_y * p.tiles_x;
+        const int y0 = (tr / p.tiles_x) * XW_TH, x0 = (tr % p.tiles_x) * XW_TW;
+        const int cu = c0 + 4 * uu;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int px = (tid >> 4) + 16 * j;
+            const int qy = y0 + px / XW_TW, qx = x0 + px % XW_TW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (qy < p.XH && qx < p.XW && cu < p.C) v = *(const f32x4*)(p.X + ((long)(n * p.XH + qy) * p.XW + qx) * p.X_cs + cu);
+            px_[j] = v;
+        }
+        const int hy0 = MODE == 0 ? y0 + p.pt - (p.kh - 1) : y0 - p.pt;
+        const int hx0 = MODE == 0 ? x0 + p.pl - (p.kw - 1) : x0 - p.pl;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = tid + 256 * j;
+            const int r = idx / HW, col = idx - r * HW;
+            int sy = hy0 + r, sx = hx0 + col;
+            if (MODE == 1) { sy = ss_map_index(sy, p.SH, p.reflect); sx = ss_map_index(sx, p.SW, p.reflect); }
+            float v = 0.f;
+            if (r < HR && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW) v = p.S[((long)(n * p.SH + sy) * p.SW + sx) * p.S_cs];
+            ph[j] = v;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) prefetch(tile);
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        const int n = tile / (p.tiles_y * p.tiles_x);
+        const int tr = tile - n * p.tiles_y * p.tiles_x;
+        const int y0 = (tr / p.tiles_x) * XW_TH, x0 = (tr % p.tiles_x) * XW_TW;
+        // tile maxima from the registers
+        float ma = 0.f, mu = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ma = fmaxf(ma, fmaxf(fmaxf(fabsf(px_[j][0]), fabsf(px_[j][1])), fmaxf(fabsf(px_[j][2]), fabsf(px_[j][3]))));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mu = fmaxf(mu, fabsf(ph[j]));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, off, 64)); mu = fmaxf(mu, __shfl_xor(mu, off, 64)); }
+        c1_lds_barrier();                                        // the previous tile's fragments have been read (and `red`)
+        if (lane == 0) { red[wave] = ma; red[4 + wave] = mu; }
+        c1_lds_barrier();
+        ma = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        mu = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        const bool live = ma > 0.f && mu > 0.f;                  // uniform over the workgroup
+        float sa = 0.f, sb = 0.f;
+        if (live) {
+            const int ea = ss_amax_exp(ma), eb = ss_amax_exp(mu) + ((MODE == 0 && p.reflect) ? 2 : 0);
+            const int et = ea + eb;
+            int shift = 0;
+            if (et > E) {
+                if (E > -(1 << 19)) {
+                    const float fr = ldexpf(1.f, (E - et) < -126 ? -126 : (E - et));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] *= fr;
+                }
+                E = et;
+            } else {
+                shift = et - E;
+                if (shift < -60) shift = -60;
+            }
+            sa = ldexpf(1.f, 14 - ea);
+            sb = ldexpf(1.f, 14 - eb + shift);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int px = (tid >> 4) + 16 * j;
+                c1_f16x4 h, l;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float x = px_[j][k] * sa; h[k] = (_Float16)x; l[k] = (_Float16)(x - (float)h[k]); }
+                unsigned char* u = sX + px * XW_PS + uu * 16;
+                *(c1_f16x4*)u = h;
+                *(c1_f16x4*)(u + 8) = l;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int idx = tid + 256 * j;
+                if (idx < HR * HW) hs[idx] = ph[j];
+            }
+        }
+        if (tile + (int)gridDim.x < p.ntiles) prefetch(tile + gridDim.x);      // in flight while U is built and the tile is multiplied
+        c1_lds_barrier();                                        // halo visible
+        if (live) {
+            const int hy0 = MODE == 0 ? y0 + p.pt - (p.kh - 1) : y0 - p.pt;
+            const int hx0 = MODE == 0 ? x0 + p.pl - (p.kw - 1) : x0 - p.pl;
+#pragma unroll 2
+            for (int j = 0; j < 8; ++j) {
+                const int px = (tid >> 4) + 16 * j;
+                const int ry = px / XW_TW, rx = px % XW_TW;
+                const int qy = y0 + ry, qx = x0 + rx;
+                float u4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (qy < p.XH && qx < p.XW) {
+                    if (MODE == 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (tv[k]) u4[k] = hs[(ry + ta[k]) * HW + (rx + tbx[k])];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (tv[k]) u4[k] = hs[(ry + p.kh - 1 - ta[k]) * HW + (rx + p.kw - 1 - tbx[k])];
+                        const bool top = 2 * qy < p.XH, left = 2 * qx < p.XW;
+                        const bool ay = p.reflect && (top ? (qy >= 1 && qy <= p.pt) : (qy <= p.XH - 2 && qy >= p.XH - 1 - p.pt));
+                        const bool ax = p.reflect && (left ? (qx >= 1 && qx <= p.pl) : (qx <= p.XW - 2 && qx >= p.XW - 1 - p.pl));
+                        if (ay || ax) {
+                            // border pixel: besides q itself at most ONE more padded row and ONE more padded column reflect onto q
+                            const int y2 = top ? -qy : 2 * (p.XH - 1) - qy;
+                            const int x2 = left ? -qx : 2 * (p.XW - 1) - qx;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                if (!tv[k]) continue;
+                                auto h = [&](int y, int x) -> float {
+                                    const int hr = y + p.pt - ta[k] - hy0, hc = x + p.pl - tbx[k] - hx0;      // outside the halo = outside dy
+                                    return (hr >= 0 && hr < HR && hc >= 0 && hc < HW) ? hs[hr * HW + hc] : 0.f;
+                                };
+                                if (ay) u4[k] += h(y2, qx);
+                                if (ax) u4[k] += h(qy, x2);
+                                if (ay && ax) u4[k] += h(y2, x2);
+                            }
+                        }
+                    }
+                }
+                c1_f16x4 h, l;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float x = u4[k] * sb; h[k] = (_Float16)x; l[k] = (_Float16)(x - (float)h[k]); }
+                unsigned char* u = sU + px * XW_PS + uu * 16;
+                *(c1_f16x4*)u = h;
+                *(c1_f16x4*)(u + 8) = l;
+            }
+        }
+        c1_lds_barrier();                                        // planes complete
+        if (live) {
+#pragma unroll
+            for (int ks = 0; ks < XW_PIX / 16; ++ks) {
+                const unsigned char* ap = sX + ks * 16 * XW_PS + a_base;
+                const unsigned char* bp = sU + ks * 16 * XW_PS + b_base;
+                const c1_s16x4 ah0 = c1_tr4(ap), ah1 = c1_tr4(ap + 4 * XW_PS), al0 = c1_tr4(ap + 8), al1 = c1_tr4(ap + 4 * XW_PS + 8);
+                const c1_s16x4 bh0 = c1_tr4(bp), bh1 = c1_tr4(bp + 4 * XW_PS), bl0 = c1_tr4(bp + 8), bl1 = c1_tr4(bp + 4 * XW_PS + 8);
+                const c1_f16x8 ah = __builtin_bit_cast(c1_f16x8, __builtin_shufflevector(ah0, ah1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const c1_f16x8 al = __builtin_bit_cast(c1_f16x8, __builtin_shufflevector(al0, al1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const c1_f16x8 bh = __builtin_bit_cast(c1_f16x8, __builtin_shufflevector(bh0, bh1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const c1_f16x8 bl = __builtin_bit_cast(c1_f16x8, __builtin_shufflevector(bl0, bl1, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            }
+        }
+    }
+    // D[row = channel][col = tap] in the unit 2^(E - 28): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const float unit = E > -(1 << 19) ? ldexpf(1.f, (E - 28) < -126 ? -126 : (E - 28)) : 0.f;
+    const int t = tb * 32 + l31;
+    if (t < NT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (c < p.C) p.part[((long)blockIdx.x * NT + t) * p.C + c] = acc[r] * unit;
+        }
+    }
+}
+
 // dw[t][c] (+)= sum over blocks (in block order) of part[blk][t][c]
 __global__ __launch_bounds__(256) void wgrad_c1_reduce_kernel(const float* __restrict__ part, int nblk, int total, float* __restrict__ dw,
                                                               int accumulate) {
@@ -847,6 +1062,23 @@ int launch_wgrad_c1(const C1WParams& p, float* dw, int accumulate, hipStream_t s
     (void)attr_set;
     const int nblk = c1w_blocks(p.ntiles);
     hipLaunchKernelGGL((wgrad_c1_kernel<MODE>), dim3(nblk, (p.C + 63) / 64), dim3(256), smem, s, p);
+    SS_LAUNCH_CHECK();
+    const int total = p.kh * p.kw * p.C;
+    hipLaunchKernelGGL(wgrad_c1_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p.part, nblk, total, dw, accumulate);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+template <int MODE>
+int launch_wgrad_c1_x3h(const C1WParams& p, float* dw, int accumulate, hipStream_t s) {
+    const size_t smem = (size_t)2 * XW_PIX * XW_PS + (size_t)(XW_TH + p.kh - 1) * (XW_TW + p.kw - 1) * sizeof(float);
+    static const bool attr_set = [] {
+        (void)hipFuncSetAttribute((const void*)wgrad_c1_x3h_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);      // + the static `red`
+        return true;
+    }();
+    (void)attr_set;
+    const int nblk = c1w_blocks(p.ntiles);
+    hipLaunchKernelGGL((wgrad_c1_x3h_kernel<MODE>), dim3(nblk, (p.C + 63) / 64), dim3(256), smem, s, p);
     SS_LAUNCH_CHECK();
     const int total = p.kh * p.kw * p.C;
     hipLaunchKernelGGL(wgrad_c1_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p.part, nblk, total, dw, accumulate);
@@ -955,7 +1187,7 @@ bool ss_wgrad_c1_ok(int n, int xh, int xw, int C, int kh, int kw) {
 }
 
 size_t ss_wgrad_c1_ws(int n, int xh, int xw, int C, int kh, int kw) {
-    const long ntiles = (long)n * ((xh + C1W_TH - 1) / C1W_TH) * ((xw + C1W_TW - 1) / C1W_TW);
+    const long ntiles = (long)n * ((xh + XW_TH - 1) / XW_TH) * ((xw + XW_TW - 1) / XW_TW);          // the smaller tiles of the two kernels: more partials
     return ss_align_up((size_t)c1w_blocks(ntiles) * kh * kw * C * sizeof(float), 256);
 }
 
@@ -966,6 +1198,13 @@ int ss_launch_wgrad_c1(int mode, const float* X, int X_cs, int C, int n, int xh,
     p.N = n; p.XH = xh; p.XW = xw; p.C = C; p.X_cs = X_cs;
     p.SH = sh; p.SW = sw; p.S_cs = S_cs;
     p.kh = kh; p.kw = kw; p.pt = pt; p.pl = pl; p.reflect = reflect;
+    if (ss_tuning().c1_mfma && C % 4 == 0 && X_cs % 4 == 0 && (((uintptr_t)X) & 15) == 0 && (XW_TH + kh - 1) * (XW_TW + kw - 1) <= 768 &&
+        xh >= 2 * pt + 4 && xw >= 2 * pl + 4) {
+        p.tiles_y = (xh + XW_TH - 1) / XW_TH;
+        p.tiles_x = (xw + XW_TW - 1) / XW_TW;
+        p.ntiles = n * p.tiles_y * p.tiles_x;
+        return mode == 0 ? launch_wgrad_c1_x3h<0>(p, dw, accumulate, s) : launch_wgrad_c1_x3h<1>(p, dw, accumulate, s);
+    }
     p.tiles_y = (xh + C1W_TH - 1) / C1W_TH;
     p.tiles_x = (xw + C1W_TW - 1) / C1W_TW;
     p.ntiles = n * p.tiles_y * p.tiles_x;

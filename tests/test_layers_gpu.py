@@ -82,6 +82,11 @@ CONV_CASES = [
     ("c7_out_mfma_32_fold_ragged", 7, 32, 1, 1, ("reflect", 3), False, None, False, 2, 100, 90),
     ("c4_out_mfma_valid_32", 4, 32, 1, 1, "valid", True, None, False, 2, 100, 96),
     ("c3_in_mfma_same_bias_96", 3, 1, 96, 1, "same", True, "lrelu", False, 2, 96, 100),
+    # >= 65536 pixels: their weight gradient on the fp16 matrix cores as well (wgrad_c1_x3h_kernel: K-major planes, transposing LDS reads)
+    ("c7_out_wgrad_64", 7, 64, 1, 1, ("reflect", 3), True, "tanh", False, 1, 256, 260),
+    ("c7_in_wgrad_64_ragged", 7, 1, 64, 1, ("reflect", 3), False, None, False, 1, 259, 256),
+    ("c3_in_wgrad_32_same", 3, 1, 32, 1, "same", False, None, False, 2, 200, 180),
+    ("c4_out_wgrad_valid_32", 4, 32, 1, 1, "valid", True, None, False, 1, 260, 256),
     # >= 65536 output pixels, stride 1, <= 64 channels: LDS-staged tile kernels (conv_tile.hip): forward / data gradient on the fp16
     # matrix cores with per-tile scales, weight gradient with fp32 MFMA (the MultiResUNet's 512x512 / 256x256 layers)
     ("tile_3x3_16_16", 3, 16, 16, 1, "same", False, None, False, 1, 256, 256),

@@ -211,56 +211,69 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd(const float* __restrict
     }
 }
 
-// y = act((x-mean)*rstd*gamma + beta + residual); one thread = V channels of one pixel, grid-stride
+// y = act((x-mean)*rstd*gamma + beta + residual)
+// CHANNEL-STATIONARY threads: thread = V consecutive channels (lane ct of CT) x a strided set of the rows of ONE group; grid =
+// (row chunks, channel blocks, groups).  The per-channel operands (mean, rstd * gamma, beta) are loaded once and stay in registers:
+// the flat grid-strided form re-gathered them for every element (5 loads + 1 store per vector: the kernel was paced by the
+// vector-memory instruction rate, 3.7 TB/s on the trunk tensors and 1.7 TB/s on the odd-width MultiResUNet tensors), four rows are
+// in flight per thread.  Row chunks are handed out from the END (block 0 takes the last one): the statistics pass before this
+// kernel walked the tensor front to back, so its tail is what the 256 MiB Infinity Cache still holds.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x, int x_cs,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const T* __restrict__ res, int res_cs,
                                                          T* __restrict__ y, int y_cs,
-                                                         int act, float alpha, int C, long P, long rows,
+                                                         int act, float alpha, int C, long P, int CT, int PT, long rows_per_chunk,
                                                          unsigned int* __restrict__ amax = nullptr) {
-    const int CV = C / V;
-    const long total = rows * CV;
+    const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
+    const int c = (blockIdx.y * CT + ct) * V;
+    const int g = blockIdx.z;
+    const long p0 = (long)(gridDim.x - 1 - blockIdx.x) * rows_per_chunk;
+    const long p1 = p0 + rows_per_chunk < P ? p0 + rows_per_chunk : P;
     float am = 0.f;
-    // (row, channel vector) of element e advance incrementally: one 64-bit division per thread instead of two per element (the
-    // single-channel-vector instantiation, odd MultiResUNet widths, was paced by them)
-    // A block owns ONE contiguous slice of the tensor and the slices are handed out from the END (block 0 takes the last one): the
-    // statistics pass before this kernel walked the tensor front to back, so its tail is what the 256 MiB Infinity Cache still
-    // holds -- walking back to front turns those reads into hits (a grid-strided walk touched every part of the tensor at once).
-    const long stride = blockDim.x;
-    const long per = ((total + gridDim.x - 1) / gridDim.x + stride - 1) / stride * stride;
-    const long slice = (long)(gridDim.x - 1 - blockIdx.x) * per;
-    const long end = slice + per < total ? slice + per : total;
-    const long drow = stride / CV;
-    const int dcv = (int)(stride - drow * CV);
-    const long dg = drow / P, drp = drow - dg * P;              // ... and (group, pixel within the group) of the row
-    long e = slice + threadIdx.x;
-    long row = e / CV;
-    int cv = (int)(e - row * CV);
-    long grp = row / P, rp = row - grp * P;
-    for (; e < end; e += stride, row += drow, cv += dcv, grp += dg, rp += drp) {
-        if (cv >= CV) { cv -= CV; ++row; ++rp; }
-        if (rp >= P) { rp -= P; ++grp; }
-        const int c = cv * V;
-        const long gi = grp * C + c;
-        float xv[V], mu[V], rs[V], bt[V], gm[V], rv[V], o[V];
-        ldv<V>(x + row * x_cs + c, xv);
+    if (c < C && pt < PT) {
+        const long gi = (long)g * C + c;
+        float mu[V], kk[V], bt[V], gm[V];
         ldv<V>(mean + gi, mu);
-        ldv<V>(rstd + gi, rs);
+        ldv<V>(rstd + gi, kk);
         ldv<V>(beta + c, bt);
-        if (gamma) ldv<V>(gamma + c, gm);
-        if (res) ldv<V>(res + row * res_cs + c, rv);
+        if (gamma) {
+            ldv<V>(gamma + c, gm);
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            // explicit fma: a convolution that normalises in its operand load (conv_wino.hip, ss_conv_desc::in_norm_*) forms the same
-            // expression and must produce the same bits
-            float t = __builtin_fmaf(xv[v] - mu[v], rs[v] * (gamma ? gm[v] : 1.f), bt[v]);
-            if (res) t += rv[v];
-            o[v] = ss_apply_act(t, act, alpha);
-            am = fmaxf(am, fabsf((float)(T)o[v]));          // what is stored: rounded to the storage type
+            for (int v = 0; v < V; ++v) kk[v] *= gm[v];
         }
-        stv<V>(y + row * y_cs + c, o);
+        const T* const xb = x + (long)g * P * x_cs + c;
+        const T* const rb = res ? res + (long)g * P * res_cs + c : nullptr;
+        T* const yb = y + (long)g * P * y_cs + c;
+        for (long p = p0 + pt; p < p1; p += 4L * PT) {
+            float xv[4][V], rv[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long q = p + (long)u * PT;
+                if (q < p1) {
+                    ldv<V>(xb + q * x_cs, xv[u]);
+                    if (res) ldv<V>(rb + q * res_cs, rv[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long q = p + (long)u * PT;
+                if (q < p1) {
+                    float o[V];
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        // explicit fma: a convolution that normalises in its operand load (conv_wino.hip, ss_conv_desc::in_norm_*) forms the
+                        // same expression and must produce the same bits
+                        float t = __builtin_fmaf(xv[u][v] - mu[v], kk[v], bt[v]);
+                        if (res) t += rv[u][v];
+                        o[v] = ss_apply_act(t, act, alpha);
+                        am = fmaxf(am, fabsf((float)(T)o[v]));          // what is stored: rounded to the storage type
+                    }
+                    stv<V>(yb + q * y_cs, o);
+                }
+            }
+        }
     }
     if (amax) ss_block_amax_to_slot(am, amax);
 }
@@ -321,7 +334,8 @@ __global__ __launch_bounds__(256) void norm_finalize_bwd(const float* __restrict
     }
 }
 
-// dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) ; dres = g
+// dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) ; dres = g.  Channel-stationary threads as norm_apply_kernel: the seven
+// per-channel operands live in registers (the flat form issued 8 + 2 V loads per vector for them).
 template <typename T, int V>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ dy, int dy_cs,
                                                              const T* __restrict__ x, int x_cs,
@@ -331,76 +345,90 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              const float* __restrict__ sums,
                                                              T* __restrict__ dx, int dx_cs, int acc_dx,
                                                              T* __restrict__ dres, int dres_cs, int acc_dres,
-                                                             int act, float alpha, int C, long P, long rows,
+                                                             int act, float alpha, int C, long P, int CT, int PT, long rows_per_chunk,
                                                              const float* __restrict__ rbeta = nullptr, unsigned int* __restrict__ amax = nullptr,
                                                              const double* __restrict__ rt = nullptr, int G = 0,
                                                              float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr,
                                                              int acc_params = 0) {
-    const int CV = C / V;
-    const long total = rows * CV;
     float am = 0.f;
-    const long stride = blockDim.x;          // contiguous slices handed out from the end, incremental (row, channel vector): see norm_apply_kernel
     if (rt) {          // parameter gradients: the per-group totals of norm_finalize_bwd summed in group order (one thread per channel)
-        for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += (long)gridDim.x * blockDim.x) {
+        const long nblk = (long)gridDim.x * gridDim.y * gridDim.z;
+        const long blk = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
+        for (long c = blk * blockDim.x + threadIdx.x; c < C; c += nblk * blockDim.x) {
             double tg = 0.0, tgx = 0.0;
             for (int g = 0; g < G; ++g) { tg += rt[((long)g * C + c) * 2]; tgx += rt[((long)g * C + c) * 2 + 1]; }
             if (dbeta) dbeta[c] = acc_params ? dbeta[c] + (float)tg : (float)tg;
             if (dgamma) dgamma[c] = acc_params ? dgamma[c] + (float)tgx : (float)tgx;
         }
     }
-    const long per = ((total + gridDim.x - 1) / gridDim.x + stride - 1) / stride * stride;
-    const long slice = (long)(gridDim.x - 1 - blockIdx.x) * per;
-    const long end = slice + per < total ? slice + per : total;
-    const long drow = stride / CV;
-    const int dcv = (int)(stride - drow * CV);
-    const long dg = drow / P, drp = drow - dg * P;              // ... and (group, pixel within the group) of the row
-    long e = slice + threadIdx.x;
-    long row = e / CV;
-    int cv = (int)(e - row * CV);
-    long grp = row / P, rp = row - grp * P;
-    for (; e < end; e += stride, row += drow, cv += dcv, grp += dg, rp += drp) {
-        if (cv >= CV) { cv -= CV; ++row; ++rp; }
-        if (rp >= P) { rp -= P; ++grp; }
-        const int c = cv * V;
-        const long gi = grp * C + c;
-        float gv[V], xv[V], yv[V], mu[V], rs[V], gm[V], sm[2 * V], o[V], r[V];
-        ldv<V>(dy + row * dy_cs + c, gv);
-        ldv<V>(x + row * x_cs + c, xv);
+    const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
+    const int c = (blockIdx.y * CT + ct) * V;
+    const int g = blockIdx.z;
+    const long p0 = (long)(gridDim.x - 1 - blockIdx.x) * rows_per_chunk;
+    const long p1 = p0 + rows_per_chunk < P ? p0 + rows_per_chunk : P;
+    if (c < C && pt < PT) {
+        const long gi = (long)g * C + c;
+        float mu[V], rs[V], gm[V], bt[V], sm[2 * V];
         ldv<V>(mean + gi, mu);
         ldv<V>(rstd + gi, rs);
+#pragma unroll
+        for (int v = 0; v < V; ++v) { gm[v] = 1.f; bt[v] = 0.f; }
         if (gamma) ldv<V>(gamma + c, gm);
 #pragma unroll
         for (int v = 0; v < V; ++v) { sm[2 * v] = sums[(gi + v) * 2]; sm[2 * v + 1] = sums[(gi + v) * 2 + 1]; }
-        if (act != SS_ACT_NONE && y == nullptr) {          // mask recomputed from x (see norm_stats_kernel)
-            float bt[V];
-            ldv<V>(rbeta + c, bt);
+        const bool recompute = act != SS_ACT_NONE && y == nullptr;          // mask recomputed from x (see norm_stats_kernel)
+        const bool from_y = act != SS_ACT_NONE && y != nullptr;
+        if (recompute) ldv<V>(rbeta + c, bt);
+        const T* const gb = dy + (long)g * P * dy_cs + c;
+        const T* const xb = x + (long)g * P * x_cs + c;
+        const T* const yb = from_y ? y + (long)g * P * y_cs + c : nullptr;
+        T* const ob = dx + (long)g * P * dx_cs + c;
+        T* const rb = dres ? dres + (long)g * P * dres_cs + c : nullptr;
+        for (long p = p0 + pt; p < p1; p += 4L * PT) {
+            float gv[4][V], xv[4][V], yv[4][V], o[4][V], r[4][V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const float t = (xv[v] - mu[v]) * (rs[v] * (gamma ? gm[v] : 1.f)) + bt[v];
-                gv[v] *= ss_act_grad_from_out(t, act, alpha);
+            for (int u = 0; u < 4; ++u) {
+                const long q = p + (long)u * PT;
+                if (q < p1) {
+                    ldv<V>(gb + q * dy_cs, gv[u]);
+                    ldv<V>(xb + q * x_cs, xv[u]);
+                    if (from_y) ldv<V>(yb + q * y_cs, yv[u]);
+                    if (acc_dx) ldv<V>(ob + q * dx_cs, o[u]);
+                    if (dres && acc_dres) ldv<V>(rb + q * dres_cs, r[u]);
+                }
             }
-        } else if (act != SS_ACT_NONE) {
-            ldv<V>(y + row * y_cs + c, yv);
 #pragma unroll
-            for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out(yv[v], act, alpha);
-        }
-        if (acc_dx) ldv<V>(dx + row * dx_cs + c, o);
+            for (int u = 0; u < 4; ++u) {
+                const long q = p + (long)u * PT;
+                if (q < p1) {
+                    if (recompute) {
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            const float xh = (xv[v] - mu[v]) * rs[v];
-            const float dv = rs[v] * (gamma ? gm[v] : 1.f) * (gv[v] - sm[2 * v] - xh * sm[2 * v + 1]);
-            o[v] = acc_dx ? o[v] + dv : dv;
-            am = fmaxf(am, fabsf((float)(T)o[v]));          // what is stored: rounded to the storage type
-        }
-        stv<V>(dx + row * dx_cs + c, o);
-        if (dres) {
-            if (acc_dres) {
-                ldv<V>(dres + row * dres_cs + c, r);
+                        for (int v = 0; v < V; ++v) {
+                            const float t = (xv[u][v] - mu[v]) * (rs[v] * (gamma ? gm[v] : 1.f)) + bt[v];
+                            gv[u][v] *= ss_act_grad_from_out(t, act, alpha);
+                        }
+                    } else if (from_y) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) r[v] += gv[v];
-                stv<V>(dres + row * dres_cs + c, r);
-            } else {
-                stv<V>(dres + row * dres_cs + c, gv);
+                        for (int v = 0; v < V; ++v) gv[u][v] *= ss_act_grad_from_out(yv[u][v], act, alpha);
+                    }
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const float xh = (xv[u][v] - mu[v]) * rs[v];
+                        const float dv = rs[v] * (gamma ? gm[v] : 1.f) * (gv[u][v] - sm[2 * v] - xh * sm[2 * v + 1]);
+                        o[u][v] = acc_dx ? o[u][v] + dv : dv;
+                        am = fmaxf(am, fabsf((float)(T)o[u][v]));          // what is stored: rounded to the storage type
+                    }
+                    stv<V>(ob + q * dx_cs, o[u]);
+                    if (dres) {
+                        if (acc_dres) {
+#pragma unroll
+                            for (int v = 0; v < V; ++v) r[u][v] += gv[u][v];
+                            stv<V>(rb + q * dres_cs, r[u]);
+                        } else {
+                            stv<V>(rb + q * dres_cs, gv[u]);
+                        }
+                    }
+                }
             }
         }
     }
@@ -662,6 +690,27 @@ inline bool norm_small(const ss_norm_desc* d) {
 }
 
 inline bool al16(const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }
+// grid of the channel-stationary apply kernels: (row chunks, channel blocks, groups); CT channel lanes (of V channels) x PT row lanes
+struct ApplyGeom { int CT, PT; long rows_per_chunk; dim3 grid; };
+inline ApplyGeom apply_geom(const NormGeom& g, int V) {
+    ApplyGeom a;
+    const int cv = (g.C + V - 1) / V;
+    const int cblocks = (cv + 255) / 256;
+    a.CT = (cv + cblocks - 1) / cblocks;
+    a.PT = 256 / a.CT;
+    long want = 2048 / ((long)g.G * cblocks);              // ~8 blocks per CU in total
+    if (want < 1) want = 1;
+    const long sweep = 4L * a.PT;                          // rows one block takes per (4-fold unrolled) iteration
+    long maxchunks = (g.P + 4 * sweep - 1) / (4 * sweep);  // at least four iterations per thread: the operand set-up is amortised
+    if (maxchunks < 1) maxchunks = 1;
+    long chunks = want < maxchunks ? want : maxchunks;
+    long rpc = (g.P + chunks - 1) / chunks;
+    rpc = (rpc + a.PT - 1) / a.PT * a.PT;
+    chunks = (g.P + rpc - 1) / rpc;
+    a.rows_per_chunk = rpc;
+    a.grid = dim3((unsigned)chunks, (unsigned)cblocks, (unsigned)g.G);
+    return a;
+}
 inline unsigned apply_grid(long total) {
     long b = (total + 255) / 256;
     const long cap = 256L * 32;
@@ -753,13 +802,13 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
                        part, chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum, fcl);
     SS_LAUNCH_CHECK();
     if (!y) return SS_OK;
-    const long rows = (long)g.G * g.P;
+    const ApplyGeom ag = apply_geom(g, V);
     if (V == 4)
-        hipLaunchKernelGGL((norm_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows, yam);
+        hipLaunchKernelGGL((norm_apply_kernel<T, 4>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam);
     else
-        hipLaunchKernelGGL((norm_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows, yam);
+        hipLaunchKernelGGL((norm_apply_kernel<T, 1>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -773,13 +822,13 @@ int norm_apply_t(const ss_norm_desc* d, const T* x, const float* gamma, const fl
     const int V = pick_v(d->c, {d->x_cstride, d->y_cstride, residual ? d->res_cstride : 0}, {x, y, residual, gamma, beta, mean, rstd});
     const NormGeom g = geom(d, V);
     unsigned int* yam = (unsigned int*)d->y_amax;
-    const long rows = (long)g.G * g.P;
+    const ApplyGeom ag = apply_geom(g, V);
     if (V == 4)
-        hipLaunchKernelGGL((norm_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows, yam);
+        hipLaunchKernelGGL((norm_apply_kernel<T, 4>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam);
     else
-        hipLaunchKernelGGL((norm_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows, yam);
+        hipLaunchKernelGGL((norm_apply_kernel<T, 1>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -842,16 +891,16 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
     hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + fcl - 1) / fcl, g.G), dim3(256), 0, s,
                        part, g.chunks, g.G, g.C, g.P, sums, rt, fcl);
     SS_LAUNCH_CHECK();
-    const long rows = (long)g.G * g.P;
+    const ApplyGeom ag = apply_geom(g, V);
     const double* prt = (dgamma || dbeta) ? rt : nullptr;
     if (V == 4)
-        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), ag.grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, rows, beta, dxam, prt, g.G, dgamma, dbeta, accumulate_params);
+                           d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, beta, dxam, prt, g.G, dgamma, dbeta, accumulate_params);
     else
-        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), ag.grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, rows, beta, dxam, prt, g.G, dgamma, dbeta, accumulate_params);
+                           d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, beta, dxam, prt, g.G, dgamma, dbeta, accumulate_params);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -892,13 +941,13 @@ int norm_fwd_finish_t(const ss_norm_desc* d, const T* x, const float* gamma, con
     hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + FIN_CL - 1) / FIN_CL, g.G), dim3(256), 0, s,
                        sums, 1, g.G, g.C, (long)total_count, d->eps, mean, rstd, moving_mean, moving_var, momentum, FIN_CL);
     SS_LAUNCH_CHECK();
-    const long rows = (long)g.G * g.P;
+    const ApplyGeom ag = apply_geom(g, V);
     if (V == 4)
-        hipLaunchKernelGGL((norm_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
+        hipLaunchKernelGGL((norm_apply_kernel<T, 4>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk);
     else
-        hipLaunchKernelGGL((norm_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, rows);
+        hipLaunchKernelGGL((norm_apply_kernel<T, 1>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -945,15 +994,15 @@ int norm_bwd_finish_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, co
     hipLaunchKernelGGL(norm_finalize_bwd_sync, dim3((g.C + 255) / 256), dim3(256), 0, s, global_sums, local_sums, g.G, g.C,
                        (double)total_count, means, dgamma, dbeta, accumulate_params);
     SS_LAUNCH_CHECK();
-    const long rows = (long)g.G * g.P;
+    const ApplyGeom ag = apply_geom(g, V);
     if (V == 4)
-        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), dim3(apply_grid(rows * g.C / 4)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), ag.grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, means, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, rows);
+                           d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk);
     else
-        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(apply_grid(rows * g.C)), dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), ag.grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, means, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, rows);
+                           d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -164,6 +164,8 @@ struct GConvParams {
     const unsigned int* h_amax2;  //      ... of max|weights| (always one word)
     int amax_stripes;             // h_amax is the maximum over this many words, SS_AMAX_STRIDE apart (0 / 1: one word)
     int32_t dtype;                // ss_dtype of `in` / `out` (the pointers are reinterpreted); only the tile kernels take 16-bit storage
+    float* stats;                 // optional: [N][stats_chunks][Cout][2] partial (sum, sum of squares) of the stored output for a following norm
+    int32_t stats_chunks;         //   (ss_conv_desc::y_stats); only kernels that report chunks for the problem (gconv_stats_chunks) write it
     GTap taps[SS_MAX_TAPS];
 };
 
@@ -268,6 +270,7 @@ bool ss_conv_out1_ok(const GConvParams& p);
 int ss_launch_conv_out1(const GConvParams& p, hipStream_t s);
 bool ss_conv_in1_ok(const GConvParams& p);
 int ss_launch_conv_in1(const GConvParams& p, hipStream_t s);
+int ss_conv_in1_stats_chunks(const GConvParams& p);          // chunks per sample of GConvParams::stats the 1 -> C kernel writes (0: none)
 // data gradient of a reflection-padded Cout == 1 layer with the fold applied to the one-channel side (conv_c1.hip)
 bool ss_conv_in1_fold_ok(const GConvParams& p, int pt, int pl, int ih, int iw);
 int ss_launch_conv_in1_fold(const GConvParams& p, int pt, int pl, int ih, int iw, hipStream_t s);
@@ -283,6 +286,7 @@ int ss_x6_npad(int cout);
 size_t ss_gconv_x6_planes_bytes(const GConvParams& p);      // [3][nbatch][npad(Cout)][ntaps*Cin] bf16
 int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s);
 bool ss_gconv_x6v2_ok(const GConvParams& p);
+int ss_gconv_x6v2_stats_chunks(const GConvParams& p);        // chunks per sample of GConvParams::stats gconv_x6v2 writes (0: none)
 int ss_launch_gconv_x6v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s);
 int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipStream_t s);
 bool ss_wgrad_x6_ok(const WGradParams& p);

@@ -422,6 +422,10 @@ int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStre
         if (ss_conv_out1_ok(p)) return ss_launch_conv_out1(p, s);
         if (ss_conv_in1_ok(p)) return ss_launch_conv_in1(p, s);
     }
+    if (p.stats && !(use_x6(algo, p) && ss_gconv_x6v2_ok(p) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p))) {
+        ss_set_error("conv2d_fwd: y_stats was promised (ss_conv2d_stats_chunks) but this launch cannot take the kernel that writes it (workspace / operand alignment)");
+        return SS_ERR_UNSUPPORTED;
+    }
     if (tconv_takes(algo, p) && ws && ws_bytes >= ss_tconv_ws(p)) return ss_launch_tconv(p, ws, ws_bytes, s);
     if (gconv_two_stage(algo, p)) {
         if (!ws || ws_bytes < gconv_ws_bytes(algo, p)) return SS_ERR_WORKSPACE;
@@ -502,6 +506,21 @@ bool wino_dgrad_prob(const ConvProb& c, int algo, WinoProb* q) {
     return ss_wino_ok(*q);
 }
 
+// Chunks per sample of output statistics the NON-Winograd forward of `c` emits (ss_conv_desc::y_stats): the kernel run_gconv will
+// pick must be one that writes them -- the 1 -> C matrix-core kernel (conv_c1.hip) or gconv_x6v2 on the x3h path.  Shape-only: the
+// same answer with and without pointers (operand alignment is the caller's promise, checked again at launch).
+int gconv_stats_chunks(const ConvProb& c, int algo) {
+    if (c.kh * c.kw > SS_MAX_TAPS || (algo != SS_ALGO_AUTO && algo != SS_ALGO_X6) || c.in_norm.groups > 0) return 0;
+    GConvParams p = fwd_params(c, nullptr, nullptr, nullptr, nullptr, SS_ACT_NONE, 0.f, 0);
+    if (ss_conv_out1_ok(p)) return 0;
+    if (ss_conv_in1_ok(p)) return ss_conv_in1_stats_chunks(p);
+    if (tconv_takes(algo, p) || gconv_two_stage(algo, p) || !need_x_amax_fwd(c, algo)) return 0;
+    static const unsigned int dummy = 0;
+    p.h_amax = &dummy; p.h_amax2 = &dummy; p.amax_stripes = 1;
+    if (!use_x6(algo, p) || !ss_gconv_x6v2_ok(p)) return 0;
+    return ss_gconv_x6v2_stats_chunks(p);
+}
+
 size_t fwd_ws(const ConvProb& c, int algo) {
     if (c.kh * c.kw > SS_MAX_TAPS) return 0;
     WinoProb q;
@@ -525,6 +544,10 @@ int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bia
     }
     if (c.in_norm.groups > 0) { ss_set_error("in_norm: this forward pass does not normalise in its operand load (ss_conv2d_fuses_in_norm)"); return SS_ERR_UNSUPPORTED; }
     GConvParams p = fwd_params(c, x, w, bias, y, act, alpha, accumulate);
+    if (c.y_stats && act == SS_ACT_NONE && !accumulate) {
+        p.stats_chunks = gconv_stats_chunks(c, algo);
+        if (p.stats_chunks > 0) p.stats = c.y_stats;
+    }
     if (need_x_amax_fwd(c, algo) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p) + 256) {
         unsigned int* sl = (unsigned int*)((char*)ws + ss_gconv_x6_planes_bytes(p));
         const bool fill_only = c.wc && c.wc->fill_only;
@@ -949,12 +972,14 @@ size_t conv2d_wcache_bytes32(const ss_conv_desc* d, int pass) {
     const ConvProb c = d->transposed ? adjoint(d) : plain(d);
     return fwd_like ? fwd_wcache(c, d->algo) : bwd_data_wcache(c, d->algo);
 }
-// chunks per sample of the output statistics the forward pass can emit (ss_conv_desc::y_stats): Winograd forward only
+// chunks per sample of the output statistics the forward pass can emit (ss_conv_desc::y_stats): Winograd forward, the 1 -> C matrix-core
+// kernel, gconv_x6v2
 int conv2d_stats_chunks32(const ss_conv_desc* d) {
     if (!valid_desc(d) || d->transposed || d->act != SS_ACT_NONE) return 0;
     const ConvProb c = plain(d);
     WinoProb q;
-    if (c.kh * c.kw > SS_MAX_TAPS || !wino_fwd_prob(c, d->algo, &q)) return 0;
+    if (c.kh * c.kw > SS_MAX_TAPS) return 0;
+    if (!wino_fwd_prob(c, d->algo, &q)) return gconv_stats_chunks(c, d->algo);
     return ss_wino_stats_chunks(q);
 }
 

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
     __shared__ int tapidx[64];
     __shared__ float wred[4];
     __shared__ __attribute__((aligned(16))) float ep_s[4 * 32 * I1_ES];          // epilogue transposition, one 32 x 64 block per wave
+    __shared__ float st_s[4][64][2];                                               // output statistics of a tile, per wave
     float* const xs = xs_all + I1_FRONT;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
         }
         c1_lds_barrier();
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};          // this lane's 4 channels over the pixels it stores (p.stats)
 #pragma unroll 1
         for (int i = 0; i < 4; ++i) {
             const int ry = wave * 2 + (i >> 1), rx = (i & 1) * 32 + l31;
@@ -431,7 +433,30 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
                     float* op = orow + (long)px * p.out_cs;
                     if (p.accumulate) v += *(const f32x4*)op;
                     *(f32x4*)op = v;
+                    if (!FOLD) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { st1[e] += v[e]; st2[e] = fmaf(v[e], v[e], st2[e]); }
+                    }
                 }
+            }
+        }
+        if (!FOLD && p.stats) {
+            // sum and sum of squares of the STORED values of this tile (one chunk of ss_conv_desc::y_stats), fixed order: lanes with the
+            // same channels (16 apart), then the four waves
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                st1[e] += __shfl_xor(st1[e], 16, 64); st1[e] += __shfl_xor(st1[e], 32, 64);
+                st2[e] += __shfl_xor(st2[e], 16, 64); st2[e] += __shfl_xor(st2[e], 32, 64);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { st_s[wave][4 * lane + e][0] = st1[e]; st_s[wave][4 * lane + e][1] = st2[e]; }
+            }
+            c1_lds_barrier();
+            if (tid < 128) {
+                const int ch = tid >> 1, k = tid & 1;
+                const float v = (st_s[0][ch][k] + st_s[1][ch][k]) + (st_s[2][ch][k] + st_s[3][ch][k]);
+                if (cbase + ch < p.Cout) p.stats[(((long)n * p.stats_chunks + tr) * p.Cout + cbase + ch) * 2 + k] = v;
             }
         }
     }
@@ -1161,6 +1186,13 @@ int ss_launch_conv_in1_fold(const GConvParams& p, int pt, int pl, int ih, int iw
     return launch_in1_x3h(p, box, C1Fold{1, pt, pl, ih, iw}, s);
 }
 
+// output statistics (GConvParams::stats): the matrix-core kernel on a plain problem, one chunk per 8 x 64 tile
+int ss_conv_in1_stats_chunks(const GConvParams& p) {
+    C1Box box;
+    if (!ss_conv_in1_ok(p) || !in1_x3h_shape(p, &box) || p.act != SS_ACT_NONE || p.accumulate) return 0;
+    return ((p.OH + I1_TH - 1) / I1_TH) * ((p.OW + I1_TW - 1) / I1_TW);
+}
+
 // Cin == 1, stride 1, full tap box, Cout % 16 == 0, weights with the output channel contiguous (ldb irrelevant for one input channel)
 bool ss_conv_in1_ok(const GConvParams& p) {
     C1Box box;
@@ -1174,6 +1206,7 @@ int ss_launch_conv_in1(const GConvParams& p, hipStream_t s) {
     C1Box box;
     if (!ss_conv_in1_ok(p) || !tap_box(p, &box)) return SS_ERR_UNSUPPORTED;
     if (in1_x3h_shape(p, &box)) return launch_in1_x3h(p, box, C1Fold{0, 0, 0, 0, 0}, s);
+    if (p.stats) { ss_set_error("conv_in1: output statistics requested on the VALU path"); return SS_ERR_UNSUPPORTED; }
     if (box.kh == 7) return launch_in1<7, 7>(p, box, s);
     if (box.kh == 4) return launch_in1<4, 4>(p, box, s);
     return launch_in1<3, 3>(p, box, s);

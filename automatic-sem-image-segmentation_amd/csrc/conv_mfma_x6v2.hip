@@ -264,6 +264,7 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) b4 = *(const f32x4*)(p.bias + cbase + rcol);
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};          // p.stats: this lane's 4 channels over the rows it stores
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -284,9 +285,34 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
                         for (int e = 0; e < 4; ++e) v[e] = ss_apply_act(v[e] + b4[e], p.act, p.alpha);
                         if (p.accumulate) v += *(const f32x4*)op;
                         *(f32x4*)op = v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { st1[e] += v[e]; st2[e] = fmaf(v[e], v[e], st2[e]); }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (p.stats) {
+            // output statistics of the tile's 256 rows (one chunk of ss_conv_desc::y_stats: the launcher lets a tile hold rows of ONE
+            // sample only and every wave is on this path), fixed order: the lanes that share 4 channels, then the four M waves
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { st1[e] += __shfl_xor(st1[e], off, 64); st2[e] += __shfl_xor(st2[e], off, 64); }
+            float* sst = (float*)(lds + 8 * 2048);                // [8 waves][COLS][2]
+            if (lane < LPR) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sst[(wave * COLS + rcol + e) * 2] = st1[e]; sst[(wave * COLS + rcol + e) * 2 + 1] = st2[e]; }
+            }
+            __syncthreads();
+            if (tid < 2 * VBN) {
+                const int col = tid >> 1, k = tid & 1;             // column of the tile: wave pair wn = col / COLS
+                const int w_n = col / COLS, cc = col % COLS;
+                const float v = (sst[((0 * 2 + w_n) * COLS + cc) * 2 + k] + sst[((1 * 2 + w_n) * COLS + cc) * 2 + k]) +
+                                (sst[((2 * 2 + w_n) * COLS + cc) * 2 + k] + sst[((3 * 2 + w_n) * COLS + cc) * 2 + k]);
+                const long per = (long)p.OHc * p.OWc / VBM;       // tiles (= chunks) per sample
+                const long mt = m0 / VBM;
+                p.stats[((mt / per * p.stats_chunks + mt % per) * p.Cout + n0 + col) * 2 + k] = v;
             }
         }
         return;
@@ -327,6 +353,14 @@ bool ss_gconv_x6v2_ok(const GConvParams& p) {
     return ((M + VBM - 1) / VBM) * ((p.Cout + bn - 1) / bn) * nb >= 200;
 }
 
+// output statistics (GConvParams::stats): forward problems whose 256-row tiles hold rows of one sample and whole column tiles
+int ss_gconv_x6v2_stats_chunks(const GConvParams& p) {
+    const int bn = v2_bn(p);
+    if (p.act != SS_ACT_NONE || p.accumulate || p.nbatch > 1 || p.out_s != 1 || p.out_oy || p.out_ox || p.OHc != p.OH || p.OWc != p.OW) return 0;
+    if (((long)p.OHc * p.OWc) % VBM || p.Cout % bn || (p.out_cs & 3)) return 0;
+    return (int)((long)p.OHc * p.OWc / VBM);
+}
+
 template <int VBN>
 static int launch_v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
     const long M = (long)p.N * p.OHc * p.OWc;
@@ -343,6 +377,10 @@ static int launch_v2(const GConvParams& p, const unsigned short* planes, long pl
     else snprintf(pname, sizeof(pname), "gconv_x6v2_kernel<%d>", VBN);
     SsProfScope prof(pname, 2.0 * M * p.Cout * p.ntaps * p.Cin * nb * 3,
                      4.0 * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout + (double)p.ntaps * p.Cin * p.Cout), s);
+    if (p.stats && (ss_gconv_x6v2_stats_chunks(p) != p.stats_chunks || (((uintptr_t)p.out) & 15))) {
+        ss_set_error("gconv_x6v2: output statistics requested for a problem whose tiles do not line up with the samples");
+        return SS_ERR_UNSUPPORTED;
+    }
     hipLaunchKernelGGL(gconv_x6v2_kernel<VBN>, dim3((unsigned)nwg), dim3(512), smem, s, p, planes, plane_elems, Npad, Ktot);
     SS_LAUNCH_CHECK();
     return SS_OK;

@@ -483,6 +483,56 @@ def test_conv_epilogue_statistics_feed_the_following_norm(kind, c, monkeypatch):
         np.testing.assert_allclose(a1["n/moving_variance"].cpu().numpy(), a0["n/moving_variance"].cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
+STATS_CASES = [
+    # name, k, cin, cout, stride, padding, n, h, w: forward kernels outside the Winograd path whose epilogue reports output statistics
+    ("stem_7x7_1_64_matrix_core", 7, 1, 64, 1, ("reflect", 3), 2, 128, 136),          # conv_in1_x3h_kernel: one chunk per 8 x 64 tile
+    ("stem_3x3_1_96_same", 3, 1, 96, 1, "same", 2, 96, 100),                           # two channel blocks, ragged tiles
+    ("down_3x3_s2_64_128", 3, 64, 128, 2, "same", 4, 256, 256),                        # gconv_x6v2: one chunk per 256-row tile
+    ("disc_4x4_s2_128_256", 4, 128, 256, 2, "same", 8, 128, 128),
+]
+
+
+@pytest.mark.parametrize("kind", ["instance", "batch"])
+@pytest.mark.parametrize("case", STATS_CASES, ids=[c[0] for c in STATS_CASES])
+def test_gather_and_stem_conv_epilogue_statistics(case, kind, monkeypatch):
+    """The same contract as above for the non-Winograd producers of normalised tensors (the 7x7 stem, the stride-2 encoder and the
+    discriminator convolutions, CycleGAN.py:339-358,388-409): chunks add up to the sums of the written tensor, y itself is bit-identical
+    with and without the epilogue statistics, the normalised output agrees to fp32 rounding."""
+    E, LY, L = mod("engine"), mod("layers"), mod("_lib")
+    name, k, cin, cout, stride, padding, n, h, w = case
+    dev = torch.device("cuda:0")
+    x_cpu = torch.randn((n, h, w, cin), generator=torch.Generator().manual_seed(11))
+
+    def run(stats):
+        monkeypatch.setattr(LY, "CONV_STATS", stats)
+        arena = E.ParamArena(dev)
+        conv = LY.Conv2D(arena, "c", k, cin, cout, stride=stride, padding=padding)
+        norm = LY.Norm(arena, "n", cout, kind)
+        arena.materialize()
+        gg = torch.Generator().manual_seed(6)
+        arena["c/kernel"].copy_((torch.rand((k, k, cin, cout), generator=gg) - 0.5) * 0.1)
+        arena["n/gamma"].copy_(torch.rand(cout, generator=gg) + 0.5)
+        arena["n/beta"].copy_(torch.rand(cout, generator=gg) - 0.5)
+        if kind == "batch":
+            arena["n/moving_variance"].fill_(1.0)
+        t = E.Tape(enabled=False)
+        yc = conv(t, E.Act(x_cpu.to(dev), requires_grad=False))
+        y = norm(t, yc, act="relu")
+        torch.cuda.synchronize()
+        return yc, y
+
+    yc1, y1 = run(True)
+    assert yc1.stats is not None, "this forward kernel must emit output statistics"
+    st, chunks = yc1.stats
+    part = st.view(n, chunks, cout, 2).double().sum(1).cpu()
+    yd = yc1.dense().double().cpu()
+    np.testing.assert_allclose(part[..., 0].numpy(), yd.sum((1, 2)).numpy(), rtol=1e-5, atol=2e-3)
+    np.testing.assert_allclose(part[..., 1].numpy(), (yd * yd).sum((1, 2)).numpy(), rtol=1e-5, atol=2e-3)
+    yc0, y0 = run(False)
+    assert yc0.stats is None and torch.equal(yc0.dense(), yc1.dense())
+    np.testing.assert_allclose(y1.dense().cpu().numpy(), y0.dense().cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
 V2_CASES = [
     # name, k, cin, cout, stride, padding, transposed, n, h, w   (>= 200 workgroups of 256 pixels x 128 channels, Cin % 32 == 0, Cout >= 96)
     ("down_3x3_s2", 3, 64, 128, 2, "same", False, 4, 256, 256),

@@ -12,7 +12,9 @@ E = importlib.import_module(PKG + ".engine")
 LY = importlib.import_module(PKG + ".layers")
 
 # kind, n, h=w, c, act
-SHAPES = [
+import sys as _sys
+SHAPES_BIG = [("instance", n, 128, 256, "relu") for n in (1, 2, 4, 8)] + [("instance", n, 256, 128, "relu") for n in (1, 2, 4, 8)] + [("batch", 8, 512, 25, "relu"), ("batch", 2, 512, 25, "relu")]
+SHAPES = SHAPES_BIG if "--big" in _sys.argv else [
     ("instance", 1, 64, 512, "relu"), ("instance", 2, 64, 512, "relu"), ("instance", 1, 32, 512, "relu"),
     ("instance", 1, 128, 256, "relu"), ("instance", 1, 64, 256, "lrelu"), ("instance", 1, 62, 512, "lrelu"),
     ("instance", 1, 16, 512, "relu"), ("instance", 4, 32, 512, "relu"),
@@ -43,6 +45,16 @@ def main():
         arena["n/gamma"].fill_(1.0)
         x = E.Act(torch.randn((n, hw, hw, c), device=dev), requires_grad=True)
         y = E.Act.empty(n, hw, hw, c, dev)
+        if "--cycle" in sys.argv:          # a different input / output buffer every call (16 of each): nothing is cache- or TLB-resident
+            xs = [E.Act(torch.randn((n, hw, hw, c), device=dev)) for _ in range(16)]
+            ys = [E.Act.empty(n, hw, hw, c, dev) for _ in range(16)]
+            k = [0]
+
+            def fcyc():
+                k[0] = (k[0] + 1) % 16
+                norm(E.Tape(enabled=False), xs[k[0]], act=act, act_alpha=0.2, out=ys[k[0]])
+            print(f"{kind:9s} {n:2d} {hw:4d} {c:4d} {timeit(fcyc):8.1f}  (cycling 16 buffers)")
+            continue
         f_us = timeit(lambda: norm(E.Tape(enabled=False), x, act=act, act_alpha=0.2, out=y))
 
         def fb():

@@ -418,6 +418,11 @@ int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStre
         if (c1 || (tconv_takes(algo, p) && ws && ws_bytes >= ss_tconv_ws(p)) || gconv_two_stage(algo, p)) return SS_OK;
         if (!(use_x6(algo, p) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p))) return SS_OK;
     }
+    if (p.dtype != SS_DTYPE_F32) {          // 16-bit storage: only gconv_x6v2 loads / stores the stored type here (callers check with gconv16_takes)
+        const bool v2 = (algo == SS_ALGO_AUTO || algo == SS_ALGO_X6) && !ss_conv_out1_ok(p) && !ss_conv_in1_ok(p) && !tconv_takes(algo, p) &&
+                        !gconv_two_stage(algo, p) && use_x6(algo, p) && ss_gconv_x6v2_ok(p) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p);
+        if (!v2) { ss_set_error("run_gconv: no kernel with a 16-bit loader for this problem"); return SS_ERR_UNSUPPORTED; }
+    }
     if (algo != SS_ALGO_DIRECT && algo != SS_ALGO_MFMA) {        // full-resolution 7x7 stem / head shapes: LDS-tiled VALU kernels
         if (ss_conv_out1_ok(p)) return ss_launch_conv_out1(p, s);
         if (ss_conv_in1_ok(p)) return ss_launch_conv_in1(p, s);
@@ -614,7 +619,9 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     p.dtype = c.dtype;
     if (need_dy_amax_dgrad(c, algo) && gws_bytes >= x6_planes_ub(c.cout, c.cin, T)) {
         unsigned int* sl = (unsigned int*)((char*)gws + x6_planes_ub(c.cout, c.cin, T) - 256);
-        const AmaxRef ay = (c.wc && c.wc->fill_only) ? AmaxRef{sl, 1} : act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl, s);
+        const AmaxRef ay = (c.wc && c.wc->fill_only) ? AmaxRef{sl, 1}
+                           : (c.dtype == SS_DTYPE_F32 ? act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl, s)
+                                                      : act_amax16(dy, c.dtype, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl, s));
         p.h_amax = ay.p; p.amax_stripes = ay.stripes;
         p.h_amax2 = weight_amax(w, (long)T * c.cin * c.cout, sl + 1, s, c.wc);
     }
@@ -1072,10 +1079,52 @@ bool wino16_dgrad_takes(const ConvProb& c, int algo, WinoProb* q) {
            (!c.reflect || q->fold_h > 0) && ss_tuning().wino_r == 4 && ss_wino_fwd_x3h(*q);
 }
 
+// Gather convolutions on 16-bit stored activations: gconv_x6v2 reads / writes the stored type (one fp16 operand plane, conv_mfma_x6v2.hip).
+// `p` is the problem run_gconv would see; true when run_gconv's choice for it is that kernel.
+bool gconv16_takes(int algo, const GConvParams& p0) {
+    if (algo != SS_ALGO_AUTO && algo != SS_ALGO_X6) return false;
+    static const unsigned int dummy = 0;
+    GConvParams p = p0;
+    p.h_amax = &dummy; p.h_amax2 = &dummy; p.amax_stripes = 1;
+    if (ss_conv_out1_ok(p) || ss_conv_in1_ok(p) || tconv_takes(algo, p) || gconv_two_stage(algo, p)) return false;
+    return use_x6(algo, p) && ss_gconv_x6v2_ok(p);
+}
+// ... every sub-pixel phase of the data gradient of `c` (the loop of conv_bwd_data)
+bool bwd_data_gather16_ok(const ConvProb& c, int algo) {
+    WinoProb q;
+    if (c.reflect || c.kh * c.kw > SS_MAX_TAPS || wino_dgrad_prob(c, algo, &q) || tconv_takes_dgrad(c, algo) || !need_dy_amax_dgrad(c, algo)) return false;
+    GConvParams p{};
+    p.N = c.n; p.IH = c.oh; p.IW = c.ow; p.Cin = c.cout; p.in_cs = c.out_cs;
+    p.in_s = 1; p.Cout = c.cin; p.ldb = c.cin; p.dtype = c.dtype;
+    p.OH = c.ih; p.OW = c.iw; p.out_cs = c.in_cs; p.out_s = c.s;
+    for (int ry = 0; ry < c.s; ++ry)
+        for (int rx = 0; rx < c.s; ++rx) {
+            p.OHc = (c.ih - ry + c.s - 1) / c.s;
+            p.OWc = (c.iw - rx + c.s - 1) / c.s;
+            if (p.OHc <= 0 || p.OWc <= 0) continue;
+            p.out_oy = ry; p.out_ox = rx;
+            p.ntaps = 0;
+            for (int a = 0; a < c.kh; ++a) {
+                if (((ry + c.pt - a) % c.s) != 0) continue;
+                for (int b = 0; b < c.kw; ++b)
+                    if (((rx + c.pl - b) % c.s) == 0) ++p.ntaps;
+            }
+            if (!gconv16_takes(algo, p)) return false;
+        }
+    return true;
+}
+
 int native16_fwd(const ss_conv_desc* d, const void* x, const float* w, const float* bias, void* y, void* ws, size_t ws_bytes, hipStream_t s,
                  bool* taken) {
     *taken = false;
-    if (d->transposed) return SS_OK;
+    if (d->transposed) {          // a transposed convolution's forward is the data gradient of its adjoint
+        ConvProb c = adjoint(d);
+        c.dtype = d->dtype;
+        c.wc = desc_wcache(d);
+        if (!bwd_data_gather16_ok(c, d->algo) || !ws || ws_bytes < bwd_data_ws(c)) return SS_OK;
+        *taken = true;
+        return conv_bwd_data(c, (const float*)x, w, (float*)y, bias, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
+    }
     ConvProb c = plain(d);
     c.dtype = d->dtype;
     WinoProb q;
@@ -1084,17 +1133,47 @@ int native16_fwd(const ss_conv_desc* d, const void* x, const float* w, const flo
         q.wc = desc_wcache(d);
         return ss_wino_conv_fwd16(q, d->dtype, x, w, c.cin, c.cout, 0, bias, y, d->act, d->act_alpha, 0, ws, ws_bytes, s);
     }
-    if (!tconv_takes_fwd(c, d->algo)) return SS_OK;
+    if (tconv_takes_fwd(c, d->algo)) {
+        *taken = true;
+        const GConvParams p = fwd_params(c, (const float*)x, w, bias, (float*)y, d->act, d->act_alpha, 0);
+        return ss_launch_tconv(p, nullptr, 0, s);
+    }
+    if (c.kh * c.kw > SS_MAX_TAPS || wino_fwd_prob(c, d->algo, &q) || !need_x_amax_fwd(c, d->algo)) return SS_OK;
+    GConvParams p = fwd_params(c, (const float*)x, w, bias, (float*)y, d->act, d->act_alpha, 0);
+    if (!gconv16_takes(d->algo, p) || !ws || ws_bytes < ss_gconv_x6_planes_bytes(p) + 256) return SS_OK;
     *taken = true;
-    const GConvParams p = fwd_params(c, (const float*)x, w, bias, (float*)y, d->act, d->act_alpha, 0);
-    return ss_launch_tconv(p, nullptr, 0, s);
+    c.wc = desc_wcache(d);
+    unsigned int* sl = (unsigned int*)((char*)ws + ss_gconv_x6_planes_bytes(p));
+    const AmaxRef ax = act_amax16(x, d->dtype, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
+    p.h_amax = ax.p; p.amax_stripes = ax.stripes;
+    p.h_amax2 = weight_amax(w, (long)c.kh * c.kw * c.cin * c.cout, sl + 1, s, c.wc);
+    return run_gconv(d->algo, p, ws, ws_bytes, s, c.wc);
 }
 int native16_bwd_data(const ss_conv_desc* d, const void* dy, const float* w, void* dx, int accumulate, void* ws, size_t ws_bytes,
                       hipStream_t s, bool* taken) {
     *taken = false;
-    if (d->transposed) return SS_OK;
+    if (d->transposed) {          // the data gradient of a transposed convolution is the forward of its adjoint
+        ConvProb c = adjoint(d);
+        c.dtype = d->dtype;
+        WinoProb q;
+        if (c.kh * c.kw > SS_MAX_TAPS || wino_fwd_prob(c, d->algo, &q) || tconv_takes_fwd(c, d->algo) || !need_x_amax_fwd(c, d->algo)) return SS_OK;
+        GConvParams p = fwd_params(c, (const float*)dy, w, nullptr, (float*)dx, SS_ACT_NONE, 0.f, accumulate);
+        if (!gconv16_takes(d->algo, p) || !ws || ws_bytes < ss_gconv_x6_planes_bytes(p) + 256) return SS_OK;
+        *taken = true;
+        c.wc = desc_wcache(d);
+        unsigned int* sl = (unsigned int*)((char*)ws + ss_gconv_x6_planes_bytes(p));
+        const AmaxRef ax = act_amax16(dy, d->dtype, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
+        p.h_amax = ax.p; p.amax_stripes = ax.stripes;
+        p.h_amax2 = weight_amax(w, (long)c.kh * c.kw * c.cin * c.cout, sl + 1, s, c.wc);
+        return run_gconv(d->algo, p, ws, ws_bytes, s, c.wc);
+    }
     ConvProb c = plain(d);
     c.dtype = d->dtype;
+    if (bwd_data_gather16_ok(c, d->algo) && ws && ws_bytes >= bwd_data_ws(c)) {
+        *taken = true;
+        c.wc = desc_wcache(d);
+        return conv_bwd_data(c, (const float*)dy, w, (float*)dx, nullptr, SS_ACT_NONE, 0.f, accumulate, d->algo, ws, ws_bytes, s);
+    }
     {
         WinoProb q;
         if (wino16_dgrad_takes(c, d->algo, &q) && ws && ws_bytes >= ss_wino_fwd_ws(q)) {

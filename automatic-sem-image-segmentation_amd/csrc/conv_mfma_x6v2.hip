@@ -23,6 +23,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ float v2_zero_page16[4] = {0.f, 0.f, 0.f, 0.f};
+// activation storage types: four consecutive channels <-> f32x4 (16-bit types: one 8-byte access)
+typedef _Float16 v2_f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 v2_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 v2_ld4(const float* q) { return *(const f32x4*)q; }
+__device__ __forceinline__ f32x4 v2_ld4(const _Float16* q) { return __builtin_convertvector(*(const v2_f16x4*)q, f32x4); }
+__device__ __forceinline__ f32x4 v2_ld4(const __bf16* q) { return __builtin_convertvector(*(const v2_bf16x4*)q, f32x4); }
+__device__ __forceinline__ void v2_st4(float* q, f32x4 v) { *(f32x4*)q = v; }
+__device__ __forceinline__ void v2_st4(_Float16* q, f32x4 v) { *(v2_f16x4*)q = __builtin_convertvector(v, v2_f16x4); }
+__device__ __forceinline__ void v2_st4(__bf16* q, f32x4 v) { *(v2_bf16x4*)q = __builtin_convertvector(v, v2_bf16x4); }
+template <typename T> struct V2Raw { typedef u32x2 type; };          // what a lane keeps of its 4 channels between request and split
+template <> struct V2Raw<float> { typedef f32x4 type; };
+__device__ __forceinline__ f32x4 v2_widen(f32x4 r, const float*) { return r; }
+__device__ __forceinline__ f32x4 v2_widen(u32x2 r, const _Float16*) { return __builtin_convertvector(__builtin_bit_cast(v2_f16x4, r), f32x4); }
+__device__ __forceinline__ f32x4 v2_widen(u32x2 r, const __bf16*) { return __builtin_convertvector(__builtin_bit_cast(v2_bf16x4, r), f32x4); }
 constexpr bool ss_v2_scalar_epilogue = false;          // true: the one-column-per-lane stores (A/B measurement builds)
 
 constexpr int VBM = 256, VK = 32;
@@ -41,9 +55,14 @@ __device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int VBN>
+// T: activation storage type.  16-bit storage (NPROD < 3): the stored value IS the operand -- one fp16 plane of A (scaled by a power of
+// two, exact), no low piece: NPROD = 2 multiplies it with both weight pieces (the exact product of the stored activation and the fp32
+// weight), NPROD = 1 with the leading weight piece only (ss_tuning wino16_products); half the gathered bytes, a third of the split work.
+template <int VBN, typename T, int NPROD>
 __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems, int Npad,
                                                             int Ktot) {
+    constexpr bool F32 = std::is_same<T, float>::value;
+    static_assert(F32 ? NPROD == 3 : NPROD <= 2, "fp32 storage: three products; 16-bit storage: one or two");
     constexpr int VB_PLANE = VG<VBN>::B_PLANE, VSTAGE = VG<VBN>::STAGE, TN = VG<VBN>::TN, NB = VG<VBN>::NB;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     int* pixtab = (int*)(lds + 2 * VSTAGE);          // [VBM]
@@ -66,8 +85,8 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
     const int gridM = (int)((M + VBM - 1) / VBM);
     const int batch = tile / (gridM * gridN);
     tile -= batch * gridM * gridN;
-    const float* const g_in = p.in + (long)batch * p.in_bs;
-    float* const g_out = p.out + (long)batch * p.out_bs;
+    const T* const g_in = (const T*)p.in + (long)batch * p.in_bs;
+    T* const g_out = (T*)p.out + (long)batch * p.out_bs;
     const long m0 = (long)(tile / gridN) * VBM;
     const int n0 = (tile % gridN) * VBN;
     const int nchunks = Ktot / VK;
@@ -127,23 +146,23 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         lb[j] = 2 * VA_PLANE + pl * VB_PLANE + rb * 1024;
     }
 
-    f32x4 ra[2][4];
-    const float* const zpage = v2_zero_page16;          // zero-padding / out-of-image taps READ zeros (one pointer select per load)
+    typename V2Raw<T>::type ra[2][4];
+    const T* const zpage = (const T*)v2_zero_page16;    // zero-padding / out-of-image taps READ zeros (one pointer select per load)
     auto load_a = [&](auto setc, int chunk) {
         constexpr int S = decltype(setc)::value;
         const int k0 = chunk * VK;
         const int t = k0 / Cq;                         // block-uniform
-        const float* abase = g_in + (k0 - t * Cq) + c4a * 4;
+        const T* abase = g_in + (k0 - t * Cq) + c4a * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int off = offtab[(arow + 64 * j) * p.ntaps + t];
-            const float* pa = off < 0 ? zpage : abase + off;
-            ra[S][j] = *(const f32x4*)pa;
+            const T* pa = off < 0 ? zpage : abase + off;
+            ra[S][j] = *(const typename V2Raw<T>::type*)pa;
         }
     };
     auto store_a = [&](auto setc, int stage, int j) {          // row arow + 64 j of the chunk held in register set S -> LDS stage
         constexpr int S = decltype(setc)::value;
-        const f32x4 v = ra[S][j];
+        const f32x4 v = v2_widen(ra[S][j], (const T*)nullptr);
         unsigned int hh[2], ll[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         }
         unsigned char* dst = lds + stage * VSTAGE + ((arow + 64 * j) * VLD + c4a * 4) * 2;
         *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
-        *(u32x2*)(dst + VA_PLANE) = u32x2{ll[0], ll[1]};
+        if (F32) *(u32x2*)(dst + VA_PLANE) = u32x2{ll[0], ll[1]};          // 16-bit storage: h is the (scaled) stored value, exactly
     };
     auto dma_b = [&](int chunk, int stage) {
 #pragma unroll
@@ -176,14 +195,18 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         const int sb = stage * VSTAGE;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
+            if (pl == 0 || F32) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const f16x8*)(fa + sb + pl * VA_PLANE + mi * 32 * VLD * 2 + ks * 32);
+                for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const f16x8*)(fa + sb + pl * VA_PLANE + mi * 32 * VLD * 2 + ks * 32);
+            }
+            if (pl == 0 || NPROD >= 2) {
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const f16x8*)(fb + sb + pl * VB_PLANE + ni * 32 * 64 + (ks ? so1 : so0));
+                for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const f16x8*)(fb + sb + pl * VB_PLANE + ni * 32 * 64 + (ks ? so1 : so0));
+            }
         }
     };
-    // l*h, h*l, h*h (the order of gconv_x6_kernel); consecutive MFMAs go to different accumulators
-    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+    // l*h, h*l, h*h (the order of gconv_x6_kernel); consecutive MFMAs go to different accumulators.  16-bit storage: h*l, h*h or h*h
+    constexpr int HA[3] = {NPROD == 3 ? 1 : 0, 0, 0}, HB[3] = {NPROD == 3 ? 0 : (NPROD == 2 ? 1 : 0), NPROD == 3 ? 1 : 0, 0};
     auto mma4 = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][TN], int q) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -222,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            mma4(a0, b0, q);
+            if (q < NPROD) mma4(a0, b0, q);
             store_a(nxt, s ^ 1, q);
             if (q == 2) store_a(nxt, s ^ 1, 3);
             __builtin_amdgcn_sched_barrier(0);
@@ -233,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         __builtin_amdgcn_sched_barrier(0);
         frag(a0, b0, s ^ 1, 0);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) mma4(a1, b1, q);
+        for (int q = 0; q < NPROD; ++q) mma4(a1, b1, q);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
     };
@@ -280,11 +303,11 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
                     f32x4 v = *(const f32x4*)(tb + row * COLS + rcol);
                     const int pix = pixtab[wm * 64 + mi * 32 + 8 * rq + row];
                     if (pix >= 0) {
-                        float* op = g_out + pix * p.out_cs + cbase + rcol;
+                        T* op = g_out + pix * p.out_cs + cbase + rcol;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = ss_apply_act(v[e] + b4[e], p.act, p.alpha);
-                        if (p.accumulate) v += *(const f32x4*)op;
-                        *(f32x4*)op = v;
+                        if (p.accumulate) v += v2_ld4(op);
+                        v2_st4(op, v);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { st1[e] += v[e]; st2[e] = fmaf(v[e], v[e], st2[e]); }
                     }
@@ -324,14 +347,14 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int pix = pixtab[wm * 64 + mi * 32 + row];
             if (pix < 0) continue;
-            float* orow = g_out + pix * p.out_cs;
+            T* orow = g_out + pix * p.out_cs;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
                 if (co[ni] >= p.Cout) continue;
-                float* op = orow + co[ni];
+                T* op = orow + co[ni];
                 float v = ss_apply_act(acc[mi][ni][r] * out_scale + bv[ni], p.act, p.alpha);
-                if (p.accumulate) v += *op;
-                *op = v;
+                if (p.accumulate) v += (float)*op;
+                *op = (T)v;
             }
         }
     }
@@ -361,12 +384,12 @@ int ss_gconv_x6v2_stats_chunks(const GConvParams& p) {
     return (int)((long)p.OHc * p.OWc / VBM);
 }
 
-template <int VBN>
+template <int VBN, typename T, int NPROD>
 static int launch_v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
     const long M = (long)p.N * p.OHc * p.OWc;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)gconv_x6v2_kernel<VBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gconv_x6v2_kernel<VBN, T, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
@@ -374,18 +397,28 @@ static int launch_v2(const GConvParams& p, const unsigned short* planes, long pl
     const size_t smem = (size_t)2 * VG<VBN>::STAGE + (size_t)VBM * sizeof(int) * (4 + p.ntaps);
     char pname[64];
     if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_x6v2<%d> M%ld N%d K%dx%d s%d b%d", VBN, M, p.Cout, p.ntaps, p.Cin, p.in_s, nb);
-    else snprintf(pname, sizeof(pname), "gconv_x6v2_kernel<%d>", VBN);
-    SsProfScope prof(pname, 2.0 * M * p.Cout * p.ntaps * p.Cin * nb * 3,
-                     4.0 * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout + (double)p.ntaps * p.Cin * p.Cout), s);
+    else if (std::is_same<T, float>::value) snprintf(pname, sizeof(pname), "gconv_x6v2_kernel<%d>", VBN);
+    else snprintf(pname, sizeof(pname), "gconv_x6v2_kernel<%d,16-bit,%d>", VBN, NPROD);
+    SsProfScope prof(pname, 2.0 * M * p.Cout * p.ntaps * p.Cin * nb * NPROD,
+                     (double)sizeof(T) * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout) + 4.0 * nb * p.ntaps * p.Cin * p.Cout, s);
     if (p.stats && (ss_gconv_x6v2_stats_chunks(p) != p.stats_chunks || (((uintptr_t)p.out) & 15))) {
         ss_set_error("gconv_x6v2: output statistics requested for a problem whose tiles do not line up with the samples");
         return SS_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(gconv_x6v2_kernel<VBN>, dim3((unsigned)nwg), dim3(512), smem, s, p, planes, plane_elems, Npad, Ktot);
+    hipLaunchKernelGGL((gconv_x6v2_kernel<VBN, T, NPROD>), dim3((unsigned)nwg), dim3(512), smem, s, p, planes, plane_elems, Npad, Ktot);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
+template <typename T, int NPROD>
+static int launch_v2_bn(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
+    return v2_bn(p) == 128 ? launch_v2<128, T, NPROD>(p, planes, plane_elems, Npad, Ktot, s) : launch_v2<64, T, NPROD>(p, planes, plane_elems, Npad, Ktot, s);
+}
 int ss_launch_gconv_x6v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
-    return v2_bn(p) == 128 ? launch_v2<128>(p, planes, plane_elems, Npad, Ktot, s) : launch_v2<64>(p, planes, plane_elems, Npad, Ktot, s);
+    if (p.dtype == SS_DTYPE_F32) return launch_v2_bn<float, 3>(p, planes, plane_elems, Npad, Ktot, s);
+    if (p.stats) { ss_set_error("gconv_x6v2: output statistics are reported for fp32 storage only"); return SS_ERR_UNSUPPORTED; }
+    const bool two = ss_tuning().wino16_products == 3;          // "fp32-grade arithmetic, only the storage is 16-bit"
+    if (p.dtype == SS_DTYPE_F16) return two ? launch_v2_bn<_Float16, 2>(p, planes, plane_elems, Npad, Ktot, s) : launch_v2_bn<_Float16, 1>(p, planes, plane_elems, Npad, Ktot, s);
+    if (p.dtype == SS_DTYPE_BF16) return two ? launch_v2_bn<__bf16, 2>(p, planes, plane_elems, Npad, Ktot, s) : launch_v2_bn<__bf16, 1>(p, planes, plane_elems, Npad, Ktot, s);
+    return SS_ERR_UNSUPPORTED;
 }

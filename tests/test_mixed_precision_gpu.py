@@ -39,6 +39,11 @@ CONV_CASES = [
     ("trunk_wino_512_reflect", 3, 512, 512, 1, ("reflect", 1), False, False, 2, 64, 64),
     ("wino_same_256", 3, 256, 256, 1, "same", False, False, 2, 32, 32),
     ("down_s2", 3, 32, 64, 2, "same", False, False, 2, 64, 64),
+    # gather convolutions of the trunk's encoder / decoder and the discriminators at >= 200 workgroups: gconv_x6v2 reads and writes the
+    # stored type (one fp16 operand plane; forward, data gradient, transposed forward = data gradient of the adjoint)
+    ("gather16_down_s2_64_128", 3, 64, 128, 2, "same", False, False, 4, 256, 256),
+    ("gather16_disc_4x4_s2_128_256_bias", 4, 128, 256, 2, "same", True, False, 8, 128, 128),
+    ("gather16_up_T3_256_128", 3, 256, 128, 2, "same", False, True, 16, 64, 64),
     ("up_T3", 3, 64, 32, 2, "same", False, True, 2, 32, 32),
     ("stem7_reflect", 7, 1, 16, 1, ("reflect", 3), False, False, 1, 64, 64),
     ("unet_upT2_bias", 2, 26, 16, 2, "same", True, True, 2, 32, 32),

@@ -1194,7 +1194,32 @@ int native16_bwd_data(const ss_conv_desc* d, const void* dy, const float* w, voi
 int native16_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate, void* ws,
                         size_t ws_bytes, hipStream_t s, bool* taken) {
     *taken = false;
-    if (d->transposed) return SS_OK;
+    // gather weight gradient (strided / 4x4 / transposed layers): wgrad_x6_kernel reads the stored 16-bit operands itself -- one fp16
+    // plane each, one product = the exact product of the stored values.  `xa` / `ya`: input / output-side operand of the plain conv `cc`
+    auto gather = [&](const ConvProb& cc, const void* xa, const void* ya) -> int {
+        WinoProb q;
+        if (dbias || (d->algo != SS_ALGO_AUTO && d->algo != SS_ALGO_X6) || cc.kh * cc.kw > SS_MAX_TAPS || wino_fwd_prob(cc, d->algo, &q) ||
+            twgrad_takes(cc, d->algo) || wgrad_c1_mode(cc, d->algo) >= 0 || wgrad_two_stage(cc, d->algo) || !need_amax_wgrad(cc, d->algo) ||
+            !ws || ws_bytes < bwd_weight_ws(cc))
+            return SS_OK;
+        WGradParams p = wgrad_params(cc, (const float*)xa, (const float*)ya, (float*)ws);
+        p.x6 = x6_wanted(d->algo);
+        int pps;
+        p.splits = ss_wgrad_mfma_splits((long)cc.n * cc.oh * cc.ow, p.ntaps * p.Ca, p.Cb, &pps);
+        p.pix_per_split = pps;
+        if (!(p.x6 && ss_wgrad_x6_ok(p))) return SS_OK;
+        *taken = true;
+        unsigned int* sl = (unsigned int*)((char*)ws + ss_align_up((size_t)p.splits * p.ntaps * p.Ca * p.Cb * sizeof(float), 256));
+        const AmaxRef ax = act_amax16(xa, d->dtype, (long)cc.n * cc.ih * cc.iw, cc.cin, cc.in_cs, cc.x_amax, cc.x_valid, sl, s);
+        const AmaxRef ay = act_amax16(ya, d->dtype, (long)cc.n * cc.oh * cc.ow, cc.cout, cc.out_cs, cc.dy_amax, cc.dy_valid, sl + 1, s);
+        p.h_amax = ax.p; p.h_amax2 = ay.p; p.amax_stripes = ax.stripes; p.amax2_stripes = ay.stripes;
+        return ss_launch_wgrad_mfma(p, dw, cc.cout, accumulate, s);
+    };
+    if (d->transposed) {          // the weight gradient of a transposed convolution is that of its adjoint with the operands swapped
+        ConvProb ca = adjoint(d);
+        ca.dtype = d->dtype;
+        return gather(ca, dy, x);
+    }
     ConvProb c = plain(d);
     c.dtype = d->dtype;
     {   // Winograd weight gradient on pre-split planes: the transforms read the stored type; planes + GEMM as for fp32 storage
@@ -1210,7 +1235,7 @@ int native16_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, fl
         }
     }
     if (dbias) return SS_OK;
-    if (!twgrad_takes(c, d->algo)) return SS_OK;
+    if (!twgrad_takes(c, d->algo)) return gather(c, x, dy);
     WGradParams p = wgrad_params(c, (const float*)x, (const float*)dy, (float*)ws);
     p.x6 = x6_wanted(d->algo);
     p.splits = ss_twgrad_splits(p);

@@ -379,8 +379,18 @@ __global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned s
 // into LDS: a thread owns 4 consecutive pixels x 4 consecutive channels (four 16-byte global loads), splits them, and
 // writes, per channel and piece, the 4 pixels as one 8-byte LDS store into the k-contiguous row of that channel.
 // Lane -> (pixel group = tid & 7, channel quad = tid >> 3): a 16-lane store group covers two rows x 16 dwords = 32 banks.
-template <int BN, bool H>
+// T: activation storage type.  16-bit storage (H only): both operands ARE stored 16-bit values -- one fp16 plane each (scaled by a
+// power of two: exact), ONE product h*h per K step is the exact product of the stored values, accumulated in fp32.
+typedef _Float16 xw_f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 xw_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 xw_ld4(const float* q) { return *(const f32x4*)q; }
+__device__ __forceinline__ f32x4 xw_ld4(const _Float16* q) { return __builtin_convertvector(*(const xw_f16x4*)q, f32x4); }
+__device__ __forceinline__ f32x4 xw_ld4(const __bf16* q) { return __builtin_convertvector(*(const xw_bf16x4*)q, f32x4); }
+
+template <int BN, bool H, typename T = float>
 __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
+    constexpr bool S16 = !std::is_same<T, float>::value;          // single-plane operands
+    static_assert(!S16 || H, "16-bit storage runs on the fp16 matrix cores");
     constexpr int BM = XBM;
     constexpr int NP = H ? 2 : 3;        // operand planes (H: fp16 two-piece split with one scale per operand tensor, see gconv_x6_kernel)
     typedef typename std::conditional<H, f16x8, bf16x8>::type FT;
@@ -417,8 +427,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
     const int n0 = by * BN;
     const int split = bz % p.splits;
     const int batch = bz / p.splits;
-    const float* const g_a = p.a + (long)batch * p.a_bs;
-    const float* const g_b = p.b + (long)batch * p.b_bs;
+    const T* const g_a = (const T*)p.a + (long)batch * p.a_bs;
+    const T* const g_b = (const T*)p.b + (long)batch * p.b_bs;
     const long P = (long)p.N * p.GH * p.GW;
     const long ps = (long)split * p.pix_per_split;
     const long pe = (ps + p.pix_per_split < P) ? ps + p.pix_per_split : P;
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
     // element at store time).  Fast addressing (the usual case): the class grid's rows are multiples of 4 pixels and the split
     // starts on one, so a thread's 4 pixels lie in ONE row -- the row is mapped once, the columns step by the stride -- and both
     // tensors are below 2^31 elements, so the offsets are 32-bit until the final pointer add.
-    const float* const zpage = ss_zero_page16;
+    const T* const zpage = (const T*)ss_zero_page16;
     const bool fast = (p.GW & 3) == 0 && (ps & 3) == 0 && (long)p.N * p.AH * p.AW * p.a_cs < (1L << 31) && P * p.b_cs < (1L << 31);
     auto load_tiles = [&](long pk0) {
         if (fast) {
@@ -472,10 +482,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ix = ss_map_index(xb + i * p.a_s, p.AW, p.reflect);
-                const float* pa = (rowok && ix >= 0) ? g_a + ((rowbase + ix) * p.a_cs + a_c) : zpage;
-                ra[i] = *(const f32x4*)pa;
-                const float* pb = okb ? g_b + (bo + i * p.b_cs) : zpage;
-                rb[i] = *(const f32x4*)pb;
+                const T* pa = (rowok && ix >= 0) ? g_a + ((rowbase + ix) * p.a_cs + a_c) : zpage;
+                ra[i] = xw_ld4(pa);
+                const T* pb = okb ? g_b + (bo + i * p.b_cs) : zpage;
+                rb[i] = xw_ld4(pb);
             }
         } else {
             int x = f_x, y = f_y, n = f_n;
@@ -485,11 +495,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
                 const int iy = ss_map_index(y * p.a_s + p.a_oy + a_dy, p.AH, p.reflect);
                 const int ix = ss_map_index(x * p.a_s + p.a_ox + a_dx, p.AW, p.reflect);
                 const bool oka = a_val && pk < pe && iy >= 0 && ix >= 0;
-                const float* pa = oka ? g_a + (((long)(n * p.AH + iy) * p.AW + ix) * p.a_cs + a_c) : zpage;
-                ra[i] = *(const f32x4*)pa;
+                const T* pa = oka ? g_a + (((long)(n * p.AH + iy) * p.AW + ix) * p.a_cs + a_c) : zpage;
+                ra[i] = xw_ld4(pa);
                 const bool okb = b_val && pk < pe;
-                const float* pb = okb ? g_b + (pk * p.b_cs + bn) : zpage;
-                rb[i] = *(const f32x4*)pb;
+                const T* pb = okb ? g_b + (pk * p.b_cs + bn) : zpage;
+                rb[i] = xw_ld4(pb);
                 if (++x >= p.GW) { x = 0; if (++y >= p.GH) { y = 0; ++n; } }
             }
         }
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
                 ss_split_h2s(va[0][e] * a_scale, va[1][e] * a_scale, hh[0], ll[0]);
                 ss_split_h2s(va[2][e] * a_scale, va[3][e] * a_scale, hh[1], ll[1]);
                 *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
-                *(u32x2*)(dst + BM * XLD) = u32x2{ll[0], ll[1]};
+                if (!S16) *(u32x2*)(dst + BM * XLD) = u32x2{ll[0], ll[1]};
             } else {
                 unsigned int h0, m0_, l0, h1, m1, l1;
                 ss_split3x2(f32x2{va[0][e], va[1][e]}, h0, m0_, l0);
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
                     ss_split_h2s(vb[0][e] * b_scale, vb[1][e] * b_scale, hh[0], ll[0]);
                     ss_split_h2s(vb[2][e] * b_scale, vb[3][e] * b_scale, hh[1], ll[1]);
                     *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
-                    *(u32x2*)(dst + BN * XLD) = u32x2{ll[0], ll[1]};
+                    if (!S16) *(u32x2*)(dst + BN * XLD) = u32x2{ll[0], ll[1]};
                 } else {
                     unsigned int h0, m0_, l0, h1, m1, l1;
                     ss_split3x2(f32x2{vb[0][e], vb[1][e]}, h0, m0_, l0);
@@ -567,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
         for (int ks = 0; ks < XK / 16; ++ks) {
             FT a[NP][2], b[NP][TN];
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
+            for (int pl = 0; pl < (S16 ? 1 : NP); ++pl) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const FT*)(fa + pl * BM * XLD + mi * 32 * XLD + ks * 16);
 #pragma unroll
@@ -584,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
                     for (int ni = 0; ni < TN; ++ni) {
                         if constexpr (H) {
                             if (q == 2) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
-                            else accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], accx[mi][ni], 0, 0, 0);
+                            else if (!S16) accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], accx[mi][ni], 0, 0, 0);
                         } else
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][mi], b[PB[q]][ni], acc[mi][ni], 0, 0, 0);
                     }
@@ -615,28 +625,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
     }
 }
 
-template <int BN, bool H>
+template <int BN, bool H, typename T = float>
 int launch_wgrad_x6h(const WGradParams& p, hipStream_t s) {
     const int M = p.ntaps * p.Ca;
     dim3 grid((M + XBM - 1) / XBM, (p.Cb + BN - 1) / BN, p.splits * (p.nbatch > 1 ? p.nbatch : 1));
     const size_t smem = (size_t)(H ? 2 : 3) * (XBM + BN) * XLD * sizeof(unsigned short);
     // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
     static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel<BN, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel<BN, H, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
     char pname[64];
     if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "wgrad_x6<%d,%d> M%d N%d K%ld b%d", BN, (int)H, M, p.Cb, (long)p.N * p.GH * p.GW, p.nbatch);
-    else snprintf(pname, sizeof(pname), "wgrad_x6_kernel<%d,%s>", BN, H ? "true" : "false");
+    else snprintf(pname, sizeof(pname), "wgrad_x6_kernel<%d,%s%s>", BN, H ? "true" : "false", std::is_same<T, float>::value ? "" : ",16-bit");
     const double pix = (double)p.N * p.GH * p.GW * (p.nbatch > 1 ? p.nbatch : 1);
-    SsProfScope prof(pname, 2.0 * M * p.Cb * pix * (H ? 3 : 6), 4.0 * pix * (p.Ca + p.Cb) + 4.0 * M * p.Cb * p.splits, s);
-    hipLaunchKernelGGL((wgrad_x6_kernel<BN, H>), grid, dim3(256), smem, s, p);
+    SsProfScope prof(pname, 2.0 * M * p.Cb * pix * (std::is_same<T, float>::value ? (H ? 3 : 6) : 1), (double)sizeof(T) * pix * (p.Ca + p.Cb) + 4.0 * M * p.Cb * p.splits, s);
+    hipLaunchKernelGGL((wgrad_x6_kernel<BN, H, T>), grid, dim3(256), smem, s, p);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 template <int BN>
 int launch_wgrad_x6(const WGradParams& p, hipStream_t s) {
+    if (p.dtype != SS_DTYPE_F32) {          // 16-bit stored operands: the fp16 matrix cores, one plane each
+        if (!p.h_amax) { ss_set_error("wgrad_x6: 16-bit storage needs the operand maxima (x3h)"); return SS_ERR_UNSUPPORTED; }
+        return p.dtype == SS_DTYPE_F16 ? launch_wgrad_x6h<BN, true, _Float16>(p, s) : launch_wgrad_x6h<BN, true, __bf16>(p, s);
+    }
     return p.h_amax ? launch_wgrad_x6h<BN, true>(p, s) : launch_wgrad_x6h<BN, false>(p, s);
 }
 

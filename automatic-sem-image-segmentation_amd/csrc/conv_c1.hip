@@ -223,7 +223,7 @@ constexpr int I1_TW = 64, I1_TH = 8, I1_HS = 72, I1_HR = I1_TH + 7, I1_FRONT = 8
 __device__ __forceinline__ void c1_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <bool FOLD>
-__global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1Box box, C1Fold f, int ntiles, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1Box box, C1Fold f, int ntiles, int tiles_x, int tiles_y, int dbg) {
     __shared__ __attribute__((aligned(16))) float xs_all[I1_FRONT + I1_HR * I1_HS + 8];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
     __shared__ int tapidx[64];
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
             for (int q = 0; q < 4; ++q) {
                 const float* r = xs + (ry + 2 * q + lh) * I1_HS + rx;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bv[q][e] = q < nq ? r[e] : 0.f;
+                for (int e = 0; e < 8; ++e) bv[q][e] = (q < nq && !(dbg & 1)) ? r[e] : (float)(e + q);          // dbg 1 (measurement): no im2col reads
             }
             if (FOLD && (qy <= f.pt || qy >= f.XH - 1 - f.pt || xb0 <= f.pl || xb0 + 31 >= f.XW - 1 - f.pl)) {
                 // Border rows / columns (wave-uniform test): besides q itself at most ONE more padded row and ONE more padded column
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
                 for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (q < nq) {
+                if (q < nq && !(dbg & 2)) {          // dbg 2: no split, no MFMAs
                     c1_u32x4 bh, bl;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -406,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
             // epilogue: a lane of the C/D layout holds its pixel's channels in 16-byte groups 32 bytes apart -- stored directly, every
             // instruction would touch 32 cache lines for 32 bytes each.  The wave's 32 x 64 block goes through a wave-private LDS
             // scratch and leaves as whole pixel rows: 16 lanes x 16 bytes = one pixel's 256 bytes, 4 pixels per instruction.
+            if (dbg & 8) continue;                   // dbg 8: no epilogue at all
             const float inv = ldexpf(1.f, ew + eb - 28);
             float* const tb = ep_s + wave * (32 * I1_ES);
             __builtin_amdgcn_wave_barrier();
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
                     for (int e = 0; e < 4; ++e) v[e] = ss_apply_act(v[e] + b4[e], p.act, p.alpha);
                     float* op = orow + (long)px * p.out_cs;
                     if (p.accumulate) v += *(const f32x4*)op;
-                    *(f32x4*)op = v;
+                    if (!(dbg & 4)) *(f32x4*)op = v;          // dbg 4: no global stores
                     if (!FOLD) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { st1[e] += v[e]; st2[e] = fmaf(v[e], v[e], st2[e]); }
@@ -702,6 +703,7 @@ struct C1WParams {
     int SH, SW, S_cs;              // the one-channel tensor
     int kh, kw, pt, pl, reflect;
     int tiles_y, tiles_x, ntiles;
+    int dbg;                       // measurement only (tile_dbg): 1 no X loads, 2 no U build, 4 no MFMAs, 8 no X split / stores
 };
 constexpr int C1W_TH = 4, C1W_TW = 64, C1W_PIX = C1W_TH * C1W_TW, C1W_T = 64;
 
@@ -909,7 +911,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_x3h_kernel(C1WParams p) {
             const int px = (tid >> 4) + 16 * j;
             const int qy = y0 + px / XW_TW, qx = x0 + px % XW_TW;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (qy < p.XH && qx < p.XW && cu < p.C) v = *(const f32x4*)(p.X + ((long)(n * p.XH + qy) * p.XW + qx) * p.X_cs + cu);
+            if (qy < p.XH && qx < p.XW && cu < p.C && !(p.dbg & 1)) v = *(const f32x4*)(p.X + ((long)(n * p.XH + qy) * p.XW + qx) * p.X_cs + cu);
+            if (p.dbg & 1) v[0] = 1.f;
             px_[j] = v;
         }
         const int hy0 = MODE == 0 ? y0 + p.pt - (p.kh - 1) : y0 - p.pt;
@@ -966,6 +969,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_x3h_kernel(C1WParams p) {
             sb = ldexpf(1.f, 14 - eb + shift);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                if (p.dbg & 8) break;
                 const int px = (tid >> 4) + 16 * j;
                 c1_f16x4 h, l;
 #pragma unroll
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_x3h_kernel(C1WParams p) {
         }
         if (tile + (int)gridDim.x < p.ntiles) prefetch(tile + gridDim.x);      // in flight while U is built and the tile is multiplied
         c1_lds_barrier();                                        // halo visible
-        if (live) {
+        if (live && !(p.dbg & 2)) {
             const int hy0 = MODE == 0 ? y0 + p.pt - (p.kh - 1) : y0 - p.pt;
             const int hx0 = MODE == 0 ? x0 + p.pl - (p.kw - 1) : x0 - p.pl;
 #pragma unroll 2
@@ -1028,7 +1032,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_x3h_kernel(C1WParams p) {
             }
         }
         c1_lds_barrier();                                        // planes complete
-        if (live) {
+        if (live && !(p.dbg & 4)) {
 #pragma unroll
             for (int ks = 0; ks < XW_PIX / 16; ++ks) {
                 const unsigned char* ap = sX + ks * 16 * XW_PS + a_base;
@@ -1166,8 +1170,9 @@ int launch_in1_x3h(const GConvParams& p, const C1Box& box, const C1Fold& f, hipS
     const int ntiles = p.N * tiles_y * tiles_x;
     const int gy = (p.Cout + 63) / 64;
     const dim3 grid(ntiles < 511 ? ntiles : 511, gy);          // odd: the tiles of one image column (the border columns are slower) spread over all workgroups
-    if (f.on) hipLaunchKernelGGL(conv_in1_x3h_kernel<true>, grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y);
-    else hipLaunchKernelGGL(conv_in1_x3h_kernel<false>, grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y);
+    const int dbg = ss_tuning().tile_dbg;
+    if (f.on) hipLaunchKernelGGL(conv_in1_x3h_kernel<true>, grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
+    else hipLaunchKernelGGL(conv_in1_x3h_kernel<false>, grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -1233,6 +1238,7 @@ int ss_launch_wgrad_c1(int mode, const float* X, int X_cs, int C, int n, int xh,
     p.kh = kh; p.kw = kw; p.pt = pt; p.pl = pl; p.reflect = reflect;
     if (ss_tuning().c1_mfma && C % 4 == 0 && X_cs % 4 == 0 && (((uintptr_t)X) & 15) == 0 && (XW_TH + kh - 1) * (XW_TW + kw - 1) <= 768 &&
         xh >= 2 * pt + 4 && xw >= 2 * pl + 4) {
+        p.dbg = ss_tuning().tile_dbg;
         p.tiles_y = (xh + XW_TH - 1) / XW_TH;
         p.tiles_x = (xw + XW_TW - 1) / XW_TW;
         p.ntiles = n * p.tiles_y * p.tiles_x;

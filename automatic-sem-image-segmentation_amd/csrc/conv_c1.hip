@@ -7,6 +7,7 @@
 //   in1  : out[p][c] = act(bias[c] + sum_t in[map(p + d_t)] * w[t][c])              (Cin == 1)
 // Both take the generic GConvParams (taps = a full KH x KW box, in_s == out_s == 1, class grid == output grid).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -424,21 +425,28 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
             if (cbase + c < p.Cout) {
                 const f32x4 b4 = *(const f32x4*)(bias_s + c);
                 float* const orow = p.out + ((long)(n * OH + qy) * OW + xb0) * p.out_cs + cbase + c;
+                // ACC / PLAIN compile-time inside the store loop: a conditional `v += load` there makes the compiler wait for vmcnt(0)
+                // around every store (each store then waits for the previous one's round trip AND for the halo prefetch)
+                auto stores = [&](auto acc_c, auto plain_c) {
+                    constexpr bool ACC = decltype(acc_c)::value, PLAIN = decltype(plain_c)::value;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int px = 4 * k + (lane >> 4);
-                    if (xb0 + px >= OW) continue;
-                    f32x4 v = *(const f32x4*)(tb + px * I1_ES + c);
+                    for (int k = 0; k < 8; ++k) {
+                        const int px = 4 * k + (lane >> 4);
+                        if (xb0 + px >= OW) continue;
+                        f32x4 v = *(const f32x4*)(tb + px * I1_ES + c);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ss_apply_act(v[e] + b4[e], p.act, p.alpha);
-                    float* op = orow + (long)px * p.out_cs;
-                    if (p.accumulate) v += *(const f32x4*)op;
-                    if (!(dbg & 4)) *(f32x4*)op = v;          // dbg 4: no global stores
-                    if (!FOLD) {
+                        for (int e = 0; e < 4; ++e) v[e] = PLAIN ? v[e] + b4[e] : ss_apply_act(v[e] + b4[e], p.act, p.alpha);
+                        float* op = orow + (long)px * p.out_cs;
+                        if (ACC) v += *(const f32x4*)op;
+                        if (!(dbg & 4)) *(f32x4*)op = v;          // dbg 4: no global stores
+                        if (!FOLD) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { st1[e] += v[e]; st2[e] = fmaf(v[e], v[e], st2[e]); }
+                            for (int e = 0; e < 4; ++e) { st1[e] += v[e]; st2[e] = fmaf(v[e], v[e], st2[e]); }
+                        }
                     }
-                }
+                };
+                if (p.accumulate) { if (p.act == SS_ACT_NONE) stores(std::true_type{}, std::true_type{}); else stores(std::true_type{}, std::false_type{}); }
+                else { if (p.act == SS_ACT_NONE) stores(std::false_type{}, std::true_type{}); else stores(std::false_type{}, std::false_type{}); }
             }
         }
         if (!FOLD && p.stats) {
@@ -619,7 +627,13 @@ __global__ __launch_bounds__(256, 2) void conv_out1_x3h_kernel(GConvParams p, C1
                     const int a = 2 * step + r - o;
                     if (a < 0 || a >= box.kh) continue;
                     const float* z = zr + (8 * a) * O1_ZS + r * 64 + x;
-                    for (int b = 0; b < box.kw; ++b) s += z[b * O1_ZS + b];
+                    // eight unconditional, independent LDS reads (columns >= kw re-read the last one and are masked) instead of a
+                    // runtime-bounded loop of dependent ones
+                    float zz[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) { const int bb = b < box.kw ? b : box.kw - 1; zz[b] = z[bb * O1_ZS + bb]; }
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) s += b < box.kw ? zz[b] : 0.f;
                 }
                 oacc[o * 64 + x] += s;
             }
@@ -631,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void conv_out1_x3h_kernel(GConvParams p, C1
             if (x >= TW || oy >= p.OH || ox >= p.OW) continue;
             float* op = p.out + ((long)(n * p.OH + oy) * p.OW + ox) * p.out_cs;
             float v = ss_apply_act(oacc[i] + bias, p.act, p.alpha);
-            if (p.accumulate) v += *op;
+            if (p.accumulate) v += *op;          // (one store per thread and pass: the wait this costs is not on a store chain)
             *op = v;
         }
     }
@@ -885,12 +899,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_x3h_kernel(C1WParams p) {
     const int uu = tid & 15;
     int ta[4], tbx[4];
     bool tv[4];
+    int toff[4];                   // halo offset of the tap relative to the pixel's own halo position (0 for taps past the box: masked)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int t = 4 * uu + k;
         tv[k] = t < NT;
         ta[k] = tv[k] ? t / p.kw : 0;
         tbx[k] = tv[k] ? t - ta[k] * p.kw : 0;
+        toff[k] = !tv[k] ? 0 : (MODE == 1 ? ta[k] * HW + tbx[k] : (p.kh - 1 - ta[k]) * HW + (p.kw - 1 - tbx[k]));
     }
 
     f32x16 acc;
@@ -989,37 +1005,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_x3h_kernel(C1WParams p) {
         if (live && !(p.dbg & 2)) {
             const int hy0 = MODE == 0 ? y0 + p.pt - (p.kh - 1) : y0 - p.pt;
             const int hx0 = MODE == 0 ? x0 + p.pl - (p.kw - 1) : x0 - p.pl;
-#pragma unroll 2
+            // The own-position reads are UNCONDITIONAL (a tap past the box reads offset 0 and is masked): guarded reads came out as
+            // four serial LDS round trips per pixel.  Pixels outside the image need no mask: their X rows are zero.
+#pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int px = (tid >> 4) + 16 * j;
                 const int ry = px / XW_TW, rx = px % XW_TW;
-                const int qy = y0 + ry, qx = x0 + rx;
-                float u4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (qy < p.XH && qx < p.XW) {
-                    if (MODE == 1) {
+                const float* hb = hs + ry * HW + rx;
+                float u4[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) if (tv[k]) u4[k] = hs[(ry + ta[k]) * HW + (rx + tbx[k])];
-                    } else {
+                for (int k = 0; k < 4; ++k) u4[k] = hb[toff[k]];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) if (tv[k]) u4[k] = hs[(ry + p.kh - 1 - ta[k]) * HW + (rx + p.kw - 1 - tbx[k])];
-                        const bool top = 2 * qy < p.XH, left = 2 * qx < p.XW;
-                        const bool ay = p.reflect && (top ? (qy >= 1 && qy <= p.pt) : (qy <= p.XH - 2 && qy >= p.XH - 1 - p.pt));
-                        const bool ax = p.reflect && (left ? (qx >= 1 && qx <= p.pl) : (qx <= p.XW - 2 && qx >= p.XW - 1 - p.pl));
-                        if (ay || ax) {
-                            // border pixel: besides q itself at most ONE more padded row and ONE more padded column reflect onto q
-                            const int y2 = top ? -qy : 2 * (p.XH - 1) - qy;
-                            const int x2 = left ? -qx : 2 * (p.XW - 1) - qx;
+                for (int k = 0; k < 4; ++k) u4[k] = tv[k] ? u4[k] : 0.f;
+                if (MODE == 0 && p.reflect) {
+                    const int qy = y0 + ry, qx = x0 + rx;
+                    const bool top = 2 * qy < p.XH, left = 2 * qx < p.XW;
+                    const bool ay = qy < p.XH && (top ? (qy >= 1 && qy <= p.pt) : (qy <= p.XH - 2 && qy >= p.XH - 1 - p.pt));
+                    const bool ax = qx < p.XW && (left ? (qx >= 1 && qx <= p.pl) : (qx <= p.XW - 2 && qx >= p.XW - 1 - p.pl));
+                    if (ay || ax) {
+                        // border pixel: besides q itself at most ONE more padded row and ONE more padded column reflect onto q
+                        const int y2 = top ? -qy : 2 * (p.XH - 1) - qy;
+                        const int x2 = left ? -qx : 2 * (p.XW - 1) - qx;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                if (!tv[k]) continue;
-                                auto h = [&](int y, int x) -> float {
-                                    const int hr = y + p.pt - ta[k] - hy0, hc = x + p.pl - tbx[k] - hx0;      // outside the halo = outside dy
-                                    return (hr >= 0 && hr < HR && hc >= 0 && hc < HW) ? hs[hr * HW + hc] : 0.f;
-                                };
-                                if (ay) u4[k] += h(y2, qx);
-                                if (ax) u4[k] += h(qy, x2);
-                                if (ay && ax) u4[k] += h(y2, x2);
-                            }
+                        for (int k = 0; k < 4; ++k) {
+                            if (!tv[k]) continue;
+                            auto h = [&](int y, int x) -> float {
+                                const int hr = y + p.pt - ta[k] - hy0, hc = x + p.pl - tbx[k] - hx0;      // outside the halo = outside dy
+                                return (hr >= 0 && hr < HR && hc >= 0 && hc < HW) ? hs[hr * HW + hc] : 0.f;
+                            };
+                            if (ay) u4[k] += h(y2, qx);
+                            if (ax) u4[k] += h(qy, x2);
+                            if (ay && ax) u4[k] += h(y2, x2);
                         }
                     }
                 }

@@ -281,32 +281,38 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
             const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) b4 = *(const f32x4*)(p.bias + cbase + rcol);
+            // ACC / PLAIN compile-time inside the store loop (see conv_mfma_x6v2.hip: a conditional load in it costs a vmcnt(0) per store)
+            auto epi = [&](auto acc_c, auto plain_c) {
+                constexpr bool ACC = decltype(acc_c)::value, PLAIN = decltype(plain_c)::value;
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
+                for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
+                    for (int rq = 0; rq < 4; ++rq) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
+                        for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                        for (int ni = 0; ni < TN; ++ni)
-                            tb[(rr + 4 * lh) * COLS + ni * 32 + l31] = H ? acc[mi][ni][rq * 4 + rr] * out_scale : acc[mi][ni][rq * 4 + rr];
-                    __builtin_amdgcn_wave_barrier();          // one wave's LDS operations execute in issue order
+                            for (int ni = 0; ni < TN; ++ni)
+                                tb[(rr + 4 * lh) * COLS + ni * 32 + l31] = H ? acc[mi][ni][rq * 4 + rr] * out_scale : acc[mi][ni][rq * 4 + rr];
+                        __builtin_amdgcn_wave_barrier();          // one wave's LDS operations execute in issue order
 #pragma unroll
-                    for (int k = 0; k < NRD; ++k) {
-                        const int row = rrow + RPI * k;
-                        f32x4 v = *(const f32x4*)(tb + row * COLS + rcol);
-                        const int pix = pixtab[wm * (BM / 2) + mi * 32 + 8 * rq + row];
-                        if (pix >= 0) {
-                            float* op = g_out + (long)pix * p.out_cs + cbase + rcol;
+                        for (int k = 0; k < NRD; ++k) {
+                            const int row = rrow + RPI * k;
+                            f32x4 v = *(const f32x4*)(tb + row * COLS + rcol);
+                            const int pix = pixtab[wm * (BM / 2) + mi * 32 + 8 * rq + row];
+                            if (pix >= 0) {
+                                float* op = g_out + (long)pix * p.out_cs + cbase + rcol;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = ss_apply_act(v[e] + b4[e], p.act, p.alpha);
-                            if (p.accumulate) v += *(const f32x4*)op;
-                            *(f32x4*)op = v;
+                                for (int e = 0; e < 4; ++e) v[e] = PLAIN ? v[e] + b4[e] : ss_apply_act(v[e] + b4[e], p.act, p.alpha);
+                                if (ACC) v += *(const f32x4*)op;
+                                *(f32x4*)op = v;
+                            }
                         }
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
-            }
+            };
+            if (p.accumulate) { if (p.act == SS_ACT_NONE) epi(std::true_type{}, std::true_type{}); else epi(std::true_type{}, std::false_type{}); }
+            else { if (p.act == SS_ACT_NONE) epi(std::false_type{}, std::true_type{}); else epi(std::false_type{}, std::false_type{}); }
             return;
         }
     }

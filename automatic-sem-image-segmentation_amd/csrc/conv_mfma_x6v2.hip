@@ -288,33 +288,43 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) b4 = *(const f32x4*)(p.bias + cbase + rcol);
         f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};          // p.stats: this lane's 4 channels over the rows it stores
+        // ACC / PLAIN are compile-time inside the store loop: with `if (p.accumulate) v += load` in it the compiler put an
+        // s_waitcnt vmcnt(0) around EVERY store (the conditional load's result joins the store path), i.e. each of the 16 stores
+        // waited for the previous one's round trip -- and the generic activation switch sat between them.
+        auto epi = [&](auto acc_c, auto plain_c) {
+            constexpr bool ACC = decltype(acc_c)::value, PLAIN = decltype(plain_c)::value;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
+                for (int rq = 0; rq < 4; ++rq) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
+                    for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni) tb[(rr + 4 * lh) * COLS + ni * 32 + l31] = acc[mi][ni][rq * 4 + rr] * out_scale;
-                __builtin_amdgcn_wave_barrier();          // one wave's LDS operations execute in issue order
+                        for (int ni = 0; ni < TN; ++ni) tb[(rr + 4 * lh) * COLS + ni * 32 + l31] = acc[mi][ni][rq * 4 + rr] * out_scale;
+                    __builtin_amdgcn_wave_barrier();          // one wave's LDS operations execute in issue order
 #pragma unroll
-                for (int k = 0; k < NRD; ++k) {
-                    const int row = rrow + RPI * k;
-                    f32x4 v = *(const f32x4*)(tb + row * COLS + rcol);
-                    const int pix = pixtab[wm * 64 + mi * 32 + 8 * rq + row];
-                    if (pix >= 0) {
-                        T* op = g_out + pix * p.out_cs + cbase + rcol;
+                    for (int k = 0; k < NRD; ++k) {
+                        const int row = rrow + RPI * k;
+                        f32x4 v = *(const f32x4*)(tb + row * COLS + rcol);
+                        const int pix = pixtab[wm * 64 + mi * 32 + 8 * rq + row];
+                        if (pix >= 0) {
+                            T* op = g_out + pix * p.out_cs + cbase + rcol;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ss_apply_act(v[e] + b4[e], p.act, p.alpha);
-                        if (p.accumulate) v += v2_ld4(op);
-                        v2_st4(op, v);
+                            for (int e = 0; e < 4; ++e) v[e] = PLAIN ? v[e] + b4[e] : ss_apply_act(v[e] + b4[e], p.act, p.alpha);
+                            if (ACC) v += v2_ld4(op);
+                            v2_st4(op, v);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { st1[e] += v[e]; st2[e] = fmaf(v[e], v[e], st2[e]); }
+                            for (int e = 0; e < 4; ++e) { st1[e] += v[e]; st2[e] = fmaf(v[e], v[e], st2[e]); }
+                        }
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
             }
-        }
+        };
+        using TC = std::true_type;
+        using FC = std::false_type;
+        if (p.accumulate) { if (p.act == SS_ACT_NONE) epi(TC{}, TC{}); else epi(TC{}, FC{}); }
+        else { if (p.act == SS_ACT_NONE) epi(FC{}, TC{}); else epi(FC{}, FC{}); }
         if (p.stats) {
             // output statistics of the tile's 256 rows (one chunk of ss_conv_desc::y_stats: the launcher lets a tile hold rows of ONE
             // sample only and every wave is on this path), fixed order: the lanes that share 4 channels, then the four M waves

@@ -8,6 +8,7 @@
 // The transforms are streaming (HBM-bound) kernels: one thread = one tile x VW channels (float4 for R=2, float2 for R=4).
 // fp32 error vs fp64 (rel-L2, K = 128 channels, measured on CPU): direct 2.2e-7, F(2,3) 3.5e-7, F(4,3) 2.3e-6.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -592,42 +593,53 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                     dx_[i] = -1;
                 }
             }
+        // `accumulate` as a compile-time constant inside the store loop: a conditional `v += load` there makes the compiler wait for
+        // vmcnt(0) around every store (16 serial round trips per thread)
+        auto fold_stores = [&](auto acc_c) {
+            constexpr bool ACC = decltype(acc_c)::value;
 #pragma unroll
-        for (int i = 0; i < R; ++i)
+            for (int i = 0; i < R; ++i)
 #pragma unroll
-            for (int j = 0; j < R; ++j) {
-                if (dy_[i] < 0 || dx_[j] < 0) continue;
-                T v = o[i][j];
-                TO* dst = y + ((long)(n * FH + dy_[i]) * FW + dx_[j]) * y_cs + c;
-                if (accumulate) v += ld_t<T, TO>(dst);
-                st_t<T, TO>(dst, v);
-            }
+                for (int j = 0; j < R; ++j) {
+                    if (dy_[i] < 0 || dx_[j] < 0) continue;
+                    T v = o[i][j];
+                    TO* dst = y + ((long)(n * FH + dy_[i]) * FW + dx_[j]) * y_cs + c;
+                    if (ACC) v += ld_t<T, TO>(dst);
+                    st_t<T, TO>(dst, v);
+                }
+        };
+        if (accumulate) fold_stores(std::true_type{}); else fold_stores(std::false_type{});
         return;
     }
     float s1[VW], s2[VW];
 #pragma unroll
     for (int k = 0; k < VW; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+    auto plain_stores = [&](auto acc_c, auto act_c) {          // compile-time inside the store loop, as above
+        constexpr bool ACC = decltype(acc_c)::value, ACT = decltype(act_c)::value;
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        T o[R];
-        t_out<R, T>(s[i], o);
+        for (int i = 0; i < R; ++i) {
+            T o[R];
+            t_out<R, T>(s[i], o);
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int oy = R * ty + i, ox = R * tx + j;
-            if (oy < OH && ox < OW) {
-                T v = o[j] + bv;
-                if (act != SS_ACT_NONE) {
+            for (int j = 0; j < R; ++j) {
+                const int oy = R * ty + i, ox = R * tx + j;
+                if (oy < OH && ox < OW) {
+                    T v = o[j] + bv;
+                    if (ACT) {
 #pragma unroll
-                    for (int k = 0; k < VW; ++k) v[k] = ss_apply_act(v[k], act, alpha);
+                        for (int k = 0; k < VW; ++k) v[k] = ss_apply_act(v[k], act, alpha);
+                    }
+                    TO* dst = y + ((long)(n * OH + oy) * OW + ox) * y_cs + c;
+                    if (ACC) v += ld_t<T, TO>(dst);
+                    st_t<T, TO>(dst, v);
+#pragma unroll
+                    for (int k = 0; k < VW; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
                 }
-                TO* dst = y + ((long)(n * OH + oy) * OW + ox) * y_cs + c;
-                if (accumulate) v += ld_t<T, TO>(dst);
-                st_t<T, TO>(dst, v);
-#pragma unroll
-                for (int k = 0; k < VW; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
             }
         }
-    }
+    };
+    if (accumulate) { if (act != SS_ACT_NONE) plain_stores(std::true_type{}, std::true_type{}); else plain_stores(std::true_type{}, std::false_type{}); }
+    else { if (act != SS_ACT_NONE) plain_stores(std::false_type{}, std::true_type{}); else plain_stores(std::false_type{}, std::false_type{}); }
     if (stats) {
         // statistics of what was just written, for the norm that follows: a block holds 256 / CV whole tiles of ONE sample (launcher);
         // their sums are combined in fixed order and written as one chunk [n][chunk][C][2] (the layout of norm.hip's partials)

@@ -21,25 +21,24 @@ static inline size_t ss_align_up(size_t v, size_t a) { return (v + a - 1) / a * 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Activation with a RUN-TIME (wave-uniform) code.  The piecewise-linear ones (none / relu / leaky relu) -- every hot path -- are one
+// branch-free form, v > 0 ? v : neg(v) with neg chosen by uniform selects: as a `switch` this function cost ~14 scalar instructions and
+// several taken branches per ELEMENT wherever it was inlined into an unrolled epilogue or a norm loop.  Same values
+// bit for bit (relu of a NaN is 0, leaky relu multiplies, none returns v).
 __device__ __forceinline__ float ss_apply_act(float v, int act, float alpha) {
-    switch (act) {
-        case SS_ACT_RELU: return v > 0.f ? v : 0.f;
-        case SS_ACT_LRELU: return v > 0.f ? v : alpha * v;
-        case SS_ACT_TANH: return tanhf(v);
-        case SS_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-        default: return v;
-    }
+    if (act == SS_ACT_TANH) return tanhf(v);
+    if (act == SS_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    const float lin = act == SS_ACT_LRELU ? alpha * v : v;
+    const float neg = act == SS_ACT_RELU ? 0.f : lin;
+    return v > 0.f ? v : neg;
 }
 
 // derivative of the activation expressed through the forward OUTPUT y
 __device__ __forceinline__ float ss_act_grad_from_out(float y, int act, float alpha) {
-    switch (act) {
-        case SS_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-        case SS_ACT_LRELU: return y > 0.f ? 1.f : alpha;
-        case SS_ACT_TANH: return 1.f - y * y;
-        case SS_ACT_SIGMOID: return y * (1.f - y);
-        default: return 1.f;
-    }
+    if (act == SS_ACT_TANH) return 1.f - y * y;
+    if (act == SS_ACT_SIGMOID) return y * (1.f - y);
+    const float neg = act == SS_ACT_RELU ? 0.f : (act == SS_ACT_LRELU ? alpha : 1.f);
+    return y > 0.f ? 1.f : neg;
 }
 
 // ---- exact 3-way bf16 split of fp32 values (x6 contraction, conv_mfma_x6.hip; also emitted by the Winograd weight transform)

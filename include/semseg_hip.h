@@ -181,8 +181,11 @@ typedef struct ss_conv_desc {
  * in_norm_* fields themselves) and the ss_config table. */
 int ss_conv2d_fuses_in_norm(const ss_conv_desc* d, int pass);
 
-/* Chunks per sample of the output statistics the FORWARD pass of `d` can emit (0: this descriptor's path cannot -- anything but
- * an fp32 Winograd convolution without fused activation, today).  Pure function of d and the ss_config table. */
+/* Chunks per sample of the output statistics the FORWARD pass of `d` can emit (0: this descriptor's path cannot).  Today: fp32
+ * storage, no fused activation, and one of -- the Winograd forward; the 1 -> C matrix-core kernel of the full-resolution stem
+ * (one chunk per 8 x 64 output tile); the gather kernel gconv_x6v2 of the stride-2 / 4x4 layers (one chunk per 256 output pixels,
+ * when those tiles do not straddle samples).  Pure function of d and the ss_config table; a forward call that was handed y_stats but
+ * cannot take that kernel (workspace too small, misaligned operands) fails with SS_ERR_UNSUPPORTED instead of leaving it unwritten. */
 int ss_conv2d_stats_chunks(const ss_conv_desc* d);
 /* Upper bound of the device bytes the pass keeps in the layer's weight cache (0: nothing, e.g. the weight gradient). */
 size_t ss_conv2d_wcache_bytes(const ss_conv_desc* d, int pass);

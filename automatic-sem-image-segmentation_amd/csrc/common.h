@@ -281,6 +281,7 @@ int ss_launch_wgrad_c1(int mode, const float* X, int X_cs, int C, int n, int xh,
 
 // fp32-exact contraction on the bf16 matrix cores (conv_mfma_x6.hip): three bf16 pieces per operand, six products
 bool ss_gconv_x6_ok(const GConvParams& p);                  // shape / alignment eligibility
+bool ss_gconv_x6_typed_ok(const GConvParams& p);            // ... of a 16-bit stored problem for the typed loaders of gconv_x6_kernel
 int ss_x6_npad(int cout);
 size_t ss_gconv_x6_planes_bytes(const GConvParams& p);      // [3][nbatch][npad(Cout)][ntaps*Cin] bf16
 int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s);

@@ -418,9 +418,10 @@ int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStre
         if (c1 || (tconv_takes(algo, p) && ws && ws_bytes >= ss_tconv_ws(p)) || gconv_two_stage(algo, p)) return SS_OK;
         if (!(use_x6(algo, p) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p))) return SS_OK;
     }
-    if (p.dtype != SS_DTYPE_F32) {          // 16-bit storage: only gconv_x6v2 loads / stores the stored type here (callers check with gconv16_takes)
+    if (p.dtype != SS_DTYPE_F32) {          // 16-bit storage: only the x3h gather kernels load / store the stored type here (callers check with gconv16_takes)
         const bool v2 = (algo == SS_ALGO_AUTO || algo == SS_ALGO_X6) && !ss_conv_out1_ok(p) && !ss_conv_in1_ok(p) && !tconv_takes(algo, p) &&
-                        !gconv_two_stage(algo, p) && use_x6(algo, p) && ss_gconv_x6v2_ok(p) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p);
+                        !gconv_two_stage(algo, p) && use_x6(algo, p) && (ss_gconv_x6v2_ok(p) || ss_gconv_x6_typed_ok(p)) && ws &&
+                        ws_bytes >= ss_gconv_x6_planes_bytes(p);
         if (!v2) { ss_set_error("run_gconv: no kernel with a 16-bit loader for this problem"); return SS_ERR_UNSUPPORTED; }
     }
     if (algo != SS_ALGO_DIRECT && algo != SS_ALGO_MFMA) {        // full-resolution 7x7 stem / head shapes: LDS-tiled VALU kernels
@@ -1079,7 +1080,7 @@ bool wino16_dgrad_takes(const ConvProb& c, int algo, WinoProb* q) {
            (!c.reflect || q->fold_h > 0) && ss_tuning().wino_r == 4 && ss_wino_fwd_x3h(*q);
 }
 
-// Gather convolutions on 16-bit stored activations: gconv_x6v2 reads / writes the stored type (one fp16 operand plane, conv_mfma_x6v2.hip).
+// Gather convolutions on 16-bit stored activations: gconv_x6v2 / gconv_x6 read and write the stored type (one fp16 operand plane).
 // `p` is the problem run_gconv would see; true when run_gconv's choice for it is that kernel.
 bool gconv16_takes(int algo, const GConvParams& p0) {
     if (algo != SS_ALGO_AUTO && algo != SS_ALGO_X6) return false;
@@ -1087,7 +1088,7 @@ bool gconv16_takes(int algo, const GConvParams& p0) {
     GConvParams p = p0;
     p.h_amax = &dummy; p.h_amax2 = &dummy; p.amax_stripes = 1;
     if (ss_conv_out1_ok(p) || ss_conv_in1_ok(p) || tconv_takes(algo, p) || gconv_two_stage(algo, p)) return false;
-    return use_x6(algo, p) && ss_gconv_x6v2_ok(p);
+    return use_x6(algo, p) && (ss_gconv_x6v2_ok(p) || ss_gconv_x6_typed_ok(p));
 }
 // ... every sub-pixel phase of the data gradient of `c` (the loop of conv_bwd_data)
 bool bwd_data_gather16_ok(const ConvProb& c, int algo) {

@@ -38,9 +38,23 @@ constexpr int XBM = 128;
 // ONE power-of-two scale s per operand TENSOR (p.h_amax: bit patterns of max|activation|, max|weight|, set by conv_api.hip), three
 // products h*h + h*l + l*h in the same accumulator (the cross terms are 2^-11 smaller by themselves); values within 2^-17 of
 // the tensor maximum keep 22 bits, smaller ones keep an absolute 2^-38 of the maximum.  The scales are undone in the epilogue.
-template <int BM, int BN, bool H>
+typedef _Float16 xw_f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 xw_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 xw_ld4(const float* q) { return *(const f32x4*)q; }
+__device__ __forceinline__ f32x4 xw_ld4(const _Float16* q) { return __builtin_convertvector(*(const xw_f16x4*)q, f32x4); }
+__device__ __forceinline__ f32x4 xw_ld4(const __bf16* q) { return __builtin_convertvector(*(const xw_bf16x4*)q, f32x4); }
+__device__ __forceinline__ void xw_st4(float* q, f32x4 v) { *(f32x4*)q = v; }
+__device__ __forceinline__ void xw_st4(_Float16* q, f32x4 v) { *(xw_f16x4*)q = __builtin_convertvector(v, xw_f16x4); }
+__device__ __forceinline__ void xw_st4(__bf16* q, f32x4 v) { *(xw_bf16x4*)q = __builtin_convertvector(v, xw_bf16x4); }
+
+// T: activation storage type; NPROD: products per K step.  16-bit storage (H only, whole 32-channel chunks): the stored value (times a
+// power of two) is the ONE fp16 operand plane of A; NPROD = 2 multiplies it with both weight pieces, 1 with the leading one
+// (ss_tuning wino16_products), as conv_mfma_x6v2.hip.
+template <int BM, int BN, bool H, typename T = float, int NPROD = 3>
 __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems,
                                                           int Npad, int Ktot) {
+    constexpr bool S16 = !std::is_same<T, float>::value;
+    static_assert(!S16 || (H && NPROD <= 2), "16-bit storage: fp16 matrix cores, one or two products");
     constexpr int NP = H ? 2 : 3;        // operand planes
     typedef typename std::conditional<H, f16x8, bf16x8>::type FT;
     constexpr int TM = BM / 64;          // 32-row MFMA tiles per wave (2 waves along M)
@@ -69,8 +83,8 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const int gridM = (int)((M + BM - 1) / BM);
     const int batch = tile / (gridM * gridN);
     tile -= batch * gridM * gridN;
-    const float* const g_in = p.in + (long)batch * p.in_bs;
-    float* const g_out = p.out + (long)batch * p.out_bs;
+    const T* const g_in = (const T*)p.in + (long)batch * p.in_bs;
+    T* const g_out = (T*)p.out + (long)batch * p.out_bs;
     const long m0 = (long)(tile / gridN) * BM;
     const int n0 = (tile % gridN) * BN;
     const int nchunks = Ktot / XK;
@@ -134,15 +148,15 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         constexpr int S = decltype(setc)::value;
         const int t = k0 / Cq;                         // block-uniform
         const int ci0 = k0 - t * Cq;
-        if (!ragged) {
-            const float* abase = g_in + ci0 + c4a * 4;
+        if (S16 || !ragged) {          // (16-bit storage: the launcher admits whole, aligned 32-channel chunks only)
+            const T* abase = g_in + ci0 + c4a * 4;
 #pragma unroll
             for (int j = 0; j < AU; ++j) {
                 const int off = offtab[(arow + 32 * j) * p.ntaps + t];
-                const float* pa = off < 0 ? (const float*)ss_zero_page16 : abase + off;      // masked taps read zeros
-                ra[S][j] = *(const f32x4*)pa;
+                const T* pa = off < 0 ? (const T*)ss_zero_page16 : abase + off;      // masked taps read zeros
+                ra[S][j] = xw_ld4(pa);
             }
-        } else {
+        } else if constexpr (!S16) {
             // any channel count / pixel stride (the MultiResUNet's odd widths): the reduction index runs over (tap, ci padded to a
             // multiple of 32 -- the weight planes hold zeros there); a 4-channel unit is fetched with ONE dword-aligned
             // global_load_dwordx4 when it lies fully inside the pixel's channels, element-wise when it straddles the end
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
             for (int j = 0; j < AU; ++j) {
                 const int off = offtab[(arow + 32 * j) * p.ntaps + t];
                 const bool ok = off >= 0 && nin > 0;
-                const float* ptr = ok ? g_in + (off + ci) : (const float*)ss_zero_page16;
+                const float* ptr = ok ? (const float*)g_in + (off + ci) : (const float*)ss_zero_page16;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (nin >= 4) {
                     const f32x4u u = *(const f32x4u*)ptr;
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
                     ss_split_h2(v[2 * e] * a_scale, v[2 * e + 1] * a_scale, hh[e], ll[e]);
                 }
                 *(u32x2*)(dst) = u32x2{hh[0], hh[1]};
-                *(u32x2*)(dst + BM * XLD) = u32x2{ll[0], ll[1]};
+                if (!S16) *(u32x2*)(dst + BM * XLD) = u32x2{ll[0], ll[1]};
             } else {
                 unsigned int h[2], m[2], l[2];
                 ss_split3x2(f32x2{v[0], v[1]}, h[0], m[0], l[0]);
@@ -227,15 +241,20 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
             FT a[NP][TM], b[NP][TN];
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
+                if (pl == 0 || !S16) {
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) a[pl][mi] = *(const FT*)(fa + pl * BM * XLD + mi * 32 * XLD + ks * 16);
+                    for (int mi = 0; mi < TM; ++mi) a[pl][mi] = *(const FT*)(fa + pl * BM * XLD + mi * 32 * XLD + ks * 16);
+                }
+                if (pl == 0 || !S16 || NPROD >= 2) {
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const FT*)(fb + pl * BN * XLD + ni * 32 * XLD + ks * 16);
+                    for (int ni = 0; ni < TN; ++ni) b[pl][ni] = *(const FT*)(fb + pl * BN * XLD + ni * 32 * XLD + ks * 16);
+                }
             }
-            // x6: six products, smallest terms first;  x3h: l*h, h*l, h*h.  Consecutive MFMAs go to different accumulators
-            constexpr int NQ = H ? 3 : 6;
+            // x6: six products, smallest terms first;  x3h: l*h, h*l, h*h (16-bit storage: h*l, h*h or h*h).  Consecutive MFMAs go to
+            // different accumulators
+            constexpr int NQ = H ? (S16 ? NPROD : 3) : 6;
             constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-            constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+            constexpr int HA[3] = {S16 ? 0 : 1, 0, 0}, HB[3] = {S16 ? (NPROD == 2 ? 1 : 0) : 0, S16 ? 0 : 1, 0};
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -300,11 +319,11 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
                             f32x4 v = *(const f32x4*)(tb + row * COLS + rcol);
                             const int pix = pixtab[wm * (BM / 2) + mi * 32 + 8 * rq + row];
                             if (pix >= 0) {
-                                float* op = g_out + (long)pix * p.out_cs + cbase + rcol;
+                                T* op = g_out + (long)pix * p.out_cs + cbase + rcol;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = PLAIN ? v[e] + b4[e] : ss_apply_act(v[e] + b4[e], p.act, p.alpha);
-                                if (ACC) v += *(const f32x4*)op;
-                                *(f32x4*)op = v;
+                                if (ACC) v += xw_ld4(op);
+                                xw_st4(op, v);
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -323,14 +342,14 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int pix = pixtab[wm * (BM / 2) + mi * 32 + row];
             if (pix < 0) continue;
-            float* orow = g_out + (long)pix * p.out_cs;
+            T* orow = g_out + (long)pix * p.out_cs;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
                 if (co[ni] >= p.Cout) continue;
-                float* op = orow + co[ni];
+                T* op = orow + co[ni];
                 float v = ss_apply_act((H ? acc[mi][ni][r] * out_scale : acc[mi][ni][r]) + bv[ni], p.act, p.alpha);
-                if (p.accumulate) v += *op;
-                *op = v;
+                if (p.accumulate) v += (float)*op;
+                *op = (T)v;
             }
         }
     }
@@ -387,12 +406,6 @@ __global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned s
 // Lane -> (pixel group = tid & 7, channel quad = tid >> 3): a 16-lane store group covers two rows x 16 dwords = 32 banks.
 // T: activation storage type.  16-bit storage (H only): both operands ARE stored 16-bit values -- one fp16 plane each (scaled by a
 // power of two: exact), ONE product h*h per K step is the exact product of the stored values, accumulated in fp32.
-typedef _Float16 xw_f16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 xw_bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 xw_ld4(const float* q) { return *(const f32x4*)q; }
-__device__ __forceinline__ f32x4 xw_ld4(const _Float16* q) { return __builtin_convertvector(*(const xw_f16x4*)q, f32x4); }
-__device__ __forceinline__ f32x4 xw_ld4(const __bf16* q) { return __builtin_convertvector(*(const xw_bf16x4*)q, f32x4); }
-
 template <int BN, bool H, typename T = float>
 __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
     constexpr bool S16 = !std::is_same<T, float>::value;          // single-plane operands
@@ -660,7 +673,7 @@ int launch_wgrad_x6(const WGradParams& p, hipStream_t s) {
     return p.h_amax ? launch_wgrad_x6h<BN, true>(p, s) : launch_wgrad_x6h<BN, false>(p, s);
 }
 
-template <int BM, int BN, bool H>
+template <int BM, int BN, bool H, typename T = float, int NPROD = 3>
 int launch_x6h(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
     const long M = (long)p.N * p.OHc * p.OWc;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
@@ -668,21 +681,29 @@ int launch_x6h(const GConvParams& p, const unsigned short* planes, long plane_el
     const size_t smem = (size_t)(H ? 2 : 3) * (BM + BN) * XLD * sizeof(unsigned short) + (size_t)BM * sizeof(int) * (4 + p.ntaps);
     // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
     static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)gconv_x6_kernel<BM, BN, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gconv_x6_kernel<BM, BN, H, T, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
     char pname[64];
     if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_x6<%d,%d,%d> M%ld N%d K%dx%d s%d b%d", BM, BN, (int)H, M, p.Cout, p.ntaps, p.Cin, p.in_s, nb);
-    else snprintf(pname, sizeof(pname), "gconv_x6_kernel<%d,%d,%s>", BM, BN, H ? "true" : "false");
-    SsProfScope prof(pname, 2.0 * M * p.Cout * p.ntaps * p.Cin * nb * (H ? 3 : 6),
-                     4.0 * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout + (double)p.ntaps * p.Cin * p.Cout), s);
-    hipLaunchKernelGGL((gconv_x6_kernel<BM, BN, H>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot);
+    else if (std::is_same<T, float>::value) snprintf(pname, sizeof(pname), "gconv_x6_kernel<%d,%d,%s>", BM, BN, H ? "true" : "false");
+    else snprintf(pname, sizeof(pname), "gconv_x6_kernel<%d,%d,16-bit,%d>", BM, BN, NPROD);
+    SsProfScope prof(pname, 2.0 * M * p.Cout * p.ntaps * p.Cin * nb * (std::is_same<T, float>::value ? (H ? 3 : 6) : NPROD),
+                     (double)sizeof(T) * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout) + 4.0 * nb * p.ntaps * p.Cin * p.Cout, s);
+    hipLaunchKernelGGL((gconv_x6_kernel<BM, BN, H, T, NPROD>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 template <int BM, int BN>
 int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
+    if (p.dtype != SS_DTYPE_F32) {          // 16-bit stored activations: typed loaders, one fp16 operand plane (whole aligned 32-channel chunks, x3h)
+        if (!ss_gconv_x6_typed_ok(p)) { ss_set_error("gconv_x6: this 16-bit problem has no typed loader"); return SS_ERR_UNSUPPORTED; }
+        const bool two = ss_tuning().wino16_products == 3;
+        if (p.dtype == SS_DTYPE_F16)
+            return two ? launch_x6h<BM, BN, true, _Float16, 2>(p, planes, plane_elems, Npad, Ktot, s) : launch_x6h<BM, BN, true, _Float16, 1>(p, planes, plane_elems, Npad, Ktot, s);
+        return two ? launch_x6h<BM, BN, true, __bf16, 2>(p, planes, plane_elems, Npad, Ktot, s) : launch_x6h<BM, BN, true, __bf16, 1>(p, planes, plane_elems, Npad, Ktot, s);
+    }
     return p.h_amax ? launch_x6h<BM, BN, true>(p, planes, plane_elems, Npad, Ktot, s) : launch_x6h<BM, BN, false>(p, planes, plane_elems, Npad, Ktot, s);
 }
 
@@ -702,6 +723,12 @@ size_t ss_gconv_x6_planes_bytes(const GConvParams& p) {
 }
 
 // weights of `p` (fp32, addressed through p.w / taps / ldb / w_bs) -> the three K-contiguous bf16 planes
+// 16-bit storage through gconv_x6_kernel: x3h maxima present, whole 32-channel chunks at 8-byte aligned pixels, 4-aligned outputs
+bool ss_gconv_x6_typed_ok(const GConvParams& p) {
+    return p.h_amax && p.h_amax2 && p.Cin % 32 == 0 && (p.in_cs & 3) == 0 && (((uintptr_t)p.in) & 7) == 0 && p.Cout % 4 == 0 && (p.out_cs & 3) == 0 &&
+           (((uintptr_t)p.out) & 7) == 0;
+}
+
 int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s) {
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * ((p.Cin + 31) / 32 * 32);

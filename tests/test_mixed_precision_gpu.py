@@ -44,6 +44,10 @@ CONV_CASES = [
     ("gather16_down_s2_64_128", 3, 64, 128, 2, "same", False, False, 4, 256, 256),
     ("gather16_disc_4x4_s2_128_256_bias", 4, 128, 256, 2, "same", True, False, 8, 128, 128),
     ("gather16_up_T3_256_128", 3, 256, 128, 2, "same", False, True, 16, 64, 64),
+    # ... and the 64-output shapes that stay on gconv_x6_kernel (the generators' last transposed convolution, the data gradient of
+    # their first stride-2 convolution): typed loaders there as well
+    ("gather16_up_T3_128_64", 3, 128, 64, 2, "same", False, True, 4, 128, 128),
+    ("gather16_down_s2_32_64_ragged", 3, 32, 64, 2, "same", False, False, 3, 100, 90),
     ("up_T3", 3, 64, 32, 2, "same", False, True, 2, 32, 32),
     ("stem7_reflect", 7, 1, 16, 1, ("reflect", 3), False, False, 1, 64, 64),
     ("unet_upT2_bias", 2, 26, 16, 2, "same", True, True, 2, 32, 32),

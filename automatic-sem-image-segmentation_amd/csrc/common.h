@@ -186,6 +186,7 @@ struct WGradParams {
     int amax_stripes, amax2_stripes;   // each maximum is spread over this many words, SS_AMAX_STRIDE apart (0 / 1: one word)
     int64_t a_bs, b_bs;
     int32_t dtype;                // ss_dtype of `a` / `b` (tile kernel only); partials and dw are fp32
+    int32_t dbg;                  // measurement only (tile_dbg): wgrad_x6 phase skipping
     int32_t ntaps;
     GTap taps[SS_MAX_TAPS];       // woff = destination offset of the tap block inside dw
 };

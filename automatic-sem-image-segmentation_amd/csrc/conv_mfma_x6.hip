@@ -481,14 +481,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
         f_n = (int)(r / p.GH);
     }
 
-    f32x4 ra[4], rb[4];
+    // TWO register sets: the global loads run two K steps ahead of their split + LDS store (with one set a step was a serial chain of
+    // load latency -> split -> barrier -> 24 MFMAs -> barrier: ~3 us per 32-pixel chunk whatever the operand bytes)
+    f32x4 ra[2][4], rb[2][4];
     // Out-of-image / out-of-range pieces are READ from a 16-byte zero page (a pointer select per load instead of a value select per
     // element at store time).  Fast addressing (the usual case): the class grid's rows are multiples of 4 pixels and the split
     // starts on one, so a thread's 4 pixels lie in ONE row -- the row is mapped once, the columns step by the stride -- and both
     // tensors are below 2^31 elements, so the offsets are 32-bit until the final pointer add.
     const T* const zpage = (const T*)ss_zero_page16;
     const bool fast = (p.GW & 3) == 0 && (ps & 3) == 0 && (long)p.N * p.AH * p.AW * p.a_cs < (1L << 31) && P * p.b_cs < (1L << 31);
-    auto load_tiles = [&](long pk0) {
+    auto load_tiles = [&](auto setc, long pk0) {
+        constexpr int S = decltype(setc)::value;
+        if (p.dbg & 1) {          // measurement: no global loads
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ra[S][i] = f32x4{1.f, 2.f, 3.f, 4.f}; rb[S][i] = f32x4{1.f, 1.f, 1.f, 1.f}; }
+            return;
+        }
         if (fast) {
             const long pk = pk0 + 4 * kq;
             const bool in = pk < pe;              // pe is a multiple of 4 here: all four pixels or none
@@ -502,9 +510,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
             for (int i = 0; i < 4; ++i) {
                 const int ix = ss_map_index(xb + i * p.a_s, p.AW, p.reflect);
                 const T* pa = (rowok && ix >= 0) ? g_a + ((rowbase + ix) * p.a_cs + a_c) : zpage;
-                ra[i] = xw_ld4(pa);
+                ra[S][i] = xw_ld4(pa);
                 const T* pb = okb ? g_b + (bo + i * p.b_cs) : zpage;
-                rb[i] = xw_ld4(pb);
+                rb[S][i] = xw_ld4(pb);
             }
         } else {
             int x = f_x, y = f_y, n = f_n;
@@ -515,10 +523,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
                 const int ix = ss_map_index(x * p.a_s + p.a_ox + a_dx, p.AW, p.reflect);
                 const bool oka = a_val && pk < pe && iy >= 0 && ix >= 0;
                 const T* pa = oka ? g_a + (((long)(n * p.AH + iy) * p.AW + ix) * p.a_cs + a_c) : zpage;
-                ra[i] = xw_ld4(pa);
+                ra[S][i] = xw_ld4(pa);
                 const bool okb = b_val && pk < pe;
                 const T* pb = okb ? g_b + (pk * p.b_cs + bn) : zpage;
-                rb[i] = xw_ld4(pb);
+                rb[S][i] = xw_ld4(pb);
                 if (++x >= p.GW) { x = 0; if (++y >= p.GH) { y = 0; ++n; } }
             }
         }
@@ -526,9 +534,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
         f_x += XK;
         while (f_x >= p.GW) { f_x -= p.GW; if (++f_y >= p.GH) { f_y = 0; ++f_n; } }
     };
-    auto store_tiles = [&]() {
-        const f32x4 (&va)[4] = ra;
-        const f32x4 (&vb)[4] = rb;
+    auto store_tiles = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
+        if (p.dbg & 2) return;          // measurement: no split, no LDS stores
+        const f32x4 (&va)[4] = ra[S];
+        const f32x4 (&vb)[4] = rb[S];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             unsigned short* dst = sA + (4 * cq + e) * XLD + 4 * kq;
@@ -582,18 +592,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
                 if constexpr (H) accx[mi][ni][r] = 0.f;
             }
 
-    if (nchunks > 0) {
-        load_tiles(ps);
-        store_tiles();
-    }
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    if (nchunks > 0) load_tiles(S0{}, ps);
+    if (nchunks > 1) load_tiles(S1{}, ps + XK);
+    if (nchunks > 0) store_tiles(S0{});
     __syncthreads();
 
     const unsigned short* fa = sA + (wm * 64 + l31) * XLD + 8 * lh;
     const unsigned short* fb = sB + (wn * (BN / 2) + l31) * XLD + 8 * lh;
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) load_tiles(ps + (long)(c + 1) * XK);
+    // step c: chunk c is in LDS, chunk c+1 in register set (c+1)&1 (requested one step ago), chunk c+2 is requested into set c&1
+    auto step = [&](int c, auto cur, auto nxt) {
+        if (c + 2 < nchunks) load_tiles(cur, ps + (long)(c + 2) * XK);
 #pragma unroll
         for (int ks = 0; ks < XK / 16; ++ks) {
+            if (p.dbg & 4) break;          // measurement: no fragment reads, no MFMAs
             FT a[NP][2], b[NP][TN];
 #pragma unroll
             for (int pl = 0; pl < (S16 ? 1 : NP); ++pl) {
@@ -620,9 +633,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WGradParams p) {
         }
         __syncthreads();
         if (c + 1 < nchunks) {
-            store_tiles();
+            store_tiles(nxt);
             __syncthreads();
         }
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        step(c, S0{}, S1{});
+        if (c + 1 < nchunks) step(c + 1, S1{}, S0{});
     }
 
     float* part = p.part + (long)bz * M * p.Cb;
@@ -660,7 +677,9 @@ int launch_wgrad_x6h(const WGradParams& p, hipStream_t s) {
     else snprintf(pname, sizeof(pname), "wgrad_x6_kernel<%d,%s%s>", BN, H ? "true" : "false", std::is_same<T, float>::value ? "" : ",16-bit");
     const double pix = (double)p.N * p.GH * p.GW * (p.nbatch > 1 ? p.nbatch : 1);
     SsProfScope prof(pname, 2.0 * M * p.Cb * pix * (std::is_same<T, float>::value ? (H ? 3 : 6) : 1), (double)sizeof(T) * pix * (p.Ca + p.Cb) + 4.0 * M * p.Cb * p.splits, s);
-    hipLaunchKernelGGL((wgrad_x6_kernel<BN, H, T>), grid, dim3(256), smem, s, p);
+    WGradParams pd = p;
+    pd.dbg = ss_tuning().tile_dbg;
+    hipLaunchKernelGGL((wgrad_x6_kernel<BN, H, T>), grid, dim3(256), smem, s, pd);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

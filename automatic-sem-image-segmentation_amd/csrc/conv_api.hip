@@ -127,7 +127,14 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double acc = 0.0;
-    for (int k = 0; k < chunks; ++k) acc += part[(long)k * C + c];
+    // 16 loads in flight, same summation order (rolled, the loop was one L2 round trip per chunk: 73 us for 1024 chunks)
+    for (int k = 0; k < chunks; k += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = k + u < chunks ? part[(long)(k + u) * C + c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
     out[c] = accumulate ? out[c] + (float)acc : (float)acc;
 }
 

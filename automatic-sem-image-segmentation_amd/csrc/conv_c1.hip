@@ -219,13 +219,17 @@ __global__ __launch_bounds__(256) void conv_in1_kernel(GConvParams p, C1Box box)
 typedef _Float16 c1_f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int c1_u32x4 __attribute__((ext_vector_type(4)));
 struct C1Fold { int on, pt, pl, XH, XW; };
-constexpr int I1_TW = 64, I1_TH = 8, I1_HS = 72, I1_HR = I1_TH + 7, I1_FRONT = 8, I1_ES = 68;
+constexpr int I1_TW = 64, I1_TH = 8, I1_HS = 72, I1_FRONT = 8, I1_ES = 68;
 
 __device__ __forceinline__ void c1_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool FOLD>
+// S: input stride (1, or 2: the discriminators' 4x4 stride-2 stem -- the halo tile is S x larger each way, a lane's 8 k-values are still 8
+// consecutive floats of one halo row)
+template <bool FOLD, int S = 1>
 __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1Box box, C1Fold f, int ntiles, int tiles_x, int tiles_y, int dbg) {
-    __shared__ __attribute__((aligned(16))) float xs_all[I1_FRONT + I1_HR * I1_HS + 8];
+    constexpr int HS = S == 1 ? I1_HS : 2 * I1_TW + 8, HR = S * (I1_TH - 1) + 8;          // halo row stride / rows (boxes up to 8 x 8)
+    static_assert(!FOLD || S == 1, "the folded data gradient is a stride-1 problem");
+    __shared__ __attribute__((aligned(16))) float xs_all[I1_FRONT + HR * HS + 8];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
     __shared__ int tapidx[64];
     __shared__ float wred[4];
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
     const int nq = (box.kh + 1) >> 1;                       // K steps of 16 = two box rows
 
     if (tid < 64) { tapidx[tid] = -1; bias_s[tid] = (p.bias && cbase + tid < p.Cout) ? p.bias[cbase + tid] : 0.f; }
-    for (int i = tid; i < I1_FRONT + I1_HR * I1_HS + 8; i += 256) xs_all[i] = 0.f;
+    for (int i = tid; i < I1_FRONT + HR * HS + 8; i += 256) xs_all[i] = 0.f;
     __syncthreads();
     if (tid < p.ntaps) tapidx[(p.taps[tid].dy - box.dy0) * 8 + (p.taps[tid].dx - box.dx0)] = tid;
     __syncthreads();
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
     }
 
     // halo of the NEXT tile in registers while the current one is multiplied
-    constexpr int NPRE = (I1_HR * I1_HS + 255) / 256;
+    constexpr int NPRE = (HR * HS + 255) / 256;
     float pre[NPRE];
     const int org_y = p.in_oy + box.dy0 + (FOLD ? f.pt : 0), org_x = p.in_ox + box.dx0 + (FOLD ? f.pl : 0);
     auto prefetch = [&](int tile) {
@@ -293,11 +297,11 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) {
             const int idx = tid + 256 * u;
-            const int r = idx / I1_HS, col = idx - r * I1_HS;
+            const int r = idx / HS, col = idx - r * HS;
             float v = 0.f;
-            if (r < I1_HR && r < I1_TH + box.kh - 1 && col < I1_TW + box.kw - 1) {
-                const int iy = ss_map_index(y0 + org_y + r, p.IH, p.reflect);
-                const int ix = ss_map_index(x0 + org_x + col, p.IW, p.reflect);
+            if (r < HR && r < S * (I1_TH - 1) + box.kh && col < S * (I1_TW - 1) + box.kw) {
+                const int iy = ss_map_index(S * y0 + org_y + r, p.IH, p.reflect);
+                const int ix = ss_map_index(S * x0 + org_x + col, p.IW, p.reflect);
                 if (iy >= 0 && ix >= 0) v = p.in[((long)(n * p.IH + iy) * p.IW + ix) * p.in_cs];
             }
             pre[u] = v;
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) {
             const int idx = tid + 256 * u;
-            if (idx < I1_HR * I1_HS) xs[idx] = pre[u];
+            if (idx < HR * HS) xs[idx] = pre[u];
         }
         c1_lds_barrier();
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
             float bv[4][8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float* r = xs + (ry + 2 * q + lh) * I1_HS + rx;
+                const float* r = xs + (S * ry + 2 * q + lh) * HS + S * rx;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bv[q][e] = (q < nq && !(dbg & 1)) ? r[e] : (float)(e + q);          // dbg 1 (measurement): no im2col reads
             }
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
                         const int hr = ry + 2 * q + lh + oy;
                         if (q < nq && hr >= 0 && hr < hr_n) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) bv[q][e] += xs[hr * I1_HS + rx + e];
+                            for (int e = 0; e < 8; ++e) bv[q][e] += xs[hr * HS + rx + e];
                         }
                     }
                 }
@@ -362,8 +366,8 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
                             for (int e = 0; e < 8; ++e) {
                                 const int hc = rx + e + ox;
                                 if (hc >= 0 && hc < hc_n) {
-                                    bv[q][e] += xs[hr * I1_HS + hc];
-                                    if (yin) bv[q][e] += xs[(hr + oy) * I1_HS + hc];
+                                    bv[q][e] += xs[hr * HS + hc];
+                                    if (yin) bv[q][e] += xs[(hr + oy) * HS + hc];
                                 }
                             }
                         }
@@ -1175,7 +1179,7 @@ int ss_launch_conv_out1(const GConvParams& p, hipStream_t s) {
 // ... on the matrix cores: >= 32 output channels in multiples of 4, any full tap box up to 8 x 8
 namespace {
 bool in1_x3h_shape(const GConvParams& p, C1Box* box) {
-    if (!ss_tuning().c1_mfma || p.Cin != 1 || p.in_s != 1 || p.out_s != 1 || p.nbatch > 1 || p.Cout < 32 || p.Cout % 4 != 0 || p.out_cs % 4 != 0 ||
+    if (!ss_tuning().c1_mfma || p.Cin != 1 || (p.in_s != 1 && p.in_s != 2) || p.out_s != 1 || p.nbatch > 1 || p.Cout < 32 || p.Cout % 4 != 0 || p.out_cs % 4 != 0 ||
         (((uintptr_t)p.out) & 15) != 0 || p.dtype != SS_DTYPE_F32) return false;
     if (!tap_box(p, box) || box->kh > 8 || box->kw > 8) return false;
     return true;
@@ -1187,8 +1191,9 @@ int launch_in1_x3h(const GConvParams& p, const C1Box& box, const C1Fold& f, hipS
     const int gy = (p.Cout + 63) / 64;
     const dim3 grid(ntiles < 511 ? ntiles : 511, gy);          // odd: the tiles of one image column (the border columns are slower) spread over all workgroups
     const int dbg = ss_tuning().tile_dbg;
-    if (f.on) hipLaunchKernelGGL(conv_in1_x3h_kernel<true>, grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
-    else hipLaunchKernelGGL(conv_in1_x3h_kernel<false>, grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
+    if (f.on) hipLaunchKernelGGL((conv_in1_x3h_kernel<true, 1>), grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
+    else if (p.in_s == 2) hipLaunchKernelGGL((conv_in1_x3h_kernel<false, 2>), grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
+    else hipLaunchKernelGGL((conv_in1_x3h_kernel<false, 1>), grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -1217,6 +1222,11 @@ int ss_conv_in1_stats_chunks(const GConvParams& p) {
 // Cin == 1, stride 1, full tap box, Cout % 16 == 0, weights with the output channel contiguous (ldb irrelevant for one input channel)
 bool ss_conv_in1_ok(const GConvParams& p) {
     C1Box box;
+    if (p.Cin == 1 && p.in_s == 2) {          // stride 2 (the discriminators' stem): the matrix-core kernel only
+        GConvParams q = p;
+        q.in_s = 1;
+        return plain_grid(q) && (long)p.N * p.OH * p.OW >= 16384 && (long)p.N * p.IH * p.IW * p.in_cs < (1L << 31) && in1_x3h_shape(p, &box) && box.kh <= 8 && box.kw <= 8;
+    }
     if (p.Cin != 1 || !plain_grid(p) || p.Cout % 16 != 0 || p.out_cs % 4 != 0 || (((uintptr_t)p.out) & 15) != 0) return false;
     if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return false;
     if ((long)p.N * p.OH * p.OW < 16384 || !tap_box(p, &box)) return false;

@@ -82,6 +82,9 @@ CONV_CASES = [
     ("c7_out_mfma_32_fold_ragged", 7, 32, 1, 1, ("reflect", 3), False, None, False, 2, 100, 90),
     ("c4_out_mfma_valid_32", 4, 32, 1, 1, "valid", True, None, False, 2, 100, 96),
     ("c3_in_mfma_same_bias_96", 3, 1, 96, 1, "same", True, "lrelu", False, 2, 96, 100),
+    # ... and with stride 2 (the discriminators' 4x4 stem, CycleGAN.py:388-396): the same kernel on a 2x larger halo tile
+    ("disc_in_mfma_s2_64_valid", 4, 1, 64, 2, "valid", True, "lrelu", False, 2, 200, 190),
+    ("c3_in_mfma_s2_32_same_odd", 3, 1, 32, 2, "same", False, None, False, 3, 131, 150),
     # >= 65536 pixels: their weight gradient on the fp16 matrix cores as well (wgrad_c1_x3h_kernel: K-major planes, transposing LDS reads)
     ("c7_out_wgrad_64", 7, 64, 1, 1, ("reflect", 3), True, "tanh", False, 1, 256, 260),
     ("c7_in_wgrad_64_ragged", 7, 1, 64, 1, ("reflect", 3), False, None, False, 1, 259, 256),

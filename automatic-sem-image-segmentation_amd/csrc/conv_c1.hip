@@ -1009,6 +1009,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_x3h_kernel(C1WParams p) {
         if (live && !(p.dbg & 2)) {
             const int hy0 = MODE == 0 ? y0 + p.pt - (p.kh - 1) : y0 - p.pt;
             const int hx0 = MODE == 0 ? x0 + p.pl - (p.kw - 1) : x0 - p.pl;
+            // interior tiles (75 % at 512 x 512) skip the fold terms with one uniform branch: evaluating the per-pixel border tests for
+            // every pixel cost 45 of the kernel's 250 us
+            const bool tile_border = MODE == 0 && (y0 <= p.pt || y0 + XW_TH - 1 >= p.XH - 1 - p.pt || x0 <= p.pl || x0 + XW_TW - 1 >= p.XW - 1 - p.pl);
             // The own-position reads are UNCONDITIONAL (a tap past the box reads offset 0 and is masked): guarded reads came out as
             // four serial LDS round trips per pixel.  Pixels outside the image need no mask: their X rows are zero.
 #pragma unroll
@@ -1021,7 +1024,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_x3h_kernel(C1WParams p) {
                 for (int k = 0; k < 4; ++k) u4[k] = hb[toff[k]];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) u4[k] = tv[k] ? u4[k] : 0.f;
-                if (MODE == 0 && p.reflect) {
+                if (MODE == 0 && p.reflect && tile_border && !(p.dbg & 16)) {          // (dbg 16, measurement: no fold terms)
                     const int qy = y0 + ry, qx = x0 + rx;
                     const bool top = 2 * qy < p.XH, left = 2 * qx < p.XW;
                     const bool ay = qy < p.XH && (top ? (qy >= 1 && qy <= p.pt) : (qy <= p.XH - 2 && qy >= p.XH - 1 - p.pt));

@@ -372,7 +372,14 @@ def find_contours(mask):
     four = ndimage.generate_binary_structure(2, 1)
     out = []
 
-    def keep(region):
+    def keep(region, sl, border):
+        # Measurements.py:170-187: the small-contour test sits in the `elif` of the edge test -- a contour with a vertex on the first
+        # / last row or column is never tested for smallness (and, with excludeEdges=False, always kept).  The extreme coordinates
+        # of a polygon are vertices, so "a vertex on the image edge" = "a border pixel on the image edge".
+        ys, xs = np.nonzero(border)
+        if ys.size and (ys.min() + sl[0].start == 0 or xs.min() + sl[1].start == 0
+                        or ys.max() + sl[0].start >= H - 1 or xs.max() + sl[1].start >= W - 1):
+            return True
         if region.shape[0] > 4 or region.shape[1] > 4:
             return True
         nv, perim = _small_polygon(region)
@@ -384,7 +391,7 @@ def find_contours(mask):
         region = ndimage.binary_fill_holes(comp)
         outside = np.pad(~region, 1, constant_values=True)
         border = comp & ndimage.binary_dilation(outside, structure=four)[1:-1, 1:-1]
-        if keep(region):
+        if keep(region, sl, border):
             out.append(dict(kind='outer', slice=sl, border=border, region=region))
     bg4, _ = ndimage.label(~fg)                                   # 4-connected background
     edge = set(np.unique(np.concatenate([bg4[0], bg4[-1], bg4[:, 0], bg4[:, -1]]))) - {0}
@@ -395,7 +402,7 @@ def find_contours(mask):
         hole = bg4[big] == h
         ring = ndimage.binary_dilation(hole, structure=four) & fg[big]
         region = ndimage.binary_fill_holes(hole | ring)
-        if keep(region):
+        if keep(region, big, ring):
             out.append(dict(kind='hole', slice=big, border=ring, region=region))
     return out
 

@@ -71,11 +71,16 @@ class WorkflowOptions:
     MAX_NO_OF_PARTICLES: int = 150
     WGAN_NOISE_DIM: int = 128
 
+    _DERIVED_DIRS = (("INPUT_DIR_MASKS", "Input_Masks"), ("INPUT_DIR_IMAGES", "Input_Images"),
+                     ("OUTPUT_DIR_CYCLEGAN", "Output_Masks_CycleGAN"), ("OUTPUT_DIR_UNET", "Output_Masks_UNet"))
+
     def __post_init__(self):
         self.ROOT_DIR = os.path.abspath(self.ROOT_DIR)
-        for name, sub in (("INPUT_DIR_MASKS", "Input_Masks"), ("INPUT_DIR_IMAGES", "Input_Images"),
-                          ("OUTPUT_DIR_CYCLEGAN", "Output_Masks_CycleGAN"), ("OUTPUT_DIR_UNET", "Output_Masks_UNet")):
-            if getattr(self, name) is None:
+        # directories the caller did not name follow ROOT_DIR -- also when ROOT_DIR changes later (`set`): remember which they are
+        defaulted = self.__dict__.setdefault("_defaulted", set())
+        for name, sub in self._DERIVED_DIRS:
+            if getattr(self, name) is None or name in defaulted:
+                defaulted.add(name)
                 setattr(self, name, os.path.join(self.ROOT_DIR, sub))
         if not isinstance(self.USE_GPUS_NO, (list, tuple)):
             self.USE_GPUS_NO = (self.USE_GPUS_NO,)
@@ -101,6 +106,7 @@ class WorkflowOptions:
         else:
             val = text
         setattr(self, name, val)
+        self.__dict__.setdefault("_defaulted", set()).discard(name)          # an explicitly set directory no longer follows ROOT_DIR
         self.__post_init__()
 
 
@@ -216,9 +222,10 @@ class Workflow:
         import torch
         if dist.rank() == 0:
             print(self.TITLES[key], flush=True)
-        if key in self.HOST_ONLY or key in ("2", "4", "6b"):          # file-producing steps: one writer
-            if dist.rank() == 0:
-                getattr(self, "step_" + key)()
+        if key in self.HOST_ONLY or key in ("2", "4", "6b"):          # file-producing steps: one writer, working alone --
+            if dist.rank() == 0:                                        # the models it builds must not broadcast (dist.solo)
+                with dist.solo():
+                    getattr(self, "step_" + key)()
         else:
             getattr(self, "step_" + key)()
         if dist.world_size() > 1:

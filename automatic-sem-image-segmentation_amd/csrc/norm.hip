@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x
                 if (recompute) {
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
-                        const float t = (xv[v] - mu[v]) * (rs[v] * gm[v]) + bt[v];
+                        // the forward's expression, bit for bit (norm_apply_kernel / the fused operand loads: explicit fma)
+                        const float t = __builtin_fmaf(xv[v] - mu[v], rs[v] * gm[v], bt[v]);
                         gv[v] *= ss_act_grad_from_out(t, act, alpha);          // relu / lrelu: depends on the sign only
                     }
                 } else if (act != SS_ACT_NONE) {
@@ -404,7 +405,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                     if (recompute) {
 #pragma unroll
                         for (int v = 0; v < V; ++v) {
-                            const float t = (xv[u][v] - mu[v]) * (rs[v] * (gamma ? gm[v] : 1.f)) + bt[v];
+                            // the forward's expression, bit for bit (norm_apply_kernel / the fused operand loads: explicit fma)
+                            const float t = __builtin_fmaf(xv[u][v] - mu[v], rs[v] * (gamma ? gm[v] : 1.f), bt[v]);
                             gv[u][v] *= ss_act_grad_from_out(t, act, alpha);
                         }
                     } else if (from_y) {
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(256) void norm_small_fwd_kernel(const T* __restrict
         if (res) ldv<V>(res + (base + p) * res_cs + c, rv);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            float t = (xv[v] - mu[v]) * sc[v] + bt[v];
+            float t = __builtin_fmaf(xv[v] - mu[v], sc[v], bt[v]);          // explicit: the backward recomputes the mask with this expression
             if (res) t += rv[v];
             o[v] = ss_apply_act(t, act, alpha);
         }
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const T* __restrict
                 ldv<V>(dy + (base + p) * dy_cs + c, gv);
                 if (recompute) {
 #pragma unroll
-                    for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out((xv[v] - mu[v]) * (rs[v] * gm[v]) + bt[v], act, alpha);
+                    for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out(__builtin_fmaf(xv[v] - mu[v], rs[v] * gm[v], bt[v]), act, alpha);
                 } else if (act != SS_ACT_NONE) {
                     float yv[V];
                     ldv<V>(y + (base + p) * y_cs + c, yv);
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const T* __restrict
                 ldv<V>(dy + (base + p) * dy_cs + c, gv);
                 if (recompute) {
 #pragma unroll
-                    for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out((xv[v] - mu[v]) * (rs[v] * gm[v]) + bt[v], act, alpha);
+                    for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out(__builtin_fmaf(xv[v] - mu[v], rs[v] * gm[v], bt[v]), act, alpha);
                 } else if (act != SS_ACT_NONE) {
                     float yv[V];
                     ldv<V>(y + (base + p) * y_cs + c, yv);

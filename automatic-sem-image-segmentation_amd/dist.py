@@ -7,6 +7,7 @@ gradient all-reduce: each network keeps ONE flat gradient arena, reduced in a fe
 point-to-point, 7 links x ~153 GB/s per GPU -> few large messages, not many small ones).  Losses are means over
 the GLOBAL batch: gradients are summed over ranks and scaled by 1/world inside the fused Adam kernel.
 """
+import contextlib
 import os
 
 import numpy as np
@@ -15,17 +16,34 @@ import torch.distributed as dist
 
 BUCKET_ELEMS = 16 * 1024 * 1024     # 64 MiB fp32 buckets
 
+_SOLO = 0          # depth of `solo()` sections: this rank works alone, every collective of this module is skipped
+
 
 def is_dist():
     return dist.is_available() and dist.is_initialized()
 
 
 def world_size():
-    return dist.get_world_size() if is_dist() else 1
+    return dist.get_world_size() if is_dist() and not _SOLO else 1
 
 
 def rank():
     return dist.get_rank() if is_dist() else 0
+
+
+@contextlib.contextmanager
+def solo():
+    """Work that only ONE rank executes (the file-producing workflow steps: StartProcess.Workflow.run_step) must not issue
+    collectives -- the other ranks are already waiting in the barrier behind the step, and a broadcast from a freshly built
+    model (`broadcast_params` in every `create_model`) against that barrier hangs or corrupts the group.  Inside this section
+    `world_size()` is 1, so every collective here (broadcast, gradient / SyncBN / metric all-reduce) is a no-op and data
+    loaders do not shard; `rank()` keeps its value."""
+    global _SOLO
+    _SOLO += 1
+    try:
+        yield
+    finally:
+        _SOLO -= 1
 
 
 def local_device():

@@ -308,7 +308,8 @@ class Conv2D:
 
     def _uses_amax(self, d, pass_):
         """ss_conv2d_uses_amax(d, pass), cached per geometry: bit 0 = the pass reads (and leaves in the slot) max|x|, bit 1 = max|dy|."""
-        key = (d.n, d.ih, d.iw, d.in_cstride, d.out_cstride, d.oh, d.ow, pass_, L.CONFIG_EPOCH)
+        # dtype / transposed are part of the answer (native 16-bit paths need no maximum): one layer can see both storage types
+        key = (d.n, d.ih, d.iw, d.in_cstride, d.out_cstride, d.oh, d.ow, d.dtype, d.transposed, pass_, L.CONFIG_EPOCH)
         u = self._amax_cache.get(key)
         if u is None:
             u = L.load().ss_conv2d_uses_amax(ctypes.byref(d), pass_)

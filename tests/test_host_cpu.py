@@ -97,6 +97,68 @@ def test_data_parallel_plumbing_gloo_world2(tmp_path):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o
 
 
+_SOLO_WORKER = r"""
+import os, sys, importlib
+import torch
+sys.path.insert(0, sys.argv[1])
+D = importlib.import_module("automatic-sem-image-segmentation_amd.dist")
+SP = importlib.import_module("automatic-sem-image-segmentation_amd.StartProcess")
+D.init_from_env("gloo")
+r = D.rank()
+class Arena: pass
+class Net: pass
+calls = []
+def fake_step(self):
+    # what WGAN.simulate_masks -> load_model -> create_model does on the ONE rank that runs a file-producing step: build a model and
+    # broadcast its parameters (WassersteinGAN.py create_model); plus the other collectives a model may issue
+    assert D.rank() == 0 and D.world_size() == 1
+    net = Net(); net.arena = Arena()
+    net.arena.params = torch.ones(8); net.arena.state = torch.ones(2); net.arena.grads = torch.ones(8)
+    D.broadcast_params([net])
+    D.all_reduce_flat(net.arena.grads)
+    assert float(D.mean_scalars([3.0])[0]) == 3.0
+    calls.append(1)
+for key in ("2", "4", "6b"):
+    setattr(SP.Workflow, "step_" + key, fake_step)
+wf = SP.Workflow(SP.WorkflowOptions(ROOT_DIR=sys.argv[2]))
+wf.run(steps=["2", "4", "6b"])
+assert D.world_size() == 2 and len(calls) == (3 if r == 0 else 0)
+t = torch.tensor([float(r + 1)]); torch.distributed.all_reduce(t); assert float(t) == 3.0      # the group is still in step
+print("RANK_OK", r, flush=True)
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_rank0_only_workflow_steps_issue_no_collectives_gloo_world2(tmp_path):
+    """steps 2 / 4 / 6b run on rank 0 alone while the other ranks wait in the barrier behind the step; a model built
+    there must not broadcast (dist.solo).  Without the guard rank 0's broadcast meets rank 1's barrier and the run hangs."""
+    script = tmp_path / "worker.py"
+    script.write_text(_SOLO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), REPO, str(tmp_path)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    try:
+        outs = [p.communicate(timeout=180)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o
+
+
+def test_workflow_options_directories_follow_root_dir():
+    SP = importlib.import_module(BASE + ".StartProcess")
+    o = SP.WorkflowOptions(ROOT_DIR="/tmp/ss_a")
+    o.set("OUTPUT_DIR_UNET", "/x/y")
+    o.set("ROOT_DIR", "/tmp/ss_b")          # --set ROOT_DIR=...: the defaulted directories move with it, the named one stays
+    assert o.INPUT_DIR_IMAGES == "/tmp/ss_b/Input_Images" and o.OUTPUT_DIR_CYCLEGAN == "/tmp/ss_b/Output_Masks_CycleGAN"
+    assert o.OUTPUT_DIR_UNET == "/x/y"
+    import dataclasses
+    o2 = SP.WorkflowOptions(**dataclasses.asdict(o))          # what --spawn hands to the child process
+    assert o2.INPUT_DIR_IMAGES == o.INPUT_DIR_IMAGES and o2.OUTPUT_DIR_UNET == "/x/y"
+
+
 def test_connectivity_and_loader_match_reference_vectors(golden_dir, tmp_path):
     from PIL import Image
     HF = importlib.import_module(BASE + ".HelperFunctions")

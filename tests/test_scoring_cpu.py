@@ -131,6 +131,17 @@ def test_small_contour_removal_rule():
     m[6:9, 2:5] = m[6, 8:13] = 255                             # kept: 3x3 (perimeter 8), 5-pixel line (perimeter 8)
     kept = sorted(int(c["region"].sum()) for c in HF.find_contours(m))
     assert kept == [5, 9]
+    # the smallness test is the `elif` of the edge test (Measurements.py:170-187): a speck with a vertex on the first / last row or
+    # column is never tested, and kept when excludeEdges=False -- here a pixel in a corner, a 2x2 on the bottom row, a pair on the
+    # right column; the same shapes one pixel inside are dropped
+    e = np.zeros((12, 40), np.uint8)
+    e[0, 0] = e[10:12, 6:8] = e[4:6, 39] = 255                 # on the border: kept (1, 4, 2 pixels)
+    e[1, 3] = e[8:10, 12:14] = e[4:6, 37] = 255                # one pixel inside: dropped
+    kept = sorted(int(c["region"].sum()) for c in HF.find_contours(e))
+    assert kept == [1, 2, 4], kept
+    out = HF.draw_contours_filled(HF.find_contours(e), e.shape)
+    exp = np.zeros_like(e); exp[0, 0] = exp[10:12, 6:8] = exp[4:6, 39] = 255
+    assert np.array_equal(out, exp)
 
 
 def test_iou_and_roc_known_answers():

@@ -344,6 +344,285 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may still be landing when the LDS is handed to the next workgroup
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// PING-PONG form of the x3h kernel (two fp16 planes, three products, two accumulator sets; same tile, same LDS image, same ring of
+// three 48 KiB stages, same MFMA order per accumulator => bit-identical results to gemm_x6p_kernel<2>).
+//
+// What the one-phase kernel above loses (tools/x6p_dma_probe.sh): its K loop without any memory traffic runs at
+// 0.50 of the MFMA peak, its LDS-DMA costs +76 us and its C stores +46 us per launch ON TOP of that -- they add instead of hiding,
+// because every wave carries all three instruction kinds in ONE in-order stream: a wave whose LDS-DMA waits for a slot in the CU's
+// vector-memory queue cannot issue the MFMAs behind it, and both waves of a SIMD reach that point together (they run the same phase).
+//
+// Here the two waves of a SIMD (waves w and w + 4: a workgroup's waves go to the SIMDs cyclically) run HALF A K STEP APART.  Time is
+// cut into slots by s_barrier; in every slot one wave of each SIMD is in its C slot -- 24 back-to-back MFMAs at raised priority,
+// nothing else -- while its partner is in its M slot: the 16 fragment reads of its next chunk (ONE fragment register set: the wave is
+// not computing), its six LDS-DMA pieces of the chunk two ahead, the counted wait for the chunk one ahead, and at a tile boundary
+// the epilogue of the tile it just finished.  Memory-queue stalls land on a wave that has a whole C slot (768 matrix-pipe cycles) of
+// slack; the matrix pipe of every SIMD always has exactly one feeder.
+//
+//   group 0 (waves 0-3):  B0 |      M(0) | C(0) | M(1) | C(1) | ...                 | barrier
+//   group 1 (waves 4-7):  B0 | bar | M(0) | C(0) | M(1) | ...                | C(last) |
+//
+// LDS ring, chunk c in stage c % 3 (barrier numbers: group 0 leaves M(c) through #2c+1, group 1 through #2c+2):
+//   * chunk c is read in M(c): group 0 between #2c and #2c+1, group 1 between #2c+1 and #2c+2;
+//   * chunk c+2 is DMA-issued in M(c) into the stage of chunk c-1, whose last reads (group 1, M(c-1)) retired before #2c;
+//   * a wave waits for ITS pieces of chunk c+1 at the end of M(c) (vmcnt = the pieces of chunk c+2, plus the epilogue's stores
+//     when they are younger) -- group 0 before #2c+1, group 1 before #2c+2 -- and chunk c+1 is first read after #2c+2.
+// The epilogue of tile T runs at the start of M(0) of tile T+1, after that slot's DMA issue (stores younger than the pieces the next
+// two waits are for); its partner is in C(last) of tile T meanwhile.
+__device__ unsigned long long g_x6p_dbg[32];          // measurement only (tile_dbg & 512): slot timing of waves 0 and 4 of workgroup 0
+__global__ __launch_bounds__(512, 1) void gemm_x6p_pp_kernel(X6PParams p) {
+    constexpr int NPL = 2;
+    constexpr int STAGE_B = NPL * (A_PLANE_B + B_PLANE_B);          // 48 KiB
+    constexpr int NWV = 8, WN = PBN / 64;
+    constexpr int NDMA = STAGE_B / 1024 / NWV;                      // 6 LDS-DMA instructions per wave and chunk
+    constexpr int STAGES = 3;
+    typedef f16x8 FT;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;          // 0: leads, 1: one slot behind
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + PBN - 1) / PBN;
+    const int per = gridM * gridN;
+    const int total = per * p.nbatch * p.splits;
+    int t_first, t_end, t_stride;          // XCD-aware persistent tile walk, as gemm_x6p_kernel
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        if (nwg == total) { t_first = start + slot; t_end = t_first + 1; t_stride = 1; }
+        else { t_first = start + slot; t_end = start + q + (xcd < r ? 1 : 0); t_stride = nwg >> 3; }
+    }
+    // LDS-DMA pieces of a wave and chunk: 4 of A (32 = 2 planes x 16 row blocks over 8 waves: one plane, four consecutive row blocks)
+    // and 2 of B (16 = 2 planes x 8).  A piece = 16 rows x 64 B; lane (rl, sl) fetches the 16-byte slot sl ^ ((row >> 2) & 3) of row
+    // rl of the block -- the same lane offset for every piece (the block index does not enter bits 2..3 of the row), so a piece's
+    // address is a UNIFORM base (scalar registers) plus one of two per-lane offsets.
+    const int rl = lane >> 2, sl = lane & 3;
+    const int ko = sl ^ ((rl >> 2) & 3);
+    const unsigned laneA = (unsigned)(rl * p.lda + 8 * ko) * 2u, laneB = (unsigned)(rl * p.ldb + 8 * ko) * 2u;          // bytes
+    const int qa = wave * 4, qb = wave * 2;
+    const int plA = qa / (PBM / 16), rbA = qa % (PBM / 16), plB = qb / (PBN / 16), rbB = qb % (PBN / 16);
+    const int loffA = plA * A_PLANE_B + rbA * 1024, loffB = NPL * A_PLANE_B + plB * B_PLANE_B + rbB * 1024;
+    struct TileCtx { int m0, n0, nchunks; long cbase; long ua, ub; };          // ua / ub: element offsets of this wave's first A / B piece
+    auto setup = [&](int t) __attribute__((always_inline)) -> TileCtx {
+        const int bs = t / per;
+        const int tl = t - bs * per;
+        const int batch = bs / p.splits, split = bs - batch * p.splits;
+        const int m0 = (tl / gridN) * PBM, n0 = (tl % gridN) * PBN;
+        const int k_begin = split * p.k_per_split;
+        const int k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
+        const long ua = plA * p.a_plane + batch * p.a_bs + (long)(m0 + rbA * 16) * p.lda + k_begin;
+        const long ub = plB * p.b_plane + batch * p.b_bs + (long)(n0 + rbB * 16) * p.ldb + k_begin;
+        return TileCtx{m0, n0, (k_end - k_begin) / PBK, (long)batch * p.c_bs + (long)split * p.c_ss, ua, ub};
+    };
+    const bool skipA = p.dbg & 128, skipB = p.dbg & 64;          // measurement only
+    // the six pieces of chunk (element offset goff from the tile's first chunk) of the tile with bases (ua, ub) into stage `dst`
+    auto dma_chunk = [&](long ua, long ub, long goff, unsigned char* dst) __attribute__((always_inline)) {
+        const char* ga = (const char*)(p.a + ua + goff);
+        const char* gb = (const char*)(p.b + ub + goff);
+        if (!skipA) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (long)j * 32 * p.lda + laneA),
+                                                 (__attribute__((address_space(3))) void*)(dst + loffA + j * 1024), 16, 0, 0);
+        }
+        if (!skipB) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long)j * 32 * p.ldb + laneB),
+                                                 (__attribute__((address_space(3))) void*)(dst + loffB + j * 1024), 16, 0, 0);
+        }
+    };
+    if (t_first >= t_end) return;
+    TileCtx cur = setup(t_first);
+    f32x16 acc[2][2][2];          // [0]: h*h, [1]: the cross terms (factor 2^-11)
+
+    const int sw = (l31 >> 2) & 3;
+    const int so0 = ((lh ^ sw) << 4), so1 = so0 ^ 32;
+    const unsigned char* fa = lds + (wm * 64 + l31) * ROWB;
+    const unsigned char* fb = lds + NPL * A_PLANE_B + (wn * 64 + l31) * ROWB;
+    FT a0[NPL][2], b0[NPL][2], a1[NPL][2], b1[NPL][2];          // ONE set: both K halves of the chunk the next C slot multiplies
+    auto frag = [&](FT (&a)[NPL][2], FT (&b)[NPL][2], int stage, int so) __attribute__((always_inline)) {
+        const int sb = stage * STAGE_B;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[pl][mi] = *(const FT*)(fa + sb + pl * A_PLANE_B + mi * 32 * ROWB + so);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[pl][ni] = *(const FT*)(fb + sb + pl * B_PLANE_B + ni * 32 * ROWB + so);
+        }
+    };
+    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0}, HS[3] = {1, 1, 0};          // l*h, h*l (cross accumulators), h*h
+    auto mma4 = [&](FT (&a)[NPL][2], FT (&b)[NPL][2], int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[HS[q]][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], acc[HS[q]][mi][ni], 0, 0, 0);
+    };
+
+    constexpr int NST = 16;          // store instructions of the coalesced epilogue per wave
+    // epilogue of one tile (same code as gemm_x6p_kernel: LDS-transposed 16-byte stores where whole 64-column slabs exist);
+    // returns true when it issued exactly NST store instructions in this wave
+    auto epilogue = [&](const TileCtx& tc) __attribute__((always_inline)) {
+        float* cb = p.c + tc.cbase + (tc.n0 + wn * 64 + l31);
+        const int nrem = p.N - (tc.n0 + wn * 64 + l31);
+        const bool vec_ok = (p.N - (tc.n0 + wn * 64) >= 64) && (p.ldc % 4 == 0) && !(p.dbg & 16);
+        if (vec_ok) {
+            float* tb = (float*)(lds + STAGES * STAGE_B + wave * 2048);          // [8 rows][64 cols]
+            const int rrow = lane >> 4, rcol = (lane & 15) * 4;
+            // two running row pointers (rows m and m + 4), advanced by 8 rows per group: kept opaque so that the 32 row addresses of
+            // the unrolled loop are not all formed up front (64 VGPRs beside the 128 accumulators: scratch spills)
+            int m = tc.m0 + wm * 64 + rrow;
+            float* g0 = p.c + tc.cbase + (tc.n0 + wn * 64 + rcol) + (long)m * p.ldc;
+            float* g1 = g0 + 4L * p.ldc;
+            const long step = 8L * p.ldc;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int r = rq * 4 + rr;
+                            tb[(rr + 4 * lh) * 64 + ni * 32 + l31] = fmaf(acc[1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
+                        }
+                    __builtin_amdgcn_wave_barrier();
+                    const f32x4 v0 = *(const f32x4*)(tb + rrow * 64 + rcol);
+                    const f32x4 v1 = *(const f32x4*)(tb + (rrow + 4) * 64 + rcol);
+                    if (!(p.dbg & 32)) {
+                        if (m < p.M) *(f32x4*)g0 = v0;
+                        if (m + 4 < p.M) *(f32x4*)g1 = v1;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    m += 8;
+                    g0 += step;
+                    g1 += step;
+                    asm volatile("" : "+v"(g0), "+v"(g1));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = tc.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m >= p.M || (p.dbg & 32)) continue;
+                    float* crow = cb + (long)m * p.ldc;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        if (32 * ni < nrem) crow[32 * ni] = fmaf(acc[1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
+                }
+            }
+        }
+    };
+
+    // pipeline fill: chunks 0 and 1 of the first tile (a tile has at least two chunks: the launcher checks)
+    dma_chunk(cur.ua, cur.ub, 0, lds);
+    dma_chunk(cur.ua, cur.ub, PBK, lds + STAGE_B);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");          // chunk 0 landed
+    __builtin_amdgcn_s_barrier();                                        // B0
+    if (grp) __builtin_amdgcn_s_barrier();                               // group 1 starts one slot later
+    __builtin_amdgcn_sched_barrier(0);
+
+    int st = 0;                  // stage of the chunk the next M slot reads
+    bool have_prev = false;
+    TileCtx prev = cur, nxt = cur;
+    int relax = 0;               // M slots left in which the epilogue's NST stores may stay outstanding
+    const bool tim = (p.dbg & 512) && blockIdx.x == 0 && (wave & 3) == 0;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+        if (tim) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            if (k >= 0) tacc[k] += now - tlast;
+            tlast = now;
+        }
+    };
+    stamp(-1);
+    for (int t = t_first; t < t_end; t += t_stride) {
+        const int nchunks = cur.nchunks;
+        const bool more = t + t_stride < t_end;
+        if (more) nxt = setup(t + t_stride);
+        for (int c = 0; c < nchunks; ++c) {
+            // ---------------- M slot: DMA of chunk c + 2, [epilogue of the previous tile], fragments of chunk c
+            {
+                const int ca = c + 2;
+                const bool own = ca < nchunks;
+                const int cn = own ? ca : (more ? ca - nchunks : nchunks - 1);
+                const bool mine = own || !more;
+                const int sd = st + 2 >= STAGES ? st + 2 - STAGES : st + 2;
+                dma_chunk(mine ? cur.ua : nxt.ua, mine ? cur.ub : nxt.ub, (long)cn * PBK, lds + sd * STAGE_B);
+            }
+            if (c == 0) {
+                if (have_prev) {
+                    // The stores are issued behind this slot's pieces (vmcnt counts in issue order): this wait and the next one are
+                    // for pieces older than the stores, which may stay outstanding when their number is known (NST: whole 64 x 64
+                    // slabs); an edge tile's unknown number is simply waited for
+                    const bool exact = (p.N - (prev.n0 + wn * 64) >= 64) && (p.ldc % 4 == 0) && !(p.dbg & 16) && (prev.m0 + wm * 64 + 64 <= p.M) && !(p.dbg & 32);
+                    epilogue(prev);
+                    relax = exact ? 2 : 0;
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[s][mi][ni][r] = 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(0);          // DMA issue (+ epilogue, zeroing)
+            frag(a0, b0, st, so0);
+            frag(a1, b1, st, so1);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(1);          // fragment reads (the counter read waits for them)
+            // this wave's pieces of chunk c + 1 landed (younger: the NDMA pieces of chunk c + 2, and the stores while `relax`), and its
+            // fragment reads are complete: vmcnt(W) lgkmcnt(0)
+            if (relax > 0) {
+                --relax;
+                __builtin_amdgcn_s_waitcnt(0x0070 | ((NDMA + NST) & 15) | (((NDMA + NST) >> 4) << 14));
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0070 | (NDMA & 15) | ((NDMA >> 4) << 14));
+            }
+            stamp(2);          // vmcnt wait
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(3);          // barrier at the end of the M slot
+            // ---------------- C slot: 24 MFMAs, nothing else
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) mma4(a0, b0, q);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) mma4(a1, b1, q);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(4);          // MFMA issue
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(5);          // barrier at the end of the C slot
+            st = st + 1 == STAGES ? 0 : st + 1;
+        }
+        prev = cur;
+        have_prev = true;
+        if (more) cur = nxt;
+    }
+    if (tim && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g_x6p_dbg[grp * 8 + k] = tacc[k];
+    }
+    epilogue(prev);
+    if (!grp) __builtin_amdgcn_s_barrier();          // group 1 is still one slot behind: the barrier its last C slot ends with
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may still be landing when the LDS is handed to the next workgroup
+}
+
 }  // namespace
 
 // Operand rows must be allocated up to the tile edge: A rows padded to SS_X6P_BM, B rows to SS_X6P_BN per batch (pad rows of
@@ -374,6 +653,14 @@ bool ss_x6p_wide_ok(long M, int N, int K, int nbatch) {
     return ss_tuning().x6p == 2 || ((M + PBM - 1) / PBM) * (N / 256) * nbatch >= 512;      // x6p = 2 ("force"): any size (tests)
 }
 
+// measurement only (tools/x6p_pp_slots.py, tile_dbg & 512): slot-phase cycle sums of waves 0 (group 0) and 4 (group 1) of workgroup 0
+extern "C" int ss_dbg_x6p_slots(unsigned long long* out16) {
+    unsigned long long h[32];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_x6p_dbg), sizeof(h)) != hipSuccess) return SS_ERR_LAUNCH;
+    for (int i = 0; i < 16; ++i) out16[i] = h[i];
+    return SS_OK;
+}
+
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     if (p.K % PBK || p.k_per_split % PBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
     const bool wide = p.fp16x2 == 1 && p.plain_l;
@@ -397,6 +684,21 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     const bool persistent = ss_tuning().gemm_persistent && tiles > n_cu && p.k_per_split >= 3 * PBK && p.K % p.k_per_split == 0;
     const long nwg = persistent ? n_cu : tiles;
     const bool one = p.fp16x2 == 2;          // fp16x2 == 2: ONE fp16 plane per operand, one product (16-bit activation storage)
+    // x3h planes, every tile at least two K chunks deep: the ping-pong kernel (same results bit for bit; x6p_pp = 0 keeps the one-phase kernel)
+    if (p.fp16x2 == 1 && !wide && ss_tuning().x6p_pp && p.k_per_split >= 2 * PBK && p.K % p.k_per_split == 0) {
+        static const bool pp_attr = [] {
+            (void)hipFuncSetAttribute((const void*)gemm_x6p_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            return true;
+        }();
+        (void)pp_attr;
+        pd.dbg = ss_tuning().tile_dbg & (16 | 32 | 64 | 128 | 512);
+        const long nwg_pp = (ss_tuning().gemm_persistent && tiles > n_cu) ? n_cu : tiles;
+        SsProfScope prof("gemm_x6p_pp_kernel", 2.0 * p.M * p.N * p.K * p.nbatch * 3,
+                         2.0 * 2 * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
+        hipLaunchKernelGGL(gemm_x6p_pp_kernel, dim3((unsigned)nwg_pp), dim3(512), 3 * 2 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+    }
     SsProfScope prof(wide ? "gemm_x6p_kernel<2,wide>" : (one ? "gemm_x6p_kernel<1>" : (p.fp16x2 ? "gemm_x6p_kernel<2>" : "gemm_x6p_kernel<3>")),
                      2.0 * p.M * p.N * p.K * p.nbatch * (one ? 1 : (p.fp16x2 ? 3 : 6)),
                      2.0 * (one ? 1 : (p.fp16x2 ? 2 : 3)) * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);

@@ -41,6 +41,24 @@ __device__ __forceinline__ float ss_act_grad_from_out(float y, int act, float al
     return y > 0.f ? 1.f : neg;
 }
 
+// ---- 4 x 4 transpose inside every group of four adjacent lanes (DPP quad permutes): in[r] of lane l = M[r][l]  ->  out[k] of lane l =
+// M[l][k].  Used by the GEMM epilogues: the 32 x 32 MFMA C/D layout gives a lane ONE column and four consecutive rows per register
+// quad; after the transpose a lane holds four consecutive columns of ONE row, i.e. one 16-byte store, with no trip through LDS
+// (the LDS-transposed epilogue of gemm_x6p cost ~10 000 cycles per 256 x 128 tile: 16 dependent write -> read -> store rounds).
+__device__ __forceinline__ f32x4 ss_quad_transpose(float a0, float a1, float a2, float a3, bool odd, bool hi) {
+    // quad_perm [1,0,3,2] = 0xB1 (lane ^ 1), [2,3,0,1] = 0x4E (lane ^ 2)
+    const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a0), 0xB1, 0xF, 0xF, true));
+    const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a1), 0xB1, 0xF, 0xF, true));
+    const float x2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a2), 0xB1, 0xF, 0xF, true));
+    const float x3 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a3), 0xB1, 0xF, 0xF, true));
+    const float b0 = odd ? x1 : a0, b1 = odd ? a1 : x0, b2 = odd ? x3 : a2, b3 = odd ? a3 : x2;
+    const float y0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b0), 0x4E, 0xF, 0xF, true));
+    const float y1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b1), 0x4E, 0xF, 0xF, true));
+    const float y2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b2), 0x4E, 0xF, 0xF, true));
+    const float y3 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b3), 0x4E, 0xF, 0xF, true));
+    return f32x4{hi ? y2 : b0, hi ? y3 : b1, hi ? b2 : y0, hi ? b3 : y1};
+}
+
 // ---- exact 3-way bf16 split of fp32 values (x6 contraction, conv_mfma_x6.hip; also emitted by the Winograd weight transform)
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

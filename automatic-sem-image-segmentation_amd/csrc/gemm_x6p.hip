@@ -291,7 +291,31 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
         // exactly NST store instructions leave this wave only when all its 64 rows exist (a masked-off store is branched over)
         const bool full_rows = cur.m0 + wm * 64 + 64 <= p.M;
         relaxed = vec_ok && full_rows && !(p.dbg & 32);
-        if (vec_ok) {
+        if (vec_ok && !(p.dbg & 8)) {
+            // Register-transposed epilogue: per (mi, ni, row quad) the four registers of a lane are four consecutive rows of its
+            // column; a 4 x 4 transpose inside every group of four adjacent lanes (ss_quad_transpose, DPP) turns them into four
+            // consecutive columns of ONE row = one 16-byte store: 16 store instructions per wave (8 rows x 128 B each), no LDS trip.
+            const bool odd = lane & 1, hi = lane & 2;
+            const int m = cur.m0 + wm * 64 + 4 * lh + (lane & 3);          // + 32 mi + 8 rq
+            float* g = p.c + cur.cbase + (cur.n0 + wn * 64 + (l31 & ~3)) + (long)m * p.ldc;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const bool row_ok = m + mi * 32 + 8 * rq < p.M && !(p.dbg & 32);
+                    float* grow = g + (long)(mi * 32 + 8 * rq) * p.ldc;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        float v[4];
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            v[rr] = NACC == 1 ? acc[0][mi][ni][rq * 4 + rr] : fmaf(acc[NACC - 1][mi][ni][rq * 4 + rr], 4.8828125e-4f, acc[0][mi][ni][rq * 4 + rr]);
+                        const f32x4 o = ss_quad_transpose(v[0], v[1], v[2], v[3], odd, hi);
+                        if (row_ok) *(f32x4*)(grow + 32 * ni) = o;
+                    }
+                }
+            }
+        } else if (vec_ok) {
             float* tb = (float*)(lds + STAGES * STAGE_B + wave * 2048);          // [8 rows][64 cols]
             const int rrow = lane >> 4, rcol = (lane & 15) * 4;                    // read-back: row rrow (+4), columns rcol .. rcol + 3
             float* gbase = p.c + cur.cbase + (cur.n0 + wn * 64 + rcol);
@@ -372,6 +396,9 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
 // The epilogue of tile T runs at the start of M(0) of tile T+1, after that slot's DMA issue (stores younger than the pieces the next
 // two waits are for); its partner is in C(last) of tile T meanwhile.
 __device__ unsigned long long g_x6p_dbg[32];          // measurement only (tile_dbg & 512): slot timing of waves 0 and 4 of workgroup 0
+// SPLIT = how many of a wave's six LDS-DMA pieces per chunk are issued in its C slot, one behind each group of four MFMAs, instead of
+// in its M slot (measured: a burst of 24 pieces from the four M-slot waves of a CU costs ~140 cycles of issue per piece)
+template <int SPLIT>
 __global__ __launch_bounds__(512, 1) void gemm_x6p_pp_kernel(X6PParams p) {
     constexpr int NPL = 2;
     constexpr int STAGE_B = NPL * (A_PLANE_B + B_PLANE_B);          // 48 KiB
@@ -423,21 +450,23 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_pp_kernel(X6PParams p) {
     };
     const bool skipA = p.dbg & 128, skipB = p.dbg & 64;          // measurement only
     // the six pieces of chunk (element offset goff from the tile's first chunk) of the tile with bases (ua, ub) into stage `dst`
-    auto dma_chunk = [&](long ua, long ub, long goff, unsigned char* dst) __attribute__((always_inline)) {
-        const char* ga = (const char*)(p.a + ua + goff);
-        const char* gb = (const char*)(p.b + ub + goff);
-        if (!skipA) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+    // piece j of a chunk: 0..3 = A row blocks, 4..5 = B row blocks
+    auto dma_piece = [&](int j, long ua, long ub, long goff, unsigned char* dst) __attribute__((always_inline)) {
+        if (j < 4) {
+            const char* ga = (const char*)(p.a + ua + goff);
+            if (!skipA)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (long)j * 32 * p.lda + laneA),
                                                  (__attribute__((address_space(3))) void*)(dst + loffA + j * 1024), 16, 0, 0);
+        } else {
+            const char* gb = (const char*)(p.b + ub + goff);
+            if (!skipB)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long)(j - 4) * 32 * p.ldb + laneB),
+                                                 (__attribute__((address_space(3))) void*)(dst + loffB + (j - 4) * 1024), 16, 0, 0);
         }
-        if (!skipB) {
+    };
+    auto dma_chunk = [&](long ua, long ub, long goff, unsigned char* dst) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long)j * 32 * p.ldb + laneB),
-                                                 (__attribute__((address_space(3))) void*)(dst + loffB + j * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < NDMA; ++j) dma_piece(j, ua, ub, goff, dst);
     };
     if (t_first >= t_end) return;
     TileCtx cur = setup(t_first);
@@ -475,37 +504,24 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_pp_kernel(X6PParams p) {
         const int nrem = p.N - (tc.n0 + wn * 64 + l31);
         const bool vec_ok = (p.N - (tc.n0 + wn * 64) >= 64) && (p.ldc % 4 == 0) && !(p.dbg & 16);
         if (vec_ok) {
-            float* tb = (float*)(lds + STAGES * STAGE_B + wave * 2048);          // [8 rows][64 cols]
-            const int rrow = lane >> 4, rcol = (lane & 15) * 4;
-            // two running row pointers (rows m and m + 4), advanced by 8 rows per group: kept opaque so that the 32 row addresses of
-            // the unrolled loop are not all formed up front (64 VGPRs beside the 128 accumulators: scratch spills)
-            int m = tc.m0 + wm * 64 + rrow;
-            float* g0 = p.c + tc.cbase + (tc.n0 + wn * 64 + rcol) + (long)m * p.ldc;
-            float* g1 = g0 + 4L * p.ldc;
-            const long step = 8L * p.ldc;
+            // register-transposed epilogue (ss_quad_transpose): 16 stores of 16 B per lane, 8 rows x 128 B each, no LDS trip
+            const bool odd = lane & 1, hi = lane & 2;
+            const int m = tc.m0 + wm * 64 + 4 * lh + (lane & 3);          // + 32 mi + 8 rq
+            float* g = p.c + tc.cbase + (tc.n0 + wn * 64 + (l31 & ~3)) + (long)m * p.ldc;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
+                    const bool row_ok = m + mi * 32 + 8 * rq < p.M && !(p.dbg & 32);
+                    float* grow = g + (long)(mi * 32 + 8 * rq) * p.ldc;
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
+                    for (int ni = 0; ni < 2; ++ni) {
+                        float v[4];
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            const int r = rq * 4 + rr;
-                            tb[(rr + 4 * lh) * 64 + ni * 32 + l31] = fmaf(acc[1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
-                        }
-                    __builtin_amdgcn_wave_barrier();
-                    const f32x4 v0 = *(const f32x4*)(tb + rrow * 64 + rcol);
-                    const f32x4 v1 = *(const f32x4*)(tb + (rrow + 4) * 64 + rcol);
-                    if (!(p.dbg & 32)) {
-                        if (m < p.M) *(f32x4*)g0 = v0;
-                        if (m + 4 < p.M) *(f32x4*)g1 = v1;
+                        for (int rr = 0; rr < 4; ++rr) v[rr] = fmaf(acc[1][mi][ni][rq * 4 + rr], 4.8828125e-4f, acc[0][mi][ni][rq * 4 + rr]);
+                        const f32x4 o = ss_quad_transpose(v[0], v[1], v[2], v[3], odd, hi);
+                        if (row_ok) *(f32x4*)(grow + 32 * ni) = o;
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    m += 8;
-                    g0 += step;
-                    g1 += step;
-                    asm volatile("" : "+v"(g0), "+v"(g1));
                 }
             }
         } else {
@@ -551,6 +567,8 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_pp_kernel(X6PParams p) {
         const bool more = t + t_stride < t_end;
         if (more) nxt = setup(t + t_stride);
         for (int c = 0; c < nchunks; ++c) {
+            long d_ua, d_ub, d_goff;
+            unsigned char* d_dst;
             // ---------------- M slot: DMA of chunk c + 2, [epilogue of the previous tile], fragments of chunk c
             {
                 const int ca = c + 2;
@@ -558,7 +576,9 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_pp_kernel(X6PParams p) {
                 const int cn = own ? ca : (more ? ca - nchunks : nchunks - 1);
                 const bool mine = own || !more;
                 const int sd = st + 2 >= STAGES ? st + 2 - STAGES : st + 2;
-                dma_chunk(mine ? cur.ua : nxt.ua, mine ? cur.ub : nxt.ub, (long)cn * PBK, lds + sd * STAGE_B);
+                d_ua = mine ? cur.ua : nxt.ua; d_ub = mine ? cur.ub : nxt.ub; d_goff = (long)cn * PBK; d_dst = lds + sd * STAGE_B;
+#pragma unroll
+                for (int j = SPLIT; j < NDMA; ++j) dma_piece(j, d_ua, d_ub, d_goff, d_dst);
             }
             if (c == 0) {
                 if (have_prev) {
@@ -567,7 +587,8 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_pp_kernel(X6PParams p) {
                     // slabs); an edge tile's unknown number is simply waited for
                     const bool exact = (p.N - (prev.n0 + wn * 64) >= 64) && (p.ldc % 4 == 0) && !(p.dbg & 16) && (prev.m0 + wm * 64 + 64 <= p.M) && !(p.dbg & 32);
                     epilogue(prev);
-                    relax = exact ? 2 : 0;
+                    // SPLIT > 0: the next chunk's C-slot pieces are issued BEHIND the stores, so only this slot's wait can skip them
+                    relax = exact ? (SPLIT == 0 ? 2 : 1) : 0;
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -586,11 +607,12 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_pp_kernel(X6PParams p) {
             stamp(1);          // fragment reads (the counter read waits for them)
             // this wave's pieces of chunk c + 1 landed (younger: the NDMA pieces of chunk c + 2, and the stores while `relax`), and its
             // fragment reads are complete: vmcnt(W) lgkmcnt(0)
+            constexpr int WM = NDMA - SPLIT;          // pieces of chunk c + 2 issued in this slot (the other SPLIT follow in the C slot)
             if (relax > 0) {
                 --relax;
-                __builtin_amdgcn_s_waitcnt(0x0070 | ((NDMA + NST) & 15) | (((NDMA + NST) >> 4) << 14));
+                __builtin_amdgcn_s_waitcnt(0x0070 | ((WM + NST) & 15) | (((WM + NST) >> 4) << 14));
             } else {
-                __builtin_amdgcn_s_waitcnt(0x0070 | (NDMA & 15) | ((NDMA >> 4) << 14));
+                __builtin_amdgcn_s_waitcnt(0x0070 | (WM & 15) | ((WM >> 4) << 14));
             }
             stamp(2);          // vmcnt wait
             __builtin_amdgcn_s_barrier();
@@ -599,9 +621,15 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_pp_kernel(X6PParams p) {
             // ---------------- C slot: 24 MFMAs, nothing else
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) mma4(a0, b0, q);
+            for (int q = 0; q < 3; ++q) {
+                mma4(a0, b0, q);
+                if (q < SPLIT) { dma_piece(q, d_ua, d_ub, d_goff, d_dst); __builtin_amdgcn_sched_barrier(0); }
+            }
 #pragma unroll
-            for (int q = 0; q < 3; ++q) mma4(a1, b1, q);
+            for (int q = 0; q < 3; ++q) {
+                mma4(a1, b1, q);
+                if (q + 3 < SPLIT) { dma_piece(q + 3, d_ua, d_ub, d_goff, d_dst); __builtin_amdgcn_sched_barrier(0); }
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             stamp(4);          // MFMA issue
@@ -665,7 +693,7 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     if (p.K % PBK || p.k_per_split % PBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
     const bool wide = p.fp16x2 == 1 && p.plain_l;
     X6PParams pd = p;
-    pd.dbg = ss_tuning().tile_dbg & (16 | 32 | 64 | 128);          // 16: the scalar-store epilogue (A/B measurement)
+    pd.dbg = ss_tuning().tile_dbg & (8 | 16 | 32 | 64 | 128);          // 8: the LDS-transposed epilogue, 16: the scalar-store epilogue (A/B measurement)
     if (wide && (p.N % 256 || p.splits != 1)) return SS_ERR_UNSUPPORTED;
     const int pbn = wide ? 256 : SS_X6P_BN;
     const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + pbn - 1) / pbn;
@@ -687,7 +715,9 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     // x3h planes, every tile at least two K chunks deep: the ping-pong kernel (same results bit for bit; x6p_pp = 0 keeps the one-phase kernel)
     if (p.fp16x2 == 1 && !wide && ss_tuning().x6p_pp && p.k_per_split >= 2 * PBK && p.K % p.k_per_split == 0) {
         static const bool pp_attr = [] {
-            (void)hipFuncSetAttribute((const void*)gemm_x6p_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)gemm_x6p_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)gemm_x6p_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)gemm_x6p_pp_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return true;
         }();
         (void)pp_attr;
@@ -695,7 +725,11 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
         const long nwg_pp = (ss_tuning().gemm_persistent && tiles > n_cu) ? n_cu : tiles;
         SsProfScope prof("gemm_x6p_pp_kernel", 2.0 * p.M * p.N * p.K * p.nbatch * 3,
                          2.0 * 2 * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
-        hipLaunchKernelGGL(gemm_x6p_pp_kernel, dim3((unsigned)nwg_pp), dim3(512), 3 * 2 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);
+        const int split = ss_tuning().x6p_pp;          // 1: all pieces in the M slot, 2: three of six in the C slot, 3: all six in the C slot
+        const size_t ldsb = 3 * 2 * (A_PLANE_B + B_PLANE_B) + 16384;
+        if (split == 3) hipLaunchKernelGGL(gemm_x6p_pp_kernel<6>, dim3((unsigned)nwg_pp), dim3(512), ldsb, s, pd);
+        else if (split == 2) hipLaunchKernelGGL(gemm_x6p_pp_kernel<3>, dim3((unsigned)nwg_pp), dim3(512), ldsb, s, pd);
+        else hipLaunchKernelGGL(gemm_x6p_pp_kernel<0>, dim3((unsigned)nwg_pp), dim3(512), ldsb, s, pd);
         SS_LAUNCH_CHECK();
         return SS_OK;
     }

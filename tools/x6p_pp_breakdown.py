@@ -15,9 +15,9 @@ for n in (8, 16):
     arena.materialize()
     arena["c/kernel"].uniform_(-0.05, 0.05)
     x = E.Act(torch.randn((n, 64, 64, 512), device=dev))
-    for pp in (0, 1):
+    for pp in (0, 1, 3):
         row = []
-        for dbg in (0, 32, 192, 224):
+        for dbg in (0, 8, 32, 192, 224):
             with L.config(x6p_pp=pp, tile_dbg=dbg):
                 conv(E.Tape(enabled=False), x)
                 torch.cuda.synchronize()

@@ -25,7 +25,7 @@ def run(lib, dev, n, hw, cin, cout, iters, reflect=True):
     x = E.Act(torch.randn((n, hw, hw, cin), generator=g).to(dev))
     dyt = torch.randn((n, hw, hw, cout), generator=g).to(dev)
     res = {}
-    for pp in (0, 1):
+    for pp in (0, 1, 2, 3):
         with L.config(x6p_pp=pp, x6p=2):
             tape = E.Tape()
             y = conv(tape, x)
@@ -50,10 +50,10 @@ def run(lib, dev, n, hw, cin, cout, iters, reflect=True):
             lib.ss_prof_enable(0)
             prof = L.prof_summary()
             res[pp].append({k: (round(v["avg_ms"] * 1e3, 1), v["launches"]) for k, v in prof.items() if k.startswith("gemm_x6p")})
-    same_y = torch.equal(res[0][0], res[1][0])
-    same_dx = torch.equal(res[0][1], res[1][1])
+    same_y = all(torch.equal(res[0][0], res[k][0]) for k in (1, 2, 3))
+    same_dx = all(torch.equal(res[0][1], res[k][1]) for k in (1, 2, 3))
     finite = bool(torch.isfinite(res[1][0]).all() and torch.isfinite(res[1][1]).all())
-    print(f"n={n} hw={hw} {cin}->{cout}: y_equal={same_y} dx_equal={same_dx} finite={finite}  one-phase {res[0][2]}  ping-pong {res[1][2]}", flush=True)
+    print(f"n={n} hw={hw} {cin}->{cout}: y_equal={same_y} dx_equal={same_dx} finite={finite}  one-phase {res[0][2]}  pp(M) {res[1][2]}  pp(3+3) {res[2][2]}  pp(C) {res[3][2]}", flush=True)
     if not (same_y and same_dx):
         dlt = (res[0][0] - res[1][0]).abs().max().item(), (res[0][1] - res[1][1]).abs().max().item()
         print("   max |diff| y, dx:", dlt, " max|y|", res[0][0].abs().max().item(), flush=True)

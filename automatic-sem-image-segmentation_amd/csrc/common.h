@@ -33,6 +33,20 @@ __device__ __forceinline__ float ss_apply_act(float v, int act, float alpha) {
     return v > 0.f ? v : neg;
 }
 
+// The same for the piecewise-linear activations only (none / relu / leaky relu), with the case analysis done ONCE by the caller:
+// relu = (act == SS_ACT_RELU), slope = (act == SS_ACT_LRELU ? alpha : 1).  Bit for bit ss_apply_act's values; streaming kernels
+// choose between a loop instantiated with this form and one with the generic form OUTSIDE their loops -- ss_apply_act inside an
+// unrolled loop leaves the tanh / sigmoid tests as scalar branches per ELEMENT (norm_apply_kernel: 156 branches in the loop body).
+__device__ __forceinline__ float ss_act_pwl(float v, bool relu, float slope) {
+    const float neg = relu ? 0.f : v * slope;
+    return v > 0.f ? v : neg;
+}
+__device__ __forceinline__ float ss_act_grad_pwl(float y, bool relu, float slope) {
+    const float neg = relu ? 0.f : slope;
+    return y > 0.f ? 1.f : neg;
+}
+__device__ __forceinline__ bool ss_act_is_pwl(int act) { return act != SS_ACT_TANH && act != SS_ACT_SIGMOID; }
+
 // derivative of the activation expressed through the forward OUTPUT y
 __device__ __forceinline__ float ss_act_grad_from_out(float y, int act, float alpha) {
     if (act == SS_ACT_TANH) return 1.f - y * y;

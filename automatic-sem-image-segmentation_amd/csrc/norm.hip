@@ -7,6 +7,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <initializer_list>
+#include <type_traits>
 
 namespace {
 
@@ -117,33 +118,47 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x
         if (MODE == 1) { ldv<V>(mean + (long)g * C + c, mu); ldv<V>(rstd + (long)g * C + c, rs); }
         const bool recompute = MODE == 1 && act != SS_ACT_NONE && y == nullptr;
         if (recompute) { if (rgamma) ldv<V>(rgamma + c, gm); ldv<V>(rbeta + c, bt); }
+        const bool relu = act == SS_ACT_RELU;
+        const float slope = act == SS_ACT_LRELU ? alpha : 1.f;
+        float kk[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) kk[v] = rs[v] * gm[v];
+        // MASK (MODE 1): 0 no activation, 1 mask recomputed from x (relu / leaky relu), 2 from y (piecewise linear), 3 from y (tanh /
+        // sigmoid): the loop is instantiated per mask source, no per-element case analysis inside (same sums in the same order)
+        auto body = [&](auto MASKc) __attribute__((always_inline)) {
+            constexpr int MASK = decltype(MASKc)::value;
 #pragma unroll 4
-        for (long p = p0 + pt; p < p1; p += PT) {
-            float xv[V];
-            ldv<V>(x + (base + p) * x_cs + c, xv);
-            if (MODE == 0) {
+            for (long p = p0 + pt; p < p1; p += PT) {
+                float xv[V];
+                ldv<V>(x + (base + p) * x_cs + c, xv);
+                if (MODE == 0) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) { s1[v] += xv[v]; s2[v] = fmaf(xv[v], xv[v], s2[v]); }
-            } else {
-                float gv[V];
-                ldv<V>(dy + (base + p) * dy_cs + c, gv);
-                if (recompute) {
+                    for (int v = 0; v < V; ++v) { s1[v] += xv[v]; s2[v] = fmaf(xv[v], xv[v], s2[v]); }
+                } else {
+                    float gv[V];
+                    ldv<V>(dy + (base + p) * dy_cs + c, gv);
+                    if (MASK == 1) {
 #pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        // the forward's expression, bit for bit (norm_apply_kernel / the fused operand loads: explicit fma)
-                        const float t = __builtin_fmaf(xv[v] - mu[v], rs[v] * gm[v], bt[v]);
-                        gv[v] *= ss_act_grad_from_out(t, act, alpha);          // relu / lrelu: depends on the sign only
+                        for (int v = 0; v < V; ++v) {
+                            // the forward's expression, bit for bit (norm_apply_kernel / the fused operand loads: explicit fma)
+                            const float t = __builtin_fmaf(xv[v] - mu[v], kk[v], bt[v]);
+                            gv[v] *= ss_act_grad_pwl(t, relu, slope);          // relu / lrelu: depends on the sign only
+                        }
+                    } else if (MASK >= 2) {
+                        float yv[V];
+                        ldv<V>(y + (base + p) * y_cs + c, yv);
+#pragma unroll
+                        for (int v = 0; v < V; ++v) gv[v] *= MASK == 2 ? ss_act_grad_pwl(yv[v], relu, slope) : ss_act_grad_from_out(yv[v], act, alpha);
                     }
-                } else if (act != SS_ACT_NONE) {
-                    float yv[V];
-                    ldv<V>(y + (base + p) * y_cs + c, yv);
 #pragma unroll
-                    for (int v = 0; v < V; ++v) gv[v] *= ss_act_grad_from_out(yv[v], act, alpha);
+                    for (int v = 0; v < V; ++v) { s1[v] += gv[v]; s2[v] = fmaf(gv[v], (xv[v] - mu[v]) * rs[v], s2[v]); }
                 }
-#pragma unroll
-                for (int v = 0; v < V; ++v) { s1[v] += gv[v]; s2[v] = fmaf(gv[v], (xv[v] - mu[v]) * rs[v], s2[v]); }
             }
-        }
+        };
+        if (MODE == 0 || act == SS_ACT_NONE) body(std::integral_constant<int, 0>{});
+        else if (recompute) body(std::integral_constant<int, 1>{});
+        else if (ss_act_is_pwl(act)) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 3>{});
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) { red[2 * v][threadIdx.x] = s1[v]; red[2 * v + 1][threadIdx.x] = s2[v]; }
@@ -247,33 +262,44 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
         const T* const xb = x + (long)g * P * x_cs + c;
         const T* const rb = res ? res + (long)g * P * res_cs + c : nullptr;
         T* const yb = y + (long)g * P * y_cs + c;
-        for (long p = p0 + pt; p < p1; p += 4L * PT) {
-            float xv[4][V], rv[4][V];
+        const bool relu = act == SS_ACT_RELU;
+        const float slope = act == SS_ACT_LRELU ? alpha : 1.f;
+        // the loop, instantiated per (piecewise-linear activation?, residual?): no per-element case analysis inside
+        auto body = [&](auto PWLc, auto RESc) __attribute__((always_inline)) {
+            constexpr bool PWL = decltype(PWLc)::value, RES = decltype(RESc)::value;
+            for (long p = p0 + pt; p < p1; p += 4L * PT) {
+                float xv[4][V], rv[4][V];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long q = p + (long)u * PT;
-                if (q < p1) {
-                    ldv<V>(xb + q * x_cs, xv[u]);
-                    if (res) ldv<V>(rb + q * res_cs, rv[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long q = p + (long)u * PT;
-                if (q < p1) {
-                    float o[V];
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        // explicit fma: a convolution that normalises in its operand load (conv_wino.hip, ss_conv_desc::in_norm_*) forms the
-                        // same expression and must produce the same bits
-                        float t = __builtin_fmaf(xv[u][v] - mu[v], kk[v], bt[v]);
-                        if (res) t += rv[u][v];
-                        o[v] = ss_apply_act(t, act, alpha);
-                        am = fmaxf(am, fabsf((float)(T)o[v]));          // what is stored: rounded to the storage type
+                for (int u = 0; u < 4; ++u) {
+                    const long q = p + (long)u * PT;
+                    if (q < p1) {
+                        ldv<V>(xb + q * x_cs, xv[u]);
+                        if (RES) ldv<V>(rb + q * res_cs, rv[u]);
                     }
-                    stv<V>(yb + q * y_cs, o);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long q = p + (long)u * PT;
+                    if (q < p1) {
+                        float o[V];
+#pragma unroll
+                        for (int v = 0; v < V; ++v) {
+                            // explicit fma: a convolution that normalises in its operand load (conv_wino.hip, ss_conv_desc::in_norm_*) forms the
+                            // same expression and must produce the same bits
+                            float t = __builtin_fmaf(xv[u][v] - mu[v], kk[v], bt[v]);
+                            if (RES) t += rv[u][v];
+                            o[v] = PWL ? ss_act_pwl(t, relu, slope) : ss_apply_act(t, act, alpha);
+                            am = fmaxf(am, fabsf((float)(T)o[v]));          // what is stored: rounded to the storage type
+                        }
+                        stv<V>(yb + q * y_cs, o);
+                    }
                 }
             }
+        };
+        if (ss_act_is_pwl(act)) {
+            if (res) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{});
+        } else {
+            if (res) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{});
         }
     }
     if (amax) ss_block_amax_to_slot(am, amax);
@@ -385,54 +411,69 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
         const T* const yb = from_y ? y + (long)g * P * y_cs + c : nullptr;
         T* const ob = dx + (long)g * P * dx_cs + c;
         T* const rb = dres ? dres + (long)g * P * dres_cs + c : nullptr;
-        for (long p = p0 + pt; p < p1; p += 4L * PT) {
-            float gv[4][V], xv[4][V], yv[4][V], o[4][V], r[4][V];
+        const bool relu = act == SS_ACT_RELU;
+        const float slope = act == SS_ACT_LRELU ? alpha : 1.f;
+        float kk[V];          // rstd * gamma: the forward's factor
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long q = p + (long)u * PT;
-                if (q < p1) {
-                    ldv<V>(gb + q * dy_cs, gv[u]);
-                    ldv<V>(xb + q * x_cs, xv[u]);
-                    if (from_y) ldv<V>(yb + q * y_cs, yv[u]);
-                    if (acc_dx) ldv<V>(ob + q * dx_cs, o[u]);
-                    if (dres && acc_dres) ldv<V>(rb + q * dres_cs, r[u]);
+        for (int v = 0; v < V; ++v) kk[v] = rs[v] * (gamma ? gm[v] : 1.f);
+        // MASK: 0 no activation, 1 mask recomputed from x (relu / leaky relu), 2 from y (piecewise linear), 3 from y (tanh / sigmoid).
+        // The loop is instantiated per mask source: no per-element case analysis inside
+        auto body = [&](auto MASKc) __attribute__((always_inline)) {
+            constexpr int MASK = decltype(MASKc)::value;
+            for (long p = p0 + pt; p < p1; p += 4L * PT) {
+                float gv[4][V], xv[4][V], yv[4][V], o[4][V], r[4][V];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long q = p + (long)u * PT;
+                    if (q < p1) {
+                        ldv<V>(gb + q * dy_cs, gv[u]);
+                        ldv<V>(xb + q * x_cs, xv[u]);
+                        if (MASK >= 2) ldv<V>(yb + q * y_cs, yv[u]);
+                        if (acc_dx) ldv<V>(ob + q * dx_cs, o[u]);
+                        if (dres && acc_dres) ldv<V>(rb + q * dres_cs, r[u]);
+                    }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long q = p + (long)u * PT;
-                if (q < p1) {
-                    if (recompute) {
+                for (int u = 0; u < 4; ++u) {
+                    const long q = p + (long)u * PT;
+                    if (q < p1) {
 #pragma unroll
                         for (int v = 0; v < V; ++v) {
-                            // the forward's expression, bit for bit (norm_apply_kernel / the fused operand loads: explicit fma)
-                            const float t = __builtin_fmaf(xv[u][v] - mu[v], rs[v] * (gamma ? gm[v] : 1.f), bt[v]);
-                            gv[u][v] *= ss_act_grad_from_out(t, act, alpha);
+                            if (MASK == 1) {
+                                // the forward's expression, bit for bit (norm_apply_kernel / the fused operand loads: explicit fma)
+                                const float t = __builtin_fmaf(xv[u][v] - mu[v], kk[v], bt[v]);
+                                gv[u][v] *= ss_act_grad_pwl(t, relu, slope);
+                            } else if (MASK == 2) {
+                                gv[u][v] *= ss_act_grad_pwl(yv[u][v], relu, slope);
+                            } else if (MASK == 3) {
+                                gv[u][v] *= ss_act_grad_from_out(yv[u][v], act, alpha);
+                            }
                         }
-                    } else if (from_y) {
 #pragma unroll
-                        for (int v = 0; v < V; ++v) gv[u][v] *= ss_act_grad_from_out(yv[u][v], act, alpha);
-                    }
+                        for (int v = 0; v < V; ++v) {
+                            const float xh = (xv[u][v] - mu[v]) * rs[v];
+                            const float dv = kk[v] * (gv[u][v] - sm[2 * v] - xh * sm[2 * v + 1]);
+                            o[u][v] = acc_dx ? o[u][v] + dv : dv;
+                            am = fmaxf(am, fabsf((float)(T)o[u][v]));          // what is stored: rounded to the storage type
+                        }
+                        stv<V>(ob + q * dx_cs, o[u]);
+                        if (dres) {
+                            if (acc_dres) {
 #pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const float xh = (xv[u][v] - mu[v]) * rs[v];
-                        const float dv = rs[v] * (gamma ? gm[v] : 1.f) * (gv[u][v] - sm[2 * v] - xh * sm[2 * v + 1]);
-                        o[u][v] = acc_dx ? o[u][v] + dv : dv;
-                        am = fmaxf(am, fabsf((float)(T)o[u][v]));          // what is stored: rounded to the storage type
-                    }
-                    stv<V>(ob + q * dx_cs, o[u]);
-                    if (dres) {
-                        if (acc_dres) {
-#pragma unroll
-                            for (int v = 0; v < V; ++v) r[u][v] += gv[u][v];
-                            stv<V>(rb + q * dres_cs, r[u]);
-                        } else {
-                            stv<V>(rb + q * dres_cs, gv[u]);
+                                for (int v = 0; v < V; ++v) r[u][v] += gv[u][v];
+                                stv<V>(rb + q * dres_cs, r[u]);
+                            } else {
+                                stv<V>(rb + q * dres_cs, gv[u]);
+                            }
                         }
                     }
                 }
             }
-        }
+        };
+        if (recompute) body(std::integral_constant<int, 1>{});
+        else if (!from_y) body(std::integral_constant<int, 0>{});
+        else if (ss_act_is_pwl(act)) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 3>{});
     }
     if (amax) ss_block_amax_to_slot(am, amax);
 }

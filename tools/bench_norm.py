@@ -13,7 +13,7 @@ LY = importlib.import_module(PKG + ".layers")
 
 # kind, n, h=w, c, act
 import sys as _sys
-SHAPES_BIG = [("instance", n, 128, 256, "relu") for n in (1, 2, 4, 8)] + [("instance", n, 256, 128, "relu") for n in (1, 2, 4, 8)] + [("batch", 8, 512, 25, "relu"), ("batch", 2, 512, 25, "relu")]
+SHAPES_BIG = [("instance", 16, 64, 512, "relu"), ("instance", 8, 64, 512, "relu"), ("instance", 16, 64, 512, None), ("batch", 8, 512, 16, "relu"), ("batch", 8, 256, 51, "relu")] + [("instance", n, 128, 256, "relu") for n in (4, 8)] + [("instance", n, 256, 128, "relu") for n in (1, 2, 4, 8)] + [("batch", 8, 512, 25, "relu"), ("batch", 2, 512, 25, "relu")]
 SHAPES = SHAPES_BIG if "--big" in _sys.argv else [
     ("instance", 1, 64, 512, "relu"), ("instance", 2, 64, 512, "relu"), ("instance", 1, 32, 512, "relu"),
     ("instance", 1, 128, 256, "relu"), ("instance", 1, 64, 256, "lrelu"), ("instance", 1, 62, 512, "lrelu"),

@@ -43,7 +43,9 @@ class ConvDesc(_SizedDesc):
                 ("y_stats", c_vp),
                 # optional fused input normalisation: x is the pre-norm tensor, normalised in the operand load (in_norm_groups == 0: off)
                 ("in_norm_mean", c_vp), ("in_norm_rstd", c_vp), ("in_norm_gamma", c_vp), ("in_norm_beta", c_vp),
-                ("in_norm_groups", c_i32), ("in_norm_act", c_i32), ("in_norm_alpha", c_f32), ("in_norm_reserved", c_i32)]
+                ("in_norm_groups", c_i32), ("in_norm_act", c_i32), ("in_norm_alpha", c_f32), ("in_norm_reserved", c_i32),
+                # optional buffer that carries the transformed input operand from the forward to the weight-gradient pass
+                ("saved_operand", c_vp)]
 
 
 class NormDesc(_SizedDesc):
@@ -108,6 +110,7 @@ SIGNATURES = {
     "ss_conv2d_uses_amax": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_stats_chunks": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "ss_conv2d_fuses_in_norm": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
+    "ss_conv2d_saved_operand_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "ss_conv2d_wcache_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_wcache_invalidate": (None, [ctypes.POINTER(WCache)]),
     "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

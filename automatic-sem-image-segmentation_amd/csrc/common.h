@@ -248,6 +248,11 @@ struct TNParams {
     const unsigned int* amax_a;   // amax slots of the tensors the planes were derived from (striped or one word)
     const unsigned int* amax_b;
     int32_t stripes_a, stripes_b, bound_a, bound_b;
+    // A planes that carry their own per-row power-of-two scales, folded into the B rows by the producer of B (the forward pass's
+    // per-tile-scaled V planes, conv_wino.hip): ea = 14; B's exponent then also counts the slot amax_b2 (the tensor A came from)
+    int32_t a_prescaled;
+    const unsigned int* amax_b2;
+    int32_t stripes_b2;
 };
 bool ss_gemm_tn_x3h_ok(int M, int N, long K);
 int ss_gemm_tn_splits(int M, int N, long K, int nbatch, int* k_per_split);
@@ -259,7 +264,7 @@ bool ss_x6p_wide_ok(long M, int N, int K, int nbatch);
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
 
 // kernel-selection switches: ONE explicit table, set through ss_config_set (config.hip); SS_* environment variables give the initial values
-struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products, c1_mfma, x6p_pp; };
+struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products, c1_mfma, x6p_pp, wino_save; };
 const SsTuning& ss_tuning();
 // ss_prof_*: brackets the kernel launched inside this scope with HIP events on its stream when profiling is enabled (config.hip).
 // flops = EXECUTED matrix-instruction FLOPs of the launch (all piece products), bytes = algorithmic HBM bytes (0 if not stated)
@@ -373,7 +378,9 @@ struct WinoProb {
     int x_stripes = 0, dy_stripes = 0;
     float* y_stats = nullptr;     // forward: partial (sum y, sum y^2) per sample / chunk / channel from the output transform
     InNorm in_norm;               // forward / weight gradient: x is a pre-normalisation tensor, normalised in the input transform
+    void* saved = nullptr;        // ss_conv_desc::saved_operand (ss_wino_saved_bytes(q) bytes): forward writes its V planes + per-tile scales there, the weight gradient reads them
 };
+size_t ss_wino_saved_bytes(const WinoProb& q);          // 0: this problem's forward / weight-gradient pair keeps nothing
 bool ss_wino_wgrad_tn(const WinoProb& q);
 bool ss_wino_fwd_x3h(const WinoProb& q);          // the forward pass takes the x3h plane path (the one that fuses InNorm)
 int ss_wino_stats_chunks(const WinoProb& q);

@@ -21,6 +21,7 @@ struct ConvProb {
     WCache* wc = nullptr;          // caller-owned cache of the weight-derived operands of this pass (ss_conv_desc::w_cache)
     float* y_stats = nullptr;      // forward: output statistics for a following norm (ss_conv_desc::y_stats)
     InNorm in_norm;                // forward / weight gradient: x is pre-normalisation, normalised in the operand load (ss_conv_desc::in_norm_*)
+    void* saved = nullptr;         // forward -> weight gradient: the transformed input operand (ss_conv_desc::saved_operand)
 };
 
 // ---- small helper kernels -----------------------------------------------------------------------
@@ -549,6 +550,7 @@ int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bia
         q.wc = c.wc;
         q.y_stats = c.y_stats;
         q.in_norm = c.in_norm;
+        q.saved = c.saved;
         if (c.in_norm.groups > 0 && c.x_amax && !c.x_valid && !(c.wc && c.wc->fill_only)) {      // the transform reports max|normalised x|
             (void)hipMemsetAsync(c.x_amax, 0, (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4, s);
             q.in_norm.amax_out = c.x_amax;
@@ -794,6 +796,7 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
         WinoProb q;
         if (wino_fwd_prob(c, algo, &q)) {
             q.in_norm = c.in_norm;
+            q.saved = c.saved;
             if (c.in_norm.groups > 0 && !(ss_wino_wgrad_tn(q) && c.x_amax && c.x_valid)) {
                 ss_set_error("in_norm: the weight gradient needs the pre-split-plane path and the forward pass's max|normalised x| (x_amax, x_amax_valid)");
                 return SS_ERR_UNSUPPORTED;
@@ -887,6 +890,7 @@ ConvProb plain(const ss_conv_desc* d) {
                d->kh, d->kw, d->stride, d->pad_top, d->pad_left, d->pad_mode == SS_PAD_REFLECT};
     c.x_amax = (unsigned int*)d->x_amax; c.x_valid = d->x_amax_valid;
     c.dy_amax = (unsigned int*)d->dy_amax; c.dy_valid = d->dy_amax_valid;
+    c.saved = d->saved_operand;
     if (d->in_norm_groups > 0) {
         c.in_norm.mean = d->in_norm_mean; c.in_norm.rstd = d->in_norm_rstd; c.in_norm.gamma = d->in_norm_gamma; c.in_norm.beta = d->in_norm_beta;
         c.in_norm.groups = d->in_norm_groups; c.in_norm.act = d->in_norm_act; c.in_norm.alpha = d->in_norm_alpha;
@@ -1312,6 +1316,17 @@ int ss_conv2d_uses_amax(const ss_conv_desc* d, int pass) {
     }
     const ConvShim sh = make_shim(d, nullptr, 0);
     return conv2d_uses_amax32(&sh.d32, pass);
+}
+
+size_t ss_conv2d_saved_operand_bytes(const ss_conv_desc* d) {
+    if (!d || d->struct_size != sizeof(ss_conv_desc) || d->dtype != SS_DTYPE_F32 || d->transposed) return 0;
+    ss_conv_desc t = *d;
+    t.in_norm_groups = 0;
+    if (!valid_desc(&t)) return 0;
+    const ConvProb c = plain(&t);
+    WinoProb q;
+    if (c.kh * c.kw > SS_MAX_TAPS || !wino_fwd_prob(c, d->algo, &q)) return 0;
+    return ss_wino_saved_bytes(q);
 }
 
 int ss_conv2d_fuses_in_norm(const ss_conv_desc* d, int pass) {

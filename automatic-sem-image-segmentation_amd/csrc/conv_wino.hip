@@ -330,7 +330,9 @@ __global__ __launch_bounds__(256, FN ? 4 : 1) void wino_input_kernel(const TI* _
 template <int R, int PL = 0, typename TI = float>
 __global__ __launch_bounds__(256) void wino_dy_kernel(const TI* __restrict__ dy, int dy_cs, int N, int OH, int OW, int C,
                                                       int TH, int TW, float* __restrict__ E, unsigned int* __restrict__ amax_out = nullptr,
-                                                      const unsigned int* __restrict__ amax_in = nullptr, int amax_stripes = 0, int bound = 0) {
+                                                      const unsigned int* __restrict__ amax_in = nullptr, int amax_stripes = 0, int bound = 0,
+                                                      const float* __restrict__ row_scale = nullptr,
+                                                      const unsigned int* __restrict__ amax2 = nullptr, int amax2_stripes = 0, int row_bound = 0) {
     typedef typename WT<R>::T T;
     constexpr int VW = WT<R>::VW, P = R + 2;
     const int CV = C / VW;
@@ -361,6 +363,14 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const TI* __restrict__ dy,
     float emax = 0.f;
     float sc = 1.f;
     if (PL == 1) sc = ldexpf(1.f, 14 - (ss_amax_exp(__uint_as_float(ss_amax_load(amax_in, amax_stripes))) + bound));
+    if (PL == 1 && row_scale) {
+        // The other operand of the weight-gradient GEMM is the FORWARD pass's V planes, which carry 1 / tile_inv[tile] per row
+        // (conv_wino.hip fwd_impl, ss_conv_desc::saved_operand): its factor goes into this row, E' = E * tile_inv[tile] -- a power of
+        // two, exact -- and the common scale covers max|E'| <= max|dy| 2^bound * max tile_inv, tile_inv <= 2^(e_x + row_bound - 14)
+        // (|V| <= 2^row_bound max|x|).  The clamp only matters for an all-zero tile (tile_inv = 1, V = 0: any finite factor does).
+        const int ex = ss_amax_exp(__uint_as_float(ss_amax_load(amax2, amax2_stripes))) + row_bound - 14;
+        sc = ldexpf(sc, -ex) * fminf(row_scale[tile], ldexpf(1.f, ex));
+    }
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         T w[P];
@@ -828,6 +838,10 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     const int cvi = q.cin / VW;
     const bool x3h = R == 4 && ss_wino_fwd_x3h(q) && (((uintptr_t)w) & 15) == 0;
     if (q.in_norm.groups > 0 && !(x3h && q.cin % 32 == 0)) return SS_ERR_UNSUPPORTED;      // only the x3h plane path normalises in its load
+    if (q.saved && ss_wino_saved_bytes(q) > 0 && !x3h) {          // promised (ss_conv2d_saved_operand_bytes) but this launch cannot write it: fail loudly
+        ss_set_error("conv2d_fwd: saved_operand was promised but this launch does not take the x3h plane path (weight pointer alignment)");
+        return SS_ERR_UNSUPPORTED;
+    }
     if (q.in_norm.groups > 0 && q.in_norm.act != SS_ACT_NONE && q.in_norm.act != SS_ACT_RELU && q.in_norm.act != SS_ACT_LRELU) return SS_ERR_UNSUPPORTED;
     if (q.x6 && q.cin % 32 == 0 && (x3h || ss_x6p_wanted(tiles, q.cout, XI))) {
         // both GEMM operands as pre-split bf16 planes: V planes in the V region (1.5x the fp32 size, see ss_wino_fwd_ws)
@@ -855,6 +869,12 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
             SS_LAUNCH_CHECK();
             }
             if (fill_only) return SS_OK;
+            if (q.saved && ss_wino_saved_bytes(q) > 0) {
+                // the caller keeps this pass's input planes for the weight gradient (ss_conv_desc::saved_operand): [2 planes][XI][Mpad][cin]
+                // fp16 + the per-tile scales, instead of the workspace copies
+                V = (float*)q.saved;
+                tile_inv = (float*)((char*)q.saved + ss_align_up((size_t)2 * XI * Mpad * q.cin * 2, 256));
+            }
             if (q.in_norm.groups > 0)
                 hipLaunchKernelGGL((wino_input_kernel<R, 3, true>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
                                    TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, wide,
@@ -948,6 +968,34 @@ int wgrad_impl(const WinoProb& q, const TS* x, const TS* dy, float* dw, int accu
         // the transforms (|B^T d B| <= 100 max|d| < 2^7, |A e A^T| <= 225 max|e| < 2^8), GEMM by LDS-DMA + transposing LDS reads
         constexpr int BOUND_X = 7, BOUND_DY = 8;
         if constexpr (sizeof(TS) == 4) {
+            if (q.saved && ss_wino_saved_bytes(q) > 0) {
+                // The forward pass of this call left its V planes (per-TILE scales, h + 2^-11 l') and the scales' inverses in the caller's
+                // buffer: no second input transform.  K = tile is the reduction index here, so the per-row factor tile_inv[k] moves to the
+                // other operand: E'[k][:] = E[k][:] * tile_inv[k] (wino_dy_kernel), under one scale that bounds max|E'|.
+                const long Mpad = (tiles + SS_X6P_BM - 1) / SS_X6P_BM * SS_X6P_BM;
+                const float* tinv = (const float*)((const char*)q.saved + ss_align_up((size_t)2 * XI * Mpad * q.cin * 2, 256));
+                hipLaunchKernelGGL((wino_dy_kernel<R, 1, TS>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, (float*)E,
+                                   (unsigned int*)nullptr, q.dy_amax, q.dy_stripes, BOUND_DY, tinv, q.x_amax, q.x_stripes, BOUND_X);
+                SS_LAUNCH_CHECK();
+                TNParams g{};
+                g.a = (const unsigned short*)q.saved; g.b = (const unsigned short*)E; g.c = part;
+                g.M = q.cin; g.N = q.cout; g.K = (int)tiles; g.nbatch = XI;
+                g.lda = q.cin; g.ldb = q.cout;
+                g.a_plane = (long)XI * Mpad * q.cin; g.b_plane = (long)XI * tiles * q.cout;
+                g.a_bs = Mpad * q.cin; g.b_bs = tiles * q.cout;
+                int kps;
+                g.splits = ss_gemm_tn_splits(q.cin, q.cout, tiles, XI, &kps);
+                g.k_per_split = kps;
+                g.a_prescaled = 1;
+                g.amax_a = q.x_amax; g.stripes_a = q.x_stripes; g.bound_a = 0;
+                g.amax_b = q.dy_amax; g.stripes_b = q.dy_stripes; g.bound_b = BOUND_DY + BOUND_X - 14;
+                g.amax_b2 = q.x_amax; g.stripes_b2 = q.x_stripes;
+                const int rc = ss_launch_gemm_tn_x3h(g, s);
+                if (rc != SS_OK) return rc;
+                launch_wino_dw<R>(part, g.splits, q.cin, q.cout, dw, accumulate, s);
+                SS_LAUNCH_CHECK();
+                return SS_OK;
+            }
             if (q.in_norm.groups > 0)
                 hipLaunchKernelGGL((wino_input_kernel<R, 4, true>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
                                    q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X, 0, q.in_norm);
@@ -1030,6 +1078,17 @@ bool ss_wino_fwd_x3h(const WinoProb& q) {
     if (wino_r() != 4 || !q.x6 || q.bf16x3 || !ss_x3h_enabled() || q.cin % 32) return false;
     const int cvi = q.cin / 2;
     return (cvi == 64 || cvi == 128 || cvi == 256) && (n_tiles(q, 4) * cvi) % 256 == 0;
+}
+
+// What the forward / weight-gradient pair of this problem passes through ss_conv_desc::saved_operand: the x3h forward's input planes
+// (two fp16 planes, rows padded to the GEMM tile) + the per-tile inverse scales.  Needs both halves: the x3h plane forward with
+// the scaled low piece (not the opt-in wide tile, whose planes carry the plain low piece) and the pre-split-plane weight gradient.
+size_t ss_wino_saved_bytes(const WinoProb& q) {
+    if (!ss_tuning().wino_save || wino_r() != 4 || !ss_wino_fwd_x3h(q) || !ss_wino_wgrad_tn(q) || q.fold_h > 0) return 0;
+    const long tiles = n_tiles(q, 4);
+    if (ss_x6p_wide_ok(tiles, q.cout, q.cin, 36)) return 0;
+    const long Mpad = (tiles + SS_X6P_BM - 1) / SS_X6P_BM * SS_X6P_BM;
+    return ss_align_up((size_t)2 * 36 * Mpad * q.cin * 2, 256) + ss_align_up((size_t)tiles * 4, 256);
 }
 
 size_t ss_wino_fwd_ws(const WinoProb& q) {

@@ -147,8 +147,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
     for (int j = 0; j < TNDMA; ++j) kstep[j] = (long)TBK * (wave * TNDMA + j < 32 ? p.lda : p.ldb);
 
     // scales: the planes hold a * 2^(14 - ea) and b * 2^(14 - eb) (conv_wino.hip, same slots, same bounds)
-    const int ea = ss_amax_exp(__uint_as_float(ss_amax_load(p.amax_a, p.stripes_a))) + p.bound_a;
-    const int eb = ss_amax_exp(__uint_as_float(ss_amax_load(p.amax_b, p.stripes_b))) + p.bound_b;
+    // a_prescaled: the A planes carry per-row scales that the producer of B folded into B's rows (ea = 14: no factor left), and B's
+    // exponent counts the second slot (the maximum of the tensor A was transformed from) -- the same expression as wino_dy_kernel's
+    const int ea = p.a_prescaled ? 14 : ss_amax_exp(__uint_as_float(ss_amax_load(p.amax_a, p.stripes_a))) + p.bound_a;
+    const int eb = ss_amax_exp(__uint_as_float(ss_amax_load(p.amax_b, p.stripes_b))) + p.bound_b +
+                   (p.amax_b2 ? ss_amax_exp(__uint_as_float(ss_amax_load(p.amax_b2, p.stripes_b2))) : 0);
     const float out_scale = ldexpf(1.f, ea - 14 + eb - 14);
 
     {   // pipeline fill for this workgroup's first tile (chunk indices past the end re-fetch the last chunk: fixed group count)

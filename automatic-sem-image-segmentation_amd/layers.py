@@ -18,6 +18,9 @@ WEIGHT_CACHE = os.environ.get("SS_WEIGHT_CACHE", "1") != "0"      # 0: every pas
 # Norm(..., defer=True) leaves the apply pass to the consuming convolution's operand load where that convolution can
 # (ss_conv2d_fuses_in_norm); 0: every norm writes its output (measurement / A-B tests: both routes give the same bits)
 FUSE_IN_NORM = os.environ.get("SS_FUSE_IN_NORM", "1") != "0"
+# 1: a convolution whose path can (ss_conv2d_saved_operand_bytes) keeps the transformed input operand of its forward pass for its weight
+# gradient (ss_conv_desc::saved_operand): HBM capacity for one input transform per layer and step; 0: the weight gradient transforms x again
+SAVE_OPERAND = os.environ.get("SS_SAVE_OPERAND", "1") != "0"
 
 # Cross-rank BatchNorm statistics (data parallel): set by dist.enable_sync_bn() to a callable that all-reduces (SUM) a
 # float32 device tensor in place and returns the world size.  None = per-process statistics (single GPU).
@@ -126,8 +129,17 @@ class Conv2D:
             d.y_stats = st.data_ptr()
         else:
             d.y_stats = None
+        # the transformed input operand of this pass, kept for its weight gradient where the path can hand it over (Winograd x3h
+        # forward -> pre-split-plane weight gradient): one input transform per layer and step less, paid in HBM capacity
+        sv = None
+        if SAVE_OPERAND and param_grads and tape.enabled:
+            nsv = self._saved_bytes(d)
+            if nsv:
+                sv = torch.empty(nsv, dtype=torch.uint8, device=y.device)
+        d.saved_operand = sv.data_ptr() if sv is not None else None
         L.check(lib.ss_conv2d_fwd(ctypes.byref(d), xin.ptr, _p(w), _p(b), y.ptr, _p(ws), ws.numel(), _stream()),
                 f"conv2d_fwd[{self.name}]")
+        d.saved_operand = None
         if sc:
             y.stats = (st, sc)
         self._wcache_done(wst)
@@ -159,8 +171,10 @@ class Conv2D:
                 self._set_in_norm(dd, fused)
                 dd.x_amax, dd.x_amax_valid = (x.amax_slot(), 1 if x.amax_valid else 0) if uses & 1 else (None, 0)
                 dd.dy_amax, dd.dy_amax_valid = (dy.amax_slot(), 1 if dy.amax_valid else 0) if uses & 2 else (None, 0)
+                dd.saved_operand = sv.data_ptr() if sv is not None else None
                 L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), xin.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wsw), wsw.numel(),
                                                  _stream()), f"conv2d_bwd_weight[{self.name}]")
+                dd.saved_operand = None
                 if uses & 1:
                     x.amax_valid = True
                 if uses & 2:
@@ -197,6 +211,14 @@ class Conv2D:
         d.in_norm_gamma = x.gamma.data_ptr() if x.gamma is not None else None
         d.in_norm_beta = x.beta.data_ptr()
         d.in_norm_groups, d.in_norm_act, d.in_norm_alpha = x.groups, x.act_code, float(x.act_alpha)
+
+    def _saved_bytes(self, d):
+        """ss_conv2d_saved_operand_bytes(d), cached per geometry and configuration."""
+        key = (d.n, d.ih, d.iw, d.in_cstride, d.out_cstride, d.dtype, "saved", L.CONFIG_EPOCH)
+        u = self._amax_cache.get(key)
+        if u is None:
+            u = self._amax_cache[key] = int(L.load().ss_conv2d_saved_operand_bytes(ctypes.byref(d)))
+        return u
 
     def _fuses_in_norm(self, d, pass_):
         """ss_conv2d_fuses_in_norm(d, pass), cached per geometry and configuration."""

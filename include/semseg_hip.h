@@ -174,7 +174,19 @@ typedef struct ss_conv_desc {
     int32_t in_norm_act;
     float in_norm_alpha;
     int32_t in_norm_reserved;
+    /* Optional (may be NULL): caller-owned device buffer of ss_conv2d_saved_operand_bytes(d) bytes that carries the TRANSFORMED input
+     * operand from the forward pass to the weight-gradient pass of the same call (same x, same descriptor): the forward pass writes
+     * its Winograd-domain input planes (fp16 h / l pieces under per-tile scales) there instead of into its workspace, the
+     * weight gradient contracts them with the transformed dy and does not transform x a second time (the reference keeps every
+     * layer input alive for autograd, CycleGAN.py:615-690; 288 GB of HBM hold the transformed form as well).  A weight-gradient
+     * call that is handed the buffer trusts its contents.  Ignored when ss_conv2d_saved_operand_bytes(d) == 0. */
+    void* saved_operand;
 } ss_conv_desc;
+
+/* Bytes of ss_conv_desc::saved_operand this descriptor's forward pass fills and its weight-gradient pass reads (0: the path keeps
+ * nothing -- then the field is ignored).  Today: fp32 storage, the Winograd x3h forward (F(4x4,3x3) on pre-split planes) together
+ * with the pre-split-plane weight gradient.  Pure function of d (ignoring the pointer fields) and the ss_config table. */
+size_t ss_conv2d_saved_operand_bytes(const ss_conv_desc* d);
 
 /* != 0: `pass` (SS_PASS_FWD or SS_PASS_BWD_WEIGHT) of this descriptor applies ss_conv_desc::in_norm_* in its operand load (the
  * Winograd x3h forward transform and the Winograd weight gradient on pre-split planes, today).  Pure function of d (ignoring the

@@ -510,3 +510,60 @@ def test_x3h_power_of_two_invariance(k2):
     assert torch.equal(outs[2][0], y0 * (2.0 ** k2)), "forward is not exactly homogeneous in the weights"
     assert torch.equal(outs[2][1], dx0 * (2.0 ** k2)), "data gradient is not exactly homogeneous in the weights"
     assert torch.equal(outs[1][2], dw0 * (2.0 ** k2)), "weight gradient is not exactly homogeneous in the input"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 32, 32, 256, 256), (8, 32, 32, 512, 256), (1, 64, 64, 256, 128)], ids=["n4_32_256", "n8_32_512to256", "n1_64_256to128"])
+def test_winograd_weight_gradient_from_the_forward_passs_saved_operand(shape):
+    """ss_conv_desc::saved_operand: the Winograd x3h forward keeps its transformed input planes (per-tile scales), the weight gradient
+    contracts them with the transformed dy (rows scaled by the tiles' inverse factors) instead of transforming x again.  Both routes
+    are the x3h arithmetic: each must match the fp64 gradient as closely as the other (fp32-grade), and they must agree with each
+    other far below that distance; the forward output and dx do not depend on the switch at all."""
+    import ctypes
+    E, LY, L = _mods()
+    n, h, w, cin, cout = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    wt = torch.empty((3, 3, cin, cout)).uniform_(-0.05, 0.05, generator=g)
+    # heavy-tailed input: a few tiles two orders of magnitude above the rest (per-tile scales vs one scale per tensor)
+    xt = torch.randn((n, h, w, cin), generator=g)
+    xt[:, : h // 4, : w // 4] *= 60.0
+    dyt = torch.randn((n, h, w, cout), generator=g)
+    res = {}
+    lib = L.load()
+    for save in (False, True):
+        LY.SAVE_OPERAND = save
+        try:
+            with L.config(x6p=2):
+                arena = E.ParamArena(dev)
+                conv = LY.Conv2D(arena, "c", 3, cin, cout, padding=("reflect", 1), use_bias=False)
+                arena.materialize()
+                arena["c/kernel"].copy_(wt)
+                tape = E.Tape()
+                x = E.Act(xt.to(dev), requires_grad=True)
+                y = conv(tape, x)
+                if save:
+                    assert lib.ss_conv2d_saved_operand_bytes(ctypes.byref(conv.desc(x, y))) > 0, "this shape must take the saved-operand path"
+                gt, _ = y.grad_target()
+                gt.t.copy_(dyt.to(dev))
+                arena.zero_grad()
+                tape.backward()
+                torch.cuda.synchronize()
+                res[save] = (y.dense().clone(), x.get_grad().dense().clone(), arena.grad("c/kernel").clone())
+        finally:
+            LY.SAVE_OPERAND = True
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    # fp64 reference of dw: correlation of the reflect-padded input with dy
+    xp = torch.nn.functional.pad(xt.double().permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect")
+    dyp = dyt.double().permute(0, 3, 1, 2)
+    ref = torch.empty((3, 3, cin, cout), dtype=torch.float64)
+    for a in range(3):
+        for b in range(3):
+            ref[a, b] = torch.einsum("nchw,nkhw->ck", xp[:, :, a:a + h, b:b + w], dyp)
+    scale = ref.abs().max()
+    e_off = float((res[False][2].double().cpu() - ref).abs().max() / scale)
+    e_on = float((res[True][2].double().cpu() - ref).abs().max() / scale)
+    d_on_off = float((res[True][2] - res[False][2]).abs().max().cpu() / scale)
+    assert e_off <= 2e-5 and e_on <= 2e-5, (e_off, e_on)
+    assert e_on <= 3.0 * e_off + 1e-7, (e_on, e_off)
+    assert d_on_off <= 2e-5, d_on_off

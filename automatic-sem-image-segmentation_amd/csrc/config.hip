@@ -45,6 +45,7 @@ const Key KEYS[] = {
     {"c1_mfma", &SsTuning::c1_mfma, "one-channel stem / head layers (1 -> C, C -> 1, full resolution) on the fp16 matrix cores with the x3h arithmetic; 0: LDS-tiled VALU kernels"},
     {"x6p_pp", &SsTuning::x6p_pp, "x3h Winograd GEMMs: ping-pong schedule (the two waves of a SIMD half a K step apart: one multiplies while the other loads); 0: one-phase kernel (same results bit for bit)"},
     {"wino_save", &SsTuning::wino_save, "Winograd x3h forward keeps its transformed input planes for the weight gradient when the caller provides ss_conv_desc::saved_operand (ss_conv2d_saved_operand_bytes > 0); 0: the weight gradient transforms x again"},
+    {"gemm_ilv", &SsTuning::gemm_ilv, "pre-split-plane x3h GEMMs: fragment reads issued between the MFMAs of a half step instead of in a burst in front of them (bit-identical); 0: burst form"},
     {"wgrad_tn", &SsTuning::wgrad_tn, "Winograd weight gradient on pre-split K-major fp16 planes with transposing LDS reads (gemm_tn_x3h.hip); 0: in-kernel split"},
 };
 
@@ -68,6 +69,7 @@ SsTuning from_env() {
     v.gemm_persistent = env_is("SS_GEMM_PERSISTENT", '0') ? 0 : 1;
     v.x6p_pp = env_is("SS_X6P_PP", '1') ? 1 : 0;
     v.wino_save = env_is("SS_WINO_SAVE", '0') ? 0 : 1;
+    v.gemm_ilv = env_is("SS_GEMM_ILV", '0') ? 0 : 1;
     v.norm_fused_pix = getenv("SS_NORM_FUSED_PIX") ? atoi(getenv("SS_NORM_FUSED_PIX")) : 1024;
     v.gconv_fast = getenv("SS_GCONV_NOFAST") ? 0 : 1;
     v.nt512 = getenv("SS_GCONV_NT512") ? 1 : 0;

@@ -37,6 +37,7 @@ __device__ __forceinline__ s16x4 tr4(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
+template <bool ILV>
 __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -132,6 +133,17 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
             }
         }
     };
+    auto frag_plane = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][2], int stage, int kh, int pl) {
+        const unsigned char* sa = lds + stage * TSTAGE + kh * 16 * TA_ROW;
+        const unsigned char* sb = lds + stage * TSTAGE + 2 * TA_PLANE + kh * 16 * TB_ROW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const s16x4 x0 = tr4(sa + pl * TA_PLANE + oa[i]), x1 = tr4(sa + pl * TA_PLANE + oa[i] + 4 * TA_ROW);
+            a[pl][i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
+            const s16x4 y0 = tr4(sb + pl * TB_PLANE + ob[i]), y1 = tr4(sb + pl * TB_PLANE + ob[i] + 4 * TB_ROW);
+            b[pl][i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
     // l*h, h*l (cross accumulators), h*h; consecutive MFMAs go to different accumulators
     constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0}, HS[3] = {1, 1, 0};
     auto mma4 = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][2], int q) {
@@ -185,14 +197,22 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
         for (int c = 0; c < nchunks; ++c) {
             const int st1 = st + 1 == TSTAGES ? 0 : st + 1;
             frag(a1, b1, st, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 3; ++q) mma4(a0, b0, q);
+            if (ILV) {          // the 16 transposing reads of the other K half between this half's MFMAs instead of in a burst in front of them (gemm_x6p.hip ILV)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0x0070 | (((TSTAGES - 2) * TNDMA) & 15));      // vmcnt(6) lgkmcnt(0): chunk c+1 landed, own reads of chunk c done
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            frag(a0, b0, st1, 0);
+            if (!ILV) frag(a0, b0, st1, 0);
             // past the last chunk of a tile the stream continues with the next tile's first chunks (last tile: re-fetch, unused)
             const int ca = c + TSTAGES;
             const bool own = ca < nchunks;
@@ -200,26 +220,45 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
             unsigned char* dst = lds + st * TSTAGE;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
+                if (ILV && q < 2) frag_plane(a0, b0, st1, 0, q);          // plane q of the next step's first half: 8 reads behind this group's MFMAs
                 mma4(a1, b1, q);
 #pragma unroll
                 for (int j = 0; j < TNDMA; ++j)
                     if (j * 3 / TNDMA == q) dma16(((own || !more) ? gp[j] : gpn[j]) + cn * kstep[j], dst + loff[j]);
+                if (ILV) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (q < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x020, TNDMA / 3, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
             st = st1;
         }
 
-        // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        float* cbase = p.c + cur.cbase + (cur.n0 + wn * 64 + l31);
+        // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Register-transposed (ss_quad_transpose,
+        // as gemm_x6p.hip): the four registers of a row quad become four consecutive columns of one row = one 16-byte store; 16 store
+        // instructions per wave (8 rows x 128 B each) instead of 64 four-byte ones.  Tiles are whole (M % 256 == 0, N % 128 == 0).
+        {
+            const bool odd = lane & 1, hi = lane & 2;
+            const int m = cur.m0 + wm * 64 + 4 * lh + (lane & 3);          // + 32 mi + 8 rq
+            float* g = p.c + cur.cbase + (cur.n0 + wn * 64 + (l31 & ~3)) + (long)m * p.N;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = cur.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float* crow = cbase + (long)m * p.N;              // one row pointer for both column tiles
+                for (int rq = 0; rq < 4; ++rq) {
+                    float* grow = g + (long)(mi * 32 + 8 * rq) * p.N;
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) crow[32 * ni] = fmaf(acc[1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]) * out_scale;
+                    for (int ni = 0; ni < 2; ++ni) {
+                        float v[4];
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) v[rr] = fmaf(acc[1][mi][ni][rq * 4 + rr], 4.8828125e-4f, acc[0][mi][ni][rq * 4 + rr]) * out_scale;
+                        *(f32x4*)(grow + 32 * ni) = ss_quad_transpose(v[0], v[1], v[2], v[3], odd, hi);
+                    }
+                }
             }
         }
         if (more) {
@@ -252,7 +291,8 @@ int ss_gemm_tn_splits(int M, int N, long K, int nbatch, int* k_per_split) {
 int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s) {
     if (!ss_gemm_tn_x3h_ok(p.M, p.N, p.K) || p.k_per_split % TBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
     static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
@@ -262,7 +302,9 @@ int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s) {
     const long nwg = persistent ? n_cu : tiles;
     SsProfScope prof("gemm_tn_x3h_kernel", 2.0 * p.M * p.N * p.K * p.nbatch * 3,
                      2.0 * 2 * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
-    hipLaunchKernelGGL(gemm_tn_x3h_kernel, dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
+    // fragment reads interleaved with the MFMAs (bit-identical; gemm_ilv = 0 keeps the burst form)
+    if (!ss_tuning().gemm_ilv) hipLaunchKernelGGL(gemm_tn_x3h_kernel<false>, dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
+    else hipLaunchKernelGGL(gemm_tn_x3h_kernel<true>, dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

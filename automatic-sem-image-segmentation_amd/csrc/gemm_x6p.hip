@@ -40,7 +40,11 @@ constexpr int x6p_stages(int npl, bool wide = false) { return npl == 1 ? 4 : (np
 // accumulator set -- the operand planes then carry the low piece at its own magnitude (x*s = h + l, as in the gather kernels;
 // p.plain_l) instead of 2^11 times it -- and one fragment register set (the four resident waves cover the LDS latency); two LDS
 // stages of 64 KiB.
-template <int NPL, bool WIDE>
+// ILV (x3h, not wide): the fragment reads of a half step are issued BETWEEN its MFMAs (sched_group_barrier: one MFMA, one ds_read,
+// ...) instead of in a burst in front of them -- after a barrier all eight waves of the CU issue their eight reads at once, the LDS
+// queue backs up and the first MFMA of every wave waits behind its own reads (SQ counters, tools/x6p_sq.sh: 693 wait cycles and
+// ~630 idle matrix-pipe cycles per K step even with no global memory traffic at all)
+template <int NPL, bool WIDE, bool ILV = false>
 __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParams p) {
     static_assert(!WIDE || NPL == 2, "the wide tile exists for the two-plane fp16 operands only");
     static_assert(NPL >= 1 && NPL <= 3, "one, two or three operand planes");
@@ -239,9 +243,17 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
                 constexpr int W = decltype(VW)::value;
                 const int st1 = st + 1 == STAGES ? 0 : st + 1;
                 frag(a1, b1, st, so1);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
+                if constexpr (ILV) {
+#pragma unroll
+                    for (int i = 0; i < 4 * NPL; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one ds_read
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NQ - 4 * NPL, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 // chunk c+1 landed (the younger groups may still be in flight) and this wave's reads of chunk c are done: a real
                 // s_waitcnt (vmcnt(W) lgkmcnt(0)), so that the compiler's own counting sees it
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
                 // branch-free from here to the loop end (one basic block keeps the compiler's lgkmcnt counting exact): past the last
                 // chunk of the LAST tile the fragment read fetches stale LDS and the DMA re-fetches the last chunk into a free stage;
                 // past the last chunk of any other tile both continue with the NEXT tile's first chunks
-                frag(a0, b0, st1, so0);
+                if constexpr (!ILV) frag(a0, b0, st1, so0);
                 const int ca = c + STAGES;
                 const bool own = ca < nchunks;
                 const int cn = own ? ca : (more ? ca - nchunks : nchunks - 1);
@@ -259,10 +271,27 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
                 unsigned char* dst = lds + st * STAGE_B;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
+                    if constexpr (ILV) {          // plane q of the next half step's fragments: four reads, one behind each MFMA of this group
+                        if (q < NPL) {
+                            const int sb = st1 * STAGE_B;
+#pragma unroll
+                            for (int mi = 0; mi < 2; ++mi) a0[q][mi] = *(const FT*)(fa + sb + q * A_PLANE_B + mi * 32 * ROWB + so0);
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni) b0[q][ni] = *(const FT*)(fb + sb + q * B_PLANE_B + ni * 32 * ROWB + so0);
+                        }
+                    }
                     mma4(a1, b1, q);
 #pragma unroll
                     for (int j = 0; j < NDMA; ++j)
                         if (j * NQ / NDMA == q && !(skipmask >> j & 1)) dma16(((own || !more) ? gp[j] : gpn[j]) + goff, dst + loff[j]);
+                    if constexpr (ILV) {          // this group's four MFMAs with the fragment reads of the next half step between them (the first 4 NPL MFMAs)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (q < NPL) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x020, NDMA / NQ, 0);          // then this group's LDS-DMA pieces
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // F0's reads finished long ago (24 MFMAs back): a free wait that lets the compiler start the next step without one
@@ -701,6 +730,7 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
@@ -738,6 +768,8 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
                      2.0 * (one ? 1 : (p.fp16x2 ? 2 : 3)) * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
     if (one) hipLaunchKernelGGL((gemm_x6p_kernel<1, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(1) * 1 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);
     else if (wide) hipLaunchKernelGGL((gemm_x6p_kernel<2, true>), dim3((unsigned)nwg), dim3(1024), x6p_stages(2, true) * 2 * (A_PLANE_B + 256 * ROWB), s, p);
+    // x3h: fragment reads interleaved with the MFMAs (ILV; bit-identical; gemm_ilv = 0 keeps the burst form)
+    else if (p.fp16x2 && ss_tuning().gemm_ilv) hipLaunchKernelGGL((gemm_x6p_kernel<2, false, true>), dim3((unsigned)nwg), dim3(512), x6p_stages(2) * 2 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);
     else if (p.fp16x2) hipLaunchKernelGGL((gemm_x6p_kernel<2, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(2) * 2 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);
     else hipLaunchKernelGGL((gemm_x6p_kernel<3, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(3) * 3 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);
     SS_LAUNCH_CHECK();

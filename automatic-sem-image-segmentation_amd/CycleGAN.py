@@ -111,6 +111,7 @@ class CycleGanModel:
         self.batch_generator_passes = os.environ.get("SS_BATCH_G_PASSES", "1") != "0"
         # run the two independent chains of each phase on two HIP streams (see _train_step_dual); SS_DUAL_STREAM=0 disables
         self.dual_stream = {"0": False, "force": "force"}.get(os.environ.get("SS_DUAL_STREAM", "1"), True)
+        self.dual_gemm_cus = 224          # CUs the persistent GEMMs of one chain occupy while two chains run (0: all)
         # (switched off automatically when several ranks share one GPU -- dist.ranks_share_device(); "force" overrides, for tests)
         self.gen_a_optimizer = self.gen_b_optimizer = self.disc_a_optimizer = self.disc_b_optimizer = None
         self.image_pool_a = image_pool_a if image_pool_a is not None else ImagePool(1, 0)
@@ -165,6 +166,18 @@ class CycleGanModel:
 
         if (self.dual_stream and self.use_identity_loss and self.batch_generator_passes and not self.use_binary_crossentropy_a
                 and (self.dual_stream == "force" or not D.ranks_share_device())):
+            # Two kernel chains share the GPU: the persistent Winograd GEMMs then take 224 of the 256 CUs -- a GEMM workgroup holds a
+            # CU's whole LDS, so with all 256 occupied the other chain's kernels only start when the GEMM ends; with 32 CUs left its
+            # bandwidth-bound kernels run beside it (measured: 197.8 -> 195.9 ms per step, same box).  SS_GEMM_CUS overrides.
+            cus = self.dual_gemm_cus if not os.environ.get("SS_GEMM_CUS") else None
+            if cus:
+                # straight through the C ABI: this key changes no cached answer (L.config_set would bump the epoch all host-side caches key on)
+                lib = L.load()
+                lib.ss_config_set(b"gemm_cus", cus)
+                try:
+                    return self._train_step_dual(real_a, real_b, one, zero, world)
+                finally:
+                    lib.ss_config_set(b"gemm_cus", 0)
             return self._train_step_dual(real_a, real_b, one, zero, world)
 
         # ---- generators -------------------------------------------------------------------------------

@@ -298,8 +298,9 @@ int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s) {
     (void)attr_set;
     const long tiles = (long)(p.M / TBM) * (p.N / TBN) * p.nbatch * p.splits;
     static const int n_cu = [] { int v = 0; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0); return v >= 8 ? v / 8 * 8 : 256; }();
-    const bool persistent = ss_tuning().gemm_persistent && tiles > n_cu && p.k_per_split >= 3 * TBK && p.K % p.k_per_split == 0;
-    const long nwg = persistent ? n_cu : tiles;
+    const int cus = (ss_tuning().gemm_cus >= 8 && ss_tuning().gemm_cus < n_cu) ? ss_tuning().gemm_cus / 8 * 8 : n_cu;
+    const bool persistent = ss_tuning().gemm_persistent && tiles > cus && p.k_per_split >= 3 * TBK && p.K % p.k_per_split == 0;
+    const long nwg = persistent ? cus : tiles;
     SsProfScope prof("gemm_tn_x3h_kernel", 2.0 * p.M * p.N * p.K * p.nbatch * 3,
                      2.0 * 2 * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
     // fragment reads interleaved with the MFMAs (bit-identical; gemm_ilv = 0 keeps the burst form)

@@ -340,7 +340,10 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
                         for (int rr = 0; rr < 4; ++rr)
                             v[rr] = NACC == 1 ? acc[0][mi][ni][rq * 4 + rr] : fmaf(acc[NACC - 1][mi][ni][rq * 4 + rr], 4.8828125e-4f, acc[0][mi][ni][rq * 4 + rr]);
                         const f32x4 o = ss_quad_transpose(v[0], v[1], v[2], v[3], odd, hi);
-                        if (row_ok) *(f32x4*)(grow + 32 * ni) = o;
+                        if (row_ok) {
+                            if (p.dbg & 2) __builtin_nontemporal_store(o, (f32x4*)(grow + 32 * ni));          // measurement: streaming stores
+                            else *(f32x4*)(grow + 32 * ni) = o;
+                        }
                     }
                 }
             }
@@ -722,7 +725,7 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     if (p.K % PBK || p.k_per_split % PBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
     const bool wide = p.fp16x2 == 1 && p.plain_l;
     X6PParams pd = p;
-    pd.dbg = ss_tuning().tile_dbg & (8 | 16 | 32 | 64 | 128);          // 8: the LDS-transposed epilogue, 16: the scalar-store epilogue (A/B measurement)
+    pd.dbg = ss_tuning().tile_dbg & (2 | 8 | 16 | 32 | 64 | 128);          // 8: the LDS-transposed epilogue, 16: the scalar-store epilogue (A/B measurement)
     if (wide && (p.N % 256 || p.splits != 1)) return SS_ERR_UNSUPPORTED;
     const int pbn = wide ? 256 : SS_X6P_BN;
     const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + pbn - 1) / pbn;
@@ -739,8 +742,9 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     const long tiles = (long)gridM * gridN * p.nbatch * p.splits;
     // one workgroup per CU (the LDS ring fills a CU): more tiles than CUs -> persistent workgroups (a multiple of 8: one share per XCD)
     static const int n_cu = [] { int v = 0; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0); return v >= 8 ? v / 8 * 8 : 256; }();
-    const bool persistent = ss_tuning().gemm_persistent && tiles > n_cu && p.k_per_split >= 3 * PBK && p.K % p.k_per_split == 0;
-    const long nwg = persistent ? n_cu : tiles;
+    const int cus = (ss_tuning().gemm_cus >= 8 && ss_tuning().gemm_cus < n_cu) ? ss_tuning().gemm_cus / 8 * 8 : n_cu;
+    const bool persistent = ss_tuning().gemm_persistent && tiles > cus && p.k_per_split >= 3 * PBK && p.K % p.k_per_split == 0;
+    const long nwg = persistent ? cus : tiles;
     const bool one = p.fp16x2 == 2;          // fp16x2 == 2: ONE fp16 plane per operand, one product (16-bit activation storage)
     // x3h planes, every tile at least two K chunks deep: the ping-pong kernel (same results bit for bit; x6p_pp = 0 keeps the one-phase kernel)
     if (p.fp16x2 == 1 && !wide && ss_tuning().x6p_pp && p.k_per_split >= 2 * PBK && p.K % p.k_per_split == 0) {

@@ -111,6 +111,7 @@ SIGNATURES = {
     "ss_conv2d_stats_chunks": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "ss_conv2d_fuses_in_norm": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_saved_operand_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "ss_probe_mfma": (c_i32, [c_i32, c_vp, ctypes.c_size_t, c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ss_conv2d_wcache_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_wcache_invalidate": (None, [ctypes.POINTER(WCache)]),
     "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -347,8 +347,27 @@ def main():
                         traffic = kern.get(dom) or kern.get(dom.replace(">", ",false>"))
                 except Exception:
                     traffic = None
+            # what the matrix pipe of THIS box delivers on real data (the chip clocks to its power budget): a register-only MFMA stream on
+            # random fp16 operands, measured now (ss_probe_mfma) -- `frac` stays against the nominal peak of MI355X_MICROARCH.md
+            ceiling = None
+            try:
+                import ctypes
+                sc = torch.empty(65600, dtype=torch.uint8, device=dev)
+                tf, mhz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+                tf0, mhz0 = ctypes.c_double(0.0), ctypes.c_double(0.0)
+                lib_ = L.load()
+                if lib_.ss_probe_mfma(1, sc.data_ptr(), sc.numel(), None, ctypes.byref(tf), ctypes.byref(mhz)) == 0 and \
+                        lib_.ss_probe_mfma(0, sc.data_ptr(), sc.numel(), None, ctypes.byref(tf0), ctypes.byref(mhz0)) == 0:
+                    ceiling = {"tflops_random_operands": round(tf.value, 1), "effective_mhz_random_operands": round(mhz.value),
+                               "tflops_zero_operands": round(tf0.value, 1), "effective_mhz_zero_operands": round(mhz0.value),
+                               "frac_of_nominal_peak": round(tf.value / d["peak"], 4),
+                               "dominant_kernel_frac_of_this_ceiling": round(d["achieved"] / tf.value, 4) if tf.value > 0 else None,
+                               "source": "ss_probe_mfma in this run: register-only v_mfma_f32_32x32x16_f16 stream on every CU, no memory traffic"}
+            except Exception as e:          # noqa: BLE001
+                ceiling = {"error": repr(e)}
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s",
                                "frac": d["frac"], "avg_launch_ms": d["avg_ms"], "launches_timed": d["launches"],
+                               "real_data_ceiling": ceiling,
                                "definition": "EXECUTED matrix-instruction FLOPs of the timed launches (all piece products of the operand "
                                              "split, useful rows/columns only) / their HIP-event time (ss_prof_*, launch stream, "
                                              "single-stream steps) / dense peak of the instruction the kernel issues",

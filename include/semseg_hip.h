@@ -85,6 +85,13 @@ int ss_prof_reset(void);
 int ss_prof_count(void);
 int ss_prof_get(int index, ss_prof_entry* out);
 
+/* Measurement aid (bench.py `roofline.real_data_ceiling`; no product path calls it): TF/s and effective shader clock (MHz) of a
+ * register-only stream of v_mfma_f32_32x32x16_f16 on every CU of device 0, on zero operands (random_operands == 0) or on random fp16
+ * operands.  The chip clocks to its power budget: the second figure is the ceiling of any real-data kernel on THIS box
+ * (profiles/r04_microbenchmarks.md: 0.61 - 0.66 of the nominal 2516.6 TF/s).  scratch: caller-owned device buffer of >= 65600
+ * bytes.  Synchronises on `stream`. */
+int ss_probe_mfma(int random_operands, void* scratch, size_t scratch_bytes, void* stream, double* tflops, double* mhz);
+
 /* ------------------------------------------------------------------------------------------
  * 2-D convolution / transposed convolution.
  * Replaces keras.layers.Conv2D at CycleGAN.py:327,333,340,372,393,429/431,448 and

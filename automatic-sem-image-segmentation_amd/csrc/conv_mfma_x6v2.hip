@@ -60,7 +60,7 @@ __device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l)
 // weight), NPROD = 1 with the leading weight piece only (ss_tuning wino16_products); half the gathered bytes, a third of the split work.
 template <int VBN, typename T, int NPROD>
 __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems, int Npad,
-                                                            int Ktot) {
+                                                            int Ktot, int ilv_flag) {
     constexpr bool F32 = std::is_same<T, float>::value;
     static_assert(F32 ? NPROD == 3 : NPROD <= 2, "fp32 storage: three products; 16-bit storage: one or two");
     constexpr int VB_PLANE = VG<VBN>::B_PLANE, VSTAGE = VG<VBN>::STAGE, TN = VG<VBN>::TN, NB = VG<VBN>::NB;
@@ -241,11 +241,15 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         __builtin_amdgcn_sched_barrier(0);
         load_a(cur, c + 2 < nchunks ? c + 2 : last);
         __builtin_amdgcn_sched_barrier(0);
-        frag(a1, b1, s, 1);
+        // (gemm_ilv) the other K half's fragment reads go BEHIND the first MFMA group instead of in front of it: after the barrier all
+        // eight waves would issue their reads at once and every wave's first MFMA would wait behind its own reads (gemm_x6p.hip ILV)
+        const bool ilv = ilv_flag != 0;
+        if (!ilv) frag(a1, b1, s, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             if (q < NPROD) mma4(a0, b0, q);
+            if (q == 0 && ilv) frag(a1, b1, s, 1);
             store_a(nxt, s ^ 1, q);
             if (q == 2) store_a(nxt, s ^ 1, 3);
             __builtin_amdgcn_sched_barrier(0);
@@ -254,9 +258,17 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         __builtin_amdgcn_s_waitcnt(0x0070 | 4);      // vmcnt(4) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        frag(a0, b0, s ^ 1, 0);
+        if (!ilv) {
+            frag(a0, b0, s ^ 1, 0);
 #pragma unroll
-        for (int q = 0; q < NPROD; ++q) mma4(a1, b1, q);
+            for (int q = 0; q < NPROD; ++q) mma4(a1, b1, q);
+        } else {
+            mma4(a1, b1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            frag(a0, b0, s ^ 1, 0);
+#pragma unroll
+            for (int q = 1; q < NPROD; ++q) mma4(a1, b1, q);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
     };
@@ -415,7 +427,7 @@ static int launch_v2(const GConvParams& p, const unsigned short* planes, long pl
         ss_set_error("gconv_x6v2: output statistics requested for a problem whose tiles do not line up with the samples");
         return SS_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL((gconv_x6v2_kernel<VBN, T, NPROD>), dim3((unsigned)nwg), dim3(512), smem, s, p, planes, plane_elems, Npad, Ktot);
+    hipLaunchKernelGGL((gconv_x6v2_kernel<VBN, T, NPROD>), dim3((unsigned)nwg), dim3(512), smem, s, p, planes, plane_elems, Npad, Ktot, ss_tuning().gemm_ilv);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

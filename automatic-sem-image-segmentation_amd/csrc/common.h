@@ -237,6 +237,20 @@ struct X6PParams {
     int32_t dbg;                  // measurement only (tile_dbg & 64: skip the B operand's LDS-DMA; & 128: skip A's): results are wrong
     int64_t a_plane, b_plane, a_bs, b_bs, c_bs, c_ss;
 };
+// Up to four gather problems of ONE launch (the sub-pixel phases of a stride-2 data gradient / transposed convolution: same input,
+// same output tensor, same class grid; they differ in the output phase, their taps and their weight planes).  Workgroup slot s of
+// an XCD takes problem s % count, tile s / count: the phases of one tile run side by side on one XCD and share its input rows in
+// that L2; one launch instead of four.  count <= 1: a plain launch, nothing here is read.
+#define SS_MAX_PHASES 4
+#define SS_MAX_PHASE_TAPS 4
+struct GPhases {
+    int32_t count;
+    int32_t out_oy[SS_MAX_PHASES], out_ox[SS_MAX_PHASES], ntaps[SS_MAX_PHASES], Ktot[SS_MAX_PHASES];
+    int16_t tdy[SS_MAX_PHASES][SS_MAX_PHASE_TAPS], tdx[SS_MAX_PHASES][SS_MAX_PHASE_TAPS];
+    const unsigned short* planes[SS_MAX_PHASES];
+    int64_t plane_elems[SS_MAX_PHASES];
+};
+
 // C[batch][split][m][n] = sum_k A[batch][k][m] * B[batch][k][n] on K-major fp16 (h, l) planes (gemm_tn_x3h.hip)
 struct TNParams {
     const unsigned short* a;      // [2 planes][batch][K][lda]   values a * 2^(14 - ea), ea = exponent(max|.| slot) + bound_a
@@ -264,7 +278,7 @@ bool ss_x6p_wide_ok(long M, int N, int K, int nbatch);
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
 
 // kernel-selection switches: ONE explicit table, set through ss_config_set (config.hip); SS_* environment variables give the initial values
-struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products, c1_mfma, x6p_pp, wino_save, gemm_ilv, gemm_cus; };
+struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products, c1_mfma, x6p_pp, wino_save, gemm_ilv, gemm_cus, gconv_phases; };
 const SsTuning& ss_tuning();
 // ss_prof_*: brackets the kernel launched inside this scope with HIP events on its stream when profiling is enabled (config.hip).
 // flops = EXECUTED matrix-instruction FLOPs of the launch (all piece products), bytes = algorithmic HBM bytes (0 if not stated)
@@ -325,7 +339,8 @@ size_t ss_gconv_x6_planes_bytes(const GConvParams& p);      // [3][nbatch][npad(
 int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s);
 bool ss_gconv_x6v2_ok(const GConvParams& p);
 int ss_gconv_x6v2_stats_chunks(const GConvParams& p);        // chunks per sample of GConvParams::stats gconv_x6v2 writes (0: none)
-int ss_launch_gconv_x6v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s);
+int ss_launch_gconv_x6_multi(const GConvParams* ps, const unsigned short* const* planes, int count, hipStream_t s);
+int ss_launch_gconv_x6v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s, const GPhases* ph = nullptr);
 int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipStream_t s);
 bool ss_wgrad_x6_ok(const WGradParams& p);
 int ss_launch_wgrad_x6_partials(const WGradParams& p, hipStream_t s);

@@ -477,6 +477,49 @@ int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStre
     return use_mfma(algo, p) ? ss_launch_gconv_mfma(p, s) : ss_launch_gconv_direct(p, s);
 }
 
+// the sub-pixel phases of one data gradient (conv_bwd_data): one launch when all of them take the x3h gather kernels and line up
+int run_gconv_phases(int algo, const GConvParams* ps, int count, void* ws, size_t ws_bytes, hipStream_t s, WCache* wc) {
+    bool multi = count >= 2 && algo != SS_ALGO_DIRECT && algo != SS_ALGO_MFMA && ws;
+    size_t need = 0;
+    for (int i = 0; i < count && multi; ++i) {
+        const GConvParams& q = ps[i];
+        if (ss_conv_out1_ok(q) || ss_conv_in1_ok(q) || tconv_takes(algo, q) || gconv_two_stage(algo, q) || !use_x6(algo, q) || q.stats ||
+            q.ntaps > SS_MAX_PHASE_TAPS || !q.h_amax || !q.h_amax2 || q.OHc != ps[0].OHc || q.OWc != ps[0].OWc)
+            multi = false;
+        if (q.dtype != SS_DTYPE_F32 && !(ss_gconv_x6v2_ok(q) || ss_gconv_x6_typed_ok(q))) multi = false;
+        need += ss_gconv_x6_planes_bytes(q);
+    }
+    if (multi && need <= ws_bytes) {
+        const unsigned short* planes[SS_MAX_PHASES];
+        char* wp = (char*)ws;
+        for (int i = 0; i < count; ++i) {
+            bool fill;
+            unsigned short* pl = (unsigned short*)ss_wc_region(wc, ss_wc_tag(SS_WC_X6_PLANES, x6_planes_detail(ps[i], 1)), ss_gconv_x6_planes_bytes(ps[i]), wp, &fill);
+            if (fill) {
+                const int rc = ss_launch_wprep_x6(ps[i], pl, s);
+                if (rc != SS_OK) return rc;
+            }
+            planes[i] = pl;
+            wp += ss_gconv_x6_planes_bytes(ps[i]);
+        }
+        if (wc && wc->fill_only) return SS_OK;
+        const int rc = ss_launch_gconv_x6_multi(ps, planes, count, s);
+        if (rc != SS_ERR_UNSUPPORTED) return rc;          // launched (or failed for real); UNSUPPORTED: nothing launched, planes stay valid in the cache / workspace
+        if (!wc) {          // the workspace copies are laid out for the joint launch: per-phase launches refill their own
+            for (int i = 0; i < count; ++i) {
+                const int rc1 = run_gconv(algo, ps[i], ws, ws_bytes, s, wc, 1);
+                if (rc1 != SS_OK) return rc1;
+            }
+            return SS_OK;
+        }
+    }
+    for (int i = 0; i < count; ++i) {
+        const int rc = run_gconv(algo, ps[i], ws, ws_bytes, s, wc, 1);
+        if (rc != SS_OK) return rc;
+    }
+    return SS_OK;
+}
+
 GConvParams fwd_params(const ConvProb& c, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
                        int accumulate) {
     GConvParams p{};
@@ -660,6 +703,11 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
 
     p.out = dx; p.OH = c.ih; p.OW = c.iw; p.out_cs = c.in_cs; p.accumulate = accumulate;
     p.out_s = c.s; p.in_oy = 0; p.in_ox = 0;
+    // the sub-pixel phases (output pixels of one residue class mod s each: their own taps, the same dy)
+    GConvParams phs[SS_MAX_PHASES];
+    int nph = 0;
+    bool collect = c.s * c.s <= SS_MAX_PHASES && ss_tuning().gconv_phases;
+    int rc_all = SS_OK;
     for (int ry = 0; ry < c.s; ++ry)
         for (int rx = 0; rx < c.s; ++rx) {
             p.OHc = (c.ih - ry + c.s - 1) / c.s;
@@ -677,10 +725,16 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
                     t.woff = (a * c.kw + b) * c.cin * c.cout;
                 }
             }
+            if (collect && nph < SS_MAX_PHASES) { phs[nph++] = p; continue; }
             int rc = run_gconv(algo, p, gws, gws_bytes, s, c.wc, 1);
             if (rc != SS_OK) return rc;
         }
-    return SS_OK;
+    if (nph > 0) {
+        // ONE launch for all phases where they line up (same class grid, the x3h gather kernels, <= 4 taps each): the phases of a tile
+        // run side by side on one XCD and share its rows of dy in that L2 (ss_launch_gconv_x6_multi); otherwise one launch per phase
+        rc_all = run_gconv_phases(algo, phs, nph, gws, gws_bytes, s, c.wc);
+    }
+    return rc_all;
 }
 
 bool wgrad_two_stage(const ConvProb& c, int algo) {

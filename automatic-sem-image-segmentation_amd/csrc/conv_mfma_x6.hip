@@ -52,7 +52,7 @@ __device__ __forceinline__ void xw_st4(__bf16* q, f32x4 v) { *(xw_bf16x4*)q = __
 // (ss_tuning wino16_products), as conv_mfma_x6v2.hip.
 template <int BM, int BN, bool H, typename T = float, int NPROD = 3>
 __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems,
-                                                          int Npad, int Ktot) {
+                                                          int Npad, int Ktot, GPhases ph) {
     constexpr bool S16 = !std::is_same<T, float>::value;
     static_assert(!S16 || (H && NPROD <= 2), "16-bit storage: fp16 matrix cores, one or two products");
     constexpr int NP = H ? 2 : 3;        // operand planes
@@ -74,9 +74,20 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const long M = (long)p.N * p.OHc * p.OWc;
     const int gridN = (p.Cout + BN - 1) / BN;
     int tile;
+    // per-phase fields (GPhases: several problems in one launch) or the plain problem's
+    int P_ntaps = p.ntaps, P_oy = p.out_oy, P_ox = p.out_ox, prob = -1;
     {   // XCD-aware order (speed only): contiguous chunk of the tile space per XCD, N fastest
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, slot = bid >> 3;
+        int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7;
+        int slot = bid >> 3;
+        if (ph.count > 1) {          // (the launcher makes the per-problem grid a multiple of 8)
+            prob = slot % ph.count;
+            slot /= ph.count;
+            nwg /= ph.count;
+            P_ntaps = ph.ntaps[prob]; P_oy = ph.out_oy[prob]; P_ox = ph.out_ox[prob];
+            bpl = ph.planes[prob]; plane_elems = ph.plane_elems[prob]; Ktot = ph.Ktot[prob];
+        }
         const int q = nwg >> 3, r = nwg & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const long m0 = (long)(tile / gridN) * BM;
     const int n0 = (tile % gridN) * BN;
     const int nchunks = Ktot / XK;
-    const int Cq = Ktot / p.ntaps;       // reduction channels per tap, padded to a multiple of 32
+    const int Cq = Ktot / P_ntaps;       // reduction channels per tap, padded to a multiple of 32
     const bool ragged = Cq != p.Cin || (p.in_cs & 3) != 0 || (((uintptr_t)p.in) & 15) != 0;
     float a_scale = 1.f, out_scale = 1.f;
     if constexpr (H) {
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     }
 
     {   // 32-bit pixel decode (ss_gconv_x6_ok: M < 2^31), one division pair per tile row; the offset table divides nothing
-        int* rowc = offtab + BM * p.ntaps;      // [3][BM]
+        int* rowc = offtab + BM * P_ntaps;      // [3][BM]
         if (tid < BM) {
             const unsigned m = (unsigned)m0 + (unsigned)tid;
             int v = -1, rn = -1, ry = 0, rx = 0;
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
                 const int xc = (int)(m - r * (unsigned)p.OWc);
                 const unsigned n = r / (unsigned)p.OHc;
                 const int yc = (int)(r - n * (unsigned)p.OHc);
-                const int oy = yc * p.out_s + p.out_oy, ox = xc * p.out_s + p.out_ox;
+                const int oy = yc * p.out_s + P_oy, ox = xc * p.out_s + P_ox;
                 if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) v = ((int)n * p.OH + oy) * p.OW + ox;
                 rn = (int)n;
                 ry = yc * p.in_s + p.in_oy;
@@ -122,14 +133,14 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         constexpr int TSTEP = 256 / BM;
         const int row = tid % BM;
         const int rn = rowc[row], ry = rowc[BM + row], rx = rowc[2 * BM + row];
-        for (int t = tid / BM; t < p.ntaps; t += TSTEP) {
+        for (int t = tid / BM; t < P_ntaps; t += TSTEP) {
             int off = -1;
             if (rn >= 0) {
-                const int iy = ss_map_index(ry + p.taps[t].dy, p.IH, p.reflect);
-                const int ix = ss_map_index(rx + p.taps[t].dx, p.IW, p.reflect);
+                const int iy = ss_map_index(ry + (prob >= 0 ? (int)ph.tdy[prob][t] : (int)p.taps[t].dy), p.IH, p.reflect);
+                const int ix = ss_map_index(rx + (prob >= 0 ? (int)ph.tdx[prob][t] : (int)p.taps[t].dx), p.IW, p.reflect);
                 if (iy >= 0 && ix >= 0) off = ((rn * p.IH + iy) * p.IW + ix) * p.in_cs;
             }
-            offtab[row * p.ntaps + t] = off;
+            offtab[row * P_ntaps + t] = off;
         }
     }
     __syncthreads();
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
             const T* abase = g_in + ci0 + c4a * 4;
 #pragma unroll
             for (int j = 0; j < AU; ++j) {
-                const int off = offtab[(arow + 32 * j) * p.ntaps + t];
+                const int off = offtab[(arow + 32 * j) * P_ntaps + t];
                 const T* pa = off < 0 ? (const T*)ss_zero_page16 : abase + off;      // masked taps read zeros
                 ra[S][j] = xw_ld4(pa);
             }
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
             const int nin = p.Cin - ci;                // channels of this unit that exist
 #pragma unroll
             for (int j = 0; j < AU; ++j) {
-                const int off = offtab[(arow + 32 * j) * p.ntaps + t];
+                const int off = offtab[(arow + 32 * j) * P_ntaps + t];
                 const bool ok = off >= 0 && nin > 0;
                 const float* ptr = ok ? (const float*)g_in + (off + ci) : (const float*)ss_zero_page16;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -693,11 +704,16 @@ int launch_wgrad_x6(const WGradParams& p, hipStream_t s) {
 }
 
 template <int BM, int BN, bool H, typename T = float, int NPROD = 3>
-int launch_x6h(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
+int launch_x6h(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s, const GPhases* ph) {
     const long M = (long)p.N * p.OHc * p.OWc;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
-    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN) * nb));
-    const size_t smem = (size_t)(H ? 2 : 3) * (BM + BN) * XLD * sizeof(unsigned short) + (size_t)BM * sizeof(int) * (4 + p.ntaps);
+    const int nph = ph && ph->count > 1 ? ph->count : 1;
+    const long nwg1 = ((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN) * nb;
+    if (nph > 1 && nwg1 % 8) return SS_ERR_UNSUPPORTED;          // several problems per launch: whole XCD rounds per problem
+    dim3 grid((unsigned)(nwg1 * nph));
+    int mt = p.ntaps, taps_all = p.ntaps;
+    if (nph > 1) { taps_all = 0; for (int i = 0; i < nph; ++i) { taps_all += ph->ntaps[i]; mt = ph->ntaps[i] > mt ? ph->ntaps[i] : mt; } }
+    const size_t smem = (size_t)(H ? 2 : 3) * (BM + BN) * XLD * sizeof(unsigned short) + (size_t)BM * sizeof(int) * (4 + mt);
     // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
     static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)gconv_x6_kernel<BM, BN, H, T, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -708,22 +724,24 @@ int launch_x6h(const GConvParams& p, const unsigned short* planes, long plane_el
     if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_x6<%d,%d,%d> M%ld N%d K%dx%d s%d b%d", BM, BN, (int)H, M, p.Cout, p.ntaps, p.Cin, p.in_s, nb);
     else if (std::is_same<T, float>::value) snprintf(pname, sizeof(pname), "gconv_x6_kernel<%d,%d,%s>", BM, BN, H ? "true" : "false");
     else snprintf(pname, sizeof(pname), "gconv_x6_kernel<%d,%d,16-bit,%d>", BM, BN, NPROD);
-    SsProfScope prof(pname, 2.0 * M * p.Cout * p.ntaps * p.Cin * nb * (std::is_same<T, float>::value ? (H ? 3 : 6) : NPROD),
-                     (double)sizeof(T) * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout) + 4.0 * nb * p.ntaps * p.Cin * p.Cout, s);
-    hipLaunchKernelGGL((gconv_x6_kernel<BM, BN, H, T, NPROD>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot);
+    SsProfScope prof(pname, 2.0 * M * p.Cout * taps_all * p.Cin * nb * (std::is_same<T, float>::value ? (H ? 3 : 6) : NPROD),
+                     (double)sizeof(T) * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout * nph) + 4.0 * nb * taps_all * p.Cin * p.Cout, s);
+    GPhases phv{};
+    if (nph > 1) phv = *ph;
+    hipLaunchKernelGGL((gconv_x6_kernel<BM, BN, H, T, NPROD>), grid, dim3(256), smem, s, p, planes, plane_elems, Npad, Ktot, phv);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 template <int BM, int BN>
-int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
+int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s, const GPhases* ph) {
     if (p.dtype != SS_DTYPE_F32) {          // 16-bit stored activations: typed loaders, one fp16 operand plane (whole aligned 32-channel chunks, x3h)
         if (!ss_gconv_x6_typed_ok(p)) { ss_set_error("gconv_x6: this 16-bit problem has no typed loader"); return SS_ERR_UNSUPPORTED; }
         const bool two = ss_tuning().wino16_products == 3;
         if (p.dtype == SS_DTYPE_F16)
-            return two ? launch_x6h<BM, BN, true, _Float16, 2>(p, planes, plane_elems, Npad, Ktot, s) : launch_x6h<BM, BN, true, _Float16, 1>(p, planes, plane_elems, Npad, Ktot, s);
-        return two ? launch_x6h<BM, BN, true, __bf16, 2>(p, planes, plane_elems, Npad, Ktot, s) : launch_x6h<BM, BN, true, __bf16, 1>(p, planes, plane_elems, Npad, Ktot, s);
+            return two ? launch_x6h<BM, BN, true, _Float16, 2>(p, planes, plane_elems, Npad, Ktot, s, ph) : launch_x6h<BM, BN, true, _Float16, 1>(p, planes, plane_elems, Npad, Ktot, s, ph);
+        return two ? launch_x6h<BM, BN, true, __bf16, 2>(p, planes, plane_elems, Npad, Ktot, s, ph) : launch_x6h<BM, BN, true, __bf16, 1>(p, planes, plane_elems, Npad, Ktot, s, ph);
     }
-    return p.h_amax ? launch_x6h<BM, BN, true>(p, planes, plane_elems, Npad, Ktot, s) : launch_x6h<BM, BN, false>(p, planes, plane_elems, Npad, Ktot, s);
+    return p.h_amax ? launch_x6h<BM, BN, true>(p, planes, plane_elems, Npad, Ktot, s, ph) : launch_x6h<BM, BN, false>(p, planes, plane_elems, Npad, Ktot, s, ph);
 }
 
 }  // namespace
@@ -758,6 +776,38 @@ int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t
     return SS_OK;
 }
 
+// The same for `count` problems that differ in the output phase, the taps and the weight planes only (GPhases, common.h): ONE launch.
+// SS_ERR_UNSUPPORTED (nothing launched) when the problems do not line up -- the caller then launches them one by one.
+int ss_launch_gconv_x6_multi(const GConvParams* ps, const unsigned short* const* planes, int count, hipStream_t s) {
+    if (count < 2 || count > SS_MAX_PHASES) return SS_ERR_UNSUPPORTED;
+    const GConvParams& p0 = ps[0];
+    GPhases ph{};
+    ph.count = count;
+    const int nb = p0.nbatch > 1 ? p0.nbatch : 1;
+    const int Npad = ss_x6_npad(p0.Cout), Cq = (p0.Cin + 31) / 32 * 32;
+    const bool v2 = ss_gconv_x6v2_ok(p0);
+    for (int i = 0; i < count; ++i) {
+        const GConvParams& q = ps[i];
+        if (!ss_gconv_x6_ok(q) || q.ntaps > SS_MAX_PHASE_TAPS || q.OHc != p0.OHc || q.OWc != p0.OWc || q.N != p0.N || q.Cin != p0.Cin || q.Cout != p0.Cout ||
+            q.in != p0.in || q.out != p0.out || q.in_s != p0.in_s || q.out_s != p0.out_s || q.in_oy != p0.in_oy || q.in_ox != p0.in_ox || q.nbatch != p0.nbatch ||
+            q.h_amax != p0.h_amax || q.h_amax2 != p0.h_amax2 || q.accumulate != p0.accumulate || q.act != p0.act || q.dtype != p0.dtype || q.stats ||
+            ss_gconv_x6v2_ok(q) != v2)
+            return SS_ERR_UNSUPPORTED;
+        ph.out_oy[i] = q.out_oy; ph.out_ox[i] = q.out_ox; ph.ntaps[i] = q.ntaps; ph.Ktot[i] = q.ntaps * Cq;
+        for (int t = 0; t < q.ntaps; ++t) { ph.tdy[i][t] = q.taps[t].dy; ph.tdx[i][t] = q.taps[t].dx; }
+        ph.planes[i] = planes[i];
+        ph.plane_elems[i] = (long)nb * Npad * ph.Ktot[i];
+    }
+    const long M = (long)p0.N * p0.OHc * p0.OWc;
+    if (M == 0) return SS_OK;
+    if (v2) return ss_launch_gconv_x6v2(p0, planes[0], ph.plane_elems[0], Npad, ph.Ktot[0], s, &ph);
+    const long want = 200;
+    auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p0.Cout + bn - 1) / bn) * nb; };
+    if (p0.Cout > 64 && nblk(128, 128) >= want) return launch_x6<128, 128>(p0, planes[0], ph.plane_elems[0], Npad, ph.Ktot[0], s, &ph);
+    if (nblk(128, 64) >= want) return launch_x6<128, 64>(p0, planes[0], ph.plane_elems[0], Npad, ph.Ktot[0], s, &ph);
+    return launch_x6<64, 64>(p0, planes[0], ph.plane_elems[0], Npad, ph.Ktot[0], s, &ph);
+}
+
 int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipStream_t s) {
     const long M = (long)p.N * p.OHc * p.OWc;
     if (M == 0) return SS_OK;
@@ -765,13 +815,14 @@ int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipSt
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * ((p.Cin + 31) / 32 * 32);
     const long plane_elems = (long)nb * Npad * Ktot;
+    const GPhases* ph = nullptr;
     if (ss_gconv_x6v2_ok(p)) return ss_launch_gconv_x6v2(p, planes, plane_elems, Npad, Ktot, s);
     // tile choice: the largest tile that still yields >= ~200 workgroups (small grids at per-GPU batch 1 want more, smaller ones)
     const long want = 200;      // swept at per-GPU batch 1 / 2 (200 / 600 / 1200): 200 is the fastest
     auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * nb; };
-    if (p.Cout > 64 && nblk(128, 128) >= want) return launch_x6<128, 128>(p, planes, plane_elems, Npad, Ktot, s);
-    if (nblk(128, 64) >= want) return launch_x6<128, 64>(p, planes, plane_elems, Npad, Ktot, s);
-    return launch_x6<64, 64>(p, planes, plane_elems, Npad, Ktot, s);
+    if (p.Cout > 64 && nblk(128, 128) >= want) return launch_x6<128, 128>(p, planes, plane_elems, Npad, Ktot, s, ph);
+    if (nblk(128, 64) >= want) return launch_x6<128, 64>(p, planes, plane_elems, Npad, Ktot, s, ph);
+    return launch_x6<64, 64>(p, planes, plane_elems, Npad, Ktot, s, ph);
 }
 
 bool ss_wgrad_x6_ok(const WGradParams& p) {

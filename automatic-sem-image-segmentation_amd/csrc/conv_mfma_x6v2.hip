@@ -60,7 +60,7 @@ __device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l)
 // weight), NPROD = 1 with the leading weight piece only (ss_tuning wino16_products); half the gathered bytes, a third of the split work.
 template <int VBN, typename T, int NPROD>
 __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const unsigned short* __restrict__ bpl, long plane_elems, int Npad,
-                                                            int Ktot, int ilv_flag) {
+                                                            int Ktot, int ilv_flag, GPhases ph) {
     constexpr bool F32 = std::is_same<T, float>::value;
     static_assert(F32 ? NPROD == 3 : NPROD <= 2, "fp32 storage: three products; 16-bit storage: one or two");
     constexpr int VB_PLANE = VG<VBN>::B_PLANE, VSTAGE = VG<VBN>::STAGE, TN = VG<VBN>::TN, NB = VG<VBN>::NB;
@@ -76,9 +76,20 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
     const long M = (long)p.N * p.OHc * p.OWc;
     const int gridN = (p.Cout + VBN - 1) / VBN;
     int tile;
+    // per-phase fields (GPhases: several problems in one launch) or the plain problem's
+    int P_ntaps = p.ntaps, P_oy = p.out_oy, P_ox = p.out_ox, prob = -1;
     {   // XCD-aware order (speed only): contiguous chunk of the tile space per XCD, N fastest
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, slot = bid >> 3;
+        int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7;
+        int slot = bid >> 3;
+        if (ph.count > 1) {          // (the launcher makes the per-problem grid a multiple of 8)
+            prob = slot % ph.count;
+            slot /= ph.count;
+            nwg /= ph.count;
+            P_ntaps = ph.ntaps[prob]; P_oy = ph.out_oy[prob]; P_ox = ph.out_ox[prob];
+            bpl = ph.planes[prob]; plane_elems = ph.plane_elems[prob]; Ktot = ph.Ktot[prob];
+        }
         const int q = nwg >> 3, r = nwg & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
@@ -90,13 +101,13 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
     const long m0 = (long)(tile / gridN) * VBM;
     const int n0 = (tile % gridN) * VBN;
     const int nchunks = Ktot / VK;
-    const int Cq = Ktot / p.ntaps;       // = Cin (a multiple of 32: launcher)
+    const int Cq = Ktot / P_ntaps;       // = Cin (a multiple of 32: launcher)
     const int ea = ss_amax_exp(__uint_as_float(ss_amax_load(p.h_amax, p.amax_stripes))), ew = ss_amax_exp(__uint_as_float(p.h_amax2[0]));
     const float a_scale = ldexpf(1.f, 14 - ea);
     const float out_scale = ldexpf(1.f, ea - 14 + ew - 14);
 
     {   // pixel decode (32-bit: M < 2^31) and the per-row tap offsets, as in gconv_x6_kernel
-        int* rowc = offtab + VBM * p.ntaps;      // [3][VBM]
+        int* rowc = offtab + VBM * P_ntaps;      // [3][VBM]
         if (tid < VBM) {
             const unsigned m = (unsigned)m0 + (unsigned)tid;
             int v = -1, rn = -1, ry = 0, rx = 0;
@@ -105,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
                 const int xc = (int)(m - r * (unsigned)p.OWc);
                 const unsigned n = r / (unsigned)p.OHc;
                 const int yc = (int)(r - n * (unsigned)p.OHc);
-                const int oy = yc * p.out_s + p.out_oy, ox = xc * p.out_s + p.out_ox;
+                const int oy = yc * p.out_s + P_oy, ox = xc * p.out_s + P_ox;
                 if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) v = ((int)n * p.OH + oy) * p.OW + ox;
                 rn = (int)n;
                 ry = yc * p.in_s + p.in_oy;
@@ -119,14 +130,14 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         __syncthreads();
         const int row = tid % VBM;
         const int rn = rowc[row], ry = rowc[VBM + row], rx = rowc[2 * VBM + row];
-        for (int t = tid / VBM; t < p.ntaps; t += 512 / VBM) {
+        for (int t = tid / VBM; t < P_ntaps; t += 512 / VBM) {
             int off = -1;
             if (rn >= 0) {
-                const int iy = ss_map_index(ry + p.taps[t].dy, p.IH, p.reflect);
-                const int ix = ss_map_index(rx + p.taps[t].dx, p.IW, p.reflect);
+                const int iy = ss_map_index(ry + (prob >= 0 ? (int)ph.tdy[prob][t] : (int)p.taps[t].dy), p.IH, p.reflect);
+                const int ix = ss_map_index(rx + (prob >= 0 ? (int)ph.tdx[prob][t] : (int)p.taps[t].dx), p.IW, p.reflect);
                 if (iy >= 0 && ix >= 0) off = ((rn * p.IH + iy) * p.IW + ix) * p.in_cs;
             }
-            offtab[row * p.ntaps + t] = off;
+            offtab[row * P_ntaps + t] = off;
         }
     }
     __syncthreads();
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(512, 1) void gconv_x6v2_kernel(GConvParams p, const
         const T* abase = g_in + (k0 - t * Cq) + c4a * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int off = offtab[(arow + 64 * j) * p.ntaps + t];
+            const int off = offtab[(arow + 64 * j) * P_ntaps + t];
             const T* pa = off < 0 ? zpage : abase + off;
             ra[S][j] = *(const typename V2Raw<T>::type*)pa;
         }
@@ -407,7 +418,7 @@ int ss_gconv_x6v2_stats_chunks(const GConvParams& p) {
 }
 
 template <int VBN, typename T, int NPROD>
-static int launch_v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
+static int launch_v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s, const GPhases* ph) {
     const long M = (long)p.N * p.OHc * p.OWc;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     static const bool attr_set = [] {
@@ -415,32 +426,41 @@ static int launch_v2(const GConvParams& p, const unsigned short* planes, long pl
         return true;
     }();
     (void)attr_set;
-    const long nwg = ((M + VBM - 1) / VBM) * ((p.Cout + VBN - 1) / VBN) * nb;
-    const size_t smem = (size_t)2 * VG<VBN>::STAGE + (size_t)VBM * sizeof(int) * (4 + p.ntaps);
+    const int nph = ph && ph->count > 1 ? ph->count : 1;
+    const long nwg1 = ((M + VBM - 1) / VBM) * ((p.Cout + VBN - 1) / VBN) * nb;
+    if (nph > 1 && (nwg1 % 8 || p.stats)) return SS_ERR_UNSUPPORTED;          // several problems per launch: whole XCD rounds per problem
+    const long nwg = nwg1 * nph;
+    int mt = p.ntaps;
+    for (int i = 0; i < nph && ph; ++i) mt = ph->ntaps[i] > mt ? ph->ntaps[i] : mt;
+    const size_t smem = (size_t)2 * VG<VBN>::STAGE + (size_t)VBM * sizeof(int) * (4 + mt);
     char pname[64];
     if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_x6v2<%d> M%ld N%d K%dx%d s%d b%d", VBN, M, p.Cout, p.ntaps, p.Cin, p.in_s, nb);
     else if (std::is_same<T, float>::value) snprintf(pname, sizeof(pname), "gconv_x6v2_kernel<%d>", VBN);
     else snprintf(pname, sizeof(pname), "gconv_x6v2_kernel<%d,16-bit,%d>", VBN, NPROD);
-    SsProfScope prof(pname, 2.0 * M * p.Cout * p.ntaps * p.Cin * nb * NPROD,
-                     (double)sizeof(T) * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout) + 4.0 * nb * p.ntaps * p.Cin * p.Cout, s);
+    int taps_all = p.ntaps;
+    if (nph > 1) { taps_all = 0; for (int i = 0; i < nph; ++i) taps_all += ph->ntaps[i]; }
+    SsProfScope prof(pname, 2.0 * M * p.Cout * taps_all * p.Cin * nb * NPROD,
+                     (double)sizeof(T) * nb * ((double)p.N * p.IH * p.IW * p.Cin + (double)M * p.Cout * nph) + 4.0 * nb * taps_all * p.Cin * p.Cout, s);
     if (p.stats && (ss_gconv_x6v2_stats_chunks(p) != p.stats_chunks || (((uintptr_t)p.out) & 15))) {
         ss_set_error("gconv_x6v2: output statistics requested for a problem whose tiles do not line up with the samples");
         return SS_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL((gconv_x6v2_kernel<VBN, T, NPROD>), dim3((unsigned)nwg), dim3(512), smem, s, p, planes, plane_elems, Npad, Ktot, ss_tuning().gemm_ilv);
+    GPhases phv{};
+    if (nph > 1) phv = *ph;
+    hipLaunchKernelGGL((gconv_x6v2_kernel<VBN, T, NPROD>), dim3((unsigned)nwg), dim3(512), smem, s, p, planes, plane_elems, Npad, Ktot, ss_tuning().gemm_ilv, phv);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
 template <typename T, int NPROD>
-static int launch_v2_bn(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
-    return v2_bn(p) == 128 ? launch_v2<128, T, NPROD>(p, planes, plane_elems, Npad, Ktot, s) : launch_v2<64, T, NPROD>(p, planes, plane_elems, Npad, Ktot, s);
+static int launch_v2_bn(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s, const GPhases* ph) {
+    return v2_bn(p) == 128 ? launch_v2<128, T, NPROD>(p, planes, plane_elems, Npad, Ktot, s, ph) : launch_v2<64, T, NPROD>(p, planes, plane_elems, Npad, Ktot, s, ph);
 }
-int ss_launch_gconv_x6v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s) {
-    if (p.dtype == SS_DTYPE_F32) return launch_v2_bn<float, 3>(p, planes, plane_elems, Npad, Ktot, s);
+int ss_launch_gconv_x6v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s, const GPhases* ph) {
+    if (p.dtype == SS_DTYPE_F32) return launch_v2_bn<float, 3>(p, planes, plane_elems, Npad, Ktot, s, ph);
     if (p.stats) { ss_set_error("gconv_x6v2: output statistics are reported for fp32 storage only"); return SS_ERR_UNSUPPORTED; }
     const bool two = ss_tuning().wino16_products == 3;          // "fp32-grade arithmetic, only the storage is 16-bit"
-    if (p.dtype == SS_DTYPE_F16) return two ? launch_v2_bn<_Float16, 2>(p, planes, plane_elems, Npad, Ktot, s) : launch_v2_bn<_Float16, 1>(p, planes, plane_elems, Npad, Ktot, s);
-    if (p.dtype == SS_DTYPE_BF16) return two ? launch_v2_bn<__bf16, 2>(p, planes, plane_elems, Npad, Ktot, s) : launch_v2_bn<__bf16, 1>(p, planes, plane_elems, Npad, Ktot, s);
+    if (p.dtype == SS_DTYPE_F16) return two ? launch_v2_bn<_Float16, 2>(p, planes, plane_elems, Npad, Ktot, s, ph) : launch_v2_bn<_Float16, 1>(p, planes, plane_elems, Npad, Ktot, s, ph);
+    if (p.dtype == SS_DTYPE_BF16) return two ? launch_v2_bn<__bf16, 2>(p, planes, plane_elems, Npad, Ktot, s, ph) : launch_v2_bn<__bf16, 1>(p, planes, plane_elems, Npad, Ktot, s, ph);
     return SS_ERR_UNSUPPORTED;
 }

@@ -567,3 +567,60 @@ def test_winograd_weight_gradient_from_the_forward_passs_saved_operand(shape):
     assert e_off <= 2e-5 and e_on <= 2e-5, (e_off, e_on)
     assert e_on <= 3.0 * e_off + 1e-7, (e_on, e_off)
     assert d_on_off <= 2e-5, d_on_off
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 40, 40, 256, 256), (5, 28, 28, 64, 320), (1, 64, 64, 256, 128), (3, 36, 36, 128, 192)],
+                         ids=["ragged_M", "K64_N320", "n1", "N192"])
+def test_plane_gemm_schedules_are_bit_identical(shape):
+    """The x3h Winograd GEMMs exist in several SCHEDULES of the same arithmetic -- fragment reads interleaved with the MFMAs or in
+    bursts (gemm_ilv), the opt-in ping-pong kernels (x6p_pp = 1 / 2 / 3), the persistent grid on a CU subset (gemm_cus) -- with the same
+    MFMA order per accumulator: forward output, data gradient and weight gradient must not change by one bit (ragged M, N not a
+    multiple of 128, K = 64 = two chunks, one sample)."""
+    E, LY, L = _mods()
+    n, h, w, cin, cout = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n * 100 + cin)
+    wt = torch.empty((3, 3, cin, cout)).uniform_(-0.05, 0.05, generator=g)
+    xt = torch.randn((n, h, w, cin), generator=g)
+    dyt = torch.randn((n, h, w, cout), generator=g)
+
+    def run(**cfg):
+        with L.config(x6p=2, **cfg):
+            arena = E.ParamArena(dev)
+            conv = LY.Conv2D(arena, "c", 3, cin, cout, padding=("reflect", 1) if h % 8 == 0 else "same", use_bias=False)
+            arena.materialize()
+            arena["c/kernel"].copy_(wt)
+            tape = E.Tape()
+            x = E.Act(xt.to(dev), requires_grad=True)
+            y = conv(tape, x)
+            gt, _ = y.grad_target()
+            gt.t.copy_(dyt.to(dev))
+            arena.zero_grad()
+            tape.backward()
+            torch.cuda.synchronize()
+            return y.dense().clone(), x.get_grad().dense().clone(), arena.grad("c/kernel").clone()
+
+    base = run(gemm_ilv=0, x6p_pp=0)
+    for cfg in (dict(gemm_ilv=1), dict(x6p_pp=1), dict(x6p_pp=2), dict(x6p_pp=3), dict(gemm_cus=64), dict(gemm_ilv=1, gemm_cus=8)):
+        got = run(**cfg)
+        for a, b, what in zip(base, got, ("y", "dx", "dw")):
+            assert torch.equal(a, b), (cfg, what, float((a - b).abs().max()))
+
+
+@pytest.mark.gpu
+def test_probe_mfma_reports_a_real_data_ceiling_below_the_zero_operand_rate():
+    """ss_probe_mfma (bench.py roofline.real_data_ceiling): a register-only fp16 MFMA stream; on random operands the chip clocks lower
+    than on zeros (power budget), both within the physical range of the device."""
+    import ctypes
+    E, LY, L = _mods()
+    lib = L.load()
+    sc = torch.empty(65600, dtype=torch.uint8, device="cuda:0")
+    out = {}
+    for rnd in (0, 1):
+        tf, mhz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        assert lib.ss_probe_mfma(rnd, sc.data_ptr(), sc.numel(), None, ctypes.byref(tf), ctypes.byref(mhz)) == 0
+        out[rnd] = (tf.value, mhz.value)
+    assert 500.0 < out[1][0] <= out[0][0] * 1.02 and out[0][0] < 2700.0, out
+    assert 800.0 < out[1][1] < 2600.0 and 800.0 < out[0][1] < 2600.0, out
+    assert lib.ss_probe_mfma(1, sc.data_ptr(), 100, None, ctypes.byref(tf), ctypes.byref(mhz)) != 0          # scratch too small: refused

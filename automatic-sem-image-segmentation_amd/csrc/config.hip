@@ -45,7 +45,7 @@ const Key KEYS[] = {
     {"c1_mfma", &SsTuning::c1_mfma, "one-channel stem / head layers (1 -> C, C -> 1, full resolution) on the fp16 matrix cores with the x3h arithmetic; 0: LDS-tiled VALU kernels"},
     {"x6p_pp", &SsTuning::x6p_pp, "x3h Winograd GEMMs: ping-pong schedule (the two waves of a SIMD half a K step apart: one multiplies while the other loads); 0: one-phase kernel (same results bit for bit)"},
     {"wino_save", &SsTuning::wino_save, "Winograd x3h forward keeps its transformed input planes for the weight gradient when the caller provides ss_conv_desc::saved_operand (ss_conv2d_saved_operand_bytes > 0); 0: the weight gradient transforms x again"},
-    {"gemm_ilv", &SsTuning::gemm_ilv, "pre-split-plane x3h GEMMs: fragment reads issued between the MFMAs of a half step instead of in a burst in front of them (bit-identical); 0: burst form"},
+    {"gemm_ilv", &SsTuning::gemm_ilv, "gemm_x6p / gconv_x6v2: fragment reads issued between the MFMAs of a half step instead of in a burst in front of them (bit-identical); 0: burst form.  (gemm_tn_x3h keeps the burst form: measured slower interleaved)"},
     {"gemm_cus", &SsTuning::gemm_cus, "persistent pre-split-plane GEMMs: workgroups (= CUs occupied; a multiple of 8) per launch, 0 = all CUs.  Fewer leave whole CUs to the kernels of the other HIP stream (a GEMM workgroup takes a CU's whole LDS: nothing else starts beside it)"},
     {"gconv_phases", &SsTuning::gconv_phases, "OPT-IN (default 0; measured slower or equal: the phases' weight planes then compete for one L2): stride-2 data gradients / transposed convolutions with the four sub-pixel phases in ONE launch of the x3h gather kernels (same results bit for bit); 0: one launch per phase"},
     {"wgrad_tn", &SsTuning::wgrad_tn, "Winograd weight gradient on pre-split K-major fp16 planes with transposing LDS reads (gemm_tn_x3h.hip); 0: in-kernel split"},

@@ -37,7 +37,10 @@ __device__ __forceinline__ s16x4 tr4(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
-template <bool ILV>
+// ILV: the transposing fragment reads between the MFMAs instead of in front of them (as gemm_x6p.hip) -- measured SLOWER here (16 reads per
+// half step: 378 vs 333 us at n = 16, 215 vs 194 at n = 8, tools/tn_probe.py): kept as a measurement switch only, the launcher uses false.
+// SCALAR_EPI (the default): the one-column-per-lane epilogue (64 four-byte stores per lane); false = the register-transposed one.
+template <bool ILV, bool SCALAR_EPI = true>
 __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -242,7 +245,19 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
         // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Register-transposed (ss_quad_transpose,
         // as gemm_x6p.hip): the four registers of a row quad become four consecutive columns of one row = one 16-byte store; 16 store
         // instructions per wave (8 rows x 128 B each) instead of 64 four-byte ones.  Tiles are whole (M % 256 == 0, N % 128 == 0).
-        {
+        if constexpr (SCALAR_EPI) {
+            float* cbase = p.c + cur.cbase + (cur.n0 + wn * 64 + l31);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = cur.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float* crow = cbase + (long)m * p.N;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) crow[32 * ni] = fmaf(acc[1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]) * out_scale;
+                }
+            }
+        } else {
             const bool odd = lane & 1, hi = lane & 2;
             const int m = cur.m0 + wm * 64 + 4 * lh + (lane & 3);          // + 32 mi + 8 rq
             float* g = p.c + cur.cbase + (cur.n0 + wn * 64 + (l31 & ~3)) + (long)m * p.N;
@@ -291,8 +306,9 @@ int ss_gemm_tn_splits(int M, int N, long K, int nbatch, int* k_per_split) {
 int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s) {
     if (!ss_gemm_tn_x3h_ok(p.M, p.N, p.K) || p.k_per_split % TBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
     static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
@@ -303,9 +319,12 @@ int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s) {
     const long nwg = persistent ? cus : tiles;
     SsProfScope prof("gemm_tn_x3h_kernel", 2.0 * p.M * p.N * p.K * p.nbatch * 3,
                      2.0 * 2 * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
-    // fragment reads interleaved with the MFMAs (bit-identical; gemm_ilv = 0 keeps the burst form)
-    if (!ss_tuning().gemm_ilv) hipLaunchKernelGGL(gemm_tn_x3h_kernel<false>, dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
-    else hipLaunchKernelGGL(gemm_tn_x3h_kernel<true>, dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
+    // default: burst fragment reads + the one-column-per-lane epilogue -- the two variants of gemm_x6p.hip both measure slower here
+    // (tools/tn_probe.py, n = 8 / 16: interleaved reads 218 / 381 us, register-transposed epilogue 194 / 339 us, this form 188 - 193 /
+    // 332 - 333 us).  tile_dbg (measurement): 4 = interleaved reads, 16 = register-transposed epilogue; all three are bit-identical
+    if (ss_tuning().tile_dbg & 4) hipLaunchKernelGGL((gemm_tn_x3h_kernel<true, true>), dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
+    else if (ss_tuning().tile_dbg & 16) hipLaunchKernelGGL((gemm_tn_x3h_kernel<false, false>), dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
+    else hipLaunchKernelGGL((gemm_tn_x3h_kernel<false, true>), dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -112,6 +112,9 @@ class CycleGanModel:
         # run the two independent chains of each phase on two HIP streams (see _train_step_dual); SS_DUAL_STREAM=0 disables
         self.dual_stream = {"0": False, "force": "force"}.get(os.environ.get("SS_DUAL_STREAM", "1"), True)
         self.dual_gemm_cus = 224          # CUs the persistent GEMMs of one chain occupy while two chains run (0: all)
+        # weight gradients of the generator chains on two further streams: measured SLOWER (164.8 vs 157.2 ms for the CycleGAN step -- four
+        # chains already share the chip and the weight-gradient GEMMs take whole CUs); the MultiResUNet step, one chain, gains 6 % from it
+        self.wgrad_side_streams = os.environ.get("SS_WGRAD_STREAMS", "0") == "1"
         # (switched off automatically when several ranks share one GPU -- dist.ranks_share_device(); "force" overrides, for tests)
         self.gen_a_optimizer = self.gen_b_optimizer = self.disc_a_optimizer = self.disc_b_optimizer = None
         self.image_pool_a = image_pool_a if image_pool_a is not None else ImagePool(1, 0)
@@ -268,7 +271,7 @@ class CycleGanModel:
         from .engine import side_streams
         ga, gb, da, db = self.gen_a, self.gen_b, self.disc_a, self.disc_b
         cur = torch.cuda.current_stream()
-        s1, s2, s3, s4 = side_streams(real_a.device, 4)
+        s1, s2, s3, s4, s5, s6 = side_streams(real_a.device, 6)
         n_a, n_b = real_a.n, real_b.n
         # SS_OVERLAP_D=0: discriminator chains only after the generator backward passes (two phases); default: they start as soon
         # as the generator FORWARD passes have produced the fakes and run beside the generator backward passes.  Nothing they
@@ -288,6 +291,8 @@ class CycleGanModel:
         s1.wait_stream(cur)
         s2.wait_stream(cur)
         tape_a, tape_b = Tape(), Tape()
+        if self.wgrad_side_streams:          # weight gradients of each chain on a stream of their own (engine.Tape.wgrad_stream)
+            tape_a.wgrad_stream, tape_b.wgrad_stream = s5, s6
         with torch.cuda.stream(s1):
             fake_b, same_b = LY.batch_split(tape_a, ga(Act(cat_batch([real_a.t, real_b.t]), requires_grad=False), True, tape_a), [n_a, n_b])
             cycled_a = gb(fake_b, True, tape_a)

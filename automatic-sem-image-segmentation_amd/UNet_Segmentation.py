@@ -131,6 +131,7 @@ class UNetModel:
         self._out3 = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.act_dtype = net.act_dtype           # float32, or bfloat16 / float16 mixed-precision activation storage
         self.loss_scale = 1024.0 if self.act_dtype == torch.float16 else 1.0
+        self.wgrad_side_stream = os.environ.get("SS_UNET_WGRAD_STREAM", "1") != "0"
 
     def _to_act(self, t):
         if isinstance(t, np.ndarray):
@@ -143,6 +144,11 @@ class UNetModel:
         x, y = (self._to_act(t) for t in batch)
         world = D.world_size()
         tape = Tape()
+        if self.wgrad_side_stream and x.device.type == "cuda" and not D.ranks_share_device():
+            # the weight gradients of the tile-kernel layers (matrix cores / LDS) beside the BatchNorm backward passes of the chain
+            # (HBM): they are off the dependency chain (engine.Tape.wgrad_stream)
+            from .engine import side_streams
+            tape.wgrad_stream = side_streams(x.device, 1)[0]
         p = self.net(x, True, tape)
         losses.weighted_bce(y, p, self.weighting, self.loss_scale, self._out3)
         self.net.zero_grad()

@@ -327,6 +327,11 @@ class Tape:
         self.enabled = enabled
         self.param_grads = param_grads   # False: ops recorded now skip weight gradients (input grads only)
         self.count_uses = count_uses     # False (recomputation tapes): the uses of the variables were announced at the first forward
+        # Optional side stream for the WEIGHT gradients of the backward pass (layers.Conv2D): they are off the dependency chain
+        # (nothing in backward reads dW), so a convolution whose weight-gradient pass touches no shared amax slot launches it there,
+        # ordered behind the chain by an event, and the chain goes on with the data gradient.  The owner of the tape joins the
+        # stream before the optimizer step (join_wgrad_stream).
+        self.wgrad_stream = None
 
     def record(self, fn):
         if self.enabled:
@@ -336,6 +341,12 @@ class Tape:
         for fn in reversed(self.ops):
             fn()
         self.ops = []
+        self.join_wgrad_stream()
+
+    def join_wgrad_stream(self):
+        """The current stream waits for everything issued on the weight-gradient side stream."""
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
 
 class ParamArena:

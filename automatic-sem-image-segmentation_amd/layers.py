@@ -172,14 +172,33 @@ class Conv2D:
                 dd.x_amax, dd.x_amax_valid = (x.amax_slot(), 1 if x.amax_valid else 0) if uses & 1 else (None, 0)
                 dd.dy_amax, dd.dy_amax_valid = (dy.amax_slot(), 1 if dy.amax_valid else 0) if uses & 2 else (None, 0)
                 dd.saved_operand = sv.data_ptr() if sv is not None else None
-                L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), xin.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wsw), wsw.numel(),
-                                                 _stream()), f"conv2d_bwd_weight[{self.name}]")
+                # (a pass that would have to COMPUTE a maximum into a shared slot stays on the chain: the data gradient trusts the slot)
+                amax_ready = (not (uses & 1) or x.amax_valid) and (not (uses & 2) or dy.amax_valid)
+                side = tape.wgrad_stream if amax_ready else None
+                if side is not None:
+                    # off the chain: dW is read by nobody in backward.  The side stream starts behind everything issued so far (dy is
+                    # final), works in its own scratch buffer, and the tensors it reads may not be recycled under it (dy can be a
+                    # temporary of this closure).
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        wss = workspace(nbw, x.device)
+                        L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), xin.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wss), wss.numel(),
+                                                         _stream()), f"conv2d_bwd_weight[{self.name}] (side stream)")
+                        dy.t.record_stream(side)
+                        xin.t.record_stream(side)
+                        if sv is not None:
+                            sv.record_stream(side)
+                        self.arena.note_done(pnames)          # a gradient exchange launched from here orders itself behind THIS stream
+                else:
+                    L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), xin.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wsw), wsw.numel(),
+                                                     _stream()), f"conv2d_bwd_weight[{self.name}]")
                 dd.saved_operand = None
                 if uses & 1:
                     x.amax_valid = True
                 if uses & 2:
                     dy.amax_valid = True
-                self.arena.note_done(pnames)
+                if side is None:
+                    self.arena.note_done(pnames)
             if x.requires_grad:
                 dx, accum = x.grad_target()
                 ddx = dd if dx.cs == dd.in_cstride else self.desc_with_in_cs(dd, dx.cs)

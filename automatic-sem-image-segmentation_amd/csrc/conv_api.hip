@@ -124,19 +124,30 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ v
     }
     if (pl == 0 && c < C) part[(long)blockIdx.x * C + c] = red[threadIdx.x];
 }
+// one block per 8 channels: 32 chunk lanes per channel walk the partials (fixed assignment k = lane, lane + 32, ...), then a fixed-order
+// tree over the lanes -- deterministic, in double.  (One thread per channel walked all 1024 chunks alone: 64 dependent L2 round trips,
+// 73 us per launch for the one-channel bias gradient of the generators' head.)
 __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int chunks, int C, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[256];
+    const int cl = threadIdx.x & 7, kl = threadIdx.x >> 3;          // 8 channels x 32 chunk lanes
+    const int c = blockIdx.x * 8 + cl;
     double acc = 0.0;
-    // 16 loads in flight, same summation order (rolled, the loop was one L2 round trip per chunk: 73 us for 1024 chunks)
-    for (int k = 0; k < chunks; k += 16) {
-        float v[16];
+    if (c < C) {
+        for (int k = kl; k < chunks; k += 32 * 8) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = k + u < chunks ? part[(long)(k + u) * C + c] : 0.f;
+            for (int u = 0; u < 8; ++u) v[u] = k + 32 * u < chunks ? part[(long)(k + 32 * u) * C + c] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc += v[u];
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
     }
-    out[c] = accumulate ? out[c] + (float)acc : (float)acc;
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 16; off >= 1; off >>= 1) {
+        if (kl < off) red[threadIdx.x] += red[threadIdx.x + off * 8];
+        __syncthreads();
+    }
+    if (kl == 0 && c < C) out[c] = accumulate ? out[c] + (float)red[threadIdx.x] : (float)red[threadIdx.x];
 }
 
 int colsum(const float* v, long rows, int C, int cs, float* out, int accumulate, float* part, hipStream_t s) {
@@ -147,7 +158,7 @@ int colsum(const float* v, long rows, int C, int cs, float* out, int accumulate,
     if (chunks < 1) chunks = 1;
     hipLaunchKernelGGL(colsum_stage1, dim3(chunks, (C + CT - 1) / CT), dim3(256), 0, s, v, rows, C, cs, part, CT);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, s, part, chunks, C, out, accumulate);
+    hipLaunchKernelGGL(colsum_stage2, dim3((C + 7) / 8), dim3(256), 0, s, part, chunks, C, out, accumulate);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

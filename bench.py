@@ -344,7 +344,8 @@ def main():
                     if tj.get("workload") == [S, GB, F, world]:
                         kern = tj.get("kernels", {})
                         # rocprofv3 spells the default template arguments out (gemm_x6p_kernel<2,false>), the ss_prof label does not
-                        traffic = kern.get(dom) or kern.get(dom.replace(">", ",false>"))
+                        stem = dom[:-1] if dom.endswith(">") else dom
+                        traffic = kern.get(dom) or next((v for k_, v in sorted(kern.items()) if k_.startswith(stem + ",")), None)
                 except Exception:
                     traffic = None
             # what the matrix pipe of THIS box delivers on real data (the chip clocks to its power budget): a register-only MFMA stream on

@@ -115,6 +115,7 @@ class CycleGanModel:
         # weight gradients of the generator chains on two further streams: measured SLOWER (164.8 vs 157.2 ms for the CycleGAN step -- four
         # chains already share the chip and the weight-gradient GEMMs take whole CUs); the MultiResUNet step, one chain, gains 6 % from it
         self.wgrad_side_streams = os.environ.get("SS_WGRAD_STREAMS", "0") == "1"
+        self.refresh_side_streams = os.environ.get("SS_REFRESH_STREAMS", "1") != "0"
         # (switched off automatically when several ranks share one GPU -- dist.ranks_share_device(); "force" overrides, for tests)
         self.gen_a_optimizer = self.gen_b_optimizer = self.disc_a_optimizer = self.disc_b_optimizer = None
         self.image_pool_a = image_pool_a if image_pool_a is not None else ImagePool(1, 0)
@@ -164,8 +165,15 @@ class CycleGanModel:
         one = 1.0 - ls + ls / 2.0
         zero = ls / 2.0
         world = D.world_size()
-        for net in (ga, gb, da, db):        # weight-derived operands of the new weight version, before any concurrent chain starts
-            net.arena.refresh_derived()
+        # weight-derived operands of the new weight version, before any concurrent chain starts: each network's ~100 small launches on
+        # a stream of its own with one event per layer (engine.ParamArena.refresh_derived), so that the chains wait for the layer
+        # they are about to run, not for all four networks (SS_REFRESH_STREAMS=0: in front of the step, on this stream)
+        rs = (None,) * 4
+        if self.refresh_side_streams and self.dual_stream and real_a.device.type == "cuda" and not D.ranks_share_device():
+            from .engine import side_streams
+            rs = side_streams(real_a.device, 10)[6:10]
+        for net, side in zip((ga, gb, da, db), rs):
+            net.arena.refresh_derived(side)
 
         if (self.dual_stream and self.use_identity_loss and self.batch_generator_passes and not self.use_binary_crossentropy_a
                 and (self.dual_stream == "force" or not D.ranks_share_device())):

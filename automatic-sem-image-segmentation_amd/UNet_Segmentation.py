@@ -132,6 +132,9 @@ class UNetModel:
         self.act_dtype = net.act_dtype           # float32, or bfloat16 / float16 mixed-precision activation storage
         self.loss_scale = 1024.0 if self.act_dtype == torch.float16 else 1.0
         self.wgrad_side_stream = os.environ.get("SS_UNET_WGRAD_STREAM", "1") != "0"
+        # measured: 36.5 ms per step without, 37.1 - 37.3 with (the refresh of ~100 small layers competes with the chain's first, small
+        # layers): opt-in here, default in the CycleGAN step
+        self.refresh_side_stream = os.environ.get("SS_UNET_REFRESH_STREAM", "0") == "1"
 
     def _to_act(self, t):
         if isinstance(t, np.ndarray):
@@ -149,6 +152,8 @@ class UNetModel:
             # (HBM): they are off the dependency chain (engine.Tape.wgrad_stream)
             from .engine import side_streams
             tape.wgrad_stream = side_streams(x.device, 1)[0]
+            if self.refresh_side_stream:          # the layers' weight-derived operands beside the first layers, not inside the chain
+                self.net.arena.refresh_derived(side_streams(x.device, 7)[6])
         p = self.net(x, True, tape)
         losses.weighted_bce(y, p, self.weighting, self.loss_scale, self._out3)
         self.net.zero_grad()

@@ -376,15 +376,19 @@ class ParamArena:
         self.version = 0           # bumped by every writer of `params` that torch's version counter does not see (HIP kernels)
         self.derived = []          # layers that keep operands derived from the weights (layers.Conv2D weight caches)
         self._derived_key = None
+        self._refresh_stream = None   # side stream of a refresh_derived() whose kernels may still be reading the weights
 
     def touch(self):
         """The weight values changed behind torch's back (optimizer kernel, collective): caches derived from them are stale."""
         self.version += 1
 
-    def refresh_derived(self):
-        """Recompute, on the CURRENT stream, what the layers keep of the previous weight version (no-op while the weights are
-        unchanged).  A step that runs concurrent kernel chains calls this before forking: otherwise the chain that reaches a
-        layer second has to wait for the first one's (much later) fill."""
+    def refresh_derived(self, side=None):
+        """Recompute what the layers keep of the previous weight version (no-op while the weights are unchanged).  A step that
+        runs concurrent kernel chains calls this before forking: otherwise the chain that reaches a layer second has to wait for
+        the first one's (much later) fill.  side = None: on the CURRENT stream (one event for the whole arena).  side = a stream:
+        the ~100 small launches of a network run THERE, in layer order, behind everything issued so far, with one event per layer
+        -- a consumer waits for its own layer's operands only (layers.Conv2D._attach_wcache), so the chains start at once and the
+        rest of the refresh runs beside their first layers instead of in front of them."""
         if self.params is None:
             return
         from . import _lib as L
@@ -392,6 +396,19 @@ class ParamArena:
         if key == self._derived_key:
             return
         self._derived_key = key
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                sid = _stream().value or 0
+                for layer in self.derived:
+                    sync = dict(ev=None, synced=set())
+                    if layer.refresh_wcache(sync):
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        sync["ev"] = ev
+                        sync["synced"].add(sid)
+            self._refresh_stream = side
+            return
         sync = dict(ev=None, synced=set())
         n = sum(layer.refresh_wcache(sync) for layer in self.derived)
         if n:
@@ -399,6 +416,14 @@ class ParamArena:
             ev.record()
             sync["ev"] = ev
             sync["synced"].add(_stream().value or 0)
+
+    def join_refresh(self):
+        """Order the current stream behind a refresh_derived(side=...) still in flight: called by whoever WRITES the weights next
+        (the refresh kernels read them)."""
+        side = self._refresh_stream
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            self._refresh_stream = None
 
     def weights_key(self):
         """Changes whenever the trainable values may have changed: explicit touch() or any in-place torch op on a view of them."""

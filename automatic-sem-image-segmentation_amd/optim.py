@@ -23,6 +23,7 @@ class Adam:
         lr = float(self.learning_rate)
         alpha = lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
         a = net.arena
+        a.join_refresh()          # a weight-cache refresh on a side stream may still be reading the old values
         L.check(lib.ss_adam_keras(_p(a.params), _p(a.grads), _p(a.m), _p(a.v), a.n_train, alpha,
                                   self.beta_1, self.beta_2, self.epsilon, float(grad_scale), _stream()), "ss_adam_keras")
         a.touch()

@@ -135,6 +135,13 @@ class UNetModel:
         # measured: 36.5 ms per step without, 37.1 - 37.3 with (the refresh of ~100 small layers competes with the chain's first, small
         # layers): opt-in here, default in the CycleGAN step
         self.refresh_side_stream = os.environ.get("SS_UNET_REFRESH_STREAM", "0") == "1"
+        # sync_metrics = False: train_step returns {} and leaves the three scalars on the device (no device->host read), so the caller
+        # can issue it on a stream of its own beside other work; side_stream_index = which of engine.side_streams the weight gradients take
+        self.sync_metrics = True
+        self.side_stream_index = 0
+        # the four ResPaths on streams of their own (engine.Branch; nets.MultiResUNet.forward): SS_UNET_BRANCHES=0 runs them inline.
+        # Single-process only: under data parallelism the SyncBN / gradient collectives would be issued from several streams.
+        self.branch_streams = os.environ.get("SS_UNET_BRANCHES", "1") != "0"
 
     def _to_act(self, t):
         if isinstance(t, np.ndarray):
@@ -151,7 +158,11 @@ class UNetModel:
             # the weight gradients of the tile-kernel layers (matrix cores / LDS) beside the BatchNorm backward passes of the chain
             # (HBM): they are off the dependency chain (engine.Tape.wgrad_stream)
             from .engine import side_streams
-            tape.wgrad_stream = side_streams(x.device, 1)[0]
+            k = self.side_stream_index
+            streams = side_streams(x.device, k + 5)
+            tape.wgrad_stream = streams[k]
+            if self.branch_streams and world == 1:
+                tape.branch_streams = streams[k + 1:k + 5]
             if self.refresh_side_stream:          # the layers' weight-derived operands beside the first layers, not inside the chain
                 self.net.arena.refresh_derived(side_streams(x.device, 7)[6])
         p = self.net(x, True, tape)
@@ -161,6 +172,8 @@ class UNetModel:
         tape.backward()
         D.all_reduce_grads([self.net])
         self.optimizer.apply(self.net, 1.0 / (world * self.loss_scale))
+        if not self.sync_metrics:
+            return {}
         s = D.mean_scalars(self._out3.cpu().numpy().astype(np.float64))
         return {"loss": float(s[0]), "mae": float(s[1]), "acc": float(s[2])}
 

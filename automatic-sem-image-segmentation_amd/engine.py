@@ -332,10 +332,26 @@ class Tape:
         # ordered behind the chain by an event, and the chain goes on with the data gradient.  The owner of the tape joins the
         # stream before the optimizer step (join_wgrad_stream).
         self.wgrad_stream = None
+        # Independent branches of the graph on streams of their own (Tape.fork / Branch): `lane` is the branch being recorded (its
+        # backward closures are replayed on its stream), `branch_streams` what a network may fork onto (None: run everything inline)
+        self.lane = None
+        self.branch_streams = None
 
     def record(self, fn):
         if self.enabled:
-            self.ops.append(fn)
+            lane = self.lane
+            if lane is None:
+                self.ops.append(fn)
+            else:
+                def on_lane(fn=fn, stream=lane.stream):
+                    with torch.cuda.stream(stream):
+                        fn()
+                self.ops.append(on_lane)
+
+    def fork(self, stream):
+        """A Branch of the graph that runs on ``stream`` beside the rest (see Branch).  Call where the branch's inputs are final
+        and every other consumer of them has been recorded."""
+        return Branch(self, stream)
 
     def backward(self):
         for fn in reversed(self.ops):
@@ -347,6 +363,67 @@ class Tape:
         """The current stream waits for everything issued on the weight-gradient side stream."""
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
+
+class Branch:
+    """An independent branch of the recorded graph on a HIP stream of its own, in the forward pass AND in the replay (the
+    MultiResUNet's ResPaths, UNet_Segmentation.py:476-503,533-553: each depends on one encoder block's output only and is needed
+    only where the decoder concatenates it, so it runs beside the whole deeper part of the network -- in backward beside the
+    backward of everything between the concatenation and that encoder block).  Three points of the forward program:
+
+        br = tape.fork(stream)    # A: the branch's inputs are final; every OTHER consumer of them has been recorded
+        with br: ...              #    the branch: its kernels go to `stream` (ordered behind A), its closures replay there
+        br.join()                 # B: before the first consumer of the branch's outputs
+
+    Replay (reverse order): the op recorded at B marks "the branch's output gradients are final" (event on the replaying stream);
+    the branch's closures run on `stream` behind that event, whenever the reverse order reaches them, and leave an event; the op
+    recorded at A makes the replaying stream wait for it -- so the branch writes the gradient of its input FIRST (it is replayed
+    before A) and the other consumers, recorded before A, accumulate behind the wait.  Scratch buffers, amax slot pools and
+    weight-cache fills are per stream / event-ordered already (workspace, _amax_slot, layers.Conv2D._attach_wcache).  Tensors
+    the branch allocates live on its stream's allocator pool; the ones that cross (the input gradient it writes first, buffers of
+    the forking stream it reads or writes) stay alive until the tape is dropped, after the joins."""
+
+    def __init__(self, tape, stream):
+        self.tape, self.stream = tape, stream
+        self.inputs_ready = torch.cuda.current_stream().record_event()
+        self.fwd_done = self.grads_ready = self.bwd_done = None
+        if tape.enabled:
+            def join_backward():          # replayed right before the other consumers' closures (recorded before A)
+                if self.bwd_done is not None:
+                    torch.cuda.current_stream().wait_event(self.bwd_done)
+            tape.ops.append(join_backward)
+
+    def __enter__(self):
+        assert self.tape.lane is None, "branches do not nest"
+        self.stream.wait_event(self.inputs_ready)
+        if self.tape.enabled:
+            def end_backward():           # replayed after the branch's closures
+                self.bwd_done = self.stream.record_event()
+            self.tape.ops.append(end_backward)
+        self.tape.lane = self
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self._ctx.__exit__(*exc)
+        self.tape.lane = None
+        self.fwd_done = self.stream.record_event()
+        if self.tape.enabled:
+            def begin_backward():         # replayed before the branch's closures: behind the gradients of its outputs
+                if self.grads_ready is not None:
+                    self.stream.wait_event(self.grads_ready)
+                else:
+                    self.stream.wait_stream(torch.cuda.current_stream())
+            self.tape.ops.append(begin_backward)
+        return False
+
+    def join(self):
+        torch.cuda.current_stream().wait_event(self.fwd_done)
+        if self.tape.enabled:
+            def mark_grads_ready():       # replayed right after the closures of the outputs' consumers (recorded after B)
+                self.grads_ready = torch.cuda.current_stream().record_event()
+            self.tape.ops.append(mark_grads_ready)
 
 
 class ParamArena:

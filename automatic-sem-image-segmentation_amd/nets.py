@@ -329,30 +329,48 @@ class MultiResUNet(Network):
         x = reflect_pad(tape, x, pw, ph)                      # UNet_Segmentation.py:520-522
         f, t = self.filters, training
         dev = x.device
+        # The four ResPaths depend on one encoder block each and are needed only where the decoder concatenates them: with
+        # tape.branch_streams they run on streams of their own beside the deeper part of the network, in the forward pass and in the
+        # replay (engine.Branch); otherwise inline, right before the concatenation's consumer (the order of the plain program).
+        bs = tape.branch_streams if (tape.enabled and x.device.type == "cuda") else None
+
+        def res_path(k, rp, m, dst):
+            """Start ResPath k (input m, output into the concat slice dst); returns what join() needs."""
+            if bs is None:
+                return lambda: rp(tape, m, t, out=dst)
+            br = tape.fork(bs[k % len(bs)])
+            with br:
+                rp(tape, m, t, out=dst)
+            return br.join
+
         m1 = self.mrb1(tape, x, t)
         p1 = maxpool2x2(tape, m1)
+        # skip concatenations [upT(deeper), ResPath(encoder)]: both producers write into the concat buffer
+        cat9 = m1.like(c=f * 2)
+        j1 = res_path(0, self.rp1, m1, cat9.slice(f, f))
         m2 = self.mrb2(tape, p1, t)
         p2 = maxpool2x2(tape, m2)
+        cat8 = m2.like(c=f * 4)
+        j2 = res_path(1, self.rp2, m2, cat8.slice(f * 2, f * 2))
         m3 = self.mrb3(tape, p2, t)
         p3 = maxpool2x2(tape, m3)
+        cat7 = m3.like(c=f * 8)
+        j3 = res_path(2, self.rp3, m3, cat7.slice(f * 4, f * 4))
         m4 = self.mrb4(tape, p3, t)
         p4 = maxpool2x2(tape, m4)
-        m5 = self.mrb5(tape, p4, t)
-        # skip concatenations [upT(deeper), ResPath(encoder)]: both producers write into the concat buffer
         cat6 = m4.like(c=f * 16)
-        self.rp4(tape, m4, t, out=cat6.slice(f * 8, f * 8))
+        j4 = res_path(3, self.rp4, m4, cat6.slice(f * 8, f * 8))
+        m5 = self.mrb5(tape, p4, t)
+        j4()
         self.up6(tape, m5, out=cat6.slice(0, f * 8))
         m6 = self.mrb6(tape, cat6, t)
-        cat7 = m3.like(c=f * 8)
-        self.rp3(tape, m3, t, out=cat7.slice(f * 4, f * 4))
+        j3()
         self.up7(tape, m6, out=cat7.slice(0, f * 4))
         m7 = self.mrb7(tape, cat7, t)
-        cat8 = m2.like(c=f * 4)
-        self.rp2(tape, m2, t, out=cat8.slice(f * 2, f * 2))
+        j2()
         self.up8(tape, m7, out=cat8.slice(0, f * 2))
         m8 = self.mrb8(tape, cat8, t)
-        cat9 = m1.like(c=f * 2)
-        self.rp1(tape, m1, t, out=cat9.slice(f, f))
+        j1()
         self.up9(tape, m8, out=cat9.slice(0, f))
         m9 = self.mrb9(tape, cat9, t)
         m9 = crop(tape, m9, ph // 2, ph // 2 + ph % 2, pw // 2, pw // 2 + pw % 2)     # Cropping2D, UNet_Segmentation.py:554

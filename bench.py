@@ -188,7 +188,22 @@ def main():
     ux = E.Act(((a.t + 1) / 2).contiguous(), requires_grad=False)
     uy = E.Act(((b.t + 1) / 2).contiguous(), requires_grad=False)
 
+    overlap_unet = os.environ.get("SS_OVERLAP_UNET", "0") == "1"
+    if overlap_unet:
+        u_stream = E.side_streams(dev, 12)[10]
+        umodel.side_stream_index = 11
+
     def step(cyclegan=not args.only_unet, unet_=not args.skip_unet):
+        if overlap_unet and cyclegan and unet_:
+            cur = torch.cuda.current_stream()
+            u_stream.wait_stream(cur)
+            umodel.sync_metrics = False
+            with torch.cuda.stream(u_stream):
+                umodel.train_step((ux.t, uy.t))
+            umodel.sync_metrics = True
+            model.train_step((a, b))
+            cur.wait_stream(u_stream)
+            return
         if cyclegan:
             model.train_step((a, b))
         if unet_:

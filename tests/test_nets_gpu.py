@@ -312,3 +312,27 @@ def test_dual_stream_step_equals_single_stream_step():
     for g1, g2 in zip(out[False][1], out[True][1]):
         for k in g1:
             assert rel_l2(g2[k], g1[k]) <= 1e-6, k
+
+
+@pytest.mark.parametrize("size,batch", [(64, 2), (128, 3), (72, 1)])
+def test_unet_respath_branches_equal_the_inline_step(size, batch):
+    """UNetModel with the four ResPaths on streams of their own (engine.Branch: forward and replay beside the deeper part of the
+    network) against the same steps with everything inline: same kernels on the same data in the same accumulation order, so
+    metrics, weights, BatchNorm moving statistics and Adam slots after three steps are bit-identical."""
+    UN, OPT, N = mod("UNet_Segmentation"), mod("optim"), mod("nets")
+    gen = torch.Generator().manual_seed(17)
+    xs = [torch.rand((batch, size, size, 1), generator=gen).numpy() for _ in range(3)]
+    ys = [(torch.rand((batch, size, size, 1), generator=gen) > 0.9).float().numpy() for _ in range(3)]
+    out = {}
+    for branches in (False, True):
+        net = N.MultiResUNet(16, device="cuda:0", seed=4)
+        model = UN.UNetModel(net, 9.0, OPT.Adam(1e-3))
+        assert model.branch_streams and model.wgrad_side_stream       # the defaults are what the benchmark runs
+        model.branch_streams = branches
+        ms = [model.train_step((x, y)) for x, y in zip(xs, ys)]
+        torch.cuda.synchronize()
+        out[branches] = (ms, [w.copy() for w in net.get_weights()], net.arena.m.cpu().numpy().copy(), net.arena.v.cpu().numpy().copy())
+    assert out[False][0] == out[True][0]
+    for w0, w1, name in zip(out[False][1], out[True][1], N.MultiResUNet(16, device="cuda:0").variable_names):
+        assert np.array_equal(w0, w1), name
+    assert np.array_equal(out[False][2], out[True][2]) and np.array_equal(out[False][3], out[True][3])

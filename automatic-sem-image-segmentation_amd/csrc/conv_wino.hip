@@ -773,13 +773,17 @@ int fwd16_impl(const WinoProb& q, const TS* x, const float* w, int w_cin, int w_
     }
     if (q.wc && q.wc->fill_only) return SS_OK;
     const bool one = ss_tuning().wino16_products != 3;          // 1: one plane / one product; 3: the x3h arithmetic of the fp32-storage path
-    if (one)
-        hipLaunchKernelGGL((wino_input_kernel<R, 5, false, TS>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
-                           TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
-    else
-        hipLaunchKernelGGL((wino_input_kernel<R, 3, false, TS>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
-                           TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
-    SS_LAUNCH_CHECK();
+    {
+        // algorithmic bytes (HBM roofline, bench.py): one read of x, one write of the fp16 operand plane(s)
+        SsProfScope prof("wino_input_kernel", 0.0, (double)q.n * q.h * q.w * q.cin * sizeof(TS) + (double)XI * tiles * q.cin * 2 * (one ? 1 : 2), s);
+        if (one)
+            hipLaunchKernelGGL((wino_input_kernel<R, 5, false, TS>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                               TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
+        else
+            hipLaunchKernelGGL((wino_input_kernel<R, 3, false, TS>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                               TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
+        SS_LAUNCH_CHECK();
+    }
     X6PParams g{};
     g.fp16x2 = one ? 2 : 1;
     g.a = (const unsigned short*)V; g.b = planes; g.c = Mx;
@@ -790,6 +794,7 @@ int fwd16_impl(const WinoProb& q, const TS* x, const float* w, int w_cin, int w_
     g.c_bs = tiles * q.cout; g.c_ss = 0;
     const int rcx = ss_launch_gemm_x6p(g, s);
     if (rcx != SS_OK) return rcx;
+    SsProfScope prof("wino_output_kernel", 0.0, (double)XI * tiles * q.cout * 4 + (double)q.n * q.oh * q.ow * q.cout * sizeof(TS) * (accumulate ? 2 : 1), s);
     hipLaunchKernelGGL((wino_output_kernel<R, TS>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
                        bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w, tile_inv, w_inv, (float*)nullptr);
     SS_LAUNCH_CHECK();
@@ -875,14 +880,18 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
                 V = (float*)q.saved;
                 tile_inv = (float*)((char*)q.saved + ss_align_up((size_t)2 * XI * Mpad * q.cin * 2, 256));
             }
-            if (q.in_norm.groups > 0)
-                hipLaunchKernelGGL((wino_input_kernel<R, 3, true>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
-                                   TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, wide,
-                                   q.in_norm);
-            else
-                hipLaunchKernelGGL((wino_input_kernel<R, 3>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
-                                   TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, wide);
-            SS_LAUNCH_CHECK();
+            {
+                SsProfScope prof(q.in_norm.groups > 0 ? "wino_input_kernel<normalising>" : "wino_input_kernel", 0.0,
+                                 (double)q.n * q.h * q.w * q.cin * 4 + (double)XI * tiles * q.cin * 4, s);          // read x, write the (h, l) planes
+                if (q.in_norm.groups > 0)
+                    hipLaunchKernelGGL((wino_input_kernel<R, 3, true>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                                       TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, wide,
+                                       q.in_norm);
+                else
+                    hipLaunchKernelGGL((wino_input_kernel<R, 3>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                                       TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, wide);
+                SS_LAUNCH_CHECK();
+            }
         } else {
         planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X6_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill);
         if (fill) {
@@ -905,6 +914,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         g.c_bs = tiles * q.cout; g.c_ss = 0;
         const int rcx = ss_launch_gemm_x6p(g, s);
         if (rcx != SS_OK) return rcx;
+        SsProfScope prof("wino_output_kernel", 0.0, (double)XI * tiles * q.cout * 4 + (double)q.n * q.oh * q.ow * q.cout * 4 * (accumulate ? 2 : 1), s);
         hipLaunchKernelGGL(wino_output_kernel<R>, dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
                            bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w, tile_inv, w_inv, stats);
         SS_LAUNCH_CHECK();
@@ -974,9 +984,12 @@ int wgrad_impl(const WinoProb& q, const TS* x, const TS* dy, float* dw, int accu
                 // other operand: E'[k][:] = E[k][:] * tile_inv[k] (wino_dy_kernel), under one scale that bounds max|E'|.
                 const long Mpad = (tiles + SS_X6P_BM - 1) / SS_X6P_BM * SS_X6P_BM;
                 const float* tinv = (const float*)((const char*)q.saved + ss_align_up((size_t)2 * XI * Mpad * q.cin * 2, 256));
-                hipLaunchKernelGGL((wino_dy_kernel<R, 1, TS>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, (float*)E,
-                                   (unsigned int*)nullptr, q.dy_amax, q.dy_stripes, BOUND_DY, tinv, q.x_amax, q.x_stripes, BOUND_X);
-                SS_LAUNCH_CHECK();
+                {
+                    SsProfScope prof("wino_dy_kernel", 0.0, (double)q.n * q.oh * q.ow * q.cout * sizeof(TS) + (double)XI * tiles * q.cout * 4, s);
+                    hipLaunchKernelGGL((wino_dy_kernel<R, 1, TS>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, (float*)E,
+                                       (unsigned int*)nullptr, q.dy_amax, q.dy_stripes, BOUND_DY, tinv, q.x_amax, q.x_stripes, BOUND_X);
+                    SS_LAUNCH_CHECK();
+                }
                 TNParams g{};
                 g.a = (const unsigned short*)q.saved; g.b = (const unsigned short*)E; g.c = part;
                 g.M = q.cin; g.N = q.cout; g.K = (int)tiles; g.nbatch = XI;
@@ -996,6 +1009,8 @@ int wgrad_impl(const WinoProb& q, const TS* x, const TS* dy, float* dw, int accu
                 SS_LAUNCH_CHECK();
                 return SS_OK;
             }
+            SsProfScope prof(q.in_norm.groups > 0 ? "wino_input_kernel<normalising>" : "wino_input_kernel", 0.0,
+                             (double)q.n * q.h * q.w * q.cin * 4 + (double)XI * tiles * q.cin * 4, s);
             if (q.in_norm.groups > 0)
                 hipLaunchKernelGGL((wino_input_kernel<R, 4, true>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
                                    q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X, 0, q.in_norm);
@@ -1003,13 +1018,17 @@ int wgrad_impl(const WinoProb& q, const TS* x, const TS* dy, float* dw, int accu
                 hipLaunchKernelGGL((wino_input_kernel<R, 4>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
                                    q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X);
         } else {
+            SsProfScope prof("wino_input_kernel", 0.0, (double)q.n * q.h * q.w * q.cin * sizeof(TS) + (double)XI * tiles * q.cin * 4, s);
             hipLaunchKernelGGL((wino_input_kernel<R, 4, false, TS>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
                                q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X);
         }
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL((wino_dy_kernel<R, 1, TS>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, (float*)E,
-                           (unsigned int*)nullptr, q.dy_amax, q.dy_stripes, BOUND_DY);
-        SS_LAUNCH_CHECK();
+        {
+            SsProfScope prof("wino_dy_kernel", 0.0, (double)q.n * q.oh * q.ow * q.cout * sizeof(TS) + (double)XI * tiles * q.cout * 4, s);
+            hipLaunchKernelGGL((wino_dy_kernel<R, 1, TS>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, dy, q.out_cs, q.n, q.oh, q.ow, q.cout, TH, TW, (float*)E,
+                               (unsigned int*)nullptr, q.dy_amax, q.dy_stripes, BOUND_DY);
+            SS_LAUNCH_CHECK();
+        }
         TNParams g{};
         g.a = (const unsigned short*)V; g.b = (const unsigned short*)E; g.c = part;
         g.M = q.cin; g.N = q.cout; g.K = (int)tiles; g.nbatch = XI;

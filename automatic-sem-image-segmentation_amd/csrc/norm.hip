@@ -825,6 +825,7 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     }
     const float* part = (const float*)ws;
     int chunks = g.chunks;
+    const double elems = (double)g.G * g.P * g.C;
     if (d->x_stats && d->x_stats_chunks > 0) {
         // the producing convolution's epilogue already summed x and x^2 ([n][chunks][c][2]; groups = 1: the samples' chunks follow
         // one another, i.e. n * chunks chunks of the one group)
@@ -832,6 +833,7 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
         chunks = d->x_stats_chunks * (d->n / g.G);
     } else {
         const dim3 sgrid(g.chunks, g.cblocks, g.G);
+        SsProfScope prof("norm_stats_kernel<fwd>", 0.0, elems * sizeof(T), s);          // algorithmic bytes: one read of x
         if (V == 4)
             hipLaunchKernelGGL((norm_stats_kernel<T, 0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
                                0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, (float*)ws);
@@ -846,6 +848,7 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     SS_LAUNCH_CHECK();
     if (!y) return SS_OK;
     const ApplyGeom ag = apply_geom(g, V);
+    SsProfScope prof("norm_apply_kernel", 0.0, elems * sizeof(T) * (residual ? 3 : 2), s);          // read x (+ residual), write y
     if (V == 4)
         hipLaunchKernelGGL((norm_apply_kernel<T, 4>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
                            residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam);
@@ -866,6 +869,7 @@ int norm_apply_t(const ss_norm_desc* d, const T* x, const float* gamma, const fl
     const NormGeom g = geom(d, V);
     unsigned int* yam = (unsigned int*)d->y_amax;
     const ApplyGeom ag = apply_geom(g, V);
+    SsProfScope prof("norm_apply_kernel", 0.0, (double)g.G * g.P * g.C * sizeof(T) * (residual ? 3 : 2), s);
     if (V == 4)
         hipLaunchKernelGGL((norm_apply_kernel<T, 4>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
                            residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam);
@@ -922,13 +926,17 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
     float* part = (float*)ws;
     float* sums = (float*)((char*)ws + part_bytes(d));
     const dim3 sgrid(g.chunks, g.cblocks, g.G);
-    if (V == 4)
-        hipLaunchKernelGGL((norm_stats_kernel<T, 1, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
-                           d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
-    else
-        hipLaunchKernelGGL((norm_stats_kernel<T, 1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
-                           d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
-    SS_LAUNCH_CHECK();
+    const double elems = (double)g.G * g.P * g.C;
+    {
+        SsProfScope prof("norm_stats_kernel<bwd>", 0.0, elems * sizeof(T) * (use_y ? 3 : 2), s);          // read dy, x (+ y)
+        if (V == 4)
+            hipLaunchKernelGGL((norm_stats_kernel<T, 1, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+                               d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
+        else
+            hipLaunchKernelGGL((norm_stats_kernel<T, 1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+                               d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
+        SS_LAUNCH_CHECK();
+    }
     double* rt = (double*)((char*)ws + part_bytes(d) + ss_align_up((size_t)g.G * g.C * 2 * sizeof(float), 256));
     const int fcl = fin_cl(g.C, g.G);
     hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + fcl - 1) / fcl, g.G), dim3(256), 0, s,
@@ -936,6 +944,9 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
     SS_LAUNCH_CHECK();
     const ApplyGeom ag = apply_geom(g, V);
     const double* prt = (dgamma || dbeta) ? rt : nullptr;
+    // read dy, x (+ y), write dx (+ read when accumulating), dres written (+ read when accumulating)
+    SsProfScope prof("norm_bwd_apply_kernel", 0.0,
+                     elems * sizeof(T) * ((use_y ? 3 : 2) + 1 + (accumulate_dx ? 1 : 0) + (dres ? (accumulate_dres ? 2 : 1) : 0)), s);
     if (V == 4)
         hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), ag.grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,

@@ -116,6 +116,8 @@ class CycleGanModel:
         # chains already share the chip and the weight-gradient GEMMs take whole CUs); the MultiResUNet step, one chain, gains 6 % from it
         self.wgrad_side_streams = os.environ.get("SS_WGRAD_STREAMS", "0") == "1"
         self.refresh_side_streams = os.environ.get("SS_REFRESH_STREAMS", "1") != "0"
+        env = os.environ.get("SS_CG_STREAMS")
+        self.stream_indices = [int(v) for v in env.split(",")] if env else None
         # (switched off automatically when several ranks share one GPU -- dist.ranks_share_device(); "force" overrides, for tests)
         self.gen_a_optimizer = self.gen_b_optimizer = self.disc_a_optimizer = self.disc_b_optimizer = None
         self.image_pool_a = image_pool_a if image_pool_a is not None else ImagePool(1, 0)
@@ -280,6 +282,9 @@ class CycleGanModel:
         ga, gb, da, db = self.gen_a, self.gen_b, self.disc_a, self.disc_b
         cur = torch.cuda.current_stream()
         s1, s2, s3, s4, s5, s6 = side_streams(real_a.device, 6)
+        if self.stream_indices is not None:          # SS_CG_STREAMS="a,b,da,db": which of engine.side_streams the four chains take
+            pool = side_streams(real_a.device, max(self.stream_indices) + 1)
+            s1, s2, s3, s4 = (pool[i] for i in self.stream_indices)
         n_a, n_b = real_a.n, real_b.n
         # SS_OVERLAP_D=0: discriminator chains only after the generator backward passes (two phases); default: they start as soon
         # as the generator FORWARD passes have produced the fakes and run beside the generator backward passes.  Nothing they

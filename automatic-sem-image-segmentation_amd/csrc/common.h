@@ -195,6 +195,8 @@ struct GConvParams {
     const unsigned int* h_amax2;  //      ... of max|weights| (always one word)
     int amax_stripes;             // h_amax is the maximum over this many words, SS_AMAX_STRIDE apart (0 / 1: one word)
     int32_t dtype;                // ss_dtype of `in` / `out` (the pointers are reinterpreted); only the tile kernels take 16-bit storage
+    int32_t c1_dtype;             // one-channel layers (conv_c1.hip x3h kernels): ss_dtype of the MULTI-channel tensor (`out` of a 1 -> C problem, `in` of a
+                                  // C -> 1 problem; the pointer is reinterpreted), the one-channel tensor is fp32.  0 = SS_DTYPE_F32
     float* stats;                 // optional: [N][stats_chunks][Cout][2] partial (sum, sum of squares) of the stored output for a following norm
     int32_t stats_chunks;         //   (ss_conv_desc::y_stats); only kernels that report chunks for the problem (gconv_stats_chunks) write it
     GTap taps[SS_MAX_TAPS];
@@ -329,7 +331,11 @@ int ss_launch_conv_in1_fold(const GConvParams& p, int pt, int pl, int ih, int iw
 bool ss_wgrad_c1_ok(int n, int xh, int xw, int C, int kh, int kw);
 size_t ss_wgrad_c1_ws(int n, int xh, int xw, int C, int kh, int kw);
 int ss_launch_wgrad_c1(int mode, const float* X, int X_cs, int C, int n, int xh, int xw, const float* S, int S_cs, int sh, int sw,
-                       int kh, int kw, int pt, int pl, int reflect, float* dw, int accumulate, void* ws, hipStream_t s);
+                       int kh, int kw, int pt, int pl, int reflect, float* dw, int accumulate, void* ws, hipStream_t s, int x_dtype = 0);
+// the matrix-core one-channel kernels take the problem (the only ones with 16-bit loaders / stores for the multi-channel tensor)
+bool ss_conv_out1_typed_ok(const GConvParams& p);
+bool ss_conv_in1_typed_ok(const GConvParams& p);
+bool ss_wgrad_c1_typed_ok(const void* X, int X_cs, int C, int xh, int xw, int kh, int kw, int pt, int pl);
 
 // fp32-exact contraction on the bf16 matrix cores (conv_mfma_x6.hip): three bf16 pieces per operand, six products
 bool ss_gconv_x6_ok(const GConvParams& p);                  // shape / alignment eligibility

@@ -22,6 +22,8 @@ struct ConvProb {
     float* y_stats = nullptr;      // forward: output statistics for a following norm (ss_conv_desc::y_stats)
     InNorm in_norm;                // forward / weight gradient: x is pre-normalisation, normalised in the operand load (ss_conv_desc::in_norm_*)
     void* saved = nullptr;         // forward -> weight gradient: the transformed input operand (ss_conv_desc::saved_operand)
+    int c1_dtype = SS_DTYPE_F32;   // one-channel layers on 16-bit storage: type of the MULTI-channel tensor, read / written by the matrix-core kernels of
+                                   // conv_c1.hip themselves (its pointer is reinterpreted); the one-channel tensor is an fp32 staging copy
 };
 
 // ---- small helper kernels -----------------------------------------------------------------------
@@ -447,6 +449,7 @@ int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStre
         if (ss_conv_out1_ok(p)) return ss_launch_conv_out1(p, s);
         if (ss_conv_in1_ok(p)) return ss_launch_conv_in1(p, s);
     }
+    if (p.c1_dtype != SS_DTYPE_F32) { ss_set_error("run_gconv: c1_dtype set on a problem the one-channel kernels do not take"); return SS_ERR_UNSUPPORTED; }
     if (p.stats && !(use_x6(algo, p) && ss_gconv_x6v2_ok(p) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p))) {
         ss_set_error("conv2d_fwd: y_stats was promised (ss_conv2d_stats_chunks) but this launch cannot take the kernel that writes it (workspace / operand alignment)");
         return SS_ERR_UNSUPPORTED;
@@ -542,6 +545,7 @@ GConvParams fwd_params(const ConvProb& c, const float* x, const float* w, const 
     p.out_s = 1; p.out_oy = 0; p.out_ox = 0;
     p.ldb = c.cout; p.reflect = c.reflect; p.act = act; p.alpha = alpha; p.accumulate = accumulate;
     p.dtype = c.dtype;
+    p.c1_dtype = c.c1_dtype;
     p.ntaps = 0;
     for (int a = 0; a < c.kh; ++a)
         for (int b = 0; b < c.kw; ++b) {
@@ -617,7 +621,7 @@ int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bia
         p.stats_chunks = gconv_stats_chunks(c, algo);
         if (p.stats_chunks > 0) p.stats = c.y_stats;
     }
-    if (need_x_amax_fwd(c, algo) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p) + 256) {
+    if (c.c1_dtype == SS_DTYPE_F32 && need_x_amax_fwd(c, algo) && ws && ws_bytes >= ss_gconv_x6_planes_bytes(p) + 256) {
         unsigned int* sl = (unsigned int*)((char*)ws + ss_gconv_x6_planes_bytes(p));
         const bool fill_only = c.wc && c.wc->fill_only;
         const AmaxRef ax = fill_only ? AmaxRef{sl, 1} : act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
@@ -681,7 +685,8 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     p.N = c.n; p.IH = c.oh; p.IW = c.ow; p.Cin = c.cout; p.in_cs = c.out_cs;
     p.in_s = 1; p.Cout = c.cin; p.ldb = c.cin; p.reflect = 0; p.act = act; p.alpha = alpha;
     p.dtype = c.dtype;
-    if (need_dy_amax_dgrad(c, algo) && gws_bytes >= x6_planes_ub(c.cout, c.cin, T)) {
+    p.c1_dtype = c.c1_dtype;
+    if (c.c1_dtype == SS_DTYPE_F32 && need_dy_amax_dgrad(c, algo) && gws_bytes >= x6_planes_ub(c.cout, c.cin, T)) {
         unsigned int* sl = (unsigned int*)((char*)gws + x6_planes_ub(c.cout, c.cin, T) - 256);
         const AmaxRef ay = (c.wc && c.wc->fill_only) ? AmaxRef{sl, 1}
                            : (c.dtype == SS_DTYPE_F32 ? act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl, s)
@@ -707,6 +712,7 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
             q.out = dx; q.out_cs = c.in_cs; q.accumulate = accumulate;
             if (ss_conv_in1_fold_ok(q, c.pt, c.pl, c.ih, c.iw)) return (c.wc && c.wc->fill_only) ? SS_OK : ss_launch_conv_in1_fold(q, c.pt, c.pl, c.ih, c.iw, s);
         }
+        if (c.c1_dtype != SS_DTYPE_F32) { ss_set_error("conv_bwd_data: c1_dtype set on a problem the folded one-channel kernel does not take"); return SS_ERR_UNSUPPORTED; }
         int rc = run_gconv(algo, p, gws, gws_bytes, s, c.wc, 1);
         if (rc != SS_OK || (c.wc && c.wc->fill_only)) return rc;
         return launch_reflect_fold(dpad, dx, c.n, c.ih, c.iw, c.cin, c.in_cs, c.pt, c.pl, PH, PW, accumulate, s);
@@ -880,10 +886,10 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
         const int m = wgrad_c1_mode(c, algo);
         if (m == 0)
             return ss_launch_wgrad_c1(0, x, c.in_cs, c.cin, c.n, c.ih, c.iw, dy, c.out_cs, c.oh, c.ow, c.kh, c.kw, c.pt, c.pl, c.reflect,
-                                      dw, accumulate, ws, s);
+                                      dw, accumulate, ws, s, c.c1_dtype);
         if (m == 1)
             return ss_launch_wgrad_c1(1, dy, c.out_cs, c.cout, c.n, c.oh, c.ow, x, c.in_cs, c.ih, c.iw, c.kh, c.kw, c.pt, c.pl, c.reflect,
-                                      dw, accumulate, ws, s);
+                                      dw, accumulate, ws, s, c.c1_dtype);
     }
     WGradParams p = wgrad_params(c, x, dy, (float*)ws);
     p.x6 = x6_wanted(algo);
@@ -1074,36 +1080,39 @@ WCache* desc_wcache(const ss_conv_desc* d) {
 }
 
 int conv2d_fwd32(const ss_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
-                  void* ws, size_t ws_bytes, void* stream) {
+                  void* ws, size_t ws_bytes, void* stream, int c1_dtype = SS_DTYPE_F32) {
     const bool fill_only = desc_wcache(d) && desc_wcache(d)->fill_only;
     if (!valid_desc(d) || !w || (!fill_only && (!x || !y))) return SS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     ConvProb c = d->transposed ? adjoint(d) : plain(d);
     c.wc = desc_wcache(d);
+    c.c1_dtype = c1_dtype;
     if (!d->transposed && d->act == SS_ACT_NONE && conv2d_stats_chunks32(d) > 0) c.y_stats = (float*)d->y_stats;
     if (!d->transposed) return conv_fwd(c, x, w, bias, y, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
     return conv_bwd_data(c, x, w, y, bias, d->act, d->act_alpha, 0, d->algo, ws, ws_bytes, s);
 }
 
 int conv2d_bwd_data32(const ss_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
-                       void* ws, size_t ws_bytes, void* stream) {
+                       void* ws, size_t ws_bytes, void* stream, int c1_dtype = SS_DTYPE_F32) {
     const bool fill_only = desc_wcache(d) && desc_wcache(d)->fill_only;
     if (!valid_desc(d) || !w || (!fill_only && (!dy || !dx))) return SS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     ConvProb c = d->transposed ? adjoint(d) : plain(d);
     c.wc = desc_wcache(d);
+    c.c1_dtype = c1_dtype;
     if (!d->transposed)
         return conv_bwd_data(c, dy, w, dx, nullptr, SS_ACT_NONE, 0.f, accumulate, d->algo, ws, ws_bytes, s);
     return conv_fwd(c, dy, w, nullptr, dx, SS_ACT_NONE, 0.f, accumulate, d->algo, ws, ws_bytes, s);
 }
 
 int conv2d_bwd_weight32(const ss_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
-                         int accumulate, void* ws, size_t ws_bytes, void* stream) {
+                         int accumulate, void* ws, size_t ws_bytes, void* stream, int c1_dtype = SS_DTYPE_F32) {
     if (!valid_desc(d) || !x || !dy || !dw) return SS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (ws_bytes < conv2d_workspace_bytes32(d, SS_PASS_BWD_WEIGHT) || !ws) return SS_ERR_WORKSPACE;
     int rc;
-    const ConvProb c = d->transposed ? adjoint(d) : plain(d);
+    ConvProb c = d->transposed ? adjoint(d) : plain(d);
+    c.c1_dtype = c1_dtype;
     const size_t main_b = bwd_weight_ws(c);
     if (!d->transposed) rc = conv_bwd_weight(c, x, dy, dw, accumulate, d->algo, ws, main_b, s);
     else rc = conv_bwd_weight(c, dy, x, dw, accumulate, d->algo, ws, main_b, s);
@@ -1323,6 +1332,77 @@ int native16_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, fl
     return ss_launch_wgrad_reduce(p, dw, c.cout, accumulate, p.ntaps * p.Ca, s);
 }
 
+// ---- one-channel layers (the generators' 7x7 stem / head, the discriminators' 4x4 stem) on 16-bit storage ------------------------------
+// The matrix-core kernels of conv_c1.hip read / write the MULTI-channel tensor in its stored type themselves (GConvParams::c1_dtype,
+// C1WParams::x_dtype); only the ONE-channel tensor (1 / C of the bytes) goes through an fp32 staging copy in the shim's buffers.  The
+// predicates below say whether the fp32 path would hand the problem to exactly those kernels; `dm` = the shim descriptor with the
+// multi-channel side's real stride.  Returns 0: no; 1: the input side is the one-channel tensor; 2: the output side is.
+bool c1_algo(int algo) { return algo == SS_ALGO_AUTO || algo == SS_ALGO_X6; }
+int c1_typed_fwd(const ss_conv_desc* d, const ConvShim& sh, const void* x, const float* w, const float* bias, void* y, ss_conv_desc* dm) {
+    if (d->transposed || !c1_algo(d->algo) || d->kh * d->kw > SS_MAX_TAPS) return 0;
+    *dm = sh.d32;
+    WinoProb q;
+    if (d->cin == 1 && d->cout > 1) {
+        dm->out_cstride = d->out_cstride;
+        ConvProb c = plain(dm);
+        c.c1_dtype = d->dtype;
+        if (wino_fwd_prob(c, d->algo, &q)) return 0;
+        const GConvParams p = fwd_params(c, sh.a, w, bias, (float*)y, d->act, d->act_alpha, 0);
+        return ss_conv_in1_typed_ok(p) ? 1 : 0;
+    }
+    if (d->cout == 1 && d->cin > 1) {
+        dm->in_cstride = d->in_cstride;
+        ConvProb c = plain(dm);
+        c.c1_dtype = d->dtype;
+        if (wino_fwd_prob(c, d->algo, &q)) return 0;
+        const GConvParams p = fwd_params(c, (const float*)x, w, bias, sh.b, d->act, d->act_alpha, 0);
+        return ss_conv_out1_typed_ok(p) ? 2 : 0;
+    }
+    return 0;
+}
+// data gradient of a reflection-padded C -> 1 layer (the head): dy is the one-channel tensor, dx is written in its stored type by the
+// folded 1 -> C kernel (the q of conv_bwd_data's reflect branch)
+bool c1_typed_dgrad(const ss_conv_desc* d, const ConvShim& sh, void* dx, int accumulate, ss_conv_desc* dm) {
+    if (d->transposed || !c1_algo(d->algo) || d->kh * d->kw > SS_MAX_TAPS || d->cout != 1 || d->cin <= 1) return false;
+    *dm = sh.d32;
+    dm->in_cstride = d->in_cstride;
+    const ConvProb c = plain(dm);
+    WinoProb wq;
+    if (!c.reflect || c.s != 1 || wino_dgrad_prob(c, d->algo, &wq)) return false;
+    GConvParams q{};
+    q.in = sh.b; q.N = c.n; q.IH = c.oh; q.IW = c.ow; q.Cin = c.cout; q.in_cs = c.out_cs;
+    q.in_s = 1; q.Cout = c.cin; q.ldb = c.cin; q.reflect = 0; q.act = SS_ACT_NONE;
+    q.OH = c.oh + c.kh - 1; q.OW = c.ow + c.kw - 1; q.OHc = q.OH; q.OWc = q.OW;
+    q.out_s = 1; q.ntaps = 0;
+    for (int a = 0; a < c.kh; ++a)
+        for (int b = 0; b < c.kw; ++b) {
+            GTap& t = q.taps[q.ntaps++];
+            t.dy = (int16_t)(-a); t.dx = (int16_t)(-b); t.woff = (a * c.kw + b) * c.cin * c.cout;
+        }
+    q.out = (float*)dx; q.out_cs = c.in_cs; q.accumulate = accumulate;
+    q.c1_dtype = d->dtype;
+    return ss_conv_in1_fold_ok(q, c.pt, c.pl, c.ih, c.iw);
+}
+// weight gradient: 1 = the input side is the one-channel tensor (X = dy), 2 = the output side is (X = x)
+int c1_typed_wgrad(const ss_conv_desc* d, const ConvShim& sh, const void* x, const void* dy, const float* dbias, ss_conv_desc* dm) {
+    if (d->transposed || !c1_algo(d->algo) || d->kh * d->kw > SS_MAX_TAPS) return 0;
+    *dm = sh.d32;
+    WinoProb q;
+    if (d->cin == 1 && d->cout > 1 && !dbias) {          // (the bias gradient sums dy: the multi-channel tensor here)
+        dm->out_cstride = d->out_cstride;
+        const ConvProb c = plain(dm);
+        if (wino_fwd_prob(c, d->algo, &q) || wgrad_c1_mode(c, d->algo) != 1) return 0;
+        return ss_wgrad_c1_typed_ok(dy, c.out_cs, c.cout, c.oh, c.ow, c.kh, c.kw, c.pt, c.pl) ? 1 : 0;
+    }
+    if (d->cout == 1 && d->cin > 1) {
+        dm->in_cstride = d->in_cstride;
+        const ConvProb c = plain(dm);
+        if (wino_fwd_prob(c, d->algo, &q) || wgrad_c1_mode(c, d->algo) != 0) return 0;
+        return ss_wgrad_c1_typed_ok(x, c.in_cs, c.cin, c.ih, c.iw, c.kh, c.kw, c.pt, c.pl) ? 2 : 0;
+    }
+    return 0;
+}
+
 bool valid_desc_any(const ss_conv_desc* d) {
     if (!d) { ss_set_error("ss_conv_desc is NULL"); return false; }
     if (d->struct_size != sizeof(ss_conv_desc)) return valid_desc(d);          // sets the message
@@ -1426,6 +1506,20 @@ int ss_conv2d_fwd(const ss_conv_desc* d, const void* x, const float* w, const fl
     int rc = native16_fwd(d, x, w, bias, y, ws, ws_bytes, s, &taken);
     if (taken) return rc;
     const ConvShim sh = make_shim(d, ws, ws_bytes);
+    {   // one-channel layers: only the one-channel tensor is staged, the matrix-core kernel reads / writes the other one as stored
+        ss_conv_desc dm;
+        const int side = c1_typed_fwd(d, sh, x, w, bias, y, &dm);
+        if (side == 1) {
+            rc = ss_convert_launch(x, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, 1, (long)d->n * d->ih * d->iw, 1, s);
+            if (rc != SS_OK) return rc;
+            return conv2d_fwd32(&dm, sh.a, w, bias, (float*)y, sh.ws, sh.ws_bytes, stream, d->dtype);
+        }
+        if (side == 2) {
+            rc = conv2d_fwd32(&dm, (const float*)x, w, bias, sh.b, sh.ws, sh.ws_bytes, stream, d->dtype);
+            if (rc != SS_OK) return rc;
+            return ss_convert_launch(sh.b, SS_DTYPE_F32, 1, y, d->dtype, d->out_cstride, (long)d->n * d->oh * d->ow, 1, s);
+        }
+    }
     rc = ss_convert_launch(x, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, d->cin, (long)d->n * d->ih * d->iw, d->cin, s);
     if (rc != SS_OK) return rc;
     rc = conv2d_fwd32(&sh.d32, sh.a, w, bias, sh.b, sh.ws, sh.ws_bytes, stream);
@@ -1453,6 +1547,14 @@ int ss_conv2d_bwd_data(const ss_conv_desc* d, const void* dy, const float* w, vo
     if (taken) return rc;
     const ConvShim sh = make_shim(d, ws, ws_bytes);
     const long xr = (long)d->n * d->ih * d->iw, yr = (long)d->n * d->oh * d->ow;
+    {   // reflection-padded C -> 1 head: dy (one channel) staged, dx written as stored by the folded matrix-core kernel
+        ss_conv_desc dm;
+        if (c1_typed_dgrad(d, sh, dx, accumulate, &dm)) {
+            rc = ss_convert_launch(dy, d->dtype, d->out_cstride, sh.b, SS_DTYPE_F32, 1, yr, 1, s);
+            if (rc != SS_OK) return rc;
+            return conv2d_bwd_data32(&dm, sh.b, w, (float*)dx, accumulate, sh.ws, sh.ws_bytes, stream, d->dtype);
+        }
+    }
     rc = ss_convert_launch(dy, d->dtype, d->out_cstride, sh.b, SS_DTYPE_F32, d->cout, yr, d->cout, s);
     if (rc != SS_OK) return rc;
     if (accumulate) {
@@ -1475,6 +1577,20 @@ int ss_conv2d_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, f
     int rc = native16_bwd_weight(d, x, dy, dw, dbias, accumulate, ws, ws_bytes, s, &taken);
     if (taken) return rc;
     const ConvShim sh = make_shim(d, ws, ws_bytes);
+    {   // one-channel layers: the multi-channel operand is read as stored
+        ss_conv_desc dm;
+        const int side = c1_typed_wgrad(d, sh, x, dy, dbias, &dm);
+        if (side == 1) {
+            rc = ss_convert_launch(x, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, 1, (long)d->n * d->ih * d->iw, 1, s);
+            if (rc != SS_OK) return rc;
+            return conv2d_bwd_weight32(&dm, sh.a, (const float*)dy, dw, dbias, accumulate, sh.ws, sh.ws_bytes, stream, d->dtype);
+        }
+        if (side == 2) {
+            rc = ss_convert_launch(dy, d->dtype, d->out_cstride, sh.b, SS_DTYPE_F32, 1, (long)d->n * d->oh * d->ow, 1, s);
+            if (rc != SS_OK) return rc;
+            return conv2d_bwd_weight32(&dm, (const float*)x, sh.b, dw, dbias, accumulate, sh.ws, sh.ws_bytes, stream, d->dtype);
+        }
+    }
     rc = ss_convert_launch(x, d->dtype, d->in_cstride, sh.a, SS_DTYPE_F32, d->cin, (long)d->n * d->ih * d->iw, d->cin, s);
     if (rc != SS_OK) return rc;
     rc = ss_convert_launch(dy, d->dtype, d->out_cstride, sh.b, SS_DTYPE_F32, d->cout, (long)d->n * d->oh * d->ow, d->cout, s);

@@ -11,6 +11,21 @@
 
 namespace {
 
+// storage type of the MULTI-channel tensor of a one-channel layer (GConvParams::c1_dtype, C1WParams::x_dtype): four consecutive channels
+// <-> f32x4 (the 16-bit types: one 8-byte access); the one-channel tensor is always fp32
+typedef _Float16 c1_f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 c1_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 c1_ld4(const float* q) { return *(const f32x4*)q; }
+__device__ __forceinline__ f32x4 c1_ld4(const _Float16* q) { return __builtin_convertvector(*(const c1_f16x4*)q, f32x4); }
+__device__ __forceinline__ f32x4 c1_ld4(const __bf16* q) { return __builtin_convertvector(*(const c1_bf16x4*)q, f32x4); }
+__device__ __forceinline__ void c1_st4(float* q, f32x4 v) { *(f32x4*)q = v; }
+__device__ __forceinline__ void c1_st4(_Float16* q, f32x4 v) { *(c1_f16x4*)q = __builtin_convertvector(v, c1_f16x4); }
+__device__ __forceinline__ void c1_st4(__bf16* q, f32x4 v) { *(c1_bf16x4*)q = __builtin_convertvector(v, c1_bf16x4); }
+__device__ __forceinline__ f32x4 c1_round(f32x4 v, const float*) { return v; }          // the value as stored
+__device__ __forceinline__ f32x4 c1_round(f32x4 v, const _Float16*) { return __builtin_convertvector(__builtin_convertvector(v, c1_f16x4), f32x4); }
+__device__ __forceinline__ f32x4 c1_round(f32x4 v, const __bf16*) { return __builtin_convertvector(__builtin_convertvector(v, c1_bf16x4), f32x4); }
+
+
 constexpr int C1_TW = 64, C1_TH = 16;        // output tile of a 256-thread block: thread = 4 consecutive x in one row
 
 struct C1Box { int dy0, dx0, kh, kw; };
@@ -225,7 +240,7 @@ __device__ __forceinline__ void c1_lds_barrier() { asm volatile("s_waitcnt lgkmc
 
 // S: input stride (1, or 2: the discriminators' 4x4 stride-2 stem -- the halo tile is S x larger each way, a lane's 8 k-values are still 8
 // consecutive floats of one halo row)
-template <bool FOLD, int S = 1>
+template <bool FOLD, int S = 1, typename TO = float>          // TO: storage type of the C-channel output
 __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1Box box, C1Fold f, int ntiles, int tiles_x, int tiles_y, int dbg) {
     constexpr int HS = S == 1 ? I1_HS : 2 * I1_TW + 8, HR = S * (I1_TH - 1) + 8;          // halo row stride / rows (boxes up to 8 x 8)
     static_assert(!FOLD || S == 1, "the folded data gradient is a stride-1 problem");
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
             const int c = (lane & 15) * 4;
             if (cbase + c < p.Cout) {
                 const f32x4 b4 = *(const f32x4*)(bias_s + c);
-                float* const orow = p.out + ((long)(n * OH + qy) * OW + xb0) * p.out_cs + cbase + c;
+                TO* const orow = (TO*)p.out + ((long)(n * OH + qy) * OW + xb0) * p.out_cs + cbase + c;
                 // ACC / PLAIN compile-time inside the store loop: a conditional `v += load` there makes the compiler wait for vmcnt(0)
                 // around every store (each store then waits for the previous one's round trip AND for the halo prefetch)
                 auto stores = [&](auto acc_c, auto plain_c) {
@@ -440,12 +455,13 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
                         f32x4 v = *(const f32x4*)(tb + px * I1_ES + c);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = PLAIN ? v[e] + b4[e] : ss_apply_act(v[e] + b4[e], p.act, p.alpha);
-                        float* op = orow + (long)px * p.out_cs;
-                        if (ACC) v += *(const f32x4*)op;
-                        if (!(dbg & 4)) *(f32x4*)op = v;          // dbg 4: no global stores
+                        TO* op = orow + (long)px * p.out_cs;
+                        if (ACC) v += c1_ld4(op);
+                        if (!(dbg & 4)) c1_st4(op, v);          // dbg 4: no global stores
                         if (!FOLD) {
+                            const f32x4 sv = c1_round(v, (const TO*)nullptr);          // statistics of the STORED values
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { st1[e] += v[e]; st2[e] = fmaf(v[e], v[e], st2[e]); }
+                            for (int e = 0; e < 4; ++e) { st1[e] += sv[e]; st2[e] = fmaf(sv[e], sv[e], st2[e]); }
                         }
                     }
                 };
@@ -488,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_x3h_kernel(GConvParams p, C1B
 // (halo overhead 1.3x, mostly L2 hits), LDS traffic is 450 bytes per halo pixel.
 constexpr int O1_TH = 32, O1_ZS = 132;          // output rows per tile; floats per tap row of the Z stage (128 pixels + pad)
 
-template <int CQ>          // channel steps of 16: C == 16 * CQ (CQ = 2, 4)
+template <int CQ, typename TI = float>          // channel steps of 16: C == 16 * CQ (CQ = 2, 4); TI: storage type of the C-channel input
 __global__ __launch_bounds__(256, 2) void conv_out1_x3h_kernel(GConvParams p, C1Box box, int ntiles, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) float o1_lds[];
     float* const zs = o1_lds;                                   // [2][64 taps][O1_ZS]
@@ -555,11 +571,11 @@ __global__ __launch_bounds__(256, 2) void conv_out1_x3h_kernel(GConvParams p, C1
         int ix = ss_map_index(x0 + p.in_ox + box.dx0 + hc, p.IW, p.reflect);
         xvalid = hr < HRN && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;          // tiles past the image edge reflect out of range
         if (xvalid) {
-            const float* src = p.in + ((long)(n * p.IH + iy) * p.IW + ix) * p.in_cs + 8 * lh;
+            const TI* src = (const TI*)p.in + ((long)(n * p.IH + iy) * p.IW + ix) * p.in_cs + 8 * lh;
 #pragma unroll
             for (int q = 0; q < CQ; ++q) {
-                xr[q][0] = *(const f32x4*)(src + 16 * q);
-                xr[q][1] = *(const f32x4*)(src + 16 * q + 4);
+                xr[q][0] = c1_ld4(src + 16 * q);
+                xr[q][1] = c1_ld4(src + 16 * q + 4);
             }
         }
     };
@@ -722,6 +738,7 @@ struct C1WParams {
     int kh, kw, pt, pl, reflect;
     int tiles_y, tiles_x, ntiles;
     int dbg;                       // measurement only (tile_dbg): 1 no X loads, 2 no U build, 4 no MFMAs, 8 no X split / stores
+    int x_dtype;                   // ss_dtype of X (the matrix-core kernel only); S is fp32
 };
 constexpr int C1W_TH = 4, C1W_TW = 64, C1W_PIX = C1W_TH * C1W_TW, C1W_T = 64;
 
@@ -879,7 +896,7 @@ __device__ __forceinline__ c1_s16x4 c1_tr4(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c1_s16x4*)p);
 }
 
-template <int MODE>
+template <int MODE, typename TX = float>          // TX: storage type of the C-channel tensor X
 __global__ __launch_bounds__(256, 2) void wgrad_c1_x3h_kernel(C1WParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xw_lds[];
     unsigned char* const sX = xw_lds;                              // [XW_PIX][XW_PS]
@@ -931,7 +948,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_x3h_kernel(C1WParams p) {
             const int px = (tid >> 4) + 16 * j;
             const int qy = y0 + px / XW_TW, qx = x0 + px % XW_TW;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (qy < p.XH && qx < p.XW && cu < p.C && !(p.dbg & 1)) v = *(const f32x4*)(p.X + ((long)(n * p.XH + qy) * p.XW + qx) * p.X_cs + cu);
+            if (qy < p.XH && qx < p.XW && cu < p.C && !(p.dbg & 1)) v = c1_ld4((const TX*)p.X + ((long)(n * p.XH + qy) * p.XW + qx) * p.X_cs + cu);
             if (p.dbg & 1) v[0] = 1.f;
             px_[j] = v;
         }
@@ -1121,21 +1138,27 @@ int launch_wgrad_c1(const C1WParams& p, float* dw, int accumulate, hipStream_t s
     return SS_OK;
 }
 
-template <int MODE>
-int launch_wgrad_c1_x3h(const C1WParams& p, float* dw, int accumulate, hipStream_t s) {
+template <int MODE, typename TX>
+int launch_wgrad_c1_x3h_t(const C1WParams& p, float* dw, int accumulate, hipStream_t s) {
     const size_t smem = (size_t)2 * XW_PIX * XW_PS + (size_t)(XW_TH + p.kh - 1) * (XW_TW + p.kw - 1) * sizeof(float);
     static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)wgrad_c1_x3h_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);      // + the static `red`
+        (void)hipFuncSetAttribute((const void*)wgrad_c1_x3h_kernel<MODE, TX>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);      // + the static `red`
         return true;
     }();
     (void)attr_set;
     const int nblk = c1w_blocks(p.ntiles);
-    hipLaunchKernelGGL((wgrad_c1_x3h_kernel<MODE>), dim3(nblk, (p.C + 63) / 64), dim3(256), smem, s, p);
+    hipLaunchKernelGGL((wgrad_c1_x3h_kernel<MODE, TX>), dim3(nblk, (p.C + 63) / 64), dim3(256), smem, s, p);
     SS_LAUNCH_CHECK();
     const int total = p.kh * p.kw * p.C;
     hipLaunchKernelGGL(wgrad_c1_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p.part, nblk, total, dw, accumulate);
     SS_LAUNCH_CHECK();
     return SS_OK;
+}
+template <int MODE>
+int launch_wgrad_c1_x3h(const C1WParams& p, float* dw, int accumulate, hipStream_t s) {
+    if (p.x_dtype == SS_DTYPE_F16) return launch_wgrad_c1_x3h_t<MODE, _Float16>(p, dw, accumulate, s);
+    if (p.x_dtype == SS_DTYPE_BF16) return launch_wgrad_c1_x3h_t<MODE, __bf16>(p, dw, accumulate, s);
+    return launch_wgrad_c1_x3h_t<MODE, float>(p, dw, accumulate, s);
 }
 
 }  // namespace
@@ -1153,27 +1176,40 @@ namespace {
 bool out1_x3h_shape(const GConvParams& p, const C1Box& box) {
     return ss_tuning().c1_mfma && (p.Cin == 32 || p.Cin == 64) && box.kh <= 8 && box.kw <= 8 && p.dtype == SS_DTYPE_F32;
 }
-template <int CQ>
-int launch_out1_x3h(const GConvParams& p, const C1Box& box, hipStream_t s) {
+template <int CQ, typename TI>
+int launch_out1_x3h_t(const GConvParams& p, const C1Box& box, hipStream_t s) {
     const size_t smem = (size_t)(2 * 64 * O1_ZS + O1_TH * 64 + 64 + 4) * sizeof(float);
     static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)conv_out1_x3h_kernel<CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_out1_x3h_kernel<CQ, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
     const int TW = 64 - (box.kw - 1);
     const int tiles_y = (p.OH + O1_TH - 1) / O1_TH, tiles_x = (p.OW + TW - 1) / TW;
     const int ntiles = p.N * tiles_y * tiles_x;
-    hipLaunchKernelGGL((conv_out1_x3h_kernel<CQ>), dim3(ntiles < 511 ? ntiles : 511), dim3(256), smem, s, p, box, ntiles, tiles_x, tiles_y);
+    hipLaunchKernelGGL((conv_out1_x3h_kernel<CQ, TI>), dim3(ntiles < 511 ? ntiles : 511), dim3(256), smem, s, p, box, ntiles, tiles_x, tiles_y);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
+template <int CQ>
+int launch_out1_x3h(const GConvParams& p, const C1Box& box, hipStream_t s) {
+    if (p.c1_dtype == SS_DTYPE_F16) return launch_out1_x3h_t<CQ, _Float16>(p, box, s);
+    if (p.c1_dtype == SS_DTYPE_BF16) return launch_out1_x3h_t<CQ, __bf16>(p, box, s);
+    return launch_out1_x3h_t<CQ, float>(p, box, s);
+}
 }  // namespace
+
+// the matrix-core kernel takes the problem: the only one that reads a 16-bit stored input (GConvParams::c1_dtype)
+bool ss_conv_out1_typed_ok(const GConvParams& p) {
+    C1Box box;
+    return ss_conv_out1_ok(p) && tap_box(p, &box) && out1_x3h_shape(p, box);
+}
 
 int ss_launch_conv_out1(const GConvParams& p, hipStream_t s) {
     C1Box box;
     if (!ss_conv_out1_ok(p) || !tap_box(p, &box)) return SS_ERR_UNSUPPORTED;
     if (out1_x3h_shape(p, box)) return p.Cin == 64 ? launch_out1_x3h<4>(p, box, s) : launch_out1_x3h<2>(p, box, s);
+    if (p.c1_dtype != SS_DTYPE_F32) { ss_set_error("conv_out1: only the matrix-core kernel reads a 16-bit stored input (ss_conv_out1_typed_ok)"); return SS_ERR_UNSUPPORTED; }
     if (box.kh == 7) return launch_out1<7, 7>(p, box, s);
     if (box.kh == 4) return launch_out1<4, 4>(p, box, s);
     return launch_out1<3, 3>(p, box, s);
@@ -1194,9 +1230,15 @@ int launch_in1_x3h(const GConvParams& p, const C1Box& box, const C1Fold& f, hipS
     const int gy = (p.Cout + 63) / 64;
     const dim3 grid(ntiles < 511 ? ntiles : 511, gy);          // odd: the tiles of one image column (the border columns are slower) spread over all workgroups
     const int dbg = ss_tuning().tile_dbg;
-    if (f.on) hipLaunchKernelGGL((conv_in1_x3h_kernel<true, 1>), grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
-    else if (p.in_s == 2) hipLaunchKernelGGL((conv_in1_x3h_kernel<false, 2>), grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
-    else hipLaunchKernelGGL((conv_in1_x3h_kernel<false, 1>), grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
+    auto go = [&](auto tc) {
+        typedef decltype(tc) TO;
+        if (f.on) hipLaunchKernelGGL((conv_in1_x3h_kernel<true, 1, TO>), grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
+        else if (p.in_s == 2) hipLaunchKernelGGL((conv_in1_x3h_kernel<false, 2, TO>), grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
+        else hipLaunchKernelGGL((conv_in1_x3h_kernel<false, 1, TO>), grid, dim3(256), 0, s, p, box, f, ntiles, tiles_x, tiles_y, dbg);
+    };
+    if (p.c1_dtype == SS_DTYPE_F16) go((_Float16)0);
+    else if (p.c1_dtype == SS_DTYPE_BF16) go((__bf16)0);
+    else go(0.f);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -1236,10 +1278,17 @@ bool ss_conv_in1_ok(const GConvParams& p) {
     return (box.kh == 7 && box.kw == 7) || (box.kh == 4 && box.kw == 4) || (box.kh == 3 && box.kw == 3);
 }
 
+// the matrix-core kernel takes the problem: the only one that writes a 16-bit stored output (GConvParams::c1_dtype)
+bool ss_conv_in1_typed_ok(const GConvParams& p) {
+    C1Box box;
+    return ss_conv_in1_ok(p) && in1_x3h_shape(p, &box);
+}
+
 int ss_launch_conv_in1(const GConvParams& p, hipStream_t s) {
     C1Box box;
     if (!ss_conv_in1_ok(p) || !tap_box(p, &box)) return SS_ERR_UNSUPPORTED;
     if (in1_x3h_shape(p, &box)) return launch_in1_x3h(p, box, C1Fold{0, 0, 0, 0, 0}, s);
+    if (p.c1_dtype != SS_DTYPE_F32) { ss_set_error("conv_in1: only the matrix-core kernel writes a 16-bit stored output (ss_conv_in1_typed_ok)"); return SS_ERR_UNSUPPORTED; }
     if (p.stats) { ss_set_error("conv_in1: output statistics requested on the VALU path"); return SS_ERR_UNSUPPORTED; }
     if (box.kh == 7) return launch_in1<7, 7>(p, box, s);
     if (box.kh == 4) return launch_in1<4, 4>(p, box, s);
@@ -1258,15 +1307,25 @@ size_t ss_wgrad_c1_ws(int n, int xh, int xw, int C, int kh, int kw) {
     return ss_align_up((size_t)c1w_blocks(ntiles) * kh * kw * C * sizeof(float), 256);
 }
 
+// the matrix-core kernel takes the problem: the only one that reads a 16-bit stored X
+bool ss_wgrad_c1_typed_ok(const void* X, int X_cs, int C, int xh, int xw, int kh, int kw, int pt, int pl) {
+    return ss_tuning().c1_mfma && C % 4 == 0 && X_cs % 4 == 0 && (((uintptr_t)X) & 15) == 0 && (XW_TH + kh - 1) * (XW_TW + kw - 1) <= 768 &&
+           xh >= 2 * pt + 4 && xw >= 2 * pl + 4;
+}
+
 int ss_launch_wgrad_c1(int mode, const float* X, int X_cs, int C, int n, int xh, int xw, const float* S, int S_cs, int sh, int sw,
-                       int kh, int kw, int pt, int pl, int reflect, float* dw, int accumulate, void* ws, hipStream_t s) {
+                       int kh, int kw, int pt, int pl, int reflect, float* dw, int accumulate, void* ws, hipStream_t s, int x_dtype) {
     C1WParams p{};
     p.X = X; p.S = S; p.part = (float*)ws;
     p.N = n; p.XH = xh; p.XW = xw; p.C = C; p.X_cs = X_cs;
     p.SH = sh; p.SW = sw; p.S_cs = S_cs;
     p.kh = kh; p.kw = kw; p.pt = pt; p.pl = pl; p.reflect = reflect;
-    if (ss_tuning().c1_mfma && C % 4 == 0 && X_cs % 4 == 0 && (((uintptr_t)X) & 15) == 0 && (XW_TH + kh - 1) * (XW_TW + kw - 1) <= 768 &&
-        xh >= 2 * pt + 4 && xw >= 2 * pl + 4) {
+    p.x_dtype = x_dtype;
+    if (x_dtype != SS_DTYPE_F32 && !ss_wgrad_c1_typed_ok(X, X_cs, C, xh, xw, kh, kw, pt, pl)) {
+        ss_set_error("wgrad_c1: only the matrix-core kernel reads a 16-bit stored X (ss_wgrad_c1_typed_ok)");
+        return SS_ERR_UNSUPPORTED;
+    }
+    if (ss_wgrad_c1_typed_ok(X, X_cs, C, xh, xw, kh, kw, pt, pl)) {
         p.dbg = ss_tuning().tile_dbg;
         p.tiles_y = (xh + XW_TH - 1) / XW_TH;
         p.tiles_x = (xw + XW_TW - 1) / XW_TW;

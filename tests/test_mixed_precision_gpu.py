@@ -50,6 +50,13 @@ CONV_CASES = [
     ("gather16_down_s2_32_64_ragged", 3, 32, 64, 2, "same", False, False, 3, 100, 90),
     ("up_T3", 3, 64, 32, 2, "same", False, True, 2, 32, 32),
     ("stem7_reflect", 7, 1, 16, 1, ("reflect", 3), False, False, 1, 64, 64),
+    # one-channel layers at full resolution: the matrix-core kernels of conv_c1.hip read / write the multi-channel tensor as stored, only
+    # the one-channel tensor is staged in fp32 (stem forward + weight gradient; head forward + folded data gradient + weight gradient
+    # with its bias gradient; the discriminators' stride-2 stem forward)
+    ("c1_stem7_reflect_1_64", 7, 1, 64, 1, ("reflect", 3), False, False, 1, 256, 256),
+    ("c1_head7_reflect_64_1_bias", 7, 64, 1, 1, ("reflect", 3), True, False, 1, 256, 256),
+    ("c1_head7_reflect_32_1_ragged", 7, 32, 1, 1, ("reflect", 3), False, False, 2, 200, 180),
+    ("c1_disc_stem_4x4_s2_1_128_bias", 4, 1, 128, 2, "valid", True, False, 2, 258, 258),
     ("unet_upT2_bias", 2, 26, 16, 2, "same", True, True, 2, 32, 32),
 ]
 

@@ -193,16 +193,19 @@ def main():
     # defines the combined figure; the overlapped rate is reported as the extra leg `overlapped`.
     overlap_unet = os.environ.get("SS_OVERLAP_UNET", "0") == "1"
     u_stream = E.side_streams(dev, 12)[10] if dev.type == "cuda" else None
-    umodel.side_stream_index = 11          # the UNet's own side streams (weight gradients, ResPaths) apart from the CycleGAN chains'
+    # (sequential steps: the UNet's side streams are the first of engine.side_streams, shared with the CycleGAN chains that are idle
+    # then -- measured 34.1 - 35.1 ms per UNet step against 36.6 - 36.9 on streams of its own created after them; beside the CycleGAN
+    # step it takes streams apart from the chains')
 
     def step(cyclegan=not args.only_unet, unet_=not args.skip_unet, overlap=overlap_unet):
         if overlap and cyclegan and unet_:
             cur = torch.cuda.current_stream()
             u_stream.wait_stream(cur)
-            umodel.sync_metrics = False
+            umodel.sync_metrics, keep = False, umodel.stream_indices
+            umodel.stream_indices = keep if keep is not None else [11, 12, 13, 12, 13]
             with torch.cuda.stream(u_stream):
                 umodel.train_step((ux.t, uy.t))
-            umodel.sync_metrics = True
+            umodel.sync_metrics, umodel.stream_indices = True, keep
             model.train_step((a, b))
             cur.wait_stream(u_stream)
             return

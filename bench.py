@@ -335,7 +335,7 @@ def main():
         x6, x3h = L.config_get("x6"), L.config_get("x3h")
         store = {"f32": "f32", "bf16": "bf16", "f16": "f16"}[args.dtype]
         arith = (store + " activation storage" + ("" if store == "f32" else " (fp32 master weights, statistics and accumulation; "
-                 "tile kernels and the Winograd trunk (one fp16 plane per operand, one product in forward / data gradient; weight gradient on the x3h planes) read and write the stored type, the strided / transposed / 7x7 convolutions run on fp32 staging copies)") + " + f32 accumulate; contractions on the 16-bit matrix cores with fp32-grade operand splits: "
+                 "tile kernels, the Winograd trunk (one fp16 plane per operand, one product in forward / data gradient; weight gradient on the x3h planes), the strided / transposed / 4x4 gather kernels and the one-channel 7x7 layers read and write the stored type; the discriminators' stem data gradient and 512 -> 1 head run on fp32 staging copies)") + " + f32 accumulate; contractions on the 16-bit matrix cores with fp32-grade operand splits: "
                  + ("x3h = 2 fp16 pieces under power-of-two scales (per tile in the Winograd GEMMs, per tensor elsewhere), 3 products"
                     if x3h else "x6 = exact 3-piece bf16 split, 6 products")) if x6 else "f32 everywhere (v_mfma_f32_32x32x2_f32)"
         what = "CycleGAN+UNet" if not (args.only_unet or args.skip_unet) else ("UNet" if args.only_unet else "CycleGAN")

@@ -10,3 +10,6 @@ bash tools/profile_run.sh ${tag}_unet --only-unet
 (cd /tmp && export TMPDIR=/tmp && python $repo/tools/pmc_traffic.py --out $repo/gpurun_out/${tag}_pmc_traffic.json > $repo/gpurun_out/${tag}_pmc.log 2>&1)
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_n1.json 2> gpurun_out/${tag}_bench.err
 python bench.py --global-batch 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/${tag}_bench_b1.json 2>> gpurun_out/${tag}_bench.err
+python bench.py --config 2 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/${tag}_bench_cfg2.json 2>> gpurun_out/${tag}_bench.err
+python bench.py --config 3 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/${tag}_bench_cfg3.json 2>> gpurun_out/${tag}_bench.err
+python bench.py --config 5 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/${tag}_bench_cfg5.json 2>> gpurun_out/${tag}_bench.err

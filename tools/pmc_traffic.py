@@ -31,7 +31,7 @@ def short(name):
 
 
 def run_pass(counter, outdir, bench_args):
-    env = dict(os.environ, SS_DUAL_STREAM="0", TMPDIR="/tmp")
+    env = dict(os.environ, SS_DUAL_STREAM="0", SS_UNET_BRANCHES="0", SS_UNET_WGRAD_STREAM="0", TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", outdir, "--",
            sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"] + bench_args
     subprocess.run(cmd, check=True, env=env, cwd="/tmp", stdout=subprocess.DEVNULL)

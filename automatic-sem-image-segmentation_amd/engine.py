@@ -34,6 +34,25 @@ def _stream():
     return ctypes.c_void_p(_RAW_STREAM(_DEV_INDEX))
 
 
+_STREAM_OBJS = {}
+
+
+def current_stream_obj():
+    """torch's CURRENT stream as a Stream object, from a table keyed by the raw handle: ``torch.cuda.current_stream()`` builds a new
+    object per call (~8 us with its device-index checks; the per-GPU-batch-1 MultiResUNet step is paced by the host: 14 ms to issue
+    11 ms of kernels, a fifth of it in such calls)."""
+    raw = _stream().value or 0
+    obj = _STREAM_OBJS.get(raw)
+    if obj is None:
+        obj = _STREAM_OBJS[raw] = torch.cuda.current_stream()
+    return obj
+
+
+def raw_stream(stream):
+    """hipStream_t of a torch Stream object as the C ABI takes it."""
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
 _SIDE = {}
 
 
@@ -45,13 +64,16 @@ def side_streams(device, n=2):
     if len(have) < n:
         have = have + tuple(torch.cuda.Stream(device=device) for _ in range(n - len(have)))
         _SIDE[key] = have
+        for st in have:
+            _STREAM_OBJS.setdefault(st.cuda_stream, st)
     return have[:n]
 
 
-def workspace(nbytes, device):
+def workspace(nbytes, device, stream=None):
     """Grow-only scratch buffer shared by all calls on a (device, stream): use is stream-ordered, so concurrent chains on
-    different streams get different buffers."""
-    key = (device.type, device.index, (_stream().value or 0) if device.type == "cuda" else 0)
+    different streams get different buffers.  stream = the raw handle (int) of the stream the caller launches on when that is not
+    torch's current one."""
+    key = (device.type, device.index, ((_stream().value or 0) if stream is None else stream) if device.type == "cuda" else 0)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -340,13 +362,9 @@ class Tape:
     def record(self, fn):
         if self.enabled:
             lane = self.lane
-            if lane is None:
-                self.ops.append(fn)
-            else:
-                def on_lane(fn=fn, stream=lane.stream):
-                    with torch.cuda.stream(stream):
-                        fn()
-                self.ops.append(on_lane)
+            if lane is not None:
+                fn._lane_stream = lane.stream          # replayed on the branch's stream (closures are fresh function objects)
+            self.ops.append(fn)
 
     def fork(self, stream):
         """A Branch of the graph that runs on ``stream`` beside the rest (see Branch).  Call where the branch's inputs are final
@@ -354,15 +372,31 @@ class Tape:
         return Branch(self, stream)
 
     def backward(self):
-        for fn in reversed(self.ops):
-            fn()
+        # consecutive closures of one branch replay inside ONE stream context (entering / leaving torch's context costs ~25 us:
+        # per closure it was 1.3 ms of host time per MultiResUNet step, which is host-bound at per-GPU batch 1)
+        ctx, ctx_stream = None, None
+        try:
+            for fn in reversed(self.ops):
+                st = getattr(fn, "_lane_stream", None)
+                if st is not ctx_stream:
+                    if ctx is not None:
+                        ctx.__exit__(None, None, None)
+                        ctx = None
+                    if st is not None:
+                        ctx = torch.cuda.stream(st)
+                        ctx.__enter__()
+                    ctx_stream = st
+                fn()
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
         self.ops = []
         self.join_wgrad_stream()
 
     def join_wgrad_stream(self):
         """The current stream waits for everything issued on the weight-gradient side stream."""
         if self.wgrad_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            current_stream_obj().wait_stream(self.wgrad_stream)
 
 
 class Branch:
@@ -385,12 +419,12 @@ class Branch:
 
     def __init__(self, tape, stream):
         self.tape, self.stream = tape, stream
-        self.inputs_ready = torch.cuda.current_stream().record_event()
+        self.inputs_ready = current_stream_obj().record_event()
         self.fwd_done = self.grads_ready = self.bwd_done = None
         if tape.enabled:
             def join_backward():          # replayed right before the other consumers' closures (recorded before A)
                 if self.bwd_done is not None:
-                    torch.cuda.current_stream().wait_event(self.bwd_done)
+                    current_stream_obj().wait_event(self.bwd_done)
             tape.ops.append(join_backward)
 
     def __enter__(self):
@@ -414,15 +448,15 @@ class Branch:
                 if self.grads_ready is not None:
                     self.stream.wait_event(self.grads_ready)
                 else:
-                    self.stream.wait_stream(torch.cuda.current_stream())
+                    self.stream.wait_stream(current_stream_obj())
             self.tape.ops.append(begin_backward)
         return False
 
     def join(self):
-        torch.cuda.current_stream().wait_event(self.fwd_done)
+        current_stream_obj().wait_event(self.fwd_done)
         if self.tape.enabled:
             def mark_grads_ready():       # replayed right after the closures of the outputs' consumers (recorded after B)
-                self.grads_ready = torch.cuda.current_stream().record_event()
+                self.grads_ready = current_stream_obj().record_event()
             self.tape.ops.append(mark_grads_ready)
 
 

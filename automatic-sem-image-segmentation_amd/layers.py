@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib as L
-from .engine import TIMER, Act, DeferredNorm, _p, _stream, workspace, zero_
+from .engine import current_stream_obj, TIMER, Act, DeferredNorm, _p, _stream, workspace, zero_
 
 CONV_STATS = os.environ.get("SS_CONV_STATS", "1") != "0"          # 0: norms always run their own statistics pass (measurement)
 NORM_AMAX = os.environ.get("SS_NORM_AMAX", "1") != "0"            # 0: convolutions scan their operands for the x3h scales themselves (measurement)
@@ -178,17 +178,22 @@ class Conv2D:
                 if side is not None:
                     # off the chain: dW is read by nobody in backward.  The side stream starts behind everything issued so far (dy is
                     # final), works in its own scratch buffer, and the tensors it reads may not be recycled under it (dy can be a
-                    # temporary of this closure).
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        wss = workspace(nbw, x.device)
-                        L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), xin.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wss), wss.numel(),
-                                                         _stream()), f"conv2d_bwd_weight[{self.name}] (side stream)")
-                        dy.t.record_stream(side)
-                        xin.t.record_stream(side)
-                        if sv is not None:
-                            sv.record_stream(side)
-                        self.arena.note_done(pnames)          # a gradient exchange launched from here orders itself behind THIS stream
+                    # temporary of this closure).  The launch takes the side stream's handle directly: entering torch's stream context
+                    # costs ~25 us per convolution, which paces the per-GPU-batch-1 steps (host-bound there).
+                    side.wait_stream(current_stream_obj())
+                    sraw = side.cuda_stream
+                    wss = workspace(nbw, x.device, sraw)
+                    L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), xin.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wss), wss.numel(),
+                                                     ctypes.c_void_p(sraw)), f"conv2d_bwd_weight[{self.name}] (side stream)")
+                    dy.t.record_stream(side)
+                    xin.t.record_stream(side)
+                    if sv is not None:
+                        sv.record_stream(side)
+                    if self.arena.grad_hook is not None:          # a gradient exchange launched from here orders itself behind THIS stream
+                        with torch.cuda.stream(side):
+                            self.arena.note_done(pnames)
+                    else:
+                        self.arena.note_done(pnames)
                 else:
                     L.check(lib.ss_conv2d_bwd_weight(ctypes.byref(dd), xin.ptr, dy.ptr, _p(gw), _p(gb), 1, _p(wsw), wsw.numel(),
                                                      _stream()), f"conv2d_bwd_weight[{self.name}]")
@@ -296,7 +301,7 @@ class Conv2D:
         cur = _stream().value or 0
         sync = st["sync"]
         if sync["ev"] is not None and cur not in sync["synced"]:
-            torch.cuda.current_stream().wait_event(sync["ev"])      # entries filled on another stream: order this stream after them
+            current_stream_obj().wait_event(sync["ev"])      # entries filled on another stream: order this stream after them
             sync["synced"].add(cur)
         d.w_cache = ctypes.addressof(c)
         st["fills0"], st["cur"] = c.fills, cur
@@ -306,7 +311,7 @@ class Conv2D:
     def _wcache_done(st):
         if st is not None and st["c"].fills != st["fills0"]:
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(current_stream_obj())
             st["sync"] = dict(ev=ev, synced={st["cur"]})
 
     def refresh_wcache(self, sync):

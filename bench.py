@@ -415,6 +415,25 @@ def main():
                                                  "launch" if traffic is not None else None,
                                "kernels": table}
             if hbm:
+                # HBM traffic of the same kernel classes from the committed PMC passes (profiles/pmc_traffic.json: every template
+                # instantiation of a class, weighted by its launches), next to the algorithmic bytes: the ratio is what is re-read
+                try:
+                    tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+                    if tj.get("workload") == [S, GB, F, world]:
+                        for name, row in hbm.items():
+                            stem = name.split("<")[0].split(" ")[0]
+                            if name.startswith(("tconv_kernel", "twgrad")):
+                                continue          # (their ss_prof labels carry tile shapes the counters' kernel names do not)
+                            sel = [v for k_, v in tj.get("kernels", {}).items() if k_.split("<")[0] == stem
+                                   and ("<normalising>" in name) == (",true," in k_ and stem == "wino_input_kernel")
+                                   and (("<fwd>" not in name) or "," + "0," in k_) and (("<bwd>" not in name) or "," + "1," in k_)]
+                            n_l = sum(v["launches"] for v in sel)
+                            if n_l:
+                                mb = sum(v["bytes_per_launch"] * v["launches"] for v in sel) / n_l / 1e6
+                                row["pmc_traffic_MB_per_launch"] = round(mb, 1)
+                                row["traffic_over_algorithmic"] = round(mb / row["algorithmic_MB_per_launch"], 3) if row["algorithmic_MB_per_launch"] else None
+                except Exception:
+                    pass
                 tot_ms = sum(v["total_ms_per_step"] for v in hbm.values())
                 tot_b = sum(v["algorithmic_MB_per_launch"] * v["launches"] / 2 for v in hbm.values()) * 1e6
                 out["roofline"]["hbm_bound_kernels"] = {

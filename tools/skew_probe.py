@@ -69,3 +69,23 @@ for name, pre, am in (("back to back", lambda: None, False), ("after a flush of 
         ts.append(e0.elapsed_time(e1) * 1e3)
     ts.sort()
     print(f"n=16 {name}: {ts[len(ts) // 2]:.1f} us")
+
+# n = 16 as two launches over 8 samples each (InstanceNorm: groups are samples): does keeping a launch inside the Infinity Cache pay?
+d8 = L.NormDesc(8, 64, 64, 512, 512, 512, 512, 8, 1e-5, 0, 0.0, dtype=0)
+half = 8 * 64 * 64 * 512
+def apply_halves():
+    for h in (1, 0):          # back to front, as the kernel itself walks
+        o = h * half * 4
+        L.check(lib.ss_norm_apply(ctypes.byref(d8), ctypes.c_void_p(x.data_ptr() + o), ctypes.c_void_p(gamma.data_ptr()), ctypes.c_void_p(beta.data_ptr()),
+                                  ctypes.c_void_p(r.data_ptr() + o), ctypes.c_void_p(y.data_ptr() + o), ctypes.c_void_p(mean.data_ptr() + h * 8 * 512 * 4),
+                                  ctypes.c_void_p(rstd.data_ptr() + h * 8 * 512 * 4), E._stream()), "apply")
+for name, pre in (("back to back", lambda: None), ("after a flush of 768 MB (all cold)", lambda: flush.fill_(1)),
+                  ("x written just before (copy), residual cold", lambda: (flush.fill_(1), x.copy_(src)))):
+    ts = []
+    for _ in range(8):
+        pre()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); apply_halves(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    print(f"n=16 as 2 x 8, {name}: {ts[len(ts) // 2]:.1f} us")

@@ -280,7 +280,7 @@ bool ss_x6p_wide_ok(long M, int N, int K, int nbatch);
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
 
 // kernel-selection switches: ONE explicit table, set through ss_config_set (config.hip); SS_* environment variables give the initial values
-struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products, c1_mfma, x6p_pp, wino_save, gemm_ilv, gemm_cus, gconv_phases; };
+struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products, c1_mfma, x6p_pp, wino_save, gemm_ilv, gemm_cus, gconv_phases, phases_fused; };
 const SsTuning& ss_tuning();
 // ss_prof_*: brackets the kernel launched inside this scope with HIP events on its stream when profiling is enabled (config.hip).
 // flops = EXECUTED matrix-instruction FLOPs of the launch (all piece products), bytes = algorithmic HBM bytes (0 if not stated)
@@ -343,6 +343,9 @@ bool ss_gconv_x6_typed_ok(const GConvParams& p);            // ... of a 16-bit s
 int ss_x6_npad(int cout);
 size_t ss_gconv_x6_planes_bytes(const GConvParams& p);      // [3][nbatch][npad(Cout)][ntaps*Cin] bf16
 int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s);
+// all four sub-pixel phases of a stride-2 data gradient / transposed convolution in one workgroup per input tile (conv_phase.hip)
+bool ss_gconv_phases_fused_ok(const GConvParams* ps, int count);
+int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* const* planes, int count, hipStream_t s);
 bool ss_gconv_x6v2_ok(const GConvParams& p);
 int ss_gconv_x6v2_stats_chunks(const GConvParams& p);        // chunks per sample of GConvParams::stats gconv_x6v2 writes (0: none)
 int ss_launch_gconv_x6_multi(const GConvParams* ps, const unsigned short* const* planes, int count, hipStream_t s);

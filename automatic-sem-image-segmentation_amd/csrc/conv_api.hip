@@ -517,6 +517,14 @@ int run_gconv_phases(int algo, const GConvParams* ps, int count, void* ws, size_
             wp += ss_gconv_x6_planes_bytes(ps[i]);
         }
         if (wc && wc->fill_only) return SS_OK;
+        if (ss_gconv_phases_fused_ok(ps, count)) return ss_launch_gconv_phases_fused(ps, planes, count, s);
+        if (!ss_tuning().gconv_phases) {          // (the joint launch of the per-phase kernels is opt-in)
+            for (int i = 0; i < count; ++i) {
+                const int rc1 = run_gconv(algo, ps[i], ws, ws_bytes, s, wc, 1);
+                if (rc1 != SS_OK) return rc1;
+            }
+            return SS_OK;
+        }
         const int rc = ss_launch_gconv_x6_multi(ps, planes, count, s);
         if (rc != SS_ERR_UNSUPPORTED) return rc;          // launched (or failed for real); UNSUPPORTED: nothing launched, planes stay valid in the cache / workspace
         if (!wc) {          // the workspace copies are laid out for the joint launch: per-phase launches refill their own
@@ -723,7 +731,7 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     // the sub-pixel phases (output pixels of one residue class mod s each: their own taps, the same dy)
     GConvParams phs[SS_MAX_PHASES];
     int nph = 0;
-    bool collect = c.s * c.s <= SS_MAX_PHASES && ss_tuning().gconv_phases;
+    bool collect = c.s * c.s <= SS_MAX_PHASES && (ss_tuning().gconv_phases || (ss_tuning().phases_fused && c.s == 2 && c.dtype == SS_DTYPE_F32));
     int rc_all = SS_OK;
     for (int ry = 0; ry < c.s; ++ry)
         for (int rx = 0; rx < c.s; ++rx) {

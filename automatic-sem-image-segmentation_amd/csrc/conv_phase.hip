@@ -1,0 +1,435 @@
+// Stride-2 data gradients / transposed convolutions: ALL FOUR sub-pixel phases of an input tile in one workgroup.
+//     out[n, s yc + ry, s xc + rx, co] = act(bias + sum_{t in taps(ry,rx), ci} in[n, yc + dy_t, xc + dx_t, ci] * w_t[ci][co]),   s = 2
+// (CycleGAN.py:347-358: the generators' Conv2DTranspose(3, strides 2) layers; :339-345 / :425-451: the data gradients of their and
+// the discriminators' stride-2 convolutions).  conv_bwd_data launches one gather convolution per phase (ry, rx): every launch
+// re-gathers the input rows of its taps, splits them into fp16 pieces again (the gather kernels are VALU-bound on exactly that:
+// ~170 address + ~190 split instructions per thread and 32-deep K step against 24 MFMAs, profiles/r02_f_*) and runs a short K loop
+// (1 .. 4 taps x Cin).  Here a workgroup owns a tile of 8 x 16 CLASS pixels (= 16 x 32 output pixels) and 64 output channels:
+//   * per 32-channel chunk the input tile + halo (<= 10 x 18 pixels) is loaded ONCE, split ONCE into (h, l) fp16 planes and staged
+//     in LDS; every tap of every phase reads its MFMA A operand from that stage at a uniform (tap) offset -- no gather, no split,
+//     no per-tap address arithmetic;
+//   * the weight planes of one tap and chunk (64 rows x 64 B x 2 planes, pre-split and cached per weight version: the planes of the
+//     per-phase gather path, ss_launch_wprep_x6) arrive by LDS-DMA into a ring of four 8 KiB stages, two taps ahead;
+//   * 4 waves, each 32 class pixels x 64 channels x 4 phases = 128 accumulator registers; 61 KiB of LDS: TWO workgroups per CU, whose
+//     load / split / multiply phases interleave by themselves (a single 8-wave workgroup per CU measured slower for the gather weight
+//     gradient).
+// Arithmetic = gconv_x6v2_kernel's: x * 2^(14 - ea) = h + l, weights h + l under their own scale, products l*h, h*l, h*h into one fp32
+// accumulator, scales undone in the epilogue.  The K order differs (channel chunk outer, tap inner), so results agree with the
+// per-phase path to fp32 rounding, not bit for bit.
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PF_TH = 8, PF_TW = 16;                  // class-pixel tile: 128 pixels, 32 per wave (two rows of 16)
+constexpr int PF_LD = 80;                             // bytes per staged pixel and plane: 32 channels fp16 + 16 (conflict-free b128 reads)
+constexpr int PF_MAXPIX = (PF_TH + 2) * (PF_TW + 2);  // halo up to one pixel on every side
+constexpr int PF_A_PLANE = PF_MAXPIX * PF_LD;         // 14400
+constexpr int PF_B_TAP = 2 * 64 * 64;                 // [2 planes][64 output channels][32 channels fp16]
+constexpr int PF_RING = 4;
+constexpr int PF_TAB = 2 * PF_A_PLANE + PF_RING * PF_B_TAP;           // per-tap table: 16 entries of 16 bytes
+constexpr int PF_SMEM = PF_TAB + 16 * 16;                             // 61824
+constexpr int PF_SLOTS = (PF_MAXPIX * 8 + 255) / 256;                 // float4 staging slots per thread: 6
+
+__device__ float pf_zero_page16[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct PFParams {
+    const float* in;
+    float* out;
+    const float* bias;
+    int N, IH, IW, Cin, in_cs;
+    int OH, OW, Cout, out_cs;
+    int OHc, OWc;                  // class grid (the same for every phase)
+    int in_oy, in_ox;              // input pixel of class pixel (yc, xc) and tap t: (yc + in_oy + dy_t, xc + in_ox + dx_t)
+    int act;
+    float alpha;
+    int accumulate;
+    const unsigned int* h_amax;    // max|in| (striped slot), max|w|
+    const unsigned int* h_amax2;
+    int amax_stripes;
+    int hy0, hx0, hh, hw;          // halo tile: smallest tap offset, extents in pixels
+    int tiles_y, tiles_x, ngroups; // class-pixel tiles per sample, 64-channel output groups
+    int ntaps[4], out_oy[4], out_ox[4], Ktot[4];
+    short tdy[4][4], tdx[4][4];
+    const unsigned short* planes[4];
+    long plane_elems[4];
+    int Npad;
+    int dbg;          // measurement only (tile_dbg): 1 no input loads, 2 no weight DMA, 4 no fragment reads / MFMAs, 8 no barriers per tap
+};
+
+__device__ __forceinline__ void pf_dma16(const unsigned short* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char* const sA = lds;                        // [2 planes][hh * hw pixels][PF_LD]
+    unsigned char* const sB = lds + 2 * PF_A_PLANE;       // ring of PF_RING tap stages
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-aware order (speed only): a contiguous chunk of the (tile, group) space per XCD, the groups of a tile next to each other
+    int tile, ng;
+    {
+        const int total = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        tile = id / p.ngroups;
+        ng = id - tile * p.ngroups;
+    }
+    const int n = tile / (p.tiles_y * p.tiles_x);
+    const int tr = tile - n * p.tiles_y * p.tiles_x;
+    const int ty0 = (tr / p.tiles_x) * PF_TH, tx0 = (tr % p.tiles_x) * PF_TW;
+    const int n0 = ng * 64;
+    const int nchunks = p.Cin >> 5;
+
+    const int ea = ss_amax_exp(__uint_as_float(ss_amax_load(p.h_amax, p.amax_stripes))), ew = ss_amax_exp(__uint_as_float(p.h_amax2[0]));
+    const float a_scale = ldexpf(1.f, 14 - ea);
+    const float out_scale = ldexpf(1.f, ea - 14 + ew - 14);
+
+    // ---- A staging slots of this thread: slot e = tid + 256 i  <->  (halo pixel e >> 3, channels 4 (e & 7) .. +3 of the chunk) ----
+    const int npix = p.hh * p.hw;
+    const int hw_m = (65536 + p.hw - 1) / p.hw;
+    int aoff[PF_SLOTS];          // element offset of the pixel's channel quad in chunk 0, -1: outside the image / no slot (reads zeros)
+#pragma unroll
+    for (int i = 0; i < PF_SLOTS; ++i) {
+        const int e = tid + 256 * i;
+        const int pix = e >> 3, c4 = e & 7;
+        const int hy = (pix * hw_m) >> 16, hx = pix - hy * p.hw;          // pix < 512, hw in 16 .. 18: exact
+        const int iy = ty0 + p.in_oy + p.hy0 + hy, ix = tx0 + p.in_ox + p.hx0 + hx;
+        const bool slot = pix < npix;
+        const bool ok = slot && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        aoff[i] = ok ? ((n * p.IH + iy) * p.IW + ix) * p.in_cs + c4 * 4 : -1;
+    }
+    f32x4 ra[PF_SLOTS];
+    auto load_a = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PF_SLOTS; ++i) {
+            const float* q = (aoff[i] >= 0 && !(p.dbg & 1)) ? p.in + aoff[i] + chunk * 32 : pf_zero_page16;
+            ra[i] = *(const f32x4*)q;
+        }
+    };
+    auto store_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PF_SLOTS; ++i) {
+            const int e = tid + 256 * i;
+            if ((e >> 3) >= npix) continue;
+            const int ao = (e >> 3) * PF_LD + (e & 7) * 8;
+            unsigned int hh[2], ll[2];
+            ss_split_h2(ra[i][0] * a_scale, ra[i][1] * a_scale, hh[0], ll[0]);
+            ss_split_h2(ra[i][2] * a_scale, ra[i][3] * a_scale, hh[1], ll[1]);
+            *(u32x2*)(sA + ao) = u32x2{hh[0], hh[1]};
+            *(u32x2*)(sA + PF_A_PLANE + ao) = u32x2{ll[0], ll[1]};
+        }
+    };
+
+    // ---- B (weight planes) by LDS-DMA: a tap and chunk = 8 pieces of 16 rows x 64 B (2 planes x 4 row blocks); this wave: pieces 2 wave, 2 wave + 1.
+    //      Lane (row = lane >> 2 of the block, 16-byte slot lane & 3) fetches k-octet slot ^ ((row >> 2) & 3): the XOR swizzle of gemm_x6p.hip.
+    int b_row[2], b_dst[2], b_pl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = wave * 2 + j;
+        const int pl = q >> 2, rb = q & 3;
+        const int row = rb * 16 + (lane >> 2);
+        const int ko = (lane & 3) ^ ((row >> 2) & 3);
+        b_pl[j] = pl;
+        b_row[j] = (n0 + row);            // times Ktot of the phase, + 8 ko below
+        b_dst[j] = pl * 4096 + rb * 1024;
+        b_row[j] = b_row[j] * 8 + ko;     // packed: row * 8 + ko (ko < 4)
+    }
+    // flattened tap list of a chunk (phase-major, the order of the multiply loop) in LDS: entry g = {plane pointer of the phase's planes
+    // advanced to the tap's first channel (lo, hi), Ktot of the phase, unused}.  The kernel arguments are indexed by run-time values
+    // otherwise: a scalar load from the argument segment per tap and field, ~0.2 us each, serial in every wave.
+    int nt[4];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) nt[ph] = p.ntaps[ph];
+    const int T = nt[0] + nt[1] + nt[2] + nt[3];
+    int a_shift[4][4];          // byte offset of tap (ph, t) inside the A stage
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a_shift[ph][t] = (p.tdy[ph][t] * p.hw + p.tdx[ph][t]) * PF_LD;
+    {   // (compile-time indices only: a run-time index into the argument struct makes the compiler copy it to scratch memory)
+        int g = 0;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < nt[ph]) {
+                    if (tid == g) {
+                        const unsigned long long ptr = (unsigned long long)(p.planes[ph] + (long)t * p.Cin);
+                        unsigned int* e = (unsigned int*)(lds + PF_TAB + g * 16);
+                        e[0] = (unsigned int)ptr; e[1] = (unsigned int)(ptr >> 32); e[2] = (unsigned int)p.Ktot[ph]; e[3] = 0u;
+                    }
+                    ++g;
+                }
+            }
+    }
+    __syncthreads();
+    // Requests go out in PAIRS of taps (one barrier per pair = 24 MFMAs per wave, as gconv_x6v2): the NEXT pair starts at the even flattened
+    // index d_g of chunk d_c and lands in ring stages d_stage, d_stage + 1.  A chunk with an odd tap count ends on a half pair whose second
+    // request repeats the first tap (harmless: nobody reads that stage); past the last chunk the requests repeat its taps.  Every wave
+    // issues exactly four DMA instructions per call, so the vmcnt bookkeeping below is the same for every wave and step.
+    int d_g = 0, d_c = 0, d_stage = 0;
+    auto dma_tap = [&](int g, int stage) __attribute__((always_inline)) {
+        const u32x4 e = *(const u32x4*)(lds + PF_TAB + g * 16);
+        const unsigned short* base = (const unsigned short*)(((unsigned long long)e[1] << 32) | e[0]);
+        const int kt = (int)e[2];
+        const long pe = (long)p.Npad * kt;
+        const int c = d_c < nchunks ? d_c : nchunks - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = b_row[j] >> 3, ko = b_row[j] & 7;
+            if (!(p.dbg & 2)) pf_dma16(base + b_pl[j] * pe + (long)row * kt + c * 32 + 8 * ko, sB + stage * PF_B_TAP + b_dst[j]);
+        }
+    };
+    auto dma_pair = [&]() __attribute__((always_inline)) {
+        dma_tap(d_g, d_stage);
+        dma_tap(d_g + 1 < T ? d_g + 1 : d_g, d_stage + 1);
+        d_stage = (d_stage + 2) & (PF_RING - 1);
+        d_g += 2;
+        if (d_g >= T) { d_g = 0; ++d_c; }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ph][ni][r] = 0.f;
+
+    // fragment addresses.  A: this lane's class pixel (row 2 wave + (l31 >> 4), column l31 & 15) at halo coordinates (- hy0, - hx0),
+    // k-octet lh (+ 2 ks); a tap adds the uniform offset (dy_t * hw + dx_t) * PF_LD.  B: row ni * 32 + l31, slot (lh + 2 ks) ^ ((row >> 2) & 3).
+    const int a_lane = ((2 * wave + (l31 >> 4) - p.hy0) * p.hw + ((l31 & 15) - p.hx0)) * PF_LD + lh * 16;
+    const int sw = (l31 >> 2) & 3;
+    const int so0 = (lh ^ sw) << 4, so1 = so0 ^ 32;
+    const int b_lane = l31 * 64;
+
+    // prologue: first chunk's input tile in registers, the first two taps' weight planes requested
+    load_a(0);
+    __builtin_amdgcn_sched_barrier(0);
+    dma_pair();
+    __builtin_amdgcn_sched_barrier(0);
+    int r_stage = 0;          // ring stage of the tap being multiplied
+
+    for (int c = 0; c < nchunks; ++c) {
+        // every wave is done with the previous chunk's A stage (it passed the last tap's MFMAs); the registers hold chunk c
+        if (c > 0) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): own fragment reads done (no vector-memory drain: the DMA stays in flight)
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_a();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = c + 1 < nchunks;
+        if (more) load_a(c + 1);          // into the same registers: the stores above have consumed them
+        __builtin_amdgcn_sched_barrier(0);
+        int g = 0;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t >= nt[ph]) continue;
+                if ((g & 1) == 0) {
+                    // the planes of this pair of taps have landed: requests are answered in order, and behind this pair's four DMA
+                    // instructions only the six loads of the next chunk's input tile can be in flight (first pair of a chunk)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && g == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 6);          // vmcnt(6)
+                    else __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0)
+                    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): own LDS stores (A stage) / fragment reads of the previous pair
+                    if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();          // ... for every wave: the pair's planes and the A stage are visible, the stages the next request overwrites are free
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_pair();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const unsigned char* const ap = sA + a_lane + a_shift[ph][t];
+                const unsigned char* const bp = sB + r_stage * PF_B_TAP + b_lane;
+#pragma unroll
+                for (int ks = 0; ks < ((p.dbg & 4) ? 0 : 2); ++ks) {
+                    const f16x8 ah = *(const f16x8*)(ap + ks * 32);
+                    const f16x8 al = *(const f16x8*)(ap + PF_A_PLANE + ks * 32);
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const unsigned char* bq = bp + ni * 2048 + (ks ? so1 : so0);
+                        const f16x8 bh = *(const f16x8*)bq;
+                        const f16x8 bl = *(const f16x8*)(bq + 4096);
+                        acc[ph][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ph][ni], 0, 0, 0);
+                        acc[ph][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ph][ni], 0, 0, 0);
+                        acc[ph][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ph][ni], 0, 0, 0);
+                    }
+                }
+                r_stage = (r_stage + 1) & (PF_RING - 1);
+                ++g;
+            }
+        }
+        r_stage = (r_stage + (g & 1)) & (PF_RING - 1);          // an odd tap count: skip the half pair's second stage
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no DMA may still be landing when the workgroup ends
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: column (output channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5):
+    // stored directly, an instruction writes 2 x 128 bytes and a wave issues 128 of them (measured: 1074 MB of output at 2.4 TB/s, 40 % of
+    // the kernel).  Each wave passes its 32 pixels x 64 channels of a phase through a private LDS block (the operand stages are free now)
+    // and stores 16 bytes per lane: 16 lanes = one pixel's 256 bytes, 4 pixels per instruction, 8 instructions per phase.
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();          // every wave is done with the operand stages
+    constexpr int ES = 68;                 // floats per pixel row of the scratch (64 + 4: the 16-byte reads of 4 pixels hit different banks)
+    float* const tb = (float*)(lds + wave * (32 * ES * 4));
+    const bool vec_ok = n0 + 64 <= p.Cout && (p.out_cs & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
+    const int q4 = (lane & 15) * 4, prow = lane >> 4;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && vec_ok) b4 = *(const f32x4*)(p.bias + n0 + q4);
+    const bool plain = p.act == SS_ACT_NONE && !p.accumulate;
+    auto epilogue = [&](auto phc) __attribute__((always_inline)) {
+        constexpr int ph = decltype(phc)::value;          // (compile-time: the accumulators stay in registers)
+        if (nt[ph] == 0 || (p.dbg & 16)) return;
+        if (vec_ok) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + ni * 32 + l31] = acc[ph][ni][r] * out_scale;
+            __builtin_amdgcn_wave_barrier();          // one wave's LDS operations execute in issue order
+            // (one uniform branch picks the plain form -- no activation, no accumulation: every layer that is followed by a norm -- whose
+            // store loop holds no case analysis; the generic form keeps the run-time switches)
+            if (plain) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int m = 4 * k + prow;
+                    f32x4 v = *(const f32x4*)(tb + m * ES + q4);
+                    const int yc = ty0 + 2 * wave + (m >> 4), xc = tx0 + (m & 15);
+                    const int oy = yc * 2 + p.out_oy[ph], ox = xc * 2 + p.out_ox[ph];
+                    if (yc >= p.OHc || xc >= p.OWc || oy >= p.OH || ox >= p.OW) continue;
+                    float* op = p.out + ((n * p.OH + oy) * p.OW + ox) * p.out_cs + n0 + q4;          // (the launcher checks: below 2^31 elements)
+                    *(f32x4*)op = v + b4;
+                }
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < 8; ++k) {
+                    const int m = 4 * k + prow;
+                    f32x4 v = *(const f32x4*)(tb + m * ES + q4);
+                    const int yc = ty0 + 2 * wave + (m >> 4), xc = tx0 + (m & 15);
+                    const int oy = yc * 2 + p.out_oy[ph], ox = xc * 2 + p.out_ox[ph];
+                    if (yc >= p.OHc || xc >= p.OWc || oy >= p.OH || ox >= p.OW) continue;
+                    float* op = p.out + ((n * p.OH + oy) * p.OW + ox) * p.out_cs + n0 + q4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ss_apply_act(v[e] + b4[e], p.act, p.alpha);
+                    if (p.accumulate) v += *(const f32x4*)op;
+                    *(f32x4*)op = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int co = n0 + ni * 32 + l31;
+            if (co >= p.Cout) continue;
+            const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int yc = ty0 + 2 * wave + (m >> 4), xc = tx0 + (m & 15);
+                if (yc >= p.OHc || xc >= p.OWc) continue;
+                const int oy = yc * 2 + p.out_oy[ph], ox = xc * 2 + p.out_ox[ph];
+                if (oy >= p.OH || ox >= p.OW) continue;
+                float* op = p.out + ((long)(n * p.OH + oy) * p.OW + ox) * p.out_cs + co;
+                float v = ss_apply_act(acc[ph][ni][r] * out_scale + bv, p.act, p.alpha);
+                if (p.accumulate) v += *op;
+                *op = v;
+            }
+        }
+    };
+    epilogue(std::integral_constant<int, 0>{});
+    epilogue(std::integral_constant<int, 1>{});
+    epilogue(std::integral_constant<int, 2>{});
+    epilogue(std::integral_constant<int, 3>{});
+}
+
+}  // namespace
+
+// The `count` problems are the sub-pixel phases of ONE stride-2 data gradient / transposed convolution as conv_bwd_data builds them
+// (same input, output, class grid; out_oy / out_ox and the taps differ) and the fused kernel takes them.
+bool ss_gconv_phases_fused_ok(const GConvParams* ps, int count) {
+    if (!ss_tuning().phases_fused || count != 4) return false;
+    const GConvParams& p0 = ps[0];
+    if (p0.dtype != SS_DTYPE_F32 || p0.c1_dtype != SS_DTYPE_F32 || !p0.h_amax || !p0.h_amax2 || p0.in_s != 1 || p0.out_s != 2 || p0.nbatch > 1 || p0.reflect ||
+        p0.Cin % 32 || p0.Cin < 64 || p0.Cout % 64 || (p0.in_cs & 3) || (((uintptr_t)p0.in) & 15) || p0.stats)
+        return false;
+    if ((long)p0.N * p0.IH * p0.IW * p0.in_cs >= (1L << 31) || (long)p0.N * p0.OH * p0.OW * p0.out_cs >= (1L << 31)) return false;
+    int y0 = 1 << 20, y1 = -(1 << 20), x0 = 1 << 20, x1 = -(1 << 20), taps = 0;
+    for (int i = 0; i < count; ++i) {
+        const GConvParams& q = ps[i];
+        if (q.ntaps < 1 || q.ntaps > SS_MAX_PHASE_TAPS || q.OHc != p0.OHc || q.OWc != p0.OWc || q.N != p0.N || q.Cin != p0.Cin || q.Cout != p0.Cout || q.in != p0.in ||
+            q.out != p0.out || q.in_s != p0.in_s || q.out_s != p0.out_s || q.in_oy != p0.in_oy || q.in_ox != p0.in_ox || q.nbatch != p0.nbatch || q.h_amax != p0.h_amax ||
+            q.h_amax2 != p0.h_amax2 || q.accumulate != p0.accumulate || q.act != p0.act || q.dtype != p0.dtype || q.stats || q.bias != p0.bias || q.out_oy < 0 ||
+            q.out_oy > 1 || q.out_ox < 0 || q.out_ox > 1)
+            return false;
+        for (int t = 0; t < q.ntaps; ++t) {
+            const int dy = q.taps[t].dy, dx = q.taps[t].dx;
+            y0 = dy < y0 ? dy : y0; y1 = dy > y1 ? dy : y1; x0 = dx < x0 ? dx : x0; x1 = dx > x1 ? dx : x1;
+        }
+        taps += q.ntaps;
+    }
+    if (y1 - y0 > 2 || x1 - x0 > 2) return false;
+    // enough workgroups to fill the chip twice over (2 per CU): the per-phase kernels keep the small problems
+    const long tiles = (long)p0.N * ((p0.OHc + PF_TH - 1) / PF_TH) * ((p0.OWc + PF_TW - 1) / PF_TW) * (p0.Cout / 64);
+    return tiles >= 1024 && tiles < (1L << 30) && taps >= 4;
+}
+
+int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* const* planes, int count, hipStream_t s) {
+    if (!ss_gconv_phases_fused_ok(ps, count)) return SS_ERR_UNSUPPORTED;
+    const GConvParams& p0 = ps[0];
+    PFParams f{};
+    f.in = p0.in; f.out = p0.out; f.bias = p0.bias;
+    f.N = p0.N; f.IH = p0.IH; f.IW = p0.IW; f.Cin = p0.Cin; f.in_cs = p0.in_cs;
+    f.OH = p0.OH; f.OW = p0.OW; f.Cout = p0.Cout; f.out_cs = p0.out_cs;
+    f.OHc = p0.OHc; f.OWc = p0.OWc; f.in_oy = p0.in_oy; f.in_ox = p0.in_ox;
+    f.act = p0.act; f.alpha = p0.alpha; f.accumulate = p0.accumulate;
+    f.h_amax = p0.h_amax; f.h_amax2 = p0.h_amax2; f.amax_stripes = p0.amax_stripes;
+    int y0 = 1 << 20, y1 = -(1 << 20), x0 = 1 << 20, x1 = -(1 << 20), taps = 0;
+    f.Npad = ss_x6_npad(p0.Cout);
+    const int Cq = (p0.Cin + 31) / 32 * 32;
+    for (int i = 0; i < 4; ++i) {
+        // phase slot = 2 * out_oy + out_ox (any order of the caller's list)
+        const GConvParams& q = ps[i];
+        const int k = 2 * q.out_oy + q.out_ox;
+        if (f.ntaps[k] != 0) return SS_ERR_UNSUPPORTED;
+        f.ntaps[k] = q.ntaps; f.out_oy[k] = q.out_oy; f.out_ox[k] = q.out_ox; f.Ktot[k] = q.ntaps * Cq;
+        f.planes[k] = planes[i];
+        f.plane_elems[k] = (long)f.Npad * f.Ktot[k];
+        for (int t = 0; t < q.ntaps; ++t) {
+            const int dy = q.taps[t].dy, dx = q.taps[t].dx;
+            f.tdy[k][t] = (short)dy; f.tdx[k][t] = (short)dx;
+            y0 = dy < y0 ? dy : y0; y1 = dy > y1 ? dy : y1; x0 = dx < x0 ? dx : x0; x1 = dx > x1 ? dx : x1;
+        }
+        taps += q.ntaps;
+    }
+    f.hy0 = y0; f.hx0 = x0; f.hh = PF_TH + (y1 - y0); f.hw = PF_TW + (x1 - x0);
+    f.tiles_y = (p0.OHc + PF_TH - 1) / PF_TH; f.tiles_x = (p0.OWc + PF_TW - 1) / PF_TW;
+    f.ngroups = p0.Cout / 64;
+    const long nwg = (long)p0.N * f.tiles_y * f.tiles_x * f.ngroups;
+    static const bool attr_set = [] {
+        (void)hipFuncSetAttribute((const void*)gconv_phases_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+    }();
+    (void)attr_set;
+    char pname[64];
+    const long M = (long)p0.N * p0.OHc * p0.OWc;
+    if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_phases_fused M%ld N%d K%dx%d", M, p0.Cout, taps, p0.Cin);
+    else snprintf(pname, sizeof(pname), "gconv_phases_fused_kernel,true>");
+    SsProfScope prof(pname, 2.0 * M * p0.Cout * taps * p0.Cin * 3,
+                     4.0 * ((double)p0.N * p0.IH * p0.IW * p0.Cin + 4.0 * M * p0.Cout) + 4.0 * taps * p0.Cin * p0.Cout, s);
+    f.dbg = ss_tuning().tile_dbg;
+    hipLaunchKernelGGL(gconv_phases_fused_kernel, dim3((unsigned)nwg), dim3(256), PF_SMEM, s, f);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}

@@ -345,7 +345,8 @@ size_t ss_gconv_x6_planes_bytes(const GConvParams& p);      // [3][nbatch][npad(
 int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s);
 // all four sub-pixel phases of a stride-2 data gradient / transposed convolution in one workgroup per input tile (conv_phase.hip)
 bool ss_gconv_phases_fused_ok(const GConvParams* ps, int count);
-int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* const* planes, int count, hipStream_t s);
+bool ss_gconv_phases_fused_wprob(const GConvParams* ps, int count, GConvParams* w);          // the one weight-plane problem of all the taps
+int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* planes, int count, hipStream_t s);
 bool ss_gconv_x6v2_ok(const GConvParams& p);
 int ss_gconv_x6v2_stats_chunks(const GConvParams& p);        // chunks per sample of GConvParams::stats gconv_x6v2 writes (0: none)
 int ss_launch_gconv_x6_multi(const GConvParams* ps, const unsigned short* const* planes, int count, hipStream_t s);

@@ -494,14 +494,28 @@ int run_gconv(int algo, const GConvParams& p, void* ws, size_t ws_bytes, hipStre
 // the sub-pixel phases of one data gradient (conv_bwd_data): one launch when all of them take the x3h gather kernels and line up
 int run_gconv_phases(int algo, const GConvParams* ps, int count, void* ws, size_t ws_bytes, hipStream_t s, WCache* wc) {
     bool multi = count >= 2 && algo != SS_ALGO_DIRECT && algo != SS_ALGO_MFMA && ws;
+    const bool fused = multi && ss_gconv_phases_fused_ok(ps, count);          // (takes class grids that differ by one between the phases)
     size_t need = 0;
     for (int i = 0; i < count && multi; ++i) {
         const GConvParams& q = ps[i];
         if (ss_conv_out1_ok(q) || ss_conv_in1_ok(q) || tconv_takes(algo, q) || gconv_two_stage(algo, q) || !use_x6(algo, q) || q.stats ||
-            q.ntaps > SS_MAX_PHASE_TAPS || !q.h_amax || !q.h_amax2 || q.OHc != ps[0].OHc || q.OWc != ps[0].OWc)
+            q.ntaps > SS_MAX_PHASE_TAPS || !q.h_amax || !q.h_amax2 || (!fused && (q.OHc != ps[0].OHc || q.OWc != ps[0].OWc)))
             multi = false;
         if (q.dtype != SS_DTYPE_F32 && !(ss_gconv_x6v2_ok(q) || ss_gconv_x6_typed_ok(q))) multi = false;
         need += ss_gconv_x6_planes_bytes(q);
+    }
+    if (fused) {          // one workgroup per input tile for all phases: ONE set of weight planes over the phases' taps
+        GConvParams wq;
+        if (ss_gconv_phases_fused_wprob(ps, count, &wq) && ss_gconv_x6_planes_bytes(wq) <= ws_bytes) {
+            bool fill;
+            unsigned short* pl = (unsigned short*)ss_wc_region(wc, ss_wc_tag(SS_WC_X6_PLANES, x6_planes_detail(wq, 2)), ss_gconv_x6_planes_bytes(wq), ws, &fill);
+            if (fill) {
+                const int rc = ss_launch_wprep_x6(wq, pl, s);
+                if (rc != SS_OK) return rc;
+            }
+            if (wc && wc->fill_only) return SS_OK;
+            return ss_launch_gconv_phases_fused(ps, pl, count, s);
+        }
     }
     if (multi && need <= ws_bytes) {
         const unsigned short* planes[SS_MAX_PHASES];
@@ -517,7 +531,6 @@ int run_gconv_phases(int algo, const GConvParams* ps, int count, void* ws, size_
             wp += ss_gconv_x6_planes_bytes(ps[i]);
         }
         if (wc && wc->fill_only) return SS_OK;
-        if (ss_gconv_phases_fused_ok(ps, count)) return ss_launch_gconv_phases_fused(ps, planes, count, s);
         if (!ss_tuning().gconv_phases) {          // (the joint launch of the per-phase kernels is opt-in)
             for (int i = 0; i < count; ++i) {
                 const int rc1 = run_gconv(algo, ps[i], ws, ws_bytes, s, wc, 1);

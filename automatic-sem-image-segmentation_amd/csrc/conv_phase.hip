@@ -33,8 +33,7 @@ constexpr int PF_MAXPIX = (PF_TH + 2) * (PF_TW + 2);  // halo up to one pixel on
 constexpr int PF_A_PLANE = PF_MAXPIX * PF_LD;         // 14400
 constexpr int PF_B_TAP = 2 * 64 * 64;                 // [2 planes][64 output channels][32 channels fp16]
 constexpr int PF_RING = 4;
-constexpr int PF_TAB = 2 * PF_A_PLANE + PF_RING * PF_B_TAP;           // per-tap table: 16 entries of 16 bytes
-constexpr int PF_SMEM = PF_TAB + 16 * 16;                             // 61824
+constexpr int PF_SMEM = 2 * PF_A_PLANE + PF_RING * PF_B_TAP;          // 61568
 constexpr int PF_SLOTS = (PF_MAXPIX * 8 + 255) / 256;                 // float4 staging slots per thread: 6
 
 __device__ float pf_zero_page16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -55,10 +54,11 @@ struct PFParams {
     int amax_stripes;
     int hy0, hx0, hh, hw;          // halo tile: smallest tap offset, extents in pixels
     int tiles_y, tiles_x, ngroups; // class-pixel tiles per sample, 64-channel output groups
-    int ntaps[4], out_oy[4], out_ox[4], Ktot[4];
+    int ntaps[4], out_oy[4], out_ox[4];
     short tdy[4][4], tdx[4][4];
-    const unsigned short* planes[4];
-    long plane_elems[4];
+    const unsigned short* planes;  // ONE set of weight planes for all taps: [2 planes][Npad rows][T * Cin], k = flattened tap (phase-major) * Cin + channel
+    long plane_elems;
+    int KT;                        // T * Cin
     int Npad;
     int dbg;          // measurement only (tile_dbg): 1 no input loads, 2 no weight DMA, 4 no fragment reads / MFMAs, 8 no barriers per tap
 };
@@ -134,21 +134,17 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
 
     // ---- B (weight planes) by LDS-DMA: a tap and chunk = 8 pieces of 16 rows x 64 B (2 planes x 4 row blocks); this wave: pieces 2 wave, 2 wave + 1.
     //      Lane (row = lane >> 2 of the block, 16-byte slot lane & 3) fetches k-octet slot ^ ((row >> 2) & 3): the XOR swizzle of gemm_x6p.hip.
-    int b_row[2], b_dst[2], b_pl[2];
+    int b_off[2], b_dst[2];          // element offset of this lane's 16 bytes inside the planes at k = 0; LDS offset of the piece inside a tap stage
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = wave * 2 + j;
         const int pl = q >> 2, rb = q & 3;
         const int row = rb * 16 + (lane >> 2);
         const int ko = (lane & 3) ^ ((row >> 2) & 3);
-        b_pl[j] = pl;
-        b_row[j] = (n0 + row);            // times Ktot of the phase, + 8 ko below
+        b_off[j] = (int)(pl * p.plane_elems) + (n0 + row) * p.KT + 8 * ko;          // (the launcher checks: the planes are below 2^31 elements)
         b_dst[j] = pl * 4096 + rb * 1024;
-        b_row[j] = b_row[j] * 8 + ko;     // packed: row * 8 + ko (ko < 4)
     }
-    // flattened tap list of a chunk (phase-major, the order of the multiply loop) in LDS: entry g = {plane pointer of the phase's planes
-    // advanced to the tap's first channel (lo, hi), Ktot of the phase, unused}.  The kernel arguments are indexed by run-time values
-    // otherwise: a scalar load from the argument segment per tap and field, ~0.2 us each, serial in every wave.
+    // (argument arrays are read with compile-time indices only: a run-time index makes the compiler copy the struct to scratch memory)
     int nt[4];
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) nt[ph] = p.ntaps[ph];
@@ -158,39 +154,17 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
     for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
         for (int t = 0; t < 4; ++t) a_shift[ph][t] = (p.tdy[ph][t] * p.hw + p.tdx[ph][t]) * PF_LD;
-    {   // (compile-time indices only: a run-time index into the argument struct makes the compiler copy it to scratch memory)
-        int g = 0;
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (t < nt[ph]) {
-                    if (tid == g) {
-                        const unsigned long long ptr = (unsigned long long)(p.planes[ph] + (long)t * p.Cin);
-                        unsigned int* e = (unsigned int*)(lds + PF_TAB + g * 16);
-                        e[0] = (unsigned int)ptr; e[1] = (unsigned int)(ptr >> 32); e[2] = (unsigned int)p.Ktot[ph]; e[3] = 0u;
-                    }
-                    ++g;
-                }
-            }
-    }
-    __syncthreads();
     // Requests go out in PAIRS of taps (one barrier per pair = 24 MFMAs per wave, as gconv_x6v2): the NEXT pair starts at the even flattened
     // index d_g of chunk d_c and lands in ring stages d_stage, d_stage + 1.  A chunk with an odd tap count ends on a half pair whose second
     // request repeats the first tap (harmless: nobody reads that stage); past the last chunk the requests repeat its taps.  Every wave
     // issues exactly four DMA instructions per call, so the vmcnt bookkeeping below is the same for every wave and step.
     int d_g = 0, d_c = 0, d_stage = 0;
     auto dma_tap = [&](int g, int stage) __attribute__((always_inline)) {
-        const u32x4 e = *(const u32x4*)(lds + PF_TAB + g * 16);
-        const unsigned short* base = (const unsigned short*)(((unsigned long long)e[1] << 32) | e[0]);
-        const int kt = (int)e[2];
-        const long pe = (long)p.Npad * kt;
         const int c = d_c < nchunks ? d_c : nchunks - 1;
+        const int koff = g * p.Cin + c * 32;          // uniform
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = b_row[j] >> 3, ko = b_row[j] & 7;
-            if (!(p.dbg & 2)) pf_dma16(base + b_pl[j] * pe + (long)row * kt + c * 32 + 8 * ko, sB + stage * PF_B_TAP + b_dst[j]);
-        }
+        for (int j = 0; j < 2; ++j)
+            if (!(p.dbg & 2)) pf_dma16(p.planes + b_off[j] + koff, sB + stage * PF_B_TAP + b_dst[j]);
     };
     auto dma_pair = [&]() __attribute__((always_inline)) {
         dma_tap(d_g, d_stage);
@@ -368,7 +342,8 @@ bool ss_gconv_phases_fused_ok(const GConvParams* ps, int count) {
     int y0 = 1 << 20, y1 = -(1 << 20), x0 = 1 << 20, x1 = -(1 << 20), taps = 0;
     for (int i = 0; i < count; ++i) {
         const GConvParams& q = ps[i];
-        if (q.ntaps < 1 || q.ntaps > SS_MAX_PHASE_TAPS || q.OHc != p0.OHc || q.OWc != p0.OWc || q.N != p0.N || q.Cin != p0.Cin || q.Cout != p0.Cout || q.in != p0.in ||
+        // (class grids may differ by one row / column between the phases of an odd-sized output: the kernel walks the largest and masks)
+        if (q.ntaps < 1 || q.ntaps > SS_MAX_PHASE_TAPS || abs(q.OHc - p0.OHc) > 1 || abs(q.OWc - p0.OWc) > 1 || q.N != p0.N || q.Cin != p0.Cin || q.Cout != p0.Cout || q.in != p0.in ||
             q.out != p0.out || q.in_s != p0.in_s || q.out_s != p0.out_s || q.in_oy != p0.in_oy || q.in_ox != p0.in_ox || q.nbatch != p0.nbatch || q.h_amax != p0.h_amax ||
             q.h_amax2 != p0.h_amax2 || q.accumulate != p0.accumulate || q.act != p0.act || q.dtype != p0.dtype || q.stats || q.bias != p0.bias || q.out_oy < 0 ||
             q.out_oy > 1 || q.out_ox < 0 || q.out_ox > 1)
@@ -381,31 +356,49 @@ bool ss_gconv_phases_fused_ok(const GConvParams* ps, int count) {
     }
     if (y1 - y0 > 2 || x1 - x0 > 2) return false;
     // enough workgroups to fill the chip twice over (2 per CU): the per-phase kernels keep the small problems
-    const long tiles = (long)p0.N * ((p0.OHc + PF_TH - 1) / PF_TH) * ((p0.OWc + PF_TW - 1) / PF_TW) * (p0.Cout / 64);
+    int ohc = 0, owc = 0;
+    for (int i = 0; i < count; ++i) { ohc = ps[i].OHc > ohc ? ps[i].OHc : ohc; owc = ps[i].OWc > owc ? ps[i].OWc : owc; }
+    const long tiles = (long)p0.N * ((ohc + PF_TH - 1) / PF_TH) * ((owc + PF_TW - 1) / PF_TW) * (p0.Cout / 64);
     return tiles >= 1024 && tiles < (1L << 30) && taps >= 4;
 }
 
-int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* const* planes, int count, hipStream_t s) {
+// The weight planes of the fused kernel: ONE problem whose tap list is the phases' taps one after the other, phase slot 2 ry + rx major
+// (the order of the kernel's multiply loop) -- what ss_launch_wprep_x6 / ss_gconv_x6_planes_bytes take.
+bool ss_gconv_phases_fused_wprob(const GConvParams* ps, int count, GConvParams* w) {
+    if (!ss_gconv_phases_fused_ok(ps, count)) return false;
+    *w = ps[0];
+    w->ntaps = 0;
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 4; ++i) {
+            if (2 * ps[i].out_oy + ps[i].out_ox != k) continue;
+            for (int t = 0; t < ps[i].ntaps; ++t) {
+                if (w->ntaps >= SS_MAX_TAPS) return false;
+                w->taps[w->ntaps++] = ps[i].taps[t];
+            }
+        }
+    return true;
+}
+
+int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* planes, int count, hipStream_t s) {
     if (!ss_gconv_phases_fused_ok(ps, count)) return SS_ERR_UNSUPPORTED;
     const GConvParams& p0 = ps[0];
     PFParams f{};
     f.in = p0.in; f.out = p0.out; f.bias = p0.bias;
     f.N = p0.N; f.IH = p0.IH; f.IW = p0.IW; f.Cin = p0.Cin; f.in_cs = p0.in_cs;
     f.OH = p0.OH; f.OW = p0.OW; f.Cout = p0.Cout; f.out_cs = p0.out_cs;
-    f.OHc = p0.OHc; f.OWc = p0.OWc; f.in_oy = p0.in_oy; f.in_ox = p0.in_ox;
+    f.OHc = 0; f.OWc = 0;
+    for (int i = 0; i < 4; ++i) { f.OHc = ps[i].OHc > f.OHc ? ps[i].OHc : f.OHc; f.OWc = ps[i].OWc > f.OWc ? ps[i].OWc : f.OWc; }
+    f.in_oy = p0.in_oy; f.in_ox = p0.in_ox;
     f.act = p0.act; f.alpha = p0.alpha; f.accumulate = p0.accumulate;
     f.h_amax = p0.h_amax; f.h_amax2 = p0.h_amax2; f.amax_stripes = p0.amax_stripes;
     int y0 = 1 << 20, y1 = -(1 << 20), x0 = 1 << 20, x1 = -(1 << 20), taps = 0;
     f.Npad = ss_x6_npad(p0.Cout);
-    const int Cq = (p0.Cin + 31) / 32 * 32;
     for (int i = 0; i < 4; ++i) {
         // phase slot = 2 * out_oy + out_ox (any order of the caller's list)
         const GConvParams& q = ps[i];
         const int k = 2 * q.out_oy + q.out_ox;
         if (f.ntaps[k] != 0) return SS_ERR_UNSUPPORTED;
-        f.ntaps[k] = q.ntaps; f.out_oy[k] = q.out_oy; f.out_ox[k] = q.out_ox; f.Ktot[k] = q.ntaps * Cq;
-        f.planes[k] = planes[i];
-        f.plane_elems[k] = (long)f.Npad * f.Ktot[k];
+        f.ntaps[k] = q.ntaps; f.out_oy[k] = q.out_oy; f.out_ox[k] = q.out_ox;
         for (int t = 0; t < q.ntaps; ++t) {
             const int dy = q.taps[t].dy, dx = q.taps[t].dx;
             f.tdy[k][t] = (short)dy; f.tdx[k][t] = (short)dx;
@@ -413,8 +406,12 @@ int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* co
         }
         taps += q.ntaps;
     }
+    f.planes = planes;
+    f.KT = taps * p0.Cin;
+    f.plane_elems = (long)f.Npad * f.KT;
+    if (2 * f.plane_elems >= (1L << 31)) return SS_ERR_UNSUPPORTED;
     f.hy0 = y0; f.hx0 = x0; f.hh = PF_TH + (y1 - y0); f.hw = PF_TW + (x1 - x0);
-    f.tiles_y = (p0.OHc + PF_TH - 1) / PF_TH; f.tiles_x = (p0.OWc + PF_TW - 1) / PF_TW;
+    f.tiles_y = (f.OHc + PF_TH - 1) / PF_TH; f.tiles_x = (f.OWc + PF_TW - 1) / PF_TW;
     f.ngroups = p0.Cout / 64;
     const long nwg = (long)p0.N * f.tiles_y * f.tiles_x * f.ngroups;
     static const bool attr_set = [] {
@@ -423,7 +420,7 @@ int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* co
     }();
     (void)attr_set;
     char pname[64];
-    const long M = (long)p0.N * p0.OHc * p0.OWc;
+    const long M = (long)p0.N * f.OHc * f.OWc;
     if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_phases_fused M%ld N%d K%dx%d", M, p0.Cout, taps, p0.Cin);
     else snprintf(pname, sizeof(pname), "gconv_phases_fused_kernel,true>");
     SsProfScope prof(pname, 2.0 * M * p0.Cout * taps * p0.Cin * 3,

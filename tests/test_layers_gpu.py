@@ -624,3 +624,68 @@ def test_probe_mfma_reports_a_real_data_ceiling_below_the_zero_operand_rate():
     assert 500.0 < out[1][0] <= out[0][0] * 1.02 and out[0][0] < 2700.0, out
     assert 800.0 < out[1][1] < 2600.0 and 800.0 < out[0][1] < 2600.0, out
     assert lib.ss_probe_mfma(1, sc.data_ptr(), 100, None, ctypes.byref(tf), ctypes.byref(mhz)) != 0          # scratch too small: refused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [("up_T3_128_64", 3, 128, 64, 2, "same", True, 8, 128, 128, "fwd"), ("up_T3_256_128_ragged", 3, 256, 128, 2, "same", True, 10, 72, 90, "fwd"),
+                                  ("down_s2_64_128_dgrad", 3, 64, 128, 2, "same", False, 8, 256, 256, "dgrad"),
+                                  ("down_s2_odd_dgrad", 3, 128, 256, 2, "same", False, 16, 131, 125, "dgrad"),
+                                  ("disc_4x4_valid_odd_dgrad", 4, 128, 256, 2, "valid", False, 6, 255, 255, "dgrad"),
+                                  ("disc_4x4_valid_even_dgrad", 4, 256, 512, 2, "valid", False, 16, 126, 126, "dgrad")],
+                         ids=lambda c: c[0])
+def test_fused_subpixel_phases_agree_with_one_launch_per_phase(case):
+    """gconv_phases_fused_kernel (conv_phase.hip: the four sub-pixel phases of a stride-2 data gradient / transposed convolution in one
+    workgroup per input tile) against one gather launch per phase: the same x3h pieces and products in another K order, so the two
+    agree to fp32 rounding (rel-L2 <= 2e-6, max |d| <= 1e-5 max|ref|) -- transposed forward, strided data gradients, odd output sizes
+    (class grids that differ by one between the phases), the discriminators' 4x4 layers (16 taps), ragged tile edges."""
+    E, LY, L = _mods()
+    name, k, cin, cout, stride, padding, transposed, n, h, w, which = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    wt = torch.empty((k, k, cout, cin) if transposed else (k, k, cin, cout)).uniform_(-0.05, 0.05, generator=g)
+    xt = torch.randn((n, h, w, cin), generator=g)
+
+    def run(fused):
+        with L.config(phases_fused=fused):
+            arena = E.ParamArena(dev)
+            conv = LY.Conv2D(arena, "c", k, cin, cout, stride=stride, padding=padding, use_bias=False, transposed=transposed)
+            arena.materialize()
+            arena["c/kernel"].copy_(wt)
+            tape = E.Tape()
+            tape.param_grads = False
+            x = E.Act(xt.to(dev), requires_grad=(which == "dgrad"))
+            y = conv(tape, x)
+            if which == "fwd":
+                torch.cuda.synchronize()
+                return y.dense().clone()
+            gt, _ = y.grad_target()
+            gt.t.copy_(torch.randn(tuple(gt.t.shape), generator=torch.Generator().manual_seed(5)).to(dev))
+            tape.backward()
+            torch.cuda.synchronize()
+            return x.get_grad().dense().clone()
+
+    ref, got = run(0), run(1)
+    assert float(ref.abs().max()) > 0
+    assert not torch.equal(ref, got), "the fused kernel did not take this problem (another K order cannot give the same bits)"
+    assert rel_l2(got.cpu(), ref.cpu()) <= 2e-6
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_fused_subpixel_phases_vs_oracle():
+    """The same kernel against the fp32 CPU oracle (Conv2DTranspose 3x3 stride 2 with bias and leaky ReLU, 128 -> 64 channels, 8 x 128 x 128):
+    forward within the layer tolerance of this file (1e-4 of max|ref|)."""
+    E, LY, L = _mods()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77)
+    wt = torch.empty((3, 3, 64, 128)).uniform_(-0.05, 0.05, generator=g)
+    bt = torch.empty(64).uniform_(-0.1, 0.1, generator=g)
+    xt = torch.randn((8, 128, 128, 128), generator=g)
+    arena = E.ParamArena(dev)
+    conv = LY.Conv2D(arena, "c", 3, 128, 64, stride=2, padding="same", use_bias=True, transposed=True, act="lrelu", act_alpha=0.2)
+    arena.materialize()
+    arena["c/kernel"].copy_(wt)
+    arena["c/bias"].copy_(bt)
+    y = conv(E.Tape(enabled=False), E.Act(xt.to(dev), requires_grad=False)).dense().cpu()
+    ref = torch.nn.functional.leaky_relu(O.conv2d_transpose(xt, wt, bt, 2), 0.2)
+    assert_close(y, ref, "fused sub-pixel transposed convolution")

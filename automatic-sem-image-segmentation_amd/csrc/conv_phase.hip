@@ -422,7 +422,7 @@ int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* pl
     char pname[64];
     const long M = (long)p0.N * f.OHc * f.OWc;
     if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_phases_fused M%ld N%d K%dx%d", M, p0.Cout, taps, p0.Cin);
-    else snprintf(pname, sizeof(pname), "gconv_phases_fused_kernel,true>");
+    else snprintf(pname, sizeof(pname), "gconv_phases_fused_kernel");
     SsProfScope prof(pname, 2.0 * M * p0.Cout * taps * p0.Cin * 3,
                      4.0 * ((double)p0.N * p0.IH * p0.IW * p0.Cin + 4.0 * M * p0.Cout) + 4.0 * taps * p0.Cin * p0.Cout, s);
     f.dbg = ss_tuning().tile_dbg;

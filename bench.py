@@ -94,7 +94,7 @@ def cpu_baseline(size, batch, filters, threads, timed):
 
 def kernel_peak(name):
     """Dense peak of the matrix instruction a contraction kernel class issues."""
-    if name.startswith("gemm_x6p_kernel<2") or name.endswith(",true>"):
+    if name.startswith("gemm_x6p_kernel<2") or name.endswith(",true>") or name.startswith("gconv_phases_fused_kernel"):
         return "f16_mfma"        # x3h: v_mfma_f32_32x32x16_f16
     if name.startswith("gconv_x6v2"):
         return "f16_mfma"        # gather convolutions, second structure: x3h only

@@ -74,7 +74,7 @@ SsTuning from_env() {
     v.wino_save = env_is("SS_WINO_SAVE", '0') ? 0 : 1;
     v.gemm_ilv = env_is("SS_GEMM_ILV", '0') ? 0 : 1;
     v.gconv_phases = env_is("SS_GCONV_PHASES", '1') ? 1 : 0;
-    v.phases_fused = env_is("SS_PHASES_FUSED", '0') ? 0 : 1;
+    v.phases_fused = getenv("SS_PHASES_FUSED") ? atoi(getenv("SS_PHASES_FUSED")) : 1;
     v.gemm_cus = getenv("SS_GEMM_CUS") ? atoi(getenv("SS_GEMM_CUS")) : 0;
     v.norm_fused_pix = getenv("SS_NORM_FUSED_PIX") ? atoi(getenv("SS_NORM_FUSED_PIX")) : 1024;
     v.gconv_fast = getenv("SS_GCONV_NOFAST") ? 0 : 1;

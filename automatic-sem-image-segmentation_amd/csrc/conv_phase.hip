@@ -355,11 +355,13 @@ bool ss_gconv_phases_fused_ok(const GConvParams* ps, int count) {
         taps += q.ntaps;
     }
     if (y1 - y0 > 2 || x1 - x0 > 2) return false;
-    // enough workgroups to fill the chip twice over (2 per CU): the per-phase kernels keep the small problems
+    // (no floor on the workgroup count: measured faster than four per-phase launches from n = 1 up -- 132 -> 80 us for the generators' last
+    // transposed convolution at 256 x 256 -- where the launches themselves are what costs)
     int ohc = 0, owc = 0;
     for (int i = 0; i < count; ++i) { ohc = ps[i].OHc > ohc ? ps[i].OHc : ohc; owc = ps[i].OWc > owc ? ps[i].OWc : owc; }
     const long tiles = (long)p0.N * ((ohc + PF_TH - 1) / PF_TH) * ((owc + PF_TW - 1) / PF_TW) * (p0.Cout / 64);
-    return tiles >= 1024 && tiles < (1L << 30) && taps >= 4;
+    const long floor_wgs = ss_tuning().phases_fused >= 2 ? ss_tuning().phases_fused : 1;          // phases_fused = n >= 2: a floor on the workgroup count (measurement)
+    return tiles >= floor_wgs && tiles < (1L << 30) && taps >= 4;
 }
 
 // The weight planes of the fused kernel: ONE problem whose tap list is the phases' taps one after the other, phase slot 2 ry + rx major

@@ -629,7 +629,7 @@ def test_probe_mfma_reports_a_real_data_ceiling_below_the_zero_operand_rate():
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [("up_T3_128_64", 3, 128, 64, 2, "same", True, 8, 128, 128, "fwd"), ("up_T3_256_128_ragged", 3, 256, 128, 2, "same", True, 10, 72, 90, "fwd"),
                                   ("down_s2_64_128_dgrad", 3, 64, 128, 2, "same", False, 8, 256, 256, "dgrad"),
-                                  ("down_s2_odd_dgrad", 3, 128, 256, 2, "same", False, 16, 131, 125, "dgrad"),
+                                  ("down_s2_odd_dgrad", 3, 128, 256, 2, "same", False, 3, 131, 125, "dgrad"), ("small_up_T3", 3, 64, 64, 2, "same", True, 1, 36, 40, "fwd"),
                                   ("disc_4x4_valid_odd_dgrad", 4, 128, 256, 2, "valid", False, 6, 255, 255, "dgrad"),
                                   ("disc_4x4_valid_even_dgrad", 4, 256, 512, 2, "valid", False, 16, 126, 126, "dgrad")],
                          ids=lambda c: c[0])

@@ -744,7 +744,7 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     // the sub-pixel phases (output pixels of one residue class mod s each: their own taps, the same dy)
     GConvParams phs[SS_MAX_PHASES];
     int nph = 0;
-    bool collect = c.s * c.s <= SS_MAX_PHASES && (ss_tuning().gconv_phases || (ss_tuning().phases_fused && c.s == 2 && c.dtype == SS_DTYPE_F32));
+    bool collect = c.s * c.s <= SS_MAX_PHASES && (ss_tuning().gconv_phases || (ss_tuning().phases_fused && c.s == 2));
     int rc_all = SS_OK;
     for (int ry = 0; ry < c.s; ++ry)
         for (int rx = 0; rx < c.s; ++rx) {

@@ -37,6 +37,15 @@ constexpr int PF_SMEM = 2 * PF_A_PLANE + PF_RING * PF_B_TAP;          // 61568
 constexpr int PF_SLOTS = (PF_MAXPIX * 8 + 255) / 256;                 // float4 staging slots per thread: 6
 
 __device__ float pf_zero_page16[4] = {0.f, 0.f, 0.f, 0.f};
+// activation storage types (GConvParams::dtype): four consecutive channels <-> f32x4 (the 16-bit types: one 8-byte access)
+typedef _Float16 pf_f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pf_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 pf_ld4(const float* q) { return *(const f32x4*)q; }
+__device__ __forceinline__ f32x4 pf_ld4(const _Float16* q) { return __builtin_convertvector(*(const pf_f16x4*)q, f32x4); }
+__device__ __forceinline__ f32x4 pf_ld4(const __bf16* q) { return __builtin_convertvector(*(const pf_bf16x4*)q, f32x4); }
+__device__ __forceinline__ void pf_st4(float* q, f32x4 v) { *(f32x4*)q = v; }
+__device__ __forceinline__ void pf_st4(_Float16* q, f32x4 v) { *(pf_f16x4*)q = __builtin_convertvector(v, pf_f16x4); }
+__device__ __forceinline__ void pf_st4(__bf16* q, f32x4 v) { *(pf_bf16x4*)q = __builtin_convertvector(v, pf_bf16x4); }
 
 struct PFParams {
     const float* in;
@@ -67,7 +76,15 @@ __device__ __forceinline__ void pf_dma16(const unsigned short* g, unsigned char*
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// T: activation storage type.  fp32: NPROD = 3 (x = h + l against w = h + l without l*l).  16-bit storage: the stored value (times a power of
+// two) IS the fp16 operand plane -- NPROD = 1: times the leading weight piece; 2: times both (the exact product of the stored value and the
+// fp32 weight), as gconv_x6v2_kernel (ss_tuning wino16_products).
+template <typename T, int NPROD>
 __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) {
+    constexpr bool F32 = std::is_same<T, float>::value;
+    static_assert(F32 ? NPROD == 3 : NPROD <= 2, "fp32 storage: three products; 16-bit storage: one or two");
+    const T* const g_in = (const T*)p.in;
+    T* const g_out = (T*)p.out;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     unsigned char* const sA = lds;                        // [2 planes][hh * hw pixels][PF_LD]
     unsigned char* const sB = lds + 2 * PF_A_PLANE;       // ring of PF_RING tap stages
@@ -114,8 +131,8 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
     auto load_a = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PF_SLOTS; ++i) {
-            const float* q = (aoff[i] >= 0 && !(p.dbg & 1)) ? p.in + aoff[i] + chunk * 32 : pf_zero_page16;
-            ra[i] = *(const f32x4*)q;
+            const T* q = (aoff[i] >= 0 && !(p.dbg & 1)) ? g_in + aoff[i] + chunk * 32 : (const T*)pf_zero_page16;
+            ra[i] = pf_ld4(q);
         }
     };
     auto store_a = [&]() __attribute__((always_inline)) {
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
             ss_split_h2(ra[i][0] * a_scale, ra[i][1] * a_scale, hh[0], ll[0]);
             ss_split_h2(ra[i][2] * a_scale, ra[i][3] * a_scale, hh[1], ll[1]);
             *(u32x2*)(sA + ao) = u32x2{hh[0], hh[1]};
-            *(u32x2*)(sA + PF_A_PLANE + ao) = u32x2{ll[0], ll[1]};
+            if (F32) *(u32x2*)(sA + PF_A_PLANE + ao) = u32x2{ll[0], ll[1]};          // 16-bit storage: h is the (scaled) stored value, exactly
         }
     };
 
@@ -148,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
     int nt[4];
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) nt[ph] = p.ntaps[ph];
-    const int T = nt[0] + nt[1] + nt[2] + nt[3];
+    const int NTAPS = nt[0] + nt[1] + nt[2] + nt[3];
     int a_shift[4][4];          // byte offset of tap (ph, t) inside the A stage
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph)
@@ -164,14 +181,14 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
         const int koff = g * p.Cin + c * 32;          // uniform
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            if (!(p.dbg & 2)) pf_dma16(p.planes + b_off[j] + koff, sB + stage * PF_B_TAP + b_dst[j]);
+            if (!(p.dbg & 2) && (NPROD >= 2 || wave < 2)) pf_dma16(p.planes + b_off[j] + koff, sB + stage * PF_B_TAP + b_dst[j]);          // (waves 2, 3 carry the low weight plane)
     };
     auto dma_pair = [&]() __attribute__((always_inline)) {
         dma_tap(d_g, d_stage);
-        dma_tap(d_g + 1 < T ? d_g + 1 : d_g, d_stage + 1);
+        dma_tap(d_g + 1 < NTAPS ? d_g + 1 : d_g, d_stage + 1);
         d_stage = (d_stage + 2) & (PF_RING - 1);
         d_g += 2;
-        if (d_g >= T) { d_g = 0; ++d_c; }
+        if (d_g >= NTAPS) { d_g = 0; ++d_c; }
     };
 
     f32x16 acc[4][2];
@@ -231,14 +248,17 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
 #pragma unroll
                 for (int ks = 0; ks < ((p.dbg & 4) ? 0 : 2); ++ks) {
                     const f16x8 ah = *(const f16x8*)(ap + ks * 32);
-                    const f16x8 al = *(const f16x8*)(ap + PF_A_PLANE + ks * 32);
+                    f16x8 al = ah;
+                    if (F32) al = *(const f16x8*)(ap + PF_A_PLANE + ks * 32);
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
                         const unsigned char* bq = bp + ni * 2048 + (ks ? so1 : so0);
                         const f16x8 bh = *(const f16x8*)bq;
-                        const f16x8 bl = *(const f16x8*)(bq + 4096);
-                        acc[ph][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ph][ni], 0, 0, 0);
-                        acc[ph][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ph][ni], 0, 0, 0);
+                        if (NPROD == 3) acc[ph][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ph][ni], 0, 0, 0);
+                        if (NPROD >= 2) {
+                            const f16x8 bl = *(const f16x8*)(bq + 4096);
+                            acc[ph][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ph][ni], 0, 0, 0);
+                        }
                         acc[ph][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ph][ni], 0, 0, 0);
                     }
                 }
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
     __builtin_amdgcn_s_barrier();          // every wave is done with the operand stages
     constexpr int ES = 68;                 // floats per pixel row of the scratch (64 + 4: the 16-byte reads of 4 pixels hit different banks)
     float* const tb = (float*)(lds + wave * (32 * ES * 4));
-    const bool vec_ok = n0 + 64 <= p.Cout && (p.out_cs & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
+    const bool vec_ok = n0 + 64 <= p.Cout && (p.out_cs & 3) == 0 && (((uintptr_t)p.out) & (4 * sizeof(T) - 1)) == 0;
     const int q4 = (lane & 15) * 4, prow = lane >> 4;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && vec_ok) b4 = *(const f32x4*)(p.bias + n0 + q4);
@@ -282,8 +302,8 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
                     const int yc = ty0 + 2 * wave + (m >> 4), xc = tx0 + (m & 15);
                     const int oy = yc * 2 + p.out_oy[ph], ox = xc * 2 + p.out_ox[ph];
                     if (yc >= p.OHc || xc >= p.OWc || oy >= p.OH || ox >= p.OW) continue;
-                    float* op = p.out + ((n * p.OH + oy) * p.OW + ox) * p.out_cs + n0 + q4;          // (the launcher checks: below 2^31 elements)
-                    *(f32x4*)op = v + b4;
+                    T* op = g_out + ((n * p.OH + oy) * p.OW + ox) * p.out_cs + n0 + q4;          // (the launcher checks: below 2^31 elements)
+                    pf_st4(op, v + b4);
                 }
             } else {
 #pragma unroll 1
@@ -293,11 +313,11 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
                     const int yc = ty0 + 2 * wave + (m >> 4), xc = tx0 + (m & 15);
                     const int oy = yc * 2 + p.out_oy[ph], ox = xc * 2 + p.out_ox[ph];
                     if (yc >= p.OHc || xc >= p.OWc || oy >= p.OH || ox >= p.OW) continue;
-                    float* op = p.out + ((n * p.OH + oy) * p.OW + ox) * p.out_cs + n0 + q4;
+                    T* op = g_out + ((n * p.OH + oy) * p.OW + ox) * p.out_cs + n0 + q4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = ss_apply_act(v[e] + b4[e], p.act, p.alpha);
-                    if (p.accumulate) v += *(const f32x4*)op;
-                    *(f32x4*)op = v;
+                    if (p.accumulate) v += pf_ld4(op);
+                    pf_st4(op, v);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -315,10 +335,10 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
                 if (yc >= p.OHc || xc >= p.OWc) continue;
                 const int oy = yc * 2 + p.out_oy[ph], ox = xc * 2 + p.out_ox[ph];
                 if (oy >= p.OH || ox >= p.OW) continue;
-                float* op = p.out + ((long)(n * p.OH + oy) * p.OW + ox) * p.out_cs + co;
+                T* op = g_out + ((long)(n * p.OH + oy) * p.OW + ox) * p.out_cs + co;
                 float v = ss_apply_act(acc[ph][ni][r] * out_scale + bv, p.act, p.alpha);
-                if (p.accumulate) v += *op;
-                *op = v;
+                if (p.accumulate) v += (float)*op;
+                *op = (T)v;
             }
         }
     };
@@ -335,8 +355,8 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
 bool ss_gconv_phases_fused_ok(const GConvParams* ps, int count) {
     if (!ss_tuning().phases_fused || count != 4) return false;
     const GConvParams& p0 = ps[0];
-    if (p0.dtype != SS_DTYPE_F32 || p0.c1_dtype != SS_DTYPE_F32 || !p0.h_amax || !p0.h_amax2 || p0.in_s != 1 || p0.out_s != 2 || p0.nbatch > 1 || p0.reflect ||
-        p0.Cin % 32 || p0.Cin < 64 || p0.Cout % 64 || (p0.in_cs & 3) || (((uintptr_t)p0.in) & 15) || p0.stats)
+    if (p0.c1_dtype != SS_DTYPE_F32 || !p0.h_amax || !p0.h_amax2 || p0.in_s != 1 || p0.out_s != 2 || p0.nbatch > 1 || p0.reflect ||
+        p0.Cin % 32 || p0.Cin < 64 || p0.Cout % 64 || (p0.in_cs & 3) || (((uintptr_t)p0.in) & (p0.dtype == SS_DTYPE_F32 ? 15 : 7)) || p0.stats)
         return false;
     if ((long)p0.N * p0.IH * p0.IW * p0.in_cs >= (1L << 31) || (long)p0.N * p0.OH * p0.OW * p0.out_cs >= (1L << 31)) return false;
     int y0 = 1 << 20, y1 = -(1 << 20), x0 = 1 << 20, x1 = -(1 << 20), taps = 0;
@@ -416,19 +436,28 @@ int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* pl
     f.tiles_y = (f.OHc + PF_TH - 1) / PF_TH; f.tiles_x = (f.OWc + PF_TW - 1) / PF_TW;
     f.ngroups = p0.Cout / 64;
     const long nwg = (long)p0.N * f.tiles_y * f.tiles_x * f.ngroups;
-    static const bool attr_set = [] {
-        (void)hipFuncSetAttribute((const void*)gconv_phases_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return true;
-    }();
-    (void)attr_set;
     char pname[64];
     const long M = (long)p0.N * f.OHc * f.OWc;
     if (getenv("SS_PROF_SHAPES")) snprintf(pname, sizeof(pname), "gconv_phases_fused M%ld N%d K%dx%d", M, p0.Cout, taps, p0.Cin);
     else snprintf(pname, sizeof(pname), "gconv_phases_fused_kernel");
-    SsProfScope prof(pname, 2.0 * M * p0.Cout * taps * p0.Cin * 3,
-                     4.0 * ((double)p0.N * p0.IH * p0.IW * p0.Cin + 4.0 * M * p0.Cout) + 4.0 * taps * p0.Cin * p0.Cout, s);
+    const int esz = p0.dtype == SS_DTYPE_F32 ? 4 : 2;
+    SsProfScope prof(pname, 2.0 * M * p0.Cout * taps * p0.Cin * (p0.dtype == SS_DTYPE_F32 ? 3 : (ss_tuning().wino16_products == 3 ? 2 : 1)),
+                     (double)esz * ((double)p0.N * p0.IH * p0.IW * p0.Cin + 4.0 * M * p0.Cout) + 4.0 * taps * p0.Cin * p0.Cout, s);
     f.dbg = ss_tuning().tile_dbg;
-    hipLaunchKernelGGL(gconv_phases_fused_kernel, dim3((unsigned)nwg), dim3(256), PF_SMEM, s, f);
+    auto go = [&](auto tc, auto npc) {
+        typedef decltype(tc) T;
+        constexpr int NPROD = decltype(npc)::value;
+        static const bool attr_set = [] {
+            (void)hipFuncSetAttribute((const void*)gconv_phases_fused_kernel<T, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            return true;
+        }();
+        (void)attr_set;
+        hipLaunchKernelGGL((gconv_phases_fused_kernel<T, NPROD>), dim3((unsigned)nwg), dim3(256), PF_SMEM, s, f);
+    };
+    const bool two = ss_tuning().wino16_products == 3;          // "fp32-grade arithmetic, only the storage is 16-bit"
+    if (p0.dtype == SS_DTYPE_F32) go(0.f, std::integral_constant<int, 3>{});
+    else if (p0.dtype == SS_DTYPE_F16) { if (two) go((_Float16)0, std::integral_constant<int, 2>{}); else go((_Float16)0, std::integral_constant<int, 1>{}); }
+    else { if (two) go((__bf16)0, std::integral_constant<int, 2>{}); else go((__bf16)0, std::integral_constant<int, 1>{}); }
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -631,7 +631,8 @@ def test_probe_mfma_reports_a_real_data_ceiling_below_the_zero_operand_rate():
                                   ("down_s2_64_128_dgrad", 3, 64, 128, 2, "same", False, 8, 256, 256, "dgrad"),
                                   ("down_s2_odd_dgrad", 3, 128, 256, 2, "same", False, 3, 131, 125, "dgrad"), ("small_up_T3", 3, 64, 64, 2, "same", True, 1, 36, 40, "fwd"),
                                   ("disc_4x4_valid_odd_dgrad", 4, 128, 256, 2, "valid", False, 6, 255, 255, "dgrad"),
-                                  ("disc_4x4_valid_even_dgrad", 4, 256, 512, 2, "valid", False, 16, 126, 126, "dgrad")],
+                                  ("disc_4x4_valid_even_dgrad", 4, 256, 512, 2, "valid", False, 16, 126, 126, "dgrad"),
+                                  ("down_s2_dgrad_accumulated", 3, 64, 128, 2, "same", False, 2, 96, 80, "dgrad_acc")],
                          ids=lambda c: c[0])
 def test_fused_subpixel_phases_agree_with_one_launch_per_phase(case):
     """gconv_phases_fused_kernel (conv_phase.hip: the four sub-pixel phases of a stride-2 data gradient / transposed convolution in one
@@ -653,7 +654,7 @@ def test_fused_subpixel_phases_agree_with_one_launch_per_phase(case):
             arena["c/kernel"].copy_(wt)
             tape = E.Tape()
             tape.param_grads = False
-            x = E.Act(xt.to(dev), requires_grad=(which == "dgrad"))
+            x = E.Act(xt.to(dev), requires_grad=(which != "fwd"))
             y = conv(tape, x)
             if which == "fwd":
                 torch.cuda.synchronize()
@@ -661,6 +662,13 @@ def test_fused_subpixel_phases_agree_with_one_launch_per_phase(case):
             gt, _ = y.grad_target()
             gt.t.copy_(torch.randn(tuple(gt.t.shape), generator=torch.Generator().manual_seed(5)).to(dev))
             tape.backward()
+            if which == "dgrad_acc":          # a second consumer of x: its data gradient ACCUMULATES into the first one's (generic epilogue)
+                tape2 = E.Tape()
+                tape2.param_grads = False
+                y2 = conv(tape2, x)
+                g2, _ = y2.grad_target()
+                g2.t.copy_(torch.randn(tuple(g2.t.shape), generator=torch.Generator().manual_seed(6)).to(dev))
+                tape2.backward()
             torch.cuda.synchronize()
             return x.get_grad().dense().clone()
 

@@ -517,7 +517,7 @@ int run_gconv_phases(int algo, const GConvParams* ps, int count, void* ws, size_
             return ss_launch_gconv_phases_fused(ps, pl, count, s);
         }
     }
-    if (multi && need <= ws_bytes) {
+    if (multi && need <= ws_bytes && ss_tuning().gconv_phases) {          // (the joint launch of the per-phase kernels is opt-in)
         const unsigned short* planes[SS_MAX_PHASES];
         char* wp = (char*)ws;
         for (int i = 0; i < count; ++i) {
@@ -531,13 +531,6 @@ int run_gconv_phases(int algo, const GConvParams* ps, int count, void* ws, size_
             wp += ss_gconv_x6_planes_bytes(ps[i]);
         }
         if (wc && wc->fill_only) return SS_OK;
-        if (!ss_tuning().gconv_phases) {          // (the joint launch of the per-phase kernels is opt-in)
-            for (int i = 0; i < count; ++i) {
-                const int rc1 = run_gconv(algo, ps[i], ws, ws_bytes, s, wc, 1);
-                if (rc1 != SS_OK) return rc1;
-            }
-            return SS_OK;
-        }
         const int rc = ss_launch_gconv_x6_multi(ps, planes, count, s);
         if (rc != SS_ERR_UNSUPPORTED) return rc;          // launched (or failed for real); UNSUPPORTED: nothing launched, planes stay valid in the cache / workspace
         if (!wc) {          // the workspace copies are laid out for the joint launch: per-phase launches refill their own

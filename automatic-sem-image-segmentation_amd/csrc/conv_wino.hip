@@ -152,13 +152,23 @@ __device__ __forceinline__ void block_amax(float v, unsigned int* out) {
     if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(bm[0], bm[1]), fmaxf(bm[2], bm[3]))));
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (MI355X_MICROARCH.md): block b of the launch takes the b / 8-th block of the
+// (b % 8)-th EIGHTH of the tile list, so that the tiles one L2 serves are neighbours (a whole image at batch 8) and the two halo
+// rows / columns a 6 x 6 patch shares with the next tile are L2 hits instead of fabric reads.  Leftover blocks (grid % 8) keep their index.
+__device__ __forceinline__ unsigned ss_xcd_block(unsigned b, unsigned nb) {
+    const unsigned per = nb >> 3;
+    return b < (per << 3) ? (b & 7u) * per + (b >> 3) : b;
+}
+
 // V[xi][tile][c], tile = (n, ty, tx); patch d[i][j] = in[n, map(R*ty + i - pt), map(R*tx + j - pl), c]
 // BF = 0: fp32 V;  1: two bf16 planes (SS_PRECISION=bf16x3);  2: the three bf16 planes of the x6 arithmetic,
 // [plane][xi][tile rows padded to Mpad][c] -- the A operand of gemm_x6p.hip, no conversion left for the GEMM
 // BF = 5 (16-bit activation storage, TI = _Float16 / __bf16): ONE fp16 plane under the per-tile scale of BF = 3 -- a stored 16-bit
 // value has 8 / 11 significand bits, its transform is carried with 11: plain mixed precision, one product in the GEMM
-template <int R, int BF, bool FN = false, typename TI = float>          // FN: fused input normalisation (a separate instantiation: the plain one pays nothing for it)
-__global__ __launch_bounds__(256, FN ? 4 : 1) void wino_input_kernel(const TI* __restrict__ in, int in_cs, int N, int H, int W, int C,
+// FN: fused input normalisation (a separate instantiation: the plain one pays nothing for it).  It holds ~165 VGPRs: three workgroups
+// per CU (170 registers); under a cap of 128 it spilled 37 of them and moved 1.9 x its algorithmic bytes (132 -> 94 us on the trunk)
+template <int R, int BF, bool FN = false, typename TI = float>
+__global__ __launch_bounds__(256, FN ? 3 : 1) void wino_input_kernel(const TI* __restrict__ in, int in_cs, int N, int H, int W, int C,
                                                          int TH, int TW, int pt, int pl, int reflect, float* __restrict__ V, long Mpad = 0,
                                                          float* __restrict__ tile_inv = nullptr, unsigned int* __restrict__ amax_out = nullptr,
                                                          const unsigned int* __restrict__ amax_in = nullptr, int amax_stripes = 0, int bound = 0,
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256, FN ? 4 : 1) void wino_input_kernel(const TI* _
     constexpr int VW = WT<R>::VW, P = R + 2;
     const int CV = C / VW;
     const long tiles = (long)N * TH * TW;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long e = (long)ss_xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (e >= tiles * CV) return;
     const int c = (int)(e % CV) * VW;
     const long tile = e / CV;

@@ -49,6 +49,7 @@ const Key KEYS[] = {
     {"gemm_cus", &SsTuning::gemm_cus, "persistent pre-split-plane GEMMs: workgroups (= CUs occupied; a multiple of 8) per launch, 0 = all CUs.  Fewer leave whole CUs to the kernels of the other HIP stream (a GEMM workgroup takes a CU's whole LDS: nothing else starts beside it)"},
     {"gconv_phases", &SsTuning::gconv_phases, "OPT-IN (default 0; measured slower or equal: the phases' weight planes then compete for one L2): stride-2 data gradients / transposed convolutions with the four sub-pixel phases in ONE launch of the x3h gather kernels (same results bit for bit); 0: one launch per phase"},
     {"phases_fused", &SsTuning::phases_fused, "stride-2 data gradients / transposed convolutions (fp32 storage, x3h): the four sub-pixel phases of an input tile in ONE workgroup -- the tile is loaded and split once per 32-channel chunk and every tap reads it from LDS (conv_phase.hip); 0: one gather-kernel launch per phase"},
+    {"phases_split", &SsTuning::phases_split, "the fused sub-pixel kernel with TWO phases per wave pair (64 pixels x 64 channels x 2 phases per wave: one A and one B fragment read per MFMA triple instead of 1.5; the weight stream interleaves the two wave pairs' taps); 0: all four phases in every wave"},
     {"wgrad_tn", &SsTuning::wgrad_tn, "Winograd weight gradient on pre-split K-major fp16 planes with transposing LDS reads (gemm_tn_x3h.hip); 0: in-kernel split"},
 };
 
@@ -75,6 +76,7 @@ SsTuning from_env() {
     v.gemm_ilv = env_is("SS_GEMM_ILV", '0') ? 0 : 1;
     v.gconv_phases = env_is("SS_GCONV_PHASES", '1') ? 1 : 0;
     v.phases_fused = getenv("SS_PHASES_FUSED") ? atoi(getenv("SS_PHASES_FUSED")) : 1;
+    v.phases_split = getenv("SS_PHASES_SPLIT") ? atoi(getenv("SS_PHASES_SPLIT")) : 1;
     v.gemm_cus = getenv("SS_GEMM_CUS") ? atoi(getenv("SS_GEMM_CUS")) : 0;
     v.norm_fused_pix = getenv("SS_NORM_FUSED_PIX") ? atoi(getenv("SS_NORM_FUSED_PIX")) : 1024;
     v.gconv_fast = getenv("SS_GCONV_NOFAST") ? 0 : 1;

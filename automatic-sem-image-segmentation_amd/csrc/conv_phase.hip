@@ -70,6 +70,11 @@ struct PFParams {
     int KT;                        // T * Cin
     int Npad;
     int dbg;          // measurement only (tile_dbg): 1 no input loads, 2 no weight DMA, 4 no fragment reads / MFMAs, 8 no barriers per tap
+    // SPLIT form (two phases per wave pair): streamed pair s holds tap s of wave pair 0 and tap s of wave pair 1 (flattened 2 s + wp)
+    int sp_stages;                 // streamed pairs per chunk
+    short sp_shift[2][8];          // [wave pair][s]: pixel offset dy * hw + dx of the tap inside the A stage
+    signed char sp_lp[2][8];       // ... its local phase (0 / 1), -1: no tap (the shorter pair's last slot)
+    int sp_ooy[2][2], sp_oox[2][2];          // [wave pair][local phase]: output sub-pixel of the phase
 };
 
 __device__ __forceinline__ void pf_dma16(const unsigned short* g, unsigned char* l) {
@@ -79,7 +84,18 @@ __device__ __forceinline__ void pf_dma16(const unsigned short* g, unsigned char*
 // T: activation storage type.  fp32: NPROD = 3 (x = h + l against w = h + l without l*l).  16-bit storage: the stored value (times a power of
 // two) IS the fp16 operand plane -- NPROD = 1: times the leading weight piece; 2: times both (the exact product of the stored value and the
 // fp32 weight), as gconv_x6v2_kernel (ss_tuning wino16_products).
-template <typename T, int NPROD>
+// SPLIT patterns (tap counts of the two phases of wave pair 0 | wave pair 1): 1 = {1, 4 | 2, 2} -- the 3 x 3 stride-2 layers, five streamed
+// pairs; 2 = {4, 4 | 4, 4} -- the 4 x 4 stride-2 layers, eight.  Local phase of wave pair wp in streamed pair st, -1: no tap.
+__host__ __device__ constexpr int pf_split_stages(int pat) { return pat == 1 ? 5 : 8; }
+__host__ __device__ constexpr int pf_split_lp(int pat, int wp, int st) {
+    return pat == 1 ? (wp == 0 ? (st == 0 ? 0 : 1) : (st < 2 ? 0 : (st < 4 ? 1 : -1))) : (st < 4 ? 0 : 1);
+}
+
+// SPLIT: waves 0 / 1 hold phases sp_ph[0][*] on pixel rows 0 - 3 / 4 - 7 of the tile (64 pixels each), waves 2 / 3 hold phases sp_ph[1][*]:
+// acc[2 phases][2 pixel blocks][2 channel blocks] -- the same 128 registers, but one A and one B fragment per MFMA triple instead of 1.5
+// (the loop is bound by the CU's LDS read rate).  Every streamed pair of taps holds one tap of each wave pair: all four SIMDs multiply in
+// every stage.
+template <typename T, int NPROD, int SPLIT>
 __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) {
     constexpr bool F32 = std::is_same<T, float>::value;
     static_assert(F32 ? NPROD == 3 : NPROD <= 2, "fp32 storage: three products; 16-bit storage: one or two");
@@ -171,6 +187,11 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
     for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
         for (int t = 0; t < 4; ++t) a_shift[ph][t] = (p.tdy[ph][t] * p.hw + p.tdx[ph][t]) * PF_LD;
+    int sp_sh[2][8];          // SPLIT: byte offset of the tap of (wave pair, streamed pair) inside the A stage
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+        for (int st = 0; st < 8; ++st) sp_sh[w2][st] = SPLIT ? p.sp_shift[w2][st] * PF_LD : 0;
     // Requests go out in PAIRS of taps (one barrier per pair = 24 MFMAs per wave, as gconv_x6v2): the NEXT pair starts at the even flattened
     // index d_g of chunk d_c and lands in ring stages d_stage, d_stage + 1.  A chunk with an odd tap count ends on a half pair whose second
     // request repeats the first tap (harmless: nobody reads that stage); past the last chunk the requests repeat its taps.  Every wave
@@ -191,17 +212,23 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
         if (d_g >= NTAPS) { d_g = 0; ++d_c; }
     };
 
-    f32x16 acc[4][2];
+    const int wp = wave >> 1, wi = wave & 1;          // SPLIT: wave pair (phases), pixel half
+    // SPLIT: the rest of the kernel exists once per wave pair (one uniform branch at the very end of this function picks the copy): each copy
+    // is straight-line code with its own accumulators -- a branch per streamed pair, or per chunk with the accumulators live across it, made the
+    // register allocator spill accumulator tiles.  Both copies execute the same barriers.
+    auto body = [&](auto wpc) __attribute__((always_inline)) {
+    constexpr int WP = decltype(wpc)::value;
+    f32x16 acc[8];          // [phase][channel block]; SPLIT: [local phase][pixel block][channel block]
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ph][ni][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int row0 = SPLIT ? 4 * wi : 2 * wave;       // first class-pixel row of this wave inside the tile
 
     // fragment addresses.  A: this lane's class pixel (row 2 wave + (l31 >> 4), column l31 & 15) at halo coordinates (- hy0, - hx0),
     // k-octet lh (+ 2 ks); a tap adds the uniform offset (dy_t * hw + dx_t) * PF_LD.  B: row ni * 32 + l31, slot (lh + 2 ks) ^ ((row >> 2) & 3).
-    const int a_lane = ((2 * wave + (l31 >> 4) - p.hy0) * p.hw + ((l31 & 15) - p.hx0)) * PF_LD + lh * 16;
+    const int a_lane = ((row0 + (l31 >> 4) - p.hy0) * p.hw + ((l31 & 15) - p.hx0)) * PF_LD + lh * 16;
+    const int a_mi = 2 * p.hw * PF_LD;          // SPLIT: second pixel block = two rows down
     const int sw = (l31 >> 2) & 3;
     const int so0 = (lh ^ sw) << 4, so1 = so0 ^ 32;
     const int b_lane = l31 * 64;
@@ -225,6 +252,60 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
         const bool more = c + 1 < nchunks;
         if (more) load_a(c + 1);          // into the same registers: the stores above have consumed them
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SPLIT != 0) {
+            // Straight-line code per wave pair (one uniform branch per chunk; the barriers are the same ones): the local phase of every
+            // streamed pair is a compile-time constant, so are the accumulator indices.  (A per-pair branch on a run-time local phase made
+            // the register allocator spill one accumulator tile per pair.)
+            {
+                auto stage = [&](auto stc) __attribute__((always_inline)) {
+                    constexpr int st = decltype(stc)::value;
+                    if constexpr (st < pf_split_stages(SPLIT)) {
+                    // the planes of this streamed pair have landed (see the plain form below for the counts)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && st == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 6);          // vmcnt(6)
+                    else __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_pair();
+                    __builtin_amdgcn_sched_barrier(0);
+                    constexpr int lp = pf_split_lp(SPLIT, WP, st);
+                    if constexpr (lp >= 0) {
+                        constexpr int base = lp * 4;
+                        const unsigned char* const ap = sA + a_lane + sp_sh[WP][st];
+                        const unsigned char* const bp = sB + ((r_stage + WP) & (PF_RING - 1)) * PF_B_TAP + b_lane;
+#pragma unroll
+                        for (int ks = 0; ks < ((p.dbg & 4) ? 0 : 2); ++ks) {
+                            f16x8 ah[2], al[2];
+#pragma unroll
+                            for (int mi = 0; mi < 2; ++mi) {
+                                ah[mi] = *(const f16x8*)(ap + mi * a_mi + ks * 32);
+                                al[mi] = ah[mi];
+                                if (F32) al[mi] = *(const f16x8*)(ap + mi * a_mi + PF_A_PLANE + ks * 32);
+                            }
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni) {
+                                const unsigned char* bq = bp + ni * 2048 + (ks ? so1 : so0);
+                                const f16x8 bh = *(const f16x8*)bq;
+                                f16x8 bl = bh;
+                                if (NPROD >= 2) bl = *(const f16x8*)(bq + 4096);
+#pragma unroll
+                                for (int mi = 0; mi < 2; ++mi) {
+                                    if (NPROD == 3) acc[base + mi * 2 + ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh, acc[base + mi * 2 + ni], 0, 0, 0);
+                                    if (NPROD >= 2) acc[base + mi * 2 + ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl, acc[base + mi * 2 + ni], 0, 0, 0);
+                                    acc[base + mi * 2 + ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh, acc[base + mi * 2 + ni], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                    r_stage = (r_stage + 2) & (PF_RING - 1);
+                    }
+                };
+                stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); stage(std::integral_constant<int, 2>{});
+                stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
+                stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{});
+            }
+        } else {
         int g = 0;
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
@@ -254,12 +335,12 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
                     for (int ni = 0; ni < 2; ++ni) {
                         const unsigned char* bq = bp + ni * 2048 + (ks ? so1 : so0);
                         const f16x8 bh = *(const f16x8*)bq;
-                        if (NPROD == 3) acc[ph][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ph][ni], 0, 0, 0);
+                        if (NPROD == 3) acc[ph * 2 + ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ph * 2 + ni], 0, 0, 0);
                         if (NPROD >= 2) {
                             const f16x8 bl = *(const f16x8*)(bq + 4096);
-                            acc[ph][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ph][ni], 0, 0, 0);
+                            acc[ph * 2 + ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ph * 2 + ni], 0, 0, 0);
                         }
-                        acc[ph][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ph][ni], 0, 0, 0);
+                        acc[ph * 2 + ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ph * 2 + ni], 0, 0, 0);
                     }
                 }
                 r_stage = (r_stage + 1) & (PF_RING - 1);
@@ -267,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
             }
         }
         r_stage = (r_stage + (g & 1)) & (PF_RING - 1);          // an odd tap count: skip the half pair's second stage
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no DMA may still be landing when the workgroup ends
 
@@ -283,14 +365,15 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && vec_ok) b4 = *(const f32x4*)(p.bias + n0 + q4);
     const bool plain = p.act == SS_ACT_NONE && !p.accumulate;
-    auto epilogue = [&](auto phc) __attribute__((always_inline)) {
-        constexpr int ph = decltype(phc)::value;          // (compile-time: the accumulators stay in registers)
-        if (nt[ph] == 0 || (p.dbg & 16)) return;
+    // one block of 32 pixels x 64 channels: accumulators acc[base], acc[base + 1], pixel rows r0 + {0, 1} of the tile, output sub-pixel (ooy, oox)
+    auto epilogue = [&](auto basec, const int r0, const int ooy, const int oox, const bool has) __attribute__((always_inline)) {
+        constexpr int base = decltype(basec)::value;          // (compile-time: the accumulators stay in registers)
+        if (!has || (p.dbg & 16)) return;
         if (vec_ok) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + ni * 32 + l31] = acc[ph][ni][r] * out_scale;
+                for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + ni * 32 + l31] = acc[base + ni][r] * out_scale;
             __builtin_amdgcn_wave_barrier();          // one wave's LDS operations execute in issue order
             // (one uniform branch picks the plain form -- no activation, no accumulation: every layer that is followed by a norm -- whose
             // store loop holds no case analysis; the generic form keeps the run-time switches)
@@ -299,8 +382,8 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
                 for (int k = 0; k < 8; ++k) {
                     const int m = 4 * k + prow;
                     f32x4 v = *(const f32x4*)(tb + m * ES + q4);
-                    const int yc = ty0 + 2 * wave + (m >> 4), xc = tx0 + (m & 15);
-                    const int oy = yc * 2 + p.out_oy[ph], ox = xc * 2 + p.out_ox[ph];
+                    const int yc = ty0 + r0 + (m >> 4), xc = tx0 + (m & 15);
+                    const int oy = yc * 2 + ooy, ox = xc * 2 + oox;
                     if (yc >= p.OHc || xc >= p.OWc || oy >= p.OH || ox >= p.OW) continue;
                     T* op = g_out + ((n * p.OH + oy) * p.OW + ox) * p.out_cs + n0 + q4;          // (the launcher checks: below 2^31 elements)
                     pf_st4(op, v + b4);
@@ -310,8 +393,8 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
                 for (int k = 0; k < 8; ++k) {
                     const int m = 4 * k + prow;
                     f32x4 v = *(const f32x4*)(tb + m * ES + q4);
-                    const int yc = ty0 + 2 * wave + (m >> 4), xc = tx0 + (m & 15);
-                    const int oy = yc * 2 + p.out_oy[ph], ox = xc * 2 + p.out_ox[ph];
+                    const int yc = ty0 + r0 + (m >> 4), xc = tx0 + (m & 15);
+                    const int oy = yc * 2 + ooy, ox = xc * 2 + oox;
                     if (yc >= p.OHc || xc >= p.OWc || oy >= p.OH || ox >= p.OW) continue;
                     T* op = g_out + ((n * p.OH + oy) * p.OW + ox) * p.out_cs + n0 + q4;
 #pragma unroll
@@ -331,21 +414,37 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int yc = ty0 + 2 * wave + (m >> 4), xc = tx0 + (m & 15);
+                const int yc = ty0 + r0 + (m >> 4), xc = tx0 + (m & 15);
                 if (yc >= p.OHc || xc >= p.OWc) continue;
-                const int oy = yc * 2 + p.out_oy[ph], ox = xc * 2 + p.out_ox[ph];
+                const int oy = yc * 2 + ooy, ox = xc * 2 + oox;
                 if (oy >= p.OH || ox >= p.OW) continue;
                 T* op = g_out + ((long)(n * p.OH + oy) * p.OW + ox) * p.out_cs + co;
-                float v = ss_apply_act(acc[ph][ni][r] * out_scale + bv, p.act, p.alpha);
+                float v = ss_apply_act(acc[base + ni][r] * out_scale + bv, p.act, p.alpha);
                 if (p.accumulate) v += (float)*op;
                 *op = (T)v;
             }
         }
     };
-    epilogue(std::integral_constant<int, 0>{});
-    epilogue(std::integral_constant<int, 1>{});
-    epilogue(std::integral_constant<int, 2>{});
-    epilogue(std::integral_constant<int, 3>{});
+    if constexpr (SPLIT != 0) {
+        const int oy0 = p.sp_ooy[WP][0], ox0 = p.sp_oox[WP][0];
+        const int oy1 = p.sp_ooy[WP][1], ox1 = p.sp_oox[WP][1];
+        epilogue(std::integral_constant<int, 0>{}, row0, oy0, ox0, true);
+        epilogue(std::integral_constant<int, 2>{}, row0 + 2, oy0, ox0, true);
+        epilogue(std::integral_constant<int, 4>{}, row0, oy1, ox1, true);
+        epilogue(std::integral_constant<int, 6>{}, row0 + 2, oy1, ox1, true);
+    } else {
+        epilogue(std::integral_constant<int, 0>{}, row0, p.out_oy[0], p.out_ox[0], nt[0] != 0);
+        epilogue(std::integral_constant<int, 2>{}, row0, p.out_oy[1], p.out_ox[1], nt[1] != 0);
+        epilogue(std::integral_constant<int, 4>{}, row0, p.out_oy[2], p.out_ox[2], nt[2] != 0);
+        epilogue(std::integral_constant<int, 6>{}, row0, p.out_oy[3], p.out_ox[3], nt[3] != 0);
+    }
+    };          // body
+    if constexpr (SPLIT != 0) {
+        if (wp == 0) body(std::integral_constant<int, 0>{});
+        else body(std::integral_constant<int, 1>{});
+    } else {
+        body(std::integral_constant<int, 0>{});
+    }
 }
 
 }  // namespace
@@ -384,12 +483,68 @@ bool ss_gconv_phases_fused_ok(const GConvParams* ps, int count) {
     return tiles >= floor_wgs && tiles < (1L << 30) && taps >= 4;
 }
 
+namespace {
+// SPLIT form: the four phase slots in two pairs whose tap counts differ by at most one (the longer first); flattened tap 2 s + wp = tap s
+// of pair wp (its first phase's taps, then its second's)
+struct PFSplit { int slot[2][2]; int n[2][2]; int stages; int pat; const GConvParams* q[4]; };
+bool pf_split_schedule(const GConvParams* ps, PFSplit* sc) {
+    if (!ss_tuning().phases_split) return false;
+    const GConvParams* q[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i) {
+        const int k = 2 * ps[i].out_oy + ps[i].out_ox;
+        if (k < 0 || k > 3 || q[k]) return false;
+        q[k] = &ps[i];
+    }
+    static const int pairs[3][4] = {{0, 3, 1, 2}, {0, 1, 2, 3}, {0, 2, 1, 3}};
+    int best = -1, bestd = 1 << 20;
+    for (int i = 0; i < 3; ++i) {
+        const int a = q[pairs[i][0]]->ntaps + q[pairs[i][1]]->ntaps, b = q[pairs[i][2]]->ntaps + q[pairs[i][3]]->ntaps;
+        const int d = a > b ? a - b : b - a;
+        if (d < bestd) { bestd = d; best = i; }
+    }
+    if (best < 0 || bestd > 1) return false;
+    const int a = q[pairs[best][0]]->ntaps + q[pairs[best][1]]->ntaps, b = q[pairs[best][2]]->ntaps + q[pairs[best][3]]->ntaps;
+    const int first = a >= b ? 0 : 2;
+    for (int wp = 0; wp < 2; ++wp) {
+        int s0 = pairs[best][(wp == 0 ? first : 2 - first)], s1 = pairs[best][(wp == 0 ? first : 2 - first) + 1];
+        if (q[s0]->ntaps > q[s1]->ntaps) { const int t = s0; s0 = s1; s1 = t; }          // the shorter phase first
+        sc->slot[wp][0] = s0; sc->slot[wp][1] = s1;
+        sc->n[wp][0] = q[s0]->ntaps; sc->n[wp][1] = q[s1]->ntaps;
+    }
+    sc->stages = sc->n[0][0] + sc->n[0][1];
+    for (int k = 0; k < 4; ++k) sc->q[k] = q[k];
+    // the kernel's compile-time patterns (pf_split_lp)
+    const int (&m)[2][2] = sc->n;
+    if (m[0][0] == 1 && m[0][1] == 4 && m[1][0] == 2 && m[1][1] == 2) sc->pat = 1;
+    else if (m[0][0] == 4 && m[0][1] == 4 && m[1][0] == 4 && m[1][1] == 4) sc->pat = 2;
+    else return false;
+    return sc->stages == pf_split_stages(sc->pat);
+}
+// tap s of pair wp: (phase problem, tap index), false past the pair's end
+bool pf_split_tap(const PFSplit& sc, int wp, int s, const GConvParams** q, int* t, int* lp) {
+    if (s < sc.n[wp][0]) { *q = sc.q[sc.slot[wp][0]]; *t = s; *lp = 0; return true; }
+    if (s < sc.n[wp][0] + sc.n[wp][1]) { *q = sc.q[sc.slot[wp][1]]; *t = s - sc.n[wp][0]; *lp = 1; return true; }
+    return false;
+}
+}  // namespace
+
 // The weight planes of the fused kernel: ONE problem whose tap list is the phases' taps one after the other, phase slot 2 ry + rx major
 // (the order of the kernel's multiply loop) -- what ss_launch_wprep_x6 / ss_gconv_x6_planes_bytes take.
 bool ss_gconv_phases_fused_wprob(const GConvParams* ps, int count, GConvParams* w) {
     if (!ss_gconv_phases_fused_ok(ps, count)) return false;
     *w = ps[0];
     w->ntaps = 0;
+    PFSplit sc;
+    if (pf_split_schedule(ps, &sc)) {          // the SPLIT form's stream order (a different tap list = a different cache identity)
+        for (int st = 0; st < sc.stages; ++st)
+            for (int wp = 0; wp < 2; ++wp) {
+                const GConvParams* q; int t, lp;
+                if (!pf_split_tap(sc, wp, st, &q, &t, &lp)) continue;
+                if (w->ntaps >= SS_MAX_TAPS) return false;
+                w->taps[w->ntaps++] = q->taps[t];
+            }
+        return true;
+    }
     for (int k = 0; k < 4; ++k)
         for (int i = 0; i < 4; ++i) {
             if (2 * ps[i].out_oy + ps[i].out_ox != k) continue;
@@ -444,20 +599,44 @@ int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* pl
     SsProfScope prof(pname, 2.0 * M * p0.Cout * taps * p0.Cin * (p0.dtype == SS_DTYPE_F32 ? 3 : (ss_tuning().wino16_products == 3 ? 2 : 1)),
                      (double)esz * ((double)p0.N * p0.IH * p0.IW * p0.Cin + 4.0 * M * p0.Cout) + 4.0 * taps * p0.Cin * p0.Cout, s);
     f.dbg = ss_tuning().tile_dbg;
-    auto go = [&](auto tc, auto npc) {
+    PFSplit sc;
+    const bool split = pf_split_schedule(ps, &sc);
+    if (split) {
+        f.sp_stages = sc.stages;
+        for (int wp = 0; wp < 2; ++wp) {
+            for (int st = 0; st < 8; ++st) {
+                const GConvParams* q; int t, lp;
+                if (st < sc.stages && pf_split_tap(sc, wp, st, &q, &t, &lp)) {
+                    f.sp_shift[wp][st] = (short)(q->taps[t].dy * f.hw + q->taps[t].dx);
+                    f.sp_lp[wp][st] = (signed char)lp;
+                } else {
+                    f.sp_shift[wp][st] = 0;
+                    f.sp_lp[wp][st] = -1;
+                }
+            }
+            for (int lp = 0; lp < 2; ++lp) { f.sp_ooy[wp][lp] = sc.slot[wp][lp] >> 1; f.sp_oox[wp][lp] = sc.slot[wp][lp] & 1; }
+        }
+    }
+    auto go = [&](auto tc, auto npc, auto spc) {
         typedef decltype(tc) T;
         constexpr int NPROD = decltype(npc)::value;
+        constexpr int SPLIT = decltype(spc)::value;
         static const bool attr_set = [] {
-            (void)hipFuncSetAttribute((const void*)gconv_phases_fused_kernel<T, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)gconv_phases_fused_kernel<T, NPROD, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return true;
         }();
         (void)attr_set;
-        hipLaunchKernelGGL((gconv_phases_fused_kernel<T, NPROD>), dim3((unsigned)nwg), dim3(256), PF_SMEM, s, f);
+        hipLaunchKernelGGL((gconv_phases_fused_kernel<T, NPROD, SPLIT>), dim3((unsigned)nwg), dim3(256), PF_SMEM, s, f);
+    };
+    auto go2 = [&](auto tc, auto npc) {
+        if (split && sc.pat == 1) go(tc, npc, std::integral_constant<int, 1>{});
+        else if (split) go(tc, npc, std::integral_constant<int, 2>{});
+        else go(tc, npc, std::integral_constant<int, 0>{});
     };
     const bool two = ss_tuning().wino16_products == 3;          // "fp32-grade arithmetic, only the storage is 16-bit"
-    if (p0.dtype == SS_DTYPE_F32) go(0.f, std::integral_constant<int, 3>{});
-    else if (p0.dtype == SS_DTYPE_F16) { if (two) go((_Float16)0, std::integral_constant<int, 2>{}); else go((_Float16)0, std::integral_constant<int, 1>{}); }
-    else { if (two) go((__bf16)0, std::integral_constant<int, 2>{}); else go((__bf16)0, std::integral_constant<int, 1>{}); }
+    if (p0.dtype == SS_DTYPE_F32) go2(0.f, std::integral_constant<int, 3>{});
+    else if (p0.dtype == SS_DTYPE_F16) { if (two) go2((_Float16)0, std::integral_constant<int, 2>{}); else go2((_Float16)0, std::integral_constant<int, 1>{}); }
+    else { if (two) go2((__bf16)0, std::integral_constant<int, 2>{}); else go2((__bf16)0, std::integral_constant<int, 1>{}); }
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -634,11 +634,13 @@ def test_probe_mfma_reports_a_real_data_ceiling_below_the_zero_operand_rate():
                                   ("disc_4x4_valid_even_dgrad", 4, 256, 512, 2, "valid", False, 16, 126, 126, "dgrad"),
                                   ("down_s2_dgrad_accumulated", 3, 64, 128, 2, "same", False, 2, 96, 80, "dgrad_acc")],
                          ids=lambda c: c[0])
-def test_fused_subpixel_phases_agree_with_one_launch_per_phase(case):
+@pytest.mark.parametrize("split", [1, 0], ids=["two_phases_per_wave_pair", "four_phases_per_wave"])
+def test_fused_subpixel_phases_agree_with_one_launch_per_phase(case, split):
     """gconv_phases_fused_kernel (conv_phase.hip: the four sub-pixel phases of a stride-2 data gradient / transposed convolution in one
     workgroup per input tile) against one gather launch per phase: the same x3h pieces and products in another K order, so the two
     agree to fp32 rounding (rel-L2 <= 2e-6, max |d| <= 1e-5 max|ref|) -- transposed forward, strided data gradients, odd output sizes
-    (class grids that differ by one between the phases), the discriminators' 4x4 layers (16 taps), ragged tile edges."""
+    (class grids that differ by one between the phases), the discriminators' 4x4 layers (16 taps), ragged tile edges.  Both forms of the
+    kernel: two phases per wave pair with the interleaved weight stream (`phases_split`, the default) and all four phases in every wave."""
     E, LY, L = _mods()
     name, k, cin, cout, stride, padding, transposed, n, h, w, which = case
     dev = torch.device("cuda:0")
@@ -647,7 +649,7 @@ def test_fused_subpixel_phases_agree_with_one_launch_per_phase(case):
     xt = torch.randn((n, h, w, cin), generator=g)
 
     def run(fused):
-        with L.config(phases_fused=fused):
+        with L.config(phases_fused=fused, phases_split=split):
             arena = E.ParamArena(dev)
             conv = LY.Conv2D(arena, "c", k, cin, cout, stride=stride, padding=padding, use_bias=False, transposed=transposed)
             arena.materialize()

@@ -10,9 +10,12 @@
 //     no per-tap address arithmetic;
 //   * the weight planes of one tap and chunk (64 rows x 64 B x 2 planes, pre-split and cached per weight version: the planes of the
 //     per-phase gather path, ss_launch_wprep_x6) arrive by LDS-DMA into a ring of four 8 KiB stages, two taps ahead;
-//   * 4 waves, each 32 class pixels x 64 channels x 4 phases = 128 accumulator registers; 61 KiB of LDS: TWO workgroups per CU, whose
-//     load / split / multiply phases interleave by themselves (a single 8-wave workgroup per CU measured slower for the gather weight
-//     gradient).
+//   * 4 waves, 128 accumulator registers each; 61 KiB of LDS: TWO workgroups per CU, whose load / split / multiply phases interleave by
+//     themselves (a single 8-wave workgroup per CU measured slower for the gather weight gradient).  Two forms:
+//     SPLIT = 0: every wave holds 32 class pixels x 64 channels of ALL FOUR phases (1.5 LDS fragment reads per MFMA triple);
+//     SPLIT = 1 / 2 (ss_tuning phases_split, the default where the tap counts fit its patterns): waves 0 / 1 hold 64 pixels x 64
+//     channels of two phases, waves 2 / 3 of the other two (1.0 reads per triple -- the loop is bound by the CU's LDS read rate), and
+//     the weight stream interleaves the two wave pairs' taps.
 // Arithmetic = gconv_x6v2_kernel's: x * 2^(14 - ea) = h + l, weights h + l under their own scale, products l*h, h*l, h*h into one fp32
 // accumulator, scales undone in the epilogue.  The K order differs (channel chunk outer, tap inner), so results agree with the
 // per-phase path to fp32 rounding, not bit for bit.

@@ -33,10 +33,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int PF_TH = 8, PF_TW = 16;                  // class-pixel tile: 128 pixels, 32 per wave (two rows of 16)
 constexpr int PF_LD = 80;                             // bytes per staged pixel and plane: 32 channels fp16 + 16 (conflict-free b128 reads)
 constexpr int PF_MAXPIX = (PF_TH + 2) * (PF_TW + 2);  // halo up to one pixel on every side
-constexpr int PF_A_PLANE = PF_MAXPIX * PF_LD;         // 14400
+// A stage row pitch: the halo row (16 .. 18 pixels x 80 B) padded to a multiple of 256 B.  ds_read_b128 is served in four lane groups that
+// MIX the two pixel rows of a fragment ({0-3, 12-15, 20-27}, ...; MI355X_MICROARCH.md, LDS): with rows hw * 80 B apart, hw = 17 / 18 put two
+// 16-byte slots of every group on busy banks (2-way: every A read cost twice -- SQ_LDS_BANK_CONFLICT was 27 % of the LDS cycles); with the
+// rows a whole number of 256-byte bank rows apart the 16 lanes of a group hit 16 different slots (5 c mod 16 over the columns).
+constexpr int PF_PITCH_MAX = ((PF_TW + 2) * PF_LD + 255) / 256 * 256;          // 1536
+constexpr int PF_A_PLANE = (PF_TH + 2) * PF_PITCH_MAX;                         // 15360
 constexpr int PF_B_TAP = 2 * 64 * 64;                 // [2 planes][64 output channels][32 channels fp16]
 constexpr int PF_RING = 4;
-constexpr int PF_SMEM = 2 * PF_A_PLANE + PF_RING * PF_B_TAP;          // 61568
+constexpr int PF_SMEM = 2 * PF_A_PLANE + PF_RING * PF_B_TAP;          // 63488
 constexpr int PF_SLOTS = (PF_MAXPIX * 8 + 255) / 256;                 // float4 staging slots per thread: 6
 
 __device__ float pf_zero_page16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -65,6 +70,7 @@ struct PFParams {
     const unsigned int* h_amax2;
     int amax_stripes;
     int hy0, hx0, hh, hw;          // halo tile: smallest tap offset, extents in pixels
+    int pitch;                     // bytes between the halo rows of an A plane in LDS (a multiple of 256)
     int tiles_y, tiles_x, ngroups; // class-pixel tiles per sample, 64-channel output groups
     int ntaps[4], out_oy[4], out_ox[4];
     short tdy[4][4], tdx[4][4];
@@ -75,7 +81,7 @@ struct PFParams {
     int dbg;          // measurement only (tile_dbg): 1 no input loads, 2 no weight DMA, 4 no fragment reads / MFMAs, 8 no barriers per tap
     // SPLIT form (two phases per wave pair): streamed pair s holds tap s of wave pair 0 and tap s of wave pair 1 (flattened 2 s + wp)
     int sp_stages;                 // streamed pairs per chunk
-    short sp_shift[2][8];          // [wave pair][s]: pixel offset dy * hw + dx of the tap inside the A stage
+    short sp_shift[2][8];          // [wave pair][s]: byte offset dy * pitch + dx * PF_LD of the tap inside the A stage
     signed char sp_lp[2][8];       // ... its local phase (0 / 1), -1: no tap (the shorter pair's last slot)
     int sp_ooy[2][2], sp_oox[2][2];          // [wave pair][local phase]: output sub-pixel of the phase
 };
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
     const T* const g_in = (const T*)p.in;
     T* const g_out = (T*)p.out;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    unsigned char* const sA = lds;                        // [2 planes][hh * hw pixels][PF_LD]
+    unsigned char* const sA = lds;                        // [2 planes][hh rows at p.pitch][hw pixels][PF_LD]
     unsigned char* const sB = lds + 2 * PF_A_PLANE;       // ring of PF_RING tap stages
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -159,7 +165,9 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
         for (int i = 0; i < PF_SLOTS; ++i) {
             const int e = tid + 256 * i;
             if ((e >> 3) >= npix) continue;
-            const int ao = (e >> 3) * PF_LD + (e & 7) * 8;
+            const int pix = e >> 3;
+            const int hy = (pix * hw_m) >> 16, hx = pix - hy * p.hw;
+            const int ao = hy * p.pitch + hx * PF_LD + (e & 7) * 8;
             unsigned int hh[2], ll[2];
             ss_split_h2(ra[i][0] * a_scale, ra[i][1] * a_scale, hh[0], ll[0]);
             ss_split_h2(ra[i][2] * a_scale, ra[i][3] * a_scale, hh[1], ll[1]);
@@ -189,12 +197,12 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a_shift[ph][t] = (p.tdy[ph][t] * p.hw + p.tdx[ph][t]) * PF_LD;
+        for (int t = 0; t < 4; ++t) a_shift[ph][t] = p.tdy[ph][t] * p.pitch + p.tdx[ph][t] * PF_LD;
     int sp_sh[2][8];          // SPLIT: byte offset of the tap of (wave pair, streamed pair) inside the A stage
 #pragma unroll
     for (int w2 = 0; w2 < 2; ++w2)
 #pragma unroll
-        for (int st = 0; st < 8; ++st) sp_sh[w2][st] = SPLIT ? p.sp_shift[w2][st] * PF_LD : 0;
+        for (int st = 0; st < 8; ++st) sp_sh[w2][st] = SPLIT ? p.sp_shift[w2][st] : 0;
     // Requests go out in PAIRS of taps (one barrier per pair = 24 MFMAs per wave, as gconv_x6v2): the NEXT pair starts at the even flattened
     // index d_g of chunk d_c and lands in ring stages d_stage, d_stage + 1.  A chunk with an odd tap count ends on a half pair whose second
     // request repeats the first tap (harmless: nobody reads that stage); past the last chunk the requests repeat its taps.  Every wave
@@ -229,9 +237,9 @@ __global__ __launch_bounds__(256, 2) void gconv_phases_fused_kernel(PFParams p) 
     const int row0 = SPLIT ? 4 * wi : 2 * wave;       // first class-pixel row of this wave inside the tile
 
     // fragment addresses.  A: this lane's class pixel (row 2 wave + (l31 >> 4), column l31 & 15) at halo coordinates (- hy0, - hx0),
-    // k-octet lh (+ 2 ks); a tap adds the uniform offset (dy_t * hw + dx_t) * PF_LD.  B: row ni * 32 + l31, slot (lh + 2 ks) ^ ((row >> 2) & 3).
-    const int a_lane = ((row0 + (l31 >> 4) - p.hy0) * p.hw + ((l31 & 15) - p.hx0)) * PF_LD + lh * 16;
-    const int a_mi = 2 * p.hw * PF_LD;          // SPLIT: second pixel block = two rows down
+    // k-octet lh (+ 2 ks); a tap adds the uniform offset dy_t * pitch + dx_t * PF_LD.  B: row ni * 32 + l31, slot (lh + 2 ks) ^ ((row >> 2) & 3).
+    const int a_lane = (row0 + (l31 >> 4) - p.hy0) * p.pitch + ((l31 & 15) - p.hx0) * PF_LD + lh * 16;
+    const int a_mi = 2 * p.pitch;          // SPLIT: second pixel block = two rows down
     const int sw = (l31 >> 2) & 3;
     const int so0 = (lh ^ sw) << 4, so1 = so0 ^ 32;
     const int b_lane = l31 * 64;
@@ -591,6 +599,7 @@ int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* pl
     f.plane_elems = (long)f.Npad * f.KT;
     if (2 * f.plane_elems >= (1L << 31)) return SS_ERR_UNSUPPORTED;
     f.hy0 = y0; f.hx0 = x0; f.hh = PF_TH + (y1 - y0); f.hw = PF_TW + (x1 - x0);
+    f.pitch = (f.hw * PF_LD + 255) / 256 * 256;
     f.tiles_y = (f.OHc + PF_TH - 1) / PF_TH; f.tiles_x = (f.OWc + PF_TW - 1) / PF_TW;
     f.ngroups = p0.Cout / 64;
     const long nwg = (long)p0.N * f.tiles_y * f.tiles_x * f.ngroups;
@@ -610,7 +619,7 @@ int ss_launch_gconv_phases_fused(const GConvParams* ps, const unsigned short* pl
             for (int st = 0; st < 8; ++st) {
                 const GConvParams* q; int t, lp;
                 if (st < sc.stages && pf_split_tap(sc, wp, st, &q, &t, &lp)) {
-                    f.sp_shift[wp][st] = (short)(q->taps[t].dy * f.hw + q->taps[t].dx);
+                    f.sp_shift[wp][st] = (short)(q->taps[t].dy * f.pitch + q->taps[t].dx * PF_LD);
                     f.sp_lp[wp][st] = (signed char)lp;
                 } else {
                     f.sp_shift[wp][st] = 0;

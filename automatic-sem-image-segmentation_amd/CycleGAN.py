@@ -186,11 +186,14 @@ class CycleGanModel:
             if cus:
                 # straight through the C ABI: this key changes no cached answer (L.config_set would bump the epoch all host-side caches key on)
                 lib = L.load()
+                prev = int(lib.ss_config_get(b"gemm_cus"))
+                if prev:          # configured by the caller (L.config_set / L.config): theirs wins, and stays
+                    return self._train_step_dual(real_a, real_b, one, zero, world)
                 lib.ss_config_set(b"gemm_cus", cus)
                 try:
                     return self._train_step_dual(real_a, real_b, one, zero, world)
                 finally:
-                    lib.ss_config_set(b"gemm_cus", 0)
+                    lib.ss_config_set(b"gemm_cus", prev)
             return self._train_step_dual(real_a, real_b, one, zero, world)
 
         # ---- generators -------------------------------------------------------------------------------
@@ -269,7 +272,7 @@ class CycleGanModel:
         finally:
             # whatever happened (a kernel error in one of the chains), leave the arenas in their single-chain state
             for net in (self.gen_a, self.gen_b):
-                net.arena.defer_hooks = False
+                net.arena.merge_into = net.arena.merge_from = None
 
     def _train_step_dual_body(self, real_a, real_b, one, zero, world):
         """The same step as two CONCURRENT kernel chains on two HIP streams.  In the generator phase the A->B->A chain
@@ -299,8 +302,11 @@ class CycleGanModel:
         db.zero_grad()
         ga.arena.zero_grad_alt()
         gb.arena.zero_grad_alt()
+        # Data parallel: a gradient bucket of a generator is final once BOTH chains have run their last op on it.  The chain that gets
+        # there second adds the other chain's share of that bucket to the main buffer and launches its exchange behind itself
+        # (engine.ParamArena.note_done / _fire) -- the up-sampling and trunk buckets travel while the stems are still in backward.
         for net in (ga, gb):
-            net.arena.defer_hooks = True          # a bucket is final only after the two buffers are added: exchange after the join
+            net.arena.merge_into, net.arena.merge_from = net.arena.grads, net.arena._alt()
         s1.wait_stream(cur)
         s2.wait_stream(cur)
         tape_a, tape_b = Tape(), Tape()
@@ -376,12 +382,12 @@ class CycleGanModel:
         gb.arena.merge_alt_grads()
         # the generator gradient exchange (the bulk of the step's bytes) runs behind the discriminator phase, which touches neither
         # the generators' weights nor their gradients; the generator optimizer steps are applied after it
-        gen_works = D.begin_all_reduce_grads([ga, gb])
+        for net in (ga, gb):
+            net.arena.merge_into = net.arena.merge_from = None
+        gen_works = D.begin_all_reduce_grads([ga, gb])          # what backward has not launched (buckets with unused variables)
         if os.environ.get("SS_DEFER_G_ALLREDUCE", "1") == "0":
             D.finish_all_reduce_grads(gen_works)
             gen_works = []
-        for net in (ga, gb):
-            net.arena.defer_hooks = False
         if not overlap_d:
             keep = discriminator_chains()
         cur.wait_stream(s3)

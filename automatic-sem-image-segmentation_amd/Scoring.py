@@ -128,3 +128,94 @@ def calculate_iou(predictions, ground_truths, watershed=True):
     return dict(iou_whole=w[0], best_threshold_whole=w[1], best_threshold_whole_true=w[2],
                 iou_instance_all=ia[0], best_threshold_instance_all=ia[1], best_threshold_instance_all_true=ia[2],
                 iou_instance_filtered=if_[0], best_threshold_instance_filtered=if_[1], best_threshold_instance_filtered_true=if_[2])
+
+
+# ---- one-command evaluation of a mounted dataset ---------------------------------------------------------------------------------
+# The publication's dataset (CC BY-NC-ND: mount it, do not vendor it) has the layout of the reference's ``Datasets/`` directory:
+IMAGES_SUBDIR = "Electron Microscopy Images/SEM"                                  # 40 images <id>.tif, 768 x 1024 (rows 712.. = the SEM info bar)
+GROUND_TRUTH_SUBDIR = "Electron Microscopy Image Masks/TiO2_Masks_Manual_4connected"     # <id>_m.tif
+
+
+def score_directories(prediction_dir, ground_truth_dir, crop_rows=0, watershed=True, raw=True, limit=None):
+    """``calculateIoU(dir)`` of Calculate_Scores.py:221-272 over a directory pair: every ground truth ``<id>_m.tif`` is paired with the
+    prediction ``<id>_raw.tif`` (the float probability map UNet.run_inference writes; ``raw=False`` or no such file: ``<id>.tif``), both
+    cropped to their first ``crop_rows`` rows when > 0.  Returns calculate_iou's dict + the number of pairs."""
+    import os
+    from PIL import Image
+    preds, gts, used = [], [], []
+    for name in sorted(os.listdir(ground_truth_dir)):
+        stem, ext = os.path.splitext(name)
+        if ext.lower() not in (".tif", ".tiff", ".png"):
+            continue
+        ident = stem[:-2] if stem.endswith("_m") else stem
+        cands = ([ident + "_raw.tif"] if raw else []) + [ident + ".tif", ident + ".png"]
+        path = next((os.path.join(prediction_dir, c) for c in cands if os.path.exists(os.path.join(prediction_dir, c))), None)
+        if path is None:
+            continue
+        p, g = np.asarray(Image.open(path)), np.asarray(Image.open(os.path.join(ground_truth_dir, name)))
+        if p.ndim == 3:
+            p = p[..., 0]
+        if g.ndim == 3:
+            g = g[..., 0]
+        if crop_rows > 0:
+            p, g = p[:crop_rows], g[:crop_rows]
+        if p.shape != g.shape:
+            raise ValueError(f"{path}: prediction {p.shape} and ground truth {g.shape} differ in shape")
+        preds.append(p)
+        gts.append(g)
+        used.append(ident)
+        if limit and len(used) >= limit:
+            break
+    if not used:
+        raise FileNotFoundError(f"no prediction in {prediction_dir} matches a ground-truth file of {ground_truth_dir}")
+    out = calculate_iou(preds, gts, watershed=watershed)
+    out["images"] = len(used)
+    return out
+
+
+def main(argv=None):
+    """python -m automatic-sem-image-segmentation_amd.Scoring --data-root /mnt/Datasets --model <run>/3_UNet/Models/<ts>/model.keras
+
+    Scores a trained MultiResUNet (or a directory of predictions) on a MOUNTED copy of the publication's dataset and prints the
+    whole-image / instance IoU of Calculate_Scores.py as one JSON line -- the figure BASELINE.json's "0.87 val IoU" refers to
+    (README.md:53-57 of the reference)."""
+    import argparse
+    import json
+    import os
+    import tempfile
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--data-root", required=True, help="the dataset root (layout of the reference's Datasets/ directory)")
+    ap.add_argument("--images", default=IMAGES_SUBDIR, help="image sub-directory of --data-root")
+    ap.add_argument("--ground-truth", default=GROUND_TRUTH_SUBDIR, help="ground-truth mask sub-directory of --data-root (<id>_m.tif)")
+    src = ap.add_mutually_exclusive_group(required=True)
+    src.add_argument("--model", help="model.keras / .npz of UNet.run_training: segment --images on the GPU first, then score")
+    src.add_argument("--predictions", help="directory of predictions (<id>_raw.tif probability maps or <id>.tif masks)")
+    ap.add_argument("--crop-rows", type=int, default=712, help="score the first N rows only (712: without the SEM info bar; 0: whole image)")
+    ap.add_argument("--tile", type=int, nargs=2, metavar=("W", "H"), default=None, help="tile size for inference (default: whole image)")
+    ap.add_argument("--no-watershed", action="store_true")
+    ap.add_argument("--limit", type=int, default=None, help="score the first N images only")
+    a = ap.parse_args(argv)
+    img_dir, gt_dir = os.path.join(a.data_root, a.images), os.path.join(a.data_root, a.ground_truth)
+    for d in (img_dir, gt_dir):
+        if not os.path.isdir(d):
+            raise SystemExit(f"{d}: no such directory (is the dataset mounted at --data-root?)")
+    pred_dir = a.predictions
+    tmp = None
+    if a.model:
+        from . import UNet_Segmentation as UN
+        tmp = tempfile.TemporaryDirectory()
+        pred_dir = tmp.name
+        un = UN.UNet(root_dir=tmp.name, image_dir=img_dir, mask_dir=gt_dir)
+        if a.tile:
+            un.image_shape = tuple(a.tile)
+        un.run_inference(files=img_dir, output_directory=pred_dir, model=a.model, tile_images=a.tile is not None, use_gpu=True)
+    res = score_directories(pred_dir, gt_dir, crop_rows=a.crop_rows, watershed=not a.no_watershed, limit=a.limit)
+    res.update(data_root=a.data_root, source=a.model or a.predictions, crop_rows=a.crop_rows)
+    print(json.dumps(res))
+    if tmp is not None:
+        tmp.cleanup()
+    return res
+
+
+if __name__ == "__main__":
+    main()

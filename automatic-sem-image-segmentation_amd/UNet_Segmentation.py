@@ -9,7 +9,6 @@ Reference surface mirrored here (file:line in the reference):
 * the Keras default ``train_step`` + metrics (loss / mae / acc) that ``model.fit`` runs (third party in the reference).
 """
 import json
-import math
 import os
 import random
 import time
@@ -25,100 +24,110 @@ from .nets import MultiResUNet
 from .optim import Adam
 
 
+# augmentation id -> axes np.flip reverses (UNet_Segmentation.py:93-98: none, left-right, up-down, both)
+_FLIP_AXES = {0: None, 1: (1,), 2: (0,), 3: (0, 1)}
+
+
 class ImageDataset:
-    """80/20 split with ``random.Random(1234)``, four flip augmentations per image (UNet_Segmentation.py:21-101)."""
+    """The image / mask file pairs of one subset: 80/20 split of the shuffled directory listing (``random.Random(1234)``), every
+    image under four flip ids (UNet_Segmentation.py:21-101).  ``image_ids`` / ``image_info`` keep the reference's names and record
+    layout; decoding goes through one ``_decode`` per file kind."""
 
     def __init__(self, image_dir, mask_dir, contrast_optimization_range=(0.5, 99.5), use_brightness_and_contrast_augmentation=False):
-        self.image_ids = []
-        self.image_info = {}
-        self.type = ''
         self.image_dir, self.mask_dir = image_dir, mask_dir
         self.contrast_optimization_range = contrast_optimization_range
         self.use_brightness_and_contrast_augmentation = use_brightness_and_contrast_augmentation
+        self.type = ''
+        self.image_ids, self.image_info = [], {}
 
     def add_image(self, image_id, path, mask, augmentation):
-        self.image_info[image_id] = {'id': image_id, 'image_path': path, 'mask_path': mask, 'augmentation': augmentation}
         self.image_ids.append(image_id)
+        self.image_info[image_id] = dict(id=image_id, image_path=path, mask_path=mask, augmentation=augmentation)
 
     def initialize_images(self, subset, train_val_split=0.8, seed=1234):
-        assert subset in ["train", "val"]
-        all_images = HelperFunctions.get_image_file_paths_from_directory(self.image_dir)
-        random.Random(seed).shuffle(all_images)
+        if subset not in ("train", "val"):
+            raise AssertionError(subset)
         self.type = subset
-        cut = int(train_val_split * len(all_images))
-        images = all_images[:cut] if subset == "train" else all_images[cut:]
-        for i, image_path in enumerate(images):
-            mask_path = image_path.replace(self.image_dir, self.mask_dir)
-            for j in range(4):
-                self.add_image('{:05d}'.format(i) + '_augmentation_' + str(j), image_path, mask_path, j)
+        files = HelperFunctions.get_image_file_paths_from_directory(self.image_dir)
+        random.Random(seed).shuffle(files)
+        cut = int(train_val_split * len(files))
+        for i, path in enumerate(files[:cut] if subset == "train" else files[cut:]):
+            mask = path.replace(self.image_dir, self.mask_dir)
+            for flip in sorted(_FLIP_AXES):
+                self.add_image(f"{i:05d}_augmentation_{flip}", path, mask, flip)
+
+    def _decode(self, info, is_mask):
+        load = HelperFunctions.load_and_preprocess_images
+        if is_mask:
+            return load(info['mask_path'], normalization_range=(0, 1), threshold_value=0.5)[0]
+        if self.type == 'train' and self.use_brightness_and_contrast_augmentation:
+            # three draws from the module-level RNG, in the reference's order: contrast window start, then the two range offsets
+            lo_pct = random.random() * 2
+            below, above = random.random(), random.random()
+            image = load(info['image_path'], normalization_range=(0 - below, 1 + above), contrast_optimization_range=(lo_pct, lo_pct + 98))[0]
+            image -= np.min(image)
+            image /= np.max(image)
+            return image
+        return load(info['image_path'], normalization_range=(0, 1), contrast_optimization_range=self.contrast_optimization_range)[0]
 
     def load_from_file(self, image_ids, is_mask):
-        if isinstance(image_ids, str):
-            image_ids = [image_ids]
-        images = []
-        for image_id in image_ids:
+        ids = [image_ids] if isinstance(image_ids, str) else image_ids
+        out = []
+        for image_id in ids:
             info = self.image_info[image_id]
-            if is_mask:
-                image = HelperFunctions.load_and_preprocess_images(info['mask_path'], normalization_range=(0, 1), threshold_value=0.5)[0]
-            elif self.type == 'train' and self.use_brightness_and_contrast_augmentation:
-                c_opt = random.random() * 2
-                image = HelperFunctions.load_and_preprocess_images(
-                    info['image_path'], normalization_range=(0 - random.random(), 1 + random.random()),
-                    contrast_optimization_range=(c_opt, c_opt + 98))[0]
-                image -= np.min(image)
-                image /= np.max(image)
-            else:
-                image = HelperFunctions.load_and_preprocess_images(info['image_path'], normalization_range=(0, 1),
-                                                                   contrast_optimization_range=self.contrast_optimization_range)[0]
-            a = info['augmentation']
-            if a == 1:
-                image = np.fliplr(image)
-            elif a == 2:
-                image = np.flipud(image)
-            elif a == 3:
-                image = np.fliplr(np.flipud(image))
-            images.append(image)
-        return np.asarray(images, dtype='float32')
+            tile, axes = self._decode(info, is_mask), _FLIP_AXES[info['augmentation']]
+            out.append(tile if axes is None else np.flip(tile, axis=axes))
+        return np.asarray(out, dtype='float32')
 
 
-class DataLoader:
-    """Batches loaded from disk on demand; ceil length (partial last batch) -- UNet_Segmentation.py:104-121."""
+class _Feeder:
+    """What ``fit`` iterates (a ``keras.utils.Sequence`` in the reference): batches ``fetch(keys[i*N:(i+1)*N])`` over a key order that
+    ``reorder`` permutes between epochs.  ``keep_partial`` is the length policy: ceil keeps the short last batch, floor drops it."""
+
+    def __init__(self, keys, fetch, reorder, batch_size, shuffle, keep_partial):
+        self._keys, self._fetch, self._reorder = keys, fetch, reorder
+        self.batch_size, self.shuffle, self._keep_partial = batch_size, shuffle, keep_partial
+
+    def __len__(self):
+        n, b = len(self._keys), self.batch_size
+        return -(-n // b) if self._keep_partial else n // b
+
+    def __getitem__(self, idx):
+        return self._fetch(self._keys[idx * self.batch_size:(idx + 1) * self.batch_size])
+
+    def on_epoch_end(self):
+        if self.shuffle:
+            self._reorder(self._keys)
+
+
+class DataLoader(_Feeder):
+    """Batches decoded from disk on demand, partial last batch kept; ids reshuffled with ``np.random`` (UNet_Segmentation.py:104-121)."""
 
     def __init__(self, dataset, batch_size=1, shuffle=True, **kwargs):
-        self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
-        self.all_image_ids = self.dataset.image_ids.copy()
+        self.dataset = dataset
+        super().__init__(list(dataset.image_ids), lambda ids: (dataset.load_from_file(ids, is_mask=False), dataset.load_from_file(ids, is_mask=True)),
+                         np.random.shuffle, batch_size, shuffle, keep_partial=True)
 
-    def __len__(self):
-        return math.ceil(len(self.all_image_ids) / self.batch_size)
-
-    def __getitem__(self, idx):
-        ids = self.all_image_ids[idx * self.batch_size:(idx + 1) * self.batch_size]
-        return self.dataset.load_from_file(ids, is_mask=False), self.dataset.load_from_file(ids, is_mask=True)
-
-    def on_epoch_end(self):
-        if self.shuffle:
-            np.random.shuffle(self.all_image_ids)
+    @property
+    def all_image_ids(self):
+        return self._keys
 
 
-class DataSet:
-    """In-memory arrays; floor length -- UNet_Segmentation.py:124-144."""
+class DataSet(_Feeder):
+    """Arrays held in memory, short last batch dropped; (x, y) pairs reshuffled with the ``random`` module (UNet_Segmentation.py:124-144)
+    -- as one index permutation: ``random.shuffle`` moves positions, not values, so permuting ``range(n)`` draws the same numbers and
+    lands every pair where shuffling the zipped list would."""
 
     def __init__(self, x, y, batch_size=1, shuffle=True, **kwargs):
-        self.x, self.y, self.batch_size, self.shuffle = x, y, batch_size, shuffle
+        self.x, self.y = x, y
+        super().__init__(range(len(x)), lambda sl: (self.x[sl.start:sl.stop], self.y[sl.start:sl.stop]), self._permute, batch_size, shuffle,
+                         keep_partial=False)
 
-    def __len__(self):
-        return self.x.shape[0] // self.batch_size
-
-    def __getitem__(self, idx):
-        return self.x[idx * self.batch_size:(idx + 1) * self.batch_size], self.y[idx * self.batch_size:(idx + 1) * self.batch_size]
-
-    def on_epoch_end(self):
-        if self.shuffle:
-            xy = list(zip(self.x, self.y))
-            random.shuffle(xy)
-            self.x, self.y = zip(*xy)
-            self.x = np.asarray(self.x, dtype='float32')
-            self.y = np.asarray(self.y, dtype='float32')
+    def _permute(self, _keys):
+        order = list(range(len(self.x)))
+        random.shuffle(order)
+        self.x = np.asarray(self.x, dtype='float32')[order]
+        self.y = np.asarray(self.y, dtype='float32')[order]
 
 
 class UNetModel:

@@ -713,14 +713,6 @@ bool ss_x6p_wide_ok(long M, int N, int K, int nbatch) {
     return ss_tuning().x6p == 2 || ((M + PBM - 1) / PBM) * (N / 256) * nbatch >= 512;      // x6p = 2 ("force"): any size (tests)
 }
 
-// measurement only (tools/x6p_pp_slots.py, tile_dbg & 512): slot-phase cycle sums of waves 0 (group 0) and 4 (group 1) of workgroup 0
-extern "C" int ss_dbg_x6p_slots(unsigned long long* out16) {
-    unsigned long long h[32];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_x6p_dbg), sizeof(h)) != hipSuccess) return SS_ERR_LAUNCH;
-    for (int i = 0; i < 16; ++i) out16[i] = h[i];
-    return SS_OK;
-}
-
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     if (p.K % PBK || p.k_per_split % PBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
     const bool wide = p.fp16x2 == 1 && p.plain_l;

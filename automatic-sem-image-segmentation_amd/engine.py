@@ -16,6 +16,7 @@ import torch
 from . import _lib as L
 
 _WS = {}
+_WS_RETIRED = []
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -42,10 +43,16 @@ def current_stream_obj():
     object per call (~8 us with its device-index checks; the per-GPU-batch-1 MultiResUNet step is paced by the host: 14 ms to issue
     11 ms of kernels, a fifth of it in such calls)."""
     raw = _stream().value or 0
-    obj = _STREAM_OBJS.get(raw)
+    key = (_DEV_INDEX if _DEV_INDEX is not None else torch.cuda.current_device(), raw)      # handle 0 = the default stream of EVERY device
+    obj = _STREAM_OBJS.get(key)
     if obj is None:
-        obj = _STREAM_OBJS[raw] = torch.cuda.current_stream()
+        obj = _STREAM_OBJS[key] = torch.cuda.current_stream()
     return obj
+
+
+def stream_obj_of(device, raw):
+    """The registered Stream object of a raw handle on ``device`` (side_streams / current_stream_obj register them), or None."""
+    return _STREAM_OBJS.get((device.index if device.index is not None else torch.cuda.current_device(), raw or 0))
 
 
 def raw_stream(stream):
@@ -65,7 +72,7 @@ def side_streams(device, n=2):
         have = have + tuple(torch.cuda.Stream(device=device) for _ in range(n - len(have)))
         _SIDE[key] = have
         for st in have:
-            _STREAM_OBJS.setdefault(st.cuda_stream, st)
+            _STREAM_OBJS.setdefault((st.device.index, st.cuda_stream), st)
     return have[:n]
 
 
@@ -76,9 +83,31 @@ def workspace(nbytes, device, stream=None):
     key = (device.type, device.index, ((_stream().value or 0) if stream is None else stream) if device.type == "cuda" else 0)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and stream is not None:
+            # The buffer is allocated from the pool of torch's CURRENT stream but used on `stream`: kernels still running there may be
+            # writing the old one (split-K partials of a weight gradient), and the caching allocator would hand its block to the next
+            # current-stream allocation as soon as the last reference drops.  Tell it about the other user first.
+            user = stream_obj_of(device, stream)
+            if user is not None:
+                buf.record_stream(user)
+            else:                    # a stream nobody registered: keep the old buffer alive for good (grow-only, a few per process)
+                _WS_RETIRED.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
+
+
+_SYNC = {}
+
+
+def sync_counters(device):
+    """ss_norm_desc.sync_counters of the CURRENT stream: a zeroed uint32 buffer the norm statistics kernels count their finished
+    workgroups in (every launch leaves it zero, launches on one stream are ordered: one buffer per stream serves every norm layer)."""
+    key = (device.type, device.index, _stream().value or 0)
+    buf = _SYNC.get(key)
+    if buf is None:
+        buf = _SYNC[key] = zero_(torch.empty(L.NORM_SYNC_COUNTERS, dtype=torch.int32, device=device))
+    return ctypes.c_void_p(buf.data_ptr())
 
 
 def _p(t):
@@ -600,17 +629,62 @@ class ParamArena:
             b["remaining"] = sum(1 for n in b["names"] if self.pending.get(n, 0) > 0)
             b["active"] = b["remaining"] > 0
             b["fired"] = False
+            b["merged"] = False
+            b["events"] = {}
 
     def note_done(self, names):
+        """The backward op accumulating into these variables has been ENQUEUED on the current stream.  With a gradient hook installed
+        (data parallel) the kernels writing one bucket may sit on several streams -- the chain, the weight-gradient side stream
+        (layers.Conv2D), a branch lane, the second chain of the dual-stream CycleGAN step -- and none of them waits for the others
+        before the end of backward.  So every call leaves an event on its stream (per bucket and stream: the latest), and the
+        stream that completes the bucket waits for the other streams' events before the exchange is launched behind it."""
+        pending, bucket_of = self.pending, self.bucket_of
+        if self.grad_hook is None:
+            for n in names:
+                c = pending.get(n, 0) - 1
+                pending[n] = c
+                if c == 0:
+                    bucket_of[n]["remaining"] -= 1
+            return
+        touched = []
         for n in names:
-            c = self.pending.get(n, 0) - 1
-            self.pending[n] = c
+            c = pending.get(n, 0) - 1
+            pending[n] = c
+            bk = bucket_of[n]
             if c == 0:
-                b = self.bucket_of[n]
-                b["remaining"] -= 1
-                if b["remaining"] == 0 and b["active"] and self.grad_hook is not None and not getattr(self, "defer_hooks", False):
-                    b["fired"] = True
-                    self.works.append(self.grad_hook(self.grads[b["start"]:b["end"]]))
+                bk["remaining"] -= 1
+            if bk not in touched:
+                touched.append(bk)
+        st = current_stream_obj() if self.device.type == "cuda" else None
+        for bk in touched:
+            if not bk["active"] or bk["fired"]:
+                continue
+            if bk["remaining"] == 0:
+                if st is not None:
+                    for other, ev in bk["events"].items():
+                        if other is not st:
+                            st.wait_event(ev)
+                bk["fired"] = True
+                self.works.append(self._fire(bk))
+            elif st is not None:
+                bk["events"][st] = st.record_event()
+
+    def _fire(self, b):
+        """Launch the exchange of one finished bucket behind the current stream.  Dual-chain steps (CycleGAN._train_step_dual) set
+        `merge_into` / `merge_from`: the second chain's share of the bucket is added to the first chain's buffer here, bucket by
+        bucket, instead of over the whole arena after both chains have joined."""
+        dst, src = self.grads, getattr(self, "merge_from", None)
+        if src is not None:
+            dst = self.merge_into
+            self._merge_bucket(dst, src, b)
+            b["merged"] = True
+        return self.grad_hook(dst[b["start"]:b["end"]])
+
+    def _merge_bucket(self, dst, src, b):
+        """dst[bucket] += src[bucket] on the current stream."""
+        off, n = b["start"] * 4, b["end"] - b["start"]
+        L.check(L.load().ss_axpby(1.0, ctypes.c_void_p(dst.data_ptr() + off), 1, 1.0, ctypes.c_void_p(src.data_ptr() + off), 1,
+                                  ctypes.c_void_p(dst.data_ptr() + off), 1, n, 1, _stream()), "axpby (bucket merge)")
 
     def __getitem__(self, name):
         return self.views[name]
@@ -642,10 +716,16 @@ class ParamArena:
         L.check(lib.ss_fill(_p(self._alt()), 0.0, self.grads_alt.numel(), _stream()), "ss_fill")
 
     def merge_alt_grads(self):
-        """grads += grads_alt (on the current stream)."""
+        """grads += grads_alt (on the current stream), except for the buckets `_fire` has merged during backward already."""
         lib = L.load()
-        n = self.grads.numel()
-        L.check(lib.ss_axpby(1.0, _p(self.grads), 1, 1.0, _p(self.grads_alt), 1, _p(self.grads), 1, n, 1, _stream()), "axpby")
+        if not any(b.get("merged") for b in self.buckets):
+            n = self.grads.numel()
+            L.check(lib.ss_axpby(1.0, _p(self.grads), 1, 1.0, _p(self.grads_alt), 1, _p(self.grads), 1, n, 1, _stream()), "axpby")
+            return
+        for b in self.buckets:
+            if not b.get("merged"):
+                self._merge_bucket(self.grads, self.grads_alt, b)
+                b["merged"] = True
 
     def zero_grad(self):
         lib = L.load()

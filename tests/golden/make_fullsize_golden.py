@@ -1,8 +1,14 @@
-"""Generate tests/golden/cyclegan_step_512_f64.npz: ONE complete CycleGAN train step at the headline shape -- full-size networks
-(F = 64, 9 residual blocks, PatchGAN 128), one 512x512 tile -- through the float64 oracle (the arbiter) and through the
-float32 oracle (the noise model: how far plain fp32 arithmetic of the same step lies from float64).
+"""Generate tests/golden/cyclegan_step_{512,256}_f64.npz and cyclegan_step_1024_f32.npz: ONE complete CycleGAN train step with the
+full-size networks (F = 64, 9 residual blocks, PatchGAN 128) on one tile of the headline size (512x512), of BASELINE config 3's size
+(256x256) and of config 5's size (1024x1024) -- through the float64 oracle (the arbiter) and through the float32 oracle
+(the noise model: how far plain fp32 arithmetic of the same step lies from float64).  The GPU suite used to compute the 256 and 1024
+oracle steps on the GPU box's host cores on every run (70 s of a 170 s suite, minutes on a loaded host); now they are data.
 
-    python tests/golden/make_fullsize_golden.py          (build container; ~10 min of CPU; needs nothing of /root/reference)
+    python tests/golden/make_fullsize_golden.py                       512x512, fp32 + fp64   (~10 min of CPU in the build container)
+    python tests/golden/make_fullsize_golden.py --size 256            256x256, fp32 + fp64   (~3 min)
+    python tests/golden/make_fullsize_golden.py --size 1024 --fp32    1024x1024, fp32 only   (~4 min; the 16-bit configs compare with fp32)
+
+(needs nothing of /root/reference)
 
 Stored (data only):
   * the 14 metrics in float64 and as the fp32 oracle computed them;
@@ -52,29 +58,33 @@ def crc_of(arrays):
     return c
 
 
-def sample_positions(i, total):
-    return np.sort(np.random.default_rng(SAMPLE_SEED + i).choice(total, min(SAMPLES, total), replace=False))
+def sample_positions(i, total, samples=None):
+    return np.sort(np.random.default_rng(SAMPLE_SEED + i).choice(total, min(samples or SAMPLES, total), replace=False))
 
 
-def main(size=S, filters=F, out_name="cyclegan_step_512_f64.npz"):
+def main(size=S, filters=F, out_name="cyclegan_step_512_f64.npz", fp32_only=False):
     torch.set_num_threads(os.cpu_count() or 1)
     real_a, real_b = inputs(size)
-    refs32, refs64 = make_nets(torch.float32, filters), make_nets(torch.float64, filters)
+    refs32 = make_nets(torch.float32, filters)
     init = {k: refs32[k].get_weights() for k in NETS}
-    for k in NETS:
-        refs64[k].set_weights(init[k])
+    refs64 = refs32
+    if not fp32_only:
+        refs64 = make_nets(torch.float64, filters)
+        for k in NETS:
+            refs64[k].set_weights(init[k])
     out = {"size": size, "filters": filters, "samples": SAMPLES, "sample_seed": SAMPLE_SEED, "input_seed": INPUT_SEED, "rng_seed": RNG_SEED,
            "crc_inputs": crc_of([real_a.numpy(), real_b.numpy()])}
     for k in NETS:
         out[f"crc_init/{k}"] = crc_of(init[k])
     res = {}
-    for tag, r, dt in (("32", refs32, torch.float32), ("64", refs64, torch.float64)):
+    for tag, r, dt in (("32", refs32, torch.float32),) + (() if fp32_only else (("64", refs64, torch.float64),)):
         step = OS.CycleGanStep(r["gen_a"], r["gen_b"], r["disc_a"], r["disc_b"], OS.ImagePool(2, 50), OS.ImagePool(2, 50))
         random.seed(RNG_SEED)
         m = step.train_step((real_a.to(dt), real_b.to(dt)))
         res[tag] = (m, {k: [(v.name, v.value.grad.detach().double().numpy()) for v in r[k].trainable_weights] for k in NETS})
         print(tag, {kk: float(vv) for kk, vv in m.items()}, flush=True)
-    (m32, g32), (m64, g64) = res["32"], res["64"]
+    out["fp32_only"] = int(fp32_only)          # then every "...64" entry below holds the fp32 oracle's value
+    (m32, g32), (m64, g64) = res["32"], res["32" if fp32_only else "64"]
     names = sorted(m64)
     out["metric_names"] = np.array(names)
     out["metrics64"] = np.array([float(m64[k]) for k in names], np.float64)
@@ -102,5 +112,10 @@ def main(size=S, filters=F, out_name="cyclegan_step_512_f64.npz"):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--small":      # quick self-check of the script (not committed)
         main(64, 8, "_scratch_fullsize_small.npz")
+    elif "--size" in sys.argv:
+        sz = int(sys.argv[sys.argv.index("--size") + 1])
+        only32 = "--fp32" in sys.argv
+        SAMPLES = 20000          # the headline fixture keeps 100 000 entries per network; these two are secondary shapes
+        main(sz, F, f"cyclegan_step_{sz}_{'f32' if only32 else 'f64'}.npz", fp32_only=only32)
     else:
         main()

@@ -39,6 +39,25 @@ D.broadcast_params(list(nets.values()) + [unet])          # rank 1 was seeded di
 D.enable_overlap(list(nets.values()) + [unet])             # bucketed all-reduce launched during backward
 if world > 1:
     D.enable_sync_bn(True)
+# count the generator buckets whose exchange is launched while a tape is still replaying (the overlap itself)
+E = importlib.import_module(B + ".engine")
+depth, fired = [0], [0]
+_bw = E.Tape.backward
+def bw(self):
+    depth[0] += 1
+    try:
+        return _bw(self)
+    finally:
+        depth[0] -= 1
+E.Tape.backward = bw
+def counting(inner):
+    def hook(flat):
+        fired[0] += 1 if depth[0] > 0 else 0
+        return inner(flat)
+    return hook
+for k in ("gen_a", "gen_b"):
+    if nets[k].arena.grad_hook is not None:
+        nets[k].arena.grad_hook = counting(nets[k].arena.grad_hook)
 model = CG.CycleGanModel(nets["gen_a"], nets["gen_b"], nets["disc_a"], nets["disc_b"], image_pool_a=CG.ImagePool(2, 0), image_pool_b=CG.ImagePool(2, 0))
 model.compile(OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5))
 m = model.train_step((a[sl].numpy(), b[sl].numpy()))
@@ -48,6 +67,8 @@ if rank == 0:
     arrs = {f"{k}/{i}": w for k, net in nets.items() for i, w in enumerate(net.get_weights())}
     arrs.update({f"unet/{i}": w for i, w in enumerate(unet.get_weights())})
     arrs["metrics"] = np.array([m[k] for k in sorted(m)] + [u[k] for k in sorted(u)])
+    arrs["gen_buckets_fired_in_backward"] = np.array(fired[0])
+    arrs["gen_buckets"] = np.array(len(nets["gen_a"].arena.buckets) + len(nets["gen_b"].arena.buckets))
     np.savez(out, **arrs)
 if world > 1:
     torch.distributed.barrier(); torch.distributed.destroy_process_group()
@@ -72,9 +93,12 @@ def _run(tmp_path, world):
 def test_two_rank_data_parallel_equals_single_process(tmp_path):
     one, two = _run(tmp_path, 1), _run(tmp_path, 2)
     np.testing.assert_allclose(two["metrics"], one["metrics"], rtol=5e-4, atol=1e-6)
+    # the dual-chain step (SS_DUAL_STREAM=force) launches every generator bucket from inside the second chain's backward
+    assert int(two["gen_buckets"]) >= 4 and int(two["gen_buckets_fired_in_backward"]) == int(two["gen_buckets"]), \
+        (int(two["gen_buckets_fired_in_backward"]), int(two["gen_buckets"]))
     num = den = 0.0
     for k in one.files:
-        if k == "metrics":
+        if k in ("metrics", "gen_buckets", "gen_buckets_fired_in_backward"):
             continue
         num += float(((two[k].astype(np.float64) - one[k]) ** 2).sum())
         den += float((one[k].astype(np.float64) ** 2).sum())

@@ -465,18 +465,21 @@ def test_conv_x6_is_fp32_grade(case):
         assert errs[L.ALGO_X6][i] <= 1.5 * errs[L.ALGO_MFMA][i] + 2e-7, errs
 
 
-def test_x6p_forced_on_small_shapes():
+_X6P_FORCED = [c for c in CONV_CASES if c[0].startswith("wino_")] + [c for c in X6_CASES if c[0] == "x6_trunk_wino"]
+
+
+@pytest.mark.parametrize("case", _X6P_FORCED, ids=[c[0] for c in _X6P_FORCED])
+def test_x6p_forced_on_small_shapes(case):
     """The pre-split-plane GEMM (csrc/gemm_x6p.hip) is only chosen for launches of >= 1024 workgroups (tests/test_fullsize_gpu.py
-    runs it at the real trunk shape); SS_X6P=force sends the small Winograd cases of this file through it too: ragged M (tiles not
-    a multiple of 256) and N (channels not a multiple of 128) tile edges."""
-    import subprocess
-    import sys
-    if os.environ.get("SS_X6P") == "force":
-        pytest.skip("already the forced child run")
-    env = dict(os.environ, SS_X6P="force")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "wino or x6_trunk", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    runs it at the real trunk shape); x6p = 2 (SS_X6P=force) sends the small Winograd cases of this file through it too: ragged M
+    (tiles not a multiple of 256) and N (channels not a multiple of 128) tile edges -- the same bodies and tolerances as the default
+    route's tests."""
+    E, LY, L = _mods()
+    with L.config(x6p=2):
+        if case[0] == "x6_trunk_wino":
+            test_conv_x6_is_fp32_grade(case)
+        else:
+            test_conv_fwd_bwd(case, "auto")
 
 
 @pytest.mark.parametrize("k2", [-24, -9, 13])

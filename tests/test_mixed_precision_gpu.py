@@ -223,38 +223,55 @@ def test_unet_train_step_config2_16bit_vs_fp32_oracle(dt, tol_p):
     assert all(np.isfinite(w).all() for w in hip.get_weights())
 
 
-def test_cyclegan_train_step_config5_fp16_checkpointed_vs_fp32_oracle():
+def _fullsize_golden_tools(golden_dir):
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("make_fullsize_golden", os.path.join(golden_dir, "make_fullsize_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_cyclegan_train_step_config5_fp16_checkpointed_vs_fp32_oracle(golden_dir):
     """BASELINE config 5 (one rank's share: 1 tile of 1024x1024): full-size CycleGAN (F = 64, 9 residual blocks) train step with
-    float16 activation storage, loss scale 1024 and the residual trunk recomputed in backward.  Against the fp32 oracle step on the
-    same tile: the 14 metrics within 2e-2 (relative, or absolute for values < 1)."""
+    float16 activation storage, loss scale 1024 and the residual trunk recomputed in backward.  Against the fp32 oracle's step on the
+    same tile -- tests/golden/cyclegan_step_1024_f32.npz, written by tests/golden/make_fullsize_golden.py --size 1024 --fp32 (the
+    oracle step costs ~1 min of the GPU box's host cores; inputs and initial weights are rebuilt from the seeds, verified by CRC):
+    the 14 metrics within 2e-2 (relative, or absolute for values < 1); the distance of sampled gradient entries is reported."""
+    import os
     CG, N, OPT = mod("CycleGAN"), mod("nets"), mod("optim")
-    S = 1024
-    g = torch.Generator().manual_seed(5)
-    real_a = torch.rand((1, S, S, 1), generator=g) * 2 - 1
-    real_b = (torch.rand((1, S, S, 1), generator=g) > 0.9).float() * 2 - 1
-    refs = dict(gen_a=ON.ResnetGenerator(filters=64, seed=1), gen_b=ON.ResnetGenerator(filters=64, seed=2),
-                disc_a=ON.PatchDiscriminator(filters=128, seed=3), disc_b=ON.PatchDiscriminator(filters=128, seed=4))
+    T = _fullsize_golden_tools(golden_dir)
+    z = np.load(os.path.join(golden_dir, "cyclegan_step_1024_f32.npz"))
+    S = int(z["size"])
+    assert S == 1024 and int(z["filters"]) == 64 and int(z["fp32_only"]) == 1
+    real_a, real_b = T.inputs(S)
+    assert T.crc_of([real_a.numpy(), real_b.numpy()]) == int(z["crc_inputs"]), "the seeded inputs differ from the fixture's"
+    refs = T.make_nets(torch.float32, 64)
+    init = {k: refs[k].get_weights() for k in T.NETS}
+    del refs
     kw = dict(device="cuda:0", act_dtype="f16")
     hips = dict(gen_a=N.ResnetGenerator(filters=64, checkpoint_blocks=True, **kw), gen_b=N.ResnetGenerator(filters=64, checkpoint_blocks=True, **kw),
                 disc_a=N.PatchDiscriminator(filters=128, **kw), disc_b=N.PatchDiscriminator(filters=128, **kw))
-    for k in refs:
-        hips[k].set_weights(refs[k].get_weights())
+    for k in T.NETS:
+        assert T.crc_of(init[k]) == int(z[f"crc_init/{k}"]), f"the seeded initial weights of {k} differ from the fixture's"
+        hips[k].set_weights(init[k])
     model = CG.CycleGanModel(hips["gen_a"], hips["gen_b"], hips["disc_a"], hips["disc_b"],
                              image_pool_a=CG.ImagePool(2, 50), image_pool_b=CG.ImagePool(2, 50))
     model.compile(OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5))
     assert model.loss_scale == 1024.0
     torch.cuda.reset_peak_memory_stats()
-    random.seed(11)
+    random.seed(int(z["rng_seed"]))
     got = model.train_step((real_a.numpy(), real_b.numpy()))
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
-    random.seed(11)
-    want = OS.CycleGanStep(refs["gen_a"], refs["gen_b"], refs["disc_a"], refs["disc_b"], OS.ImagePool(2, 50), OS.ImagePool(2, 50)).train_step((real_a, real_b))
+    want = {str(k): float(v) for k, v in zip(z["metric_names"], z["metrics32"])}
     worst = max(abs(got[k] - want[k]) / max(abs(want[k]), 1.0) for k in want)
     print(f"config 5 (fp16, checkpointed, 1 x {S}x{S}): worst metric deviation {worst:.2e}; peak device memory {peak:.1f} GiB")
     for k in want:
         assert abs(got[k] - want[k]) <= 2e-2 * max(abs(want[k]), 1.0), (k, got[k], want[k])
-    for k in hips:
+    for i, k in enumerate(T.NETS):
         assert all(np.isfinite(w).all() for w in hips[k].get_weights()), k
-        a = np.concatenate([w.ravel() for w in hips[k].get_weights()])
-        b = np.concatenate([w.ravel() for w in refs[k].get_weights()])
-        print(f"  {k}: updated weights rel-L2 vs fp32 oracle {rel_l2(a, b):.2e}")
+        gh = hips[k].get_gradients()
+        vec = np.concatenate([np.asarray(gh[str(n)], np.float64).ravel() for n in z[f"{k}/tensor_names"]]) / model.loss_scale
+        pos = T.sample_positions(i, vec.size, int(z["samples"]))
+        s32 = z[f"{k}/sample32"].astype(np.float64)
+        print(f"  {k}: sampled gradient entries rel-L2 vs fp32 oracle {rel_l2(vec[pos], s32):.2e}")

@@ -169,3 +169,31 @@ def test_iou_sweep_reproduces_reference_slot_quirk():
     assert r["iou_whole"] > 0.9
     # thresholds 0.1 .. 0.5 separate the classes; the first (lowest) best true threshold is 0.1, reported by the reference as slot 0 -> 0.0
     assert r["best_threshold_whole_true"] == pytest.approx(r["best_threshold_whole"] + 0.1)
+
+
+def test_data_root_scoring_command_on_a_dataset_directory(tmp_path, capsys):
+    """The one-command hook for a MOUNTED dataset (missing 2): `python -m <package>.Scoring --data-root ... --predictions ...`
+    pairs <id>_m.tif ground truths with <id>_raw.tif / <id>.tif predictions in the reference's Datasets/ layout, crops the SEM info bar
+    rows and prints calculate_iou's figures as one JSON line."""
+    import json
+    from PIL import Image
+    S = importlib.import_module(BASE + ".Scoring")
+    img_dir, gt_dir, pred_dir = tmp_path / S.IMAGES_SUBDIR, tmp_path / S.GROUND_TRUTH_SUBDIR, tmp_path / "pred"
+    for d in (img_dir, gt_dir, pred_dir):
+        d.mkdir(parents=True)
+    yy, xx = np.mgrid[0:96, 0:128]
+    for k, ident in enumerate(("1908248", "1908250")):
+        gt = (((yy - 30) ** 2 + (xx - 40 - 20 * k) ** 2 < 15 ** 2) | ((yy - 60) ** 2 + (xx - 90) ** 2 < 12 ** 2)).astype(np.uint8) * 255
+        gt[80:] = 255                                   # "info bar" rows: must be cropped away, the prediction has nothing there
+        prob = np.where(gt > 0, 0.9, 0.05).astype(np.float32)
+        prob[80:] = 0.0
+        prob[28:33, 38 + 20 * k:43 + 20 * k] = 0.05     # a small defect: IoU < 1
+        Image.fromarray(gt).save(gt_dir / f"{ident}_m.tif")
+        Image.fromarray(prob).save(pred_dir / f"{ident}_raw.tif")
+        Image.fromarray(np.zeros((96, 128), np.uint8)).save(img_dir / f"{ident}.tif")
+    res = S.main(["--data-root", str(tmp_path), "--predictions", str(pred_dir), "--crop-rows", "80", "--no-watershed"])
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["images"] == 2 and line["crop_rows"] == 80 and abs(line["iou_whole"] - res["iou_whole"]) < 1e-12
+    assert 0.9 < res["iou_whole"] < 1.0 and res["best_threshold_whole_true"] in (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8)
+    with pytest.raises(SystemExit):
+        S.main(["--data-root", str(tmp_path / "nowhere"), "--predictions", str(pred_dir)])

@@ -88,6 +88,21 @@ def test_train_step_matches_oracle_incl_gradient_penalty(dropout):
     gen, crit = W.WganGenerator(hw[0], hw[1], n_z=n_z), W.WganCritic(hw[0], hw[1])
     gen.set_weights(gw)
     crit.set_weights(dw)
+    # the float64 oracle arbitrates, as in the CycleGAN / UNet step tests: same weights, same draws
+    go64, do64 = OW.WganGenerator(hw[0], hw[1], n_z=n_z, seed=1, dtype=torch.float64), OW.WganCritic(hw[0], hw[1], seed=2, dtype=torch.float64)
+    go64.set_weights(gw)
+    do64.set_weights(dw)
+    ostep64 = OW.WganStep(go64, do64, d_steps=d_steps)
+
+    def to64(v):
+        if isinstance(v, torch.Tensor):
+            return v.double()
+        if isinstance(v, dict):
+            return {k: to64(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [to64(x) for x in v]
+        return v
+
     ostep = OW.WganStep(go, do, d_steps=d_steps)
     model = W.WGAN_GP(discriminator=crit, generator=gen, latent_dim=n_z, discriminator_extra_steps=d_steps)
     model.compile(d_optimizer=OPT.Adam(learning_rate=0.0002, beta_1=0.5, beta_2=0.9),
@@ -97,6 +112,7 @@ def test_train_step_matches_oracle_incl_gradient_penalty(dropout):
     for it in range(2):
         draws = _draws(n, n_z, d_steps, do, hw, 100 + it, dropout)
         ref = ostep.train_step(real, draws)
+        ref64 = ostep64.train_step(real.double(), to64(draws)) if it == 0 else None
         model.grad_log = {"d": [], "g": []}
         model.train_step(real.numpy(), draws)
         got = model.last
@@ -106,11 +122,18 @@ def test_train_step_matches_oracle_incl_gradient_penalty(dropout):
         for i in range(d_steps):
             got_g = [model.grad_log["d"][i][nme].reshape(gr.shape) for nme, gr in zip(dnames, ref["d_grads"][i])]
             if (it, i) == (0, 0):
-                # strict, per variable, on the first update (identical weights; fp32 vs fp32 -- the fake (+1/n) and real (-1/n)
-                # halves nearly cancel in the first layers)
-                for nme, a_, gr in zip(dnames, got_g, ref["d_grads"][i]):
-                    e = _rel(a_, gr.numpy())
-                    assert e < 5e-3, (it, "critic", i, nme, e)
+                # strict, per variable, on the first update (identical weights).  The fake (+1/n) and real (-1/n) halves nearly cancel
+                # in the first layers, so the noise model is the fp32 oracle's own distance to float64: per variable the HIP gradient
+                # may be 3x as far from float64 as that -- floored, for variables the fp32 oracle happens to hit exactly, at the fp32
+                # oracle's whole-gradient relative error -- plus 1e-4 of the variable's norm (the rule of test_fullsize_gpu.py).
+                g64 = [g.numpy() for g in ref64["d_grads"][0]]
+                g32 = [g.numpy().astype(np.float64) for g in ref["d_grads"][0]]
+                net32 = (sum(float(((a - b) ** 2).sum()) for a, b in zip(g32, g64)) / sum(float((b ** 2).sum()) for b in g64)) ** 0.5
+                for nme, a_, b32, b64 in zip(dnames, got_g, g32, g64):
+                    n64 = float(np.linalg.norm(b64))
+                    e_hip = float(np.linalg.norm(a_.astype(np.float64) - b64))
+                    allow = 3 * max(float(np.linalg.norm(b32 - b64)), net32 * n64) + 1e-4 * n64
+                    assert e_hip <= allow, (it, "critic", i, nme, e_hip, allow, n64)
             # Later updates start from weights that already differ: Adam's first steps are lr * sign(g), so a gradient element
             # whose rounding differs in sign moves a weight by 2 lr = 4e-4.  Whole-gradient relative L2 error there.
             num = sum(float(((a_.astype(np.float64) - gr.numpy().astype(np.float64)) ** 2).sum()) for a_, gr in zip(got_g, ref["d_grads"][i]))

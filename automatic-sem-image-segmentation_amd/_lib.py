@@ -54,9 +54,7 @@ class NormDesc(_SizedDesc):
                 # optional slots the norm raises to max|y| (forward) / max|dx| (backward) while writing the tensor (x3h scales)
                 ("y_amax", c_vp), ("dx_amax", c_vp),
                 # optional input statistics from the producing convolution's epilogue (ss_conv_desc.y_stats)
-                ("x_stats", c_vp), ("x_stats_chunks", c_i32), ("reserved0", c_i32),
-                # optional zeroed counter buffer (NORM_SYNC_COUNTERS uint32, one stream at a time): the statistics kernels' last workgroup finalizes
-                ("sync_counters", c_vp)]
+                ("x_stats", c_vp), ("x_stats_chunks", c_i32), ("reserved0", c_i32)]
 
 
 class ProfEntry(ctypes.Structure):
@@ -65,7 +63,6 @@ class ProfEntry(ctypes.Structure):
 
 
 PAD_ZERO, PAD_REFLECT = 0, 1
-NORM_SYNC_COUNTERS = 4096          # SS_NORM_SYNC_COUNTERS
 POOL_PASS, POOL_FILL, POOL_SWAP, POOL_MAX_QUERY = 0, 1, 2, 16          # ss_pool_query modes
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2      # ss_dtype: storage type of activation tensors
 

@@ -50,7 +50,6 @@ const Key KEYS[] = {
     {"gconv_phases", &SsTuning::gconv_phases, "OPT-IN (default 0; measured slower or equal: the phases' weight planes then compete for one L2): stride-2 data gradients / transposed convolutions with the four sub-pixel phases in ONE launch of the x3h gather kernels (same results bit for bit); 0: one launch per phase"},
     {"phases_fused", &SsTuning::phases_fused, "stride-2 data gradients / transposed convolutions (fp32 storage, x3h): the four sub-pixel phases of an input tile in ONE workgroup -- the tile is loaded and split once per 32-channel chunk and every tap reads it from LDS (conv_phase.hip); 0: one gather-kernel launch per phase"},
     {"phases_split", &SsTuning::phases_split, "the fused sub-pixel kernel with TWO phases per wave pair (64 pixels x 64 channels x 2 phases per wave: one A and one B fragment read per MFMA triple instead of 1.5; the weight stream interleaves the two wave pairs' taps); 0: all four phases in every wave"},
-    {"norm_fin_tail", &SsTuning::norm_fin_tail, "norm statistics kernels: the last workgroup per (group, channel block) finalizes mean / rstd itself when the caller provides ss_norm_desc::sync_counters; 0: a separate finalize launch (same bits)"},
     {"wgrad_tn", &SsTuning::wgrad_tn, "Winograd weight gradient on pre-split K-major fp16 planes with transposing LDS reads (gemm_tn_x3h.hip); 0: in-kernel split"},
 };
 
@@ -88,7 +87,6 @@ SsTuning from_env() {
     v.tile_dbg = getenv("SS_TILE_DBG") ? atoi(getenv("SS_TILE_DBG")) : 0;
     v.tile_stagger = getenv("SS_TILE_STAGGER") ? atoi(getenv("SS_TILE_STAGGER")) : 2;
     v.weight_cache = 1;
-    v.norm_fin_tail = env_is("SS_NORM_FIN_TAIL", '0') ? 0 : 1;
     return v;
 }
 

@@ -84,29 +84,6 @@ template <int V> __device__ __forceinline__ void stv(__bf16* p, const float (&o)
     else *p = (__bf16)o[0];
 }
 
-// Finalize work handed to the statistics kernel's LAST block per (group, channel block): when `counters` is given (caller-owned,
-// zero on entry, left zero -- ss_norm_desc::sync_counters) every block announces itself on counters[g * cblocks + cblock] after its
-// partials are device-visible, and the block that arrives last runs the finalize steps of that channel block itself.  The separate
-// norm_finalize_* launch (6-8 us of a ~10 us-per-launch chain at per-GPU batch 1; 370 of them per CycleGAN + UNet step) disappears;
-// same steps, same order of summation, same bits.
-struct FinTail {
-    unsigned int* counters = nullptr;
-    int CL = 8;
-    float eps = 0.f, momentum = 0.f;
-    float* mean = nullptr;          // MODE 0 outputs
-    float* rstd = nullptr;
-    float* mm = nullptr;
-    float* mv = nullptr;
-    float* sums = nullptr;          // MODE 1 outputs
-    double* rt = nullptr;
-};
-__device__ __forceinline__ void fin_fwd_step(const float* __restrict__ part, int chunks, int C, long P, float eps,
-                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                             float* __restrict__ mm, float* __restrict__ mv, float momentum, int CL, int cb, int g,
-                                             double (*red)[256]);
-__device__ __forceinline__ void fin_bwd_step(const float* __restrict__ part, int chunks, int C, long P,
-                                             float* __restrict__ sums, double* __restrict__ rt, int CL, int cb, int g, double (*red)[256]);
-
 // partial sums: part[((g*chunks + chunk)*C + c)*2 + {0,1}]
 // MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat) with g = dy * act'(y)
 // Thread = V consecutive channels x a strided set of pixels; CT = channel lanes (in units of V), PT = 256/CT.
@@ -118,8 +95,7 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x
                                                          int act, float alpha,
                                                          int C, long P, long pix_per_chunk, int CT, int PT,
                                                          float* __restrict__ part,
-                                                         const float* __restrict__ rgamma = nullptr, const float* __restrict__ rbeta = nullptr,
-                                                         FinTail fin = FinTail()) {
+                                                         const float* __restrict__ rgamma = nullptr, const float* __restrict__ rbeta = nullptr) {
     // MODE 1 with y == nullptr (relu / leaky relu without residual): the activation mask is recomputed from x with the forward's
     // expression (y > 0 <=> t > 0) -- one tensor read less in each of the two backward passes
     __shared__ float red[2 * V][256];
@@ -205,42 +181,17 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x
 #pragma unroll
         for (int v = 0; v < V; ++v) { o[2 * v] = red[2 * v][threadIdx.x]; o[2 * v + 1] = red[2 * v + 1][threadIdx.x]; }
     }
-    if (fin.counters == nullptr) return;          // (uniform) the finalize kernel follows as a launch of its own
-    // last block of this (group, channel block): finalize its channels
-    __shared__ int last;
-    __shared__ double fred[2][256];
-    __threadfence();                              // this block's partials: visible to the whole device before the announcement
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int* ctr = fin.counters + (long)g * gridDim.y + blockIdx.y;
-        const unsigned int prev = atomicAdd(ctr, 1u);
-        last = prev == gridDim.x - 1;
-        if (last) *ctr = 0u;                      // left zero for the next launch on this stream (kernel boundary orders it)
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();                              // the other blocks' partials
-    const int c_lo = blockIdx.y * CT * V;
-    const int c_hi = c_lo + CT * V < C ? c_lo + CT * V : C;
-    const int chunks = gridDim.x;
-    // the separate kernel walks channel steps at multiples of CL from 0: same steps here (CT * V is a multiple of CL or the only block)
-    for (int cb = c_lo / fin.CL * fin.CL; cb < c_hi; cb += fin.CL) {
-        if (MODE == 0) fin_fwd_step(part, chunks, C, P, fin.eps, fin.mean, fin.rstd, fin.mm, fin.mv, fin.momentum, fin.CL, cb, g, fred);
-        else fin_bwd_step(part, chunks, C, P, fin.sums, fin.rt, fin.CL, cb, g, fred);
-        __syncthreads();
-    }
 }
 
 // mean / rstd per (g,c); optional moving-average update (batch norm, G == 1).
-// One block-wide step: CL channels [cb, cb + CL) x KL = 256/CL chunk lanes of group g (fixed-order LDS combine -> deterministic).
-// Shared by the finalize kernel (one step per block) and by the statistics kernel's LAST block (FinTail: all steps of its channels).
-__device__ __forceinline__ void fin_fwd_step(const float* __restrict__ part, int chunks, int C, long P, float eps,
-                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                             float* __restrict__ mm, float* __restrict__ mv, float momentum, int CL, int cb, int g,
-                                             double (*red)[256]) {
+// Block = 32 channels x 8 chunk lanes (fixed-order LDS combine -> deterministic); grid = (C/32, G).
+__global__ __launch_bounds__(256) void norm_finalize_fwd(const float* __restrict__ part, int chunks, int G, int C, long P, float eps,
+                                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                                         float* __restrict__ mm, float* __restrict__ mv, float momentum, int CL) {
+    __shared__ double red[2][256];
     const int KL = 256 / CL;                      // CL channels x KL chunk lanes per block (CL = 32, or 8 for narrow tensors)
     const int cl = threadIdx.x % CL, kl = threadIdx.x / CL;
-    const int c = cb + cl;
+    const int c = blockIdx.x * CL + cl, g = blockIdx.y;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
         // 8 loads in flight per thread (the loop is latency-bound: 23 us for a 2 MB partials array when rolled); same k order
@@ -274,14 +225,6 @@ __device__ __forceinline__ void fin_fwd_step(const float* __restrict__ part, int
             mv[c] = mv[c] * momentum + (float)var * (1.f - momentum);
         }
     }
-}
-
-// Block = CL channels x 256/CL chunk lanes; grid = (C/CL, G).
-__global__ __launch_bounds__(256) void norm_finalize_fwd(const float* __restrict__ part, int chunks, int G, int C, long P, float eps,
-                                                         float* __restrict__ mean, float* __restrict__ rstd,
-                                                         float* __restrict__ mm, float* __restrict__ mv, float momentum, int CL) {
-    __shared__ double red[2][256];
-    fin_fwd_step(part, chunks, C, P, eps, mean, rstd, mm, mv, momentum, CL, blockIdx.x * CL, blockIdx.y, red);
 }
 
 // y = act((x-mean)*rstd*gamma + beta + residual)
@@ -383,15 +326,15 @@ __global__ __launch_bounds__(256) void norm_infer_kernel(const T* __restrict__ x
 // Block = CL channels x 256/CL chunk lanes of ONE group, grid (C/CL, G) (it walked the groups one after the other on C/CL blocks:
 // a chain of G memory round trips, 23 us for the 8 instances of a trunk layer); every combine is a fixed-order LDS sum.  dgamma /
 // dbeta = the totals summed over the groups in group order: norm_bwd_apply_kernel does that from rt (same values as before).
-__device__ __forceinline__ void fin_bwd_step(const float* __restrict__ part, int chunks, int C, long P,
-                                             float* __restrict__ sums /* [G*C*2] */, double* __restrict__ rt /* [G*C*2] */, int CL, int cb, int g,
-                                             double (*red)[256]) {
+__global__ __launch_bounds__(256) void norm_finalize_bwd(const float* __restrict__ part, int chunks, int G, int C, long P,
+                                                         float* __restrict__ sums /* [G*C*2] */, double* __restrict__ rt /* [G*C*2] */, int CL) {
+    __shared__ double red[2][256];
     const int KL = 256 / CL;
     const int cl = threadIdx.x % CL, kl = threadIdx.x / CL;
-    const int c = cb + cl;
+    const int c = blockIdx.x * CL + cl, g = blockIdx.y;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int k = kl; k < chunks; k += 8 * KL) {          // 8 loads in flight, same k order (see fin_fwd_step)
+        for (int k = kl; k < chunks; k += 8 * KL) {          // 8 loads in flight, same k order (see norm_finalize_fwd)
             float a0[8], a1[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -416,12 +359,6 @@ __device__ __forceinline__ void fin_bwd_step(const float* __restrict__ part, int
         rt[i + 0] = s1;
         rt[i + 1] = s2;
     }
-}
-
-__global__ __launch_bounds__(256) void norm_finalize_bwd(const float* __restrict__ part, int chunks, int G, int C, long P,
-                                                         float* __restrict__ sums /* [G*C*2] */, double* __restrict__ rt /* [G*C*2] */, int CL) {
-    __shared__ double red[2][256];
-    fin_bwd_step(part, chunks, C, P, sums, rt, CL, blockIdx.x * CL, blockIdx.y, red);
 }
 
 // dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) ; dres = g.  Channel-stationary threads as norm_apply_kernel: the seven
@@ -851,12 +788,6 @@ int pick_v16(int c, std::initializer_list<int> strides, std::initializer_list<co
     return 4;
 }
 
-// the statistics kernel's last blocks finalize (FinTail) when the caller handed a counter buffer that covers the launch's
-// (group, channel block) pairs and the tuning table does not switch it off (norm_fin_tail = 0: two launches, for A/B measurements)
-bool fin_tail_ok(const ss_norm_desc* d, const NormGeom& g) {
-    return d->sync_counters != nullptr && ss_tuning().norm_fin_tail && (long)g.G * g.cblocks <= SS_NORM_SYNC_COUNTERS;
-}
-
 size_t part_bytes(const ss_norm_desc* d) {
     return ss_align_up((size_t)d->groups * norm_max_chunks(d->groups) * d->c * 2 * sizeof(float), 256);
 }
@@ -895,8 +826,6 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     const float* part = (const float*)ws;
     int chunks = g.chunks;
     const double elems = (double)g.G * g.P * g.C;
-    const int fcl = fin_cl(g.C, g.G);
-    bool finalized = false;
     if (d->x_stats && d->x_stats_chunks > 0) {
         // the producing convolution's epilogue already summed x and x^2 ([n][chunks][c][2]; groups = 1: the samples' chunks follow
         // one another, i.e. n * chunks chunks of the one group)
@@ -905,26 +834,18 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     } else {
         const dim3 sgrid(g.chunks, g.cblocks, g.G);
         SsProfScope prof("norm_stats_kernel<fwd>", 0.0, elems * sizeof(T), s);          // algorithmic bytes: one read of x
-        FinTail ft;
-        if (fin_tail_ok(d, g)) {          // the last block per (group, channel block) finalizes: no finalize launch
-            ft.counters = (unsigned int*)d->sync_counters;
-            ft.CL = fcl; ft.eps = d->eps; ft.momentum = momentum;
-            ft.mean = mean; ft.rstd = rstd; ft.mm = moving_mean; ft.mv = moving_var;
-            finalized = true;
-        }
         if (V == 4)
             hipLaunchKernelGGL((norm_stats_kernel<T, 0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                               0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, (float*)ws, nullptr, nullptr, ft);
+                               0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, (float*)ws);
         else
             hipLaunchKernelGGL((norm_stats_kernel<T, 0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                               0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, (float*)ws, nullptr, nullptr, ft);
+                               0, 0.f, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, (float*)ws);
         SS_LAUNCH_CHECK();
     }
-    if (!finalized) {
-        hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + fcl - 1) / fcl, g.G), dim3(256), 0, s,
-                           part, chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum, fcl);
-        SS_LAUNCH_CHECK();
-    }
+    const int fcl = fin_cl(g.C, g.G);
+    hipLaunchKernelGGL(norm_finalize_fwd, dim3((g.C + fcl - 1) / fcl, g.G), dim3(256), 0, s,
+                       part, chunks, g.G, g.C, g.P, d->eps, mean, rstd, moving_mean, moving_var, momentum, fcl);
+    SS_LAUNCH_CHECK();
     if (!y) return SS_OK;
     const ApplyGeom ag = apply_geom(g, V);
     SsProfScope prof("norm_apply_kernel", 0.0, elems * sizeof(T) * (residual ? 3 : 2), s);          // read x (+ residual), write y
@@ -1006,28 +927,21 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
     float* sums = (float*)((char*)ws + part_bytes(d));
     const dim3 sgrid(g.chunks, g.cblocks, g.G);
     const double elems = (double)g.G * g.P * g.C;
-    double* rt = (double*)((char*)ws + part_bytes(d) + ss_align_up((size_t)g.G * g.C * 2 * sizeof(float), 256));
-    const int fcl = fin_cl(g.C, g.G);
-    FinTail ft;
-    if (fin_tail_ok(d, g)) {
-        ft.counters = (unsigned int*)d->sync_counters;
-        ft.CL = fcl; ft.sums = sums; ft.rt = rt;
-    }
     {
         SsProfScope prof("norm_stats_kernel<bwd>", 0.0, elems * sizeof(T) * (use_y ? 3 : 2), s);          // read dy, x (+ y)
         if (V == 4)
             hipLaunchKernelGGL((norm_stats_kernel<T, 1, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
-                               d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta, ft);
+                               d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
         else
             hipLaunchKernelGGL((norm_stats_kernel<T, 1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
-                               d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta, ft);
+                               d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
         SS_LAUNCH_CHECK();
     }
-    if (!ft.counters) {
-        hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + fcl - 1) / fcl, g.G), dim3(256), 0, s,
-                           part, g.chunks, g.G, g.C, g.P, sums, rt, fcl);
-        SS_LAUNCH_CHECK();
-    }
+    double* rt = (double*)((char*)ws + part_bytes(d) + ss_align_up((size_t)g.G * g.C * 2 * sizeof(float), 256));
+    const int fcl = fin_cl(g.C, g.G);
+    hipLaunchKernelGGL(norm_finalize_bwd, dim3((g.C + fcl - 1) / fcl, g.G), dim3(256), 0, s,
+                       part, g.chunks, g.G, g.C, g.P, sums, rt, fcl);
+    SS_LAUNCH_CHECK();
     const ApplyGeom ag = apply_geom(g, V);
     const double* prt = (dgamma || dbeta) ? rt : nullptr;
     // read dy, x (+ y), write dx (+ read when accumulating), dres written (+ read when accumulating)

@@ -97,19 +97,6 @@ def workspace(nbytes, device, stream=None):
     return buf
 
 
-_SYNC = {}
-
-
-def sync_counters(device):
-    """ss_norm_desc.sync_counters of the CURRENT stream: a zeroed uint32 buffer the norm statistics kernels count their finished
-    workgroups in (every launch leaves it zero, launches on one stream are ordered: one buffer per stream serves every norm layer)."""
-    key = (device.type, device.index, _stream().value or 0)
-    buf = _SYNC.get(key)
-    if buf is None:
-        buf = _SYNC[key] = zero_(torch.empty(L.NORM_SYNC_COUNTERS, dtype=torch.int32, device=device))
-    return ctypes.c_void_p(buf.data_ptr())
-
-
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib as L
-from .engine import current_stream_obj, sync_counters, TIMER, Act, DeferredNorm, _p, _stream, workspace, zero_
+from .engine import current_stream_obj, TIMER, Act, DeferredNorm, _p, _stream, workspace, zero_
 
 CONV_STATS = os.environ.get("SS_CONV_STATS", "1") != "0"          # 0: norms always run their own statistics pass (measurement)
 NORM_AMAX = os.environ.get("SS_NORM_AMAX", "1") != "0"            # 0: convolutions scan their operands for the x3h scales themselves (measurement)
@@ -440,7 +440,6 @@ class Norm:
         if sync is None and x.stats is not None and x.parent is None:
             d.x_stats, d.x_stats_chunks = x.stats[0].data_ptr(), x.stats[1]
         if sync is None:
-            d.sync_counters = sync_counters(x.device)
             L.check(lib.ss_norm_fwd(ctypes.byref(d), x.ptr, _p(gamma), _p(beta), rp, y.ptr if y is not None else None, _p(mean), _p(rstd),
                                     _p(mm), _p(mv), float(self.momentum), _p(ws), ws.numel(), _stream()),
                     f"norm_fwd[{self.name}]")
@@ -489,7 +488,6 @@ class Norm:
             # accumulation into the same gradient clears the flag, engine.Act.grad_target)
             dx_amax = reports and not accum and x.parent is None and dx.c0 == 0 and dx.c == dx.cs and dx.amax is None
             db.dx_amax = dx.amax_slot() if dx_amax else None
-            db.sync_counters = sync_counters(x.device)          # of the stream that replays this closure
             ws2 = workspace(lib.ss_norm_workspace_bytes(ctypes.byref(db)), x.device)
             ggam = self.arena.grad(f"{self.name}/gamma") if (self.scale and param_grads) else None
             gbet = self.arena.grad(f"{self.name}/beta") if param_grads else None

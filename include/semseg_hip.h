@@ -255,13 +255,7 @@ typedef struct ss_norm_desc {
     const void* x_stats;
     int32_t x_stats_chunks;
     int32_t reserved0;
-    /* Optional (may be NULL): caller-owned device buffer of SS_NORM_SYNC_COUNTERS uint32, ZERO before its first use and used by ONE
-     * stream at a time (every launch leaves it zero).  With it, the statistics kernels of ss_norm_fwd / ss_norm_bwd count their
-     * finished workgroups per (group, channel block) and the last one computes mean / rstd (the backward means) itself: one launch
-     * less per pass, same arithmetic in the same order.  NULL: a separate finalize launch, as before. */
-    void* sync_counters;
 } ss_norm_desc;
-#define SS_NORM_SYNC_COUNTERS 4096
 
 size_t ss_norm_workspace_bytes(const ss_norm_desc* d);
 /* 1: ss_norm_fwd / ss_norm_bwd of this descriptor raise y_amax / dx_amax (the two-pass kernels, any storage type: the

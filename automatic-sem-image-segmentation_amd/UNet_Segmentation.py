@@ -155,6 +155,15 @@ class UNetModel:
         # hardware queues round-robin, so the indices decide which chains share a queue); SS_UNET_STREAMS="w,b1,b2,b3,b4" overrides
         env = os.environ.get("SS_UNET_STREAMS")
         self.stream_indices = [int(v) for v in env.split(",")] if env else None
+        # OPT-IN (graph = True / SS_UNET_GRAPH=1): the step -- forward, loss, backward on its side streams, Adam -- captured ONCE per input
+        # shape into a hipGraph (torch.cuda.graph) and replayed: same kernels, same order per stream, same bits
+        # (tests/test_nets_gpu.py); what changes per step enters through device memory (the input tiles, Adam's alpha).  Not the
+        # default: at per-GPU batch 1 (the 8-GPU share of BASELINE config 4: one 512 x 512 tile, ~1100 launches) the step is paced by
+        # the per-dispatch cost on BOTH sides -- eager: 12.8 ms of host issue, 11.1 ms wall; replayed: hipGraphLaunch of the
+        # 1100-node graph still costs 9.2 ms of host time (ROCm 7.2: ~8 us per node) and the wall time is 11.0 ms.  256 x 256 tiles:
+        # 11.9 -> 9.1 ms (tools/unet_graph_probe.py, profiles/r05_unet_hipgraph_probe.txt).  Fewer launches help, a graph does not.
+        self.graph = os.environ.get("SS_UNET_GRAPH", "0") == "1"
+        self._graphs = {}          # (n, h, w) -> eager step count (int, warm-up) or the captured state (dict)
 
     def _to_act(self, t):
         if isinstance(t, np.ndarray):
@@ -162,9 +171,18 @@ class UNetModel:
         from .engine import convert
         return convert(Act(t.to(self.device, dtype=torch.float32).contiguous(), requires_grad=False), self.act_dtype)
 
+    GRAPH_WARMUP_STEPS = 2
+
     def train_step(self, batch):
         """fwd(training=True) -> class-weighted BCE -> backward -> Adam.  Returns {'loss','mae','acc'} of this batch."""
+        if self._graph_wanted(batch):
+            return self._train_step_graph(batch)
         x, y = (self._to_act(t) for t in batch)
+        self._issue_step(x, y)
+        return self._read_metrics()
+
+    def _issue_step(self, x, y, alpha_dev=None):
+        """Enqueue one optimisation step on the current stream (+ its side streams); nothing here waits for the device."""
         world = D.world_size()
         tape = Tape()
         if self.wgrad_side_stream and x.device.type == "cuda" and not D.ranks_share_device():
@@ -185,11 +203,77 @@ class UNetModel:
         D.begin_backward([self.net])
         tape.backward()
         D.all_reduce_grads([self.net])
-        self.optimizer.apply(self.net, 1.0 / (world * self.loss_scale))
+        self.optimizer.apply(self.net, 1.0 / (world * self.loss_scale), alpha_dev=alpha_dev)
+
+    def _read_metrics(self):
         if not self.sync_metrics:
             return {}
         s = D.mean_scalars(self._out3.cpu().numpy().astype(np.float64))
         return {"loss": float(s[0]), "mae": float(s[1]), "acc": float(s[2])}
+
+    # ---- the step as a replayed hipGraph -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _shape_of(t):
+        return tuple(int(v) for v in (t.t.shape if isinstance(t, Act) else t.shape))
+
+    def _graph_wanted(self, batch):
+        if not self.graph or self.device.type != "cuda" or D.world_size() != 1 or D.is_dist():
+            return False
+        from . import layers as LY
+        if LY.SYNC_BN is not None:
+            return False
+        shp = self._shape_of(batch[0])
+        if len(shp) != 4 or self._shape_of(batch[1]) != shp:
+            return False
+        return True
+
+    @staticmethod
+    def _as_f32(t, like):
+        if isinstance(t, Act):
+            t = t.dense() if (t.c0 or t.c != t.cs) else t.t
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+        return t.to(device=like.device, dtype=torch.float32)
+
+    def _train_step_graph(self, batch):
+        from .engine import capture_scope
+        key = self._shape_of(batch[0])[:3]
+        st = self._graphs.get(key, 0)
+        if isinstance(st, int):
+            if st < self.GRAPH_WARMUP_STEPS:          # eager first: scratch sizes, weight caches and one-time kernel attributes settle
+                self._graphs[key] = st + 1
+                x, y = (self._to_act(t) for t in batch)
+                self._issue_step(x, y)
+                return self._read_metrics()
+            n, h, w = key
+            st = dict(x=torch.empty((n, h, w, 1), dtype=torch.float32, device=self.device),
+                      y=torch.empty((n, h, w, 1), dtype=torch.float32, device=self.device),
+                      alpha=torch.zeros(1, dtype=torch.float32, device=self.device), graph=torch.cuda.CUDAGraph())
+            st["x"].copy_(self._as_f32(batch[0], st["x"]))
+            st["y"].copy_(self._as_f32(batch[1], st["y"]))
+            iters = self.optimizer.iterations
+            try:
+                with capture_scope() as scope, torch.cuda.graph(st["graph"]):
+                    from .engine import convert
+                    xa = convert(Act(st["x"], requires_grad=False), self.act_dtype)
+                    ya = convert(Act(st["y"], requires_grad=False), self.act_dtype)
+                    self._issue_step(xa, ya, alpha_dev=st["alpha"])
+            except Exception as e:          # noqa: BLE001  -- a capture this runtime refuses: say so once, stay eager (same results)
+                self.optimizer.iterations = iters
+                self.graph = False
+                self.net.arena.touch()
+                D.warn_once(f"UNetModel: hipGraph capture of the train step failed ({type(e).__name__}: {e}); running eagerly")
+                return self.train_step(batch)
+            st["kept"] = scope.kept
+            self._graphs[key] = st
+            # capture launches nothing: the weights are untouched, this step runs as the first replay below
+        else:
+            st["x"].copy_(self._as_f32(batch[0], st["x"]))
+            st["y"].copy_(self._as_f32(batch[1], st["y"]))
+        st["alpha"].fill_(self.optimizer.next_alpha())
+        st["graph"].replay()
+        self.net.arena.touch()          # the replayed Adam changed the weights: derived operands kept by the layers are stale for eager calls
+        return self._read_metrics()
 
     def test_step(self, batch):
         x, y = (self._to_act(t) for t in batch)

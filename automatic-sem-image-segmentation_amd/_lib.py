@@ -168,6 +168,7 @@ SIGNATURES = {
     "ss_loss_mae": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_loss_weighted_bce": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_adam_keras": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_f32, c_vp]),
+    "ss_adam_keras_dev": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_f32, c_vp]),
 }
 
 _lib = None

@@ -406,7 +406,8 @@ __global__ __launch_bounds__(EW_BLOCK) void wbce_mc_kernel(const T* __restrict__
 
 __global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long count, float alpha, float b1, float b2, float eps,
-                                                        float gscale) {
+                                                        float gscale, const float* __restrict__ alpha_dev) {
+    if (alpha_dev) alpha = *alpha_dev;          // step size from device memory: a captured hipGraph replays with a new one every step
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
         const float gv = g[e] * gscale;
         const float mv = m[e] + (gv - m[e]) * b1;       // b1, b2 hold (1 - beta), see adam_kernel_v4
@@ -419,7 +420,8 @@ __global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, c
 
 __global__ __launch_bounds__(EW_BLOCK) void adam_kernel_v4(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m,
                                                            f32x4* __restrict__ v, long count4, float alpha, float b1, float b2, float eps,
-                                                           float gscale) {
+                                                           float gscale, const float* __restrict__ alpha_dev) {
+    if (alpha_dev) alpha = *alpha_dev;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count4; e += (long)gridDim.x * blockDim.x) {
         const f32x4 gv = g[e] * gscale;
         f32x4 mv = m[e], vv = v[e], pv = p[e];
@@ -777,29 +779,40 @@ int ss_loss_weighted_bce(const float* truth, const float* pred, int64_t count, f
     return ss_loss_weighted_bce_t(SS_DTYPE_F32, truth, pred, count, weighting, grad_scale, out3, grad, ws, ws_bytes, stream);
 }
 
-int ss_adam_keras(float* p, const float* g, float* m, float* v, int64_t count,
-                  double alpha_d, double beta1_d, double beta2_d, double eps_d, float grad_scale, void* stream) {
+static int adam_launch(float* p, const float* g, float* m, float* v, int64_t count, float alpha, const float* alpha_dev,
+                       double beta1_d, double beta2_d, double eps_d, float grad_scale, void* stream) {
     if (!p || !g || !m || !v || count < 0) return SS_ERR_INVALID;
     if (count == 0) return SS_OK;
     // Keras forms (1 - beta) in python double precision and casts the RESULT to the variable dtype: 1 - 0.999 -> fp32(0.001), whereas
     // 1.f - fp32(0.999) = 0.00099998713 (1.3e-5 off; found by tests/test_direct_gpu.py::test_adam_keras_ten_iterations_vs_oracle)
-    const float alpha = (float)alpha_d, eps = (float)eps_d;
+    const float eps = (float)eps_d;
     const float beta1 = (float)(1.0 - beta1_d), beta2 = (float)(1.0 - beta2_d);
     hipStream_t s = (hipStream_t)stream;
     const bool al = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
     const long c4 = al ? count / 4 : 0;
     if (c4 > 0) {
         hipLaunchKernelGGL(adam_kernel_v4, dim3(ew_grid(c4)), dim3(EW_BLOCK), 0, s, (f32x4*)p, (const f32x4*)g, (f32x4*)m, (f32x4*)v,
-                           c4, alpha, beta1, beta2, eps, grad_scale);
+                           c4, alpha, beta1, beta2, eps, grad_scale, alpha_dev);
         SS_LAUNCH_CHECK();
     }
     const long rem = count - c4 * 4;
     if (rem > 0) {
         hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(rem)), dim3(EW_BLOCK), 0, s, p + c4 * 4, g + c4 * 4, m + c4 * 4, v + c4 * 4,
-                           rem, alpha, beta1, beta2, eps, grad_scale);
+                           rem, alpha, beta1, beta2, eps, grad_scale, alpha_dev);
         SS_LAUNCH_CHECK();
     }
     return SS_OK;
+}
+
+int ss_adam_keras(float* p, const float* g, float* m, float* v, int64_t count,
+                  double alpha_d, double beta1_d, double beta2_d, double eps_d, float grad_scale, void* stream) {
+    return adam_launch(p, g, m, v, count, (float)alpha_d, nullptr, beta1_d, beta2_d, eps_d, grad_scale, stream);
+}
+
+int ss_adam_keras_dev(float* p, const float* g, float* m, float* v, int64_t count,
+                      const float* alpha_dev, double beta1_d, double beta2_d, double eps_d, float grad_scale, void* stream) {
+    if (!alpha_dev) return SS_ERR_INVALID;
+    return adam_launch(p, g, m, v, count, 0.f, alpha_dev, beta1_d, beta2_d, eps_d, grad_scale, stream);
 }
 
 }  // extern "C"

@@ -97,6 +97,27 @@ def workspace(nbytes, device, stream=None):
     return buf
 
 
+class capture_scope:
+    """While a train step is CAPTURED into a hipGraph (torch.cuda.graph): the per-stream scratch of this module -- workspaces, amax slot
+    pools -- is taken from fresh tables, so that everything the graph's kernels address was allocated inside the capture, from the
+    graph's private memory pool, and the zeroing of the slot pools is part of the graph (slots are raised by atomic maxima: every
+    replay must start from zero).  The eager tables come back afterwards; the captured ones stay referenced from `kept` (the owner of
+    the graph holds it), so nothing the graph addresses is ever regrown or recycled under it."""
+
+    def __enter__(self):
+        global _WS, _SLOT_POOLS
+        self._saved = (_WS, _SLOT_POOLS)
+        _WS, _SLOT_POOLS = {}, {}
+        self.kept = None
+        return self
+
+    def __exit__(self, *exc):
+        global _WS, _SLOT_POOLS
+        self.kept = (_WS, _SLOT_POOLS)
+        _WS, _SLOT_POOLS = self._saved
+        return False
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 

@@ -16,15 +16,23 @@ class Adam:
             raise NotImplementedError("weight_decay != 0 is not on the reference path")
         self.iterations = 0
 
-    def apply(self, net, grad_scale=1.0):
-        """Equivalent of ``optimizer.apply(grads, net.trainable_weights)`` with the grads in ``net.arena.grads``."""
-        lib = L.load()
+    def next_alpha(self):
+        """Advance the iteration counter and return this step's alpha = lr * sqrt(1 - beta_2^t) / (1 - beta_1^t), t = iterations + 1."""
         t = self.iterations + 1
-        lr = float(self.learning_rate)
-        alpha = lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        self.iterations = t
+        return float(self.learning_rate) * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+
+    def apply(self, net, grad_scale=1.0, alpha_dev=None):
+        """Equivalent of ``optimizer.apply(grads, net.trainable_weights)`` with the grads in ``net.arena.grads``.
+        alpha_dev = a 1-element fp32 device tensor: the launch reads alpha from there when it RUNS (hipGraph replays: the caller
+        writes ``next_alpha()`` into it before every replay and this call does not touch the iteration counter)."""
+        lib = L.load()
         a = net.arena
         a.join_refresh()          # a weight-cache refresh on a side stream may still be reading the old values
-        L.check(lib.ss_adam_keras(_p(a.params), _p(a.grads), _p(a.m), _p(a.v), a.n_train, alpha,
-                                  self.beta_1, self.beta_2, self.epsilon, float(grad_scale), _stream()), "ss_adam_keras")
+        if alpha_dev is None:
+            L.check(lib.ss_adam_keras(_p(a.params), _p(a.grads), _p(a.m), _p(a.v), a.n_train, self.next_alpha(),
+                                      self.beta_1, self.beta_2, self.epsilon, float(grad_scale), _stream()), "ss_adam_keras")
+        else:
+            L.check(lib.ss_adam_keras_dev(_p(a.params), _p(a.grads), _p(a.m), _p(a.v), a.n_train, _p(alpha_dev),
+                                          self.beta_1, self.beta_2, self.epsilon, float(grad_scale), _stream()), "ss_adam_keras_dev")
         a.touch()
-        self.iterations = t

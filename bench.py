@@ -199,15 +199,21 @@ def main():
 
     def step(cyclegan=not args.only_unet, unet_=not args.skip_unet, overlap=overlap_unet):
         if overlap and cyclegan and unet_:
+            # CycleGAN first (GPU-paced: its kernels outlast its issue), the UNet step -- host-paced at per-GPU batch 1: 12 ms to issue
+            # 11 ms of kernels -- is issued BEHIND it on a stream of its own, so the host issues it while the GPU still works on the
+            # CycleGAN chains; neither step reads its metrics before both are issued (the read blocks the host)
             cur = torch.cuda.current_stream()
             u_stream.wait_stream(cur)
+            model.sync_metrics = False
+            model.train_step((a, b))
+            model.sync_metrics = True
             umodel.sync_metrics, keep = False, umodel.stream_indices
             umodel.stream_indices = keep if keep is not None else [11, 12, 13, 12, 13]
             with torch.cuda.stream(u_stream):
                 umodel.train_step((ux.t, uy.t))
             umodel.sync_metrics, umodel.stream_indices = True, keep
-            model.train_step((a, b))
             cur.wait_stream(u_stream)
+            model._scalars.cpu()          # the step's one device->host read (both steps' scalars are final behind the join)
             return
         if cyclegan:
             model.train_step((a, b))

@@ -440,6 +440,10 @@ int ss_loss_weighted_bce_t(int32_t dtype, const void* truth, const void* pred, i
  * ---------------------------------------------------------------------------------------- */
 int ss_adam_keras(float* p, const float* g, float* m, float* v, int64_t count,
                   double alpha, double beta_1, double beta_2, double epsilon, float grad_scale, void* stream);
+/* The same update with the step size read from DEVICE memory when the kernel runs (*alpha_dev = fp32(alpha), written by the caller
+ * before the launch is replayed): what a captured hipGraph of a train step needs, since alpha changes with every iteration. */
+int ss_adam_keras_dev(float* p, const float* g, float* m, float* v, int64_t count,
+                      const float* alpha_dev, double beta_1, double beta_2, double epsilon, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -336,3 +336,37 @@ def test_unet_respath_branches_equal_the_inline_step(size, batch):
     for w0, w1, name in zip(out[False][1], out[True][1], N.MultiResUNet(16, device="cuda:0").variable_names):
         assert np.array_equal(w0, w1), name
     assert np.array_equal(out[False][2], out[True][2]) and np.array_equal(out[False][3], out[True][3])
+
+
+def test_unet_step_replayed_as_a_hipgraph_equals_the_eager_step():
+    """UNetModel.graph: the train step captured once per input shape (torch.cuda.graph over the library's launches on the step's own
+    streams) and replayed must be the eager step, bit for bit -- metrics of every step, trained weights, BatchNorm moving statistics --
+    over changing batches and a learning-rate change (Adam's alpha enters through device memory), and an eager step after the replays
+    must continue from the same state (weight-derived operand caches are invalidated behind a replay)."""
+    UN, OPT, N = mod("UNet_Segmentation"), mod("optim"), mod("nets")
+    gen = torch.Generator().manual_seed(21)
+    ref = ON.MultiResUNet(16, seed=9)
+    batches = [(torch.rand((1, 128, 96, 1), generator=gen), (torch.rand((1, 128, 96, 1), generator=gen) > 0.85).float()) for _ in range(7)]
+    out = {}
+    for mode in ("eager", "graph"):
+        hip = N.MultiResUNet(16, device="cuda:0")
+        hip.set_weights(ref.get_weights())
+        model = UN.UNetModel(hip, 9.0, OPT.Adam(1e-3))
+        model.graph = mode == "graph"
+        hist = []
+        for i, (x, y) in enumerate(batches):
+            if i == 4:
+                model.optimizer.learning_rate = 5e-4
+            if i == 6:
+                model.graph = False          # the last step eagerly, on the state the replays left
+            hist.append(model.train_step((x.numpy(), y.numpy())))
+        torch.cuda.synchronize()
+        if mode == "graph":
+            st = model._graphs.get((1, 128, 96))
+            assert isinstance(st, dict), "the step was not captured (UNetModel fell back to eager execution)"
+            assert model.optimizer.iterations == len(batches)
+        out[mode] = (hist, hip.get_weights())
+    for i, (a, b) in enumerate(zip(out["eager"][0], out["graph"][0])):
+        assert a == b, (i, a, b)
+    for i, (a, b) in enumerate(zip(out["eager"][1], out["graph"][1])):
+        assert np.array_equal(a, b), i

@@ -137,7 +137,7 @@ def test_multiresunet_prepad_and_crop():
     gen = torch.Generator().manual_seed(8)
     hip = mod("nets").MultiResUNet(16, device="cuda:0")
     run_net_fwd_bwd(hip, lambda dt: ON.MultiResUNet(16, seed=7, dtype=dt), torch.rand((2, 72, 88, 1), generator=gen), gen, grad_tol=2e-3,
-                    noise_mult=5, aggregate=True)
+                    noise_mult=3, aggregate=True)
 
 
 def test_discriminator_fwd_bwd():
@@ -152,7 +152,7 @@ def test_multiresunet_fwd_bwd_and_state():
     hip = mod("nets").MultiResUNet(16, device="cuda:0")
     assert hip.count_params() == 2429491
     ref, _ = run_net_fwd_bwd(hip, lambda dt: ON.MultiResUNet(16, seed=7, dtype=dt), torch.rand((2, 64, 64, 1), generator=gen), gen,
-                             grad_tol=2e-3, noise_mult=5, aggregate=True)   # 85 BatchNorms + ReLU masks: the fp32 oracle itself is 1e-3..2e-2 from fp64 here
+                             grad_tol=2e-3, noise_mult=3, aggregate=True)   # 85 BatchNorms + ReLU masks: the fp32 oracle itself is 1e-3..2e-2 from fp64 here
     # BatchNorm moving statistics after one training-mode forward
     for name, got, want in zip(hip.variable_names, hip.get_weights(), ref.get_weights()):
         if "moving" in name:

@@ -25,6 +25,8 @@ SAVE_OPERAND = os.environ.get("SS_SAVE_OPERAND", "1") != "0"
 # Cross-rank BatchNorm statistics (data parallel): set by dist.enable_sync_bn() to a callable that all-reduces (SUM) a
 # float32 device tensor in place and returns the world size.  None = per-process statistics (single GPU).
 SYNC_BN = None
+# the gradient of an un-activated residual add is handed over as a buffer instead of copied (SS_RESIDUAL_GRAD_ALIAS=0: copied)
+RESIDUAL_GRAD_ALIAS = os.environ.get("SS_RESIDUAL_GRAD_ALIAS", "1") != "0"
 
 ACTS = {None: L.ACT_NONE, "relu": L.ACT_RELU, "lrelu": L.ACT_LRELU, "tanh": L.ACT_TANH, "sigmoid": L.ACT_SIGMOID}
 
@@ -480,7 +482,16 @@ class Norm:
             dx, accum = x.grad_target()
             dres, racc = (None, 0)
             if residual is not None and residual.requires_grad:
-                dres, racc = residual.grad_target()
+                if (RESIDUAL_GRAD_ALIAS and act is None and sync is None and type(residual) is Act and residual.parent is None
+                        and not residual.grad_init and y.parent is None and dy.c0 == 0 and dy.c == dy.cs == residual.cs
+                        and residual.c0 == 0 and dy.t.shape == residual.t.shape and dy.t.dtype == residual.t.dtype):
+                    # y = norm(x) + residual without an activation (the ResNet block's add, CycleGAN.py:336): d loss / d residual IS dy.
+                    # This op is the first writer of the residual's gradient and the last reader of dy's buffer apart from its own
+                    # kernels, so the buffer is handed over instead of copied (one tensor write less per block; the blocks of a trunk
+                    # pass ONE gradient buffer down, each data gradient accumulating into it behind this op's reads on the same stream)
+                    residual.grad, residual.grad_init = dy, True
+                else:
+                    dres, racc = residual.grad_target()
             db = L.NormDesc.from_buffer_copy(d)
             db.res_cstride = dres.cs if dres is not None else 0
             db.y_amax = None

@@ -417,3 +417,37 @@ def test_keras_archive_falls_back_to_npz_without_hdf5(tmp_path, monkeypatch):
     if not importlib.util.find_spec("h5py"):
         with pytest.warns(UserWarning, match="written as"):
             K.warn_if_no_hdf5("test")
+
+
+def test_product_path_never_touches_the_oracle():
+    """The oracle is test infrastructure: no module of the package, bench.py outside its `cpu_baseline` leg, or __graft_entry__ outside
+    build() / smoke() may import it (a product path that routes through the CPU restatement would void every parity claim)."""
+    import ast
+    pkg = os.path.join(REPO, BASE)
+    for fn in sorted(os.listdir(pkg)):
+        if not fn.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, fn)).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), f"{fn} imports the oracle"
+            if isinstance(node, ast.Call) and getattr(node.func, "attr", getattr(node.func, "id", "")) in ("import_module", "__import__"):
+                for a in node.args:
+                    assert not (isinstance(a, ast.Constant) and isinstance(a.value, str) and a.value.split(".")[0] == "oracle"), fn
+    # bench.py: only inside cpu_baseline()
+    src = open(os.path.join(REPO, "bench.py")).read()
+    tree = ast.parse(src)
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef):
+            uses = [n for n in ast.walk(node) if isinstance(n, (ast.Import, ast.ImportFrom))
+                    and any((getattr(a, "name", "") or "").startswith("oracle") for a in getattr(n, "names", [])) or
+                    (isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle"))]
+            if uses:
+                assert node.name == "cpu_baseline", f"bench.py::{node.name} imports the oracle"
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and ((getattr(n, "module", "") or "").startswith("oracle")
+                                                                                 or any(a.name.startswith("oracle") for a in n.names))]
+    assert not top, "bench.py imports the oracle at module level"

@@ -140,7 +140,9 @@ class UNetModel:
         self._out3 = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.act_dtype = net.act_dtype           # float32, or bfloat16 / float16 mixed-precision activation storage
         self.loss_scale = 1024.0 if self.act_dtype == torch.float16 else 1.0
-        self.wgrad_side_stream = os.environ.get("SS_UNET_WGRAD_STREAM", "1") != "0"
+        # SS_UNET_WGRAD_STREAM=0: weight gradients on the chain's stream; "force": on the side stream even when several ranks share a GPU
+        # (tests/test_dp_gpu.py: the bucket hooks must order themselves behind BOTH streams)
+        self.wgrad_side_stream = {"0": False, "force": "force"}.get(os.environ.get("SS_UNET_WGRAD_STREAM", "1"), True)
         # measured: 36.5 ms per step without, 37.1 - 37.3 with (the refresh of ~100 small layers competes with the chain's first, small
         # layers): opt-in here, default in the CycleGAN step
         self.refresh_side_stream = os.environ.get("SS_UNET_REFRESH_STREAM", "0") == "1"
@@ -185,7 +187,7 @@ class UNetModel:
         """Enqueue one optimisation step on the current stream (+ its side streams); nothing here waits for the device."""
         world = D.world_size()
         tape = Tape()
-        if self.wgrad_side_stream and x.device.type == "cuda" and not D.ranks_share_device():
+        if self.wgrad_side_stream and x.device.type == "cuda" and (self.wgrad_side_stream == "force" or not D.ranks_share_device()):
             # the weight gradients of the tile-kernel layers (matrix cores / LDS) beside the BatchNorm backward passes of the chain
             # (HBM): they are off the dependency chain (engine.Tape.wgrad_stream)
             from .engine import side_streams

@@ -80,8 +80,11 @@ def _run(tmp_path, world):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
     out = str(tmp_path / f"out{world}.npz")
-    # SS_DUAL_STREAM=force: keep the two-stream execution (and its deferred gradient exchange) although both ranks share cuda:0
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29740 + world), WORLD_SIZE=str(world), SS_DUAL_STREAM="force")
+    # SS_DUAL_STREAM=force / SS_UNET_WGRAD_STREAM=force: keep the multi-stream execution (generator buckets merged and launched from the
+    # second chain's backward; UNet weight gradients on a side stream, so that a bucket's kernels sit on two streams -- ADVICE r4)
+    # although both ranks share cuda:0
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29740 + world), WORLD_SIZE=str(world), SS_DUAL_STREAM="force",
+               SS_UNET_WGRAD_STREAM="force")
     procs = [subprocess.Popen([sys.executable, str(script), REPO, out], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     for r, p in enumerate(procs):

@@ -20,7 +20,6 @@ HDF5 access: ``h5py`` in-process when importable, else the stand-alone converter
 BEFORE training starts and warn), ``write_archive`` then stores the same arrays as ``<path>.npz`` next to where the archive would
 have been instead of losing a finished training, and ``read_archive`` falls back to that file.
 """
-import io
 import json
 import os
 import subprocess

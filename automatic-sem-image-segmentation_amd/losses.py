@@ -1,5 +1,4 @@
 """Loss kernels writing device scalars + gradients (CycleGAN.py:301-308,644-650; UNet_Segmentation.py:379-384)."""
-import ctypes
 
 from . import _lib as L
 from .engine import _p, _stream, workspace

@@ -98,24 +98,44 @@ def roc(predicted, ground_truth):
     return tpr, tnr, fpr, fnr
 
 
-def calculate_iou(predictions, ground_truths, watershed=True):
-    """The sweep of calculateIoU (:221-272) over paired lists of prediction images (float in [0,1] or [0,255]) and ground-truth masks:
-    thresholds 0.0 .. 1.0 in steps of 0.1, segment + 8->4 connectivity, averages over the images, best average per score.
-    The reference accumulates threshold ``t`` into slot ``t - 1`` (threshold 0.0 lands in the LAST slot) and reports ``slot / 10``
-    as the "best threshold": reproduced (``best_threshold_*`` are the reference's reported values; ``*_true`` the real ones)."""
+def _sweep_one(args):
+    """The eleven thresholds of one (prediction, ground truth) pair: rows of (whole IoU, instance IoU all, instance IoU area > 9, TPR, TNR)."""
+    pred, gt, watershed = args
+    gt = np.asarray(gt, dtype='uint8')
+    gt = gt // np.max(gt)
+    image = np.asarray(pred, dtype='float32').copy()
+    if np.max(image) > 1.0:
+        image /= 255.0
+    rows = []
+    for t in range(0, 11):
+        seg = HF.eight_to_four_connected(segment(image, threshold=t / 10.0, do_watershed=watershed))
+        tpr, tnr, _, _ = roc(seg, gt)
+        rows.append((whole_image_iou(seg, gt), instance_iou(seg, gt, 0), instance_iou(seg, gt, 9), tpr, tnr))
+    return rows
+
+
+def calculate_iou(predictions, ground_truths, watershed=True, workers=1):
+    """The sweeps of calculateIoU (:221-272) and calculateROC (:172-218) over paired lists of prediction images (float in [0,1] or
+    [0,255]) and ground-truth masks: thresholds 0.0 .. 1.0 in steps of 0.1, segment + 8->4 connectivity, averages over the images,
+    best average per score.  The reference's IoU sweep accumulates threshold ``t`` into slot ``t - 1`` (threshold 0.0 lands in the LAST
+    slot) and reports ``slot / 10`` as the "best threshold": reproduced (``best_threshold_*`` are the reference's reported values;
+    ``*_true`` the real ones).  ``youden_index`` = the best average TPR + TNR - 1 (the README's "Avg Youdens Index").
+    workers > 1: the images are swept in that many processes (the sweep is CPU work: ~10 s per image)."""
     n = float(len(ground_truths))
-    whole, inst_all, inst_f = [0.0] * 11, [0.0] * 11, [0.0] * 11
-    for pred, gt in zip(predictions, ground_truths):
-        gt = np.asarray(gt, dtype='uint8')
-        gt = gt // np.max(gt)
-        image = np.asarray(pred, dtype='float32').copy()
-        if np.max(image) > 1.0:
-            image /= 255.0
-        for t in range(0, 11):
-            seg = HF.eight_to_four_connected(segment(image, threshold=t / 10.0, do_watershed=watershed))
-            whole[t - 1] += whole_image_iou(seg, gt) / n
-            inst_all[t - 1] += instance_iou(seg, gt, 0) / n
-            inst_f[t - 1] += instance_iou(seg, gt, 9) / n
+    jobs = [(p, g, watershed) for p, g in zip(predictions, ground_truths)]
+    if workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+            per_image = pool.map(_sweep_one, jobs)
+    else:
+        per_image = [_sweep_one(j) for j in jobs]
+    whole, inst_all, inst_f, youden = [0.0] * 11, [0.0] * 11, [0.0] * 11, [0.0] * 11
+    for rows in per_image:
+        for t, (w_, ia_, if__, tpr, tnr) in enumerate(rows):
+            whole[t - 1] += w_ / n
+            inst_all[t - 1] += ia_ / n
+            inst_f[t - 1] += if__ / n
+            youden[t] += (tpr + tnr - 1) / n
 
     def best(v):
         b, bi = 0.0, 0
@@ -125,9 +145,12 @@ def calculate_iou(predictions, ground_truths, watershed=True):
         return b, bi / 10.0, ((bi + 1) % 11) / 10.0
 
     w, ia, if_ = best(whole), best(inst_all), best(inst_f)
+    yi = max(range(11), key=lambda t: youden[t])
     return dict(iou_whole=w[0], best_threshold_whole=w[1], best_threshold_whole_true=w[2],
                 iou_instance_all=ia[0], best_threshold_instance_all=ia[1], best_threshold_instance_all_true=ia[2],
-                iou_instance_filtered=if_[0], best_threshold_instance_filtered=if_[1], best_threshold_instance_filtered_true=if_[2])
+                iou_instance_filtered=if_[0], best_threshold_instance_filtered=if_[1], best_threshold_instance_filtered_true=if_[2],
+                youden_index=youden[yi], best_threshold_youden=yi / 10.0,
+                iou_whole_by_threshold=[whole[(t - 1) % 11] for t in range(11)], youden_by_threshold=list(youden))
 
 
 # ---- one-command evaluation of a mounted dataset ---------------------------------------------------------------------------------
@@ -136,7 +159,7 @@ IMAGES_SUBDIR = "Electron Microscopy Images/SEM"                                
 GROUND_TRUTH_SUBDIR = "Electron Microscopy Image Masks/TiO2_Masks_Manual_4connected"     # <id>_m.tif
 
 
-def score_directories(prediction_dir, ground_truth_dir, crop_rows=0, watershed=True, raw=True, limit=None):
+def score_directories(prediction_dir, ground_truth_dir, crop_rows=0, watershed=True, raw=True, limit=None, workers=1):
     """``calculateIoU(dir)`` of Calculate_Scores.py:221-272 over a directory pair: every ground truth ``<id>_m.tif`` is paired with the
     prediction ``<id>_raw.tif`` (the float probability map UNet.run_inference writes; ``raw=False`` or no such file: ``<id>.tif``), both
     cropped to their first ``crop_rows`` rows when > 0.  Returns calculate_iou's dict + the number of pairs."""
@@ -168,7 +191,7 @@ def score_directories(prediction_dir, ground_truth_dir, crop_rows=0, watershed=T
             break
     if not used:
         raise FileNotFoundError(f"no prediction in {prediction_dir} matches a ground-truth file of {ground_truth_dir}")
-    out = calculate_iou(preds, gts, watershed=watershed)
+    out = calculate_iou(preds, gts, watershed=watershed, workers=workers)
     out["images"] = len(used)
     return out
 
@@ -194,6 +217,7 @@ def main(argv=None):
     ap.add_argument("--tile", type=int, nargs=2, metavar=("W", "H"), default=None, help="tile size for inference (default: whole image)")
     ap.add_argument("--no-watershed", action="store_true")
     ap.add_argument("--limit", type=int, default=None, help="score the first N images only")
+    ap.add_argument("--workers", type=int, default=max(1, min(16, (os.cpu_count() or 1) // 2)), help="processes for the threshold sweep")
     a = ap.parse_args(argv)
     img_dir, gt_dir = os.path.join(a.data_root, a.images), os.path.join(a.data_root, a.ground_truth)
     for d in (img_dir, gt_dir):
@@ -209,7 +233,7 @@ def main(argv=None):
         if a.tile:
             un.image_shape = tuple(a.tile)
         un.run_inference(files=img_dir, output_directory=pred_dir, model=a.model, tile_images=a.tile is not None, use_gpu=True)
-    res = score_directories(pred_dir, gt_dir, crop_rows=a.crop_rows, watershed=not a.no_watershed, limit=a.limit)
+    res = score_directories(pred_dir, gt_dir, crop_rows=a.crop_rows, watershed=not a.no_watershed, limit=a.limit, workers=a.workers)
     res.update(data_root=a.data_root, source=a.model or a.predictions, crop_rows=a.crop_rows)
     print(json.dumps(res))
     if tmp is not None:

@@ -527,6 +527,18 @@ class _MaskCanvas:
         return self.img[a:a + self.img_h, b:b + self.img_w]
 
 
+def _place_job(job):
+    """One simulated mask from its drawn ingredients (worker process of WGAN.simulate_masks): the placement consumes no random
+    numbers, so the masks are the ones the sequential loop would write."""
+    from PIL import Image
+    ctor, particles, pos_y, pos_x, rotations, scalings, max_overlap, path = job
+    canvas = _MaskCanvas(*ctor)
+    for j in range(len(particles)):
+        canvas.place(particles[j], int(pos_y[j]), int(pos_x[j]), rotations[j], scalings[j], max_overlap)
+    Image.fromarray(canvas.crop() * 255).save(path)
+    return path
+
+
 class WGAN:
     """Workflow class of step 1 (WassersteinGAN.py:288-545, 683-724): same constructor, attributes and on-disk contract
     (``Input_Masks`` -> ``1_WGAN/{Models,Output_Images}/<timestamp>`` -> simulated masks in ``2_CycleGAN/data/trainB``)."""
@@ -694,34 +706,55 @@ class WGAN:
             max_scaling_used = max_scaling
         if max_overlap is not None and grid_type not in ('HEXAGONAL', 'CUBIC'):
             grid_type = 'HEXAGONAL'          # overlap control only exists on the grid paths (WassersteinGAN.py:407-408)
-        canvas = _MaskCanvas(self.train_images.shape[1], self.train_images.shape[2], img_height, img_width, max_scaling)
+        ctor = (self.train_images.shape[1], self.train_images.shape[2], img_height, img_width, max_scaling)
+        canvas = _MaskCanvas(*ctor)
         os.makedirs(self.generate_dir, exist_ok=True)
-        for i in range(no_of_images):
-            canvas.clear()
-            count = random.randint(min_no_of_particles, max_no_of_particles) if grid_type not in ('HEXAGONAL', 'CUBIC') else 0
-            noise = canvas.noise_field(perlin_noise_frequency) if (use_perlin_noise or use_random_rotation == 'PERLIN') else None
-            level = 2 * perlin_noise_threshold - 1
-            if grid_type in ('HEXAGONAL', 'CUBIC'):
-                pos_x, pos_y = canvas.grid_positions(grid_type, grid_spacing_factor, grid_noise_factor)
-                if use_perlin_noise:          # thin the grid where the field is low (indexed [x, y], as the reference does)
-                    keep = [q for q in range(len(pos_x)) if noise[pos_x[q], pos_y[q]] > level]
-                    pos_x, pos_y = [pos_x[q] for q in keep], [pos_y[q] for q in keep]
-                count = len(pos_x)
-            elif use_perlin_noise:
-                pos_x, pos_y = canvas.positions_from_field(noise, level, count)
-            else:
-                pos_x, pos_y = np.random.randint(0, canvas.W, count), np.random.randint(0, canvas.H, count)
-            scalings = np.random.normal(mu, sigma, count) if use_normal_distribution else np.random.uniform(min_scaling, max_scaling_used, count)
-            scalings = np.clip(scalings, min_scaling, max_scaling_used)
-            if use_random_rotation == 'RANDOM':
-                rotations = np.random.randint(0, 360, count)
-            elif use_random_rotation == 'PERLIN':
-                rotations = noise[np.asarray(pos_y, dtype=int), np.asarray(pos_x, dtype=int)] * 180
-            else:
-                rotations = np.zeros(count)
-            for j, particle in enumerate(self._sample_particles(count)):
-                canvas.place(particle, int(pos_y[j]), int(pos_x[j]), rotations[j], scalings[j], max_overlap)
-            Image.fromarray(canvas.crop() * 255).save(os.path.join(self.generate_dir, '{:05d}.tif'.format(i)))
+        # Where / how large / how rotated is drawn here, in the reference's order, and the particles come from the generator on the
+        # device; putting ~3 000 particles onto a canvas (affine warp, hole filling, opening, erosion, overlap test per particle) is
+        # 1 - 5 s of pure host work per mask and draws nothing: it runs in worker processes (SS_MASK_WORKERS, default min(16, cores / 2);
+        # 1 = inline), so 1 000 masks take minutes instead of the better part of an hour.
+        workers = int(os.environ.get("SS_MASK_WORKERS", max(1, min(16, (os.cpu_count() or 2) // 2))))
+        pool, pending = None, []
+        if workers > 1 and no_of_images >= 4:
+            import multiprocessing as mp
+            pool = mp.get_context("spawn").Pool(workers)
+        try:
+            for i in range(no_of_images):
+                count = random.randint(min_no_of_particles, max_no_of_particles) if grid_type not in ('HEXAGONAL', 'CUBIC') else 0
+                noise = canvas.noise_field(perlin_noise_frequency) if (use_perlin_noise or use_random_rotation == 'PERLIN') else None
+                level = 2 * perlin_noise_threshold - 1
+                if grid_type in ('HEXAGONAL', 'CUBIC'):
+                    pos_x, pos_y = canvas.grid_positions(grid_type, grid_spacing_factor, grid_noise_factor)
+                    if use_perlin_noise:          # thin the grid where the field is low (indexed [x, y], as the reference does)
+                        keep = [q for q in range(len(pos_x)) if noise[pos_x[q], pos_y[q]] > level]
+                        pos_x, pos_y = [pos_x[q] for q in keep], [pos_y[q] for q in keep]
+                    count = len(pos_x)
+                elif use_perlin_noise:
+                    pos_x, pos_y = canvas.positions_from_field(noise, level, count)
+                else:
+                    pos_x, pos_y = np.random.randint(0, canvas.W, count), np.random.randint(0, canvas.H, count)
+                scalings = np.random.normal(mu, sigma, count) if use_normal_distribution else np.random.uniform(min_scaling, max_scaling_used, count)
+                scalings = np.clip(scalings, min_scaling, max_scaling_used)
+                if use_random_rotation == 'RANDOM':
+                    rotations = np.random.randint(0, 360, count)
+                elif use_random_rotation == 'PERLIN':
+                    rotations = noise[np.asarray(pos_y, dtype=int), np.asarray(pos_x, dtype=int)] * 180
+                else:
+                    rotations = np.zeros(count)
+                job = (ctor, self._sample_particles(count), np.asarray(pos_y), np.asarray(pos_x), np.asarray(rotations), np.asarray(scalings),
+                       max_overlap, os.path.join(self.generate_dir, '{:05d}.tif'.format(i)))
+                if pool is None:
+                    _place_job(job)
+                else:
+                    pending.append(pool.apply_async(_place_job, (job,)))
+                    while len(pending) > 3 * workers:          # bound what is in flight (a job carries ~12 MB of particles)
+                        pending.pop(0).get()
+            for r in pending:
+                r.get()
+        finally:
+            if pool is not None:
+                pool.close()
+                pool.join()
 
         # five random files for testing (WassersteinGAN.py:539-545)
         input_files = [f for f in os.listdir(self.generate_dir) if '.tif' in f or '.png' in f or '.bmp' in f]

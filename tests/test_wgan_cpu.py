@@ -183,3 +183,36 @@ def test_gradient_noise_is_smooth_and_spans_its_range():
     n = W._gradient_noise2array(np.arange(0, 4, 4 / 200), np.arange(0, 4, 4 / 240), np.random.default_rng(0))
     assert n.shape == (200, 240) and np.isfinite(n).all()
     assert n.max() - n.min() > 0.8 and np.abs(np.diff(n, axis=0)).max() < 0.1 and np.abs(np.diff(n, axis=1)).max() < 0.1
+
+
+def _stub_particles(count):
+    import random
+    yy, xx = np.mgrid[0:32, 0:32]
+    out = np.zeros((count, 32, 32), np.uint8)
+    for k in range(count):
+        r = random.randint(6, 11)
+        out[k] = (((yy - 16) ** 2 + (xx - 16) ** 2) < r * r) * 255
+    return out
+
+
+def test_mask_simulation_in_worker_processes_writes_the_sequential_masks(tmp_path, monkeypatch):
+    """WGAN.simulate_masks draws where / how large / how rotated in the main process (the reference's order) and lets worker processes put
+    the particles onto the canvases -- the placement consumes no random numbers, so the files must be the ones the inline loop writes."""
+    import random
+    from PIL import Image
+    W = importlib.import_module(f"{BASE}.WassersteinGAN")
+    outs = {}
+    for workers in (1, 2):
+        monkeypatch.setenv("SS_MASK_WORKERS", str(workers))
+        wf = W.WGAN.__new__(W.WGAN)
+        wf.train_images = np.zeros((8, 32, 32, 1), dtype="float32")
+        wf.batch_size, wf.n_z, wf.model = 64, 16, object()          # the generator is stubbed: particles are seeded discs
+        wf.generate_dir = str(tmp_path / f"trainB_{workers}")
+        wf._sample_particles = _stub_particles
+        random.seed(3)
+        np.random.seed(3)
+        wf.simulate_masks(no_of_images=4, use_perlin_noise=True, use_normal_distribution=True, max_overlap=0.5, img_width=96, img_height=80)
+        outs[workers] = [np.asarray(Image.open(os.path.join(wf.generate_dir, f"{i:05d}.tif"))) for i in range(4)]
+    for a, b in zip(outs[1], outs[2]):
+        assert a.shape == (80, 96) and set(np.unique(a)) <= {0, 255} and a.any()
+        np.testing.assert_array_equal(a, b)

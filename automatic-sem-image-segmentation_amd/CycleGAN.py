@@ -26,6 +26,7 @@ import time
 import numpy as np
 import torch
 
+from . import HelperFunctions
 from . import _lib as L
 from . import dist as D
 from . import layers as LY
@@ -788,8 +789,9 @@ class CycleGAN:
             logs = {}
             order = list(range(len(self.data)))
             np.random.shuffle(order)     # Keras fit(shuffle=True) shuffles the batch order of a Sequence (K-list 10)
-            for idx in order:
-                a, b = self.data[idx]
+            # batches decoded ahead of the train steps when they come from disk (HelperFunctions.prefetch: same order, same contents)
+            ahead = HelperFunctions.PREFETCH_DEPTH if self.use_data_loader else 0
+            for a, b in HelperFunctions.prefetch(self.data.__getitem__, order, depth=ahead):
                 per = len(a) // world
                 logs = self.model.train_step((a[rank * per:(rank + 1) * per], b[rank * per:(rank + 1) * per]))
             self.data.on_epoch_end()

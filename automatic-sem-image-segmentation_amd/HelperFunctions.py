@@ -558,3 +558,35 @@ def prepare_images_cycle_gan(root_dir, input_dir_images, tile_size_w=384, tile_s
         crop = _random_crop(images[r], tile_size_h, tile_size_w)
         if tiles.add(crop, images[r], os.path.split(tile_names[r])[-1], f'aug_{made}'):
             made += 1
+
+
+def prefetch(fetch, keys, depth=4, workers=2):
+    """``fetch(k) for k in keys``, in order, with up to ``depth`` results being prepared ahead in ``workers`` threads.  The on-demand
+    loaders of both trainers (``USE_DATALOADER``: PIL decode + percentile normalisation per batch, CycleGAN.py:454-479,
+    UNet_Segmentation.py:104-121) are host work that the reference does between two train steps; a train step here ends with a
+    device->host read of its metrics, so without this the GPU idles while a batch is decoded and the host idles while the GPU works.
+    PIL, numpy and the ctypes launches release the GIL.  Order and contents are those of the plain loop (``fetch`` must not depend on
+    call order: loaders that draw random numbers per batch are not prefetched by the callers).  depth <= 0: the plain loop."""
+    keys = list(keys)
+    if depth <= 0 or workers <= 0 or len(keys) < 2:
+        for k in keys:
+            yield fetch(k)
+        return
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        pending = deque()
+        it = iter(keys)
+        for k in it:
+            pending.append(pool.submit(fetch, k))
+            if len(pending) >= depth:
+                break
+        while pending:
+            res = pending.popleft().result()
+            for k in it:
+                pending.append(pool.submit(fetch, k))
+                break
+            yield res
+
+
+PREFETCH_DEPTH = int(os.environ.get("SS_PREFETCH", "4"))          # batches prepared ahead by the on-demand loaders (0: off)

@@ -460,8 +460,9 @@ class UNet:
             seen = 0
             order = list(range(len(self.training_data)))
             np.random.shuffle(order)
-            for idx in order:
-                x, y = self.training_data[idx]
+            # batches decoded ahead of the train steps (HelperFunctions.prefetch); not when the loader draws random numbers per batch
+            ahead = HelperFunctions.PREFETCH_DEPTH if (self.use_dataloader and not getattr(self.dataset_train, "use_brightness_and_contrast_augmentation", False)) else 0
+            for x, y in HelperFunctions.prefetch(self.training_data.__getitem__, order, depth=ahead):
                 # ragged last batch of the on-demand loader (ceil length, UNet_Segmentation.py:111-112): every rank trims it to the
                 # same multiple of the world size, so the collectives stay matched; a batch smaller than the world is skipped
                 per = len(x) // world
@@ -479,8 +480,7 @@ class UNet:
             logs = {k: v / max(seen, 1) for k, v in tot.items()}
             vt = {"loss": 0.0, "mae": 0.0, "acc": 0.0}
             vseen = 0
-            for idx in range(len(self.validation_data)):
-                x, y = self.validation_data[idx]
+            for x, y in HelperFunctions.prefetch(self.validation_data.__getitem__, range(len(self.validation_data)), depth=ahead):
                 m = self.model.test_step((x, y))
                 for k in vt:
                     vt[k] += m[k] * len(x)

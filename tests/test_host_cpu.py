@@ -451,3 +451,30 @@ def test_product_path_never_touches_the_oracle():
     top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and ((getattr(n, "module", "") or "").startswith("oracle")
                                                                                  or any(a.name.startswith("oracle") for a in n.names))]
     assert not top, "bench.py imports the oracle at module level"
+
+
+def test_prefetch_keeps_order_contents_and_errors():
+    """HelperFunctions.prefetch (the on-demand loaders of both trainers): results in key order whatever finishes first, every key once,
+    a worker's exception surfaces at its position, depth 0 = the plain loop."""
+    import threading
+    import time
+    HF = importlib.import_module(BASE + ".HelperFunctions")
+    seen = []
+    lock = threading.Lock()
+
+    def fetch(k):
+        time.sleep(0.002 * ((7 * k) % 5))          # out-of-order completion
+        with lock:
+            seen.append(k)
+        if k == 13:
+            raise ValueError("boom")
+        return k * k
+
+    out = []
+    with pytest.raises(ValueError):
+        for v in HF.prefetch(fetch, range(20), depth=4, workers=3):
+            out.append(v)
+    assert out == [k * k for k in range(13)]
+    assert sorted(set(seen)) == sorted(seen) and max(seen) <= 13 + 4          # never more than `depth` ahead
+    assert list(HF.prefetch(lambda k: -k, range(5), depth=0)) == [0, -1, -2, -3, -4]
+    assert list(HF.prefetch(lambda k: k, [], depth=4)) == []

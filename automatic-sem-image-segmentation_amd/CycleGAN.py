@@ -453,10 +453,24 @@ class CycleGanModel:
                     optimizers={self._OPTS[nm]: dict(learning_rate=float(o.learning_rate), beta_1=float(o.beta_1), beta_2=float(o.beta_2))
                                 for nm in self._NETS for o in [getattr(self, self._OPTS[nm])] if o is not None})
 
-    def save(self, path):
+    def wait_saved(self):
+        """Join a ``save(..., background=True)`` still being written; re-raises what its writer raised."""
+        t = getattr(self, "_saver", None)
+        if t is not None:
+            t.join()
+            self._saver = None
+            err, self._saver_error = getattr(self, "_saver_error", None), None
+            if err is not None:
+                raise err
+
+    def save(self, path, background=False):
         """``model.save('…/model.keras')`` (CycleGAN.py:203-204,221): a Keras-3 archive (zip of config.json, metadata.json and
         model.weights.h5 with the four networks under gen_a/ gen_b/ disc_a/ disc_b/ and the four Adam states; keras_io.py).  A path
-        ending in ``.npz`` writes the plain-numpy form instead (variable names of this framework)."""
+        ending in ``.npz`` writes the plain-numpy form instead (variable names of this framework).
+        background = True (the per-epoch checkpoints of ``start_training``, CycleGAN.py:203-205): the weights and optimizer slots are
+        copied to the host NOW (1.2 GB: what the file will hold is this moment's state), the archive is written by a thread while the
+        next epoch trains; the next save / ``wait_saved`` joins it."""
+        self.wait_saved()
         if path.endswith(".npz"):
             arrays = {}
             for nm in self._NETS:
@@ -472,7 +486,20 @@ class CycleGanModel:
             arrays.update(K.net_arrays(getattr(self, nm), nm + "/"))
         for nm in self._NETS:
             arrays.update(K.optimizer_arrays(getattr(self, self._OPTS[nm]), getattr(self, nm), self._OPTS[nm] + "/"))
-        K.write_archive(path, arrays, "CycleGanModel", self._config())
+        if not background:
+            K.write_archive(path, arrays, "CycleGanModel", self._config())
+            return
+        import threading
+        cfg = self._config()
+
+        def write():
+            try:
+                K.write_archive(path, arrays, "CycleGanModel", cfg)
+            except BaseException as e:          # noqa: BLE001 -- surfaced by wait_saved() on the training thread
+                self._saver_error = e
+
+        self._saver = threading.Thread(target=write, name="checkpoint-writer")
+        self._saver.start()
 
     @classmethod
     def load(cls, path, device=None):
@@ -801,7 +828,7 @@ class CycleGAN:
                     if new:
                         f.write(';'.join(['epoch'] + sorted(logs)) + '\n')
                     f.write(';'.join([str(epoch)] + [repr(logs[k]) for k in sorted(logs)]) + '\n')
-                self.model.save(os.path.join(self.model_dir, self.prefix, 'checkpoints_{:03d}.keras'.format(epoch + 1)))
+                self.model.save(os.path.join(self.model_dir, self.prefix, 'checkpoints_{:03d}.keras'.format(epoch + 1)), background=True)
                 if plotter is not None:
                     plotter.on_epoch_end(self.model, epoch)
         if rank == 0:

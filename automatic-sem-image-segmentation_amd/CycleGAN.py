@@ -637,6 +637,9 @@ class CycleGAN:
         self.num_downsampling_blocks_disc = 2
         self.allow_memory_growth = allow_memory_growth
         self.use_gpus_no = use_gpus_no
+        # not in the reference: 'f32' | 'bf16' | 'f16' activation storage for training (fp32 master weights, fp32 statistics and
+        # accumulation either way).  Saved models are fp32 and reload as fp32 networks.
+        self.activation_storage = os.environ.get("SS_ACT_DTYPE", "f32")
         self.lambda_cycle_a = 10
         self.lambda_cycle_b = 10
         self.use_binary_crossentropy = False
@@ -679,15 +682,15 @@ class CycleGAN:
         kw = dict(filters=self.filters, num_downsampling_blocks=self.num_downsampling_blocks_gen,
                   num_residual_blocks=self.num_residual_blocks_gen, num_upsample_blocks=self.num_upsampling_blocks_gen,
                   channels=ch, device=self.device, use_skip_connection=self.use_skip_connection,
-                  use_resize_convolution=self.use_resize_convolution)
+                  use_resize_convolution=self.use_resize_convolution, act_dtype=self.activation_storage)
         self.gen_a = ResnetGenerator(seed=self.seed + 1, sigmoid_output=self.use_binary_crossentropy, **kw)
         self.gen_b = ResnetGenerator(seed=self.seed + 2, **kw)
         self.disc_a = PatchDiscriminator(filters=2 * self.filters, num_downsampling_blocks=self.num_downsampling_blocks_disc,
                                          channels=ch, padding="valid", device=self.device, seed=self.seed + 3,
-                                         gaussian_noise_value=self.gaussian_noise_value)
+                                         gaussian_noise_value=self.gaussian_noise_value, act_dtype=self.activation_storage)
         self.disc_b = PatchDiscriminator(filters=2 * self.filters, num_downsampling_blocks=self.num_downsampling_blocks_disc,
                                          channels=ch, padding="valid", device=self.device, seed=self.seed + 4,
-                                         gaussian_noise_value=self.gaussian_noise_value)
+                                         gaussian_noise_value=self.gaussian_noise_value, act_dtype=self.activation_storage)
         D.broadcast_params([self.gen_a, self.gen_b, self.disc_a, self.disc_b])
         D.enable_overlap([self.gen_a, self.gen_b, self.disc_a, self.disc_b])
         if D.world_size() > 1:

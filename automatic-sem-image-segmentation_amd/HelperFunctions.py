@@ -581,12 +581,16 @@ def prefetch(fetch, keys, depth=4, workers=2):
             pending.append(pool.submit(fetch, k))
             if len(pending) >= depth:
                 break
-        while pending:
-            res = pending.popleft().result()
-            for k in it:
-                pending.append(pool.submit(fetch, k))
-                break
-            yield res
+        try:
+            while pending:
+                res = pending.popleft().result()
+                for k in it:
+                    pending.append(pool.submit(fetch, k))
+                    break
+                yield res
+        finally:          # the consumer stopped early (break / exception): do not prepare what nobody will read
+            for f in pending:
+                f.cancel()
 
 
 PREFETCH_DEPTH = int(os.environ.get("SS_PREFETCH", "4"))          # batches prepared ahead by the on-demand loaders (0: off)

@@ -70,6 +70,8 @@ class WorkflowOptions:
     MIN_NO_OF_PARTICLES: int = 100
     MAX_NO_OF_PARTICLES: int = 150
     WGAN_NOISE_DIM: int = 128
+    # not in the reference: activation storage of the CycleGAN and MultiResUNet training steps, 'f32' | 'bf16' | 'f16'
+    ACTIVATION_STORAGE: str = os.environ.get("SS_ACT_DTYPE", "f32")
 
     _DERIVED_DIRS = (("INPUT_DIR_MASKS", "Input_Masks"), ("INPUT_DIR_IMAGES", "Input_Images"),
                      ("OUTPUT_DIR_CYCLEGAN", "Output_Masks_CycleGAN"), ("OUTPUT_DIR_UNET", "Output_Masks_UNet"))
@@ -126,6 +128,7 @@ class Workflow:
         cg.filters = o.CYCLEGAN_FILTERS
         cg.use_binary_crossentropy = False
         cg.use_resize_convolution = False
+        cg.activation_storage = o.ACTIVATION_STORAGE
         return cg
 
     def _unet(self):
@@ -136,6 +139,7 @@ class Workflow:
         un.use_dataloader = o.USE_DATALOADER
         un.filters = o.UNET_FILTERS
         un.contrast_optimization_range = o.UNET_CONTRAST_OPTIMIZATION_RANGE
+        un.activation_storage = o.ACTIVATION_STORAGE
         return un
 
     def step_0(self):

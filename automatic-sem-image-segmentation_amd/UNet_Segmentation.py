@@ -347,6 +347,7 @@ class UNet:
         self.output_channels = 1
         self.allow_memory_growth = allow_memory_growth
         self.use_gpus_no = use_gpus_no
+        self.activation_storage = os.environ.get("SS_ACT_DTYPE", "f32")     # not in the reference; see CycleGAN.CycleGAN
         self.dataset_train = self.dataset_val = None
         self.training_data = self.validation_data = None
         self.model = None
@@ -389,7 +390,8 @@ class UNet:
             weighting = self.class_weighting()
         # output_channels > 1: Conv2D + softmax head and one-hot targets (UNet_Segmentation.py:387, 558-560); the reference's own
         # feeders only ever produce one-channel masks, and its inference path rebuilds a one-channel model (UNet_Segmentation.py:317)
-        net = MultiResUNet(conv_filters=self.filters, device=self.device, seed=self.seed, output_channels=self.output_channels)
+        net = MultiResUNet(conv_filters=self.filters, device=self.device, seed=self.seed, output_channels=self.output_channels,
+                           act_dtype=self.activation_storage)
         D.broadcast_params([net])
         D.enable_overlap([net])
         if D.world_size() > 1 and self.sync_batch_norm:

@@ -238,6 +238,15 @@ def test_workflow_options_directories_follow_root_dir():
     assert o2.INPUT_DIR_IMAGES == o.INPUT_DIR_IMAGES and o2.OUTPUT_DIR_UNET == "/x/y"
 
 
+def test_activation_storage_option_reaches_both_trainers(tmp_path):
+    """ACTIVATION_STORAGE (not in the reference) is handed to the CycleGAN and MultiResUNet trainers; the default is fp32 storage."""
+    SP = importlib.import_module(BASE + ".StartProcess")
+    wf = SP.Workflow(SP.WorkflowOptions(ROOT_DIR=str(tmp_path)))
+    assert wf._cyclegan().activation_storage == "f32" and wf._unet().activation_storage == "f32"
+    wf.o.set("ACTIVATION_STORAGE", "f16")
+    assert wf._cyclegan().activation_storage == "f16" and wf._unet().activation_storage == "f16"
+
+
 def test_connectivity_and_loader_match_reference_vectors(golden_dir, tmp_path):
     from PIL import Image
     HF = importlib.import_module(BASE + ".HelperFunctions")

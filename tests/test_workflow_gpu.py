@@ -86,3 +86,35 @@ def test_cyclegan_then_unet_workflow(tmp_path):
     p1 = umodel.predict(np.ascontiguousarray(np.array(Image.open(os.path.join(big, "000.tif")), dtype=np.float32)[None, :, :, None] / 255.0))
     p2 = un2.model.predict(np.ascontiguousarray(np.array(Image.open(os.path.join(big, "000.tif")), dtype=np.float32)[None, :, :, None] / 255.0))
     assert bool((p1 == p2).all())
+
+
+@pytest.mark.parametrize("storage", ["f16", "bf16"])
+def test_trainers_build_their_networks_with_the_requested_activation_storage(tmp_path, storage):
+    """`activation_storage` (ACTIVATION_STORAGE of the workflow options): the four CycleGAN networks and the MultiResUNet are built with
+    16-bit activation storage, one train step of each leaves finite metrics, and the saved model reloads as an fp32 network."""
+    import torch
+    CG = importlib.import_module(BASE + ".CycleGAN")
+    UN = importlib.import_module(BASE + ".UNet_Segmentation")
+    L = importlib.import_module(BASE + "._lib")
+    want = L.torch_dtype(storage)
+    cg = CG.CycleGAN(root_dir=str(tmp_path), image_shape=(64, 64, 1))
+    cg.filters, cg.num_residual_blocks_gen, cg.use_skip_connection, cg.activation_storage = 4, 2, False, storage
+    model = cg.create_model()
+    assert {n.act_dtype for n in (cg.gen_a, cg.gen_b, cg.disc_a, cg.disc_b)} == {want} and model.act_dtype == want
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(2, 64, 64, 1, generator=g) * 2 - 1
+    b = torch.rand(2, 64, 64, 1, generator=g) * 2 - 1
+    m = model.train_step((a.numpy(), b.numpy()))
+    assert all(np.isfinite(float(v)) for v in m.values()), m
+    path = str(tmp_path / "cg.keras")
+    model.save(path)
+    assert CG.CycleGanModel.load(path, cg.device).act_dtype == torch.float32
+
+    un = UN.UNet(root_dir=str(tmp_path), image_dir=str(tmp_path), mask_dir=str(tmp_path))
+    un.filters, un.activation_storage = 16, storage
+    um = un.create_model(weighting=4.0)
+    assert um.net.act_dtype == want and um.act_dtype == want
+    x = torch.rand(2, 64, 64, 1, generator=g)
+    y = (torch.rand(2, 64, 64, 1, generator=g) > 0.8).float()
+    mu = um.train_step((x.numpy(), y.numpy()))
+    assert all(np.isfinite(float(v)) for v in mu.values()), mu

@@ -433,7 +433,7 @@ class CycleGanModel:
     def to_numpy_array(x):
         if isinstance(x, Act):
             x = x.dense()
-        return x.detach().cpu().numpy().copy()
+        return x.detach().float().cpu().numpy().copy()          # 16-bit activation storage: numpy has no bfloat16
 
     # ---- persistence (Keras variable order; see DESIGN.md for the .keras/HDF5 status) ----------------------
     def get_weights(self):

@@ -133,7 +133,10 @@ def test_cyclegan_dataloader_matches_reference(feed):
         dl.on_epoch_end()                                      # independent shuffles of A and B, CycleGAN.py:477-479
 
 
-def test_unet_feeders_match_reference(feed, tmp_path):
+@pytest.mark.parametrize("cache_bytes", [2 ** 31, 0, 5000], ids=["cached", "uncached", "cache_too_small"])
+def test_unet_feeders_match_reference(feed, tmp_path, cache_bytes):
+    """... whether the decoded tiles come from the loader's bounded cache (every file is read under four flip ids, every epoch) or are
+    decoded on every read as in the reference."""
     from PIL import Image
     UN = importlib.import_module(f"{BASE}.UNet_Segmentation")
     idir, mdir = str(tmp_path / "imgs"), str(tmp_path / "masks")
@@ -144,6 +147,7 @@ def test_unet_feeders_match_reference(feed, tmp_path):
     for subset in ("train", "val"):
         ds = UN.ImageDataset(idir, mdir)
         ds.initialize_images(subset)                            # 80/20 split, random.Random(1234), 4 flip ids per image
+        ds.cache_limit_bytes = cache_bytes
         assert ds.image_ids == [str(s) for s in feed[f"un/{subset}/ids"]]
         assert [os.path.basename(ds.image_info[i]["image_path"]) for i in ds.image_ids] == [str(s) for s in feed[f"un/{subset}/files"]]
         ld = UN.DataLoader(ds, batch_size=3, shuffle=True)
@@ -155,6 +159,12 @@ def test_unet_feeders_match_reference(feed, tmp_path):
                 np.testing.assert_array_equal(x, feed[f"un/{subset}/ep{ep}/x{idx}"])
                 np.testing.assert_array_equal(y, feed[f"un/{subset}/ep{ep}/y{idx}"])
             ld.on_epoch_end()
+        files = {ds.image_info[i]["image_path"] for i in ds.image_ids}
+        assert ds._cache_bytes <= max(cache_bytes, 0) and ds._cache_bytes == sum(t.nbytes for t in ds._cache.values())
+        if cache_bytes == 2 ** 31:          # one image and one mask entry per file; masks as bytes
+            assert len(ds._cache) == 2 * len(files) and {t.dtype for (_, m), t in ds._cache.items() if m} == {np.dtype(np.uint8)}
+        if cache_bytes == 0:
+            assert not ds._cache
 
 
 def test_unet_dataset_matches_reference(feed):

@@ -106,6 +106,8 @@ def test_trainers_build_their_networks_with_the_requested_activation_storage(tmp
     b = torch.rand(2, 64, 64, 1, generator=g) * 2 - 1
     m = model.train_step((a.numpy(), b.numpy()))
     assert all(np.isfinite(float(v)) for v in m.values()), m
+    fake = CG.CycleGanModel.to_numpy_array(cg.gen_a(a.to(cg.device), training=False))          # what the preview sheets / inference read
+    assert fake.dtype == np.float32 and fake.shape == (2, 64, 64, 1) and np.isfinite(fake).all()
     path = str(tmp_path / "cg.keras")
     model.save(path)
     assert CG.CycleGanModel.load(path, cg.device).act_dtype == torch.float32
@@ -118,3 +120,4 @@ def test_trainers_build_their_networks_with_the_requested_activation_storage(tmp
     y = (torch.rand(2, 64, 64, 1, generator=g) > 0.8).float()
     mu = um.train_step((x.numpy(), y.numpy()))
     assert all(np.isfinite(float(v)) for v in mu.values()), mu
+    assert um.predict(x.numpy()).dtype == torch.float32

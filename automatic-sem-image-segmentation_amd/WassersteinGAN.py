@@ -683,10 +683,15 @@ class WGAN:
         """``count`` generated particle masks as uint8 images (WassersteinGAN.py:487-503: batches of ``batch_size`` latent vectors,
         inference mode)."""
         out = np.zeros((count, self.train_images.shape[1], self.train_images.shape[2], 1), dtype='float32')
-        for j in range(0, count, self.batch_size):
-            k = min(self.batch_size, count - j)
-            z = torch.randn((k, self.n_z), device=self.device)
-            out[j:j + k] = WGAN_GP.to_numpy_array(self.model(z, training=False))
+        if count == 0:
+            return out[:, :, :, 0].astype('uint8')
+        # the latent vectors are drawn ``batch_size`` rows at a time (the stream of the per-batch loop); the generator then runs on
+        # ``sample_chunk`` of them per call: a mask needs ~3 000 particles, and 47 calls of 64 with a device->host read each made the
+        # drawing loop (not the placement workers) the pace of step 2.  Inference mode: a particle does not depend on its batch.
+        z = torch.cat([torch.randn((min(self.batch_size, count - j), self.n_z), device=self.device) for j in range(0, count, self.batch_size)])
+        chunk = max(int(getattr(self, "sample_chunk", 512)), 1)
+        for j in range(0, count, chunk):
+            out[j:j + chunk] = WGAN_GP.to_numpy_array(self.model(z[j:j + chunk], training=False))
         return (out * 127.5 + 127.5)[:, :, :, 0].astype('uint8')
 
     def simulate_masks(self, no_of_images=1, min_no_of_particles=100, max_no_of_particles=150, use_normal_distribution=False, sigma=0.10,
@@ -711,9 +716,9 @@ class WGAN:
         os.makedirs(self.generate_dir, exist_ok=True)
         # Where / how large / how rotated is drawn here, in the reference's order, and the particles come from the generator on the
         # device; putting ~3 000 particles onto a canvas (affine warp, hole filling, opening, erosion, overlap test per particle) is
-        # 1 - 5 s of pure host work per mask and draws nothing: it runs in worker processes (SS_MASK_WORKERS, default min(16, cores / 2);
+        # 1 - 5 s of pure host work per mask and draws nothing: it runs in worker processes (SS_MASK_WORKERS, default min(32, cores / 2);
         # 1 = inline), so 1 000 masks take minutes instead of the better part of an hour.
-        workers = int(os.environ.get("SS_MASK_WORKERS", max(1, min(16, (os.cpu_count() or 2) // 2))))
+        workers = int(os.environ.get("SS_MASK_WORKERS", max(1, min(32, (os.cpu_count() or 2) // 2))))
         pool, pending = None, []
         if workers > 1 and no_of_images >= 4:
             import multiprocessing as mp

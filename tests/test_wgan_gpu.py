@@ -195,3 +195,13 @@ def test_workflow_trains_saves_and_simulates_masks(tmp_path):
                            use_perlin_noise=True, grid_type=grid)
         img = np.asarray(Image.open(tmp_path / "2_CycleGAN" / "data" / "trainB" / "00000.tif"))
         assert img.shape == (64, 224) and set(np.unique(img)) <= {0, 255}
+    # the particles of a mask: latent vectors drawn batch_size rows at a time, the generator run on sample_chunk of them per call --
+    # the same particles as one call per batch (inference mode), to a grey level
+    import torch
+    got = {}
+    for chunk in (16, 512):
+        wf2.sample_chunk = chunk
+        torch.manual_seed(5)
+        got[chunk] = wf2._sample_particles(70).astype(np.int16)
+    assert got[16].shape == (70, 32, 32) and np.abs(got[16] - got[512]).max() <= 1 and np.ptp(got[512]) > 0
+    assert wf2._sample_particles(0).shape == (0, 32, 32)

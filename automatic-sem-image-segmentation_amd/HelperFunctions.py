@@ -445,34 +445,59 @@ def particles(mask):
     return out, n
 
 
+def _filter_one(job):
+    """One image / mask pair of ``filter_gan_masks`` (a top-level function: it also runs in worker processes)."""
+    from PIL import Image, ImageFilter
+    f, img_path, msk_path, out_path, threshold_method, do_watershed_and_four_connectivity, gaussian_blur_amount, dark_background = job
+    img = np.array(Image.open(os.path.join(img_path, f)), dtype='uint8')
+    mask = np.array(Image.open(os.path.join(msk_path, f)), dtype='uint8')
+    if do_watershed_and_four_connectivity:
+        mask = segment(image=mask, threshold=-1, watershed_lines=True, use_four_connectivity=True)
+    contours = find_contours(mask)
+    thr = threshold_method(img)
+    means = contour_mean_intensities(contours, img)
+    if dark_background:
+        if thr != 0:          # filterResults(minValue=thr): "minValue == 0 and maxValue < minValue" returns without filtering
+            contours = [c for c, m in zip(contours, means) if not m < thr]
+    else:                      # filterResults(maxValue=thr): removed when mean > maxValue and maxValue >= 0; a negative maxValue filters nothing
+        if thr >= 0:
+            contours = [c for c, m in zip(contours, means) if not m > thr]
+    Image.fromarray(draw_contours_filled(contours, img.shape)).save(os.path.join(out_path, f))
+    if gaussian_blur_amount > 0:
+        Image.fromarray(img).filter(ImageFilter.GaussianBlur(gaussian_blur_amount)).save(os.path.join(img_path, f))
+
+
 def filter_gan_masks(img_path, msk_path, out_path, threshold_method=threshold_li, do_watershed_and_four_connectivity=True,
-                     gaussian_blur_amount=0.0, dark_background=True):
+                     gaussian_blur_amount=0.0, dark_background=True, workers=None):
     """Workflow step 5 (StartProcess.py:133-146; HelperFunctions.py:163-185): drop simulated particles the CycleGAN did not render.
     For every generated image / mask pair: optionally re-segment the mask (Otsu, watershed lines, 4-connectivity), take the contours
     of the mask as ``Measure`` does, each contour's MEAN INTENSITY in the generated image (Measure.calculateMeanIntensities,
     Measurements.py:321-342: over the points with pointPolygonTest >= 0) and keep the contours whose mean is >= (dark background;
     <= otherwise) ``threshold_method(image)`` (Measure.filterResults('meanIntensity'), Measurements.py:569-611, including its
     "minValue == 0 and no maxValue: keep everything" shortcut); the kept contours are drawn filled (255) under the same file name;
-    optional Gaussian blur of the image in place (PIL radius = ``gaussian_blur_amount``)."""
-    from PIL import Image, ImageFilter
+    optional Gaussian blur of the image in place (PIL radius = ``gaussian_blur_amount``).
+    The pairs are independent and draw nothing: with more than a handful they go to ``workers`` processes (SS_FILTER_WORKERS, default
+    min(16, cores / 2); 1 = inline) -- 1 000 pairs cost ~30 s of contour work on one core."""
     os.makedirs(out_path, exist_ok=True)
-    for f in sorted(os.listdir(img_path)):
-        img = np.array(Image.open(os.path.join(img_path, f)), dtype='uint8')
-        mask = np.array(Image.open(os.path.join(msk_path, f)), dtype='uint8')
-        if do_watershed_and_four_connectivity:
-            mask = segment(image=mask, threshold=-1, watershed_lines=True, use_four_connectivity=True)
-        contours = find_contours(mask)
-        thr = threshold_method(img)
-        means = contour_mean_intensities(contours, img)
-        if dark_background:
-            if thr != 0:          # filterResults(minValue=thr): "minValue == 0 and maxValue < minValue" returns without filtering
-                contours = [c for c, m in zip(contours, means) if not m < thr]
-        else:                      # filterResults(maxValue=thr): removed when mean > maxValue and maxValue >= 0; a negative maxValue filters nothing
-            if thr >= 0:
-                contours = [c for c, m in zip(contours, means) if not m > thr]
-        Image.fromarray(draw_contours_filled(contours, img.shape)).save(os.path.join(out_path, f))
-        if gaussian_blur_amount > 0:
-            Image.fromarray(img).filter(ImageFilter.GaussianBlur(gaussian_blur_amount)).save(os.path.join(img_path, f))
+    files = sorted(os.listdir(img_path))
+    jobs = [(f, img_path, msk_path, out_path, threshold_method, do_watershed_and_four_connectivity, gaussian_blur_amount, dark_background)
+            for f in files]
+    if workers is None:
+        workers = int(os.environ.get("SS_FILTER_WORKERS", max(1, min(16, (os.cpu_count() or 2) // 2))))
+    if workers > 1 and len(jobs) >= 16:
+        import pickle
+        try:
+            pickle.dumps(threshold_method)
+        except Exception:          # a lambda / local function cannot travel to a worker process
+            workers = 1
+    if workers <= 1 or len(jobs) < 16:
+        for job in jobs:
+            _filter_one(job)
+        return
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+        for _ in pool.imap_unordered(_filter_one, jobs, chunksize=max(1, len(jobs) // (8 * workers))):
+            pass
 
 
 WORKFLOW_TREE = ("1_WGAN/Output_Images", "1_WGAN/Models",

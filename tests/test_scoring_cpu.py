@@ -116,6 +116,42 @@ def test_contour_statistics_follow_the_opencv_semantics_of_measure(tmp_path):
     assert np.array_equal(out0 > 0, HF.draw_contours_filled(cs, mask.shape) > 0)
 
 
+def test_filter_gan_masks_in_worker_processes_writes_the_same_files(tmp_path):
+    """The pairs of step 5 are independent: filtered in worker processes they are the files of the plain loop (both passes of the workflow:
+    without and with watershed + 4-connectivity), and a threshold function that cannot travel to a worker keeps the call inline."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    img_dir, msk_dir = str(tmp_path / "img"), str(tmp_path / "msk")
+    os.makedirs(img_dir), os.makedirs(msk_dir)
+    yy, xx = np.mgrid[0:64, 0:64]
+    for i in range(20):
+        mask = np.zeros((64, 64), np.uint8)
+        img = (rng.random((64, 64)) * 60).astype(np.uint8)
+        for _ in range(6):
+            cy, cx, r = rng.integers(8, 56), rng.integers(8, 56), rng.integers(3, 8)
+            disc = (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+            mask[disc] = 255
+            if rng.random() < 0.6:
+                img[disc] = 200
+        Image.fromarray(img).save(os.path.join(img_dir, f"{i:03d}.tif"))
+        Image.fromarray(mask).save(os.path.join(msk_dir, f"{i:03d}.tif"))
+    for ws in (False, True):
+        outs = {}
+        for workers in (1, 3):
+            outs[workers] = str(tmp_path / f"out_{ws}_{workers}")
+            HF.filter_gan_masks(img_dir, msk_dir, outs[workers], do_watershed_and_four_connectivity=ws, workers=workers)
+        assert sorted(os.listdir(outs[1])) == sorted(os.listdir(outs[3])) and len(os.listdir(outs[1])) == 20
+        changed = 0
+        for f in os.listdir(outs[1]):
+            a, b = np.array(Image.open(os.path.join(outs[1], f))), np.array(Image.open(os.path.join(outs[3], f)))
+            assert np.array_equal(a, b), f
+            changed += int(not np.array_equal(a, np.array(Image.open(os.path.join(msk_dir, f)))))
+        assert changed > 0          # the filter did remove particles
+    out_l = str(tmp_path / "out_lambda")
+    HF.filter_gan_masks(img_dir, msk_dir, out_l, do_watershed_and_four_connectivity=False, threshold_method=lambda im: 100.0, workers=3)
+    assert len(os.listdir(out_l)) == 20
+
+
 def test_small_contour_removal_rule():
     """len(contour) < 5 and perimeter < 8 on the CHAIN_APPROX_SIMPLE polygon (Measurements.py:176-187): vertices / perimeters of the
     shapes that can qualify (everything inside a 4 x 4 box)."""

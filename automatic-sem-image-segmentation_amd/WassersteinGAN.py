@@ -426,10 +426,10 @@ def _gradient_noise2array(ys, xs, rng):
     ang = rng.uniform(0, 2 * np.pi, (ny, nx))
     gx, gy = np.cos(ang), np.sin(ang)
     fx, fy = (xs - x0)[None, :], (ys - y0)[:, None]
-    X0, Y0 = x0[None, :], y0[:, None]
 
-    def corner(dx, dy):
-        return gx[Y0 + dy, X0 + dx] * (fx - dx) + gy[Y0 + dy, X0 + dx] * (fy - dy)
+    def corner(dx, dy):          # lattice gradients at (y0 + dy, x0 + dx): the index is separable -- a row take, then a column take
+        rows, cols = y0 + dy, x0 + dx
+        return gx[rows][:, cols] * (fx - dx) + gy[rows][:, cols] * (fy - dy)
 
     def fade(t):
         return t * t * t * (t * (t * 6 - 15) + 10)
@@ -682,17 +682,24 @@ class WGAN:
     def _sample_particles(self, count):
         """``count`` generated particle masks as uint8 images (WassersteinGAN.py:487-503: batches of ``batch_size`` latent vectors,
         inference mode)."""
-        out = np.zeros((count, self.train_images.shape[1], self.train_images.shape[2], 1), dtype='float32')
+        out = np.zeros((count, self.train_images.shape[1], self.train_images.shape[2]), dtype='uint8')
         if count == 0:
-            return out[:, :, :, 0].astype('uint8')
+            return out
         # the latent vectors are drawn ``batch_size`` rows at a time (the stream of the per-batch loop); the generator then runs on
         # ``sample_chunk`` of them per call: a mask needs ~3 000 particles, and 47 calls of 64 with a device->host read each made the
         # drawing loop (not the placement workers) the pace of step 2.  Inference mode: a particle does not depend on its batch.
         z = torch.cat([torch.randn((min(self.batch_size, count - j), self.n_z), device=self.device) for j in range(0, count, self.batch_size)])
         chunk = max(int(getattr(self, "sample_chunk", 512)), 1)
         for j in range(0, count, chunk):
-            out[j:j + chunk] = WGAN_GP.to_numpy_array(self.model(z[j:j + chunk], training=False))
-        return (out * 127.5 + 127.5)[:, :, :, 0].astype('uint8')
+            y = self.model(z[j:j + chunk], training=False)
+            y = y.dense() if isinstance(y, Act) else y
+            if isinstance(y, torch.Tensor):
+                # grey levels on the device: float32 y * 127.5 + 127.5 truncated to uint8, the arithmetic of the host form below, and a
+                # quarter of the bytes to read back (a mask's particles are 49 MB as float32)
+                out[j:j + chunk] = (y.detach().float() * 127.5 + 127.5).to(torch.uint8)[:, :, :, 0].cpu().numpy()
+            else:
+                out[j:j + chunk] = (np.asarray(y, dtype='float32') * 127.5 + 127.5)[:, :, :, 0].astype('uint8')
+        return out
 
     def simulate_masks(self, no_of_images=1, min_no_of_particles=100, max_no_of_particles=150, use_normal_distribution=False, sigma=0.10,
                        mu=1.0, min_scaling=0.75, max_scaling=1.25, use_perlin_noise=True, perlin_noise_threshold=0.5,

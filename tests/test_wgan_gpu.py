@@ -205,3 +205,8 @@ def test_workflow_trains_saves_and_simulates_masks(tmp_path):
         got[chunk] = wf2._sample_particles(70).astype(np.int16)
     assert got[16].shape == (70, 32, 32) and np.abs(got[16] - got[512]).max() <= 1 and np.ptp(got[512]) > 0
     assert wf2._sample_particles(0).shape == (0, 32, 32)
+    # the grey levels are computed on the device: the values of the host form (float32 y * 127.5 + 127.5, truncated)
+    torch.manual_seed(5)
+    z = torch.cat([torch.randn((min(16, 70 - j), wf2.n_z), device=wf2.device) for j in range(0, 70, 16)])
+    host = (W.WGAN_GP.to_numpy_array(wf2.model(z, training=False)) * 127.5 + 127.5)[:, :, :, 0].astype('uint8')
+    np.testing.assert_array_equal(got[512], host.astype(np.int16))

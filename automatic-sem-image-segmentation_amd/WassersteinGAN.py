@@ -394,6 +394,9 @@ class GANMonitor:
         Image.fromarray(sheet).save(os.path.join(self.output_dir, 'Epoch_{:05d}.png'.format(epoch)))
 
 
+_ROW9, _COL9 = np.ones((1, 9), dtype=bool), np.ones((9, 1), dtype=bool)
+
+
 def _rotation_matrix_2d(center, angle, scale):
     """cv2.getRotationMatrix2D (WassersteinGAN.py:510): angle in degrees, positive = counter-clockwise, origin top-left."""
     a = scale * math.cos(math.radians(angle))
@@ -511,7 +514,11 @@ class _MaskCanvas:
         m[0, 2] += bound_h / 2 - centre[0]
         m[1, 2] += bound_w / 2 - centre[1]
         shape = _warp_affine(particle, m, (bound_h, bound_w)) > 127
-        shape = ndimage.binary_opening(ndimage.binary_fill_holes(shape), structure=np.ones((9, 9)))
+        # 9 x 9 opening as its separable form (a square's erosion / dilation is the row pass followed by the column pass, also at the
+        # zero border): the same pixels at 18 instead of 81 structure elements per pixel and pass
+        shape = ndimage.binary_fill_holes(shape)
+        for op in (ndimage.binary_erosion, ndimage.binary_dilation):
+            shape = op(op(shape, structure=_ROW9), structure=_COL9)
         core = ndimage.binary_erosion(shape, iterations=2)
         if not np.any(core):
             return False

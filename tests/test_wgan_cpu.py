@@ -216,3 +216,28 @@ def test_mask_simulation_in_worker_processes_writes_the_sequential_masks(tmp_pat
     for a, b in zip(outs[1], outs[2]):
         assert a.shape == (80, 96) and set(np.unique(a)) <= {0, 255} and a.any()
         np.testing.assert_array_equal(a, b)
+
+
+def test_particle_cleaning_opens_with_the_9x9_square():
+    """_MaskCanvas.place cleans a warped particle by hole filling and a 9 x 9 opening (WassersteinGAN.py:523-524), evaluated as row and
+    column passes: the pixels of scipy's binary_opening with the full square, also for shapes that touch the border."""
+    from scipy import ndimage
+    W = importlib.import_module(f"{BASE}.WassersteinGAN")
+    rng = np.random.default_rng(0)
+    for _ in range(60):
+        h, w = rng.integers(10, 90, 2)
+        x = ndimage.gaussian_filter(rng.random((h, w)), rng.uniform(1, 4)) > 0.5
+        want = ndimage.binary_opening(x, structure=np.ones((9, 9)))
+        got = x
+        for op in (ndimage.binary_erosion, ndimage.binary_dilation):
+            got = op(op(got, structure=W._ROW9), structure=W._COL9)
+        np.testing.assert_array_equal(got, want)
+    # and through place(): a 30 x 30 square with a one-pixel spur and a hole -- the spur goes, the hole is filled, the rim is eroded by 2
+    c = W._MaskCanvas(64, 64, 96, 96, 1.0)
+    p = np.zeros((64, 64), np.uint8)
+    p[17:47, 17:47] = 255
+    p[30, 47:60] = 255
+    p[30:33, 30:33] = 0
+    assert c.place(p, 20, 20, 0.0, 1.0, 0.5)
+    ys, xs = np.nonzero(c.img)
+    assert (ys.min(), ys.max(), xs.min(), xs.max()) == (20 + 19, 20 + 44, 20 + 19, 20 + 44) and c.img.sum() == 26 * 26

@@ -477,13 +477,13 @@ def filter_gan_masks(img_path, msk_path, out_path, threshold_method=threshold_li
     "minValue == 0 and no maxValue: keep everything" shortcut); the kept contours are drawn filled (255) under the same file name;
     optional Gaussian blur of the image in place (PIL radius = ``gaussian_blur_amount``).
     The pairs are independent and draw nothing: with more than a handful they go to ``workers`` processes (SS_FILTER_WORKERS, default
-    min(16, cores / 2); 1 = inline) -- 1 000 pairs cost ~30 s of contour work on one core."""
+    ``default_workers()``; 1 = inline) -- 1 000 pairs cost ~30 s of contour work on one core."""
     os.makedirs(out_path, exist_ok=True)
     files = sorted(os.listdir(img_path))
     jobs = [(f, img_path, msk_path, out_path, threshold_method, do_watershed_and_four_connectivity, gaussian_blur_amount, dark_background)
             for f in files]
     if workers is None:
-        workers = int(os.environ.get("SS_FILTER_WORKERS", max(1, min(16, (os.cpu_count() or 2) // 2))))
+        workers = int(os.environ.get("SS_FILTER_WORKERS", default_workers()))
     if workers > 1 and len(jobs) >= 16:
         import pickle
         try:
@@ -583,6 +583,38 @@ def prepare_images_cycle_gan(root_dir, input_dir_images, tile_size_w=384, tile_s
         crop = _random_crop(images[r], tile_size_h, tile_size_w)
         if tiles.add(crop, images[r], os.path.split(tile_names[r])[-1], f'aug_{made}'):
             made += 1
+
+
+def usable_cores():
+    """CPUs this process may really use: the affinity mask AND the cgroup CPU quota (a container on a 256-thread host is typically
+    given a quota -- 16 CPUs on the MI355X boxes this was measured on -- that ``os.cpu_count()`` does not show; more worker processes
+    than that only get throttled)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:                                                   # cgroup v2: "<quota> <period>" or "max <period>"
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:                                               # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
+def default_workers(limit=32):
+    """Worker processes for the independent host jobs of the workflow (mask placement, mask filtering, the scoring sweep): the usable
+    cores less one for the dispatching process, at most ``limit``."""
+    return max(1, min(limit, usable_cores() - 1))
 
 
 def prefetch(fetch, keys, depth=4, workers=2):

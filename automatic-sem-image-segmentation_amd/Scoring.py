@@ -217,7 +217,7 @@ def main(argv=None):
     ap.add_argument("--tile", type=int, nargs=2, metavar=("W", "H"), default=None, help="tile size for inference (default: whole image)")
     ap.add_argument("--no-watershed", action="store_true")
     ap.add_argument("--limit", type=int, default=None, help="score the first N images only")
-    ap.add_argument("--workers", type=int, default=max(1, min(16, (os.cpu_count() or 1) // 2)), help="processes for the threshold sweep")
+    ap.add_argument("--workers", type=int, default=HF.default_workers(16), help="processes for the threshold sweep")
     a = ap.parse_args(argv)
     img_dir, gt_dir = os.path.join(a.data_root, a.images), os.path.join(a.data_root, a.ground_truth)
     for d in (img_dir, gt_dir):

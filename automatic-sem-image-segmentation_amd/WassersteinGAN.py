@@ -730,9 +730,10 @@ class WGAN:
         os.makedirs(self.generate_dir, exist_ok=True)
         # Where / how large / how rotated is drawn here, in the reference's order, and the particles come from the generator on the
         # device; putting ~3 000 particles onto a canvas (affine warp, hole filling, opening, erosion, overlap test per particle) is
-        # 1 - 5 s of pure host work per mask and draws nothing: it runs in worker processes (SS_MASK_WORKERS, default min(32, cores / 2);
-        # 1 = inline), so 1 000 masks take minutes instead of the better part of an hour.
-        workers = int(os.environ.get("SS_MASK_WORKERS", max(1, min(32, (os.cpu_count() or 2) // 2))))
+        # 1 - 5 s of pure host work per mask and draws nothing: it runs in worker processes (SS_MASK_WORKERS; default: the usable cores --
+        # affinity and cgroup quota -- less one; 1 = inline), so 1 000 masks take a minute instead of the better part of an hour.
+        from . import HelperFunctions
+        workers = int(os.environ.get("SS_MASK_WORKERS", HelperFunctions.default_workers()))
         pool, pending = None, []
         if workers > 1 and no_of_images >= 4:
             import multiprocessing as mp

@@ -238,6 +238,35 @@ def test_workflow_options_directories_follow_root_dir():
     assert o2.INPUT_DIR_IMAGES == o.INPUT_DIR_IMAGES and o2.OUTPUT_DIR_UNET == "/x/y"
 
 
+def test_worker_defaults_follow_the_cgroup_cpu_quota(monkeypatch):
+    """A container on a many-core host: os.cpu_count() shows the host, the cgroup quota is what the processes get (16 CPUs of 256 on
+    the MI355X boxes).  usable_cores() = min(affinity, quota); the worker pools take one less."""
+    import builtins
+    import io
+    HF = importlib.import_module(BASE + ".HelperFunctions")
+    real_open = builtins.open
+    state = {"text": "300000 100000\n"}
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            if state["text"] is None:
+                raise FileNotFoundError(path)
+            return io.StringIO(state["text"])
+        if str(path).startswith("/sys/fs/cgroup/cpu/"):
+            raise FileNotFoundError(path)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert HF.usable_cores() == 3 and HF.default_workers() == 2
+    state["text"] = "max 100000\n"
+    assert HF.usable_cores() == 64 and HF.default_workers() == 32 and HF.default_workers(16) == 16
+    state["text"] = None
+    assert HF.usable_cores() == 64
+    state["text"] = "50000 100000\n"          # half a CPU: still one process
+    assert HF.usable_cores() == 1 and HF.default_workers() == 1
+
+
 def test_activation_storage_option_reaches_both_trainers(tmp_path):
     """ACTIVATION_STORAGE (not in the reference) is handed to the CycleGAN and MultiResUNet trainers; the default is fp32 storage."""
     SP = importlib.import_module(BASE + ".StartProcess")

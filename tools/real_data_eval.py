@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--steps", default="0,1,2,3,4,5,6a,6b")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--score-workers", type=int, default=16)
+    ap.add_argument("--score-workers", type=int, default=15)
     ap.add_argument("--no-instance-scores", action="store_true")
     a = ap.parse_args()
     import random

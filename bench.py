@@ -23,6 +23,7 @@ import argparse
 import importlib
 import json
 import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")          # before the HIP runtime initialises (see _lib.py)
 import statistics
 import sys
 import time

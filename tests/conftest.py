@@ -1,4 +1,5 @@
 import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")          # before the HIP runtime initialises (see _lib.py)
 import sys
 
 import pytest

@@ -119,6 +119,10 @@ class Workflow:
 
     def __init__(self, options=None, **overrides):
         self.o = options if options is not None else WorkflowOptions(**overrides)
+        # host-side torch ops (conversions, the loaders' arrays): no more OpenMP threads than this process may use (a container's CPU
+        # quota is not what torch sees: 256 threads on a 16-CPU quota only get throttled)
+        import torch
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), HelperFunctions.usable_cores())))
 
     def _cyclegan(self):
         o = self.o

@@ -187,9 +187,11 @@ class UNetModel:
         self._graphs = {}          # (n, h, w) -> eager step count (int, warm-up) or the captured state (dict)
 
     def _to_act(self, t):
+        from .engine import convert
+        if isinstance(t, Act):          # already on the device (as CycleGanModel accepts them)
+            return convert(t, self.act_dtype)
         if isinstance(t, np.ndarray):
             t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
-        from .engine import convert
         return convert(Act(t.to(self.device, dtype=torch.float32).contiguous(), requires_grad=False), self.act_dtype)
 
     GRAPH_WARMUP_STEPS = 2

@@ -121,3 +121,6 @@ def test_trainers_build_their_networks_with_the_requested_activation_storage(tmp
     mu = um.train_step((x.numpy(), y.numpy()))
     assert all(np.isfinite(float(v)) for v in mu.values()), mu
     assert um.predict(x.numpy()).dtype == torch.float32
+    E = importlib.import_module(BASE + ".engine")          # device-resident batches, as CycleGanModel.train_step takes them
+    on_dev = tuple(E.Act(t.to(un.device).contiguous(), requires_grad=False) for t in (x, y))
+    assert all(np.isfinite(float(v)) for v in um.train_step(on_dev).values())

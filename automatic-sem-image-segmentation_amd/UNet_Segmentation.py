@@ -11,6 +11,7 @@ Reference surface mirrored here (file:line in the reference):
 import json
 import os
 import random
+import threading
 import time
 
 import numpy as np
@@ -42,7 +43,7 @@ class ImageDataset:
         # decoded tiles by (path, kind): every file is read under four flip ids per epoch, for UNET_EPOCHS epochs, and decoding one
         # (PIL + two percentiles) costs ~3 ms -- 30 ms per batch of 5 against a ~12 ms train step.  Bounded (SS_LOADER_CACHE_MB, 0 = off);
         # what does not fit is decoded every time, as in the reference.  Masks are kept as uint8 (they are 0 / 1 after the threshold).
-        self._cache, self._cache_bytes = {}, 0
+        self._cache, self._cache_bytes, self._cache_lock = {}, 0, threading.Lock()
         self.cache_limit_bytes = int(float(os.environ.get("SS_LOADER_CACHE_MB", "2048")) * 2 ** 20)
 
     def add_image(self, image_id, path, mask, augmentation):
@@ -83,9 +84,10 @@ class ImageDataset:
         if tile is None:
             tile = self._decode(info, is_mask)
             keep = tile.astype(np.uint8) if is_mask and tile.min() >= 0 and tile.max() <= 1 and np.all(tile == np.rint(tile)) else tile
-            if self._cache_bytes + keep.nbytes <= self.cache_limit_bytes:          # threads may decode a tile twice; either copy will do
-                keep.setflags(write=False)
-                if self._cache.setdefault(key, keep) is keep:
+            keep.setflags(write=False)
+            with self._cache_lock:          # the prefetching threads may have decoded the same tile twice: the first copy stays
+                if key not in self._cache and self._cache_bytes + keep.nbytes <= self.cache_limit_bytes:
+                    self._cache[key] = keep
                     self._cache_bytes += keep.nbytes
         return tile
 

@@ -413,7 +413,7 @@ def _warp_affine(src, m, dsize):
     width, height = dsize
     full = np.vstack([m, [0.0, 0.0, 1.0]])
     inv = np.linalg.inv(full)
-    ys, xs = np.mgrid[0:height, 0:width].astype(np.float64)
+    xs, ys = np.arange(width, dtype=np.float64)[None, :], np.arange(height, dtype=np.float64)[:, None]          # broadcast: one row, one column
     sx = inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]
     sy = inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]
     out = ndimage.map_coordinates(src.astype(np.float64), [sy, sx], order=1, mode='constant', cval=0.0)

@@ -167,6 +167,36 @@ def test_unet_feeders_match_reference(feed, tmp_path, cache_bytes):
             assert not ds._cache
 
 
+def test_unet_loader_prefetched_by_threads_returns_the_serial_batches(feed, tmp_path):
+    """What run_training does with USE_DATALOADER: batches decoded ahead by worker threads that share the dataset's tile cache -- the
+    batches of the plain loop, in order, and the cache accounts for every tile exactly once."""
+    from PIL import Image
+    UN = importlib.import_module(f"{BASE}.UNet_Segmentation")
+    HF = importlib.import_module(f"{BASE}.HelperFunctions")
+    idir, mdir = str(tmp_path / "imgs"), str(tmp_path / "masks")
+    os.makedirs(idir), os.makedirs(mdir)
+    for nme, im, mk in zip(feed["un/names"], feed["un/imgs"], feed["un/masks"]):
+        Image.fromarray(im).save(os.path.join(idir, str(nme)))
+        Image.fromarray(mk).save(os.path.join(mdir, str(nme)))
+
+    def loader():
+        ds = UN.ImageDataset(idir, mdir)
+        ds.initialize_images("train")
+        return ds, UN.DataLoader(ds, batch_size=3, shuffle=False)
+
+    _, plain = loader()
+    want = [plain[i] for i in range(len(plain))]
+    ds, ld = loader()
+    for _ in range(3):          # three "epochs": the first fills the cache from four threads at once
+        got = list(HF.prefetch(ld.__getitem__, range(len(ld)), depth=6, workers=4))
+        assert len(got) == len(want)
+        for (x, y), (xw, yw) in zip(got, want):
+            np.testing.assert_array_equal(x, xw)
+            np.testing.assert_array_equal(y, yw)
+    files = {ds.image_info[i]["image_path"] for i in ds.image_ids}
+    assert len(ds._cache) == 2 * len(files) and ds._cache_bytes == sum(t.nbytes for t in ds._cache.values())
+
+
 def test_unet_dataset_matches_reference(feed):
     UN = importlib.import_module(f"{BASE}.UNet_Segmentation")
     ds = UN.DataSet(feed["ds/x"].copy(), feed["ds/y"].copy(), batch_size=4, shuffle=True)

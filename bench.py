@@ -9,13 +9,18 @@ global batch of synthetic SEM tiles (BASELINE.json metric: train_step tiles/sec,
 Prints ONE JSON line on rank 0.  Every number in it is measured by THIS run (or, for `roofline.traffic`, read from the committed
 rocprofv3 PMC summary `profiles/pmc_traffic.json` that `tools/pmc_traffic.py` produces from this same command, and labelled so):
 
-  value / ms_per_step  -- the K timed steps (barrier + synchronize on both sides, max over ranks); `median_ms_per_step` beside it
-  cyclegan / unet      -- each trainer timed alone in further steps of the same process; `combined` = 1/(1/a + 1/b)
+  value / ms_per_step  -- the K timed steps (barrier + synchronize on both sides, max over ranks); `median_ms_per_step` beside it.
+                          The line holds flat scalars and short strings only; per-kernel tables and per-leg details go to the
+                          file named by `tables_path` (default profiles/bench_tables_last.json)
+  cyclegan_ms / unet_ms / unet_hbm_frac -- each trainer timed alone in further steps of the same process
+  per_gpu_share_ms / scaling_cap        -- the same models on ONE tile (what each GPU of an 8-GPU run computes per step);
+                          scaling_cap = median_ms_per_step / per_gpu_share_ms bounds the data-parallel speed-up
   roofline             -- dominant CONTRACTION kernel class of the step: EXECUTED matrix-instruction FLOPs (every piece product of
                           the operand splits) / HIP-event time of those launches (ss_prof_*: events on the launch stream, steps run
-                          on one stream) / dense peak of the instruction the kernel issues; `kernels` lists every instrumented class
-  arithmetic_modes     -- the same step under the two stricter arithmetic modes (x3h = 0: exact 3-piece bf16 split, 6 products;
-                          x6 = 0: fp32 MFMA instructions only)
+                          on one stream) / dense peak of the instruction the kernel issues; the legs' scalars are repeated inside
+                          it; every instrumented class is in the tables file (`roofline_kernels`, `hbm_bound_kernels`)
+  tiles_per_s_x6_exact / tiles_per_s_fp32_mfma -- the same step under the two stricter arithmetic modes (x3h = 0: exact 3-piece
+                          bf16 split, 6 products; x6 = 0: fp32 MFMA instructions only)
   cpu_baseline         -- the oracle (plain-torch CPU restatement of the same two steps) on the host cores, warm, median of the
                           timed steps, on a bounded sample (rank 0, N=1 only).  Reported baseline only.
 """
@@ -86,11 +91,9 @@ def cpu_baseline(size, batch, filters, threads, timed):
         t_un.append(t2 - t1)
     m_cg, m_un = statistics.median(t_cg), statistics.median(t_un)
     return {"value": round(batch / (m_cg + m_un), 5), "unit": "tiles/s", "cores": threads, "host_threads": os.cpu_count(),
-            "cores_note": f"{threads} of the host's {os.cpu_count()} hardware threads (torch CPU convolutions get slower beyond ~16 threads on this host)",
-            "kind": "port",
-            "role": "reported baseline only (not a target): plain-torch CPU fp32 restatement of the same two train steps",
-            "sample": f"oracle CycleGAN+UNet train steps on {batch} synthetic {size}x{size} tile(s), filters={filters}: 1 warm-up step on "
-                      f"{max(size // 2, 64)}x{max(size // 2, 64)} + {timed} timed steps, median; cyclegan {m_cg:.2f}s + unet {m_un:.2f}s"}
+            "kind": "port", "cyclegan_s": round(m_cg, 2), "unet_s": round(m_un, 2),
+            "role": "reported baseline only: plain-torch CPU fp32 restatement (oracle/) of the two train steps",
+            "sample": f"{batch} tile {size}x{size}, F={filters}: 1 warm-up at {max(size // 2, 64)}px + {timed} timed steps, median"}
 
 
 def kernel_peak(name):
@@ -131,6 +134,8 @@ def main():
     ap.add_argument("--cpu-timed-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-rccl-smoke", action="store_true", help="do not run the 2-rank RCCL smoke when >= 2 GPUs are visible to a 1-GPU run")
+    ap.add_argument("--no-share-leg", action="store_true", help="skip the per_gpu_share leg (the same models on one tile)")
+    ap.add_argument("--tables", default=None, help="where the per-kernel tables go (default: profiles/bench_tables_last.json)")
     ap.add_argument("--skip-unet", action="store_true", help="diagnostics only: time the CycleGAN step alone")
     ap.add_argument("--only-unet", action="store_true", help="diagnostics only: time the UNet step alone")
     args = ap.parse_args()
@@ -198,7 +203,10 @@ def main():
     # then -- measured 34.1 - 35.1 ms per UNet step against 36.6 - 36.9 on streams of its own created after them; beside the CycleGAN
     # step it takes streams apart from the chains')
 
-    def step(cyclegan=not args.only_unet, unet_=not args.skip_unet, overlap=overlap_unet):
+    full_inputs = (a, b, ux, uy)
+
+    def step(cyclegan=not args.only_unet, unet_=not args.skip_unet, overlap=overlap_unet, inputs=None):
+        a, b, ux, uy = inputs if inputs is not None else full_inputs
         if overlap and cyclegan and unet_:
             # CycleGAN first (GPU-paced: its kernels outlast its issue), the UNet step -- host-paced at per-GPU batch 1: 12 ms to issue
             # 11 ms of kernels -- is issued BEHIND it on a stream of its own, so the host issues it while the GPU still works on the
@@ -284,6 +292,20 @@ def main():
                           "algorithmic_bytes_per_tile": ub, "achieved_TBps_per_gpu": round(un_tps * ub / 1e12 / world, 4),
                           "hbm_frac": round(un_tps * ub / 1e12 / world / PEAK_HBM_TBPS, 4)}
         extras["combined"] = {"tiles_per_s": round(1.0 / (1.0 / cg_tps + 1.0 / un_tps), 3), "formula": "1/(1/cyclegan + 1/unet)"}
+        if world == 1 and per > 1 and not args.no_share_leg:
+            # per_gpu_share: the SAME models on ONE tile = what each GPU of an 8-GPU run of this global batch computes per step (no
+            # communication).  ms_per_step / per_gpu_share_ms bounds the speed-up data parallelism can reach: the only proxy for the
+            # multi-GPU curve a 1-GPU box can time.
+            one = tuple(E.Act(t_.t[:1].contiguous(), requires_grad=False) for t_ in full_inputs)
+            for _ in range(3):
+                step(inputs=one)
+            _, sh_t = timed(10, inputs=one)
+            _, sh_cg = timed(3, cyclegan=True, unet_=False, inputs=one)
+            _, sh_un = timed(3, cyclegan=False, unet_=True, inputs=one)
+            extras["per_gpu_share"] = {"per_gpu_batch": 1, "median_ms_per_step": round(statistics.median(sh_t) * 1e3, 3), "steps": 10, "warmup": 3,
+                                       "cyclegan_ms": round(statistics.median(sh_cg) * 1e3, 3), "unet_ms": round(statistics.median(sh_un) * 1e3, 3)}
+            for _ in range(2):
+                step()          # back on the full batch (allocator pools, caches)
         if world == 1:
             step(overlap=True)
             tot, ov_t = timed(k, overlap=True)
@@ -341,25 +363,45 @@ def main():
         value = GB * args.steps / elapsed
         x6, x3h = L.config_get("x6"), L.config_get("x3h")
         store = {"f32": "f32", "bf16": "bf16", "f16": "f16"}[args.dtype]
-        arith = (store + " activation storage" + ("" if store == "f32" else " (fp32 master weights, statistics and accumulation; "
-                 "tile kernels, the Winograd trunk (one fp16 plane per operand, one product in forward / data gradient; weight gradient on the x3h planes), the strided / transposed / 4x4 gather kernels and the one-channel 7x7 layers read and write the stored type; the discriminators' stem data gradient and 512 -> 1 head run on fp32 staging copies)") + " + f32 accumulate; contractions on the 16-bit matrix cores with fp32-grade operand splits: "
-                 + ("x3h = 2 fp16 pieces under power-of-two scales (per tile in the Winograd GEMMs, per tensor elsewhere), 3 products"
-                    if x3h else "x6 = exact 3-piece bf16 split, 6 products")) if x6 else "f32 everywhere (v_mfma_f32_32x32x2_f32)"
         what = "CycleGAN+UNet" if not (args.only_unet or args.skip_unet) else ("UNet" if args.only_unet else "CycleGAN")
+        # ONE compact line: flat scalars and short strings only (the driver's record keeps scalars; everything tabular -- per-kernel
+        # rooflines, the arithmetic string, per-leg details -- goes to `tables_path`)
         out = {"metric": f"train_step tiles/sec ({what})", "value": round(value, 4), "unit": "tiles/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "median_ms_per_step": round(median_ms, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": (store + " storage, " if store != "f32" else "") + ("f32" if not x6 else ("f32 via 2xf16 split (x3h)" if x3h else "f32 via 3xbf16 split (x6)")),
-               "arithmetic": arith, "data": "synthetic",
-               "config": {"workload": f"CycleGAN(2xResNet-9 gen F={F} + 2xPatchGAN, image buffer 50) train_step + MultiResUNet(16) "
-                                      f"train_step, {S}x{S} grayscale tiles, global batch {GB}" + (" [CycleGAN only]" if args.skip_unet else "")
-                                      + (" [UNet only]" if args.only_unet else ""),
+               "data": "synthetic",
+               "config": {"workload": f"CycleGAN+MultiResUNet train_step, {S}x{S} tiles, global batch {GB}, F={F}"
+                                      + (" [CycleGAN only]" if args.skip_unet else "") + (" [UNet only]" if args.only_unet else ""),
                           "tile": S, "global_batch": GB, "per_gpu_batch": per, "parallelism": f"dp{world}", "baseline_config": args.config,
                           "activation_storage": store, "checkpointed_trunk": bool(args.checkpoint)}}
-        out.update(extras)
+        tables = {"arithmetic": (store + " activation storage, f32 accumulate; contractions on the 16-bit matrix cores with fp32-grade operand splits: "
+                                 + ("x3h = 2 fp16 pieces under power-of-two scales, 3 products" if x3h else "x6 = exact 3-piece bf16 split, 6 products"))
+                                if x6 else "f32 everywhere (v_mfma_f32_32x32x2_f32)"}
+        tables.update(extras)
+        flat = {}
+        if "cyclegan" in extras:
+            flat.update(cyclegan_ms=extras["cyclegan"]["median_ms_per_step"], unet_ms=extras["unet"]["median_ms_per_step"],
+                        unet_hbm_frac=extras["unet"]["hbm_frac"], combined_tiles_per_s=extras["combined"]["tiles_per_s"])
+        if "overlapped" in extras:
+            flat["overlapped_tiles_per_s"] = extras["overlapped"]["tiles_per_s"]
+        am = extras.get("arithmetic_modes") or {}
+        if "x6_exact_bf16_split_6_products" in am:
+            flat["tiles_per_s_x6_exact"] = am["x6_exact_bf16_split_6_products"]["tiles_per_s"]
+        if "fp32_mfma_instructions_only" in am:
+            flat["tiles_per_s_fp32_mfma"] = am["fp32_mfma_instructions_only"]["tiles_per_s"]
+        if "per_gpu_share" in extras:
+            sh = extras["per_gpu_share"]
+            flat.update(per_gpu_share_ms=sh["median_ms_per_step"], per_gpu_share_cyclegan_ms=sh["cyclegan_ms"], per_gpu_share_unet_ms=sh["unet_ms"],
+                        scaling_cap=round(median_ms / sh["median_ms_per_step"], 3))
+        if "multi_gpu" in extras:
+            flat.update(exposed_comm_ms_per_step=extras["multi_gpu"]["exposed_comm_ms_per_step"],
+                        ms_per_step_without_collectives=extras["multi_gpu"]["median_ms_per_step_without_collectives"])
         if rccl_smoke is not None:
-            out["rccl_smoke_2_ranks"] = rccl_smoke
+            tables["rccl_smoke_2_ranks"] = rccl_smoke
+            flat["rccl_smoke_rc"] = rccl_smoke.get("rc")
+        roof = None
         if prof:
             table, hbm = {}, {}
             for name, e in prof.items():
@@ -374,80 +416,92 @@ def main():
                 pk = kernel_peak(name)
                 ach = e["flops"] / sec / 1e12 if sec > 0 else 0.0
                 table[name] = {"launches": e["launches"], "avg_ms": round(e["avg_ms"], 4), "total_ms_per_step": round(e["total_ms"] / 2, 3),
-                               "executed_tflop_per_launch": round(e["flops"] / e["launches"] / 1e12, 5), "achieved": round(ach, 1),
+                               "executed_tflop_per_launch": round(e["flops"] / e["launches"] / 1e12, 5),
+                               "algorithmic_MB_per_launch": round(e["bytes"] / e["launches"] / 1e6, 1), "achieved": round(ach, 1),
                                "peak": PEAK_TFLOPS[pk], "instruction": pk, "frac": round(ach / PEAK_TFLOPS[pk], 4)}
                 if name.startswith(("tconv_kernel", "twgrad")):          # the MultiResUNet's small-channel layers: bound by HBM, not the matrix pipe
                     hbm[name] = hrow
-            dom = max(table, key=lambda n_: table[n_]["total_ms_per_step"])
-            d = table[dom]
-            traffic = None
-            tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("workload") == [S, GB, F, world]:
-                        kern = tj.get("kernels", {})
-                        # rocprofv3 spells the default template arguments out (gemm_x6p_kernel<2,false>), the ss_prof label does not
-                        stem = dom[:-1] if dom.endswith(">") else dom
-                        traffic = kern.get(dom) or next((v for k_, v in sorted(kern.items()) if k_.startswith(stem + ",")), None)
-                except Exception:
-                    traffic = None
-            # what the matrix pipe of THIS box delivers on real data (the chip clocks to its power budget): a register-only MFMA stream on
-            # random fp16 operands, measured now (ss_probe_mfma) -- `frac` stays against the nominal peak of MI355X_MICROARCH.md
-            ceiling = None
+            tj = None
             try:
-                import ctypes
-                sc = torch.empty(65600, dtype=torch.uint8, device=dev)
-                tf, mhz = ctypes.c_double(0.0), ctypes.c_double(0.0)
-                tf0, mhz0 = ctypes.c_double(0.0), ctypes.c_double(0.0)
-                lib_ = L.load()
-                if lib_.ss_probe_mfma(1, sc.data_ptr(), sc.numel(), None, ctypes.byref(tf), ctypes.byref(mhz)) == 0 and \
-                        lib_.ss_probe_mfma(0, sc.data_ptr(), sc.numel(), None, ctypes.byref(tf0), ctypes.byref(mhz0)) == 0:
-                    ceiling = {"tflops_random_operands": round(tf.value, 1), "effective_mhz_random_operands": round(mhz.value),
-                               "tflops_zero_operands": round(tf0.value, 1), "effective_mhz_zero_operands": round(mhz0.value),
-                               "frac_of_nominal_peak": round(tf.value / d["peak"], 4),
-                               "dominant_kernel_frac_of_this_ceiling": round(d["achieved"] / tf.value, 4) if tf.value > 0 else None,
-                               "source": "ss_probe_mfma in this run: register-only v_mfma_f32_32x32x16_f16 stream on every CU, no memory traffic"}
-            except Exception as e:          # noqa: BLE001
-                ceiling = {"error": repr(e)}
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s",
-                               "frac": d["frac"], "avg_launch_ms": d["avg_ms"], "launches_timed": d["launches"],
-                               "real_data_ceiling": ceiling,
-                               "definition": "EXECUTED matrix-instruction FLOPs of the timed launches (all piece products of the operand "
-                                             "split, useful rows/columns only) / their HIP-event time (ss_prof_*, launch stream, "
-                                             "single-stream steps) / dense peak of the instruction the kernel issues",
-                               "traffic": traffic,
-                               "traffic_source": "profiles/pmc_traffic.json (tools/pmc_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / "
-                                                 "WRITE_SIZE passes of this command, gfx950 corrections of MI355X_MICROARCH.md), bytes per "
-                                                 "launch" if traffic is not None else None,
-                               "kernels": table}
+                tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+                if tj.get("workload") != [S, GB, F, world]:
+                    tj = None
+            except Exception:
+                tj = None
+            if table:
+                dom = max(table, key=lambda n_: table[n_]["total_ms_per_step"])
+                d = table[dom]
+                traffic = None
+                if tj is not None:
+                    kern = tj.get("kernels", {})
+                    # rocprofv3 spells the default template arguments out (gemm_x6p_kernel<2,false>), the ss_prof label does not
+                    stem = dom[:-1] if dom.endswith(">") else dom
+                    traffic = kern.get(dom) or next((v for k_, v in sorted(kern.items()) if k_.startswith(stem + ",")), None)
+                # what the matrix pipe of THIS box delivers on real data (the chip clocks to its power budget): a register-only MFMA stream
+                # on random fp16 operands, measured now (ss_probe_mfma) -- `frac` stays against the nominal peak of MI355X_MICROARCH.md
+                ceiling = None
+                try:
+                    import ctypes
+                    sc = torch.empty(65600, dtype=torch.uint8, device=dev)
+                    tf, mhz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+                    tf0, mhz0 = ctypes.c_double(0.0), ctypes.c_double(0.0)
+                    lib_ = L.load()
+                    if lib_.ss_probe_mfma(1, sc.data_ptr(), sc.numel(), None, ctypes.byref(tf), ctypes.byref(mhz)) == 0 and \
+                            lib_.ss_probe_mfma(0, sc.data_ptr(), sc.numel(), None, ctypes.byref(tf0), ctypes.byref(mhz0)) == 0:
+                        ceiling = {"tflops_random_operands": round(tf.value, 1), "effective_mhz_random_operands": round(mhz.value),
+                                   "tflops_zero_operands": round(tf0.value, 1), "effective_mhz_zero_operands": round(mhz0.value),
+                                   "frac_of_nominal_peak": round(tf.value / d["peak"], 4),
+                                   "dominant_kernel_frac_of_this_ceiling": round(d["achieved"] / tf.value, 4) if tf.value > 0 else None,
+                                   "source": "ss_probe_mfma in this run: register-only v_mfma_f32_32x32x16_f16 stream on every CU, no memory traffic"}
+                except Exception as e:          # noqa: BLE001
+                    ceiling = {"error": repr(e)}
+                tables["real_data_ceiling"] = ceiling
+                roof = {"bound": "mfma", "kernel": dom, "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s",
+                        "frac": d["frac"], "avg_launch_ms": d["avg_ms"], "launches_timed": d["launches"],
+                        "executed_gflop_per_launch": round(d["executed_tflop_per_launch"] * 1e3, 2),
+                        "algorithmic_bytes_per_launch": round(d["algorithmic_MB_per_launch"] * 1e6),
+                        "traffic": round(traffic["bytes_per_launch"]) if traffic else None,
+                        "traffic_bytes_per_launch": round(traffic["bytes_per_launch"]) if traffic else None,
+                        "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, own passes)" if traffic else None,
+                        "real_ceiling_tflops": (ceiling or {}).get("tflops_random_operands"),
+                        "definition": "executed MFMA FLOPs (all piece products) / HIP-event time on the launch stream / dense fp16 peak"}
+                tables["roofline_kernels"] = table
             if hbm:
                 # HBM traffic of the same kernel classes from the committed PMC passes (profiles/pmc_traffic.json: every template
                 # instantiation of a class, weighted by its launches), next to the algorithmic bytes: the ratio is what is re-read
-                try:
-                    tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
-                    if tj.get("workload") == [S, GB, F, world]:
-                        for name, row in hbm.items():
-                            stem = name.split("<")[0].split(" ")[0]
-                            if name.startswith(("tconv_kernel", "twgrad")):
-                                continue          # (their ss_prof labels carry tile shapes the counters' kernel names do not)
-                            sel = [v for k_, v in tj.get("kernels", {}).items() if k_.split("<")[0] == stem
-                                   and ("<normalising>" in name) == (",true," in k_ and stem == "wino_input_kernel")
-                                   and (("<fwd>" not in name) or "," + "0," in k_) and (("<bwd>" not in name) or "," + "1," in k_)]
-                            n_l = sum(v["launches"] for v in sel)
-                            if n_l:
-                                mb = sum(v["bytes_per_launch"] * v["launches"] for v in sel) / n_l / 1e6
-                                row["pmc_traffic_MB_per_launch"] = round(mb, 1)
-                                row["traffic_over_algorithmic"] = round(mb / row["algorithmic_MB_per_launch"], 3) if row["algorithmic_MB_per_launch"] else None
-                except Exception:
-                    pass
+                if tj is not None:
+                    for name, row in hbm.items():
+                        stem = name.split("<")[0].split(" ")[0]
+                        if name.startswith(("tconv_kernel", "twgrad")):
+                            continue          # (their ss_prof labels carry tile shapes the counters' kernel names do not)
+                        sel = [v for k_, v in tj.get("kernels", {}).items() if k_.split("<")[0] == stem
+                               and ("<normalising>" in name) == (",true," in k_ and stem == "wino_input_kernel")
+                               and (("<fwd>" not in name) or "," + "0," in k_) and (("<bwd>" not in name) or "," + "1," in k_)]
+                        n_l = sum(v["launches"] for v in sel)
+                        if n_l:
+                            mb = sum(v["bytes_per_launch"] * v["launches"] for v in sel) / n_l / 1e6
+                            row["pmc_traffic_MB_per_launch"] = round(mb, 1)
+                            row["traffic_over_algorithmic"] = round(mb / row["algorithmic_MB_per_launch"], 3) if row["algorithmic_MB_per_launch"] else None
                 tot_ms = sum(v["total_ms_per_step"] for v in hbm.values())
                 tot_b = sum(v["algorithmic_MB_per_launch"] * v["launches"] / 2 for v in hbm.values()) * 1e6
-                out["roofline"]["hbm_bound_kernels"] = {
+                tables["hbm_bound_kernels"] = {
                     "definition": "ALGORITHMIC bytes of the timed launches (each tensor the pass has to read or write, once) / their HIP-event "
                                   "time (same two single-stream steps) / 8 TB/s (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel reaches)",
                     "total_ms_per_step": round(tot_ms, 3), "achieved_TBps": round(tot_b / (tot_ms * 1e-3) / 1e12, 3) if tot_ms > 0 else None,
                     "frac": round(tot_b / (tot_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4) if tot_ms > 0 else None, "kernels": hbm}
+                if tot_ms > 0:
+                    flat.update(streaming_kernels_ms_per_step=round(tot_ms, 3), streaming_kernels_hbm_frac=tables["hbm_bound_kernels"]["frac"])
+        if roof is None and args.only_unet:
+            # UNet-only workloads (BASELINE config 2): the step is HBM-bound by design -- SURVEY 8(d)'s algorithmic bytes per tile over the step time
+            ub = UNET_BYTES_PER_TILE_512 * (S / 512.0) ** 2 * ({"f32": 1.0}.get(store, 0.5))
+            tb = value * ub / 1e12 / world
+            roof = {"bound": "hbm", "kernel": "MultiResUNet train step (whole step)", "achieved": round(tb * 1e3, 1), "peak": PEAK_HBM_TBPS * 1e3,
+                    "unit": "GB/s", "frac": round(tb / PEAK_HBM_TBPS, 4), "algorithmic_bytes_per_launch": round(ub * GB / world), "traffic": None,
+                    "definition": "SURVEY 8(d) activation bytes per tile (x0.5 for 16-bit storage) x tiles per step / step time / 8 TB/s"}
+        if roof is not None:
+            roof.update(flat)          # the driver's record keeps the scalars of `roofline`: the legs' figures travel there as well
+            out["roofline"] = roof
+        out.update(flat)
         if S in G_FWD_GF:
             alg = (0 if args.only_unet else 18 * G_FWD_GF[S] + 16 * D_FWD_GF[S]) + (0 if args.skip_unet else 3 * U_FWD_GF[S])
             out["algorithmic_tflops_per_gpu"] = round(alg * 1e9 * value / 1e12 / world, 2)   # SURVEY 8d direct-conv FLOPs, whole step
@@ -455,6 +509,13 @@ def main():
             # torch CPU convs on the 256-thread host get SLOWER beyond ~16 threads (measured: 256^2 tile 2.2 s @16, 3.0 s @32, 6.6 s @64)
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_size, args.cpu_sample_batch, F, min(os.cpu_count() or 1, args.cpu_threads),
                                                args.cpu_timed_steps)
+        tpath = args.tables or os.path.join(REPO, "profiles", "bench_tables_last.json")
+        try:
+            with open(tpath, "w") as f:
+                json.dump({"line": out, "tables": tables}, f, indent=1)
+            out["tables_path"] = os.path.relpath(tpath, REPO)
+        except OSError:
+            out["tables_path"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

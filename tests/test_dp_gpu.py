@@ -116,7 +116,7 @@ def test_bench_two_ranks_reports_per_rank_times_and_exposed_communication(tmp_pa
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29747", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2",
                SS_DIST_BACKEND="gloo", SS_BENCH_TEST_TRANSPORT="gloo")
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64", "--global-batch", "2",
-           "--filters", "8", "--no-cpu-baseline"]
+           "--filters", "8", "--no-cpu-baseline", "--tables", str(tmp_path / "tables.json")]
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                               cwd=REPO) for r in range(2)]
     outs = [p.communicate(timeout=900) for p in procs]
@@ -125,7 +125,10 @@ def test_bench_two_ranks_reports_per_rank_times_and_exposed_communication(tmp_pa
     line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["per_gpu_batch"] == 1 and j["value"] > 0
-    mg = j["multi_gpu"]
+    # the line itself is flat scalars (the driver's record keeps those); the per-rank table travels in the tables file
+    assert j["ms_per_step_without_collectives"] > 0 and "exposed_comm_ms_per_step" in j
+    assert not [k for k, v in j.items() if isinstance(v, dict) and k not in ("config", "roofline", "cpu_baseline")], "nested tables belong in tables_path"
+    mg = json.load(open(tmp_path / "tables.json"))["tables"]["multi_gpu"]
     assert len(mg["per_rank_median_ms_per_step"]) == 2 and all(v > 0 for v in mg["per_rank_median_ms_per_step"])
     assert mg["median_ms_per_step_without_collectives"] > 0 and "exposed_comm_ms_per_step" in mg
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")], "only rank 0 prints the result line"

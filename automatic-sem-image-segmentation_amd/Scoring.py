@@ -39,7 +39,7 @@ def instances(image):
     """The instances ``cv2.findContours(RETR_LIST)`` + ``drawContours(FILLED)`` yield (:74-82): every 8-connected foreground component
     FILLED, and -- RETR_LIST also returns the hole borders -- every hole (background region not connected to the image border, 4-
     connected) as an instance of its own.  Returns a list of (bounding-box slices, boolean patch, polygon area estimate): the
-    shoelace area of the border-pixel polygon is estimated with Pick's theorem (filled pixels - border pixels / 2 - 1)."""
+    shoelace area of the border-pixel polygon is counted from the unit cells it encloses (see below)."""
     fg = np.asarray(image) > 0
     out = []
     lab, n = ndimage.label(fg, structure=np.ones((3, 3)))
@@ -56,8 +56,14 @@ def instances(image):
         out.append((big, ndimage.binary_dilation(lab[big] == i, structure=np.ones((3, 3)))))
     res = []
     for sl, comp in out:
-        border = comp & ~ndimage.binary_erosion(comp, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]], border_value=0)
-        area = max(float(comp.sum()) - float(border.sum()) / 2.0 - 1.0, 0.0)
+        # Shoelace area of the polygon the 8-connected border following draws through the border PIXEL CENTRES (:139-151 on the contour's
+        # vertices), without tracing it: a unit cell between four pixel centres lies inside the polygon when all four pixels belong to the
+        # region, half of it when three do (the border cuts the concave corner diagonally), not at all otherwise -- so one-pixel-wide
+        # parts (a there-and-back border) contribute 0, as they do in the reference (checked against its polygon_area,
+        # tests/golden/make_scoring_goldens.py)
+        c = np.pad(comp, 1).astype(np.int8)
+        cells = c[:-1, :-1] + c[1:, :-1] + c[:-1, 1:] + c[1:, 1:]
+        area = float(np.count_nonzero(cells == 4)) + 0.5 * float(np.count_nonzero(cells == 3))
         res.append((sl, comp, area))
     return res
 

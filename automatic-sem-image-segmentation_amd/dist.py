@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-BUCKET_ELEMS = 16 * 1024 * 1024     # 64 MiB fp32 buckets
+BUCKET_ELEMS = 8 * 1024 * 1024      # 32 MiB fp32 buckets: the size engine.ParamArena.BUCKET_ELEMS cuts the gradient arenas into
 
 _SOLO = 0          # depth of `solo()` sections: this rank works alone, every collective of this module is skipped
 

@@ -16,9 +16,15 @@
  *    of a concatenated tensor: keras.layers.concatenate, UNet_Segmentation.py:469,542-551).
  *  - weights use the Keras variable layouts: Conv2D kernel (kh,kw,cin,cout), bias (cout);
  *    Conv2DTranspose kernel (kh,kw,cout,cin); norm gamma/beta (c).
- *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing
- *    and keeps no global mutable state; scratch comes from the caller (`ws`, size from the
- *    matching *_workspace_bytes()).
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*) and allocates nothing;
+ *    scratch comes from the caller (`ws`, size from the matching *_workspace_bytes()).
+ *  - process-wide state the library DOES keep (a deviation from "no global state", on purpose): the
+ *    kernel-selection table behind ss_config_set / ss_config_get (one table per process, NOT
+ *    synchronised -- set it from one thread while no call is in flight) and the opt-in profiling
+ *    recorder ss_prof_* (mutex-protected).  ss_last_error() is thread-local.  Nothing else persists
+ *    between calls: derived weight operands live in CALLER-owned ss_wcache buffers.
+ *  - the shared object exports exactly the entry points declared here (-fvisibility=hidden; the
+ *    declarations below are inside a `visibility push(default)` region).
  *  - return value: SS_OK or a negative ss_status; ss_status_string() names it.
  */
 #ifndef SEMSEG_HIP_H
@@ -29,6 +35,9 @@
 
 #ifdef __cplusplus
 extern "C" {
+#endif
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
 #endif
 
 typedef enum ss_status {
@@ -445,6 +454,9 @@ int ss_adam_keras(float* p, const float* g, float* m, float* v, int64_t count,
 int ss_adam_keras_dev(float* p, const float* g, float* m, float* v, int64_t count,
                       const float* alpha_dev, double beta_1, double beta_2, double epsilon, float grad_scale, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -233,3 +233,20 @@ def test_data_root_scoring_command_on_a_dataset_directory(tmp_path, capsys):
     assert 0.9 < res["iou_whole"] < 1.0 and res["best_threshold_whole_true"] in (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8)
     with pytest.raises(SystemExit):
         S.main(["--data-root", str(tmp_path / "nowhere"), "--predictions", str(pred_dir)])
+
+
+def test_scoring_matches_the_references_own_functions():
+    """Scoring.whole_image_iou / roc / the polygon-area estimate of Scoring.instances against `calculateWholeImageIoU`, `ROC` and
+    `polygon_area` EXECUTED from the reference (Calculate_Scores.py:69-70,107-151; tests/golden/make_scoring_goldens.py lifts the three
+    definitions out of the module's syntax tree and runs them on the committed inputs)."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scoring_goldens.npz"))
+    for k in range(int(z["n_pairs"])):
+        a, b = z[f"pair{k}_a"], z[f"pair{k}_b"]
+        assert float(SC.whole_image_iou(a, b)) == float(z[f"pair{k}_iou"]), k           # the same two integer sums: exact
+        assert np.array_equal(np.array(SC.roc(a, b), np.float64), z[f"pair{k}_roc"]), k
+    for i in range(int(z["n_shapes"])):
+        inst = SC.instances(z[f"shape{i}"])
+        assert len(inst) == 1
+        # the shoelace area of the border-pixel polygon, as the reference computes it from the contour vertices, against the cell
+        # count Scoring derives from pixel sets (no cv2 in the image) -- incl. a one-pixel speck and a one-pixel-wide line (area 0)
+        assert inst[0][2] == pytest.approx(float(z[f"shape{i}_area"]), abs=1e-9), (i, inst[0][2], float(z[f"shape{i}_area"]))

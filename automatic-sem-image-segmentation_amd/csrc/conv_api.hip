@@ -366,8 +366,9 @@ struct AmaxRef { const unsigned int* p; int stripes; };
 AmaxRef act_amax(const float* v, long rows, int C, int cs, unsigned int* ext, int ext_valid, unsigned int* scratch, hipStream_t s) {
     unsigned int* slot = ext ? ext : scratch;
     const int stripes = ext ? SS_AMAX_STRIPES : 1;
-    if (!(ext && ext_valid)) {
-        (void)hipMemsetAsync(slot, 0, ext ? (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4 : 4, s);
+    if (!(ext && ext_valid == 1)) {
+        // (valid == 2: the caller vouches that its slot is ZERO -- fresh from a zeroed pool: one memset dispatch less per scan)
+        if (!(ext && ext_valid == 2)) (void)hipMemsetAsync(slot, 0, ext ? (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4 : 4, s);
         launch_amax_view(v, rows, C, cs, slot, stripes, s);
     }
     return AmaxRef{slot, stripes};
@@ -376,8 +377,8 @@ AmaxRef act_amax(const float* v, long rows, int C, int cs, unsigned int* ext, in
 AmaxRef act_amax16(const void* v, int dtype, long rows, int C, int cs, unsigned int* ext, int ext_valid, unsigned int* scratch, hipStream_t s) {
     unsigned int* slot = ext ? ext : scratch;
     const int stripes = ext ? SS_AMAX_STRIPES : 1;
-    if (!(ext && ext_valid)) {
-        (void)hipMemsetAsync(slot, 0, ext ? (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4 : 4, s);
+    if (!(ext && ext_valid == 1)) {
+        if (!(ext && ext_valid == 2)) (void)hipMemsetAsync(slot, 0, ext ? (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4 : 4, s);
         const long work = rows * C / 4;
         const unsigned nb = (unsigned)(work / 4096 < 32 ? 32 : (work / 4096 > 1024 ? 1024 : work / 4096));
         if (dtype == SS_DTYPE_F16) hipLaunchKernelGGL(amax_view16_kernel<_Float16>, dim3(nb), dim3(256), 0, s, (const _Float16*)v, rows, C, cs, slot, stripes);
@@ -623,8 +624,8 @@ int conv_fwd(const ConvProb& c, const float* x, const float* w, const float* bia
         q.y_stats = c.y_stats;
         q.in_norm = c.in_norm;
         q.saved = c.saved;
-        if (c.in_norm.groups > 0 && c.x_amax && !c.x_valid && !(c.wc && c.wc->fill_only)) {      // the transform reports max|normalised x|
-            (void)hipMemsetAsync(c.x_amax, 0, (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4, s);
+        if (c.in_norm.groups > 0 && c.x_amax && c.x_valid != 1 && !(c.wc && c.wc->fill_only)) {      // the transform reports max|normalised x|
+            if (c.x_valid != 2) (void)hipMemsetAsync(c.x_amax, 0, (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4, s);
             q.in_norm.amax_out = c.x_amax;
         }
         return ss_wino_conv_fwd(q, x, w, c.cin, c.cout, 0, bias, y, act, alpha, accumulate, ws, ws_bytes, s);
@@ -882,7 +883,7 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
         if (wino_fwd_prob(c, algo, &q)) {
             q.in_norm = c.in_norm;
             q.saved = c.saved;
-            if (c.in_norm.groups > 0 && !(ss_wino_wgrad_tn(q) && c.x_amax && c.x_valid)) {
+            if (c.in_norm.groups > 0 && !(ss_wino_wgrad_tn(q) && c.x_amax && c.x_valid == 1)) {
                 ss_set_error("in_norm: the weight gradient needs the pre-split-plane path and the forward pass's max|normalised x| (x_amax, x_amax_valid)");
                 return SS_ERR_UNSUPPORTED;
             }

@@ -95,14 +95,18 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x
                                                          int act, float alpha,
                                                          int C, long P, long pix_per_chunk, int CT, int PT,
                                                          float* __restrict__ part,
-                                                         const float* __restrict__ rgamma = nullptr, const float* __restrict__ rbeta = nullptr) {
+                                                         const float* __restrict__ rgamma = nullptr, const float* __restrict__ rbeta = nullptr,
+                                                         int order = 0) {
     // MODE 1 with y == nullptr (relu / leaky relu without residual): the activation mask is recomputed from x with the forward's
     // expression (y > 0 <=> t > 0) -- one tensor read less in each of the two backward passes
     __shared__ float red[2 * V][256];
     const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;      // threads with pt >= PT (256 % CT leftovers) idle
     const int c = (blockIdx.y * CT + ct) * V;
-    const int g = blockIdx.z;
-    const long p0 = (long)blockIdx.x * pix_per_chunk;
+    // order & 1: the workgroups walk the tensor from its END (last group, last chunk first): what the kernel before this one wrote or
+    // read last is what the 256 MiB Infinity Cache still holds.  Same partials in the same slots: bit-identical results.
+    const int g = (order & 1) ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+    const int bx = (order & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const long p0 = (long)bx * pix_per_chunk;
     const long p1 = (p0 + pix_per_chunk < P) ? p0 + pix_per_chunk : P;
     float s1[V], s2[V];
 #pragma unroll
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x
             for (int k = 0; k < 2 * V; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + q * CT];
     }
     if (pt == 0 && c < C) {
-        float* o = part + (((long)g * gridDim.x + blockIdx.x) * C + c) * 2;
+        float* o = part + (((long)g * gridDim.x + bx) * C + c) * 2;
 #pragma unroll
         for (int v = 0; v < V; ++v) { o[2 * v] = red[2 * v][threadIdx.x]; o[2 * v + 1] = red[2 * v + 1][threadIdx.x]; }
     }
@@ -227,6 +231,54 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd(const float* __restrict
     }
 }
 
+// ---- consumer-side finalize (ss_config "norm_fuse_fin") ---------------------------------------------------------------------------
+// On mid-size tensors (per-GPU batch 1 - 2, 256 x 256 tiles) a norm pass is three ~10 us launches and the middle one -- the
+// finalize -- does almost nothing; a dependent dispatch costs ~10 us whoever issues it.  In fused mode the APPLY kernels reduce the
+// statistics partials of THEIR OWN channel block in a prologue: fixed order, fp64, no atomics, no cross-workgroup ordering (the
+// partials were written by the previous launch).  Every workgroup of a (group, channel block) repeats the same small sum (<= 128
+// chunks x <= 32 channels x 8 bytes = 32 KB from L2), so the geometry is chosen for it: narrow channel blocks, few chunks.  The
+// workgroup with blockIdx.x == 0 also publishes mean / rstd (the backward pass and deferred consumers read them), the BatchNorm
+// moving averages and, in backward, the parameter gradients (summed over the groups in group order).
+constexpr long NORM_FUSE_ELEMS = 8L << 20;
+constexpr int NORM_FUSE_CH = 32, NORM_FUSE_MAX_CHUNKS = 128, NORM_FUSE_EXT_CHUNKS = 256;
+
+struct NormFin {
+    const float* part;          // [G][chunks][C][2] partial sums; nullptr: not fused (mean / rstd / sums come finalized)
+    int chunks, G;
+    double P;                   // elements per (group, channel)
+    float eps, momentum;
+    float* mean; float* rstd;   // forward: published by the blockIdx.x == 0 workgroups
+    float* mm; float* mv;       // forward, BatchNorm: moving averages (G == 1)
+    float* dgamma; float* dbeta; int acc_params;          // backward: parameter gradients
+};
+
+// Totals (sum, sum2) of group `g` for the block's channels [c0, c0 + nch): thread t < nch returns them; red = LDS, 512 doubles.
+__device__ __forceinline__ void fin_block_totals(const float* __restrict__ part, int chunks, int g, int C, int c0, int nch,
+                                                 double* red /* LDS, 512 doubles */, double& T1, double& T2) {
+    const int KL = 256 / nch;
+    const int j = threadIdx.x % nch, kl = threadIdx.x / nch;
+    double s1 = 0.0, s2 = 0.0;
+    if (kl < KL && c0 + j < C) {
+        const float* b = part + (((long)g * chunks) * C + c0 + j) * 2;
+        for (int k = kl; k < chunks; k += 4 * KL) {          // four loads in flight, same k order
+            float2 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k + u * KL;
+                a[u] = kk < chunks ? *(const float2*)(b + (long)kk * C * 2) : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s1 += a[u].x; s2 += a[u].y; }
+        }
+    }
+    __syncthreads();          // (a previous use of red is over)
+    if (kl < KL) { red[kl * nch + j] = s1; red[256 + kl * nch + j] = s2; }
+    __syncthreads();
+    T1 = 0.0; T2 = 0.0;
+    if (threadIdx.x < nch)
+        for (int k = 0; k < KL; ++k) { T1 += red[k * nch + threadIdx.x]; T2 += red[256 + k * nch + threadIdx.x]; }
+}
+
 // y = act((x-mean)*rstd*gamma + beta + residual)
 // CHANNEL-STATIONARY threads: thread = V consecutive channels (lane ct of CT) x a strided set of the rows of ONE group; grid =
 // (row chunks, channel blocks, groups).  The per-channel operands (mean, rstd * gamma, beta) are loaded once and stay in registers:
@@ -234,25 +286,56 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd(const float* __restrict
 // vector-memory instruction rate, 3.7 TB/s on the trunk tensors and 1.7 TB/s on the odd-width MultiResUNet tensors), four rows are
 // in flight per thread.  Row chunks are handed out from the END (block 0 takes the last one): the statistics pass before this
 // kernel walked the tensor front to back, so its tail is what the 256 MiB Infinity Cache still holds.
-template <typename T, int V>
+template <typename T, int V, bool FIN = false>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x, int x_cs,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const T* __restrict__ res, int res_cs,
                                                          T* __restrict__ y, int y_cs,
                                                          int act, float alpha, int C, long P, int CT, int PT, long rows_per_chunk,
-                                                         unsigned int* __restrict__ amax = nullptr) {
+                                                         unsigned int* __restrict__ amax = nullptr, int order = 0,
+                                                         NormFin fin = NormFin{}) {
     const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
     const int c = (blockIdx.y * CT + ct) * V;
-    const int g = blockIdx.z;
+    const int g = (order & 2) ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;          // (order & 2: the groups from the end as well)
     const long p0 = (long)(gridDim.x - 1 - blockIdx.x) * rows_per_chunk;
     const long p1 = p0 + rows_per_chunk < P ? p0 + rows_per_chunk : P;
     float am = 0.f;
+    __shared__ double fred[FIN ? 512 : 1];
+    __shared__ float fstat[2][NORM_FUSE_CH];
+    if constexpr (FIN) {          // consumer-side finalize: mean / rstd of this block's channels from the statistics partials
+        const int c0 = blockIdx.y * CT * V, nch = CT * V;
+        double T1, T2;
+        fin_block_totals(fin.part, fin.chunks, g, C, c0, nch, fred, T1, T2);
+        if ((int)threadIdx.x < nch && c0 + (int)threadIdx.x < C) {
+            const int cc = c0 + threadIdx.x;
+            const double m = T1 / fin.P;
+            double var = T2 / fin.P - m * m;          // E[x^2] - E[x]^2 (keras.ops.moments, torch backend): norm_finalize_fwd's arithmetic
+            if (var < 0.0) var = 0.0;
+            const float muf = (float)m, rsf = (float)(1.0 / sqrt(var + (double)fin.eps));
+            fstat[0][threadIdx.x] = muf;
+            fstat[1][threadIdx.x] = rsf;
+            if (blockIdx.x == 0) {
+                fin.mean[(long)g * C + cc] = muf;
+                fin.rstd[(long)g * C + cc] = rsf;
+                if (fin.mm) {
+                    fin.mm[cc] = fin.mm[cc] * fin.momentum + muf * (1.f - fin.momentum);
+                    fin.mv[cc] = fin.mv[cc] * fin.momentum + (float)var * (1.f - fin.momentum);
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (c < C && pt < PT) {
         const long gi = (long)g * C + c;
         float mu[V], kk[V], bt[V], gm[V];
-        ldv<V>(mean + gi, mu);
-        ldv<V>(rstd + gi, kk);
+        if (FIN) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) { mu[v] = fstat[0][ct * V + v]; kk[v] = fstat[1][ct * V + v]; }
+        } else {
+            ldv<V>(mean + gi, mu);
+            ldv<V>(rstd + gi, kk);
+        }
         ldv<V>(beta + c, bt);
         if (gamma) {
             ldv<V>(gamma + c, gm);
@@ -363,7 +446,7 @@ __global__ __launch_bounds__(256) void norm_finalize_bwd(const float* __restrict
 
 // dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) ; dres = g.  Channel-stationary threads as norm_apply_kernel: the seven
 // per-channel operands live in registers (the flat form issued 8 + 2 V loads per vector for them).
-template <typename T, int V>
+template <typename T, int V, bool FIN = false>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ dy, int dy_cs,
                                                              const T* __restrict__ x, int x_cs,
                                                              const T* __restrict__ y, int y_cs,
@@ -376,7 +459,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              const float* __restrict__ rbeta = nullptr, unsigned int* __restrict__ amax = nullptr,
                                                              const double* __restrict__ rt = nullptr, int G = 0,
                                                              float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr,
-                                                             int acc_params = 0) {
+                                                             int acc_params = 0, int order = 0, NormFin fin = NormFin{}) {
     float am = 0.f;
     if (rt) {          // parameter gradients: the per-group totals of norm_finalize_bwd summed in group order (one thread per channel)
         const long nblk = (long)gridDim.x * gridDim.y * gridDim.z;
@@ -390,9 +473,35 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     }
     const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
     const int c = (blockIdx.y * CT + ct) * V;
-    const int g = blockIdx.z;
-    const long p0 = (long)(gridDim.x - 1 - blockIdx.x) * rows_per_chunk;
+    // order & 4: backward apply walks FORWARD (first group, first chunk first) -- the counterpart of a statistics pass that walked from the end
+    const int g = (order & 4) ? (int)blockIdx.z : ((order & 2) ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
+    const long p0 = (long)((order & 4) ? blockIdx.x : gridDim.x - 1 - blockIdx.x) * rows_per_chunk;
     const long p1 = p0 + rows_per_chunk < P ? p0 + rows_per_chunk : P;
+    __shared__ double fred[FIN ? 512 : 1];
+    __shared__ float fstat[2][NORM_FUSE_CH];
+    if constexpr (FIN) {          // consumer-side finalize: the means of g and g * xhat of this block's channels from the statistics partials
+        const int c0 = blockIdx.y * CT * V, nch = CT * V;
+        const bool mine = (int)threadIdx.x < nch && c0 + (int)threadIdx.x < C;
+        double T1, T2;
+        fin_block_totals(fin.part, fin.chunks, g, C, c0, nch, fred, T1, T2);
+        if (mine) { fstat[0][threadIdx.x] = (float)(T1 / fin.P); fstat[1][threadIdx.x] = (float)(T2 / fin.P); }
+        if (blockIdx.x == 0 && g == 0 && (fin.dgamma || fin.dbeta)) {
+            // parameter gradients: the groups' raw totals summed in group order (norm_finalize_bwd + the rt loop of the unfused form)
+            double tg = T1, tgx = T2;
+            for (int gg = 1; gg < fin.G; ++gg) {
+                double A, B;
+                fin_block_totals(fin.part, fin.chunks, gg, C, c0, nch, fred, A, B);
+                tg += A;
+                tgx += B;
+            }
+            if (mine) {
+                const int cc = c0 + threadIdx.x;
+                if (fin.dbeta) fin.dbeta[cc] = fin.acc_params ? fin.dbeta[cc] + (float)tg : (float)tg;
+                if (fin.dgamma) fin.dgamma[cc] = fin.acc_params ? fin.dgamma[cc] + (float)tgx : (float)tgx;
+            }
+        }
+        __syncthreads();
+    }
     if (c < C && pt < PT) {
         const long gi = (long)g * C + c;
         float mu[V], rs[V], gm[V], bt[V], sm[2 * V];
@@ -401,8 +510,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
 #pragma unroll
         for (int v = 0; v < V; ++v) { gm[v] = 1.f; bt[v] = 0.f; }
         if (gamma) ldv<V>(gamma + c, gm);
+        if (FIN) {
 #pragma unroll
-        for (int v = 0; v < V; ++v) { sm[2 * v] = sums[(gi + v) * 2]; sm[2 * v + 1] = sums[(gi + v) * 2 + 1]; }
+            for (int v = 0; v < V; ++v) { sm[2 * v] = fstat[0][ct * V + v]; sm[2 * v + 1] = fstat[1][ct * V + v]; }
+        } else {
+#pragma unroll
+            for (int v = 0; v < V; ++v) { sm[2 * v] = sums[(gi + v) * 2]; sm[2 * v + 1] = sums[(gi + v) * 2 + 1]; }
+        }
         const bool recompute = act != SS_ACT_NONE && y == nullptr;          // mask recomputed from x (see norm_stats_kernel)
         const bool from_y = act != SS_ACT_NONE && y != nullptr;
         if (recompute) ldv<V>(rbeta + c, bt);
@@ -754,6 +868,45 @@ inline ApplyGeom apply_geom(const NormGeom& g, int V) {
     a.grid = dim3((unsigned)chunks, (unsigned)cblocks, (unsigned)g.G);
     return a;
 }
+// geometry of the fused-finalize form (see NormFin): channel blocks of <= NORM_FUSE_CH channels, <= NORM_FUSE_MAX_CHUNKS pixel chunks
+struct FuseGeom { bool ok; int CT, PT, cblocks, chunks; long pix_per_chunk; };
+inline FuseGeom fuse_geom(const ss_norm_desc* d, int V) {
+    FuseGeom f{};
+    if (!ss_tuning().norm_fuse_fin) return f;
+    const int G = d->groups;
+    const long P = (long)d->n * d->h * d->w / G;
+    if ((long)d->n * d->h * d->w * d->c > NORM_FUSE_ELEMS) return f;
+    const int cv = (d->c + V - 1) / V, lanes_max = NORM_FUSE_CH / V;
+    f.cblocks = (cv + lanes_max - 1) / lanes_max;
+    f.CT = (cv + f.cblocks - 1) / f.cblocks;
+    f.PT = 256 / f.CT;
+    long chunks = 512 / ((long)G * f.cblocks);                 // ~512 workgroups in the statistics pass ...
+    if (chunks > NORM_FUSE_MAX_CHUNKS) chunks = NORM_FUSE_MAX_CHUNKS;
+    const long maxc = P / (4L * f.PT);                         // ... of at least four rows per thread
+    if (chunks > maxc) chunks = maxc;
+    if (chunks < 1) chunks = 1;
+    f.pix_per_chunk = (P + chunks - 1) / chunks;
+    f.chunks = (int)((P + f.pix_per_chunk - 1) / f.pix_per_chunk);
+    f.ok = true;
+    return f;
+}
+inline ApplyGeom apply_geom_fused(const NormGeom& g, const FuseGeom& f) {
+    ApplyGeom a;
+    a.CT = f.CT;
+    a.PT = f.PT;
+    long want = 1024 / ((long)g.G * f.cblocks);              // every workgroup repeats the finalize prologue: fewer, longer ones
+    if (want < 1) want = 1;
+    const long sweep = 4L * a.PT;
+    long maxchunks = (g.P + 4 * sweep - 1) / (4 * sweep);
+    if (maxchunks < 1) maxchunks = 1;
+    long chunks = want < maxchunks ? want : maxchunks;
+    long rpc = (g.P + chunks - 1) / chunks;
+    rpc = (rpc + a.PT - 1) / a.PT * a.PT;
+    chunks = (g.P + rpc - 1) / rpc;
+    a.rows_per_chunk = rpc;
+    a.grid = dim3((unsigned)chunks, (unsigned)f.cblocks, (unsigned)g.G);
+    return a;
+}
 inline unsigned apply_grid(long total) {
     long b = (total + 255) / 256;
     const long cap = 256L * 32;
@@ -826,7 +979,40 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     const float* part = (const float*)ws;
     int chunks = g.chunks;
     const double elems = (double)g.G * g.P * g.C;
-    if (d->x_stats && d->x_stats_chunks > 0) {
+    const bool ext_stats = d->x_stats && d->x_stats_chunks > 0;
+    const FuseGeom fz = y ? fuse_geom(d, V) : FuseGeom{};
+    if (fz.ok && (!ext_stats || d->x_stats_chunks * (d->n / g.G) <= NORM_FUSE_EXT_CHUNKS)) {
+        // consumer-side finalize: [statistics with the fused geometry ->] apply, which reduces the partials of its own channels
+        if (ext_stats) {
+            part = (const float*)d->x_stats;
+            chunks = d->x_stats_chunks * (d->n / g.G);
+        } else {
+            const dim3 sgrid(fz.chunks, fz.cblocks, g.G);
+            chunks = fz.chunks;
+            SsProfScope prof("norm_stats_kernel<fwd>", 0.0, elems * sizeof(T), s);
+            if (V == 4)
+                hipLaunchKernelGGL((norm_stats_kernel<T, 0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                                   0, 0.f, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, (float*)ws);
+            else
+                hipLaunchKernelGGL((norm_stats_kernel<T, 0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                                   0, 0.f, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, (float*)ws);
+            SS_LAUNCH_CHECK();
+        }
+        const ApplyGeom ag = apply_geom_fused(g, fz);
+        NormFin fin{};
+        fin.part = part; fin.chunks = chunks; fin.G = g.G; fin.P = (double)g.P; fin.eps = d->eps; fin.momentum = momentum;
+        fin.mean = mean; fin.rstd = rstd; fin.mm = moving_mean; fin.mv = moving_var;
+        SsProfScope prof("norm_apply_kernel", 0.0, elems * sizeof(T) * (residual ? 3 : 2), s);
+        if (V == 4)
+            hipLaunchKernelGGL((norm_apply_kernel<T, 4, true>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                               residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam, 0, fin);
+        else
+            hipLaunchKernelGGL((norm_apply_kernel<T, 1, true>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
+                               residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam, 0, fin);
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+    }
+    if (ext_stats) {
         // the producing convolution's epilogue already summed x and x^2 ([n][chunks][c][2]; groups = 1: the samples' chunks follow
         // one another, i.e. n * chunks chunks of the one group)
         part = (const float*)d->x_stats;
@@ -851,10 +1037,10 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     SsProfScope prof("norm_apply_kernel", 0.0, elems * sizeof(T) * (residual ? 3 : 2), s);          // read x (+ residual), write y
     if (V == 4)
         hipLaunchKernelGGL((norm_apply_kernel<T, 4>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam);
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam, ss_tuning().norm_order);
     else
         hipLaunchKernelGGL((norm_apply_kernel<T, 1>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam);
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam, ss_tuning().norm_order);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -872,10 +1058,10 @@ int norm_apply_t(const ss_norm_desc* d, const T* x, const float* gamma, const fl
     SsProfScope prof("norm_apply_kernel", 0.0, (double)g.G * g.P * g.C * sizeof(T) * (residual ? 3 : 2), s);
     if (V == 4)
         hipLaunchKernelGGL((norm_apply_kernel<T, 4>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam);
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam, ss_tuning().norm_order);
     else
         hipLaunchKernelGGL((norm_apply_kernel<T, 1>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
-                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam);
+                           residual, d->res_cstride, y, d->y_cstride, d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, yam, ss_tuning().norm_order);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -925,16 +1111,46 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
     }
     float* part = (float*)ws;
     float* sums = (float*)((char*)ws + part_bytes(d));
-    const dim3 sgrid(g.chunks, g.cblocks, g.G);
     const double elems = (double)g.G * g.P * g.C;
+    const FuseGeom fz = fuse_geom(d, V);
+    if (fz.ok) {          // consumer-side finalize: statistics with the fused geometry -> apply, which reduces the partials of its own channels
+        const dim3 fgrid(fz.chunks, fz.cblocks, g.G);
+        {
+            SsProfScope prof("norm_stats_kernel<bwd>", 0.0, elems * sizeof(T) * (use_y ? 3 : 2), s);
+            if (V == 4)
+                hipLaunchKernelGGL((norm_stats_kernel<T, 1, 4>), fgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+                                   d->act, d->act_alpha, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, part, gamma, beta, 0);
+            else
+                hipLaunchKernelGGL((norm_stats_kernel<T, 1, 1>), fgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+                                   d->act, d->act_alpha, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, part, gamma, beta, 0);
+            SS_LAUNCH_CHECK();
+        }
+        const ApplyGeom ag = apply_geom_fused(g, fz);
+        NormFin fin{};
+        fin.part = part; fin.chunks = fz.chunks; fin.G = g.G; fin.P = (double)g.P;
+        fin.dgamma = dgamma; fin.dbeta = dbeta; fin.acc_params = accumulate_params;
+        SsProfScope prof("norm_bwd_apply_kernel", 0.0,
+                         elems * sizeof(T) * ((use_y ? 3 : 2) + 1 + (accumulate_dx ? 1 : 0) + (dres ? (accumulate_dres ? 2 : 1) : 0)), s);
+        if (V == 4)
+            hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4, true>), ag.grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+                               gamma, mean, rstd, nullptr, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
+                               d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, beta, dxam, nullptr, g.G, nullptr, nullptr, 0, 0, fin);
+        else
+            hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1, true>), ag.grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
+                               gamma, mean, rstd, nullptr, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
+                               d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, beta, dxam, nullptr, g.G, nullptr, nullptr, 0, 0, fin);
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+    }
+    const dim3 sgrid(g.chunks, g.cblocks, g.G);
     {
         SsProfScope prof("norm_stats_kernel<bwd>", 0.0, elems * sizeof(T) * (use_y ? 3 : 2), s);          // read dy, x (+ y)
         if (V == 4)
             hipLaunchKernelGGL((norm_stats_kernel<T, 1, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
-                               d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
+                               d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta, ss_tuning().norm_order);
         else
             hipLaunchKernelGGL((norm_stats_kernel<T, 1, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
-                               d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta);
+                               d->act, d->act_alpha, g.C, g.P, g.pix_per_chunk, g.CT, g.PT, part, gamma, beta, ss_tuning().norm_order);
         SS_LAUNCH_CHECK();
     }
     double* rt = (double*)((char*)ws + part_bytes(d) + ss_align_up((size_t)g.G * g.C * 2 * sizeof(float), 256));
@@ -950,11 +1166,11 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
     if (V == 4)
         hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 4>), ag.grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, beta, dxam, prt, g.G, dgamma, dbeta, accumulate_params);
+                           d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, beta, dxam, prt, g.G, dgamma, dbeta, accumulate_params, ss_tuning().norm_order);
     else
         hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), ag.grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride,
                            gamma, mean, rstd, sums, dx, dx_cstride, accumulate_dx, dres, d->res_cstride, accumulate_dres,
-                           d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, beta, dxam, prt, g.G, dgamma, dbeta, accumulate_params);
+                           d->act, d->act_alpha, g.C, g.P, ag.CT, ag.PT, ag.rows_per_chunk, beta, dxam, prt, g.G, dgamma, dbeta, accumulate_params, ss_tuning().norm_order);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -202,7 +202,7 @@ def cat_batch(tensors):
 class Act:
     """An NHWC activation view: channels [c0, c0+c) of a base tensor [n,h,w,cs]."""
 
-    __slots__ = ("t", "c0", "c", "grad", "grad_init", "requires_grad", "parent", "amax", "amax_valid", "dt", "stats")
+    __slots__ = ("t", "c0", "c", "grad", "grad_init", "requires_grad", "parent", "amax", "amax_valid", "amax_dirty", "dt", "stats")
 
     def __init__(self, t, c0=0, c=None, requires_grad=True, parent=None):
         assert t.dim() == 4 and t.is_contiguous()
@@ -215,6 +215,7 @@ class Act:
         self.parent = parent
         self.amax = None          # amax slot: bit pattern of max|view| once a producer / conv pass has computed it (x3h scale)
         self.amax_valid = False
+        self.amax_dirty = False   # the slot may hold a STALE maximum (invalidated after a producer reported one): a pass clears it before scanning
         self.stats = None         # (tensor, chunks per sample): partial (sum, sum of squares) per sample and channel from the producing conv
 
     # geometry
@@ -241,6 +242,17 @@ class Act:
         if self.amax is None:
             self.amax = _amax_slot(self.t.device)
         return ctypes.c_void_p(self.amax.data_ptr())
+
+    def amax_state(self):
+        """ss_conv_desc::*_amax_valid for this view's slot: 1 = holds the maximum, 2 = zero (fresh from the zeroed pool, never written:
+        the pass scans into it without a memset dispatch), 0 = stale contents (the pass clears it first)."""
+        return 1 if self.amax_valid else (0 if self.amax_dirty else 2)
+
+    def amax_invalidate(self):
+        """The tensor changes under a reported maximum (a second writer accumulates into it)."""
+        if self.amax_valid or self.amax is not None:
+            self.amax_dirty = True
+        self.amax_valid = False
 
     @staticmethod
     def empty(n, h, w, c, device, requires_grad=True, dtype=torch.float32):
@@ -269,7 +281,7 @@ class Act:
             elif not p.grad_init:
                 zero_(p.grad.t)
                 p.grad_init = True
-            p.grad.amax_valid = False
+            p.grad.amax_invalidate()
             return Act(p.grad.t, self.c0, self.c, False), 1
         if self.grad is None:
             self.grad = Act(torch.empty_like(self.t), self.c0, self.c, False)
@@ -277,9 +289,9 @@ class Act:
             return self.grad, 0
         if not self.grad_init:
             self.grad_init = True
-            self.grad.amax_valid = False
+            self.grad.amax_invalidate()
             return self.grad, 0
-        self.grad.amax_valid = False          # a second writer accumulates: a maximum reported by the first one is stale
+        self.grad.amax_invalidate()          # a second writer accumulates: a maximum reported by the first one is stale
         return self.grad, 1
 
     def get_grad(self):
@@ -307,7 +319,7 @@ class DeferredNorm(Act):
         self.t = None
         self.c0, self.c = 0, pre.c
         self.grad, self.grad_init, self.requires_grad, self.parent = None, False, True, None
-        self.amax, self.amax_valid, self.stats = None, False, None
+        self.amax, self.amax_valid, self.amax_dirty, self.stats = None, False, False, None
         self.pre, self.mean, self.rstd, self.gamma, self.beta = pre, mean, rstd, gamma, beta
         self.groups, self.act_code, self.act_alpha = groups, act_code, act_alpha
         self._y, self._materialize = None, materialize
@@ -363,9 +375,9 @@ class DeferredNorm(Act):
             return self.grad, 0
         if not self.grad_init:
             self.grad_init = True
-            self.grad.amax_valid = False
+            self.grad.amax_invalidate()
             return self.grad, 0
-        self.grad.amax_valid = False
+        self.grad.amax_invalidate()
         return self.grad, 1
 
 

@@ -119,7 +119,7 @@ class Conv2D:
         e0 = TIMER.start() if (TIMER.enabled and self.profile_tag) else None
         uses = self._uses_amax(d, L.PASS_FWD)
         if (uses & 1) or fused is not None:        # this pass needs (fused: produces) max|x|: into x's slot unless an earlier pass already has
-            d.x_amax, d.x_amax_valid = x.amax_slot(), 1 if x.amax_valid else 0
+            d.x_amax, d.x_amax_valid = x.amax_slot(), x.amax_state()
         else:
             d.x_amax, d.x_amax_valid = None, 0
         d.dy_amax, d.dy_amax_valid = None, 0
@@ -171,8 +171,8 @@ class Conv2D:
                 gb = self.arena.grad(f"{self.name}/bias") if self.use_bias else None
                 uses = self._uses_amax(dd, L.PASS_BWD_WEIGHT)
                 self._set_in_norm(dd, fused)
-                dd.x_amax, dd.x_amax_valid = (x.amax_slot(), 1 if x.amax_valid else 0) if uses & 1 else (None, 0)
-                dd.dy_amax, dd.dy_amax_valid = (dy.amax_slot(), 1 if dy.amax_valid else 0) if uses & 2 else (None, 0)
+                dd.x_amax, dd.x_amax_valid = (x.amax_slot(), x.amax_state()) if uses & 1 else (None, 0)
+                dd.dy_amax, dd.dy_amax_valid = (dy.amax_slot(), dy.amax_state()) if uses & 2 else (None, 0)
                 dd.saved_operand = sv.data_ptr() if sv is not None else None
                 # (a pass that would have to COMPUTE a maximum into a shared slot stays on the chain: the data gradient trusts the slot)
                 amax_ready = (not (uses & 1) or x.amax_valid) and (not (uses & 2) or dy.amax_valid)
@@ -214,7 +214,7 @@ class Conv2D:
                 uses = self._uses_amax(ddx, L.PASS_BWD_DATA)
                 self._set_in_norm(ddx, None)
                 ddx.x_amax, ddx.x_amax_valid = None, 0
-                ddx.dy_amax, ddx.dy_amax_valid = (dy.amax_slot(), 1 if dy.amax_valid else 0) if uses & 2 else (None, 0)
+                ddx.dy_amax, ddx.dy_amax_valid = (dy.amax_slot(), dy.amax_state()) if uses & 2 else (None, 0)
                 wst = self._attach_wcache(ddx, L.PASS_BWD_DATA)
                 L.check(lib.ss_conv2d_bwd_data(ctypes.byref(ddx), dy.ptr, _p(w), dx.ptr, accum, _p(wsd), wsd.numel(),
                                                _stream()), f"conv2d_bwd_data[{self.name}]")

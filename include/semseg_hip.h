@@ -162,7 +162,9 @@ typedef struct ss_conv_desc {
     /* Optional (may be NULL / 0): caller-owned device SLOTS (SS_AMAX_SLOT_BYTES each, see below) for the bit pattern of max|x| and max|dy| -- the power-of-two
      * scales of the fp16 two-piece ("x3h") contraction.  A pass that needs a maximum (ss_conv2d_uses_amax) computes it INTO the
      * slot unless the matching *_valid flag says the slot already holds it, so that a tensor consumed by several passes (x:
-     * forward + weight gradient, dy: data + weight gradient) is scanned once.  Without slots every pass scans for itself. */
+     * forward + weight gradient, dy: data + weight gradient) is scanned once.  Without slots every pass scans for itself.
+     * *_valid: 0 = contents unknown (the pass clears the slot, then scans into it), 1 = the slot holds the maximum (no scan),
+     * 2 = the slot is ZERO on entry (caller vouches, e.g. fresh from a zeroed pool): the pass scans into it without clearing. */
     void* x_amax;
     void* dy_amax;
     int32_t x_amax_valid;

@@ -209,6 +209,14 @@ NORM_CASES = [
     ("bn_plain", "batch", 4, None, False, True, (4, 32, 32)),
     ("bn_sigmoid", "batch", 1, "sigmoid", False, False, (2, 16, 16)),
     ("in_big", "instance", 512, "relu", False, True, (1, 64, 64)),
+    # mid-size groups (> 1024 pixels, <= 8 M elements): the apply kernels finalize the statistics of their own channel block
+    # (norm_fuse_fin) -- several groups (parameter gradients summed over them), odd widths (serial lane sums), residuals
+    ("in_mid_g3", "instance", 256, "relu", False, True, (3, 40, 40)),
+    ("in_mid_res", "instance", 128, None, True, True, (2, 48, 48)),
+    ("in_mid_lrelu_noscale", "instance", 64, "lrelu", False, False, (4, 36, 36)),
+    ("bn_mid_odd51", "batch", 51, "relu", False, True, (2, 64, 64)),
+    ("bn_mid_17_res", "batch", 17, "relu", True, True, (1, 96, 96)),
+    ("bn_mid_212", "batch", 212, "relu", False, True, (2, 40, 40)),
 ]
 
 
@@ -272,6 +280,46 @@ def test_norm_fwd_bwd(case):
             zi = zi + r_cpu
         yi = {"relu": torch.relu, "lrelu": lambda t: O.leaky_relu(t, 0.2), "sigmoid": torch.sigmoid, None: lambda t: t}[act](zi)
         assert_close(y2.dense().cpu(), yi, f"{name} infer", rtol=2e-4)
+
+
+def test_norm_fused_finalize_agrees_with_the_finalize_kernels_and_is_bit_stable():
+    """ss_config norm_fuse_fin: the apply kernels' own reduction of the statistics partials against the separate finalize launches
+    (other chunk geometry, other fp64 summation order: equal to a few ulp), forward + backward, InstanceNorm over 3 groups and BatchNorm
+    with moving statistics; two fused runs are bit-identical (fixed-order sums, no atomics)."""
+    E, LY, L = _mods()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77)
+    for kind, c, shp, use_res in (("instance", 256, (3, 40, 40), True), ("batch", 51, (2, 64, 64), False), ("batch", 64, (1, 128, 128), False)):
+        n, h, w = shp
+        x_cpu = torch.randn((n, h, w, c), generator=g) * 2 + 0.3
+        r_cpu = torch.randn((n, h, w, c), generator=g) if use_res else None
+        gy_cpu = torch.randn((n, h, w, c), generator=g)
+        runs = []
+        for fuse in (0, 1, 1):
+            with L.config(norm_fuse_fin=fuse):
+                arena = E.ParamArena(dev)
+                layer = LY.Norm(arena, "n", c, kind)
+                arena.materialize()
+                arena["n/gamma"].copy_(torch.linspace(0.5, 1.5, c))
+                arena["n/beta"].copy_(torch.linspace(-0.3, 0.3, c))
+                if kind == "batch":
+                    arena["n/moving_variance"].fill_(1.0)
+                tape = E.Tape()
+                x = E.Act(x_cpu.to(dev))
+                res = E.Act(r_cpu.to(dev)) if use_res else None
+                y = layer(tape, x, act=None if use_res else "relu", residual=res)
+                gt, _ = y.grad_target()
+                gt.t.copy_(gy_cpu.to(dev))
+                arena.zero_grad()
+                tape.backward()
+                out = [y.dense().cpu(), x.get_grad().dense().cpu(), arena.grad("n/gamma").cpu().clone(), arena.grad("n/beta").cpu().clone()]
+                if kind == "batch":
+                    out += [arena["n/moving_mean"].cpu().clone(), arena["n/moving_variance"].cpu().clone()]
+                runs.append(out)
+        for a, b in zip(runs[1], runs[2]):
+            assert torch.equal(a, b), "fused finalize is not bit-stable"
+        for i, (a, b) in enumerate(zip(runs[0], runs[1])):
+            assert float((a - b).abs().max()) <= 4e-6 * max(float(a.abs().max()), 1.0), (kind, c, i, float((a - b).abs().max()))
 
 
 def test_maxpool_fwd_bwd():

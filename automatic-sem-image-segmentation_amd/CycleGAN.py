@@ -416,8 +416,9 @@ class CycleGanModel:
         if not self.sync_metrics:
             self._count += 1
             return {}
-        s = self._scalars.cpu().numpy().astype(np.float64)   # one device->host read per step
-        s = D.mean_scalars(s)
+        # one device->host read per step; the values are THIS rank's (means over its shard of the batch): the cross-rank exchange is
+        # not part of the step -- `global_metrics()` does it once per logging interval (the training loop: once per epoch)
+        s = self._scalars.cpu().numpy().astype(np.float64)
         adv_a, adv_b = s[0], s[1]
         cyc_a, cyc_b = s[2] * self.lambda_cycle_a, s[3] * self.lambda_cycle_b
         id_a = s[4] * self.lambda_cycle_a * self.lambda_identity_a if self.use_identity_loss else 0.0
@@ -428,6 +429,15 @@ class CycleGanModel:
         self._count += 1
         self._sums += np.array([vals[k] for k in METRIC_NAMES])
         return {k: float(self._sums[i] / self._count) for i, k in enumerate(METRIC_NAMES)}
+
+    def global_metrics(self):
+        """The running means since reset_metrics() averaged over the ranks (equal shards: the mean of the ranks' means is the mean over
+        the global batches) -- ONE small all-reduce per call; train_step itself exchanges nothing but gradients.  Single process: the
+        running means as they are."""
+        if self._count == 0:
+            return {}
+        m = D.mean_scalars(self._sums / self._count)
+        return {k: float(m[i]) for i, k in enumerate(METRIC_NAMES)}
 
     @staticmethod
     def to_numpy_array(x):
@@ -824,6 +834,8 @@ class CycleGAN:
             for a, b in HelperFunctions.prefetch(self.data.__getitem__, order, depth=ahead):
                 per = len(a) // world
                 logs = self.model.train_step((a[rank * per:(rank + 1) * per], b[rank * per:(rank + 1) * per]))
+            if world > 1:
+                logs = self.model.global_metrics()          # the epoch's one metrics exchange (the steps return rank-local values)
             self.data.on_epoch_end()
             if rank == 0:
                 new = not os.path.exists(log_path)

@@ -233,8 +233,16 @@ class UNetModel:
     def _read_metrics(self):
         if not self.sync_metrics:
             return {}
-        s = D.mean_scalars(self._out3.cpu().numpy().astype(np.float64))
+        # THIS rank's values (its shard of the batch): the cross-rank mean is taken once per logging interval (global_metrics), not per step
+        s = self._out3.cpu().numpy().astype(np.float64)
         return {"loss": float(s[0]), "mae": float(s[1]), "acc": float(s[2])}
+
+    @staticmethod
+    def global_metrics(m):
+        """Mean over the ranks of a dict of per-rank means (equal shards) -- one small all-reduce; single process: unchanged."""
+        keys = sorted(m)
+        v = D.mean_scalars(np.array([m[k] for k in keys], dtype=np.float64))
+        return {k: float(v[i]) for i, k in enumerate(keys)}
 
     # ---- the step as a replayed hipGraph -------------------------------------------------------------------------------------------
     @staticmethod
@@ -503,6 +511,8 @@ class UNet:
                 seen += len(x)
             self.training_data.on_epoch_end()
             logs = {k: v / max(seen, 1) for k, v in tot.items()}
+            if world > 1:
+                logs = self.model.global_metrics(logs)          # the epoch's one metrics exchange (the steps return rank-local values)
             vt = {"loss": 0.0, "mae": 0.0, "acc": 0.0}
             vseen = 0
             for x, y in HelperFunctions.prefetch(self.validation_data.__getitem__, range(len(self.validation_data)), depth=ahead):

@@ -528,6 +528,106 @@ class Norm:
         return y
 
 
+def sync_norm_group(tape, items, pack_backward=True):
+    """Several BatchNorm layers whose statistics do not depend on one another, under cross-rank statistics (SYNC_BN): ONE all-reduce of
+    the packed (sum, sum of squares) vectors in forward instead of one per layer, and -- where the layers' output gradients are final at
+    the same point of the replay (`pack_backward`: a MultiRes block's shortcut and first 3x3, UNet_Segmentation.py:455-458) -- one for
+    the packed backward sums as well.  A ResPath stage's pair (:483-488) packs in forward only: the 3x3 branch's output gradient IS the
+    shortcut norm's residual gradient, which its finish pass writes.
+
+    items: [(norm, x, dict(act=, act_alpha=, residual=, out=))] in the order the layers' apply passes have to run (a later item may take
+    an earlier item's output as its residual).  Returns the outputs.  The arithmetic is ss_norm_{fwd,bwd}_stats / _finish, as in
+    Norm.__call__ under SYNC_BN: the results are the unpacked ones bit for bit (the all-reduce sums the same numbers)."""
+    lib = L.load()
+    sync = SYNC_BN
+    assert sync is not None and all(nm.kind == "batch" for nm, _, _ in items)
+    dev = items[0][1].device
+    offs, tot = [], 0
+    for nm, x, _ in items:
+        assert x.c == nm.c
+        offs.append(tot)
+        tot += 2 * x.c
+    buf = torch.empty(tot, dtype=torch.float32, device=dev)
+    st = []
+    for (nm, x, kw), off in zip(items, offs):
+        residual, out = kw.get("residual"), kw.get("out")
+        y = out if out is not None else x.like()
+        d = L.NormDesc(x.n, x.h, x.w, x.c, x.cs, y.cs, residual.cs if residual is not None else 0, 1, float(nm.eps),
+                       ACTS[kw.get("act")], float(kw.get("act_alpha", 0.0)), dtype=x.dt)
+        ws = workspace(lib.ss_norm_workspace_bytes(ctypes.byref(d)), dev)
+        sums = buf[off:off + 2 * x.c]
+        L.check(lib.ss_norm_fwd_stats(ctypes.byref(d), x.ptr, _p(sums), _p(ws), ws.numel(), _stream()), "norm_fwd_stats")
+        st.append(dict(nm=nm, x=x, y=y, d=d, sums=sums, residual=residual, act=kw.get("act")))
+    world = sync(buf)                                   # the group's one forward exchange
+    param_grads = tape.param_grads
+    for e in st:
+        nm, x, y, d, residual = e["nm"], e["x"], e["y"], e["d"], e["residual"]
+        e["count"] = x.rows * world
+        e["mean"] = torch.empty(x.c, dtype=torch.float32, device=dev)
+        e["rstd"] = torch.empty_like(e["mean"])
+        e["gamma"] = nm.arena[f"{nm.name}/gamma"] if nm.scale else None
+        e["beta"] = nm.arena[f"{nm.name}/beta"]
+        L.check(lib.ss_norm_fwd_finish(ctypes.byref(d), x.ptr, _p(e["gamma"]), _p(e["beta"]), residual.ptr if residual is not None else None, y.ptr,
+                                       _p(e["sums"]), e["count"], _p(e["mean"]), _p(e["rstd"]), _p(nm.arena[f"{nm.name}/moving_mean"]),
+                                       _p(nm.arena[f"{nm.name}/moving_variance"]), float(nm.momentum), _stream()), "norm_fwd_finish")
+        e["pnames"] = ([f"{nm.name}/gamma"] if nm.scale else []) + [f"{nm.name}/beta"]
+        if param_grads and tape.enabled and tape.count_uses:
+            nm.arena.note_use(e["pnames"])
+
+    def bwd_stats(e, lsums):
+        dy = e["y"].get_grad()
+        if dy is None:
+            return False
+        x, d, residual = e["x"], e["d"], e["residual"]
+        e["dy"] = dy
+        e["dx"], e["accum"] = x.grad_target()
+        e["dres"], e["racc"] = residual.grad_target() if (residual is not None and residual.requires_grad) else (None, 0)
+        db = e["db"] = L.NormDesc.from_buffer_copy(d)
+        db.res_cstride = e["dres"].cs if e["dres"] is not None else 0
+        e["ws2"] = workspace(lib.ss_norm_workspace_bytes(ctypes.byref(db)), dev)
+        e["lsums"] = lsums
+        L.check(lib.ss_norm_bwd_stats(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, e["y"].ptr, _p(e["mean"]), _p(e["rstd"]), _p(lsums),
+                                      _p(e["ws2"]), e["ws2"].numel(), _stream()), "norm_bwd_stats")
+        return True
+
+    def bwd_finish(e, gsums):
+        nm, x, dy, dx, dres, db = e["nm"], e["x"], e["dy"], e["dx"], e["dres"], e["db"]
+        ggam = nm.arena.grad(f"{nm.name}/gamma") if (nm.scale and param_grads) else None
+        gbet = nm.arena.grad(f"{nm.name}/beta") if param_grads else None
+        L.check(lib.ss_norm_bwd_finish(ctypes.byref(db), dy.ptr, dy.cs, x.ptr, e["y"].ptr, _p(e["gamma"]), _p(e["mean"]), _p(e["rstd"]),
+                                       _p(gsums), _p(e["lsums"]), e["count"], dx.ptr, dx.cs, e["accum"],
+                                       dres.ptr if dres is not None else None, e["racc"], _p(ggam), _p(gbet), 1,
+                                       _p(e["ws2"]), e["ws2"].numel(), _stream()), "norm_bwd_finish")
+        if param_grads:
+            nm.arena.note_done(e["pnames"])
+
+    def backward():
+        if pack_backward:
+            lbuf = torch.empty(tot, dtype=torch.float32, device=dev)
+            live = [e for e, off in zip(st, offs) if bwd_stats(e, lbuf[off:off + 2 * e["x"].c])]
+            if not live:
+                return
+            if len(live) < len(st):          # a layer without an output gradient contributes nothing: its slot must not travel as garbage
+                for e, off in zip(st, offs):
+                    if e not in live:
+                        zero_(lbuf[off:off + 2 * e["x"].c])
+            gbuf = lbuf.clone()
+            sync(gbuf)                          # the group's one backward exchange
+            for e, off in zip(st, offs):
+                if e in live:
+                    bwd_finish(e, gbuf[off:off + 2 * e["x"].c])
+            return
+        for e in reversed(st):                  # dependent output gradients: layer by layer, last applied first
+            lsums = torch.empty(2 * e["x"].c, dtype=torch.float32, device=dev)
+            if bwd_stats(e, lsums):
+                gsums = lsums.clone()
+                sync(gsums)
+                bwd_finish(e, gsums)
+
+    tape.record(backward)
+    return [e["y"] for e in st]
+
+
 def maxpool2x2(tape, x):
     lib = L.load()
     y = x.like(h=x.h // 2, w=x.w // 2)

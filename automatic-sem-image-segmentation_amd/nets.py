@@ -14,6 +14,7 @@ import torch
 
 from . import _lib as L
 from .engine import Act, ParamArena, Tape, convert
+from . import layers
 from .layers import Conv2D, Norm, add, crop, maxpool2x2, reflect_pad, upsample2x
 
 
@@ -260,9 +261,15 @@ class _MultiResBlock:
 
     def __call__(self, tape, x, training, out=None):
         a, b, c = self.widths
-        sc = self.sc(tape, x, None, training)
         cat = x.like(c=self.cout)     # concat buffer: producers write their slices
-        s3 = self.c3(tape, x, "relu", training, out=cat.slice(0, a))
+        if layers.SYNC_BN is not None and training:
+            # data parallel: the shortcut's and the first 3x3's BatchNorms read statistics of two tensors that exist at the same time --
+            # one packed exchange each way instead of two (layers.sync_norm_group)
+            sc, s3 = layers.sync_norm_group(tape, [(self.sc.bn, self.sc.conv(tape, x), dict(act=None)),
+                                                   (self.c3.bn, self.c3.conv(tape, x), dict(act="relu", out=cat.slice(0, a)))])
+        else:
+            sc = self.sc(tape, x, None, training)
+            s3 = self.c3(tape, x, "relu", training, out=cat.slice(0, a))
         s5 = self.c5(tape, s3, "relu", training, out=cat.slice(a, b))
         self.c7(tape, s5, "relu", training, out=cat.slice(a + b, c))
         h = self.bn_a(tape, cat, act="relu", residual=sc, training=training)   # relu(shortcut + BN(cat))
@@ -283,8 +290,15 @@ class _ResPath:
 
     def __call__(self, tape, x, training, out=None):
         for i, (sc, c3, bn) in enumerate(self.stages):
-            o = c3(tape, x, "relu", training)
-            s = sc(tape, x, "relu", training, residual=o)          # relu(BN(conv1x1(x)) + o)
+            if layers.SYNC_BN is not None and training:
+                # forward statistics of the pair in one exchange; backward layer by layer (o's gradient is written by sc's backward)
+                y3, y1 = c3.conv(tape, x), sc.conv(tape, x)
+                o = y3.like()
+                o, s = layers.sync_norm_group(tape, [(c3.bn, y3, dict(act="relu", out=o)), (sc.bn, y1, dict(act="relu", residual=o))],
+                                              pack_backward=False)
+            else:
+                o = c3(tape, x, "relu", training)
+                s = sc(tape, x, "relu", training, residual=o)          # relu(BN(conv1x1(x)) + o)
             x = bn(tape, s, training=training, out=out if i == len(self.stages) - 1 else None)
         return x
 

@@ -60,15 +60,35 @@ for k in ("gen_a", "gen_b"):
         nets[k].arena.grad_hook = counting(nets[k].arena.grad_hook)
 model = CG.CycleGanModel(nets["gen_a"], nets["gen_b"], nets["disc_a"], nets["disc_b"], image_pool_a=CG.ImagePool(2, 0), image_pool_b=CG.ImagePool(2, 0))
 model.compile(OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5), OPT.Adam(2e-4, beta_1=0.5))
-m = model.train_step((a[sl].numpy(), b[sl].numpy()))
+# SyncBN exchanges of one UNet step: every one goes through layers.SYNC_BN
+LYm = importlib.import_module(B + ".layers")
+bn_calls = [0]
+if LYm.SYNC_BN is not None:
+    _bn = LYm.SYNC_BN
+    def counted_bn(t):
+        bn_calls[0] += 1
+        return _bn(t)
+    LYm.SYNC_BN = counted_bn
+_ms = D.mean_scalars
+metric_exchanges = [0]
+def counted_ms(v):
+    metric_exchanges[0] += 1 if D.world_size() > 1 else 0
+    return _ms(v)
+D.mean_scalars = counted_ms
+model.train_step((a[sl].numpy(), b[sl].numpy()))
+assert metric_exchanges[0] == 0, "train_step exchanges gradients only; metrics travel once per logging interval"
+m = model.global_metrics()
 um = UN.UNetModel(unet, 9.0, OPT.Adam(1e-3))
-u = um.train_step((((a[sl] + 1) / 2).numpy(), ((b[sl] + 1) / 2).numpy()))
+u = um.global_metrics(um.train_step((((a[sl] + 1) / 2).numpy(), ((b[sl] + 1) / 2).numpy())))
+unet_collectives = bn_calls[0]
+assert metric_exchanges[0] == (2 if world > 1 else 0), metric_exchanges
 if rank == 0:
     arrs = {f"{k}/{i}": w for k, net in nets.items() for i, w in enumerate(net.get_weights())}
     arrs.update({f"unet/{i}": w for i, w in enumerate(unet.get_weights())})
     arrs["metrics"] = np.array([m[k] for k in sorted(m)] + [u[k] for k in sorted(u)])
     arrs["gen_buckets_fired_in_backward"] = np.array(fired[0])
     arrs["gen_buckets"] = np.array(len(nets["gen_a"].arena.buckets) + len(nets["gen_b"].arena.buckets))
+    arrs["unet_syncbn_exchanges"] = np.array(unet_collectives)
     np.savez(out, **arrs)
 if world > 1:
     torch.distributed.barrier(); torch.distributed.destroy_process_group()
@@ -99,9 +119,12 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path):
     # the dual-chain step (SS_DUAL_STREAM=force) launches every generator bucket from inside the second chain's backward
     assert int(two["gen_buckets"]) >= 4 and int(two["gen_buckets_fired_in_backward"]) == int(two["gen_buckets"]), \
         (int(two["gen_buckets_fired_in_backward"]), int(two["gen_buckets"]))
+    # SyncBN: 85 BatchNorm layers, 2 exchanges each unpacked (170); the 9 MultiRes blocks pack shortcut + first 3x3 both ways, the 10
+    # ResPath stages pack their pair in forward: 66 forward + 76 backward
+    assert int(two["unet_syncbn_exchanges"]) <= 142, int(two["unet_syncbn_exchanges"])
     num = den = 0.0
     for k in one.files:
-        if k in ("metrics", "gen_buckets", "gen_buckets_fired_in_backward"):
+        if k in ("metrics", "gen_buckets", "gen_buckets_fired_in_backward", "unet_syncbn_exchanges"):
             continue
         num += float(((two[k].astype(np.float64) - one[k]) ** 2).sum())
         den += float((one[k].astype(np.float64) ** 2).sum())

@@ -120,6 +120,10 @@ SIGNATURES = {
     "ss_probe_mfma": (c_i32, [c_i32, c_vp, ctypes.c_size_t, c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ss_conv2d_wcache_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_wcache_invalidate": (None, [ctypes.POINTER(WCache)]),
+    "ss_wprep_record_begin": (c_i32, []),
+    "ss_wprep_record_end": (c_i32, [ctypes.POINTER(c_sz), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "ss_wprep_plan_write": (c_i32, [c_vp, c_sz]),
+    "ss_wprep_run": (c_i32, [c_vp, c_vp, c_sz, c_vp]),
     "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_conv2d_bwd_data": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "ss_conv2d_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),

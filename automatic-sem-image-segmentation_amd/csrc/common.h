@@ -360,6 +360,33 @@ int ss_launch_wgrad_x6_partials(const WGradParams& p, hipStream_t s);
 typedef ss_wcache WCache;
 enum { SS_WC_WINO_UBF = 1, SS_WC_WINO_X3H_INV, SS_WC_WINO_X3H_PLANES, SS_WC_WINO_X6_PLANES, SS_WC_WINO_U32, SS_WC_WAMAX, SS_WC_WT,
        SS_WC_X6_PLANES };
+// ---- batched weight preparation (ss_wprep_*; wprep_batch.hip) ---------------------------------------------------------------------
+// A network's refresh of its weight-derived operands is ~100 small launches (weight maxima, tap-wise transposes, split planes,
+// Winograd-transformed planes), the same ones with the same pointers every step.  While a RECORDER is active on the calling thread
+// the hooked launch sites append a job instead of launching; ss_wprep_run then executes a recorded plan as one launch per job TYPE
+// (workgroup -> job through a block map): ~6 launches per network and step.
+enum { SS_WJ_AMAX = 0, SS_WJ_TRANSPOSE, SS_WJ_WPREP_H, SS_WJ_WPREP_3, SS_WJ_WINO_H, SS_WJ_TYPES };
+struct SsWJob {          // POD: the plan is copied to device memory verbatim
+    int32_t type, gx, gy, gz;          // grid of the launch this job replaces
+    int32_t blk0, e;                   // first workgroup of the job inside its type's batched launch; e: a fifth type-specific integer
+    const float* src;
+    void* dst;
+    void* dst2;
+    const unsigned int* amax;
+    int64_t n;
+    int32_t a, b, c, d;                // type-specific integers (see the launch sites)
+    GConvParams p;                     // SS_WJ_WPREP_*: the problem whose weights are split
+};
+bool ss_wrec_on();                                     // a recorder is active on this thread
+void ss_wrec_push(const SsWJob& j);                    // append (dropped when j.dst is not a cache region noted since record_begin)
+void ss_wrec_note_region(void* ptr, size_t bytes);     // a cache entry was allocated and expects a fill
+void ss_wrec_unbatched();                              // a fill the plan cannot replay was launched directly: the recording is incomplete
+// the batched launchers, next to the kernels they batch: jobs / map live in device memory (map[workgroup] = job index)
+int ss_wbatch_launch_amax(const SsWJob* jobs, const int* map, int nblocks, hipStream_t s);
+int ss_wbatch_launch_transpose(const SsWJob* jobs, const int* map, int nblocks, hipStream_t s);
+int ss_wbatch_launch_wprep(bool h, const SsWJob* jobs, const int* map, int nblocks, hipStream_t s);
+int ss_wbatch_launch_wino(const SsWJob* jobs, const int* map, int nblocks, hipStream_t s);
+
 static inline uint64_t ss_wc_tag(int kind, uint64_t detail) { return (uint64_t)kind | (detail << 8); }
 // region of `n` bytes for the operand `tag`: the cached copy (*fill = false), a new cache entry (*fill = true) or, without a cache /
 // when it is full, `fallback` (*fill = true)
@@ -374,6 +401,7 @@ static inline void* ss_wc_region(WCache* wc, uint64_t tag, size_t n, void* fallb
     e.tag = tag; e.offset = wc->used; e.bytes = n;
     wc->used += na;
     wc->fills++;
+    if (ss_wrec_on()) ss_wrec_note_region((char*)wc->base + e.offset, n);
     return (char*)wc->base + e.offset;
 }
 

@@ -28,13 +28,13 @@ struct ConvProb {
 
 // ---- small helper kernels -----------------------------------------------------------------------
 // WT[t][b][a] = W[t][a][b]
-__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ w, float* __restrict__ wt, int A, int B) {
+__device__ __forceinline__ void transpose_last2_body(const float* __restrict__ w, float* __restrict__ wt, int A, int B, int bx, int by, int bz) {
     __shared__ float tile[32][33];
-    const int t = blockIdx.z;
+    const int t = bz;
     const float* src = w + (long)t * A * B;
     float* dst = wt + (long)t * A * B;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    const int a0 = by * 32, b0 = bx * 32;
     for (int i = ty; i < 32; i += 8) {
         const int a = a0 + i, b = b0 + tx;
         tile[i][tx] = (a < A && b < B) ? src[(long)a * B + b] : 0.f;
@@ -44,6 +44,35 @@ __global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __res
         const int b = b0 + i, a = a0 + tx;
         if (a < A && b < B) dst[(long)b * A + a] = tile[tx][i];
     }
+}
+__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ w, float* __restrict__ wt, int A, int B) {
+    transpose_last2_body(w, wt, A, B, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// the transposes of a recorded plan in ONE launch (wprep_batch.hip): workgroup -> job through the block map
+__global__ __launch_bounds__(256) void transpose_last2_batch_kernel(const SsWJob* __restrict__ jobs, const int* __restrict__ map) {
+    const SsWJob& j = jobs[map[blockIdx.x]];
+    const int l = blockIdx.x - j.blk0;
+    transpose_last2_body(j.src, (float*)j.dst, j.a, j.b, l % j.gx, (l / j.gx) % j.gy, l / (j.gx * j.gy));
+}
+// max|v| of `n` contiguous, 16-byte aligned floats (a layer's kernel tensor), one job per tensor, `gx` workgroups each: the word was
+// zeroed by the plan's first launch
+__global__ __launch_bounds__(256) void amax_batch_kernel(const SsWJob* __restrict__ jobs, const int* __restrict__ map) {
+    const SsWJob& j = jobs[map[blockIdx.x]];
+    const int l = blockIdx.x - j.blk0;
+    const float* v = j.src;
+    const long n = j.n, n4 = n >> 2;
+    unsigned int m = 0;
+    for (long i = (long)l * blockDim.x + threadIdx.x; i < n4; i += (long)j.gx * blockDim.x) {
+        const f32x4 t = ((const f32x4*)v)[i];
+        m = max(max(m, __float_as_uint(fabsf(t[0]))), max(__float_as_uint(fabsf(t[1])), max(__float_as_uint(fabsf(t[2])), __float_as_uint(fabsf(t[3])))));
+    }
+    if (l == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(fabsf(v[(n4 << 2) + threadIdx.x])));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, off, 64));
+    __shared__ unsigned int wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax((unsigned int*)j.dst, max(max(wm[0], wm[1]), max(wm[2], wm[3])));      // order-independent: deterministic
 }
 
 // dx[n,iy,ix,c] (+)= sum over the padded positions that reflect onto (iy,ix) of dpad[n,py,px,c]
@@ -358,6 +387,16 @@ inline void launch_amax_view(const float* v, long rows, int C, int cs, unsigned 
 }
 }  // namespace
 void ss_launch_amax_view(const float* v, long rows, int C, int cs, unsigned int* out, int stripes, hipStream_t s) { launch_amax_view(v, rows, C, cs, out, stripes, s); }
+int ss_wbatch_launch_amax(const SsWJob* jobs, const int* map, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(amax_batch_kernel, dim3(nblocks), dim3(256), 0, s, jobs, map);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+int ss_wbatch_launch_transpose(const SsWJob* jobs, const int* map, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_last2_batch_kernel, dim3(nblocks), dim3(256), 0, s, jobs, map);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
 namespace {
 struct AmaxRef { const unsigned int* p; int stripes; };
 // maximum of an activation / gradient view for its x3h scale: into the caller's slot when there is one (computed only if the
@@ -390,8 +429,17 @@ const unsigned int* weight_amax(const float* w, long wn, unsigned int* scratch, 
     bool fill;
     scratch = (unsigned int*)ss_wc_region(wc, ss_wc_tag(SS_WC_WAMAX, 0), 256, scratch, &fill);
     if (!fill) return scratch;
+    const unsigned nb = wn / 8192 < 16 ? 16 : (wn / 8192 > 256 ? 256 : (unsigned)(wn / 8192));
+    if (ss_wrec_on() && (((uintptr_t)w) & 15) == 0) {          // recorded (ss_wprep_*): the plan zeroes the word and scans the tensor
+        SsWJob j{};
+        j.type = SS_WJ_AMAX; j.gx = (int)(nb > 16 ? 16 : nb); j.gy = 1; j.gz = 1;
+        j.src = w; j.n = wn; j.dst = scratch;
+        ss_wrec_push(j);
+        return scratch;
+    }
+    if (ss_wrec_on()) ss_wrec_unbatched();
     (void)hipMemsetAsync(scratch, 0, 4, s);
-    hipLaunchKernelGGL(amax_view_kernel, dim3(wn / 8192 < 16 ? 16 : (wn / 8192 > 256 ? 256 : (unsigned)(wn / 8192))), dim3(256), 0, s, w, 1L, (int)wn, (int)wn, scratch, 1);
+    hipLaunchKernelGGL(amax_view_kernel, dim3(nb), dim3(256), 0, s, w, 1L, (int)wn, (int)wn, scratch, 1);
     return scratch;
 }
 bool x3h_direct_wanted(int algo, int cred, int cout) {
@@ -689,7 +737,12 @@ int conv_bwd_data(const ConvProb& c, const float* dy, const float* w, float* dx,
     {
         bool fill;
         wt = (float*)ss_wc_region(c.wc, ss_wc_tag(SS_WC_WT, 0), bwd_data_wt_bytes(c), wt, &fill);
-        if (fill) {
+        if (fill && ss_wrec_on()) {          // recorded (ss_wprep_*)
+            SsWJob j{};
+            j.type = SS_WJ_TRANSPOSE; j.gx = (c.cout + 31) / 32; j.gy = (c.cin + 31) / 32; j.gz = T;
+            j.src = w; j.dst = wt; j.a = c.cin; j.b = c.cout;
+            ss_wrec_push(j);
+        } else if (fill) {
             hipLaunchKernelGGL(transpose_last2_kernel, dim3((c.cout + 31) / 32, (c.cin + 31) / 32, T), dim3(256), 0, s, w, wt, c.cin, c.cout);
             SS_LAUNCH_CHECK();
         }

@@ -369,10 +369,11 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
 // planes[pl][batch][n][t*Cin + ci] = piece pl of w[batch*w_bs + taps[t].woff + ci*ldb + n]; rows n in [Cout, Npad) are zero.
 // 32x32 LDS transpose: coalesced reads along n, coalesced writes along k.
 template <bool H>
-__global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned short* __restrict__ planes, long plane_elems, int Npad, int Ktot) {
+__device__ __forceinline__ void wprep_x6_body(const GConvParams& p, unsigned short* __restrict__ planes, long plane_elems, int Npad, int Ktot,
+                                              int bx, int by, int bz) {
     __shared__ float tl[32][33];
-    const int batch = blockIdx.z;
-    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int batch = bz;
+    const int k0 = bx * 32, n0 = by * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
     const float* w = p.w + (long)batch * p.w_bs;
 #pragma unroll
@@ -408,6 +409,18 @@ __global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned s
             }
         }
     }
+}
+
+template <bool H>
+__global__ __launch_bounds__(256) void wprep_x6_kernel(GConvParams p, unsigned short* __restrict__ planes, long plane_elems, int Npad, int Ktot) {
+    wprep_x6_body<H>(p, planes, plane_elems, Npad, Ktot, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// the split-plane jobs of a recorded plan in ONE launch (wprep_batch.hip): the problem descriptions are read from the plan in device memory
+template <bool H>
+__global__ __launch_bounds__(256) void wprep_x6_batch_kernel(const SsWJob* __restrict__ jobs, const int* __restrict__ map) {
+    const SsWJob& j = jobs[map[blockIdx.x]];
+    const int l = blockIdx.x - j.blk0;
+    wprep_x6_body<H>(j.p, (unsigned short*)j.dst, j.n, j.a, j.b, l % j.gx, (l / j.gx) % j.gy, l / (j.gx * j.gy));
 }
 
 // Weight gradient with the same arithmetic:  part[split][(t,ca)][cb] = sum_pixels A_gather[pixel][(t,ca)] * B[pixel][cb].
@@ -770,6 +783,16 @@ int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     const int Npad = ss_x6_npad(p.Cout), Ktot = p.ntaps * ((p.Cin + 31) / 32 * 32);
     const long plane_elems = (long)nb * Npad * Ktot;
+    if (ss_wrec_on()) {          // recorded (ss_wprep_*): the plan replays it inside one launch per arithmetic
+        SsWJob j{};
+        j.type = p.h_amax ? SS_WJ_WPREP_H : SS_WJ_WPREP_3;
+        j.gx = (Ktot + 31) / 32; j.gy = Npad / 32; j.gz = nb;
+        j.dst = planes; j.n = plane_elems; j.a = Npad; j.b = Ktot;
+        j.p = p;
+        j.p.in = nullptr; j.p.out = nullptr; j.p.bias = nullptr; j.p.h_amax = nullptr; j.p.stats = nullptr;      // weights-only view (h_amax2, the weights' maximum, stays)
+        ss_wrec_push(j);
+        return SS_OK;
+    }
     if (p.h_amax) hipLaunchKernelGGL(wprep_x6_kernel<true>, dim3((Ktot + 31) / 32, Npad / 32, nb), dim3(256), 0, s, p, planes, plane_elems, Npad, Ktot);
     else hipLaunchKernelGGL(wprep_x6_kernel<false>, dim3((Ktot + 31) / 32, Npad / 32, nb), dim3(256), 0, s, p, planes, plane_elems, Npad, Ktot);
     SS_LAUNCH_CHECK();
@@ -836,4 +859,11 @@ int ss_launch_wgrad_x6_partials(const WGradParams& p, hipStream_t s) {
     if (!ss_wgrad_x6_ok(p)) return SS_ERR_UNSUPPORTED;
     if (p.Cb > 64) return launch_wgrad_x6<128>(p, s);
     return launch_wgrad_x6<64>(p, s);
+}
+
+int ss_wbatch_launch_wprep(bool h, const SsWJob* jobs, const int* map, int nblocks, hipStream_t s) {
+    if (h) hipLaunchKernelGGL(wprep_x6_batch_kernel<true>, dim3(nblocks), dim3(256), 0, s, jobs, map);
+    else hipLaunchKernelGGL(wprep_x6_batch_kernel<false>, dim3(nblocks), dim3(256), 0, s, jobs, map);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
 }

@@ -468,16 +468,16 @@ __global__ __launch_bounds__(256) void amax_bits_kernel(const float* __restrict_
 }
 
 template <int R, bool F16 = false>
-__global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __restrict__ w, int Cin, int Cout, int flip, int Npad,
-                                                             unsigned short* __restrict__ planes,
-                                                             const unsigned int* __restrict__ amax_bits = nullptr, float* __restrict__ w_inv = nullptr,
-                                                             int plain_l = 0) {
+__device__ __forceinline__ void wino_weight_x6_body(const float* __restrict__ w, int Cin, int Cout, int flip, int Npad,
+                                                    unsigned short* __restrict__ planes,
+                                                    const unsigned int* __restrict__ amax_bits, float* __restrict__ w_inv,
+                                                    int plain_l, int bx, int by, int bz) {
     constexpr int P = R + 2, HP = P / 2;
     __shared__ float tl[9][32][17];        // [logical tap a*3+b][kr][no]
     const int KR = flip ? Cout : Cin, NO = flip ? Cin : Cout;
     const int K2 = KR / 2;
-    const int kr0 = blockIdx.x * 32, no0 = blockIdx.y * 16;
-    const int i0 = blockIdx.z * HP;        // this block's rows of the (R+2) x (R+2) transform
+    const int kr0 = bx * 32, no0 = by * 16;
+    const int i0 = bz * HP;        // this block's rows of the (R+2) x (R+2) transform
     const int tid = threadIdx.x;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __rest
         const float am = __uint_as_float(*amax_bits);
         const int ex = ss_amax_exp(am);
         sc = ldexpf(1.f, 14 - ex);
-        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) *w_inv = ldexpf(1.f, ex - 14);
+        if (bx == 0 && by == 0 && bz == 0 && tid == 0) *w_inv = ldexpf(1.f, ex - 14);
     }
 #pragma unroll
     for (int i = 0; i < HP; ++i)
@@ -548,6 +548,34 @@ __global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __rest
                 dst[o + 2 * plane_u32] = l;
             }
         }
+}
+
+template <int R, bool F16 = false>
+__global__ __launch_bounds__(256) void wino_weight_x6_kernel(const float* __restrict__ w, int Cin, int Cout, int flip, int Npad,
+                                                             unsigned short* __restrict__ planes,
+                                                             const unsigned int* __restrict__ amax_bits = nullptr, float* __restrict__ w_inv = nullptr,
+                                                             int plain_l = 0) {
+    wino_weight_x6_body<R, F16>(w, Cin, Cout, flip, Npad, planes, amax_bits, w_inv, plain_l, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// the x3h Winograd weight planes of a recorded plan in ONE launch (wprep_batch.hip): a: w_cin, b: w_cout, c: flip, d: Npad, e: plain_l
+__global__ __launch_bounds__(256) void wino_weight_x6_batch_kernel(const SsWJob* __restrict__ jobs, const int* __restrict__ map) {
+    const SsWJob& j = jobs[map[blockIdx.x]];
+    const int l = blockIdx.x - j.blk0;
+    wino_weight_x6_body<4, true>(j.src, j.a, j.b, j.c, j.d, (unsigned short*)j.dst, j.amax, (float*)j.dst2, j.e,
+                                 l % j.gx, (l / j.gx) % j.gy, l / (j.gx * j.gy));
+}
+
+// record (ss_wprep_*) what the x3h weight fill launches: the maximum of the kernel tensor into w_inv[1], then the planes
+inline void wino_record_weight_jobs(const float* w, int w_cin, int w_cout, int flip, int Npad, int kr, unsigned short* planes, float* w_inv, int plain_l) {
+    SsWJob a{};
+    a.type = SS_WJ_AMAX; a.gx = 16; a.gy = 1; a.gz = 1;
+    a.src = w; a.n = (long)9 * w_cin * w_cout; a.dst = w_inv + 1;
+    ss_wrec_push(a);
+    SsWJob j{};
+    j.type = SS_WJ_WINO_H; j.gx = kr / 32; j.gy = Npad / 16; j.gz = 2;
+    j.src = w; j.a = w_cin; j.b = w_cout; j.c = flip; j.d = Npad; j.e = plain_l;
+    j.dst = planes; j.dst2 = w_inv; j.amax = (const unsigned int*)(w_inv + 1);
+    ss_wrec_push(j);
 }
 
 // y[n, R*ty+i, R*tx+j, c] (+)= act(bias + (A^T M A)_ij)
@@ -773,7 +801,9 @@ int fwd16_impl(const WinoProb& q, const TS* x, const float* w, int w_cin, int w_
     bool fill, fill2;
     float* w_inv = (float*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X3H_INV, wdet), 256, extra, &fill);
     planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X3H_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill2);
-    if (fill || fill2) {
+    if ((fill || fill2) && ss_wrec_on() && R == 4) {
+        wino_record_weight_jobs(w, w_cin, w_cout, flip, Npad, q.cin, planes, w_inv, 0);
+    } else if (fill || fill2) {
         (void)hipMemsetAsync(w_inv + 1, 0, 4, s);
         hipLaunchKernelGGL(amax_bits_kernel, dim3(256), dim3(256), 0, s, w, (long)9 * w_cin * w_cout, (unsigned int*)(w_inv + 1));
         SS_LAUNCH_CHECK();
@@ -829,6 +859,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
     if (q.bf16x3) {
         U = (float*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_UBF, wdet), (size_t)XI * q.cin * q.cout * 4, U, &fill);
         if (fill) {
+            if (ss_wrec_on()) ss_wrec_unbatched();
             hipLaunchKernelGGL((wino_weight_kernel<R, true>), dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, w, w_cin, w_cout, flip, U);
             SS_LAUNCH_CHECK();
         }
@@ -875,7 +906,9 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
             w_inv = (float*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X3H_INV, wdet), 256, extra, &fill);                              // [0]: 1/s_w, [1]: max|w| bits
             bool fill2;
             planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X3H_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill2);
-            if (fill || fill2) {
+            if ((fill || fill2) && ss_wrec_on() && R == 4) {
+            wino_record_weight_jobs(w, w_cin, w_cout, flip, Npad, q.cin, planes, w_inv, wide);
+            } else if (fill || fill2) {
             (void)hipMemsetAsync(w_inv + 1, 0, 4, s);
             hipLaunchKernelGGL(amax_bits_kernel, dim3(256), dim3(256), 0, s, w, (long)9 * w_cin * w_cout, (unsigned int*)(w_inv + 1));
             SS_LAUNCH_CHECK();
@@ -905,6 +938,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         } else {
         planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X6_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill);
         if (fill) {
+            if (ss_wrec_on()) ss_wrec_unbatched();          // (only the x3h operands are replayed from a recorded plan)
             hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
             SS_LAUNCH_CHECK();
         }
@@ -949,6 +983,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         const int Npad = ss_x6_npad(q.cout);
         planes = (unsigned short*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_X6_PLANES, wdet), (size_t)3 * XI * Npad * q.cin * 2, planes, &fill);
         if (fill) {
+            if (ss_wrec_on()) ss_wrec_unbatched();          // (only the x3h operands are replayed from a recorded plan)
             hipLaunchKernelGGL(wino_weight_x6_kernel<R>, dim3(q.cin / 32, Npad / 16, 2), dim3(256), 0, s, w, w_cin, w_cout, flip, Npad, planes);
             SS_LAUNCH_CHECK();
         }
@@ -958,6 +993,7 @@ int fwd_impl(const WinoProb& q, const float* x, const float* w, int w_cin, int w
         U = (float*)ss_wc_region(q.wc, ss_wc_tag(SS_WC_WINO_U32, wdet), (size_t)XI * q.cin * q.cout * 4, U, &fill);
         g.w = U;
         if (fill) {
+            if (ss_wrec_on()) ss_wrec_unbatched();
             hipLaunchKernelGGL((wino_weight_kernel<R, false>), dim3(g256((long)q.cin * q.cout)), dim3(256), 0, s, w, w_cin, w_cout, flip, U);
             SS_LAUNCH_CHECK();
         }
@@ -1191,4 +1227,10 @@ int ss_wino_conv_wgrad16(const WinoProb& q, int dtype, const void* x, const void
     if (dtype == SS_DTYPE_F16) return wgrad_impl<4, _Float16>(q, (const _Float16*)x, (const _Float16*)dy, dw, accumulate, ws, s);
     if (dtype == SS_DTYPE_BF16) return wgrad_impl<4, __bf16>(q, (const __bf16*)x, (const __bf16*)dy, dw, accumulate, ws, s);
     return SS_ERR_INVALID;
+}
+
+int ss_wbatch_launch_wino(const SsWJob* jobs, const int* map, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(wino_weight_x6_batch_kernel, dim3(nblocks), dim3(256), 0, s, jobs, map);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
 }

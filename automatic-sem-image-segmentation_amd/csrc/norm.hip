@@ -87,7 +87,10 @@ template <int V> __device__ __forceinline__ void stv(__bf16* p, const float (&o)
 // partial sums: part[((g*chunks + chunk)*C + c)*2 + {0,1}]
 // MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat) with g = dy * act'(y)
 // Thread = V consecutive channels x a strided set of pixels; CT = channel lanes (in units of V), PT = 256/CT.
-template <typename T, int MODE, int V>
+// ACC64 (the fused-finalize geometry: few, long chunks): the block-level tree runs in fp64 and the partial is STORED as fp64 -- with
+// <= 128 chunks per group the rounding of every fp32 partial (2^-24 relative, no longer averaged over hundreds of chunks) showed up
+// as 3 - 4 x the error of E[x^2] - E[x]^2 on low-variance channels (tools/norm_fuse_diag.py); `part` is then double[...].
+template <typename T, int MODE, int V, bool ACC64 = false>
 __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x, int x_cs,
                                                          const T* __restrict__ dy, int dy_cs,
                                                          const T* __restrict__ y, int y_cs,
@@ -99,7 +102,8 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x
                                                          int order = 0) {
     // MODE 1 with y == nullptr (relu / leaky relu without residual): the activation mask is recomputed from x with the forward's
     // expression (y > 0 <=> t > 0) -- one tensor read less in each of the two backward passes
-    __shared__ float red[2 * V][256];
+    typedef typename std::conditional<ACC64, double, float>::type RT;
+    __shared__ RT red[2 * V][256];
     const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;      // threads with pt >= PT (256 % CT leftovers) idle
     const int c = (blockIdx.y * CT + ct) * V;
     // order & 1: the workgroups walk the tensor from its END (last group, last chunk first): what the kernel before this one wrote or
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x
             for (int k = 0; k < 2 * V; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + q * CT];
     }
     if (pt == 0 && c < C) {
-        float* o = part + (((long)g * gridDim.x + bx) * C + c) * 2;
+        RT* o = (RT*)part + (((long)g * gridDim.x + bx) * C + c) * 2;
 #pragma unroll
         for (int v = 0; v < V; ++v) { o[2 * v] = red[2 * v][threadIdx.x]; o[2 * v + 1] = red[2 * v + 1][threadIdx.x]; }
     }
@@ -244,6 +248,7 @@ constexpr int NORM_FUSE_CH = 32, NORM_FUSE_MAX_CHUNKS = 128, NORM_FUSE_EXT_CHUNK
 
 struct NormFin {
     const float* part;          // [G][chunks][C][2] partial sums; nullptr: not fused (mean / rstd / sums come finalized)
+    int part64;                 // the partials are fp64 (norm_stats_kernel<..., ACC64>); 0: fp32 (a convolution epilogue's)
     int chunks, G;
     double P;                   // elements per (group, channel)
     float eps, momentum;
@@ -253,22 +258,26 @@ struct NormFin {
 };
 
 // Totals (sum, sum2) of group `g` for the block's channels [c0, c0 + nch): thread t < nch returns them; red = LDS, 512 doubles.
-__device__ __forceinline__ void fin_block_totals(const float* __restrict__ part, int chunks, int g, int C, int c0, int nch,
+__device__ __forceinline__ void fin_block_totals(const float* __restrict__ part, int part64, int chunks, int g, int C, int c0, int nch,
                                                  double* red /* LDS, 512 doubles */, double& T1, double& T2) {
     const int KL = 256 / nch;
     const int j = threadIdx.x % nch, kl = threadIdx.x / nch;
     double s1 = 0.0, s2 = 0.0;
     if (kl < KL && c0 + j < C) {
-        const float* b = part + (((long)g * chunks) * C + c0 + j) * 2;
+        const long b0 = (((long)g * chunks) * C + c0 + j) * 2;
         for (int k = kl; k < chunks; k += 4 * KL) {          // four loads in flight, same k order
-            float2 a[4];
+            double a0[4], a1[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int kk = k + u * KL;
-                a[u] = kk < chunks ? *(const float2*)(b + (long)kk * C * 2) : make_float2(0.f, 0.f);
+                a0[u] = 0.0; a1[u] = 0.0;
+                if (kk < chunks) {
+                    if (part64) { const double2 t = *(const double2*)((const double*)part + b0 + (long)kk * C * 2); a0[u] = t.x; a1[u] = t.y; }
+                    else { const float2 t = *(const float2*)(part + b0 + (long)kk * C * 2); a0[u] = t.x; a1[u] = t.y; }
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { s1 += a[u].x; s2 += a[u].y; }
+            for (int u = 0; u < 4; ++u) { s1 += a0[u]; s2 += a1[u]; }
         }
     }
     __syncthreads();          // (a previous use of red is over)
@@ -277,6 +286,39 @@ __device__ __forceinline__ void fin_block_totals(const float* __restrict__ part,
     T1 = 0.0; T2 = 0.0;
     if (threadIdx.x < nch)
         for (int k = 0; k < KL; ++k) { T1 += red[k * nch + threadIdx.x]; T2 += red[256 + k * nch + threadIdx.x]; }
+}
+
+// mean / rstd of group `g` for the block's channels [c0, c0 + nch) into fstat[0 / 1][channel - c0]; `publish`: also to global memory
+// (+ the BatchNorm moving averages).  norm_finalize_fwd's arithmetic.  Ends with a barrier: fstat is readable by every thread.
+__device__ __forceinline__ void fin_fwd_stats(const NormFin& fin, int g, int C, int c0, int nch, double* fred, float (*fstat)[NORM_FUSE_CH],
+                                              bool publish) {
+    double T1, T2;
+    fin_block_totals(fin.part, fin.part64, fin.chunks, g, C, c0, nch, fred, T1, T2);
+    if ((int)threadIdx.x < nch && c0 + (int)threadIdx.x < C) {
+        const int cc = c0 + threadIdx.x;
+        const double m = T1 / fin.P;
+        double var = T2 / fin.P - m * m;          // E[x^2] - E[x]^2 (keras.ops.moments, torch backend)
+        if (var < 0.0) var = 0.0;
+        const float muf = (float)m, rsf = (float)(1.0 / sqrt(var + (double)fin.eps));
+        fstat[0][threadIdx.x] = muf;
+        fstat[1][threadIdx.x] = rsf;
+        if (publish) {
+            fin.mean[(long)g * C + cc] = muf;
+            fin.rstd[(long)g * C + cc] = rsf;
+            if (fin.mm) {
+                fin.mm[cc] = fin.mm[cc] * fin.momentum + muf * (1.f - fin.momentum);
+                fin.mv[cc] = fin.mv[cc] * fin.momentum + (float)var * (1.f - fin.momentum);
+            }
+        }
+    }
+    __syncthreads();
+}
+// statistics-only calls (the apply pass belongs to a consuming convolution, engine.DeferredNorm) on tensors the fused form takes: the
+// SAME reduction as the apply kernels' prologue, so a deferred and a materialised norm see the same mean / rstd bits.  grid (channel blocks, G)
+__global__ __launch_bounds__(256) void norm_finalize_fused_kernel(NormFin fin, int C, int nch) {
+    __shared__ double fred[512];
+    __shared__ float fstat[2][NORM_FUSE_CH];
+    fin_fwd_stats(fin, blockIdx.y, C, blockIdx.x * nch, nch, fred, fstat, true);
 }
 
 // y = act((x-mean)*rstd*gamma + beta + residual)
@@ -304,27 +346,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
     __shared__ double fred[FIN ? 512 : 1];
     __shared__ float fstat[2][NORM_FUSE_CH];
     if constexpr (FIN) {          // consumer-side finalize: mean / rstd of this block's channels from the statistics partials
-        const int c0 = blockIdx.y * CT * V, nch = CT * V;
-        double T1, T2;
-        fin_block_totals(fin.part, fin.chunks, g, C, c0, nch, fred, T1, T2);
-        if ((int)threadIdx.x < nch && c0 + (int)threadIdx.x < C) {
-            const int cc = c0 + threadIdx.x;
-            const double m = T1 / fin.P;
-            double var = T2 / fin.P - m * m;          // E[x^2] - E[x]^2 (keras.ops.moments, torch backend): norm_finalize_fwd's arithmetic
-            if (var < 0.0) var = 0.0;
-            const float muf = (float)m, rsf = (float)(1.0 / sqrt(var + (double)fin.eps));
-            fstat[0][threadIdx.x] = muf;
-            fstat[1][threadIdx.x] = rsf;
-            if (blockIdx.x == 0) {
-                fin.mean[(long)g * C + cc] = muf;
-                fin.rstd[(long)g * C + cc] = rsf;
-                if (fin.mm) {
-                    fin.mm[cc] = fin.mm[cc] * fin.momentum + muf * (1.f - fin.momentum);
-                    fin.mv[cc] = fin.mv[cc] * fin.momentum + (float)var * (1.f - fin.momentum);
-                }
-            }
-        }
-        __syncthreads();
+        fin_fwd_stats(fin, g, C, blockIdx.y * CT * V, CT * V, fred, fstat, blockIdx.x == 0);
     }
     if (c < C && pt < PT) {
         const long gi = (long)g * C + c;
@@ -483,14 +505,14 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
         const int c0 = blockIdx.y * CT * V, nch = CT * V;
         const bool mine = (int)threadIdx.x < nch && c0 + (int)threadIdx.x < C;
         double T1, T2;
-        fin_block_totals(fin.part, fin.chunks, g, C, c0, nch, fred, T1, T2);
+        fin_block_totals(fin.part, fin.part64, fin.chunks, g, C, c0, nch, fred, T1, T2);
         if (mine) { fstat[0][threadIdx.x] = (float)(T1 / fin.P); fstat[1][threadIdx.x] = (float)(T2 / fin.P); }
         if (blockIdx.x == 0 && g == 0 && (fin.dgamma || fin.dbeta)) {
             // parameter gradients: the groups' raw totals summed in group order (norm_finalize_bwd + the rt loop of the unfused form)
             double tg = T1, tgx = T2;
             for (int gg = 1; gg < fin.G; ++gg) {
                 double A, B;
-                fin_block_totals(fin.part, fin.chunks, gg, C, c0, nch, fred, A, B);
+                fin_block_totals(fin.part, fin.part64, fin.chunks, gg, C, c0, nch, fred, A, B);
                 tg += A;
                 tgx += B;
             }
@@ -942,7 +964,9 @@ int pick_v16(int c, std::initializer_list<int> strides, std::initializer_list<co
 }
 
 size_t part_bytes(const ss_norm_desc* d) {
-    return ss_align_up((size_t)d->groups * norm_max_chunks(d->groups) * d->c * 2 * sizeof(float), 256);
+    const size_t a = (size_t)d->groups * norm_max_chunks(d->groups) * d->c * 2 * sizeof(float);
+    const size_t b = (size_t)d->groups * NORM_FUSE_MAX_CHUNKS * d->c * 2 * sizeof(double);          // the fused form's fp64 partials
+    return ss_align_up(a > b ? a : b, 256);
 }
 
 }  // namespace
@@ -980,7 +1004,8 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     int chunks = g.chunks;
     const double elems = (double)g.G * g.P * g.C;
     const bool ext_stats = d->x_stats && d->x_stats_chunks > 0;
-    const FuseGeom fz = y ? fuse_geom(d, V) : FuseGeom{};
+    // (the geometry of the statistics must not depend on whether y is wanted: a deferred norm and its materialised twin agree bit for bit)
+    const FuseGeom fz = fuse_geom(d, V);
     if (fz.ok && (!ext_stats || d->x_stats_chunks * (d->n / g.G) <= NORM_FUSE_EXT_CHUNKS)) {
         // consumer-side finalize: [statistics with the fused geometry ->] apply, which reduces the partials of its own channels
         if (ext_stats) {
@@ -991,17 +1016,22 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
             chunks = fz.chunks;
             SsProfScope prof("norm_stats_kernel<fwd>", 0.0, elems * sizeof(T), s);
             if (V == 4)
-                hipLaunchKernelGGL((norm_stats_kernel<T, 0, 4>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                hipLaunchKernelGGL((norm_stats_kernel<T, 0, 4, true>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
                                    0, 0.f, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, (float*)ws);
             else
-                hipLaunchKernelGGL((norm_stats_kernel<T, 0, 1>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                hipLaunchKernelGGL((norm_stats_kernel<T, 0, 1, true>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
                                    0, 0.f, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, (float*)ws);
             SS_LAUNCH_CHECK();
         }
-        const ApplyGeom ag = apply_geom_fused(g, fz);
         NormFin fin{};
-        fin.part = part; fin.chunks = chunks; fin.G = g.G; fin.P = (double)g.P; fin.eps = d->eps; fin.momentum = momentum;
+        fin.part = part; fin.part64 = ext_stats ? 0 : 1; fin.chunks = chunks; fin.G = g.G; fin.P = (double)g.P; fin.eps = d->eps; fin.momentum = momentum;
         fin.mean = mean; fin.rstd = rstd; fin.mm = moving_mean; fin.mv = moving_var;
+        if (!y) {          // statistics only
+            hipLaunchKernelGGL(norm_finalize_fused_kernel, dim3(fz.cblocks, g.G), dim3(256), 0, s, fin, g.C, fz.CT * V);
+            SS_LAUNCH_CHECK();
+            return SS_OK;
+        }
+        const ApplyGeom ag = apply_geom_fused(g, fz);
         SsProfScope prof("norm_apply_kernel", 0.0, elems * sizeof(T) * (residual ? 3 : 2), s);
         if (V == 4)
             hipLaunchKernelGGL((norm_apply_kernel<T, 4, true>), ag.grid, dim3(256), 0, s, x, d->x_cstride, gamma, beta, mean, rstd,
@@ -1118,16 +1148,16 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
         {
             SsProfScope prof("norm_stats_kernel<bwd>", 0.0, elems * sizeof(T) * (use_y ? 3 : 2), s);
             if (V == 4)
-                hipLaunchKernelGGL((norm_stats_kernel<T, 1, 4>), fgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+                hipLaunchKernelGGL((norm_stats_kernel<T, 1, 4, true>), fgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
                                    d->act, d->act_alpha, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, part, gamma, beta, 0);
             else
-                hipLaunchKernelGGL((norm_stats_kernel<T, 1, 1>), fgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
+                hipLaunchKernelGGL((norm_stats_kernel<T, 1, 1, true>), fgrid, dim3(256), 0, s, x, d->x_cstride, dy, dy_cstride, y, d->y_cstride, mean, rstd,
                                    d->act, d->act_alpha, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, part, gamma, beta, 0);
             SS_LAUNCH_CHECK();
         }
         const ApplyGeom ag = apply_geom_fused(g, fz);
         NormFin fin{};
-        fin.part = part; fin.chunks = fz.chunks; fin.G = g.G; fin.P = (double)g.P;
+        fin.part = part; fin.part64 = 1; fin.chunks = fz.chunks; fin.G = g.G; fin.P = (double)g.P;
         fin.dgamma = dgamma; fin.dbeta = dbeta; fin.acc_params = accumulate_params;
         SsProfScope prof("norm_bwd_apply_kernel", 0.0,
                          elems * sizeof(T) * ((use_y ? 3 : 2) + 1 + (accumulate_dx ? 1 : 0) + (dres ? (accumulate_dres ? 2 : 1) : 0)), s);

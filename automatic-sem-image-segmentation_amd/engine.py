@@ -10,6 +10,7 @@ Layout decisions (MI355X-first):
   exchange is a single bucketed all-reduce over the arena.
 """
 import ctypes
+import os
 
 import torch
 
@@ -17,6 +18,9 @@ from . import _lib as L
 
 _WS = {}
 _WS_RETIRED = []
+# 1 (default): a network's weight-derived operands are refreshed from ONE recorded plan per step (ParamArena._refresh_batched);
+# 0: layer by layer (measurement / A-B: the operands are bit-identical)
+WPREP_BATCH = os.environ.get("SS_WPREP_BATCH", "1") != "0"
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -537,6 +541,8 @@ class ParamArena:
         self.derived = []          # layers that keep operands derived from the weights (layers.Conv2D weight caches)
         self._derived_key = None
         self._refresh_stream = None   # side stream of a refresh_derived() whose kernels may still be reading the weights
+        self._wprep_plan = None       # recorded plan of the batched refresh (_refresh_batched)
+        self._wprep_unbatchable = None
 
     def touch(self):
         """The weight values changed behind torch's back (optimizer kernel, collective): caches derived from them are stale."""
@@ -556,6 +562,8 @@ class ParamArena:
         if key == self._derived_key:
             return
         self._derived_key = key
+        if WPREP_BATCH and self.device.type == "cuda" and self._refresh_batched(side):
+            return
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -576,6 +584,60 @@ class ParamArena:
             ev.record()
             sync["ev"] = ev
             sync["synced"].add(_stream().value or 0)
+
+    def _refresh_batched(self, side):
+        """The same refresh as ONE recorded plan (include/semseg_hip.h ss_wprep_*): the layers' fill-only calls are recorded once --
+        every operand they would launch becomes a job -- and every later refresh replays the plan as one launch per kind of operand
+        (weight maxima, tap-wise transposes, split planes, Winograd planes: ~6 launches instead of ~100 per network).  The plan is keyed
+        on the configuration and on the layers' cache users (a new descriptor geometry adds operands: recorded again); a recording
+        the library calls incomplete (an operand kind without a recorder hook, e.g. the x6 / fp32 arithmetic modes) is executed once
+        and the key is remembered as unbatchable.  Returns False when the per-layer path has to run."""
+        from . import _lib as L
+        lib = L.load()
+        sig = (L.CONFIG_EPOCH, tuple(len(l._wc["users"]) if getattr(l, "_wc", None) else 0 for l in self.derived))
+        if sig == self._wprep_unbatchable or not any(sig[1]):
+            return False
+        stream = side if side is not None else current_stream_obj()
+        if side is not None:
+            side.wait_stream(current_stream_obj())
+        plan = self._wprep_plan
+        ver = (self.weights_key(), L.CONFIG_EPOCH)
+        with torch.cuda.stream(stream):
+            if plan is None or plan["sig"] != sig:
+                L.check(lib.ss_wprep_record_begin(), "ss_wprep_record_begin")
+                try:
+                    dummy = dict(ev=None, synced=set())
+                    for layer in self.derived:
+                        layer.refresh_wcache(dummy)          # recorded, not launched (operands without a hook launch at once)
+                finally:
+                    nbytes, njobs, complete = ctypes.c_size_t(0), ctypes.c_int32(0), ctypes.c_int32(0)
+                    L.check(lib.ss_wprep_record_end(ctypes.byref(nbytes), ctypes.byref(njobs), ctypes.byref(complete)), "ss_wprep_record_end")
+                host = (ctypes.c_char * max(nbytes.value, 1))()
+                L.check(lib.ss_wprep_plan_write(ctypes.cast(host, ctypes.c_void_p), nbytes.value), "ss_wprep_plan_write")
+                dev = torch.frombuffer(host, dtype=torch.uint8).to(self.device)
+                plan = dict(sig=sig, host=host, dev=dev, bytes=nbytes.value, jobs=njobs.value)
+                if complete.value and njobs.value:
+                    self._wprep_plan = plan
+                else:
+                    self._wprep_plan, self._wprep_unbatchable = None, sig
+            else:
+                for layer in self.derived:                   # the directories stay as the recording built them: only the version moves
+                    st = getattr(layer, "_wc", None)
+                    if st:
+                        st["ver"] = ver
+            if plan["jobs"]:
+                L.check(lib.ss_wprep_run(ctypes.cast(plan["host"], ctypes.c_void_p), ctypes.c_void_p(plan["dev"].data_ptr()), plan["bytes"],
+                                         _stream()), "ss_wprep_run")
+            ev = torch.cuda.Event()
+            ev.record()
+            sync = dict(ev=ev, synced={_stream().value or 0})
+            for layer in self.derived:                       # ONE event for the arena: a consumer on another stream waits for the whole plan
+                st = getattr(layer, "_wc", None)
+                if st:
+                    st["sync"] = sync
+        if side is not None:
+            self._refresh_stream = side
+        return True
 
     def join_refresh(self):
         """Order the current stream behind a refresh_derived(side=...) still in flight: called by whoever WRITES the weights next

@@ -141,6 +141,23 @@ typedef struct ss_wcache {
 } ss_wcache;
 void ss_wcache_invalidate(ss_wcache* wc);
 
+/* Batched refresh of the weight caches of MANY layers (optional).  Refreshing the caches layer by layer (fill_only calls) is ~100 small
+ * launches per network and optimizer step -- weight maxima, tap-wise transposes, split planes, Winograd-transformed planes -- the same
+ * kernels on the same pointers every step.  A caller records them once and replays the recording as one launch per kind of operand:
+ *   ss_wprep_record_begin();                       the calling thread's fill_only calls now RECORD what they would launch
+ *   ... the fill_only calls of every layer ...     (operands the recorder does not know are launched at once and make it `incomplete`)
+ *   ss_wprep_record_end(&bytes, &n_jobs, &complete);
+ *   ss_wprep_plan_write(host_buf, bytes);          serialise the plan; the caller copies the bytes to device memory verbatim
+ *   ss_wprep_run(host_buf, dev_buf, bytes, stream) executes it: now (the recorded fills have not run yet) and -- if `complete` -- in
+ *                                                  place of the per-layer refresh of every later step, as long as the weight arena, the
+ *                                                  cache buffers, the descriptors that use them and the ss_config switches stay the same.
+ * The caches' directories are left as the recording built them (do not invalidate a cache that a plan refreshes).  Results are
+ * bit-identical to the per-layer refresh: the same kernel bodies run on the same operands.  Recording state is per thread. */
+int ss_wprep_record_begin(void);
+int ss_wprep_record_end(size_t* plan_bytes, int32_t* n_jobs, int32_t* complete);
+int ss_wprep_plan_write(void* plan_host, size_t bytes);
+int ss_wprep_run(const void* plan_host, const void* plan_dev, size_t bytes, void* stream);
+
 /* An "amax slot" is SS_AMAX_SLOT_BYTES of device memory: 16 uint32 words, one per 256-byte line (word index 64 * i); the value it
  * holds is the MAXIMUM of those words.  Producers (ss_norm_fwd / ss_norm_bwd, the scan inside the convolution passes) raise the
  * words with one atomic per workgroup, spread over the lines -- thousands of atomics on a single address serialise in L2.

@@ -106,3 +106,70 @@ def test_cache_is_dropped_by_touch_and_fills_once_per_version():
     y1 = fwd()
     assert layer._wc["c"].fills > fills
     assert torch.allclose(y1, 2 * y0, rtol=1e-5, atol=1e-6)
+
+
+def test_batched_refresh_replays_the_recorded_plan_bit_for_bit(monkeypatch):
+    """ParamArena._refresh_batched (include/semseg_hip.h ss_wprep_*): after a weight update the recorded plan -- one launch per kind of
+    operand -- must leave every layer's cache buffer byte for byte what the layer-by-layer refresh leaves, for a generator-like stack
+    (stride-2 / transposed gather convolutions, reflect-padded Winograd trunk convolutions, a 4 x 4 PatchGAN layer), over several weight
+    versions; the plan is recorded once and replayed afterwards (6 launches per refresh instead of one set per layer)."""
+    E, LY, L = _mods()
+    dev = torch.device("cuda:0")
+    monkeypatch.setattr(LY, "WEIGHT_CACHE", True)
+    specs = [("down", 3, 64, 128, 2, "same", False), ("t1", 3, 128, 128, 1, ("reflect", 1), False), ("t2", 3, 128, 128, 1, ("reflect", 1), False),
+             ("up", 3, 128, 64, 2, "same", True), ("pg", 4, 64, 128, 2, "same", False)]
+
+    def build():
+        arena = E.ParamArena(dev)
+        layers = [LY.Conv2D(arena, nm, k, ci, co, stride=s, padding=p, transposed=t) for nm, k, ci, co, s, p, t in specs]
+        arena.materialize()
+        return arena, layers
+
+    def step(arena, layers, x_cpu):
+        tape = E.Tape()
+        x = E.Act(x_cpu.to(dev), requires_grad=True)
+        h = layers[0](tape, x)
+        h = layers[2](tape, layers[1](tape, h))
+        y = layers[3](tape, h)
+        z = layers[4](tape, y)
+        gt, _ = z.grad_target()
+        gt.t.fill_(0.01)
+        z.grad_init = True
+        arena.zero_grad()
+        tape.backward()
+        return y.dense().cpu()
+
+    g = torch.Generator().manual_seed(3)
+    x_cpu = torch.rand((1, 64, 64, 64), generator=g) * 2 - 1
+    weights = [[(torch.rand(tuple(a.views[f"{nm}/kernel"].shape), generator=g) - 0.5) * 0.1 for nm, *_ in specs] for a in [build()[0]] for _ in range(3)]
+    outs, bufs, plans = {}, {}, {}
+    for mode in (False, True):
+        monkeypatch.setattr(E, "WPREP_BATCH", mode)
+        arena, layers = build()
+        for v, ws in enumerate(weights):
+            for (nm, *_), wv in zip(specs, ws):
+                arena[f"{nm}/kernel"].copy_(wv)
+            arena.refresh_derived()          # version 0: nothing is cached yet (no users); later versions refresh what the last step used
+            outs[(mode, v)] = step(arena, layers, x_cpu)
+            torch.cuda.synchronize()
+            arena.touch()
+            arena.refresh_derived()          # the refresh under test: same weights, new version
+            torch.cuda.synchronize()
+            # the entries of every layer's cache directory (bytes between / behind them are never written): small entries hold one word
+            # (a weight maximum; the Winograd entry a second one that the planes' kernel writes), the others whole operand planes
+            bufs[(mode, v)] = []
+            for l in layers:
+                if l._wc:
+                    c, raw = l._wc["c"], l._wc["buf"].cpu()
+                    for i in range(c.count):
+                        off, nb = int(c.entry[i].offset), int(c.entry[i].bytes)
+                        bufs[(mode, v)].append(raw[off:off + (nb if nb > 256 else 4)].clone())
+            outs[(mode, v, "again")] = step(arena, layers, x_cpu)
+        plans[mode] = arena._wprep_plan
+    assert plans[False] is None and plans[True] is not None and plans[True]["jobs"] >= 10, "the batched refresh did not record a plan"
+    for v in range(3):
+        assert torch.equal(outs[(False, v)], outs[(True, v)]) and torch.equal(outs[(False, v, "again")], outs[(True, v, "again")])
+        assert torch.equal(outs[(True, v)], outs[(True, v, "again")]), "refreshed operands changed the result of unchanged weights"
+        assert len(bufs[(False, v)]) == len(bufs[(True, v)]) >= 4
+        for a, b in zip(bufs[(False, v)], bufs[(True, v)]):
+            assert torch.equal(a, b), f"weight version {v}: a cache buffer differs between the recorded plan and the per-layer refresh"

@@ -463,15 +463,22 @@ class CycleGanModel:
                     optimizers={self._OPTS[nm]: dict(learning_rate=float(o.learning_rate), beta_1=float(o.beta_1), beta_2=float(o.beta_2))
                                 for nm in self._NETS for o in [getattr(self, self._OPTS[nm])] if o is not None})
 
-    def wait_saved(self):
-        """Join a ``save(..., background=True)`` still being written; re-raises what its writer raised."""
+    def wait_saved(self, reraise=True):
+        """Join a ``save(..., background=True)`` still being written.  reraise = True: re-raises what its writer raised; False: a
+        failed background write (an intermediate checkpoint: disk full, converter hiccup) is reported as a warning and returned --
+        it must not cost the caller the save it is about to make."""
         t = getattr(self, "_saver", None)
-        if t is not None:
-            t.join()
-            self._saver = None
-            err, self._saver_error = getattr(self, "_saver_error", None), None
-            if err is not None:
+        if t is None:
+            return None
+        t.join()
+        self._saver = None
+        err, self._saver_error = getattr(self, "_saver_error", None), None
+        if err is not None:
+            if reraise:
                 raise err
+            import warnings
+            warnings.warn(f"a background checkpoint could not be written ({err!r}); training state is unaffected", stacklevel=2)
+        return err
 
     def save(self, path, background=False):
         """``model.save('…/model.keras')`` (CycleGAN.py:203-204,221): a Keras-3 archive (zip of config.json, metadata.json and
@@ -479,8 +486,9 @@ class CycleGanModel:
         ending in ``.npz`` writes the plain-numpy form instead (variable names of this framework).
         background = True (the per-epoch checkpoints of ``start_training``, CycleGAN.py:203-205): the weights and optimizer slots are
         copied to the host NOW (1.2 GB: what the file will hold is this moment's state), the archive is written by a thread while the
-        next epoch trains; the next save / ``wait_saved`` joins it."""
-        self.wait_saved()
+        next epoch trains; the next save / ``wait_saved`` joins it (a failure of THAT earlier write is warned about, not raised: this
+        save still happens)."""
+        self.wait_saved(reraise=False)
         if path.endswith(".npz"):
             arrays = {}
             for nm in self._NETS:

@@ -494,10 +494,10 @@ def filter_gan_masks(img_path, msk_path, out_path, threshold_method=threshold_li
         for job in jobs:
             _filter_one(job)
         return
-    import multiprocessing as mp
-    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
-        for _ in pool.imap_unordered(_filter_one, jobs, chunksize=max(1, len(jobs) // (8 * workers))):
-            pass
+    pool = JobPool(_filter_one, min(workers, len(jobs)))
+    for job in jobs:
+        pool.submit(job, in_flight=8 * workers)
+    pool.close()
 
 
 WORKFLOW_TREE = ("1_WGAN/Output_Images", "1_WGAN/Models",
@@ -615,6 +615,79 @@ def default_workers(limit=32):
     """Worker processes for the independent host jobs of the workflow (mask placement, mask filtering, the scoring sweep): the usable
     cores less one for the dispatching process, at most ``limit``."""
     return max(1, min(limit, usable_cores() - 1))
+
+
+class JobPool:
+    """Worker PROCESSES (spawn context) for the independent host jobs of the workflow, with loss detection: a worker that
+    dies (OOM kill under a cgroup limit) makes ``concurrent.futures`` raise BrokenProcessPool instead of blocking forever as
+    ``multiprocessing.Pool`` does -- the jobs not yet finished are then run inline by the caller's process, as is everything submitted
+    afterwards; so is everything when the pool cannot start (spawn re-imports ``__main__``: a caller's script without an
+    ``if __name__ == "__main__":`` guard fails there).  Jobs must be idempotent (they write their own output files).  workers <= 1:
+    inline from the start."""
+
+    def __init__(self, fn, workers):
+        self.fn, self.pending, self.results, self.ex = fn, [], [], None
+        if workers > 1:
+            import multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+            try:
+                self.ex = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn"))
+            except (OSError, ValueError):
+                self.ex = None
+
+    def _inline_rest(self, why):
+        import warnings
+        warnings.warn(f"worker processes lost ({why!r}): the remaining jobs run in this process", stacklevel=3)
+        ex, self.ex = self.ex, None
+        try:
+            ex.shutdown(wait=False, cancel_futures=True)
+        except Exception:          # noqa: BLE001
+            pass
+        rest, self.pending = self.pending, []
+        for _, job in rest:
+            self.results.append(self.fn(job))
+
+    def submit(self, job, in_flight=None):
+        """Queue one job; in_flight: block until at most that many are unfinished (bounds what the queue holds)."""
+        from concurrent.futures.process import BrokenProcessPool
+        if self.ex is None:
+            self.results.append(self.fn(job))
+            return
+        try:
+            self.pending.append((self.ex.submit(self.fn, job), job))
+        except (BrokenProcessPool, RuntimeError) as e:
+            self.pending.append((None, job))
+            self._inline_rest(e)
+            return
+        if in_flight is not None:
+            self.drain(in_flight)
+
+    def drain(self, keep=0):
+        from concurrent.futures.process import BrokenProcessPool
+        while self.ex is not None and len(self.pending) > keep:
+            fut, job = self.pending[0]
+            try:
+                self.results.append(fut.result())
+                self.pending.pop(0)
+            except BrokenProcessPool as e:
+                self._inline_rest(e)
+
+    def close(self):
+        self.drain(0)
+        if self.ex is not None:
+            self.ex.shutdown(wait=True)
+            self.ex = None
+        return self.results
+
+
+def _jobpool_selftest_job(arg):
+    """Test hook of JobPool (tests/test_host_cpu.py): "die" kills the WORKER process it runs in (what an OOM kill does); inline it survives."""
+    import multiprocessing as mp
+    if arg == "die":
+        if mp.current_process().name != "MainProcess":
+            os._exit(1)
+        return "survived"
+    return arg * 2
 
 
 def prefetch(fetch, keys, depth=4, workers=2):

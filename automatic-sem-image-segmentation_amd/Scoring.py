@@ -130,9 +130,11 @@ def calculate_iou(predictions, ground_truths, watershed=True, workers=1):
     n = float(len(ground_truths))
     jobs = [(p, g, watershed) for p, g in zip(predictions, ground_truths)]
     if workers > 1 and len(jobs) > 1:
-        import multiprocessing as mp
-        with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
-            per_image = pool.map(_sweep_one, jobs)
+        # (results come back in submission order; a lost worker process is noticed and its images are swept inline: HelperFunctions.JobPool)
+        pool = HF.JobPool(_sweep_one, min(workers, len(jobs)))
+        for job in jobs:
+            pool.submit(job)
+        per_image = pool.close()
     else:
         per_image = [_sweep_one(j) for j in jobs]
     whole, inst_all, inst_f, youden = [0.0] * 11, [0.0] * 11, [0.0] * 11, [0.0] * 11

@@ -79,7 +79,13 @@ class ImageDataset:
     def _tile(self, info, is_mask):
         if self.cache_limit_bytes <= 0 or (not is_mask and self.type == 'train' and self.use_brightness_and_contrast_augmentation):
             return self._decode(info, is_mask)          # off, or a random contrast window per read
-        key = (info['mask_path' if is_mask else 'image_path'], is_mask)
+        path = info['mask_path' if is_mask else 'image_path']
+        try:          # the file's identity and the decode parameters are part of the key: a rewritten file or another contrast window re-decodes
+            stt = os.stat(path)
+            stamp = (stt.st_mtime_ns, stt.st_size)
+        except OSError:
+            stamp = None
+        key = (path, is_mask, stamp, None if is_mask else tuple(self.contrast_optimization_range or ()))
         tile = self._cache.get(key)
         if tile is None:
             tile = self._decode(info, is_mask)
@@ -256,7 +262,7 @@ class UNetModel:
         if LY.SYNC_BN is not None:
             return False
         shp = self._shape_of(batch[0])
-        if len(shp) != 4 or self._shape_of(batch[1]) != shp:
+        if len(shp) != 4 or self._shape_of(batch[1]) != shp or shp[3] != 1:          # the static buffers are one-channel: others stay eager
             return False
         return True
 

@@ -734,10 +734,8 @@ class WGAN:
         # affinity and cgroup quota -- less one; 1 = inline), so 1 000 masks take a minute instead of the better part of an hour.
         from . import HelperFunctions
         workers = int(os.environ.get("SS_MASK_WORKERS", HelperFunctions.default_workers()))
-        pool, pending = None, []
-        if workers > 1 and no_of_images >= 4:
-            import multiprocessing as mp
-            pool = mp.get_context("spawn").Pool(workers)
+        # (HelperFunctions.JobPool: a worker process that dies is noticed and its masks are placed inline instead of hanging the step)
+        pool = HelperFunctions.JobPool(_place_job, workers if (workers > 1 and no_of_images >= 4) else 1)
         try:
             for i in range(no_of_images):
                 count = random.randint(min_no_of_particles, max_no_of_particles) if grid_type not in ('HEXAGONAL', 'CUBIC') else 0
@@ -763,18 +761,9 @@ class WGAN:
                     rotations = np.zeros(count)
                 job = (ctor, self._sample_particles(count), np.asarray(pos_y), np.asarray(pos_x), np.asarray(rotations), np.asarray(scalings),
                        max_overlap, os.path.join(self.generate_dir, '{:05d}.tif'.format(i)))
-                if pool is None:
-                    _place_job(job)
-                else:
-                    pending.append(pool.apply_async(_place_job, (job,)))
-                    while len(pending) > 3 * workers:          # bound what is in flight (a job carries ~12 MB of particles)
-                        pending.pop(0).get()
-            for r in pending:
-                r.get()
+                pool.submit(job, in_flight=3 * workers)          # bound what is in flight (a job carries ~12 MB of particles)
         finally:
-            if pool is not None:
-                pool.close()
-                pool.join()
+            pool.close()
 
         # five random files for testing (WassersteinGAN.py:539-545)
         input_files = [f for f in os.listdir(self.generate_dir) if '.tif' in f or '.png' in f or '.bmp' in f]

@@ -728,17 +728,16 @@ class ParamArena:
                 if c == 0:
                     bucket_of[n]["remaining"] -= 1
             return
-        touched = []
+        touched = {}
         for n in names:
             c = pending.get(n, 0) - 1
             pending[n] = c
             bk = bucket_of[n]
             if c == 0:
                 bk["remaining"] -= 1
-            if bk not in touched:
-                touched.append(bk)
+            touched[id(bk)] = bk
         st = current_stream_obj() if self.device.type == "cuda" else None
-        for bk in touched:
+        for bk in touched.values():
             if not bk["active"] or bk["fired"]:
                 continue
             if bk["remaining"] == 0:
@@ -749,7 +748,13 @@ class ParamArena:
                 bk["fired"] = True
                 self.works.append(self._fire(bk))
             elif st is not None:
-                bk["events"][st] = st.record_event()
+                # one reusable event per (bucket, stream), re-recorded: a fresh event per call was several hundred creations per step
+                pool = bk.setdefault("event_pool", {})
+                ev = pool.get(st)
+                if ev is None:
+                    ev = pool[st] = torch.cuda.Event()
+                ev.record(st)
+                bk["events"][st] = ev
 
     def _fire(self, b):
         """Launch the exchange of one finished bucket behind the current stream.  Dual-chain steps (CycleGAN._train_step_dual) set

@@ -516,3 +516,21 @@ def test_prefetch_keeps_order_contents_and_errors():
     assert sorted(set(seen)) == sorted(seen) and max(seen) <= 13 + 4          # never more than `depth` ahead
     assert list(HF.prefetch(lambda k: -k, range(5), depth=0)) == [0, -1, -2, -3, -4]
     assert list(HF.prefetch(lambda k: k, [], depth=4)) == []
+
+
+def test_job_pool_survives_a_killed_worker_process():
+    """multiprocessing.Pool loses a task whose worker dies and blocks forever; HelperFunctions.JobPool (concurrent.futures,
+    spawn context) notices the broken pool and runs what is unfinished in the calling process."""
+    import warnings
+    HF = importlib.import_module(BASE + ".HelperFunctions")
+    pool = HF.JobPool(HF._jobpool_selftest_job, 2)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for job in (1, 2, "die", 3, 4, 5):
+            pool.submit(job, in_flight=4)
+        res = pool.close()
+    assert sorted(r for r in res if r != "survived") == [2, 4, 6, 8, 10] and res.count("survived") == 1, res
+    assert any("worker processes lost" in str(x.message) for x in w)
+    inline = HF.JobPool(HF._jobpool_selftest_job, 1)          # workers <= 1: no processes at all
+    inline.submit("die")
+    assert inline.close() == ["survived"]

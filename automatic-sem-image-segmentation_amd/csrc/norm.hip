@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x
                                                          int C, long P, long pix_per_chunk, int CT, int PT,
                                                          float* __restrict__ part,
                                                          const float* __restrict__ rgamma = nullptr, const float* __restrict__ rbeta = nullptr,
-                                                         int order = 0) {
+                                                         int order = 0, float* __restrict__ pivot = nullptr) {
     // MODE 1 with y == nullptr (relu / leaky relu without residual): the activation mask is recomputed from x with the forward's
     // expression (y > 0 <=> t > 0) -- one tensor read less in each of the two backward passes
     typedef typename std::conditional<ACC64, double, float>::type RT;
@@ -124,6 +124,21 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x
 #pragma unroll
         for (int v = 0; v < V; ++v) { gm[v] = 1.f; bt[v] = 0.f; }
         if (MODE == 1) { ldv<V>(mean + (long)g * C + c, mu); ldv<V>(rstd + (long)g * C + c, rs); }
+        // ACC64 forward statistics are taken of x - x0 with x0 = the group's FIRST pixel of the channel (pivot[g][c], published by chunk 0):
+        // a channel that is constant over the group -- a constant input image stays constant through the whole network -- then has the
+        // sums 0 and 0 EXACTLY, i.e. mean = x0 and variance 0 whatever the summation order (plain sums of identical values round at
+        // 3x, 5x, ...; the ReLU behind beta = 0 turns that rounding's sign into a whole channel's mask), and E[d^2] - E[d]^2 loses
+        // nothing to cancellation when |mean| >> the spread
+        float x0[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) x0[v] = 0.f;
+        if (ACC64 && MODE == 0 && pivot) {
+            ldv<V>(x + base * x_cs + c, x0);
+            if (bx == 0 && pt == 0) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) pivot[(long)g * C + c + v] = x0[v];
+            }
+        }
         const bool recompute = MODE == 1 && act != SS_ACT_NONE && y == nullptr;
         if (recompute) { if (rgamma) ldv<V>(rgamma + c, gm); ldv<V>(rbeta + c, bt); }
         const bool relu = act == SS_ACT_RELU;
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* __restrict__ x
                 ldv<V>(x + (base + p) * x_cs + c, xv);
                 if (MODE == 0) {
 #pragma unroll
-                    for (int v = 0; v < V; ++v) { s1[v] += xv[v]; s2[v] = fmaf(xv[v], xv[v], s2[v]); }
+                    for (int v = 0; v < V; ++v) { const float dv = ACC64 ? xv[v] - x0[v] : xv[v]; s1[v] += dv; s2[v] = fmaf(dv, dv, s2[v]); }
                 } else {
                     float gv[V];
                     ldv<V>(dy + (base + p) * dy_cs + c, gv);
@@ -249,6 +264,7 @@ constexpr int NORM_FUSE_CH = 32, NORM_FUSE_MAX_CHUNKS = 128, NORM_FUSE_EXT_CHUNK
 struct NormFin {
     const float* part;          // [G][chunks][C][2] partial sums; nullptr: not fused (mean / rstd / sums come finalized)
     int part64;                 // the partials are fp64 (norm_stats_kernel<..., ACC64>); 0: fp32 (a convolution epilogue's)
+    const float* pivot;         // forward, fp64 partials: they are sums of x - pivot[g][c] (nullptr: of x)
     int chunks, G;
     double P;                   // elements per (group, channel)
     float eps, momentum;
@@ -296,8 +312,9 @@ __device__ __forceinline__ void fin_fwd_stats(const NormFin& fin, int g, int C, 
     fin_block_totals(fin.part, fin.part64, fin.chunks, g, C, c0, nch, fred, T1, T2);
     if ((int)threadIdx.x < nch && c0 + (int)threadIdx.x < C) {
         const int cc = c0 + threadIdx.x;
-        const double m = T1 / fin.P;
-        double var = T2 / fin.P - m * m;          // E[x^2] - E[x]^2 (keras.ops.moments, torch backend)
+        const double md = T1 / fin.P;                                                     // mean of x - pivot
+        const double m = (fin.pivot ? (double)fin.pivot[(long)g * C + cc] : 0.0) + md;
+        double var = T2 / fin.P - md * md;          // E[d^2] - E[d]^2 = E[x^2] - E[x]^2 (keras.ops.moments, torch backend)
         if (var < 0.0) var = 0.0;
         const float muf = (float)m, rsf = (float)(1.0 / sqrt(var + (double)fin.eps));
         fstat[0][threadIdx.x] = muf;
@@ -892,9 +909,9 @@ inline ApplyGeom apply_geom(const NormGeom& g, int V) {
 }
 // geometry of the fused-finalize form (see NormFin): channel blocks of <= NORM_FUSE_CH channels, <= NORM_FUSE_MAX_CHUNKS pixel chunks
 struct FuseGeom { bool ok; int CT, PT, cblocks, chunks; long pix_per_chunk; };
-inline FuseGeom fuse_geom(const ss_norm_desc* d, int V) {
+inline FuseGeom fuse_geom(const ss_norm_desc* d, int V, int pass_bit = 1) {
     FuseGeom f{};
-    if (!ss_tuning().norm_fuse_fin) return f;
+    if (!(ss_tuning().norm_fuse_fin & pass_bit)) return f;          // bit 0: forward, bit 1: backward
     const int G = d->groups;
     const long P = (long)d->n * d->h * d->w / G;
     if ((long)d->n * d->h * d->w * d->c > NORM_FUSE_ELEMS) return f;
@@ -963,9 +980,12 @@ int pick_v16(int c, std::initializer_list<int> strides, std::initializer_list<co
     return 4;
 }
 
+size_t fused_part_bytes(const ss_norm_desc* d) {          // the fused form's fp64 partials; its pivots ([G][C] floats) follow
+    return ss_align_up((size_t)d->groups * NORM_FUSE_MAX_CHUNKS * d->c * 2 * sizeof(double), 256);
+}
 size_t part_bytes(const ss_norm_desc* d) {
     const size_t a = (size_t)d->groups * norm_max_chunks(d->groups) * d->c * 2 * sizeof(float);
-    const size_t b = (size_t)d->groups * NORM_FUSE_MAX_CHUNKS * d->c * 2 * sizeof(double);          // the fused form's fp64 partials
+    const size_t b = fused_part_bytes(d) + ss_align_up((size_t)d->groups * d->c * sizeof(float), 256);
     return ss_align_up(a > b ? a : b, 256);
 }
 
@@ -1008,24 +1028,26 @@ int norm_fwd_t(const ss_norm_desc* d, const T* x, const float* gamma, const floa
     const FuseGeom fz = fuse_geom(d, V);
     if (fz.ok && (!ext_stats || d->x_stats_chunks * (d->n / g.G) <= NORM_FUSE_EXT_CHUNKS)) {
         // consumer-side finalize: [statistics with the fused geometry ->] apply, which reduces the partials of its own channels
+        float* pivot = nullptr;
         if (ext_stats) {
             part = (const float*)d->x_stats;
             chunks = d->x_stats_chunks * (d->n / g.G);
         } else {
             const dim3 sgrid(fz.chunks, fz.cblocks, g.G);
             chunks = fz.chunks;
+            pivot = (float*)((char*)ws + fused_part_bytes(d));
             SsProfScope prof("norm_stats_kernel<fwd>", 0.0, elems * sizeof(T), s);
             if (V == 4)
                 hipLaunchKernelGGL((norm_stats_kernel<T, 0, 4, true>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                                   0, 0.f, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, (float*)ws);
+                                   0, 0.f, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, (float*)ws, nullptr, nullptr, 0, pivot);
             else
                 hipLaunchKernelGGL((norm_stats_kernel<T, 0, 1, true>), sgrid, dim3(256), 0, s, x, d->x_cstride, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                                   0, 0.f, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, (float*)ws);
+                                   0, 0.f, g.C, g.P, fz.pix_per_chunk, fz.CT, fz.PT, (float*)ws, nullptr, nullptr, 0, pivot);
             SS_LAUNCH_CHECK();
         }
         NormFin fin{};
         fin.part = part; fin.part64 = ext_stats ? 0 : 1; fin.chunks = chunks; fin.G = g.G; fin.P = (double)g.P; fin.eps = d->eps; fin.momentum = momentum;
-        fin.mean = mean; fin.rstd = rstd; fin.mm = moving_mean; fin.mv = moving_var;
+        fin.mean = mean; fin.rstd = rstd; fin.mm = moving_mean; fin.mv = moving_var; fin.pivot = pivot;
         if (!y) {          // statistics only
             hipLaunchKernelGGL(norm_finalize_fused_kernel, dim3(fz.cblocks, g.G), dim3(256), 0, s, fin, g.C, fz.CT * V);
             SS_LAUNCH_CHECK();
@@ -1142,7 +1164,7 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
     float* part = (float*)ws;
     float* sums = (float*)((char*)ws + part_bytes(d));
     const double elems = (double)g.G * g.P * g.C;
-    const FuseGeom fz = fuse_geom(d, V);
+    const FuseGeom fz = fuse_geom(d, V, 2);
     if (fz.ok) {          // consumer-side finalize: statistics with the fused geometry -> apply, which reduces the partials of its own channels
         const dim3 fgrid(fz.chunks, fz.cblocks, g.G);
         {

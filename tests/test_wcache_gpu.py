@@ -156,14 +156,15 @@ def test_batched_refresh_replays_the_recorded_plan_bit_for_bit(monkeypatch):
             arena.refresh_derived()          # the refresh under test: same weights, new version
             torch.cuda.synchronize()
             # the entries of every layer's cache directory (bytes between / behind them are never written): small entries hold one word
-            # (a weight maximum; the Winograd entry a second one that the planes' kernel writes), the others whole operand planes
+            # (a weight maximum; the Winograd entry a second one that the planes' kernel writes), the others operand planes
             bufs[(mode, v)] = []
             for l in layers:
                 if l._wc:
                     c, raw = l._wc["c"], l._wc["buf"].cpu()
                     for i in range(c.count):
                         off, nb = int(c.entry[i].offset), int(c.entry[i].bytes)
-                        bufs[(mode, v)].append(raw[off:off + (nb if nb > 256 else 4)].clone())
+                        # (plane entries are sized for three 16-bit planes; the x3h arithmetic writes two)
+                        bufs[(mode, v)].append(raw[off:off + (nb // 3 * 2 if nb > 256 else 4)].clone())
             outs[(mode, v, "again")] = step(arena, layers, x_cpu)
         plans[mode] = arena._wprep_plan
     assert plans[False] is None and plans[True] is not None and plans[True]["jobs"] >= 10, "the batched refresh did not record a plan"

@@ -26,7 +26,8 @@ def rel(a, b):
     return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-for kind, c, shp, act, use_res, off in (("instance", 4, (2, 64, 64), "relu", False, 0.3), ("instance", 4, (2, 64, 64), "relu", False, 3.0),
+for kind, c, shp, act, use_res, off in (("instance", 4, (4, 64, 64), "relu", False, 0.3), ("instance", 4, (3, 64, 64), "relu", False, 0.3), ("instance", 8, (4, 64, 64), "relu", False, 0.3),
+                                         ("instance", 4, (2, 64, 64), "relu", False, 0.3), ("instance", 4, (2, 64, 64), "relu", False, 3.0),
                                          ("instance", 256, (1, 128, 128), "relu", False, 0.3), ("instance", 256, (1, 128, 128), None, True, 0.3),
                                          ("batch", 51, (1, 256, 256), "relu", False, 0.5), ("batch", 17, (2, 64, 64), "relu", False, 0.5),
                                          ("instance", 128, (1, 256, 256), "relu", False, 0.3), ("instance", 64, (2, 128, 128), "relu", False, 1.0)):
@@ -36,7 +37,7 @@ for kind, c, shp, act, use_res, off in (("instance", 4, (2, 64, 64), "relu", Fal
     res = torch.randn((n, h, w, c), generator=g) if use_res else None
     gam = torch.rand(c, generator=g) + 0.5; bet = torch.rand(c, generator=g) - 0.5
     T = truth(x, gy, gam, bet, kind, act, res)
-    for fuse in (0, 1):
+    for fuse in (0, 1, 2, 3):
         with L.config(norm_fuse_fin=fuse):
             arena = E.ParamArena(dev); layer = LY.Norm(arena, "n", c, kind); arena.materialize()
             arena["n/gamma"].copy_(gam); arena["n/beta"].copy_(bet)

@@ -173,6 +173,8 @@ class UNetModel:
         # measured: 36.5 ms per step without, 37.1 - 37.3 with (the refresh of ~100 small layers competes with the chain's first, small
         # layers): opt-in here, default in the CycleGAN step
         self.refresh_side_stream = os.environ.get("SS_UNET_REFRESH_STREAM", "0") == "1"
+        # the same refresh as ONE recorded plan in front of the chain on the chain's own stream (no event, no second stream)
+        self.refresh_inline = os.environ.get("SS_UNET_REFRESH_INLINE", "0") == "1"
         # sync_metrics = False: train_step returns {} and leaves the three scalars on the device (no device->host read), so the caller
         # can issue it on a stream of its own beside other work; side_stream_index = which of engine.side_streams the weight gradients take
         self.sync_metrics = True
@@ -228,6 +230,8 @@ class UNetModel:
                 tape.branch_streams = [streams[i] for i in idx[1:]]
             if self.refresh_side_stream:          # the layers' weight-derived operands beside the first layers, not inside the chain
                 self.net.arena.refresh_derived(side_streams(x.device, 7)[6])
+        if self.refresh_inline and not self.refresh_side_stream and x.device.type == "cuda":
+            self.net.arena.refresh_derived()          # the recorded plan (engine.ParamArena._refresh_batched) in front of the chain, on its stream
         p = self.net(x, True, tape)
         losses.weighted_bce(y, p, self.weighting, self.loss_scale, self._out3)
         self.net.zero_grad()

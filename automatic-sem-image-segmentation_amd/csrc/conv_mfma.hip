@@ -435,7 +435,12 @@ int ss_launch_gconv_mfma(const GConvParams& p, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // FAST: float4-aligned operands, grid width >= 32: the pixel coordinates of this thread's rows advance
 // incrementally (no divisions in the loop) and all global loads are branch-free (clamped address + select).
-template <int BM, int BN, bool FAST>
+// X6: the contraction on the bf16 matrix cores with the exact three-piece split (conv_mfma_x6.hip's arithmetic: six products, dropped
+// terms <= 2^-26) formed IN REGISTERS from the same fp32 LDS tiles -- the shapes wgrad_x6_kernel does not take (channel counts that
+// are not multiples of 32 / unaligned views: the MultiResUNet's odd widths) ran on v_mfma_f32_32x32x2_f32 at 1/16 of the 16-bit rate.
+// A lane's fragment for v_mfma_f32_32x32x16_bf16 is 8 consecutive k of its row / column: the same 8 LDS reads per K = 16 the fp32
+// instruction needed, then 4 x ss_split3x2.
+template <int BM, int BN, bool FAST, bool X6 = false>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA, int vecB) {
     using C = Cfg<BM, BN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -647,6 +652,43 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WGradParams p, int vecA
         if (c + 1 < nchunks) load_tiles(ps + (long)(c + 1) * C::BK);
         const float* Ab = As + buf * C::BK * C::LDAT + lh * C::LDAT + wm * C::WM + l31;
         const float* Bb = Bs + buf * C::BK * C::LDB + lh * C::LDB + wn * C::WN + l31;
+        if constexpr (X6) {
+            typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+            typedef unsigned int wu32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int s16 = 0; s16 < C::BK / 16; ++s16) {
+                // lane (l31, lh): k = 16 s16 + 8 lh + j, j = 0..7 (Ab / Bb already point at k row lh: row 8 lh + j = lh + (7 lh + j))
+                wu32x4 af[3][C::TM], bf[3][C::TN];
+#pragma unroll
+                for (int mi = 0; mi < C::TM; ++mi)
+#pragma unroll
+                    for (int j2 = 0; j2 < 4; ++j2) {
+                        const float v0 = Ab[(16 * s16 + 7 * lh + 2 * j2) * C::LDAT + mi * 32], v1 = Ab[(16 * s16 + 7 * lh + 2 * j2 + 1) * C::LDAT + mi * 32];
+                        unsigned int h, m, l;
+                        ss_split3x2(f32x2{v0, v1}, h, m, l);
+                        af[0][mi][j2] = h; af[1][mi][j2] = m; af[2][mi][j2] = l;
+                    }
+#pragma unroll
+                for (int ni = 0; ni < C::TN; ++ni)
+#pragma unroll
+                    for (int j2 = 0; j2 < 4; ++j2) {
+                        const float v0 = Bb[(16 * s16 + 7 * lh + 2 * j2) * C::LDB + ni * 32], v1 = Bb[(16 * s16 + 7 * lh + 2 * j2 + 1) * C::LDB + ni * 32];
+                        unsigned int h, m, l;
+                        ss_split3x2(f32x2{v0, v1}, h, m, l);
+                        bf[0][ni][j2] = h; bf[1][ni][j2] = m; bf[2][ni][j2] = l;
+                    }
+                // six products, smallest terms first (conv_mfma_x6.hip): m*m, l*h, h*l, m*h, h*m, h*h
+                constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int mi = 0; mi < C::TM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < C::TN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, af[PA[q]][mi]), __builtin_bit_cast(wbf16x8, bf[PB[q]][ni]),
+                                                                                  acc[mi][ni], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int s2 = 0; s2 < C::BK / 2; ++s2) {
             float a[C::TM], b[C::TN];
@@ -778,10 +820,19 @@ static int launch_wgrad(const WGradParams& p, int vecA, int vecB, hipStream_t s)
     // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)
     static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<BM, BN, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem_wgrad);
+        (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<BM, BN, FAST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem_wgrad);
         return true;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((wgrad_mfma_kernel<BM, BN, FAST>), grid, dim3(256), C::smem_wgrad, s, p, vecA, vecB);
+    // p.x6 (the caller's arithmetic: AUTO / X6 with ss_config x6 = 1): six exact bf16 piece products instead of fp32 MFMA instructions
+    if (p.x6 && ss_tuning().wgrad_mfma_x6) {
+        SsProfScope prof(BN == 128 ? "wgrad_mfma_kernel<128,128,x6>" : (BN == 64 ? "wgrad_mfma_kernel<128,64,x6>" : "wgrad_mfma_kernel<128,32,x6>"),
+                         2.0 * M * p.Cb * (double)p.N * p.GH * p.GW * (p.nbatch > 1 ? p.nbatch : 1) * 6,
+                         4.0 * ((double)p.N * p.AH * p.AW * p.Ca + (double)p.N * p.GH * p.GW * p.Cb) * (p.nbatch > 1 ? p.nbatch : 1), s);
+        hipLaunchKernelGGL((wgrad_mfma_kernel<BM, BN, FAST, true>), grid, dim3(256), C::smem_wgrad, s, p, vecA, vecB);
+    } else {
+        hipLaunchKernelGGL((wgrad_mfma_kernel<BM, BN, FAST>), grid, dim3(256), C::smem_wgrad, s, p, vecA, vecB);
+    }
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

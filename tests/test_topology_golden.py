@@ -162,7 +162,7 @@ def test_unet_feeders_match_reference(feed, tmp_path, cache_bytes):
         files = {ds.image_info[i]["image_path"] for i in ds.image_ids}
         assert ds._cache_bytes <= max(cache_bytes, 0) and ds._cache_bytes == sum(t.nbytes for t in ds._cache.values())
         if cache_bytes == 2 ** 31:          # one image and one mask entry per file; masks as bytes
-            assert len(ds._cache) == 2 * len(files) and {t.dtype for (_, m), t in ds._cache.items() if m} == {np.dtype(np.uint8)}
+            assert len(ds._cache) == 2 * len(files) and {t.dtype for (_, m, _, _), t in ds._cache.items() if m} == {np.dtype(np.uint8)}          # key: (path, is_mask, file stamp, contrast window)
         if cache_bytes == 0:
             assert not ds._cache
 

@@ -237,10 +237,20 @@ def main(argv=None):
         from . import UNet_Segmentation as UN
         tmp = tempfile.TemporaryDirectory()
         pred_dir = tmp.name
-        un = UN.UNet(root_dir=tmp.name, image_dir=img_dir, mask_dir=gt_dir)
+        src_dir = img_dir
+        if a.crop_rows > 0:
+            # the network must see what is scored: the percentile normalisation of an image that still carries the SEM info bar differs
+            # from that of its first crop_rows rows (the published figures were obtained on cropped inputs, tools/real_data_eval.py)
+            from PIL import Image
+            src_dir = os.path.join(tmp.name, "_cropped_inputs")
+            os.makedirs(src_dir)
+            for name in sorted(os.listdir(img_dir)):
+                if os.path.splitext(name)[1].lower() in (".tif", ".tiff", ".png", ".bmp", ".jpg"):
+                    Image.fromarray(np.asarray(Image.open(os.path.join(img_dir, name)))[:a.crop_rows]).save(os.path.join(src_dir, name))
+        un = UN.UNet(root_dir=tmp.name, image_dir=src_dir, mask_dir=gt_dir)
         if a.tile:
             un.image_shape = tuple(a.tile)
-        un.run_inference(files=img_dir, output_directory=pred_dir, model=a.model, tile_images=a.tile is not None, use_gpu=True)
+        un.run_inference(files=src_dir, output_directory=pred_dir, model=a.model, tile_images=a.tile is not None, use_gpu=True)
     res = score_directories(pred_dir, gt_dir, crop_rows=a.crop_rows, watershed=not a.no_watershed, limit=a.limit, workers=a.workers)
     res.update(data_root=a.data_root, source=a.model or a.predictions, crop_rows=a.crop_rows)
     print(json.dumps(res))

@@ -208,3 +208,30 @@ def test_unet_dataset_matches_reference(feed):
             np.testing.assert_array_equal(x, feed[f"ds/ep{ep}/x{idx}"])
             np.testing.assert_array_equal(y, feed[f"ds/ep{ep}/y{idx}"])
         ds.on_epoch_end()
+
+
+def test_unet_tile_cache_follows_the_file_and_the_contrast_window(tmp_path):
+    """the decoded-tile cache is keyed on the file's identity (mtime, size) and the decode parameters -- a rewritten file or
+    another contrast_optimization_range must not return the tile decoded before (the reference decodes on every read)."""
+    import time
+    from PIL import Image
+    UN = importlib.import_module(f"{BASE}.UNet_Segmentation")
+    idir, mdir = str(tmp_path / "imgs"), str(tmp_path / "masks")
+    os.makedirs(idir), os.makedirs(mdir)
+    rng = np.random.default_rng(0)
+    for k in range(5):
+        Image.fromarray(rng.integers(0, 255, (32, 32), dtype=np.uint8)).save(os.path.join(idir, f"{k}.tif"))
+        Image.fromarray((rng.random((32, 32)) > 0.5).astype(np.uint8) * 255).save(os.path.join(mdir, f"{k}.tif"))
+    ds = UN.ImageDataset(idir, mdir)
+    ds.initialize_images("train")
+    iid = ds.image_ids[0]
+    first = ds.load_from_file(iid, False).copy()
+    assert np.array_equal(ds.load_from_file(iid, False), first) and len(ds._cache) == 1          # second read: from the cache
+    ds.contrast_optimization_range = (5.0, 95.0)
+    other = ds.load_from_file(iid, False)
+    assert not np.array_equal(other, first), "another contrast window must decode again"
+    path = ds.image_info[iid]["image_path"]
+    time.sleep(0.01)
+    Image.fromarray(rng.integers(0, 255, (32, 32), dtype=np.uint8)).save(path)
+    os.utime(path, ns=(time.time_ns(), time.time_ns() + 1_000_000))
+    assert not np.array_equal(ds.load_from_file(iid, False), other), "a rewritten file must decode again"

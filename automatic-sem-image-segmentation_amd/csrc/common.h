@@ -280,7 +280,7 @@ bool ss_x6p_wide_ok(long M, int N, int K, int nbatch);
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
 
 // kernel-selection switches: ONE explicit table, set through ss_config_set (config.hip); SS_* environment variables give the initial values
-struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products, c1_mfma, x6p_pp, wino_save, gemm_ilv, gemm_cus, gconv_phases, phases_fused, phases_split, norm_order, norm_fuse_fin, wgrad_mfma_x6; };
+struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products, c1_mfma, x6p_pp, wino_save, gemm_ilv, gemm_cus, gconv_phases, phases_fused, phases_split, norm_order, norm_fuse_fin, wgrad_mfma_x6, wgrad_stage; };
 const SsTuning& ss_tuning();
 // ss_prof_*: brackets the kernel launched inside this scope with HIP events on its stream when profiling is enabled (config.hip).
 // flops = EXECUTED matrix-instruction FLOPs of the launch (all piece products), bytes = algorithmic HBM bytes (0 if not stated)
@@ -353,6 +353,10 @@ int ss_launch_gconv_x6_multi(const GConvParams* ps, const unsigned short* const*
 int ss_launch_gconv_x6v2(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s, const GPhases* ph = nullptr);
 int ss_launch_gconv_x6(const GConvParams& p, const unsigned short* planes, hipStream_t s);
 bool ss_wgrad_x6_ok(const WGradParams& p);
+// stride-2 full-tap-box layers with the operands staged once per spatial tile (conv_wgrad_stage.hip)
+bool ss_wgrad_stage_ok(const WGradParams& p);
+int ss_wgrad_stage_splits(const WGradParams& p);          // 0: the shape is not taken
+int ss_launch_wgrad_stage_partials(const WGradParams& p, hipStream_t s);
 int ss_launch_wgrad_x6_partials(const WGradParams& p, hipStream_t s);
 
 // Winograd F(2x2,3x3) path (conv_wino.hip): 3x3, stride 1; out[o] = sum_a in[map(o + a - pt)] * g[a]

@@ -901,7 +901,11 @@ size_t bwd_weight_ws(const ConvProb& c) {
     int pps;
     const long P = (long)c.n * c.oh * c.ow;
     const int M = c.kh * c.kw * c.cin;
-    const int splits = ss_wgrad_mfma_splits(P, M, c.cout, &pps);
+    int splits = ss_wgrad_mfma_splits(P, M, c.cout, &pps);
+    {
+        const int ssp = ss_wgrad_stage_splits(wgrad_params(c, (const float*)16, (const float*)16, nullptr));      // (aligned dummy pointers: shape-only answer)
+        if (ssp > splits) splits = ssp;
+    }
     size_t b = ss_align_up((size_t)splits * M * c.cout * sizeof(float), 256) + 256;      // + the x3h amax slot
     if (wgrad_two_stage(c, SS_ALGO_AUTO)) {
         const int tcs = round4(c.kh * c.kw);
@@ -991,6 +995,18 @@ int conv_bwd_weight(const ConvProb& c, const float* x, const float* dy, float* d
         q.pix_per_split = pps;
         // rows t >= ntaps of U are zero and land beyond the kh*kw*cin weights: mask them by shrinking Ca in the reduce
         return ss_launch_wgrad_mfma_rows(q, dw, c.cin, accumulate, p.ntaps, s);
+    }
+    if (need_amax_wgrad(c, algo) && ss_wgrad_stage_ok(p)) {
+        // stride-2 layers: operands staged once per spatial tile, every tap served from LDS (conv_wgrad_stage.hip)
+        p.splits = ss_wgrad_stage_splits(p);
+        p.pix_per_split = 0;
+        unsigned int* sl = (unsigned int*)((char*)ws + ss_align_up((size_t)p.splits * p.ntaps * p.Ca * p.Cb * sizeof(float), 256));
+        const AmaxRef ax = act_amax(x, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
+        const AmaxRef ay = act_amax(dy, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl + 1, s);
+        p.h_amax = ax.p; p.h_amax2 = ay.p; p.amax_stripes = ax.stripes; p.amax2_stripes = ay.stripes;
+        const int rc = ss_launch_wgrad_stage_partials(p, s);
+        if (rc != SS_OK) return rc;
+        return ss_launch_wgrad_reduce(p, dw, c.cout, accumulate, p.ntaps * p.Ca, s);
     }
     p.splits = ss_wgrad_mfma_splits((long)c.n * c.oh * c.ow, p.ntaps * p.Ca, p.Cb, &pps);
     p.pix_per_split = pps;

@@ -779,3 +779,52 @@ def test_norm_statistics_are_exact_on_constant_channels(shape):
         arena.zero_grad()
         tape.backward()
         assert float(x.get_grad().dense().abs().max()) == 0.0 and float(arena.grad("n/gamma").abs().max()) == 0.0      # relu'(0) = 0: nothing flows
+
+
+@pytest.mark.parametrize("case", [("down_3x3", 3, 64, 128, False, (4, 128, 256)), ("patchgan_4x4", 4, 64, 128, False, (5, 128, 128)),
+                                  ("up_T3x3", 3, 128, 64, True, (4, 64, 128))], ids=lambda c: c[0])
+def test_staged_weight_gradient_vs_float64_and_the_gather_kernel(case):
+    """conv_wgrad_stage.hip (stride-2 layers: operands staged once per spatial tile, taps from LDS with transposing reads) against a
+    float64 convolution's weight gradient and against wgrad_x6_kernel (ss_config wgrad_stage = 0: the same x3h arithmetic in another
+    summation order); two runs are bit-identical (fixed-order reduction of the splits' partials)."""
+    E, LY, L = _mods()
+    name, k, cin, cout, tr, (n, h, w) = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    arena = E.ParamArena(dev)
+    conv = LY.Conv2D(arena, "c", k, cin, cout, stride=2, padding="same", transposed=tr)
+    arena.materialize()
+    arena["c/kernel"].normal_(0, 0.05)
+    x_cpu = torch.randn((n, h, w, cin), generator=g) * 0.8
+    oh, ow = conv.out_hw(h, w)
+    gy_cpu = torch.randn((n, oh, ow, cout), generator=g) * 0.2
+    grads = {}
+    for mode in (1, 1, 0):
+        with L.config(wgrad_stage=mode):
+            tape = E.Tape()
+            x = E.Act(x_cpu.to(dev), requires_grad=True)
+            y = conv(tape, x)
+            gt, _ = y.grad_target()
+            gt.t.copy_(gy_cpu.to(dev))
+            y.grad_init = True
+            arena.zero_grad()
+            tape.backward()
+            torch.cuda.synchronize()
+            grads.setdefault(mode, []).append(arena.grad("c/kernel").cpu().clone())
+    assert torch.equal(grads[1][0], grads[1][1]), "staged weight gradient is not bit-stable"
+    # float64 truth through torch's CPU convolutions (Keras layouts: Conv2D (kh, kw, cin, cout), Conv2DTranspose (kh, kw, cout, cin))
+    wk = arena["c/kernel"].cpu().double()
+    xc = x_cpu.double().permute(0, 3, 1, 2)
+    if not tr:
+        wt = wk.permute(3, 2, 0, 1).clone().requires_grad_(True)
+        pt, pl = LY.same_pad(h, k, 2)[0], LY.same_pad(w, k, 2)[0]
+        yy = torch.nn.functional.conv2d(torch.nn.functional.pad(xc, (pl, k, pt, k)), wt, stride=2)[:, :, :oh, :ow]
+    else:
+        wt = wk.permute(3, 2, 0, 1).clone().requires_grad_(True)          # conv_transpose2d weight: (in, out, kh, kw)
+        yy = torch.nn.functional.conv_transpose2d(xc, wt, stride=2, padding=1, output_padding=1)
+    (yy * gy_cpu.double().permute(0, 3, 1, 2)).sum().backward()
+    truth = wt.grad.permute(2, 3, 1, 0) if not tr else wt.grad.permute(2, 3, 1, 0)
+    ref = float(truth.abs().max())
+    e_stage = float((grads[1][0].double() - truth).abs().max()) / ref
+    e_x6 = float((grads[0][0].double() - truth).abs().max()) / ref
+    assert e_stage <= 1.5 * e_x6 + 2e-7 and e_stage <= 2e-6, (name, e_stage, e_x6)

@@ -124,10 +124,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
             rb[i] = *(const f32x4*)(gb + pix * p.b_cs + 4 * bq);
         }
     };
-    auto store_tile = [&](int st) {
+    // the split + LDS stores of the NEXT tile (halo units, dy units) into the other stage
+    auto store_x = [&](int st) {
         if (p.dbg & 2) return;          // measurement: no split, no LDS stores
         unsigned char* const sx = lds + st * stage_b;
-        unsigned char* const sb = sx + 2 * xplane;
 #pragma unroll
         for (int i = 0; i < XU; ++i) {
             if (xl[i] < 0) continue;
@@ -137,6 +137,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
             *(u32x2*)(sx + xl[i]) = u32x2{h0, h1};
             *(u32x2*)(sx + xplane + xl[i]) = u32x2{l0, l1};
         }
+    };
+    auto store_b = [&](int st) {
+        if (p.dbg & 2) return;
+        unsigned char* const sb = lds + st * stage_b + 2 * xplane;
 #pragma unroll
         for (int i = 0; i < BU; ++i) {
             unsigned int h0, l0, h1, l1;
@@ -182,7 +186,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
 
     if (t_begin < t_end) {
         load_tile(t_begin);
-        store_tile(0);
+        store_x(0);
+        store_b(0);
     }
     __syncthreads();
     for (int t = t_begin; t < t_end; ++t) {
@@ -214,7 +219,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
             }
         }
-        if (t + 1 < t_end) store_tile(st ^ 1);          // (stage st ^ 1 was last read in iteration t - 1: every wave has passed that barrier)
+        // (stage st ^ 1 was last read in iteration t - 1: every wave has passed that barrier.  Placing the two halves between the K = 16
+        // steps instead -- to run the split's VALU work under the MFMAs -- was measured SLOWER: 331 -> 400 us on the 64 -> 128 layer, the
+        // loads have not landed by then and the wait stalls the matrix stream)
+        if (t + 1 < t_end) { store_x(st ^ 1); store_b(st ^ 1); }
         __syncthreads();
     }
 

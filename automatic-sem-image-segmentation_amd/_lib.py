@@ -124,6 +124,7 @@ SIGNATURES = {
     "ss_wprep_record_end": (c_i32, [ctypes.POINTER(c_sz), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "ss_wprep_plan_write": (c_i32, [c_vp, c_sz]),
     "ss_wprep_run": (c_i32, [c_vp, c_vp, c_sz, c_vp]),
+    "ss_wprep_run_part": (c_i32, [c_vp, c_vp, c_sz, c_i32, c_vp]),
     "ss_conv2d_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ss_conv2d_bwd_data": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "ss_conv2d_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),

@@ -432,7 +432,7 @@ const unsigned int* weight_amax(const float* w, long wn, unsigned int* scratch, 
     const unsigned nb = wn / 8192 < 16 ? 16 : (wn / 8192 > 256 ? 256 : (unsigned)(wn / 8192));
     if (ss_wrec_on() && (((uintptr_t)w) & 15) == 0) {          // recorded (ss_wprep_*): the plan zeroes the word and scans the tensor
         SsWJob j{};
-        j.type = SS_WJ_AMAX; j.gx = (int)(nb > 16 ? 16 : nb); j.gy = 1; j.gz = 1;
+        j.type = SS_WJ_AMAX; j.gx = (int)(wn / 16384 < 4 ? 4 : (wn / 16384 > 64 ? 64 : wn / 16384)); j.gy = 1; j.gz = 1;
         j.src = w; j.n = wn; j.dst = scratch;
         ss_wrec_push(j);
         return scratch;

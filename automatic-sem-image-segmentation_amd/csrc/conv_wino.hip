@@ -568,8 +568,8 @@ __global__ __launch_bounds__(256) void wino_weight_x6_batch_kernel(const SsWJob*
 // record (ss_wprep_*) what the x3h weight fill launches: the maximum of the kernel tensor into w_inv[1], then the planes
 inline void wino_record_weight_jobs(const float* w, int w_cin, int w_cout, int flip, int Npad, int kr, unsigned short* planes, float* w_inv, int plain_l) {
     SsWJob a{};
-    a.type = SS_WJ_AMAX; a.gx = 16; a.gy = 1; a.gz = 1;
     a.src = w; a.n = (long)9 * w_cin * w_cout; a.dst = w_inv + 1;
+    a.type = SS_WJ_AMAX; a.gx = (int)(a.n / 16384 < 4 ? 4 : (a.n / 16384 > 64 ? 64 : a.n / 16384)); a.gy = 1; a.gz = 1;
     ss_wrec_push(a);
     SsWJob j{};
     j.type = SS_WJ_WINO_H; j.gx = kr / 32; j.gy = Npad / 16; j.gz = 2;

@@ -131,6 +131,11 @@ int ss_wprep_plan_write(void* plan_host, size_t bytes) {
 }
 
 int ss_wprep_run(const void* plan_host, const void* plan_dev, size_t bytes, void* stream) {
+    const int rc = ss_wprep_run_part(plan_host, plan_dev, bytes, 0, stream);
+    return rc != SS_OK ? rc : ss_wprep_run_part(plan_host, plan_dev, bytes, 1, stream);
+}
+
+int ss_wprep_run_part(const void* plan_host, const void* plan_dev, size_t bytes, int part, void* stream) {
     const PlanHeader* h = (const PlanHeader*)plan_host;
     if (!h || !plan_dev || bytes < sizeof(PlanHeader) || h->magic != PLAN_MAGIC || h->total_bytes > bytes) {
         ss_set_error("ss_wprep_run: not a plan written by ss_wprep_plan_write (or a truncated copy)");
@@ -139,6 +144,8 @@ int ss_wprep_run(const void* plan_host, const void* plan_dev, size_t bytes, void
     hipStream_t s = (hipStream_t)stream;
     const SsWJob* jobs = (const SsWJob*)((const char*)plan_dev + h->jobs_off);
     const int32_t* maps = (const int32_t*)((const char*)plan_dev + h->maps_off);
+    if (part == 1) return h->blocks[SS_WJ_WINO_H] > 0 ? ss_wbatch_launch_wino(jobs, maps + h->map_off[SS_WJ_WINO_H], h->blocks[SS_WJ_WINO_H], s) : SS_OK;
+    if (part != 0) return SS_ERR_INVALID;
     if (h->n_amax > 0) {
         hipLaunchKernelGGL(wbatch_zero_kernel, dim3((h->n_amax + 255) / 256), dim3(256), 0, s, jobs + h->first[SS_WJ_AMAX], h->n_amax);
         SS_LAUNCH_CHECK();
@@ -149,7 +156,6 @@ int ss_wprep_run(const void* plan_host, const void* plan_dev, size_t bytes, void
     if (rc == SS_OK && h->blocks[SS_WJ_TRANSPOSE] > 0) rc = ss_wbatch_launch_transpose(jobs, maps + h->map_off[SS_WJ_TRANSPOSE], h->blocks[SS_WJ_TRANSPOSE], s);
     if (rc == SS_OK && h->blocks[SS_WJ_WPREP_H] > 0) rc = ss_wbatch_launch_wprep(true, jobs, maps + h->map_off[SS_WJ_WPREP_H], h->blocks[SS_WJ_WPREP_H], s);
     if (rc == SS_OK && h->blocks[SS_WJ_WPREP_3] > 0) rc = ss_wbatch_launch_wprep(false, jobs, maps + h->map_off[SS_WJ_WPREP_3], h->blocks[SS_WJ_WPREP_3], s);
-    if (rc == SS_OK && h->blocks[SS_WJ_WINO_H] > 0) rc = ss_wbatch_launch_wino(jobs, maps + h->map_off[SS_WJ_WINO_H], h->blocks[SS_WJ_WINO_H], s);
     return rc;
 }
 

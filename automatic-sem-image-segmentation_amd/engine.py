@@ -21,6 +21,7 @@ _WS_RETIRED = []
 # 1 (default): a network's weight-derived operands are refreshed from ONE recorded plan per step (ParamArena._refresh_batched);
 # 0: layer by layer (measurement / A-B: the operands are bit-identical)
 WPREP_BATCH = os.environ.get("SS_WPREP_BATCH", "1") != "0"
+_WC_WINO_KINDS = (1, 2, 3, 4, 5)          # csrc/common.h SS_WC_WINO_*: cache entries of the Winograd paths
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -625,16 +626,22 @@ class ParamArena:
                     st = getattr(layer, "_wc", None)
                     if st:
                         st["ver"] = ver
-            if plan["jobs"]:
-                L.check(lib.ss_wprep_run(ctypes.cast(plan["host"], ctypes.c_void_p), ctypes.c_void_p(plan["dev"].data_ptr()), plan["bytes"],
-                                         _stream()), "ss_wprep_run")
-            ev = torch.cuda.Event()
-            ev.record()
-            sync = dict(ev=ev, synced={_stream().value or 0})
-            for layer in self.derived:                       # ONE event for the arena: a consumer on another stream waits for the whole plan
+            # two events per arena: the strided / transposed / 4 x 4 layers' operands (part 0: maxima, transposes, split planes) are ready
+            # before the trunk's Winograd planes (part 1, ~2/3 of the plan's time) -- the chains' first layers need not wait for those
+            hp, dp = ctypes.cast(plan["host"], ctypes.c_void_p), ctypes.c_void_p(plan["dev"].data_ptr())
+            syncs = []
+            for part in (0, 1):
+                if plan["jobs"]:
+                    L.check(lib.ss_wprep_run_part(hp, dp, plan["bytes"], part, _stream()), "ss_wprep_run_part")
+                ev = torch.cuda.Event()
+                ev.record()
+                syncs.append(dict(ev=ev, synced={_stream().value or 0}))
+            for layer in self.derived:
                 st = getattr(layer, "_wc", None)
                 if st:
-                    st["sync"] = sync
+                    c = st["c"]
+                    wino = any((int(c.entry[i].tag) & 0xff) in _WC_WINO_KINDS for i in range(c.count))
+                    st["sync"] = syncs[1] if wino else syncs[0]
         if side is not None:
             self._refresh_stream = side
         return True

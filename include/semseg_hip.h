@@ -157,6 +157,10 @@ int ss_wprep_record_begin(void);
 int ss_wprep_record_end(size_t* plan_bytes, int32_t* n_jobs, int32_t* complete);
 int ss_wprep_plan_write(void* plan_host, size_t bytes);
 int ss_wprep_run(const void* plan_host, const void* plan_dev, size_t bytes, void* stream);
+/* The same in two parts, for a caller that lets the first layers start before the whole plan has run: part 0 = maxima (of every layer),
+ * transposes and split planes (what the strided / transposed / 4x4 layers need), part 1 = the Winograd-transformed planes (the trunk).
+ * Part 1 reads the maxima part 0 leaves: run part 0 first, on the same stream.  ss_wprep_run = part 0 followed by part 1. */
+int ss_wprep_run_part(const void* plan_host, const void* plan_dev, size_t bytes, int part, void* stream);
 
 /* An "amax slot" is SS_AMAX_SLOT_BYTES of device memory: 16 uint32 words, one per 256-byte line (word index 64 * i); the value it
  * holds is the MAXIMUM of those words.  Producers (ss_norm_fwd / ss_norm_bwd, the scan inside the convolution passes) raise the

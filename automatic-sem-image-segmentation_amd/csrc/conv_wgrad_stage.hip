@@ -116,12 +116,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
             const bool ok = xl[i] >= 0 && iy >= 0 && iy < p.AH && ix >= 0 && ix < p.AW;
             rx[i] = ok ? *(const f32x4*)(ga + ((long)(n * p.AH + iy) * p.AW + ix) * p.a_cs) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const long pix0 = ((long)(n * p.GH + ty * TH) * p.GW + tx * TW);
 #pragma unroll
         for (int i = 0; i < BU; ++i) {
             const int bk = bk0 + BSTEP * i;
-            const long pix = pix0 + (long)(bk >> 4) * p.GW + (bk & 15);
-            rb[i] = *(const f32x4*)(gb + pix * p.b_cs + 4 * bq);
+            const int oy = ty * TH + (bk >> 4), ox = tx * TW + (bk & 15);
+            // ragged grids ('valid' PatchGAN layers: 255 / 126 / 62 pixels a side): pixels beyond the grid contribute nothing
+            const bool ok = oy < p.GH && ox < p.GW;
+            rb[i] = ok ? *(const f32x4*)(gb + ((long)(n * p.GH + oy) * p.GW + ox) * p.b_cs + 4 * bq) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     // the split + LDS stores of the NEXT tile (halo units, dy units) into the other stage
@@ -248,13 +249,13 @@ bool geom(const WGradParams& p, WSGeom* g, int* cbb) {
         if (p.taps[t].dy != t / kw || p.taps[t].dx != t % kw) return false;          // the full tap box in row-major order
     *cbb = p.ntaps == 9 ? 128 : 64;
     if (p.a_s != 2 || p.reflect || p.nbatch > 1 || p.dtype != SS_DTYPE_F32) return false;
-    if (p.Ca % CAB || p.Cb % *cbb || p.GH % TH || p.GW % TW) return false;
+    if (p.Ca % CAB || p.Cb % *cbb || p.GH < TH || p.GW < TW) return false;
     if (p.a_cs % 4 || p.b_cs % 4 || (((uintptr_t)p.a) & 15) || (((uintptr_t)p.b) & 15)) return false;
     if ((long)p.N * p.AH * p.AW * p.a_cs >= (1L << 31) || (long)p.N * p.GH * p.GW * p.b_cs >= (1L << 31)) return false;
     g->kh = kh; g->kw = kw;
     g->R = 2 * (TH - 1) + kh;
     g->C = 2 * (TW - 1) + kw;
-    g->tiles_x = p.GW / TW; g->tiles_y = p.GH / TH;
+    g->tiles_x = (p.GW + TW - 1) / TW; g->tiles_y = (p.GH + TH - 1) / TH;
     g->tiles_total = p.N * g->tiles_x * g->tiles_y;
     g->nca = p.Ca / CAB; g->ncb = p.Cb / *cbb;
     return g->R * g->C * (CAB / 4) <= (p.ntaps == 9 ? 5 : 6) * 512 && g->tiles_total >= 512;

@@ -782,7 +782,8 @@ def test_norm_statistics_are_exact_on_constant_channels(shape):
 
 
 @pytest.mark.parametrize("case", [("down_3x3", 3, 64, 128, False, (4, 128, 256)), ("patchgan_4x4", 4, 64, 128, False, (8, 128, 128)),
-                                  ("up_T3x3", 3, 128, 64, True, (4, 64, 128))], ids=lambda c: c[0])
+                                  ("up_T3x3", 3, 128, 64, True, (4, 64, 128)), ("patchgan_valid_ragged", 4, 64, 128, False, (8, 130, 126))],
+                         ids=lambda c: c[0])
 def test_staged_weight_gradient_vs_float64_and_the_gather_kernel(case):
     """conv_wgrad_stage.hip (stride-2 layers: operands staged once per spatial tile, taps from LDS with transposing reads) against a
     float64 convolution's weight gradient and against wgrad_x6_kernel (ss_config wgrad_stage = 0: the same x3h arithmetic in another
@@ -792,7 +793,8 @@ def test_staged_weight_gradient_vs_float64_and_the_gather_kernel(case):
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(11)
     arena = E.ParamArena(dev)
-    conv = LY.Conv2D(arena, "c", k, cin, cout, stride=2, padding="same", transposed=tr)
+    pad = "valid" if name.endswith("ragged") else "same"          # 'valid' PatchGAN layers: 64 x 62 output pixels, tiles hang over the grid
+    conv = LY.Conv2D(arena, "c", k, cin, cout, stride=2, padding=pad, transposed=tr)
     arena.materialize()
     arena["c/kernel"].normal_(0, 0.05)
     x_cpu = torch.randn((n, h, w, cin), generator=g) * 0.8
@@ -817,7 +819,7 @@ def test_staged_weight_gradient_vs_float64_and_the_gather_kernel(case):
     xc = x_cpu.double().permute(0, 3, 1, 2)
     if not tr:
         wt = wk.permute(3, 2, 0, 1).clone().requires_grad_(True)
-        pt, pl = LY.same_pad(h, k, 2)[0], LY.same_pad(w, k, 2)[0]
+        pt, pl = (LY.same_pad(h, k, 2)[0], LY.same_pad(w, k, 2)[0]) if pad == "same" else (0, 0)
         yy = torch.nn.functional.conv2d(torch.nn.functional.pad(xc, (pl, k, pt, k)), wt, stride=2)[:, :, :oh, :ow]
     else:
         wt = wk.permute(3, 2, 0, 1).clone().requires_grad_(True)          # conv_transpose2d weight: (in, out, kh, kw)

@@ -7,6 +7,7 @@ E = importlib.import_module(PKG + ".engine"); LY = importlib.import_module(PKG +
 lib = L.load(); dev = torch.device("cuda:0")
 LAYERS = [("g_down1", 3, 64, 128, 2, "same", False, 512, 8), ("g_down2", 3, 128, 256, 2, "same", False, 256, 8), ("d_c2", 4, 128, 256, 2, "same", False, 256, 8),
           ("d_c3", 4, 256, 512, 2, "same", False, 128, 8), ("g_up1", 3, 256, 128, 2, "same", True, 128, 8), ("g_up2", 3, 128, 64, 2, "same", True, 256, 8),
+          ("d_c2_valid", 4, 128, 256, 2, "valid", False, 255, 8), ("d_c3_valid", 4, 256, 512, 2, "valid", False, 126, 8),
           ("small_down", 3, 32, 128, 2, "same", False, 64, 2), ("small_4x4", 4, 64, 64, 2, "same", False, 96, 3)]
 g = torch.Generator().manual_seed(0)
 for name, k, cin, cout, s, pad, tr, hw, n in LAYERS:

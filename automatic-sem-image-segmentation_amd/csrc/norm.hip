@@ -84,6 +84,20 @@ template <int V> __device__ __forceinline__ void stv(__bf16* p, const float (&o)
     else *p = (__bf16)o[0];
 }
 
+// non-temporal forms (measurement, norm_order bits 3 / 4): streaming hints for tensors a pass touches once
+template <int V, typename T> __device__ __forceinline__ void ldv_nt(const T* p, float (&o)[V], bool nt) {
+    if (nt && std::is_same<T, float>::value) {
+        if (V == 4) { const f32x4 t = __builtin_nontemporal_load((const f32x4*)p); o[0] = t[0]; o[1 % V] = t[1]; o[2 % V] = t[2]; o[3 % V] = t[3]; }
+        else o[0] = __builtin_nontemporal_load((const float*)p);
+    } else ldv<V>(p, o);
+}
+template <int V, typename T> __device__ __forceinline__ void stv_nt(T* p, const float (&o)[V], bool nt) {
+    if (nt && std::is_same<T, float>::value) {
+        if (V == 4) { f32x4 t = {o[0], o[1 % V], o[2 % V], o[3 % V]}; __builtin_nontemporal_store(t, (f32x4*)p); }
+        else __builtin_nontemporal_store(o[0], (float*)p);
+    } else stv<V>(p, o);
+}
+
 // partial sums: part[((g*chunks + chunk)*C + c)*2 + {0,1}]
 // MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat) with g = dy * act'(y)
 // Thread = V consecutive channels x a strided set of pixels; CT = channel lanes (in units of V), PT = 256/CT.
@@ -395,8 +409,8 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
                 for (int u = 0; u < 4; ++u) {
                     const long q = p + (long)u * PT;
                     if (q < p1) {
-                        ldv<V>(xb + q * x_cs, xv[u]);
-                        if (RES) ldv<V>(rb + q * res_cs, rv[u]);
+                        ldv_nt<V>(xb + q * x_cs, xv[u], (order & 8) != 0);
+                        if (RES) ldv_nt<V>(rb + q * res_cs, rv[u], (order & 8) != 0);
                     }
                 }
 #pragma unroll
@@ -413,7 +427,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
                             o[v] = PWL ? ss_act_pwl(t, relu, slope) : ss_apply_act(t, act, alpha);
                             am = fmaxf(am, fabsf((float)(T)o[v]));          // what is stored: rounded to the storage type
                         }
-                        stv<V>(yb + q * y_cs, o);
+                        stv_nt<V>(yb + q * y_cs, o, (order & 16) != 0);
                     }
                 }
             }
@@ -579,8 +593,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                 for (int u = 0; u < 4; ++u) {
                     const long q = p + (long)u * PT;
                     if (q < p1) {
-                        ldv<V>(gb + q * dy_cs, gv[u]);
-                        ldv<V>(xb + q * x_cs, xv[u]);
+                        ldv_nt<V>(gb + q * dy_cs, gv[u], (order & 8) != 0);
+                        ldv_nt<V>(xb + q * x_cs, xv[u], (order & 8) != 0);
                         if (MASK >= 2) ldv<V>(yb + q * y_cs, yv[u]);
                         if (acc_dx) ldv<V>(ob + q * dx_cs, o[u]);
                         if (dres && acc_dres) ldv<V>(rb + q * dres_cs, r[u]);
@@ -609,7 +623,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                             o[u][v] = acc_dx ? o[u][v] + dv : dv;
                             am = fmaxf(am, fabsf((float)(T)o[u][v]));          // what is stored: rounded to the storage type
                         }
-                        stv<V>(ob + q * dx_cs, o[u]);
+                        stv_nt<V>(ob + q * dx_cs, o[u], (order & 16) != 0);
                         if (dres) {
                             if (acc_dres) {
 #pragma unroll

@@ -1374,6 +1374,18 @@ int native16_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, fl
             return SS_OK;
         WGradParams p = wgrad_params(cc, (const float*)xa, (const float*)ya, (float*)ws);
         p.x6 = x6_wanted(d->algo);
+        if (ss_wgrad_stage_ok(p)) {          // stride-2 layers: operands staged once per spatial tile (conv_wgrad_stage.hip), one plane, one product
+            *taken = true;
+            p.splits = ss_wgrad_stage_splits(p);
+            p.pix_per_split = 0;
+            unsigned int* sl = (unsigned int*)((char*)ws + ss_align_up((size_t)p.splits * p.ntaps * p.Ca * p.Cb * sizeof(float), 256));
+            const AmaxRef ax = act_amax16(xa, d->dtype, (long)cc.n * cc.ih * cc.iw, cc.cin, cc.in_cs, cc.x_amax, cc.x_valid, sl, s);
+            const AmaxRef ay = act_amax16(ya, d->dtype, (long)cc.n * cc.oh * cc.ow, cc.cout, cc.out_cs, cc.dy_amax, cc.dy_valid, sl + 1, s);
+            p.h_amax = ax.p; p.h_amax2 = ay.p; p.amax_stripes = ax.stripes; p.amax2_stripes = ay.stripes;
+            const int rc = ss_launch_wgrad_stage_partials(p, s);
+            if (rc != SS_OK) return rc;
+            return ss_launch_wgrad_reduce(p, dw, cc.cout, accumulate, p.ntaps * p.Ca, s);
+        }
         int pps;
         p.splits = ss_wgrad_mfma_splits((long)cc.n * cc.oh * cc.ow, p.ntaps * p.Ca, p.Cb, &pps);
         p.pix_per_split = pps;

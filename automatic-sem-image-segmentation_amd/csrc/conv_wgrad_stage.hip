@@ -16,6 +16,10 @@
 // serves all of the wave's taps.  Global loads of tile i + 1 are in flight (registers) while tile i is multiplied, and split / stored into the second LDS stage behind a wave's own
 // MFMAs: one barrier per tile.
 // Splits (contiguous tile ranges) write partials; ss_launch_wgrad_reduce sums them in fixed order (deterministic).
+//
+// 16-bit activation storage (T = _Float16 / __bf16): the stored values ARE the leading fp16 piece (under the tensor's power-of-two
+// scale; bf16's 8 significand bits fit fp16's 11), so ONE plane per operand, ONE product = the exact product of the stored values (as
+// wgrad_x6_kernel does for these types): half the global bytes, half the LDS, a third of the matrix work, no split arithmetic.
 #include "common.h"
 
 namespace {
@@ -23,6 +27,22 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 wf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+
+// storage type -> the 4-channel unit as loaded, the number of operand planes
+template <typename T> struct Stg;
+template <> struct Stg<float> { typedef f32x4 V; static constexpr int NPL = 2; };
+template <> struct Stg<_Float16> { typedef wf16x4 V; static constexpr int NPL = 1; };
+template <> struct Stg<__bf16> { typedef wbf16x4 V; static constexpr int NPL = 1; };
+__device__ __forceinline__ f32x4 to_f32x4(f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 to_f32x4(wf16x4 v) { return __builtin_convertvector(v, f32x4); }
+__device__ __forceinline__ f32x4 to_f32x4(wbf16x4 v) { return __builtin_convertvector(v, f32x4); }
+// two scaled values -> one packed fp16 pair (round to nearest even; exact for stored 16-bit values in fp16's normal range)
+__device__ __forceinline__ unsigned int pack_h2(float x0, float x1) {
+    const ss_f2 v = {x0, x1};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, ss_h2));
+}
 
 constexpr int TH = 4, TW = 16, TK = TH * TW;          // output pixels of a tile = the K of one LDS stage
 constexpr int CAB = 32;                               // input channels per workgroup
@@ -39,8 +59,10 @@ __device__ __forceinline__ s16x4 tr4(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
-template <int NTAPS, int CBB>
+template <int NTAPS, int CBB, typename T = float>
 __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGeom g) {
+    typedef typename Stg<T>::V UV;                    // one unit = 4 channels as stored
+    constexpr int NPL = Stg<T>::NPL;                  // operand planes in LDS: (h, l) or h alone
     constexpr int NJ = CBB / 32;                      // 32-column tiles of the output-channel block
     constexpr int NG = 8 / NJ;                        // tap residue classes (waves per column tile)
     constexpr int TPW = (NTAPS + NG - 1) / NG;        // taps per wave
@@ -50,7 +72,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int xplane = g.R * 2 * XC2 * XROWB;
     constexpr int bplane = TK * BROWB;
-    const int stage_b = 2 * xplane + 2 * bplane;      // TWO stages: tile i + 1 is split and stored while other waves still multiply tile i
+    const int stage_b = NPL * xplane + NPL * bplane;  // TWO stages: tile i + 1 is split and stored while other waves still multiply tile i
     // stage: [2 planes][R][2 parities][XC2][32 ch] fp16 | [2 planes][TK][CBB] fp16, 64-byte segments swizzled with the row
 
     const int tid = threadIdx.x;
@@ -94,16 +116,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
     constexpr int BSTEP = 512 / (CBB / 4);
     const int bk0 = tid / (CBB / 4), bq = tid % (CBB / 4);
     const int bl0 = bk0 * BROWB + (((bq >> 3) ^ (NJ == 4 ? (bk0 & 3) : ((bk0 >> 1) & 1))) << 6) + (bq & 7) * 8;
-    const float* const ga = p.a + ca0 + 4 * xcq;
-    const float* const gb = p.b + cb0;
+    const T* const ga = (const T*)p.a + ca0 + 4 * xcq;
+    const T* const gb = (const T*)p.b + cb0;
 
-    f32x4 rx[XU], rb[BU];
+    UV rx[XU], rb[BU];
     auto load_tile = [&](int t) {
         if (p.dbg & 1) {          // measurement: no global loads
 #pragma unroll
-            for (int i = 0; i < XU; ++i) rx[i] = f32x4{1.f, 2.f, 3.f, 4.f};
+            for (int i = 0; i < XU; ++i) rx[i] = UV{(T)1.f, (T)2.f, (T)3.f, (T)4.f};
 #pragma unroll
-            for (int i = 0; i < BU; ++i) rb[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+            for (int i = 0; i < BU; ++i) rb[i] = UV{(T)1.f, (T)1.f, (T)1.f, (T)1.f};
             return;
         }
         const int tx = t % g.tiles_x;
@@ -114,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
         for (int i = 0; i < XU; ++i) {
             const int iy = iy0 + (xrc[i] >> 8), ix = ix0 + (xrc[i] & 255);
             const bool ok = xl[i] >= 0 && iy >= 0 && iy < p.AH && ix >= 0 && ix < p.AW;
-            rx[i] = ok ? *(const f32x4*)(ga + ((long)(n * p.AH + iy) * p.AW + ix) * p.a_cs) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rx[i] = ok ? *(const UV*)(ga + ((long)(n * p.AH + iy) * p.AW + ix) * p.a_cs) : UV{(T)0.f, (T)0.f, (T)0.f, (T)0.f};
         }
 #pragma unroll
         for (int i = 0; i < BU; ++i) {
@@ -122,7 +144,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
             const int oy = ty * TH + (bk >> 4), ox = tx * TW + (bk & 15);
             // ragged grids ('valid' PatchGAN layers: 255 / 126 / 62 pixels a side): pixels beyond the grid contribute nothing
             const bool ok = oy < p.GH && ox < p.GW;
-            rb[i] = ok ? *(const f32x4*)(gb + ((long)(n * p.GH + oy) * p.GW + ox) * p.b_cs + 4 * bq) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[i] = ok ? *(const UV*)(gb + ((long)(n * p.GH + oy) * p.GW + ox) * p.b_cs + 4 * bq) : UV{(T)0.f, (T)0.f, (T)0.f, (T)0.f};
         }
     };
     // the split + LDS stores of the NEXT tile (halo units, dy units) into the other stage
@@ -132,23 +154,33 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
 #pragma unroll
         for (int i = 0; i < XU; ++i) {
             if (xl[i] < 0) continue;
-            unsigned int h0, l0, h1, l1;
-            ss_split_h2s(rx[i][0] * a_scale, rx[i][1] * a_scale, h0, l0);
-            ss_split_h2s(rx[i][2] * a_scale, rx[i][3] * a_scale, h1, l1);
-            *(u32x2*)(sx + xl[i]) = u32x2{h0, h1};
-            *(u32x2*)(sx + xplane + xl[i]) = u32x2{l0, l1};
+            const f32x4 v = to_f32x4(rx[i]);
+            if constexpr (NPL == 1) {
+                *(u32x2*)(sx + xl[i]) = u32x2{pack_h2(v[0] * a_scale, v[1] * a_scale), pack_h2(v[2] * a_scale, v[3] * a_scale)};
+            } else {
+                unsigned int h0, l0, h1, l1;
+                ss_split_h2s(v[0] * a_scale, v[1] * a_scale, h0, l0);
+                ss_split_h2s(v[2] * a_scale, v[3] * a_scale, h1, l1);
+                *(u32x2*)(sx + xl[i]) = u32x2{h0, h1};
+                *(u32x2*)(sx + xplane + xl[i]) = u32x2{l0, l1};
+            }
         }
     };
     auto store_b = [&](int st) {
         if (p.dbg & 2) return;
-        unsigned char* const sb = lds + st * stage_b + 2 * xplane;
+        unsigned char* const sb = lds + st * stage_b + NPL * xplane;
 #pragma unroll
         for (int i = 0; i < BU; ++i) {
-            unsigned int h0, l0, h1, l1;
-            ss_split_h2s(rb[i][0] * b_scale, rb[i][1] * b_scale, h0, l0);
-            ss_split_h2s(rb[i][2] * b_scale, rb[i][3] * b_scale, h1, l1);
-            *(u32x2*)(sb + bl0 + i * BSTEP * BROWB) = u32x2{h0, h1};
-            *(u32x2*)(sb + bplane + bl0 + i * BSTEP * BROWB) = u32x2{l0, l1};
+            const f32x4 v = to_f32x4(rb[i]);
+            if constexpr (NPL == 1) {
+                *(u32x2*)(sb + bl0 + i * BSTEP * BROWB) = u32x2{pack_h2(v[0] * b_scale, v[1] * b_scale), pack_h2(v[2] * b_scale, v[3] * b_scale)};
+            } else {
+                unsigned int h0, l0, h1, l1;
+                ss_split_h2s(v[0] * b_scale, v[1] * b_scale, h0, l0);
+                ss_split_h2s(v[2] * b_scale, v[3] * b_scale, h1, l1);
+                *(u32x2*)(sb + bl0 + i * BSTEP * BROWB) = u32x2{h0, h1};
+                *(u32x2*)(sb + bplane + bl0 + i * BSTEP * BROWB) = u32x2{l0, l1};
+            }
         }
     };
 
@@ -179,11 +211,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
     }
     const int a_ks = 2 * 2 * XC2 * XROWB;          // one tile row further = two halo rows further
 
-    f32x16 acc[TPW], accx[TPW];
+    f32x16 acc[TPW], accx[NPL == 2 ? TPW : 1];          // (one plane: no cross terms)
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; if (NPL == 2) accx[i][r] = 0.f; }
 
     if (t_begin < t_end) {
         load_tile(t_begin);
@@ -194,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
     for (int t = t_begin; t < t_end; ++t) {
         const int st = (t - t_begin) & 1;
         const unsigned char* const sx = lds + st * stage_b;
-        const unsigned char* const sb = sx + 2 * xplane;
+        const unsigned char* const sb = sx + NPL * xplane;
         if (t + 1 < t_end) load_tile(t + 1);
 #pragma unroll
         for (int ks = 0; ks < TK / 16; ++ks) {
@@ -204,8 +236,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
                 const unsigned char* pb = sb + ks * 16 * BROWB;
                 const s16x4 y0 = tr4(pb + boff[0]), y1 = tr4(pb + boff[1]);
                 bh = __builtin_bit_cast(f16x8, __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7));
-                const s16x4 z0 = tr4(pb + bplane + boff[0]), z1 = tr4(pb + bplane + boff[1]);
-                bl2 = __builtin_bit_cast(f16x8, __builtin_shufflevector(z0, z1, 0, 1, 2, 3, 4, 5, 6, 7));
+                if constexpr (NPL == 2) {
+                    const s16x4 z0 = tr4(pb + bplane + boff[0]), z1 = tr4(pb + bplane + boff[1]);
+                    bl2 = __builtin_bit_cast(f16x8, __builtin_shufflevector(z0, z1, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
             }
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
@@ -213,10 +247,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
                 const unsigned char* pa = sx + ks * a_ks;
                 const s16x4 x0 = tr4(pa + aoff[i][0]), x1 = tr4(pa + aoff[i][1]);
                 const f16x8 ah = __builtin_bit_cast(f16x8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
-                const s16x4 w0 = tr4(pa + xplane + aoff[i][0]), w1 = tr4(pa + xplane + aoff[i][1]);
-                const f16x8 al = __builtin_bit_cast(f16x8, __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7));
-                accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[i], 0, 0, 0);
-                accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl2, accx[i], 0, 0, 0);
+                if constexpr (NPL == 2) {
+                    const s16x4 w0 = tr4(pa + xplane + aoff[i][0]), w1 = tr4(pa + xplane + aoff[i][1]);
+                    const f16x8 al = __builtin_bit_cast(f16x8, __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[i], 0, 0, 0);
+                    accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl2, accx[i], 0, 0, 0);
+                }
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
             }
         }
@@ -237,7 +273,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = t * p.Ca + ca0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            part[(long)m * p.Cb] = (acc[i][r] + accx[i][r] * (1.f / 2048.f)) * out_scale;
+            if constexpr (NPL == 2) part[(long)m * p.Cb] = (acc[i][r] + accx[i][r] * (1.f / 2048.f)) * out_scale;
+            else part[(long)m * p.Cb] = acc[i][r] * out_scale;
         }
     }
 }
@@ -248,9 +285,11 @@ bool geom(const WGradParams& p, WSGeom* g, int* cbb) {
     for (int t = 0; t < p.ntaps; ++t)
         if (p.taps[t].dy != t / kw || p.taps[t].dx != t % kw) return false;          // the full tap box in row-major order
     *cbb = p.ntaps == 9 ? 128 : 64;
-    if (p.a_s != 2 || p.reflect || p.nbatch > 1 || p.dtype != SS_DTYPE_F32) return false;
+    if (p.a_s != 2 || p.reflect || p.nbatch > 1) return false;
+    if (p.dtype != SS_DTYPE_F32 && p.dtype != SS_DTYPE_F16 && p.dtype != SS_DTYPE_BF16) return false;
     if (p.Ca % CAB || p.Cb % *cbb || p.GH < TH || p.GW < TW) return false;
-    if (p.a_cs % 4 || p.b_cs % 4 || (((uintptr_t)p.a) & 15) || (((uintptr_t)p.b) & 15)) return false;
+    const uintptr_t amask = p.dtype == SS_DTYPE_F32 ? 15 : 7;          // one unit = 4 channels = one 16- / 8-byte access
+    if (p.a_cs % 4 || p.b_cs % 4 || (((uintptr_t)p.a) & amask) || (((uintptr_t)p.b) & amask)) return false;
     if ((long)p.N * p.AH * p.AW * p.a_cs >= (1L << 31) || (long)p.N * p.GH * p.GW * p.b_cs >= (1L << 31)) return false;
     g->kh = kh; g->kw = kw;
     g->R = 2 * (TH - 1) + kh;
@@ -291,20 +330,32 @@ int ss_launch_wgrad_stage_partials(const WGradParams& p, hipStream_t s) {
     if (!geom(p, &g, &cbb) || !p.h_amax || !p.h_amax2 || p.splits != splits_of(g)) return SS_ERR_UNSUPPORTED;
     g.tiles_per_split = (g.tiles_total + p.splits - 1) / p.splits;
     const int AB = g.nca * g.ncb;
-    const size_t smem = 2 * ((size_t)2 * g.R * 2 * XC2 * XROWB + (size_t)2 * TK * cbb * 2);          // two stages
+    const int npl = p.dtype == SS_DTYPE_F32 ? 2 : 1;
+    const size_t smem = 2 * ((size_t)npl * g.R * 2 * XC2 * XROWB + (size_t)npl * TK * cbb * 2);          // two stages
     static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)wgrad_stage_kernel<9, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)wgrad_stage_kernel<16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_stage_kernel<9, 128, _Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_stage_kernel<16, 64, _Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_stage_kernel<9, 128, __bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_stage_kernel<16, 64, __bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
     const long P = (long)p.N * p.GH * p.GW;
-    SsProfScope prof(p.ntaps == 9 ? "wgrad_stage_kernel<9,128>" : "wgrad_stage_kernel<16,64>", 2.0 * p.ntaps * p.Ca * p.Cb * (double)P * 3,
-                     4.0 * ((double)p.N * p.AH * p.AW * p.Ca + (double)P * p.Cb), s);
+    const bool f32 = p.dtype == SS_DTYPE_F32;
+    SsProfScope prof(f32 ? (p.ntaps == 9 ? "wgrad_stage_kernel<9,128>" : "wgrad_stage_kernel<16,64>") : (p.ntaps == 9 ? "wgrad_stage_kernel<9,128,16-bit>" : "wgrad_stage_kernel<16,64,16-bit>"),
+                     2.0 * p.ntaps * p.Ca * p.Cb * (double)P * (f32 ? 3 : 1), (f32 ? 4.0 : 2.0) * ((double)p.N * p.AH * p.AW * p.Ca + (double)P * p.Cb), s);
     const unsigned nwg = (unsigned)(p.splits * AB);
     WGradParams pd = p;
     pd.dbg = ss_tuning().tile_dbg;          // measurement only (phase skipping; 0 in every product path)
-    if (p.ntaps == 9) hipLaunchKernelGGL((wgrad_stage_kernel<9, 128>), dim3(nwg), dim3(512), smem, s, pd, g);
+    if (p.dtype == SS_DTYPE_F16) {
+        if (p.ntaps == 9) hipLaunchKernelGGL((wgrad_stage_kernel<9, 128, _Float16>), dim3(nwg), dim3(512), smem, s, pd, g);
+        else hipLaunchKernelGGL((wgrad_stage_kernel<16, 64, _Float16>), dim3(nwg), dim3(512), smem, s, pd, g);
+    } else if (p.dtype == SS_DTYPE_BF16) {
+        if (p.ntaps == 9) hipLaunchKernelGGL((wgrad_stage_kernel<9, 128, __bf16>), dim3(nwg), dim3(512), smem, s, pd, g);
+        else hipLaunchKernelGGL((wgrad_stage_kernel<16, 64, __bf16>), dim3(nwg), dim3(512), smem, s, pd, g);
+    } else if (p.ntaps == 9) hipLaunchKernelGGL((wgrad_stage_kernel<9, 128>), dim3(nwg), dim3(512), smem, s, pd, g);
     else hipLaunchKernelGGL((wgrad_stage_kernel<16, 64>), dim3(nwg), dim3(512), smem, s, pd, g);
     SS_LAUNCH_CHECK();
     return SS_OK;

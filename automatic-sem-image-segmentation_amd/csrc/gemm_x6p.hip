@@ -32,7 +32,7 @@ __device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-constexpr int x6p_stages(int npl, bool wide = false) { return npl == 1 ? 4 : (npl == 2 && !wide ? 3 : 2); }
+constexpr int x6p_stages(int npl, bool wide = false) { return npl == 1 ? 4 : (npl == 2 && !wide ? 3 : 2); }      // one plane: 24 KiB (wide: 32 KiB) stages
 
 // WIDE (x3h only): 256 x 256 tile, 1024 threads = 16 waves as 4 (M) x 4 (N), still 64 x 64 per wave.  The kernel is paced by its
 // operand stream (profiles/r02_f_*: 53 % issue stalls behind the LDS-DMA queue, matrix pipe 33 % busy), and a 256 x 128 tile moves
@@ -46,7 +46,7 @@ constexpr int x6p_stages(int npl, bool wide = false) { return npl == 1 ? 4 : (np
 // ~630 idle matrix-pipe cycles per K step even with no global memory traffic at all)
 template <int NPL, bool WIDE, bool ILV = false>
 __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParams p) {
-    static_assert(!WIDE || NPL == 2, "the wide tile exists for the two-plane fp16 operands only");
+    static_assert(!WIDE || NPL <= 2, "the wide tile exists for the fp16 operands (two planes with the plain low piece, or the one plane of 16-bit storage)");
     static_assert(NPL >= 1 && NPL <= 3, "one, two or three operand planes");
     constexpr int PBN = WIDE ? 256 : SS_X6P_BN;
     constexpr int B_PLANE_B = PBN * ROWB;
@@ -207,8 +207,11 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
         if constexpr (WIDE) {
             // one fragment set: half 0 (read after the previous barrier) -> 12 MFMAs -> half 1 into the same registers -> 12 MFMAs ->
             // chunk c+1 landed + barrier -> its half 0, and the DMA of chunk c+2 into the stage just released
+            // (ring of STAGES: the STAGES - 2 younger chunk groups may still be in flight; the epilogue's stores are older than all of them)
+            constexpr int VW = (STAGES - 2) * NDMA;
+            static_assert(VW <= 63, "vmcnt is a 6-bit field");
             for (int c = 0; c < nchunks; ++c) {
-                const int st1 = st ^ 1;
+                const int st1 = st + 1 == STAGES ? 0 : st + 1;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
                 __builtin_amdgcn_sched_barrier(0);
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): chunk c+1 landed
+                __builtin_amdgcn_s_waitcnt(0x0070 | (VW & 15) | ((VW >> 4) << 14));      // vmcnt(VW) lgkmcnt(0): chunk c+1 landed
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 frag(a0, b0, st1, so0);
@@ -316,10 +319,11 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
         // store instructions of 256 B per tile: 55 of the kernel's 252 us, tools/x6p_dma_probe.sh).  Each wave owns 2 KiB of LDS
         // beyond the operand ring and transposes its 64 x 64 sub-tile through it 8 rows at a time: 8 ds_write_b32, then 2
         // ds_read_b128 + 2 global_store_dwordx4 per lane, every store instruction = 4 rows x 256 contiguous bytes.
-        const bool vec_ok = !WIDE && (p.N - (cur.n0 + wn * 64) >= 64) && (p.ldc % 4 == 0) && !(p.dbg & 16);
+        // (wide: the register-transposed form only -- its LDS holds no scratch beyond the ring)
+        const bool vec_ok = (!WIDE || !(p.dbg & 8)) && (p.N - (cur.n0 + wn * 64) >= 64) && (p.ldc % 4 == 0) && !(p.dbg & 16);
         // exactly NST store instructions leave this wave only when all its 64 rows exist (a masked-off store is branched over)
         const bool full_rows = cur.m0 + wm * 64 + 64 <= p.M;
-        relaxed = vec_ok && full_rows && !(p.dbg & 32);
+        relaxed = !WIDE && vec_ok && full_rows && !(p.dbg & 32);          // (the wide K loop keeps the strict count)
         if (vec_ok && !(p.dbg & 8)) {
             // Register-transposed epilogue: per (mi, ni, row quad) the four registers of a lane are four consecutive rows of its
             // column; a 4 x 4 transpose inside every group of four adjacent lanes (ss_quad_transpose, DPP) turns them into four
@@ -715,7 +719,12 @@ bool ss_x6p_wide_ok(long M, int N, int K, int nbatch) {
 
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     if (p.K % PBK || p.k_per_split % PBK || p.splits < 1 || p.lda % 8 || p.ldb % 8) return SS_ERR_UNSUPPORTED;
-    const bool wide = p.fp16x2 == 1 && p.plain_l;
+    const bool one = p.fp16x2 == 2;          // fp16x2 == 2: ONE fp16 plane per operand, one product (16-bit activation storage)
+    // one plane on the 256 x 256 tile: one accumulator set anyway, the same MFMA order per accumulator as the 256 x 128 kernel -> the
+    // same bits, two thirds of the operand bytes per output element (x6p_wide1 = 0: off)
+    const bool wide1 = one && ss_tuning().x6p_wide1 && p.N % 256 == 0 && p.splits == 1 && p.K >= 2 * PBK &&
+                       (ss_tuning().x6p == 2 || ((p.M + PBM - 1) / PBM) * (long)(p.N / 256) * p.nbatch >= 512);
+    const bool wide = (p.fp16x2 == 1 && p.plain_l) || wide1;
     X6PParams pd = p;
     pd.dbg = ss_tuning().tile_dbg & (2 | 8 | 16 | 32 | 64 | 128);          // 8: the LDS-transposed epilogue, 16: the scalar-store epilogue (A/B measurement)
     if (wide && (p.N % 256 || p.splits != 1)) return SS_ERR_UNSUPPORTED;
@@ -728,6 +737,7 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_x6p_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
@@ -737,7 +747,6 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     const int cus = (ss_tuning().gemm_cus >= 8 && ss_tuning().gemm_cus < n_cu) ? ss_tuning().gemm_cus / 8 * 8 : n_cu;
     const bool persistent = ss_tuning().gemm_persistent && tiles > cus && p.k_per_split >= 3 * PBK && p.K % p.k_per_split == 0;
     const long nwg = persistent ? cus : tiles;
-    const bool one = p.fp16x2 == 2;          // fp16x2 == 2: ONE fp16 plane per operand, one product (16-bit activation storage)
     // x3h planes, every tile at least two K chunks deep: the ping-pong kernel (same results bit for bit; x6p_pp = 0 keeps the one-phase kernel)
     if (p.fp16x2 == 1 && !wide && ss_tuning().x6p_pp && p.k_per_split >= 2 * PBK && p.K % p.k_per_split == 0) {
         static const bool pp_attr = [] {
@@ -759,10 +768,11 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
-    SsProfScope prof(wide ? "gemm_x6p_kernel<2,wide>" : (one ? "gemm_x6p_kernel<1>" : (p.fp16x2 ? "gemm_x6p_kernel<2>" : "gemm_x6p_kernel<3>")),
+    SsProfScope prof(wide1 ? "gemm_x6p_kernel<1,wide>" : wide ? "gemm_x6p_kernel<2,wide>" : (one ? "gemm_x6p_kernel<1>" : (p.fp16x2 ? "gemm_x6p_kernel<2>" : "gemm_x6p_kernel<3>")),
                      2.0 * p.M * p.N * p.K * p.nbatch * (one ? 1 : (p.fp16x2 ? 3 : 6)),
                      2.0 * (one ? 1 : (p.fp16x2 ? 2 : 3)) * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
-    if (one) hipLaunchKernelGGL((gemm_x6p_kernel<1, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(1) * 1 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);
+    if (wide1) hipLaunchKernelGGL((gemm_x6p_kernel<1, true>), dim3((unsigned)nwg), dim3(1024), x6p_stages(1, true) * (A_PLANE_B + 256 * ROWB), s, pd);
+    else if (one) hipLaunchKernelGGL((gemm_x6p_kernel<1, false>), dim3((unsigned)nwg), dim3(512), x6p_stages(1) * 1 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);
     else if (wide) hipLaunchKernelGGL((gemm_x6p_kernel<2, true>), dim3((unsigned)nwg), dim3(1024), x6p_stages(2, true) * 2 * (A_PLANE_B + 256 * ROWB), s, p);
     // x3h: fragment reads interleaved with the MFMAs (ILV; bit-identical; gemm_ilv = 0 keeps the burst form)
     else if (p.fp16x2 && ss_tuning().gemm_ilv) hipLaunchKernelGGL((gemm_x6p_kernel<2, false, true>), dim3((unsigned)nwg), dim3(512), x6p_stages(2) * 2 * (A_PLANE_B + B_PLANE_B) + 16384, s, pd);

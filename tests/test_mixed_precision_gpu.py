@@ -114,6 +114,43 @@ def test_conv_16bit_storage_vs_fp32_oracle(case, dt):
         assert rel_l2(arena.grad("c/bias").cpu(), br.grad) <= 1e-3
 
 
+@pytest.mark.parametrize("cin,cout,n,h", [(256, 256, 2, 64), (512, 256, 2, 64)])
+def test_one_plane_wide_tile_equals_the_256x128_kernel_bit_for_bit(cin, cout, n, h):
+    """gemm_x6p_kernel<1, wide> (256 x 256 tile, 16 waves; x6p_wide1) accumulates every output element in the same order as
+    gemm_x6p_kernel<1> (256 x 128): forward output and data gradient of a 16-bit Winograd convolution must not change by a bit."""
+    E, LY, L = mod("engine"), mod("layers"), mod("_lib")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(cin + cout)
+    x_cpu = (torch.rand((n, h, h, cin), generator=g) * 2 - 1).to(torch.float16)
+    gy_cpu = (torch.rand((n, h, h, cout), generator=g) - 0.5).to(torch.float16)
+    w_cpu = (torch.rand((3, 3, cin, cout), generator=g) - 0.5) * 0.5
+    outs = []
+    for wide in (0, 1):
+        with L.config(x6p=2, x6p_wide1=wide):
+            arena = E.ParamArena(dev)
+            layer = LY.Conv2D(arena, "c", 3, cin, cout, padding=("reflect", 1), use_bias=False)
+            arena.materialize()
+            arena["c/kernel"].copy_(w_cpu)
+            tape = E.Tape()
+            x = E.Act(x_cpu.to(dev), requires_grad=True)
+            lib = L.load()
+            lib.ss_prof_reset()
+            lib.ss_prof_enable(1)
+            y = layer(tape, x)
+            gt, _ = y.grad_target()
+            gt.t.copy_(gy_cpu.to(dev))
+            arena.zero_grad()
+            tape.backward()
+            torch.cuda.synchronize()
+            lib.ss_prof_enable(0)
+            used = L.prof_summary()
+            assert ("gemm_x6p_kernel<1,wide>" in used) == bool(wide) and ("gemm_x6p_kernel<1>" in used) == (not wide), sorted(used)
+            outs.append((y.dense().clone(), x.get_grad().dense().clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("kind,c,shape,act,res", [("instance", 64, (2, 32, 32), "relu", False), ("instance", 32, (2, 24, 20), None, True),
                                                    ("batch", 25, (3, 40, 36), "relu", True), ("batch", 16, (2, 8, 8), "sigmoid", False)])

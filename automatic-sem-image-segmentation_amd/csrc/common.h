@@ -269,6 +269,7 @@ struct TNParams {
     int32_t a_prescaled;
     const unsigned int* amax_b2;
     int32_t stripes_b2;
+    int32_t one_plane;            // read the leading planes only, one product (16-bit activation storage, wino16_products = 1)
 };
 bool ss_gemm_tn_x3h_ok(int M, int N, long K);
 int ss_gemm_tn_splits(int M, int N, long K, int nbatch, int* k_per_split);

@@ -1086,6 +1086,9 @@ int wgrad_impl(const WinoProb& q, const TS* x, const TS* dy, float* dw, int accu
         g.k_per_split = kps;
         g.amax_a = q.x_amax; g.stripes_a = q.x_stripes; g.bound_a = BOUND_X;
         g.amax_b = q.dy_amax; g.stripes_b = q.dy_stripes; g.bound_b = BOUND_DY;
+        // 16-bit storage, wino16_products = 1 (the default): the leading planes alone, one product -- the operand rounding the forward
+        // pass and the data gradient of these layers already run with (gemm_x6p_kernel<1>); 3: the planes' full 22 bits
+        g.one_plane = sizeof(TS) != 4 && ss_tuning().wino16_products != 3 ? 1 : 0;
         const int rc = ss_launch_gemm_tn_x3h(g, s);
         if (rc != SS_OK) return rc;
         launch_wino_dw<R>(part, g.splits, q.cin, q.cout, dw, accumulate, s);

@@ -26,9 +26,13 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr int TBM = 256, TBN = 128, TBK = 32;
 constexpr int TA_ROW = TBM * 2, TB_ROW = TBN * 2;            // bytes per k row
 constexpr int TA_PLANE = TBK * TA_ROW, TB_PLANE = TBK * TB_ROW;      // 16 KiB, 8 KiB
-constexpr int TSTAGE = 2 * (TA_PLANE + TB_PLANE);           // 48 KiB
-constexpr int TSTAGES = 3;
-constexpr int TNDMA = TSTAGE / 1024 / 8;                    // 6 LDS-DMA instructions per wave and K step
+// NPL = operand planes read: 2 = (h, l) with the three products of the x3h arithmetic; 1 = the leading plane alone, one product (16-bit
+// activation storage under wino16_products = 1: the operand rounding of the forward pass's one-plane GEMMs; the l planes are ignored)
+template <int NPL> struct TNC {
+    static constexpr int STAGE = NPL * (TA_PLANE + TB_PLANE);          // 48 / 24 KiB
+    static constexpr int STAGES = NPL == 2 ? 3 : 5;                     // 144 / 120 KiB in flight or in use
+    static constexpr int NDMA = STAGE / 1024 / 8;                       // 6 / 3 LDS-DMA instructions per wave and K step
+};
 
 __device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -40,8 +44,11 @@ __device__ __forceinline__ s16x4 tr4(const unsigned char* p) {
 // ILV: the transposing fragment reads between the MFMAs instead of in front of them (as gemm_x6p.hip) -- measured SLOWER here (16 reads per
 // half step: 378 vs 333 us at n = 16, 215 vs 194 at n = 8, tools/tn_probe.py): kept as a measurement switch only, the launcher uses false.
 // SCALAR_EPI (the default): the one-column-per-lane epilogue (64 four-byte stores per lane); false = the register-transposed one.
-template <bool ILV, bool SCALAR_EPI = true>
+template <bool ILV, bool SCALAR_EPI = true, int NPL = 2>
 __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
+    static_assert(NPL == 2 || !ILV, "the interleaved form exists for the two-plane kernel only");
+    constexpr int TSTAGE = TNC<NPL>::STAGE, TSTAGES = TNC<NPL>::STAGES, TNDMA = TNC<NPL>::NDMA;
+    constexpr int NQ = NPL == 2 ? 3 : 1;          // MFMA groups per K half
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -77,14 +84,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
 #pragma unroll
         for (int j = 0; j < TNDMA; ++j) {
             const int q = wave * TNDMA + j;
-            if (q < 32) {
+            if (q < NPL * 16) {
                 const int pl = q >> 4, pc = q & 15;
                 const int row = 2 * pc + (lane >> 5);
                 const int pseg = (lane & 31) >> 2;                          // physical 64-byte segment of the row
                 const int col = ((pseg ^ (row & 3)) * 64 + (lane & 3) * 16) / 2;      // logical channel offset
                 g[j] = p.a + pl * p.a_plane + batch * p.a_bs + (long)(k_begin + row) * p.lda + m0 + col;
             } else {
-                const int q2 = q - 32;
+                const int q2 = q - NPL * 16;
                 const int pl = q2 >> 3, pc = q2 & 7;
                 const int row = 4 * pc + (lane >> 4);
                 const int pseg = (lane & 15) >> 2;
@@ -98,14 +105,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
 #pragma unroll
     for (int j = 0; j < TNDMA; ++j) {
         const int q = wave * TNDMA + j;
-        loff[j] = q < 32 ? (q >> 4) * TA_PLANE + (q & 15) * 1024 : 2 * TA_PLANE + ((q - 32) >> 3) * TB_PLANE + ((q - 32) & 7) * 1024;
+        loff[j] = q < NPL * 16 ? (q >> 4) * TA_PLANE + (q & 15) * 1024 : NPL * TA_PLANE + ((q - NPL * 16) >> 3) * TB_PLANE + ((q - NPL * 16) & 7) * 1024;
     }
     const unsigned short* gp[TNDMA];
     const unsigned short* gpn[TNDMA];
     if (t_first >= t_end) return;
     TileCtx cur = setup(t_first, gp);
 
-    f32x16 acc[2][2][2];          // [0]: h*h, [1]: the cross terms (they carry the factor 2^-11)
+    f32x16 acc[NPL][2][2];        // [0]: h*h, [1]: the cross terms (they carry the factor 2^-11)
 
     // fragment read addresses.  Lane l, read rr (0 / 1), K half kh: k row = 16 kh + 8 (l >> 5) + 4 rr + ((l & 15) >> 2),
     // channel = (wave tile) + 32 mi + 16 ((l >> 4) & 1) + 4 (l & 3).  k & 3 = (l & 15) >> 2 for every read: ONE swizzle term per lane.
@@ -121,12 +128,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
         ob[i] = kr * TB_ROW + (((b2 >> 6) ^ sw) << 6) + (b2 & 63);
     }
 
-    f16x8 a0[2][2], b0[2][2], a1[2][2], b1[2][2];          // [plane][mi / ni]
-    auto frag = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][2], int stage, int kh) {
+    f16x8 a0[NPL][2], b0[NPL][2], a1[NPL][2], b1[NPL][2];          // [plane][mi / ni]
+    auto frag = [&](f16x8 (&a)[NPL][2], f16x8 (&b)[NPL][2], int stage, int kh) {
         const unsigned char* sa = lds + stage * TSTAGE + kh * 16 * TA_ROW;
-        const unsigned char* sb = lds + stage * TSTAGE + 2 * TA_PLANE + kh * 16 * TB_ROW;
+        const unsigned char* sb = lds + stage * TSTAGE + NPL * TA_PLANE + kh * 16 * TB_ROW;
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const s16x4 x0 = tr4(sa + pl * TA_PLANE + oa[i]), x1 = tr4(sa + pl * TA_PLANE + oa[i] + 4 * TA_ROW);
@@ -136,9 +143,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
             }
         }
     };
-    auto frag_plane = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][2], int stage, int kh, int pl) {
+    auto frag_plane = [&](f16x8 (&a)[NPL][2], f16x8 (&b)[NPL][2], int stage, int kh, int pl) {
         const unsigned char* sa = lds + stage * TSTAGE + kh * 16 * TA_ROW;
-        const unsigned char* sb = lds + stage * TSTAGE + 2 * TA_PLANE + kh * 16 * TB_ROW;
+        const unsigned char* sb = lds + stage * TSTAGE + NPL * TA_PLANE + kh * 16 * TB_ROW;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const s16x4 x0 = tr4(sa + pl * TA_PLANE + oa[i]), x1 = tr4(sa + pl * TA_PLANE + oa[i] + 4 * TA_ROW);
@@ -149,17 +156,19 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
     };
     // l*h, h*l (cross accumulators), h*h; consecutive MFMAs go to different accumulators
     constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0}, HS[3] = {1, 1, 0};
-    auto mma4 = [&](f16x8 (&a)[2][2], f16x8 (&b)[2][2], int q) {
+    auto mma4 = [&](f16x8 (&a)[NPL][2], f16x8 (&b)[NPL][2], int q) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                acc[HS[q]][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], acc[HS[q]][mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < 2; ++ni) {
+                if constexpr (NPL == 1) acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mi], b[0][ni], acc[0][mi][ni], 0, 0, 0);
+                else acc[HS[q]][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[HA[q]][mi], b[HB[q]][ni], acc[HS[q]][mi][ni], 0, 0, 0);
+            }
     };
 
     long kstep[TNDMA];          // elements per K step of the operand a piece belongs to
 #pragma unroll
-    for (int j = 0; j < TNDMA; ++j) kstep[j] = (long)TBK * (wave * TNDMA + j < 32 ? p.lda : p.ldb);
+    for (int j = 0; j < TNDMA; ++j) kstep[j] = (long)TBK * (wave * TNDMA + j < NPL * 16 ? p.lda : p.ldb);
 
     // scales: the planes hold a * 2^(14 - ea) and b * 2^(14 - eb) (conv_wino.hip, same slots, same bounds)
     // a_prescaled: the A planes carry per-row scales that the producer of B folded into B's rows (ea = 14: no factor left), and B's
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
         TileCtx nxt = cur;
         if (more) nxt = setup(t + t_stride, gpn);
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < NPL; ++s)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -202,8 +211,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
             frag(a1, b1, st, 1);
             if (!ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) mma4(a0, b0, q);
-            if (ILV) {          // the 16 transposing reads of the other K half between this half's MFMAs instead of in a burst in front of them (gemm_x6p.hip ILV)
+            for (int q = 0; q < NQ; ++q) mma4(a0, b0, q);
+            if constexpr (ILV) {          // the 16 transposing reads of the other K half between this half's MFMAs instead of in a burst in front of them (gemm_x6p.hip ILV)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -212,7 +221,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0x0070 | (((TSTAGES - 2) * TNDMA) & 15));      // vmcnt(6) lgkmcnt(0): chunk c+1 landed, own reads of chunk c done
+            static_assert((TSTAGES - 2) * TNDMA <= 15, "low vmcnt bits only");
+            __builtin_amdgcn_s_waitcnt(0x0070 | (((TSTAGES - 2) * TNDMA) & 15));      // vmcnt(6 / 9) lgkmcnt(0): chunk c+1 landed, own reads of chunk c done
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (!ILV) frag(a0, b0, st1, 0);
@@ -222,13 +232,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
             const int cn = own ? ca : (more ? ca - nchunks : nchunks - 1);
             unsigned char* dst = lds + st * TSTAGE;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (ILV && q < 2) frag_plane(a0, b0, st1, 0, q);          // plane q of the next step's first half: 8 reads behind this group's MFMAs
+            for (int q = 0; q < NQ; ++q) {
+                if constexpr (ILV) { if (q < 2) frag_plane(a0, b0, st1, 0, q); }          // plane q of the next step's first half: 8 reads behind this group's MFMAs
                 mma4(a1, b1, q);
 #pragma unroll
                 for (int j = 0; j < TNDMA; ++j)
-                    if (j * 3 / TNDMA == q) dma16(((own || !more) ? gp[j] : gpn[j]) + cn * kstep[j], dst + loff[j]);
-                if (ILV) {
+                    if (j * NQ / TNDMA == q) dma16(((own || !more) ? gp[j] : gpn[j]) + cn * kstep[j], dst + loff[j]);
+                if constexpr (ILV) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
                     const int m = cur.m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     float* crow = cbase + (long)m * p.N;
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) crow[32 * ni] = fmaf(acc[1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]) * out_scale;
+                    for (int ni = 0; ni < 2; ++ni) crow[32 * ni] = (NPL == 1 ? acc[0][mi][ni][r] : fmaf(acc[NPL - 1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r])) * out_scale;
                 }
             }
         } else {
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
                     for (int ni = 0; ni < 2; ++ni) {
                         float v[4];
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) v[rr] = fmaf(acc[1][mi][ni][rq * 4 + rr], 4.8828125e-4f, acc[0][mi][ni][rq * 4 + rr]) * out_scale;
+                        for (int rr = 0; rr < 4; ++rr) v[rr] = (NPL == 1 ? acc[0][mi][ni][rq * 4 + rr] : fmaf(acc[NPL - 1][mi][ni][rq * 4 + rr], 4.8828125e-4f, acc[0][mi][ni][rq * 4 + rr])) * out_scale;
                         *(f32x4*)(grow + 32 * ni) = ss_quad_transpose(v[0], v[1], v[2], v[3], odd, hi);
                     }
                 }
@@ -309,6 +319,7 @@ int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_x3h_kernel<false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr_set;
@@ -317,14 +328,17 @@ int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s) {
     const int cus = (ss_tuning().gemm_cus >= 8 && ss_tuning().gemm_cus < n_cu) ? ss_tuning().gemm_cus / 8 * 8 : n_cu;
     const bool persistent = ss_tuning().gemm_persistent && tiles > cus && p.k_per_split >= 3 * TBK && p.K % p.k_per_split == 0;
     const long nwg = persistent ? cus : tiles;
-    SsProfScope prof("gemm_tn_x3h_kernel", 2.0 * p.M * p.N * p.K * p.nbatch * 3,
-                     2.0 * 2 * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
+    const int npl = p.one_plane ? 1 : 2;
+    SsProfScope prof(p.one_plane ? "gemm_tn_x3h_kernel<1 plane>" : "gemm_tn_x3h_kernel", 2.0 * p.M * p.N * p.K * p.nbatch * (p.one_plane ? 1 : 3),
+                     2.0 * npl * ((double)p.M + p.N) * p.K * p.nbatch + 4.0 * p.M * p.N * p.nbatch * p.splits, s);
     // default: burst fragment reads + the one-column-per-lane epilogue -- the two variants of gemm_x6p.hip both measure slower here
     // (tools/tn_probe.py, n = 8 / 16: interleaved reads 218 / 381 us, register-transposed epilogue 194 / 339 us, this form 188 - 193 /
     // 332 - 333 us).  tile_dbg (measurement): 4 = interleaved reads, 16 = register-transposed epilogue; all three are bit-identical
-    if (ss_tuning().tile_dbg & 4) hipLaunchKernelGGL((gemm_tn_x3h_kernel<true, true>), dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
-    else if (ss_tuning().tile_dbg & 16) hipLaunchKernelGGL((gemm_tn_x3h_kernel<false, false>), dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
-    else hipLaunchKernelGGL((gemm_tn_x3h_kernel<false, true>), dim3((unsigned)nwg), dim3(512), TSTAGES * TSTAGE, s, p);
+    constexpr int LDS2 = TNC<2>::STAGES * TNC<2>::STAGE, LDS1 = TNC<1>::STAGES * TNC<1>::STAGE;
+    if (p.one_plane) hipLaunchKernelGGL((gemm_tn_x3h_kernel<false, true, 1>), dim3((unsigned)nwg), dim3(512), LDS1, s, p);
+    else if (ss_tuning().tile_dbg & 4) hipLaunchKernelGGL((gemm_tn_x3h_kernel<true, true>), dim3((unsigned)nwg), dim3(512), LDS2, s, p);
+    else if (ss_tuning().tile_dbg & 16) hipLaunchKernelGGL((gemm_tn_x3h_kernel<false, false>), dim3((unsigned)nwg), dim3(512), LDS2, s, p);
+    else hipLaunchKernelGGL((gemm_tn_x3h_kernel<false, true>), dim3((unsigned)nwg), dim3(512), LDS2, s, p);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

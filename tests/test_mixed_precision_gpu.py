@@ -109,7 +109,9 @@ def test_conv_16bit_storage_vs_fp32_oracle(case, dt):
     # (the one-product Winograd path rounds the TRANSFORMED operands to fp16's 11 bits and F(4x4,3x3) amplifies that ~10x: 3e-3 measured)
     tol = 6e-3 if dt == "bf16" else (5e-3 if "wino" in name else 1e-3)
     assert e_y <= tol and e_dx <= tol, (e_y, e_dx)
-    assert e_dw <= 1e-3, e_dw           # fp32 weight gradient of exactly representable operands
+    # fp32 weight gradient of exactly representable operands; the Winograd weight gradient rounds the TRANSFORMED operands to one fp16
+    # plane each as the forward pass does (wino16_products = 1)
+    assert e_dw <= (5e-3 if "wino" in name else 1e-3), e_dw
     if bias:
         assert rel_l2(arena.grad("c/bias").cpu(), br.grad) <= 1e-3
 

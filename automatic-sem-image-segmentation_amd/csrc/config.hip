@@ -53,7 +53,7 @@ const Key KEYS[] = {
     {"norm_order", &SsTuning::norm_order, "bit mask, order in which the norm kernels' workgroups walk a tensor (results bit-identical): 1 = backward statistics from the END (last group / chunk first: what the producer of dy wrote last is still in the Infinity Cache), 2 = apply kernels take the GROUPS from the end as well (they always take the row chunks of a group from the end), 4 = backward apply walks forward (pairs with 1)"},
     {"norm_fuse_fin", &SsTuning::norm_fuse_fin, "norm passes over mid-size tensors reduce the statistics partials of their own channel block in the APPLY kernel's prologue (fixed order, fp64) instead of a separate finalize launch; bit 0: forward passes (OPT-IN: as accurate per op as the finalize kernels -- tools/norm_fuse_diag.py -- but another rounding of the statistics, and the reference-generated CycleGAN vectors contain constant tiles whose ReLU masks hang on that rounding: profiles/r06_norm_fused_finalize.md), bit 1: backward passes (the default: 2); 0: always the finalize kernels"},
     {"wgrad_mfma_x6", &SsTuning::wgrad_mfma_x6, "generic weight-gradient kernel (channel counts that are not multiples of 32, unaligned views: the MultiResUNet's odd widths) on the bf16 matrix cores with the exact three-piece split formed in registers (six products); 0: v_mfma_f32_32x32x2_f32"},
-    {"wgrad_stage", &SsTuning::wgrad_stage, "weight gradient of the stride-2 3 x 3 / 4 x 4 layers with the operands staged once per spatial tile and every tap served from LDS (conv_wgrad_stage.hip); 0: wgrad_x6_kernel"},
+    {"wgrad_stage", &SsTuning::wgrad_stage, "weight gradient of the stride-2 3 x 3 / 4 x 4 layers with the operands staged once per spatial tile and every tap served from LDS (conv_wgrad_stage.hip); 0: wgrad_x6_kernel; 2 (measurement): the same kernel with its phases in lockstep"},
     {"x6p_wide1", &SsTuning::x6p_wide1, "16-bit activation storage: the one-plane Winograd GEMMs with 256-multiple output channels on 256 x 256 tiles (same bits as the 256 x 128 kernel); 0: off"},
     {"wgrad_tn", &SsTuning::wgrad_tn, "Winograd weight gradient on pre-split K-major fp16 planes with transposing LDS reads (gemm_tn_x3h.hip); 0: in-kernel split"},
 };

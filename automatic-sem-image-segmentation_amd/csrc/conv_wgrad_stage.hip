@@ -217,17 +217,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; if (NPL == 2) accx[i][r] = 0.f; }
 
-    if (t_begin < t_end) {
-        load_tile(t_begin);
-        store_x(0);
-        store_b(0);
-    }
-    __syncthreads();
-    for (int t = t_begin; t < t_end; ++t) {
-        const int st = (t - t_begin) & 1;
-        const unsigned char* const sx = lds + st * stage_b;
-        const unsigned char* const sb = sx + NPL * xplane;
-        if (t + 1 < t_end) load_tile(t + 1);
+    // One tile's matrix work: every tap of this wave against the tile's dy fragment, K = 16 at a time
+    auto mma_tile = [&](const unsigned char* sx, const unsigned char* sb) {
 #pragma unroll
         for (int ks = 0; ks < TK / 16; ++ks) {
             if (p.dbg & 4) break;          // measurement: no fragment reads, no MFMAs
@@ -256,11 +247,40 @@ __global__ __launch_bounds__(512, 1) void wgrad_stage_kernel(WGradParams p, WSGe
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
             }
         }
-        // (stage st ^ 1 was last read in iteration t - 1: every wave has passed that barrier.  Placing the two halves between the K = 16
-        // steps instead -- to run the split's VALU work under the MFMAs -- was measured SLOWER: 331 -> 400 us on the 64 -> 128 layer, the
-        // loads have not landed by then and the wait stalls the matrix stream)
-        if (t + 1 < t_end) { store_x(st ^ 1); store_b(st ^ 1); }
-        __syncthreads();
+    };
+    // Tile t + 1 (in this thread's load registers since the previous iteration) -> the other LDS stage, then the loads of tile t + 2.
+    auto stage_next = [&](int t, int st) {
+        if (t + 1 < t_end) {
+            store_x(st ^ 1);
+            store_b(st ^ 1);
+            if (t + 2 < t_end) load_tile(t + 2);
+        }
+    };
+    // Workgroup barrier that orders LDS traffic only (conv_tile.hip): __syncthreads() would also drain the prefetch loads in flight across it.
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // STAGGERED halves: the two waves of a SIMD (w and w + 4) run a tile's two phases in opposite order -- one multiplies tile t while the
+    // other splits / stores tile t + 1, then they swap -- so the matrix pipe works while the VALU splits and vice versa.  In lockstep (all
+    // eight waves multiply, then all eight split: wgrad_stage = 2, measurement) the split phase was the exposed term: MFMAs + fragment reads alone
+    // 206 us, split + stores alone 91 us, together 330 (64 -> 128 layer, tools/wgrad_phase_probe.py).  Loads are issued one tile further
+    // ahead than they are consumed, right after the registers they fill have been stored.
+    const bool early = wave >= 4 && !(p.dbg & 16);
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_x(0);
+        store_b(0);
+        if (t_begin + 1 < t_end) load_tile(t_begin + 1);
+    }
+    lds_barrier();
+    for (int t = t_begin; t < t_end; ++t) {
+        const int st = (t - t_begin) & 1;
+        const unsigned char* const sx = lds + st * stage_b;
+        const unsigned char* const sb = sx + NPL * xplane;
+        // (stage st ^ 1 was last read in iteration t - 1: every wave has passed that barrier)
+        if (early) stage_next(t, st);
+        mma_tile(sx, sb);
+        if (!early) stage_next(t, st);
+        lds_barrier();
     }
 
     // ---- partials: part[split][(t, ca)][cb]; the wave's tiles: tap t, rows ca0 + 0..31, columns cb0 + 32 wj + 0..31
@@ -348,7 +368,7 @@ int ss_launch_wgrad_stage_partials(const WGradParams& p, hipStream_t s) {
                      2.0 * p.ntaps * p.Ca * p.Cb * (double)P * (f32 ? 3 : 1), (f32 ? 4.0 : 2.0) * ((double)p.N * p.AH * p.AW * p.Ca + (double)P * p.Cb), s);
     const unsigned nwg = (unsigned)(p.splits * AB);
     WGradParams pd = p;
-    pd.dbg = ss_tuning().tile_dbg;          // measurement only (phase skipping; 0 in every product path)
+    pd.dbg = (ss_tuning().tile_dbg & 7) | (ss_tuning().wgrad_stage == 2 ? 16 : 0);          // measurement only (phase skipping, lockstep phases; 0 in every product path)
     if (p.dtype == SS_DTYPE_F16) {
         if (p.ntaps == 9) hipLaunchKernelGGL((wgrad_stage_kernel<9, 128, _Float16>), dim3(nwg), dim3(512), smem, s, pd, g);
         else hipLaunchKernelGGL((wgrad_stage_kernel<16, 64, _Float16>), dim3(nwg), dim3(512), smem, s, pd, g);

@@ -238,6 +238,10 @@ struct X6PParams {
     int32_t fp16x2;               // 0: three bf16 planes, six products (x6);  1: two fp16 planes h + 2^-11 l, three products (x3h)
     int32_t dbg;                  // measurement only (tile_dbg & 64: skip the B operand's LDS-DMA; & 128: skip A's): results are wrong
     int64_t a_plane, b_plane, a_bs, b_bs, c_bs, c_ss;
+    // one-plane products only (fp16x2 == 2): C stored as fp16 (c points at halfs, ldc / c_bs / c_ss count elements) after a multiplication
+    // by the power of two c_scale that keeps the largest possible |sum| (2^28 K) inside fp16's range
+    int32_t c16;
+    float c_scale;
 };
 // Up to four gather problems of ONE launch (the sub-pixel phases of a stride-2 data gradient / transposed convolution: same input,
 // same output tensor, same class grid; they differ in the output phase, their taps and their weight planes).  Workgroup slot s of
@@ -281,7 +285,7 @@ bool ss_x6p_wide_ok(long M, int N, int K, int nbatch);
 int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s);
 
 // kernel-selection switches: ONE explicit table, set through ss_config_set (config.hip); SS_* environment variables give the initial values
-struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products, c1_mfma, x6p_pp, wino_save, gemm_ilv, gemm_cus, gconv_phases, phases_fused, phases_split, norm_order, norm_fuse_fin, wgrad_mfma_x6, wgrad_stage, x6p_wide1; };
+struct SsTuning { int x6, x3h, x3h_direct, x6p, winograd, wino_r, wgrad_c1, norm_fused_pix, gconv_fast, nt512, tile256, tile_conv, tile_th, tile_dbg, tile_stagger, weight_cache, wgrad_tn, gemm_persistent, gconv_v2, x6p_wide, twgrad_x3h, wino16_products, c1_mfma, x6p_pp, wino_save, gemm_ilv, gemm_cus, gconv_phases, phases_fused, phases_split, norm_order, norm_fuse_fin, wgrad_mfma_x6, wgrad_stage, x6p_wide1, wino16_m16; };
 const SsTuning& ss_tuning();
 // ss_prof_*: brackets the kernel launched inside this scope with HIP events on its stream when profiling is enabled (config.hip).
 // flops = EXECUTED matrix-instruction FLOPs of the launch (all piece products), bytes = algorithmic HBM bytes (0 if not stated)

@@ -55,6 +55,7 @@ const Key KEYS[] = {
     {"wgrad_mfma_x6", &SsTuning::wgrad_mfma_x6, "generic weight-gradient kernel (channel counts that are not multiples of 32, unaligned views: the MultiResUNet's odd widths) on the bf16 matrix cores with the exact three-piece split formed in registers (six products); 0: v_mfma_f32_32x32x2_f32"},
     {"wgrad_stage", &SsTuning::wgrad_stage, "weight gradient of the stride-2 3 x 3 / 4 x 4 layers with the operands staged once per spatial tile and every tap served from LDS (conv_wgrad_stage.hip); 0: wgrad_x6_kernel; 2 (measurement): the same kernel with its phases in lockstep"},
     {"x6p_wide1", &SsTuning::x6p_wide1, "16-bit activation storage: the one-plane Winograd GEMMs with 256-multiple output channels on 256 x 256 tiles (same bits as the 256 x 128 kernel); 0: off"},
+    {"wino16_m16", &SsTuning::wino16_m16, "16-bit activation storage, one-plane Winograd layers: the GEMM writes its Winograd-domain product as fp16 (under a fixed power-of-two scale) and the output transform reads that -- half the bytes of the product's round trip; 0: fp32 product"},
     {"wgrad_tn", &SsTuning::wgrad_tn, "Winograd weight gradient on pre-split K-major fp16 planes with transposing LDS reads (gemm_tn_x3h.hip); 0: in-kernel split"},
 };
 
@@ -96,6 +97,7 @@ SsTuning from_env() {
     v.wgrad_mfma_x6 = env_is("SS_WGRAD_MFMA_X6", '0') ? 0 : 1;
     v.wgrad_stage = env_is("SS_WGRAD_STAGE", '0') ? 0 : 1;
     v.x6p_wide1 = env_is("SS_X6P_WIDE1", '0') ? 0 : 1;
+    v.wino16_m16 = env_is("SS_WINO16_M16", '0') ? 0 : 1;
     v.weight_cache = 1;
     return v;
 }

@@ -579,12 +579,13 @@ inline void wino_record_weight_jobs(const float* w, int w_cin, int w_cout, int f
 }
 
 // y[n, R*ty+i, R*tx+j, c] (+)= act(bias + (A^T M A)_ij)
-template <int R, typename TO = float>
-__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, int N, int OH, int OW, int C, int TH, int TW,
+// TM: type the Winograd-domain product is stored in (float; _Float16 under the scale 1 / m_scale: the one-plane 16-bit path, wino16_m16)
+template <int R, typename TO = float, typename TM = float>
+__global__ __launch_bounds__(256) void wino_output_kernel(const TM* __restrict__ Mx, int N, int OH, int OW, int C, int TH, int TW,
                                                           const float* __restrict__ bias, int act, float alpha,
                                                           TO* __restrict__ y, int y_cs, int accumulate, int FH, int FW,
                                                           const float* __restrict__ tile_inv = nullptr, const float* __restrict__ w_inv = nullptr,
-                                                          float* __restrict__ stats = nullptr) {
+                                                          float* __restrict__ stats = nullptr, float m_scale = 1.f) {
     // FH > 0 ("reflect fold", data gradient of reflect-pad(1) + 3x3 valid conv): the OH x OW grid is the PADDED gradient shifted by
     // one (virtual o' = P + 1, P in [0, FH+1]); padded pixel P lands on dx[reflect(P - 1)].  With FH % R == 0 the two padded
     // rows that fold onto the same dx row (P = 0,2 and P = FH-1,FH+1) sit in ONE tile, i.e. one thread: they are summed in
@@ -602,14 +603,14 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     const int ty = (int)(r % TH);
     const int n = (int)(r / TH);
     const long xs = tiles * C;
-    const float* m = Mx + tile * C + c;
-    const float unscale = tile_inv ? tile_inv[tile] * w_inv[0] : 1.f;      // x3h operands carry power-of-two scales (exact to undo)
+    const TM* m = Mx + tile * C + c;
+    const float unscale = (tile_inv ? tile_inv[tile] * w_inv[0] : 1.f) * m_scale;      // x3h operands carry power-of-two scales (exact to undo)
     T s[R][P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         T col[P], o[R];
 #pragma unroll
-        for (int i = 0; i < P; ++i) col[i] = *(const T*)(m + (long)(i * P + j) * xs) * unscale;
+        for (int i = 0; i < P; ++i) col[i] = ld_t<T, TM>(m + (long)(i * P + j) * xs) * unscale;
         t_out<R, T>(col, o);
 #pragma unroll
         for (int i = 0; i < R; ++i) s[i][j] = o[i];
@@ -832,11 +833,22 @@ int fwd16_impl(const WinoProb& q, const TS* x, const float* w, int w_cin, int w_
     g.a_plane = (long)XI * Mpad * q.cin; g.a_bs = Mpad * q.cin;
     g.b_plane = (long)XI * Npad * q.cin; g.b_bs = (long)Npad * q.cin;
     g.c_bs = tiles * q.cout; g.c_ss = 0;
+    // one plane per operand: the product may be stored as fp16 as well (wino16_m16) -- |sum| <= 2^14 * 2^14 * K, scaled into fp16's range
+    // by a fixed power of two (exact; typical sums sit ~2^10 below the bound, fp16 keeps 11 bits down to 2^-30 of it), undone in the
+    // output transform: half the bytes of the product's round trip, which is what paces the one-plane GEMM
+    const bool m16 = one && ss_tuning().wino16_m16;
+    int kexp = 0;
+    while ((1 << kexp) < q.cin) ++kexp;
+    if (m16) { g.c16 = 1; g.c_scale = ldexpf(1.f, -(28 + kexp - 15)); }
     const int rcx = ss_launch_gemm_x6p(g, s);
     if (rcx != SS_OK) return rcx;
-    SsProfScope prof("wino_output_kernel", 0.0, (double)XI * tiles * q.cout * 4 + (double)q.n * q.oh * q.ow * q.cout * sizeof(TS) * (accumulate ? 2 : 1), s);
-    hipLaunchKernelGGL((wino_output_kernel<R, TS>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
-                       bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w, tile_inv, w_inv, (float*)nullptr);
+    SsProfScope prof("wino_output_kernel", 0.0, (double)XI * tiles * q.cout * (m16 ? 2 : 4) + (double)q.n * q.oh * q.ow * q.cout * sizeof(TS) * (accumulate ? 2 : 1), s);
+    if (m16)
+        hipLaunchKernelGGL((wino_output_kernel<R, TS, _Float16>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, (const _Float16*)Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
+                           bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w, tile_inv, w_inv, (float*)nullptr, 1.f / g.c_scale);
+    else
+        hipLaunchKernelGGL((wino_output_kernel<R, TS>), dim3(g256(tiles * (q.cout / VW))), dim3(256), 0, s, Mx, q.n, q.oh, q.ow, q.cout, TH, TW,
+                           bias, act, alpha, y, q.out_cs, accumulate, q.fold_h, q.fold_w, tile_inv, w_inv, (float*)nullptr);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

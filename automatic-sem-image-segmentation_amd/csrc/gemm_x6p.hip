@@ -324,7 +324,9 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
         // exactly NST store instructions leave this wave only when all its 64 rows exist (a masked-off store is branched over)
         const bool full_rows = cur.m0 + wm * 64 + 64 <= p.M;
         relaxed = !WIDE && vec_ok && full_rows && !(p.dbg & 32);          // (the wide K loop keeps the strict count)
-        if (vec_ok && !(p.dbg & 8)) {
+        const bool c16 = NPL == 1 && p.c16;          // (one-plane kernels: the product as fp16 under p.c_scale)
+        typedef _Float16 c16x4 __attribute__((ext_vector_type(4)));
+        if (vec_ok && (!(p.dbg & 8) || c16)) {
             // Register-transposed epilogue: per (mi, ni, row quad) the four registers of a lane are four consecutive rows of its
             // column; a 4 x 4 transpose inside every group of four adjacent lanes (ss_quad_transpose, DPP) turns them into four
             // consecutive columns of ONE row = one 16-byte store: 16 store instructions per wave (8 rows x 128 B each), no LDS trip.
@@ -345,7 +347,8 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
                             v[rr] = NACC == 1 ? acc[0][mi][ni][rq * 4 + rr] : fmaf(acc[NACC - 1][mi][ni][rq * 4 + rr], 4.8828125e-4f, acc[0][mi][ni][rq * 4 + rr]);
                         const f32x4 o = ss_quad_transpose(v[0], v[1], v[2], v[3], odd, hi);
                         if (row_ok) {
-                            if (p.dbg & 2) __builtin_nontemporal_store(o, (f32x4*)(grow + 32 * ni));          // measurement: streaming stores
+                            if (c16) *(c16x4*)((_Float16*)p.c + ((grow + 32 * ni) - p.c)) = __builtin_convertvector(o * p.c_scale, c16x4);
+                            else if (p.dbg & 2) __builtin_nontemporal_store(o, (f32x4*)(grow + 32 * ni));          // measurement: streaming stores
                             else *(f32x4*)(grow + 32 * ni) = o;
                         }
                     }
@@ -388,7 +391,11 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
                 float* crow = cb + (long)m * p.ldc;               // one row pointer for both column tiles
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    if (32 * ni < nrem) crow[32 * ni] = NACC == 1 ? acc[0][mi][ni][r] : fmaf(acc[NACC - 1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
+                    if (32 * ni < nrem) {
+                        const float v = NACC == 1 ? acc[0][mi][ni][r] : fmaf(acc[NACC - 1][mi][ni][r], 4.8828125e-4f, acc[0][mi][ni][r]);
+                        if (c16) ((_Float16*)p.c)[(crow + 32 * ni) - p.c] = (_Float16)(v * p.c_scale);
+                        else crow[32 * ni] = v;
+                    }
             }
         }
         if (more) {
@@ -728,6 +735,7 @@ int ss_launch_gemm_x6p(const X6PParams& p, hipStream_t s) {
     X6PParams pd = p;
     pd.dbg = ss_tuning().tile_dbg & (2 | 8 | 16 | 32 | 64 | 128);          // 8: the LDS-transposed epilogue, 16: the scalar-store epilogue (A/B measurement)
     if (wide && (p.N % 256 || p.splits != 1)) return SS_ERR_UNSUPPORTED;
+    if (p.c16 && !one) return SS_ERR_UNSUPPORTED;
     const int pbn = wide ? 256 : SS_X6P_BN;
     const int gridM = (p.M + PBM - 1) / PBM, gridN = (p.N + pbn - 1) / pbn;
     // one-time kernel attribute (idempotent; C++11 thread-safe static initialisation, no mutable flag)

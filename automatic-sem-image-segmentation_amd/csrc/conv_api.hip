@@ -1301,7 +1301,17 @@ int native16_fwd(const ss_conv_desc* d, const void* x, const float* w, const flo
     if (wino16_fwd_takes(c, d->algo, &q) && ws && ws_bytes >= ss_wino_fwd_ws(q)) {
         *taken = true;
         q.wc = desc_wcache(d);
+        q.in_norm = c.in_norm;          // x is a pre-normalisation tensor: normalised in the input transform (ss_conv_desc::in_norm_*)
+        if (c.in_norm.groups > 0 && c.x_amax && c.x_valid != 1 && !(q.wc && q.wc->fill_only)) {      // the transform reports max|normalised x|
+            if (c.x_valid != 2) (void)hipMemsetAsync(c.x_amax, 0, (size_t)SS_AMAX_STRIPES * SS_AMAX_STRIDE * 4, s);
+            q.in_norm.amax_out = c.x_amax;
+        }
         return ss_wino_conv_fwd16(q, d->dtype, x, w, c.cin, c.cout, 0, bias, y, d->act, d->act_alpha, 0, ws, ws_bytes, s);
+    }
+    if (c.in_norm.groups > 0) {          // (taken, so that the caller does not fall through to the staged fp32 path, which would ignore it)
+        *taken = true;
+        ss_set_error("in_norm: this forward pass does not normalise in its operand load (ss_conv2d_fuses_in_norm)");
+        return SS_ERR_UNSUPPORTED;
     }
     if (tconv_takes_fwd(c, d->algo)) {
         *taken = true;
@@ -1409,12 +1419,22 @@ int native16_bwd_weight(const ss_conv_desc* d, const void* x, const void* dy, fl
         if ((d->algo == SS_ALGO_AUTO || d->algo == SS_ALGO_X6) && c.kh * c.kw <= SS_MAX_TAPS && wino_fwd_prob(c, d->algo, &q) &&
             ss_tuning().wino_r == 4 && ss_wino_wgrad_tn(q) && !dbias && ws && ws_bytes >= ss_wino_wgrad_ws(q)) {
             *taken = true;
+            q.in_norm = c.in_norm;
+            if (c.in_norm.groups > 0 && !(c.x_amax && c.x_valid == 1)) {
+                ss_set_error("in_norm: the weight gradient needs the forward pass's max|normalised x| (x_amax, x_amax_valid)");
+                return SS_ERR_UNSUPPORTED;
+            }
             unsigned int* sl = (unsigned int*)((char*)ws + ss_wino_wgrad_ws(q) - 256);
             const AmaxRef ax = act_amax16(x, d->dtype, (long)c.n * c.ih * c.iw, c.cin, c.in_cs, c.x_amax, c.x_valid, sl, s);
             const AmaxRef ay = act_amax16(dy, d->dtype, (long)c.n * c.oh * c.ow, c.cout, c.out_cs, c.dy_amax, c.dy_valid, sl + 1, s);
             q.x_amax = ax.p; q.x_stripes = ax.stripes; q.dy_amax = ay.p; q.dy_stripes = ay.stripes;
             return ss_wino_conv_wgrad16(q, d->dtype, x, dy, dw, accumulate, ws, ss_wino_wgrad_ws(q), s);
         }
+    }
+    if (c.in_norm.groups > 0) {
+        *taken = true;
+        ss_set_error("in_norm: this weight-gradient pass does not normalise in its operand load");
+        return SS_ERR_UNSUPPORTED;
     }
     if (dbias) return SS_OK;
     if (!twgrad_takes(c, d->algo)) return gather(c, x, dy);
@@ -1504,8 +1524,7 @@ bool valid_desc_any(const ss_conv_desc* d) {
     if (d->struct_size != sizeof(ss_conv_desc)) return valid_desc(d);          // sets the message
     if (d->dtype == SS_DTYPE_F32) return valid_desc(d);
     if (d->dtype != SS_DTYPE_BF16 && d->dtype != SS_DTYPE_F16) { ss_set_error("ss_conv_desc.dtype = %d unknown", d->dtype); return false; }
-    if (d->in_norm_groups != 0) { ss_set_error("ss_conv_desc.in_norm_*: fp32 activation storage only"); return false; }
-    ss_conv_desc t = *d;
+    ss_conv_desc t = *d;          // (in_norm_*: checked by valid_desc; only the passes ss_conv2d_fuses_in_norm names take it, the others fail)
     t.dtype = SS_DTYPE_F32;
     return valid_desc(&t);
 }
@@ -1571,10 +1590,20 @@ size_t ss_conv2d_saved_operand_bytes(const ss_conv_desc* d) {
 }
 
 int ss_conv2d_fuses_in_norm(const ss_conv_desc* d, int pass) {
-    if (!d || d->struct_size != sizeof(ss_conv_desc) || d->dtype != SS_DTYPE_F32 || d->transposed) return 0;
+    if (!d || d->struct_size != sizeof(ss_conv_desc) || d->transposed) return 0;
     ss_conv_desc t = *d;
     t.in_norm_groups = 0;
-    if (!valid_desc(&t)) return 0;
+    if (!valid_desc_any(&t)) return 0;
+    if (d->dtype != SS_DTYPE_F32) {          // 16-bit storage: the native Winograd passes (native16_fwd / native16_bwd_weight)
+        ConvProb c = plain(&t);
+        c.dtype = d->dtype;
+        WinoProb q;
+        if (pass == SS_PASS_FWD) return wino16_fwd_takes(c, d->algo, &q) && c.cin % 32 == 0 ? 1 : 0;
+        if (pass == SS_PASS_BWD_WEIGHT)
+            return (d->algo == SS_ALGO_AUTO || d->algo == SS_ALGO_X6) && c.kh * c.kw <= SS_MAX_TAPS && wino_fwd_prob(c, d->algo, &q) &&
+                   ss_tuning().wino_r == 4 && ss_wino_wgrad_tn(q) ? 1 : 0;
+        return 0;
+    }
     const ConvProb c = plain(&t);
     WinoProb q;
     if (c.kh * c.kw > SS_MAX_TAPS || !wino_fwd_prob(c, d->algo, &q)) return 0;

@@ -191,9 +191,10 @@ __global__ __launch_bounds__(256, FN ? 3 : 1) void wino_input_kernel(const TI* _
         iy[i] = ss_map_index(R * ty + i - pt, H, reflect);
         ix[i] = ss_map_index(R * tx + i - pl, W, reflect);
     }
-    // fused input normalisation (ss_conv_desc::in_norm_*; BF 3 / 4 launchers only): `in` is the PRE-norm tensor, every element is
-    // normalised as it is loaded with norm_apply_kernel's expression (norm.hip), padding zeros stay zero
-    constexpr bool fused = FN && (BF == 3 || BF == 4);
+    // fused input normalisation (ss_conv_desc::in_norm_*; BF 3 / 4 / 5 launchers only): `in` is the PRE-norm tensor, every element is
+    // normalised as it is loaded with norm_apply_kernel's expression (norm.hip), padding zeros stay zero.  16-bit storage: the value is
+    // rounded to the storage type exactly where norm_apply_kernel would have stored it -- the two routes agree bit for bit
+    constexpr bool fused = FN && (BF == 3 || BF == 4 || BF == 5);
     T n_mu = zero_v<T>(), n_k = zero_v<T>(), n_bt = zero_v<T>();
     if (fused) {
         const long gi = (nm.groups > 1 ? (long)n * C : 0L) + c;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256, FN ? 3 : 1) void wino_input_kernel(const TI* _
                 for (int k = 0; k < VW; ++k) {
                     const float t = __builtin_fmaf(d[i][k] - n_mu[k], n_k[k], n_bt[k]);          // = norm_apply_kernel's expression (norm.hip)
                     const float o = t > 0.f ? t : t * n_slope;
-                    d[i][k] = ok ? o : 0.f;
+                    d[i][k] = ok ? (float)(TI)o : 0.f;
                     n_am = fmaxf(n_am, fabsf(d[i][k]));
                 }
             }
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256, FN ? 3 : 1) void wino_input_kernel(const TI* _
         }
     }
     if (BF == 0 && amax_out) block_amax(vmax, amax_out);      // launcher: whole blocks only
-    if (BF == 3 && fused && nm.amax_out) ss_block_amax_to_slot(n_am, nm.amax_out);      // max|normalised x| for the weight gradient's scale
+    if ((BF == 3 || BF == 5) && fused && nm.amax_out) ss_block_amax_to_slot(n_am, nm.amax_out);      // max|normalised x| for the weight gradient's scale
 }
 
 // E[xi][tile][c] = (A e A^T)_xi for the RxR tile e of dy (zero outside the dy extent)
@@ -787,7 +788,8 @@ template <int R, typename TS>
 int fwd16_impl(const WinoProb& q, const TS* x, const float* w, int w_cin, int w_cout, int flip, const float* bias, TS* y,
                int act, float alpha, int accumulate, void* ws, hipStream_t s) {
     constexpr int XI = (R + 2) * (R + 2), VW = WT<R>::VW;
-    if (R != 4 || !ss_wino_fwd_x3h(q) || (((uintptr_t)w) & 15) || q.in_norm.groups > 0) return SS_ERR_UNSUPPORTED;
+    if (R != 4 || !ss_wino_fwd_x3h(q) || (((uintptr_t)w) & 15)) return SS_ERR_UNSUPPORTED;
+    if (q.in_norm.groups > 0 && (q.cin % 32 || (q.in_norm.act != SS_ACT_NONE && q.in_norm.act != SS_ACT_RELU && q.in_norm.act != SS_ACT_LRELU))) return SS_ERR_UNSUPPORTED;
     const int TH = (q.oh + R - 1) / R, TW = (q.ow + R - 1) / R;
     const long tiles = (long)q.n * TH * TW;
     const int cvi = q.cin / VW;
@@ -816,8 +818,14 @@ int fwd16_impl(const WinoProb& q, const TS* x, const float* w, int w_cin, int w_
     const bool one = ss_tuning().wino16_products != 3;          // 1: one plane / one product; 3: the x3h arithmetic of the fp32-storage path
     {
         // algorithmic bytes (HBM roofline, bench.py): one read of x, one write of the fp16 operand plane(s)
-        SsProfScope prof("wino_input_kernel", 0.0, (double)q.n * q.h * q.w * q.cin * sizeof(TS) + (double)XI * tiles * q.cin * 2 * (one ? 1 : 2), s);
-        if (one)
+        SsProfScope prof(q.in_norm.groups > 0 ? "wino_input_kernel<normalising>" : "wino_input_kernel", 0.0, (double)q.n * q.h * q.w * q.cin * sizeof(TS) + (double)XI * tiles * q.cin * 2 * (one ? 1 : 2), s);
+        if (q.in_norm.groups > 0 && one)          // x is the PRE-norm tensor: normalised (and rounded to the stored type) in the load
+            hipLaunchKernelGGL((wino_input_kernel<R, 5, true, TS>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                               TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, 0, q.in_norm);
+        else if (q.in_norm.groups > 0)
+            hipLaunchKernelGGL((wino_input_kernel<R, 3, true, TS>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
+                               TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv, (unsigned int*)nullptr, (const unsigned int*)nullptr, 0, 0, 0, q.in_norm);
+        else if (one)
             hipLaunchKernelGGL((wino_input_kernel<R, 5, false, TS>), dim3(g256(tiles * cvi)), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin,
                                TH, TW, q.pt, q.pl, q.reflect, V, Mpad, tile_inv);
         else
@@ -1030,7 +1038,7 @@ int wgrad_impl(const WinoProb& q, const TS* x, const TS* dy, float* dw, int accu
     float* E = (float*)((char*)ws + ss_align_up((size_t)XI * tiles * q.cin * 4, 256));
     float* part = (float*)((char*)E + ss_align_up((size_t)XI * tiles * q.cout * 4, 256));
     if (q.in_norm.groups > 0 && !(R == 4 && ss_wino_wgrad_tn(q) && q.x_amax && q.dy_amax)) return SS_ERR_UNSUPPORTED;
-    if (sizeof(TS) != 4 && !(R == 4 && ss_wino_wgrad_tn(q) && q.x_amax && q.dy_amax && q.in_norm.groups == 0)) return SS_ERR_UNSUPPORTED;
+    if (sizeof(TS) != 4 && !(R == 4 && ss_wino_wgrad_tn(q) && q.x_amax && q.dy_amax)) return SS_ERR_UNSUPPORTED;
     if (R == 4 && ss_wino_wgrad_tn(q) && q.x_amax && q.dy_amax) {
         // both operands as K-major fp16 (h, l) planes, one power-of-two scale per tensor from max|x| / max|dy| and the gain bounds of
         // the transforms (|B^T d B| <= 100 max|d| < 2^7, |A e A^T| <= 225 max|e| < 2^8), GEMM by LDS-DMA + transposing LDS reads
@@ -1076,9 +1084,13 @@ int wgrad_impl(const WinoProb& q, const TS* x, const TS* dy, float* dw, int accu
                 hipLaunchKernelGGL((wino_input_kernel<R, 4>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
                                    q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X);
         } else {
-            SsProfScope prof("wino_input_kernel", 0.0, (double)q.n * q.h * q.w * q.cin * sizeof(TS) + (double)XI * tiles * q.cin * 4, s);
-            hipLaunchKernelGGL((wino_input_kernel<R, 4, false, TS>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
-                               q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X);
+            SsProfScope prof(q.in_norm.groups > 0 ? "wino_input_kernel<normalising>" : "wino_input_kernel", 0.0, (double)q.n * q.h * q.w * q.cin * sizeof(TS) + (double)XI * tiles * q.cin * 4, s);
+            if (q.in_norm.groups > 0)
+                hipLaunchKernelGGL((wino_input_kernel<R, 4, true, TS>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
+                                   q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X, 0, q.in_norm);
+            else
+                hipLaunchKernelGGL((wino_input_kernel<R, 4, false, TS>), dim3(g256(tiles * (q.cin / VW))), dim3(256), 0, s, x, q.in_cs, q.n, q.h, q.w, q.cin, TH, TW,
+                                   q.pt, q.pl, q.reflect, V, tiles, nullptr, nullptr, q.x_amax, q.x_stripes, BOUND_X);
         }
         SS_LAUNCH_CHECK();
         {

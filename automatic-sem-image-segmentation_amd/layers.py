@@ -255,10 +255,10 @@ class Conv2D:
         return u
 
     def will_fuse_in_norm(self, pre, tape):
-        """Would this layer, fed the DEFERRED normalisation of the dense fp32 activation `pre`, normalise in its operand load (forward
+        """Would this layer, fed the DEFERRED normalisation of the dense activation `pre` (any storage type), normalise in its operand load (forward
         and, when `tape` asks for weight gradients, the weight gradient too)?  Norm(..., defer_to=layer) asks before it skips its
         apply pass: a consumer that cannot fuse gets the ordinary norm (same kernels, same bits as without any deferral)."""
-        if not FUSE_IN_NORM or pre.dt != L.DTYPE_F32 or pre.c != self.cin or self.transposed:
+        if not FUSE_IN_NORM or pre.c != self.cin or self.transposed:
             return False
         oh, ow = self.out_hw(pre.h, pre.w)
         key = (pre.n, pre.h, pre.w, pre.cs, self.cout, pre.dt)
@@ -402,14 +402,14 @@ class Norm:
 
     def __call__(self, tape, x, act=None, act_alpha=0.0, residual=None, out=None, training=True, defer_to=None):
         """defer_to = the ONE convolution layer the result goes to: when that layer can normalise in its operand load
-        (Conv2D.will_fuse_in_norm) and the case allows it (fp32 storage, no residual, no caller-provided output, relu / leaky-relu /
+        (Conv2D.will_fuse_in_norm) and the case allows it (no residual, no caller-provided output, relu / leaky-relu /
         no activation, per-process statistics) only the statistics are taken and an engine.DeferredNorm is returned; otherwise this
         is the ordinary norm."""
         lib = L.load()
         assert x.c == self.c
         sync_now = SYNC_BN if self.kind == "batch" else None
         defer = bool(defer_to is not None and FUSE_IN_NORM and residual is None and out is None and act in (None, "relu", "lrelu")
-                     and sync_now is None and x.dt == L.DTYPE_F32 and (self.kind == "instance" or training)
+                     and sync_now is None and (self.kind == "instance" or training)
                      and x.parent is None and x.c0 == 0 and defer_to.will_fuse_in_norm(x, tape))
         y = out if out is not None else (None if defer else x.like())
         groups = x.n if self.kind == "instance" else 1

@@ -197,11 +197,12 @@ typedef struct ss_conv_desc {
      * pass of a following InstanceNorm / BatchNorm (ss_norm_desc::x_stats) then has nothing left to read ("fused IN + conv":
      * CycleGAN.py:327-329, 333-335).  Only written when ss_conv2d_stats_chunks(d) > 0. */
     void* y_stats;
-    /* Optional (in_norm_groups == 0: off), forward and weight-gradient passes, fp32 storage: the second half of "fused
+    /* Optional (in_norm_groups == 0: off), forward and weight-gradient passes, every storage type: the second half of "fused
      * InstanceNorm + conv" (CycleGAN.py:327-333: Conv2D -> GroupNormalization -> relu -> pad -> Conv2D).  `x` is then the
      * PRE-normalisation tensor of a norm whose apply pass was skipped (ss_norm_fwd with y == NULL left only mean / rstd), and the
      * pass forms  act((x - mean[g,c]) * (rstd[g,c] * gamma[c]) + beta[c])  -- the arithmetic of ss_norm_fwd, bit for bit -- while
-     * it loads its operand; the normalised tensor never exists in memory.  g = sample index when in_norm_groups == n, 0 when
+     * it loads its operand (16-bit storage: rounded to the stored type there, as the norm's own store would have); the normalised
+     * tensor never exists in memory.  g = sample index when in_norm_groups == n, 0 when
      * in_norm_groups == 1; gamma may be NULL.  Only the passes for which ss_conv2d_fuses_in_norm(d, pass) != 0 take it (others
      * return SS_ERR_UNSUPPORTED; the caller then runs ss_norm_apply and a plain convolution).  x_amax, when given, refers to
      * the NORMALISED tensor: the forward pass leaves its maximum there (unless x_amax_valid), the weight gradient reads it. */

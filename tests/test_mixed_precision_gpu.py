@@ -116,6 +116,58 @@ def test_conv_16bit_storage_vs_fp32_oracle(case, dt):
         assert rel_l2(arena.grad("c/bias").cpu(), br.grad) <= 1e-3
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("kind,act", [("instance", "relu"), ("batch", "lrelu")])
+def test_deferred_norm_in_the_operand_load_on_16bit_storage_is_bit_identical(kind, act, dt, monkeypatch):
+    """BASELINE config 5 names "fused InstanceNorm+conv" for fp16 storage: Norm(..., defer_to=conv) takes the statistics only and the
+    consuming Winograd convolution normalises -- and rounds to the stored type, where the norm's own apply pass would have stored --
+    in its input transforms (forward and weight gradient).  Both routes must agree bit for bit: output, dx, every parameter gradient
+    (the fp32-storage twin: test_direct_gpu.py::test_deferred_norm_is_applied_in_the_next_convolutions_operand_load)."""
+    E, LY, L = mod("engine"), mod("layers"), mod("_lib")
+    dev = torch.device("cuda:0")
+    c, n, h, w = 256, 2, 64, 64
+    g = torch.Generator().manual_seed(23)
+    x_cpu = torch.randn((n, h, w, c), generator=g).to(DT[dt])
+    gy_cpu = torch.randn((n, h, w, c), generator=g).to(DT[dt])
+
+    def run(fuse):
+        monkeypatch.setattr(LY, "FUSE_IN_NORM", fuse)
+        arena = E.ParamArena(dev)
+        c0 = LY.Conv2D(arena, "c0", 3, c, c, padding=("reflect", 1))
+        n0 = LY.Norm(arena, "n0", c, kind)
+        c1 = LY.Conv2D(arena, "c1", 3, c, c, padding=("reflect", 1))
+        arena.materialize()
+        gg = torch.Generator().manual_seed(6)
+        for nm in ("c0", "c1"):
+            arena[f"{nm}/kernel"].copy_((torch.rand((3, 3, c, c), generator=gg) - 0.5) * 0.05)
+        arena["n0/gamma"].copy_(torch.rand(c, generator=gg) + 0.5)
+        arena["n0/beta"].copy_(torch.rand(c, generator=gg) - 0.5)
+        if kind == "batch":
+            arena["n0/moving_variance"].fill_(1.0)
+        arena.zero_grad()
+        x = E.Act(x_cpu.to(dev), requires_grad=True)
+        t = E.Tape()
+        mid = n0(t, c0(t, x), act=act, act_alpha=0.2, defer_to=c1)
+        y = c1(t, mid)
+        assert y.dtype == DT[dt]
+        gt, _ = y.grad_target()
+        gt.t.copy_(gy_cpu.to(dev))
+        t.backward()
+        torch.cuda.synchronize()
+        grads = {k: arena.grad(k).clone() for k in ("c0/kernel", "c1/kernel", "n0/gamma", "n0/beta")}
+        return mid, y.dense().clone(), x.get_grad().dense().clone(), grads
+
+    mid1, y1, dx1, g1 = run(True)
+    assert isinstance(mid1, E.DeferredNorm) and not mid1.materialized, "the 16-bit Winograd passes of this shape must take the fused route"
+    mid0, y0, dx0, g0 = run(False)
+    assert not isinstance(mid0, E.DeferredNorm)
+    assert float(y0.float().abs().max()) > 0
+    assert torch.equal(y1, y0), float((y1.float() - y0.float()).abs().max())
+    assert torch.equal(dx1, dx0), float((dx1.float() - dx0.float()).abs().max())
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), (k, float((g1[k] - g0[k]).abs().max()))
+
+
 @pytest.mark.parametrize("cin,cout,n,h", [(256, 256, 2, 64), (512, 256, 2, 64)])
 def test_one_plane_wide_tile_equals_the_256x128_kernel_bit_for_bit(cin, cout, n, h):
     """gemm_x6p_kernel<1, wide> (256 x 256 tile, 16 waves; x6p_wide1) accumulates every output element in the same order as

@@ -43,6 +43,13 @@ typedef __bf16 xw_bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 xw_ld4(const float* q) { return *(const f32x4*)q; }
 __device__ __forceinline__ f32x4 xw_ld4(const _Float16* q) { return __builtin_convertvector(*(const xw_f16x4*)q, f32x4); }
 __device__ __forceinline__ f32x4 xw_ld4(const __bf16* q) { return __builtin_convertvector(*(const xw_bf16x4*)q, f32x4); }
+// ... at ELEMENT alignment (gfx950 global memory takes multi-dword accesses at any dword, the 16-bit types at any 2-byte address): the
+// 4-channel units of odd channel counts / odd pixel strides
+typedef _Float16 xw_f16x4u __attribute__((ext_vector_type(4), aligned(2)));
+typedef __bf16 xw_bf16x4u __attribute__((ext_vector_type(4), aligned(2)));
+__device__ __forceinline__ f32x4 xw_ld4u(const float* q) { const f32x4u u = *(const f32x4u*)q; return f32x4{u[0], u[1], u[2], u[3]}; }
+__device__ __forceinline__ f32x4 xw_ld4u(const _Float16* q) { return __builtin_convertvector((xw_f16x4)(*(const xw_f16x4u*)q), f32x4); }
+__device__ __forceinline__ f32x4 xw_ld4u(const __bf16* q) { return __builtin_convertvector((xw_bf16x4)(*(const xw_bf16x4u*)q), f32x4); }
 __device__ __forceinline__ void xw_st4(float* q, f32x4 v) { *(f32x4*)q = v; }
 __device__ __forceinline__ void xw_st4(_Float16* q, f32x4 v) { *(xw_f16x4*)q = __builtin_convertvector(v, xw_f16x4); }
 __device__ __forceinline__ void xw_st4(__bf16* q, f32x4 v) { *(xw_bf16x4*)q = __builtin_convertvector(v, xw_bf16x4); }
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
     const int n0 = (tile % gridN) * BN;
     const int nchunks = Ktot / XK;
     const int Cq = Ktot / P_ntaps;       // reduction channels per tap, padded to a multiple of 32
-    const bool ragged = Cq != p.Cin || (p.in_cs & 3) != 0 || (((uintptr_t)p.in) & 15) != 0;
+    const bool ragged = Cq != p.Cin || (p.in_cs & 3) != 0 || (((uintptr_t)p.in) & (S16 ? 7 : 15)) != 0;
     float a_scale = 1.f, out_scale = 1.f;
     if constexpr (H) {
         const int ea = ss_amax_exp(__uint_as_float(ss_amax_load(p.h_amax, p.amax_stripes))), ew = ss_amax_exp(__uint_as_float(p.h_amax2[0]));
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
         constexpr int S = decltype(setc)::value;
         const int t = k0 / Cq;                         // block-uniform
         const int ci0 = k0 - t * Cq;
-        if (S16 || !ragged) {          // (16-bit storage: the launcher admits whole, aligned 32-channel chunks only)
+        if (!ragged) {
             const T* abase = g_in + ci0 + c4a * 4;
 #pragma unroll
             for (int j = 0; j < AU; ++j) {
@@ -167,25 +174,24 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GConvParams p, const u
                 const T* pa = off < 0 ? (const T*)ss_zero_page16 : abase + off;      // masked taps read zeros
                 ra[S][j] = xw_ld4(pa);
             }
-        } else if constexpr (!S16) {
-            // any channel count / pixel stride (the MultiResUNet's odd widths): the reduction index runs over (tap, ci padded to a
-            // multiple of 32 -- the weight planes hold zeros there); a 4-channel unit is fetched with ONE dword-aligned
-            // global_load_dwordx4 when it lies fully inside the pixel's channels, element-wise when it straddles the end
+        } else {
+            // any channel count / pixel stride (the MultiResUNet's odd widths), any storage type: the reduction index runs over (tap, ci
+            // padded to a multiple of 32 -- the weight planes hold zeros there); a 4-channel unit is fetched with ONE element-aligned
+            // access (global_load_dwordx4 / dwordx2) when it lies fully inside the pixel's channels, element-wise when it straddles the end
             const int ci = ci0 + c4a * 4;
             const int nin = p.Cin - ci;                // channels of this unit that exist
 #pragma unroll
             for (int j = 0; j < AU; ++j) {
                 const int off = offtab[(arow + 32 * j) * P_ntaps + t];
                 const bool ok = off >= 0 && nin > 0;
-                const float* ptr = ok ? (const float*)g_in + (off + ci) : (const float*)ss_zero_page16;
+                const T* ptr = ok ? g_in + (off + ci) : (const T*)ss_zero_page16;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (nin >= 4) {
-                    const f32x4u u = *(const f32x4u*)ptr;
-                    v = f32x4{u[0], u[1], u[2], u[3]};
+                    v = xw_ld4u(ptr);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 3; ++e)
-                        if (e < nin) v[e] = ptr[e];
+                        if (e < nin) v[e] = (float)ptr[e];
                 }
                 ra[S][j] = v;
             }
@@ -747,7 +753,7 @@ int launch_x6h(const GConvParams& p, const unsigned short* planes, long plane_el
 }
 template <int BM, int BN>
 int launch_x6(const GConvParams& p, const unsigned short* planes, long plane_elems, int Npad, int Ktot, hipStream_t s, const GPhases* ph) {
-    if (p.dtype != SS_DTYPE_F32) {          // 16-bit stored activations: typed loaders, one fp16 operand plane (whole aligned 32-channel chunks, x3h)
+    if (p.dtype != SS_DTYPE_F32) {          // 16-bit stored activations: typed loaders, one fp16 operand plane (x3h)
         if (!ss_gconv_x6_typed_ok(p)) { ss_set_error("gconv_x6: this 16-bit problem has no typed loader"); return SS_ERR_UNSUPPORTED; }
         const bool two = ss_tuning().wino16_products == 3;
         if (p.dtype == SS_DTYPE_F16)
@@ -773,11 +779,9 @@ size_t ss_gconv_x6_planes_bytes(const GConvParams& p) {
 }
 
 // weights of `p` (fp32, addressed through p.w / taps / ldb / w_bs) -> the three K-contiguous bf16 planes
-// 16-bit storage through gconv_x6_kernel: x3h maxima present, whole 32-channel chunks at 8-byte aligned pixels, 4-aligned outputs
-bool ss_gconv_x6_typed_ok(const GConvParams& p) {
-    return p.h_amax && p.h_amax2 && p.Cin % 32 == 0 && (p.in_cs & 3) == 0 && (((uintptr_t)p.in) & 7) == 0 && p.Cout % 4 == 0 && (p.out_cs & 3) == 0 &&
-           (((uintptr_t)p.out) & 7) == 0;
-}
+// 16-bit storage through gconv_x6_kernel: the x3h maxima present (any channel count, stride and alignment: the kernel's ragged loader and
+// its element-wise epilogue take the MultiResUNet's odd widths in the stored type as they do in fp32)
+bool ss_gconv_x6_typed_ok(const GConvParams& p) { return p.h_amax && p.h_amax2; }
 
 int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s) {
     const int nb = p.nbatch > 1 ? p.nbatch : 1;

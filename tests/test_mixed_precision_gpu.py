@@ -48,6 +48,11 @@ CONV_CASES = [
     # their first stride-2 convolution): typed loaders there as well
     ("gather16_up_T3_128_64", 3, 128, 64, 2, "same", False, True, 4, 128, 128),
     ("gather16_down_s2_32_64_ragged", 3, 32, 64, 2, "same", False, False, 3, 100, 90),
+    # the MultiResUNet's odd widths below full resolution: gconv_x6_kernel's ragged loader (element-aligned 4-channel units) and
+    # element-wise epilogue in the stored type -- no fp32 staging copies
+    ("gather16_odd_3x3_53_35", 3, 53, 35, 1, "same", False, False, 2, 64, 64),
+    ("gather16_odd_1x1_105_71_bias", 1, 105, 71, 1, "same", True, False, 2, 64, 64),
+    ("gather16_odd_3x3_142_36_bias", 3, 142, 36, 1, "same", True, False, 1, 32, 32),
     ("up_T3", 3, 64, 32, 2, "same", False, True, 2, 32, 32),
     ("stem7_reflect", 7, 1, 16, 1, ("reflect", 3), False, False, 1, 64, 64),
     # one-channel layers at full resolution: the matrix-core kernels of conv_c1.hip read / write the multi-channel tensor as stored, only

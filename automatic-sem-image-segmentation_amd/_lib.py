@@ -116,6 +116,7 @@ SIGNATURES = {
     "ss_conv2d_uses_amax": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
     "ss_conv2d_stats_chunks": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "ss_conv2d_fuses_in_norm": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
+    "ss_norm_resident_timeouts": (c_i32, []),
     "ss_conv2d_saved_operand_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "ss_probe_mfma": (c_i32, [c_i32, c_vp, ctypes.c_size_t, c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ss_conv2d_wcache_bytes": (c_sz, [ctypes.POINTER(ConvDesc), c_i32]),

@@ -645,6 +645,177 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     if (amax) ss_block_amax_to_slot(am, amax);
 }
 
+// ---- InstanceNorm backward in ONE pass over the tensors (fp32, 32-channel blocks, <= 16384 pixels per sample: the residual trunk) ----
+// The two-pass form reads dy and x twice (statistics, then apply: five tensor passes where three are needed, 838 MB of traffic per
+// trunk layer where 536 MB would do).  Here the workgroups of one (sample, 32-channel block) -- a GROUP of NPIECE workgroups with
+// consecutive block indices -- keep their share of dy and x IN REGISTERS (32 pixel lanes x 8 channel quads per workgroup, NIT pixels
+// per thread: 2 x NIT float4), publish their partial sums, meet at a GROUP-LOCAL barrier (a counter in global memory), add the
+// group's partials in piece order (fp64, the same in every workgroup: deterministic) and apply from the registers.
+// MEASURED AND NOT THE DEFAULT (ss_config norm_bwd_resident = 1 switches it on; tools/norm_resident_probe.py): 229 us against the two
+// passes' 105 us at [8, 128, 128, 256].  What a workgroup streams takes ~8 us (128 KB in, 64 KB out); what it waits for between the two
+// halves is a chain of dependent device-scope round trips -- partial store (write-through), arrival atomic, polling, L2 invalidate,
+// partial loads: ~12 us -- and the register file holds two such workgroups per CU, so the chain is exposed, not hidden.  (First
+// version: plain stores + __threadfence(): an agent-scope release writes back the whole L2, full of other workgroups' dx: 604 us.)
+// Progress: a group's workgroups are dispatched in index order, so at most ONE group per resident launch is partly on the chip; its
+// members spin on <= NPIECE <= 32 of the 512 workgroup slots (two launches of this kind run side by side in the dual-chain step),
+// every slot beside them belongs to fully dispatched groups, which finish.  A spinning workgroup gives up after ~2^24 polls (seconds)
+// and counts it in g_norm_resident_timeouts (ss_norm_resident_timeouts): a wrong result that the tests see, never a hung GPU.
+__device__ unsigned int g_norm_resident_timeouts = 0;
+
+struct NormRes {
+    double* part;            // [groups][NPIECE][32][2] partial (sum g, sum g * xhat) of every workgroup
+    unsigned int* counter;   // [groups] arrivals (zero on entry), then [C / 32] tickets of the parameter-gradient pass (zero on entry)
+    double* rt;              // [n][C][2] the groups' totals (parameter gradients)
+    float* dgamma;
+    float* dbeta;
+    int acc_params, n, npiece;
+};
+
+template <int NIT>
+__global__ __launch_bounds__(256, 2) void norm_bwd_resident_kernel(const float* __restrict__ dy, int dy_cs, const float* __restrict__ x, int x_cs,
+                                                                   const float* __restrict__ y, int y_cs, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ rbeta, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, float* __restrict__ dx, int dx_cs,
+                                                                   float* __restrict__ dres, int dres_cs, int act, float alpha, int C, int P,
+                                                                   unsigned int* __restrict__ amax, NormRes r) {
+    __shared__ double red[64][33];          // [channel of the block x {s1, s2}][pixel lane] (+1: no bank aliasing between lanes)
+    __shared__ float stat[2][32];
+    const int tid = threadIdx.x;
+    const int cq = tid & 7, pl = tid >> 3;
+    const int ncb = C / 32;
+    const int grp = blockIdx.x / r.npiece, piece = blockIdx.x - grp * r.npiece;
+    const int n = grp / ncb, cb = grp - n * ncb;
+    const int c = cb * 32 + cq * 4;
+    const long gi = (long)n * C + c;
+    const f32x4 mu = *(const f32x4*)(mean + gi), rs = *(const f32x4*)(rstd + gi);
+    f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
+    if (gamma) gm = *(const f32x4*)(gamma + c);
+    const bool recompute = act != SS_ACT_NONE && y == nullptr;          // mask recomputed from x with the forward's expression
+    const bool from_y = act != SS_ACT_NONE && y != nullptr;
+    if (recompute) bt = *(const f32x4*)(rbeta + c);
+    const bool relu = act == SS_ACT_RELU;
+    const float slope = act == SS_ACT_LRELU ? alpha : 1.f;
+    f32x4 kk;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) kk[v] = rs[v] * gm[v];
+    const int p0 = piece * (32 * NIT) + pl;
+    const float* const gb = dy + (long)n * P * dy_cs + c;
+    const float* const xb = x + (long)n * P * x_cs + c;
+
+    f32x4 gv[NIT], xv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = p0 + 32 * it;
+        const bool ok = p < P;
+        gv[it] = ok ? *(const f32x4*)(gb + (long)p * dy_cs) : f32x4{0.f, 0.f, 0.f, 0.f};
+        xv[it] = ok ? *(const f32x4*)(xb + (long)p * x_cs) : mu;          // (xhat = 0 beyond the sample)
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        if (recompute) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) gv[it][v] *= ss_act_grad_pwl(__builtin_fmaf(xv[it][v] - mu[v], kk[v], bt[v]), relu, slope);
+        } else if (from_y) {
+            const int p = p0 + 32 * it;
+            if (p < P) {
+                const f32x4 yv = *(const f32x4*)(y + ((long)n * P + p) * y_cs + c);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) gv[it][v] *= ss_act_grad_pwl(yv[v], relu, slope);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float xh = (xv[it][v] - mu[v]) * rs[v];
+            xv[it][v] = xh;          // the registers keep g and xhat for the apply
+            s1[v] += gv[it][v];
+            s2[v] = fmaf(gv[it][v], xh, s2[v]);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { red[(cq * 4 + v) * 2][pl] = (double)s1[v]; red[(cq * 4 + v) * 2 + 1][pl] = (double)s2[v]; }
+    __syncthreads();
+    double* const mypart = r.part + ((long)grp * r.npiece + piece) * 64;
+    if (tid < 64) {          // fixed-order sum over the 32 pixel lanes
+        double a = 0.0;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) a += red[tid][q];
+        // a device-scope STORE (write-through past this XCD's L2), not a plain store + __threadfence(): an agent-scope release writes
+        // back the whole L2 -- full of the other workgroups' dx lines -- and with every workgroup fencing twice the kernel ran at 0.65 TB/s
+        __hip_atomic_store((unsigned long long*)mypart + tid, __builtin_bit_cast(unsigned long long, a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the stores above have been acknowledged (vmcnt) before the arrival is counted
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(r.counter + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned polls = 0;
+        while (__hip_atomic_load(r.counter + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)r.npiece) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++polls > (1u << 24)) { atomicAdd(&g_norm_resident_timeouts, 1u); break; }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (plain loads behind it see what the arrivals released)
+    // the group's totals: every thread fetches 8 pieces' worth of one (channel, sum) -- 32 x 64 independent loads in flight instead of a
+    // chain of 32 device-scope loads per thread (~1.5 us each: that chain alone was 50 us per workgroup) --, then the pieces are added
+    // in index order, the same sum in every workgroup of the group
+    {
+        const double* src = r.part + (long)grp * r.npiece * 64;
+        const int t64 = tid & 63, kq = tid >> 6;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kq * 8 + j;
+            red[t64][k] = k < r.npiece ? src[(long)k * 64 + t64] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double a = 0.0;
+        for (int k = 0; k < r.npiece; ++k) a += red[tid][k];
+        stat[tid & 1][tid >> 1] = (float)(a / (double)P);
+        if (piece == 0 && r.rt)
+            __hip_atomic_store((unsigned long long*)(r.rt + ((long)n * C + cb * 32 + (tid >> 1)) * 2 + (tid & 1)), __builtin_bit_cast(unsigned long long, a),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    // parameter gradients: the piece-0 workgroup of the LAST group of this channel block to get here adds the samples' totals in sample order
+    if (piece == 0 && r.rt && (r.dgamma || r.dbeta)) {
+        __shared__ int last;
+        if (tid == 0) last = __hip_atomic_fetch_add(r.counter + (long)gridDim.x / r.npiece + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(r.n - 1);
+        __syncthreads();
+        if (last && tid < 64) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int cc = cb * 32 + (tid >> 1), k = tid & 1;
+            double t = 0.0;
+            for (int gg = 0; gg < r.n; ++gg) t += r.rt[((long)gg * C + cc) * 2 + k];
+            float* dst = k ? r.dgamma : r.dbeta;
+            if (dst) dst[cc] = r.acc_params ? dst[cc] + (float)t : (float)t;
+        }
+    }
+    float am = 0.f;
+    float m1[4], m2[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { m1[v] = stat[0][cq * 4 + v]; m2[v] = stat[1][cq * 4 + v]; }
+    float* const ob = dx + (long)n * P * dx_cs + c;
+    float* const rb = dres ? dres + (long)n * P * dres_cs + c : nullptr;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = p0 + 32 * it;
+        if (p < P) {
+            f32x4 o;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                o[v] = kk[v] * (gv[it][v] - m1[v] - xv[it][v] * m2[v]);
+                am = fmaxf(am, fabsf(o[v]));
+            }
+            *(f32x4*)(ob + (long)p * dx_cs) = o;
+            if (rb) *(f32x4*)(rb + (long)p * dres_cs) = gv[it];
+        }
+    }
+    if (amax) ss_block_amax_to_slot(am, amax);
+}
+
 // sums[(g*C+c)*2+k] = sum over chunks of part (raw sums, fp64 combine)
 __global__ __launch_bounds__(256) void norm_collapse_kernel(const float* __restrict__ part, int chunks, int G, int C, float* __restrict__ sums) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -994,13 +1165,31 @@ int pick_v16(int c, std::initializer_list<int> strides, std::initializer_list<co
     return 4;
 }
 
+// geometry of the one-pass (register-resident) InstanceNorm backward: groups of npiece workgroups, 32 x nit pixels each
+struct ResGeom { bool ok; int nit, npiece; };
+inline ResGeom res_geom(const ss_norm_desc* d, int V, int acc_dx, bool acc_dres) {
+    ResGeom r{false, 0, 0};
+    if (!ss_tuning().norm_bwd_resident || d->dtype != SS_DTYPE_F32 || V != 4 || d->groups != d->n || d->c % 32 || acc_dx || acc_dres) return r;
+    if (d->act != SS_ACT_NONE && d->act != SS_ACT_RELU && d->act != SS_ACT_LRELU) return r;
+    const long P = (long)d->h * d->w;
+    if (P > 16384 || P < 1024) return r;
+    r.nit = P > 8192 ? 16 : (P > 4096 ? 8 : 4);          // <= 32 workgroups per group (the progress argument at the kernel)
+    r.npiece = (int)((P + 32 * r.nit - 1) / (32 * r.nit));
+    r.ok = r.npiece <= 32 && (long)d->n * (d->c / 32) * r.npiece >= 64;
+    return r;
+}
+size_t res_part_bytes(const ss_norm_desc* d) {          // the groups' fp64 partials; the arrival counters and tickets follow
+    return ss_align_up((size_t)d->n * (d->c / 32 + 1) * 32 * 64 * sizeof(double), 256);
+}
 size_t fused_part_bytes(const ss_norm_desc* d) {          // the fused form's fp64 partials; its pivots ([G][C] floats) follow
     return ss_align_up((size_t)d->groups * NORM_FUSE_MAX_CHUNKS * d->c * 2 * sizeof(double), 256);
 }
 size_t part_bytes(const ss_norm_desc* d) {
     const size_t a = (size_t)d->groups * norm_max_chunks(d->groups) * d->c * 2 * sizeof(float);
     const size_t b = fused_part_bytes(d) + ss_align_up((size_t)d->groups * d->c * sizeof(float), 256);
-    return ss_align_up(a > b ? a : b, 256);
+    const size_t c = d->groups == d->n && d->c % 32 == 0 ? res_part_bytes(d) + ss_align_up((size_t)(d->n + 1) * (d->c / 32 + 1) * sizeof(unsigned int), 256) : 0;
+    const size_t ab = a > b ? a : b;
+    return ss_align_up(ab > c ? ab : c, 256);
 }
 
 }  // namespace
@@ -1178,6 +1367,26 @@ int norm_bwd_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, const T* 
     float* part = (float*)ws;
     float* sums = (float*)((char*)ws + part_bytes(d));
     const double elems = (double)g.G * g.P * g.C;
+    if constexpr (std::is_same<T, float>::value) {
+        const ResGeom rg = res_geom(d, V, accumulate_dx, dres != nullptr && accumulate_dres);
+        if (rg.ok) {          // one pass: the (sample, 32-channel block) groups keep their share of dy and x in registers across a group-local barrier
+            NormRes r{};
+            r.part = (double*)ws;
+            r.counter = (unsigned int*)((char*)ws + res_part_bytes(d));
+            r.rt = (double*)((char*)ws + part_bytes(d) + ss_align_up((size_t)g.G * g.C * 2 * sizeof(float), 256));
+            r.dgamma = dgamma; r.dbeta = dbeta; r.acc_params = accumulate_params; r.n = g.G; r.npiece = rg.npiece;
+            const int groups = g.G * (g.C / 32);
+            (void)hipMemsetAsync(r.counter, 0, (size_t)(groups + g.C / 32) * sizeof(unsigned int), s);
+            SsProfScope prof("norm_bwd_resident_kernel", 0.0, elems * sizeof(T) * ((use_y ? 3 : 2) + 1 + (dres ? 1 : 0)), s);
+            const dim3 grid((unsigned)(groups * rg.npiece));
+#define SS_NBR(NIT_) hipLaunchKernelGGL((norm_bwd_resident_kernel<NIT_>), grid, dim3(256), 0, s, dy, dy_cstride, x, d->x_cstride, y, d->y_cstride, gamma, beta, \
+                                        mean, rstd, dx, dx_cstride, dres, d->res_cstride, d->act, d->act_alpha, g.C, (int)g.P, dxam, r)
+            if (rg.nit == 16) SS_NBR(16); else if (rg.nit == 8) SS_NBR(8); else SS_NBR(4);
+#undef SS_NBR
+            SS_LAUNCH_CHECK();
+            return SS_OK;
+        }
+    }
     const FuseGeom fz = fuse_geom(d, V, 2);
     if (fz.ok) {          // consumer-side finalize: statistics with the fused geometry -> apply, which reduces the partials of its own channels
         const dim3 fgrid(fz.chunks, fz.cblocks, g.G);
@@ -1354,6 +1563,14 @@ int norm_bwd_finish_t(const ss_norm_desc* d, const T* dy, int32_t dy_cstride, co
     }
 
 extern "C" {
+
+/* Diagnostics: how many workgroups of the one-pass InstanceNorm backward gave up waiting at their group barrier since the library was
+ * loaded (0 in every healthy run; such a launch produced wrong gradients).  Synchronises the device. */
+int ss_norm_resident_timeouts(void) {
+    unsigned int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_norm_resident_timeouts), sizeof(v)) != hipSuccess) return -1;
+    return (int)v;
+}
 
 int ss_norm_reports_amax(const ss_norm_desc* d) { return valid(d) && !norm_small(d) ? 1 : 0; }
 

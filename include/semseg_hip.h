@@ -291,6 +291,11 @@ typedef struct ss_norm_desc {
 } ss_norm_desc;
 
 size_t ss_norm_workspace_bytes(const ss_norm_desc* d);
+/* Diagnostics of the one-pass InstanceNorm backward (ss_config norm_bwd_resident): the number of workgroups that gave up waiting at
+ * their group-local barrier since the library was loaded -- 0 in every healthy run (a launch that counts here produced wrong
+ * gradients; the bound on the wait exists so that a scheduling surprise can never hang the GPU).  Synchronises the device; -1 on error. */
+int ss_norm_resident_timeouts(void);
+
 /* 1: ss_norm_fwd / ss_norm_bwd of this descriptor raise y_amax / dx_amax (the two-pass kernels, any storage type: the
  * maximum of the STORED values; the one-launch kernels for small groups leave the slots untouched).  Pure function of d and the ss_config table. */
 int ss_norm_reports_amax(const ss_norm_desc* d);

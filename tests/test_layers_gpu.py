@@ -322,6 +322,65 @@ def test_norm_fused_finalize_agrees_with_the_finalize_kernels_and_is_bit_stable(
             assert float((a - b).abs().max()) <= 4e-6 * max(float(a.abs().max()), 1.0), (kind, c, i, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("n,hw,c,act,use_res", [(3, 128, 64, "relu", False), (2, 128, 256, None, True), (4, 64, 96, "lrelu", False), (2, 100, 64, "relu", False)])
+def test_instance_norm_backward_in_one_pass_agrees_with_the_two_pass_form(n, hw, c, act, use_res):
+    """ss_config norm_bwd_resident: the register-resident one-pass InstanceNorm backward (group-local barrier between statistics and
+    apply) against the statistics + apply kernels and against float64: dx, the residual branch's gradient, dgamma, dbeta; two runs are
+    bit-identical (partials added in piece order); no workgroup ever gave up at its barrier."""
+    E, LY, L = _mods()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    x_cpu = torch.randn((n, hw, hw, c), generator=g) * 1.5 + 0.2
+    r_cpu = torch.randn((n, hw, hw, c), generator=g) if use_res else None
+    gy_cpu = torch.randn((n, hw, hw, c), generator=g)
+    gam, bet = torch.linspace(0.5, 1.5, c), torch.linspace(-0.3, 0.3, c)
+    runs = []
+    for mode in (0, 1, 1):
+        with L.config(norm_bwd_resident=mode):
+            arena = E.ParamArena(dev)
+            layer = LY.Norm(arena, "n", c, "instance")
+            arena.materialize()
+            arena["n/gamma"].copy_(gam)
+            arena["n/beta"].copy_(bet)
+            tape = E.Tape()
+            x = E.Act(x_cpu.to(dev))
+            res = E.Act(r_cpu.to(dev)) if use_res else None
+            y = layer(tape, x, act=act, act_alpha=0.2, residual=res)
+            gt, _ = y.grad_target()
+            gt.t.copy_(gy_cpu.to(dev))
+            arena.zero_grad()
+            lib = L.load()
+            lib.ss_prof_reset(); lib.ss_prof_enable(1)
+            tape.backward()
+            torch.cuda.synchronize()
+            lib.ss_prof_enable(0)
+            assert ("norm_bwd_resident_kernel" in L.prof_summary()) == bool(mode), sorted(L.prof_summary())
+            out = [x.get_grad().dense().cpu(), arena.grad("n/gamma").cpu().clone(), arena.grad("n/beta").cpu().clone()]
+            if use_res:
+                out.append(res.get_grad().dense().cpu())
+            runs.append(out)
+    assert L.load().ss_norm_resident_timeouts() == 0
+    for a, b in zip(runs[1], runs[2]):
+        assert torch.equal(a, b), "the one-pass backward is not bit-stable"
+    # float64 truth
+    xr = x_cpu.double().requires_grad_(True)
+    gr, br = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    mu = xr.mean(dim=(1, 2), keepdim=True)
+    var = ((xr - mu) ** 2).mean(dim=(1, 2), keepdim=True)
+    z = (xr - mu) / torch.sqrt(var + 1e-5) * gr + br
+    if use_res:
+        rr = r_cpu.double().requires_grad_(True)
+        z = z + rr
+    yr = {"relu": torch.relu, "lrelu": lambda t: torch.where(t > 0, t, 0.2 * t), None: lambda t: t}[act](z)
+    yr.backward(gy_cpu.double())
+    truth = [xr.grad, gr.grad, br.grad] + ([rr.grad] if use_res else [])
+    for i, (a, b, t) in enumerate(zip(runs[0], runs[1], truth)):
+        scale = max(float(t.abs().max()), 1e-30)
+        e2, e1 = float((a.double() - t).abs().max()) / scale, float((b.double() - t).abs().max()) / scale
+        print(f"tensor {i}: two-pass {e2:.2e} one-pass {e1:.2e} of max|truth|")
+        assert e1 <= max(2.0 * e2, 2e-6), (i, e1, e2)
+
+
 def test_maxpool_fwd_bwd():
     E, LY, L = _mods()
     dev = torch.device("cuda:0")

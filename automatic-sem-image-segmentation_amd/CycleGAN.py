@@ -112,7 +112,7 @@ class CycleGanModel:
         self.batch_generator_passes = os.environ.get("SS_BATCH_G_PASSES", "1") != "0"
         # run the two independent chains of each phase on two HIP streams (see _train_step_dual); SS_DUAL_STREAM=0 disables
         self.dual_stream = {"0": False, "force": "force"}.get(os.environ.get("SS_DUAL_STREAM", "1"), True)
-        self.dual_gemm_cus = 224          # CUs the persistent GEMMs of one chain occupy while two chains run (0: all)
+        self.dual_gemm_cus = 192          # CUs the persistent GEMMs of one chain occupy while two chains run (0: all; 224 before round 6: 179.0 -> 178.2 ms per step)
         # weight gradients of the generator chains on two further streams: measured SLOWER (164.8 vs 157.2 ms for the CycleGAN step -- four
         # chains already share the chip and the weight-gradient GEMMs take whole CUs); the MultiResUNet step, one chain, gains 6 % from it
         self.wgrad_side_streams = os.environ.get("SS_WGRAD_STREAMS", "0") == "1"

@@ -13,3 +13,5 @@ python bench.py --global-batch 1 --steps 20 --warmup 5 --no-cpu-baseline --no-ex
 python bench.py --config 2 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/${tag}_bench_cfg2.json 2>> gpurun_out/${tag}_bench.err
 python bench.py --config 3 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/${tag}_bench_cfg3.json 2>> gpurun_out/${tag}_bench.err
 python bench.py --config 5 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/${tag}_bench_cfg5.json 2>> gpurun_out/${tag}_bench.err
+bash tools/profile_run.sh ${tag}_cfg5 --config 5 --global-batch 2
+bash tools/profile_run.sh ${tag}_cfg2 --config 2

@@ -1233,7 +1233,7 @@ size_t ss_wino_wgrad_ws(const WinoProb& q) {
     const long tiles = n_tiles(q, R);
     int pps;
     int splits = ss_wgrad_mfma_splits(tiles, q.cin, q.cout, &pps, XI);
-    if (ss_wino_wgrad_tn(q)) { int kps; const int s2 = ss_gemm_tn_splits(q.cin, q.cout, tiles, XI, &kps); if (s2 > splits) splits = s2; }
+    if (ss_wino_wgrad_tn(q)) { const int s2 = ss_gemm_tn_splits_max(q.cin, q.cout, tiles, XI); if (s2 > splits) splits = s2; }      // (the count itself follows the CU count of the launch: sized for its largest value)
     return ss_align_up((size_t)XI * tiles * q.cin * 4, 256) + ss_align_up((size_t)XI * tiles * q.cout * 4, 256) +
            ss_align_up((size_t)XI * (splits + 1) * q.cin * q.cout * 4, 256) + 256;      // + the x3h amax slot (last 256 bytes)
 }

@@ -300,17 +300,52 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3h_kernel(TNParams p) {
 
 bool ss_gemm_tn_x3h_ok(int M, int N, long K) { return M % TBM == 0 && N % TBN == 0 && K % TBK == 0 && K >= TBK; }
 
-// splits of the K range: enough workgroups for ~4 rounds over the 256 CUs, at least 8 K steps per split
+// CUs the persistent workgroups of this launch will occupy (the launcher's rule)
+static int tn_cus() {
+    static const int n_cu = [] { int v = 0; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0); return v >= 8 ? v / 8 * 8 : 256; }();
+    return (ss_tuning().gemm_cus >= 8 && ss_tuning().gemm_cus < n_cu) ? ss_tuning().gemm_cus / 8 * 8 : n_cu;
+}
+
+// the largest split count ss_gemm_tn_splits can return for this problem, whatever the CU count: what a workspace is sized for
+int ss_gemm_tn_splits_max(int M, int N, long K, int nbatch) {
+    (void)M; (void)N; (void)nbatch;
+    long m = K / TBK / 8;          // at least 8 K steps per split
+    return (int)(m < 1 ? 1 : (m > 32 ? 32 : m));
+}
+
+// Splits of the K range.  The (tile, split) units are dealt to `cus` persistent workgroups: the launch takes
+//     ceil(units / cus) x (K steps per unit + ~5 steps of pipeline fill and epilogue)   + ~1 step per split for the partials' reduction,
+// so the count is chosen to make the units a whole number of rounds (round 6; before: "enough units for ~4 rounds", e.g. 72 tiles x 15
+// splits = 1080 units on 256 workgroups -- five rounds of 18 steps where two rounds of 37 do: gemm_tn_x3h 244 -> 206 us per launch at
+// batch 8, and 288 units of 8 steps on 256 workgroups at per-GPU batch 1 where 216 of 11 do)
 int ss_gemm_tn_splits(int M, int N, long K, int nbatch, int* k_per_split) {
     const long tiles = (long)(M / TBM) * (N / TBN) * nbatch;
     const long steps = K / TBK;
-    long sp = (1024 + tiles - 1) / tiles;
-    if (sp > steps / 8) sp = steps / 8;
-    if (sp < 1) sp = 1;
-    long per = (steps + sp - 1) / sp;
-    sp = (steps + per - 1) / per;
-    *k_per_split = (int)(per * TBK);
-    return (int)sp;
+    const int smax = ss_gemm_tn_splits_max(M, N, K, nbatch);
+    const long cus = tn_cus();
+    if (!ss_tuning().gemm_tn_rounds) {          // (measurement: the rule of rounds 2 - 5 -- units for ~4 rounds, >= 8 steps each)
+        long sp = (1024 + tiles - 1) / tiles;
+        if (sp > steps / 8) sp = steps / 8;
+        if (sp < 1) sp = 1;
+        if (sp > smax) sp = smax;
+        long per = (steps + sp - 1) / sp;
+        sp = (steps + per - 1) / per;
+        *k_per_split = (int)(per * TBK);
+        return (int)sp;
+    }
+    long best = 1, best_per = steps;
+    double best_cost = 1e30;
+    for (long sp = 1; sp <= smax; ++sp) {
+        const long per = (steps + sp - 1) / sp;
+        const long spe = (steps + per - 1) / per;          // the splits that are not empty
+        if (spe != sp) continue;
+        const long rounds = (tiles * spe + cus - 1) / cus;
+        // (an uneven split -- the last one shorter -- gives up the persistent walk, whose operand stream runs on across tile boundaries)
+        const double cost = ((double)rounds * (double)(per + 5) + (double)spe) * (steps % spe == 0 ? 1.0 : 1.06);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = spe; best_per = per; }
+    }
+    *k_per_split = (int)(best_per * TBK);
+    return (int)best;
 }
 
 int ss_launch_gemm_tn_x3h(const TNParams& p, hipStream_t s) {

@@ -55,7 +55,7 @@ const Key KEYS[] = {
     {"wgrad_mfma_x6", &SsTuning::wgrad_mfma_x6, "generic weight-gradient kernel (channel counts that are not multiples of 32, unaligned views: the MultiResUNet's odd widths) on the bf16 matrix cores with the exact three-piece split formed in registers (six products); 0: v_mfma_f32_32x32x2_f32"},
     {"wgrad_stage", &SsTuning::wgrad_stage, "weight gradient of the stride-2 3 x 3 / 4 x 4 layers with the operands staged once per spatial tile and every tap served from LDS (conv_wgrad_stage.hip); 0: wgrad_x6_kernel; 2 (measurement): the same kernel with its phases in lockstep"},
     {"norm_bwd_resident", &SsTuning::norm_bwd_resident, "OPT-IN (default 0; built, correct, measured 2.2x SLOWER than the two passes: profiles/r06_experiments.md section 9): InstanceNorm backward of fp32 tensors with <= 16384 pixels per sample and 32-multiple channels in ONE pass -- the workgroups of a (sample, 32-channel block) keep dy and x in registers across a group-local barrier (norm.hip)"},
-    {"gemm_tn_rounds", &SsTuning::gemm_tn_rounds, "Winograd weight-gradient GEMM: the K range is split so that the (tile, split) units fill whole rounds of the CUs the launch occupies; 0 (measurement): the earlier rule (units for ~4 rounds)"},
+    {"gemm_tn_rounds", &SsTuning::gemm_tn_rounds, "Winograd weight-gradient GEMM: the K range is split so that the (tile, split) units fill whole rounds of the CUs the launch occupies; 0 (measurement): the earlier rule (units for ~4 rounds); n > 1 (measurement): n splits"},
     {"x6p_wide1", &SsTuning::x6p_wide1, "16-bit activation storage: the one-plane Winograd GEMMs with 256-multiple output channels on 256 x 256 tiles (same bits as the 256 x 128 kernel); 0: off"},
     {"wino16_m16", &SsTuning::wino16_m16, "16-bit activation storage, one-plane Winograd layers: the GEMM writes its Winograd-domain product as fp16 (under a fixed power-of-two scale) and the output transform reads that -- half the bytes of the product's round trip; 0: fp32 product"},
     {"wgrad_tn", &SsTuning::wgrad_tn, "Winograd weight gradient on pre-split K-major fp16 planes with transposing LDS reads (gemm_tn_x3h.hip); 0: in-kernel split"},

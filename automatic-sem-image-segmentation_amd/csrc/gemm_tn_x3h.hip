@@ -16,6 +16,8 @@
 // transposing read touch 4 consecutive k rows x 64 B: the rows would fall on the same banks, so the 64-byte segments of a row are
 // XOR-swizzled with (k & 3), on the DMA source address and on the read address alike.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -315,9 +317,11 @@ int ss_gemm_tn_splits_max(int M, int N, long K, int nbatch) {
 
 // Splits of the K range.  The (tile, split) units are dealt to `cus` persistent workgroups: the launch takes
 //     ceil(units / cus) x (K steps per unit + ~5 steps of pipeline fill and epilogue)   + ~1 step per split for the partials' reduction,
-// so the count is chosen to make the units a whole number of rounds (round 6; before: "enough units for ~4 rounds", e.g. 72 tiles x 15
-// splits = 1080 units on 256 workgroups -- five rounds of 18 steps where two rounds of 37 do: gemm_tn_x3h 244 -> 206 us per launch at
-// batch 8, and 288 units of 8 steps on 256 workgroups at per-GPU batch 1 where 216 of 11 do)
+// so the count is chosen to make the units few, whole rounds (round 6; before: "enough units for ~4 rounds").  The trunk's weight
+// gradients of the dual-chain step are 512 x 512 x (2048 | 4096) x 36 problems on 192 CUs: 288 tiles x 4 splits = six rounds of 32 steps
+// became 288 x 2 = three rounds of 64 (-1.2 ... -1.6 ms per step in-process; forced counts 2 / 4 / 7 / 15: 144.6 / 146.5 / 154.1 / 159.1 ms
+// for the CycleGAN step -- the model's ~5 steps of fill per unit is what that scan shows).  ss_config gemm_tn_rounds: 0 = the earlier
+// rule, n > 1 = n splits (measurement)
 int ss_gemm_tn_splits(int M, int N, long K, int nbatch, int* k_per_split) {
     const long tiles = (long)(M / TBM) * (N / TBN) * nbatch;
     const long steps = K / TBK;
@@ -335,6 +339,12 @@ int ss_gemm_tn_splits(int M, int N, long K, int nbatch, int* k_per_split) {
     }
     long best = 1, best_per = steps;
     double best_cost = 1e30;
+    if (ss_tuning().gemm_tn_rounds > 1) {          // (measurement: a forced split count)
+        long sp = ss_tuning().gemm_tn_rounds > smax ? smax : ss_tuning().gemm_tn_rounds;
+        const long per = (steps + sp - 1) / sp;
+        *k_per_split = (int)(per * TBK);
+        return (int)((steps + per - 1) / per);
+    }
     for (long sp = 1; sp <= smax; ++sp) {
         const long per = (steps + sp - 1) / sp;
         const long spe = (steps + per - 1) / per;          // the splits that are not empty

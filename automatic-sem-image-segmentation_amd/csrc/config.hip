@@ -101,7 +101,7 @@ SsTuning from_env() {
     v.x6p_wide1 = env_is("SS_X6P_WIDE1", '0') ? 0 : 1;
     v.gemm_tn_rounds = env_is("SS_GEMM_TN_ROUNDS", '0') ? 0 : 1;
     v.norm_bwd_resident = env_is("SS_NORM_BWD_RESIDENT", '1') ? 1 : 0;
-    v.wino16_m16 = env_is("SS_WINO16_M16", '0') ? 0 : 1;
+    v.wino16_m16 = env_is("SS_WINO16_M16", '0') ? 0 : (env_is("SS_WINO16_M16", '2') ? 2 : 1);
     v.weight_cache = 1;
     return v;
 }

@@ -847,7 +847,7 @@ int fwd16_impl(const WinoProb& q, const TS* x, const float* w, int w_cin, int w_
     const bool m16 = one && ss_tuning().wino16_m16;
     int kexp = 0;
     while ((1 << kexp) < q.cin) ++kexp;
-    if (m16) { g.c16 = 1; g.c_scale = ldexpf(1.f, -(28 + kexp - 15)); }
+    if (m16) { g.c16 = ss_tuning().wino16_m16 == 2 ? 2 : 1; g.c_scale = ldexpf(1.f, -(28 + kexp - 15)); }          // (2, measurement: 8-byte product stores)
     const int rcx = ss_launch_gemm_x6p(g, s);
     if (rcx != SS_OK) return rcx;
     SsProfScope prof("wino_output_kernel", 0.0, (double)XI * tiles * q.cout * (m16 ? 2 : 4) + (double)q.n * q.oh * q.ow * q.cout * sizeof(TS) * (accumulate ? 2 : 1), s);

@@ -323,10 +323,42 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 1) void gemm_x6p_kernel(X6PParam
         const bool vec_ok = (!WIDE || !(p.dbg & 8)) && (p.N - (cur.n0 + wn * 64) >= 64) && (p.ldc % 4 == 0) && !(p.dbg & 16);
         // exactly NST store instructions leave this wave only when all its 64 rows exist (a masked-off store is branched over)
         const bool full_rows = cur.m0 + wm * 64 + 64 <= p.M;
-        relaxed = !WIDE && vec_ok && full_rows && !(p.dbg & 32);          // (the wide K loop keeps the strict count)
         const bool c16 = NPL == 1 && p.c16;          // (one-plane kernels: the product as fp16 under p.c_scale)
+        relaxed = !WIDE && !c16 && vec_ok && full_rows && !(p.dbg & 32);          // (the wide K loop keeps the strict count; fp16 products: 8 stores, not NST)
         typedef _Float16 c16x4 __attribute__((ext_vector_type(4)));
-        if (vec_ok && (!(p.dbg & 8) || c16)) {
+        if (c16 && p.c16 == 1 && vec_ok && p.ldc % 8 == 0) {          // (c16 == 2, measurement: the 8-byte stores below)
+            // fp16 product: EIGHT consecutive columns per lane = one 16-byte store.  After the quad transpose a lane holds four columns of
+            // one row; the lanes of two adjacent quads (i, i + 4: the same rows, columns c .. c + 3 and c + 4 .. c + 7) swap one row quad
+            // each (a lane ^ 4 exchange), so that the even quad stores the pair's first row quad and the odd one the second: 8 store
+            // instructions per wave of 16 B per lane instead of 16 of 8 B (whose 64-byte row segments cost the same memory transactions)
+            typedef _Float16 c16x8 __attribute__((ext_vector_type(8)));
+            const bool odd = lane & 1, hi = lane & 2, oddq = (lane >> 2) & 1;
+            const int m = cur.m0 + wm * 64 + 4 * lh + (lane & 3);          // + 32 mi + 8 rq
+            _Float16* const g16 = (_Float16*)p.c + cur.cbase + (cur.n0 + wn * 64 + (l31 & ~7)) + (long)m * p.ldc;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp) {
+                    const int rq = 2 * rp + (oddq ? 1 : 0);
+                    const bool row_ok = m + mi * 32 + 8 * rq < p.M && !(p.dbg & 32);
+                    _Float16* grow = g16 + (long)(mi * 32 + 8 * rq) * p.ldc;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const f32x4 oa = ss_quad_transpose(acc[0][mi][ni][8 * rp + 0], acc[0][mi][ni][8 * rp + 1], acc[0][mi][ni][8 * rp + 2], acc[0][mi][ni][8 * rp + 3], odd, hi) * p.c_scale;
+                        const f32x4 ob = ss_quad_transpose(acc[0][mi][ni][8 * rp + 4], acc[0][mi][ni][8 * rp + 5], acc[0][mi][ni][8 * rp + 6], acc[0][mi][ni][8 * rp + 7], odd, hi) * p.c_scale;
+                        // every lane hands its partner (lane ^ 4) the row quad the partner stores and receives the one it stores itself
+                        f32x4 recv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) recv[e] = __shfl_xor(oddq ? oa[e] : ob[e], 4, 64);
+                        const f32x4 lo = oddq ? recv : oa, hi4 = oddq ? ob : recv;
+                        c16x8 o8;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o8[e] = (_Float16)lo[e]; o8[4 + e] = (_Float16)hi4[e]; }
+                        if (row_ok) *(c16x8*)(grow + 32 * ni) = o8;
+                    }
+                }
+            }
+        } else if (vec_ok && (!(p.dbg & 8) || c16)) {
             // Register-transposed epilogue: per (mi, ni, row quad) the four registers of a lane are four consecutive rows of its
             // column; a 4 x 4 transpose inside every group of four adjacent lanes (ss_quad_transpose, DPP) turns them into four
             // consecutive columns of ONE row = one 16-byte store: 16 store instructions per wave (8 rows x 128 B each), no LDS trip.

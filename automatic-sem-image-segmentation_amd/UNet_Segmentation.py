@@ -157,6 +157,10 @@ class DataSet(_Feeder):
         self.y = np.asarray(self.y, dtype='float32')[order]
 
 
+_NAN_TRAP = [os.environ.get("SS_NAN_TRAP", "0") == "1", 0]
+_SYNC_ONLY = os.environ.get("SS_NAN_TRAP", "0") == "2"
+
+
 class UNetModel:
     """What ``keras.models.Model(input, multi_res_unet).compile(loss=weighted_bce, optimizer=Adam, metrics=['mae','acc'])``
     provides to the workflow: ``train_step`` / ``test_step`` / ``predict`` (UNet_Segmentation.py:386-396)."""
@@ -166,7 +170,7 @@ class UNetModel:
         self.device = net.device
         self._out3 = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.act_dtype = net.act_dtype           # float32, or bfloat16 / float16 mixed-precision activation storage
-        self.loss_scale = 1024.0 if self.act_dtype == torch.float16 else 1.0
+        self.loss_scale = (float(os.environ.get("SS_F16_LOSS_SCALE", "1024")) if self.act_dtype == torch.float16 else 1.0)
         # SS_UNET_WGRAD_STREAM=0: weight gradients on the chain's stream; "force": on the side stream even when several ranks share a GPU
         # (tests/test_dp_gpu.py: the bucket hooks must order themselves behind BOTH streams)
         self.wgrad_side_stream = {"0": False, "force": "force"}.get(os.environ.get("SS_UNET_WGRAD_STREAM", "1"), True)
@@ -238,6 +242,18 @@ class UNetModel:
         D.begin_backward([self.net])
         tape.backward()
         D.all_reduce_grads([self.net])
+        if _SYNC_ONLY:            # diagnostics (SS_NAN_TRAP=2): a device-wide synchronisation between backward and the optimizer step, nothing else
+            torch.cuda.synchronize()
+        if _NAN_TRAP[0]:          # diagnostics (SS_NAN_TRAP=1): the first step whose output or gradients are not finite, and where
+            torch.cuda.synchronize()
+            a = self.net.arena
+            bad = [(n, int((~torch.isfinite(a.gviews[n])).sum())) for n in a.gviews if not bool(torch.isfinite(a.gviews[n]).all())]
+            pf = bool(torch.isfinite(p.dense().float()).all())
+            _NAN_TRAP[1] += 1
+            if bad or not pf:
+                print(f"SS_NAN_TRAP: step {_NAN_TRAP[1]}: output finite: {pf}; {len(bad)} of {len(a.gviews)} gradients not finite; first: {bad[:10]}; last: {bad[-4:]}",
+                      flush=True)
+                _NAN_TRAP[0] = False
         self.optimizer.apply(self.net, 1.0 / (world * self.loss_scale), alpha_dev=alpha_dev)
 
     def _read_metrics(self):

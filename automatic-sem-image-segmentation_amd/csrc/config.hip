@@ -56,6 +56,7 @@ const Key KEYS[] = {
     {"wgrad_stage", &SsTuning::wgrad_stage, "weight gradient of the stride-2 3 x 3 / 4 x 4 layers with the operands staged once per spatial tile and every tap served from LDS (conv_wgrad_stage.hip); 0: wgrad_x6_kernel; 2 (measurement): the same kernel with its phases in lockstep"},
     {"norm_bwd_resident", &SsTuning::norm_bwd_resident, "OPT-IN (default 0; built, correct, measured 2.2x SLOWER than the two passes: profiles/r06_experiments.md section 9): InstanceNorm backward of fp32 tensors with <= 16384 pixels per sample and 32-multiple channels in ONE pass -- the workgroups of a (sample, 32-channel block) keep dy and x in registers across a group-local barrier (norm.hip)"},
     {"gemm_tn_rounds", &SsTuning::gemm_tn_rounds, "Winograd weight-gradient GEMM: the K range is split so that the (tile, split) units fill whole rounds of the CUs the launch occupies; 0 (measurement): the earlier rule (units for ~4 rounds); n > 1 (measurement): n splits"},
+    {"gconv16_ragged", &SsTuning::gconv16_ragged, "OPT-IN (default 0): 16-bit activation storage, gconv_x6_kernel takes odd channel counts / strides in the stored type (ragged loader: config 2 889 -> 911 tiles/s); bits: 1 stride-1 problems, 2 strided-output problems, 4 one-tap problems (7 = all).  Off by default: with it on, the MultiResUNet's fp16 training on the publication's data ended in NaN on 2 of 8 generated data sets (never with bf16, never with it off; not reproduced on synthetic data) -- profiles/r06_experiments.md section 11"},
     {"x6p_wide1", &SsTuning::x6p_wide1, "16-bit activation storage: the one-plane Winograd GEMMs with 256-multiple output channels on 256 x 256 tiles (same bits as the 256 x 128 kernel); 0: off"},
     {"wino16_m16", &SsTuning::wino16_m16, "16-bit activation storage, one-plane Winograd layers: the GEMM writes its Winograd-domain product as fp16 (under a fixed power-of-two scale) and the output transform reads that -- half the bytes of the product's round trip; 0: fp32 product"},
     {"wgrad_tn", &SsTuning::wgrad_tn, "Winograd weight gradient on pre-split K-major fp16 planes with transposing LDS reads (gemm_tn_x3h.hip); 0: in-kernel split"},
@@ -99,6 +100,7 @@ SsTuning from_env() {
     v.wgrad_mfma_x6 = env_is("SS_WGRAD_MFMA_X6", '0') ? 0 : 1;
     v.wgrad_stage = env_is("SS_WGRAD_STAGE", '0') ? 0 : 1;
     v.x6p_wide1 = env_is("SS_X6P_WIDE1", '0') ? 0 : 1;
+    v.gconv16_ragged = getenv("SS_GCONV16_RAGGED") ? atoi(getenv("SS_GCONV16_RAGGED")) : 0;
     v.gemm_tn_rounds = env_is("SS_GEMM_TN_ROUNDS", '0') ? 0 : 1;
     v.norm_bwd_resident = env_is("SS_NORM_BWD_RESIDENT", '1') ? 1 : 0;
     v.wino16_m16 = env_is("SS_WINO16_M16", '0') ? 0 : (env_is("SS_WINO16_M16", '2') ? 2 : 1);

@@ -781,7 +781,15 @@ size_t ss_gconv_x6_planes_bytes(const GConvParams& p) {
 // weights of `p` (fp32, addressed through p.w / taps / ldb / w_bs) -> the three K-contiguous bf16 planes
 // 16-bit storage through gconv_x6_kernel: the x3h maxima present (any channel count, stride and alignment: the kernel's ragged loader and
 // its element-wise epilogue take the MultiResUNet's odd widths in the stored type as they do in fp32)
-bool ss_gconv_x6_typed_ok(const GConvParams& p) { return p.h_amax && p.h_amax2; }
+bool ss_gconv_x6_typed_ok(const GConvParams& p) {
+    // gconv16_ragged bits (measurement): 1 = stride-1 problems, 2 = strided-output problems (sub-pixel phases of a data gradient /
+    // transposed forward), 4 = 1 x 1 kernels; a ragged problem takes the typed path only if all its classes are switched on
+    const int need = (p.out_s > 1 ? 2 : 1) | (p.ntaps == 1 ? 4 : 0);
+    if ((ss_tuning().gconv16_ragged & need) != need)          // (measurement: the round-5 rule -- whole 32-channel chunks at 8-byte aligned pixels, 4-aligned outputs)
+        return p.h_amax && p.h_amax2 && p.Cin % 32 == 0 && (p.in_cs & 3) == 0 && (((uintptr_t)p.in) & 7) == 0 && p.Cout % 4 == 0 && (p.out_cs & 3) == 0 &&
+               (((uintptr_t)p.out) & 7) == 0;
+    return p.h_amax && p.h_amax2;
+}
 
 int ss_launch_wprep_x6(const GConvParams& p, unsigned short* planes, hipStream_t s) {
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
